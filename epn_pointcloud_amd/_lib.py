@@ -1,0 +1,92 @@
+"""ctypes binding of libepn_so3conv.so (include/epn_so3conv.h) on torch device tensors.
+
+PyTorch is plumbing here: it owns device memory and the current HIP stream; every compute call goes
+through the C ABI.  There is NO CPU or eager fallback: a missing library or a non-device tensor
+raises (the reference's extensions do the same through CHECK_CUDA, grouping_cuda.cpp:66-68).
+"""
+import ctypes
+import os
+
+import torch
+
+_PKG = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_PKG, "libepn_so3conv.so")
+
+EXPORTS = [
+    "epn_version", "epn_strerror",
+    "epn_ball_query_f32", "epn_fps_f32", "epn_gather_fwd_f32", "epn_gather_bwd_f32",
+    "epn_inter_workspace_bytes", "epn_inter_so3conv_fwd_f32", "epn_inter_so3conv_bwd_data_f32",
+    "epn_inter_so3conv_bwd_weight_f32", "epn_inter_weights_f32",
+    "epn_intra_so3conv_fwd_f32", "epn_intra_so3conv_bwd_data_f32", "epn_intra_so3conv_bwd_weight_f32",
+]
+
+_vp, _ci, _cf, _sz = ctypes.c_void_p, ctypes.c_int, ctypes.c_float, ctypes.c_size_t
+
+
+class InterDesc(ctypes.Structure):
+    """struct epn_inter_desc (include/epn_so3conv.h)."""
+    _fields_ = [("xyz", _vp), ("new_xyz", _vp), ("ball_idx", _vp), ("anchors", _vp), ("kernels", _vp),
+                ("dense_w", _vp), ("sigma", _cf), ("b", _ci), ("p1", _ci), ("p2", _ci), ("nn", _ci),
+                ("na", _ci), ("ks", _ci), ("cin", _ci), ("cout", _ci)]
+
+
+_lib = None
+
+
+def get_lib():
+    """Load the HIP library or fail loudly (no fallback path exists)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise RuntimeError(
+            f"{LIB_PATH} is missing: the HIP extension was not built. Run "
+            "`python -c 'import __graft_entry__ as g; g.build()'` (hipcc --offload-arch=gfx950). "
+            "epn_pointcloud_amd has no CPU/eager fallback.")
+    lib = ctypes.CDLL(LIB_PATH)
+    lib.epn_version.restype = ctypes.c_char_p
+    lib.epn_strerror.restype = ctypes.c_char_p
+    lib.epn_strerror.argtypes = [_ci]
+    lib.epn_ball_query_f32.argtypes = [_vp, _vp, _ci, _ci, _ci, _cf, _ci, _vp, _vp]
+    lib.epn_fps_f32.argtypes = [_vp, _ci, _ci, _ci, _vp, _vp]
+    lib.epn_gather_fwd_f32.argtypes = [_vp, _vp, _ci, _ci, _ci, _ci, _vp, _vp]
+    lib.epn_gather_bwd_f32.argtypes = [_vp, _vp, _ci, _ci, _ci, _ci, _vp, _vp]
+    dp = ctypes.POINTER(InterDesc)
+    lib.epn_inter_workspace_bytes.argtypes = [dp]
+    lib.epn_inter_workspace_bytes.restype = _sz
+    lib.epn_inter_so3conv_fwd_f32.argtypes = [dp, _vp, _vp, _vp, _vp, _sz, _vp]
+    lib.epn_inter_so3conv_bwd_data_f32.argtypes = [dp, _vp, _vp, _vp, _vp, _sz, _vp]
+    lib.epn_inter_so3conv_bwd_weight_f32.argtypes = [dp, _vp, _vp, _vp, _vp, _sz, _vp]
+    lib.epn_inter_weights_f32.argtypes = [dp, _vp, _vp]
+    lib.epn_intra_so3conv_fwd_f32.argtypes = [_vp, _vp, _vp, _ci, _ci, _ci, _ci, _ci, _ci, _vp, _vp]
+    lib.epn_intra_so3conv_bwd_data_f32.argtypes = [_vp, _vp, _vp, _ci, _ci, _ci, _ci, _ci, _ci, _vp, _vp]
+    lib.epn_intra_so3conv_bwd_weight_f32.argtypes = [_vp, _vp, _vp, _ci, _ci, _ci, _ci, _ci, _ci, _vp, _vp]
+    for name in EXPORTS:
+        getattr(lib, name)  # AttributeError here = header/library mismatch
+        if name.endswith("_f32"):
+            getattr(lib, name).restype = _ci
+    _lib = lib
+    return lib
+
+
+def check(rc, what):
+    if rc != 0:
+        msg = get_lib().epn_strerror(int(rc)).decode()
+        raise RuntimeError(f"{what} failed: {msg} (code {rc})")
+
+
+def stream_of(t):
+    return ctypes.c_void_p(torch.cuda.current_stream(t.device).cuda_stream)
+
+
+def dev_ptr(t, name, dtype=torch.float32):
+    """Pointer of a device tensor; mirrors the reference's CHECK_INPUT (grouping_cuda.cpp:66-68)."""
+    if t is None:
+        return ctypes.c_void_p(0)
+    if not t.is_cuda:
+        raise RuntimeError(f"{name} must be a CUDA tensor")  # ROCm devices are 'cuda' in torch
+    if not t.is_contiguous():
+        raise RuntimeError(f"{name} must be contiguous")
+    if t.dtype != dtype:
+        raise TypeError(f"{name} must be {dtype}, got {t.dtype}")
+    return ctypes.c_void_p(t.data_ptr())

@@ -1,0 +1,195 @@
+// extern "C" entry points of libepn_so3conv.so for the convolution path (see include/epn_so3conv.h).
+// Dispatch: fused MFMA kernels when cin and cout are multiples of 16, generic kernels otherwise
+// (EPN_FORCE_GENERIC=1 in the environment forces the generic path; used by the cross-check tests).
+#include <cstdlib>
+#include <cstring>
+
+#include "conv_internal.h"
+
+using namespace epn;
+
+static bool force_generic() {
+    const char *e = std::getenv("EPN_FORCE_GENERIC");
+    return e && e[0] == '1';
+}
+
+static int check_desc(const epn_inter_desc *d) {
+    if (!d) return EPN_ENULL;
+    if (d->b < 0 || d->p1 < 1 || d->p2 < 0 || d->nn < 1 || d->na < 1 || d->ks < 1 || d->cin < 1 || d->cout < 1)
+        return EPN_EINVAL;
+    if (d->ks > EPN_KS_MAX) return EPN_EINVAL;
+    if (!(d->sigma > 0.f) && !d->dense_w) return EPN_EINVAL;
+    if (!d->ball_idx) return EPN_ENULL;
+    if (!d->dense_w && (!d->xyz || !d->new_xyz || !d->anchors || !d->kernels)) return EPN_ENULL;
+    return 0;
+}
+
+static bool use_mfma(const epn_inter_desc *d) { return inter_uses_mfma(d) && !force_generic() && !d->dense_w; }
+
+extern "C" const char *epn_version(void) { return "epn_so3conv 0.1 (gfx950)"; }
+
+extern "C" const char *epn_strerror(int code) {
+    switch (code) {
+        case 0: return "success";
+        case EPN_EINVAL: return "epn: invalid size or unsupported shape";
+        case EPN_EWORKSPACE: return "epn: workspace missing or too small";
+        case EPN_ENULL: return "epn: required pointer is NULL";
+        default: return code > 0 ? hipGetErrorString((hipError_t)code) : "epn: unknown error";
+    }
+}
+
+extern "C" size_t epn_inter_workspace_bytes(const epn_inter_desc *d) {
+    if (!d) return 0;
+    InterWs w = inter_ws(d);
+    // the generic path may be forced at run time, so always report the larger requirement when asked to
+    if (force_generic() || d->dense_w) {
+        epn_inter_desc g = *d;
+        g.cin = d->cin; g.cout = d->cout;
+        const size_t big = (size_t)d->b * d->p2 * d->na * d->cin * d->ks;
+        return (w.big_off + rnd64(big)) * sizeof(float);
+    }
+    return w.total_floats * sizeof(float);
+}
+
+static int prep(const epn_inter_desc *d, void *workspace, size_t bytes, bool need_big, InterWs &ws, float *&base,
+                hipStream_t st) {
+    int rc = check_desc(d);
+    if (rc) return rc;
+    ws = inter_ws(d);
+    const size_t big = need_big ? rnd64((size_t)d->b * d->p2 * d->na * d->cin * d->ks) : 0;
+    if (!workspace || bytes < (ws.big_off + big) * sizeof(float)) return EPN_EWORKSPACE;
+    base = static_cast<float *>(workspace);
+    if (!d->dense_w) {
+        rc = launch_rk_table(d, base + ws.rk_off, st);
+        if (rc) return rc;
+    }
+    return 0;
+}
+
+extern "C" int epn_inter_weights_f32(const epn_inter_desc *d, float *w, epn_stream_t stream) {
+    int rc = check_desc(d);
+    if (rc) return rc;
+    if (!w || !d->xyz || !d->new_xyz || !d->anchors || !d->kernels) return EPN_ENULL;
+    if (d->b == 0 || d->p2 == 0) return 0;
+    return launch_inter_weights(d, w, epn_stream(stream));
+}
+
+extern "C" int epn_inter_so3conv_fwd_f32(const epn_inter_desc *d, const float *feats_cl, const float *W,
+                                         float *out_cl, void *workspace, size_t workspace_bytes,
+                                         epn_stream_t stream) {
+    hipStream_t st = epn_stream(stream);
+    InterWs ws;
+    float *base = nullptr;
+    const bool mf = d && use_mfma(d);
+    int rc = prep(d, workspace, workspace_bytes, !mf, ws, base, st);
+    if (rc) return rc;
+    if (!feats_cl || !W || !out_cl) return EPN_ENULL;
+    if (d->b == 0 || d->p2 == 0) return 0;
+    if (mf) {
+        rc = launch_inter_tables_mfma(d, base + ws.rk_off, base + ws.rk4_off, base + ws.beta_off, st);
+        if (rc) return rc;
+        return launch_inter_fwd_mfma(d, base + ws.rk4_off, base + ws.beta_off, feats_cl, W, out_cl, st);
+    }
+    float *G = base + ws.big_off;
+    rc = launch_inter_group(d, base + ws.rk_off, feats_cl, G, st);
+    if (rc) return rc;
+    return launch_rowgemm_nt(G, W, (size_t)d->b * d->p2 * d->na, d->cin * d->ks, d->cout, out_cl, st);
+}
+
+extern "C" int epn_inter_so3conv_bwd_data_f32(const epn_inter_desc *d, const float *grad_out_cl, const float *W,
+                                              float *grad_feats_cl, void *workspace, size_t workspace_bytes,
+                                              epn_stream_t stream) {
+    hipStream_t st = epn_stream(stream);
+    InterWs ws;
+    float *base = nullptr;
+    const bool mf = d && use_mfma(d);
+    int rc = prep(d, workspace, workspace_bytes, !mf, ws, base, st);
+    if (rc) return rc;
+    if (!grad_feats_cl) return EPN_ENULL;
+    EPN_HIP(hipMemsetAsync(grad_feats_cl, 0, sizeof(float) * (size_t)d->b * d->p1 * d->na * d->cin, st));
+    if (d->b == 0 || d->p2 == 0) return 0;
+    if (!grad_out_cl || !W) return EPN_ENULL;
+    if (mf) {
+        rc = launch_inter_tables_mfma(d, base + ws.rk_off, base + ws.rk4_off, base + ws.beta_off, st);
+        if (rc) return rc;
+        return launch_inter_bwd_data_mfma(d, base + ws.rk4_off, base + ws.beta_off, grad_out_cl, W, grad_feats_cl, st);
+    }
+    float *dG = base + ws.big_off;
+    rc = launch_rowgemm_nn(grad_out_cl, W, (size_t)d->b * d->p2 * d->na, d->cin * d->ks, d->cout, dG, st);
+    if (rc) return rc;
+    return launch_inter_scatter(d, base + ws.rk_off, dG, grad_feats_cl, st);
+}
+
+extern "C" int epn_inter_so3conv_bwd_weight_f32(const epn_inter_desc *d, const float *feats_cl,
+                                                const float *grad_out_cl, float *grad_W, void *workspace,
+                                                size_t workspace_bytes, epn_stream_t stream) {
+    hipStream_t st = epn_stream(stream);
+    InterWs ws;
+    float *base = nullptr;
+    const bool mf = d && use_mfma(d);
+    int rc = prep(d, workspace, workspace_bytes, !mf, ws, base, st);
+    if (rc) return rc;
+    if (!grad_W) return EPN_ENULL;
+    EPN_HIP(hipMemsetAsync(grad_W, 0, sizeof(float) * (size_t)d->cout * d->cin * d->ks, st));
+    if (d->b == 0 || d->p2 == 0) return 0;
+    if (!feats_cl || !grad_out_cl) return EPN_ENULL;
+    if (mf) {
+        rc = launch_inter_tables_mfma(d, base + ws.rk_off, base + ws.rk4_off, base + ws.beta_off, st);
+        if (rc) return rc;
+        return launch_inter_bwd_weight_mfma(d, base + ws.rk4_off, base + ws.beta_off, feats_cl, grad_out_cl, grad_W,
+                                            st);
+    }
+    float *G = base + ws.big_off;
+    rc = launch_inter_group(d, base + ws.rk_off, feats_cl, G, st);
+    if (rc) return rc;
+    return launch_colreduce_dw(grad_out_cl, G, (size_t)d->b * d->p2 * d->na, d->cin * d->ks, d->cout, grad_W, st);
+}
+
+static int check_intra(int b, int p, int na, int kn, int cin, int cout) {
+    if (b < 0 || p < 0 || na < 1 || kn < 1 || cin < 1 || cout < 1) return EPN_EINVAL;
+    return 0;
+}
+
+extern "C" int epn_intra_so3conv_fwd_f32(const float *feats_cl, const int32_t *intra_idx, const float *W, int b,
+                                         int p, int na, int kn, int cin, int cout, float *out_cl,
+                                         epn_stream_t stream) {
+    int rc = check_intra(b, p, na, kn, cin, cout);
+    if (rc) return rc;
+    if (b == 0 || p == 0) return 0;
+    if (!feats_cl || !intra_idx || !W || !out_cl) return EPN_ENULL;
+    hipStream_t st = epn_stream(stream);
+    if (intra_uses_mfma(na, kn, cin, cout) && !force_generic())
+        return launch_intra_fwd_mfma(feats_cl, intra_idx, W, b, p, na, kn, cin, cout, out_cl, st);
+    return launch_intra_fwd_generic(feats_cl, intra_idx, W, (size_t)b * p, na, kn, cin, cout, out_cl, st);
+}
+
+extern "C" int epn_intra_so3conv_bwd_data_f32(const float *grad_out_cl, const int32_t *intra_idx, const float *W,
+                                              int b, int p, int na, int kn, int cin, int cout,
+                                              float *grad_feats_cl, epn_stream_t stream) {
+    int rc = check_intra(b, p, na, kn, cin, cout);
+    if (rc) return rc;
+    if (b == 0 || p == 0) return 0;
+    if (!grad_out_cl || !intra_idx || !W || !grad_feats_cl) return EPN_ENULL;
+    hipStream_t st = epn_stream(stream);
+    if (intra_uses_mfma(na, kn, cin, cout) && !force_generic())
+        return launch_intra_bwd_data_mfma(grad_out_cl, intra_idx, W, b, p, na, kn, cin, cout, grad_feats_cl, st);
+    EPN_HIP(hipMemsetAsync(grad_feats_cl, 0, sizeof(float) * (size_t)b * p * na * cin, st));
+    return launch_intra_bwd_data_generic(grad_out_cl, intra_idx, W, (size_t)b * p, na, kn, cin, cout, grad_feats_cl,
+                                         st);
+}
+
+extern "C" int epn_intra_so3conv_bwd_weight_f32(const float *feats_cl, const float *grad_out_cl,
+                                                const int32_t *intra_idx, int b, int p, int na, int kn, int cin,
+                                                int cout, float *grad_W, epn_stream_t stream) {
+    int rc = check_intra(b, p, na, kn, cin, cout);
+    if (rc) return rc;
+    if (!grad_W) return EPN_ENULL;
+    hipStream_t st = epn_stream(stream);
+    EPN_HIP(hipMemsetAsync(grad_W, 0, sizeof(float) * (size_t)cout * cin * kn, st));
+    if (b == 0 || p == 0) return 0;
+    if (!feats_cl || !grad_out_cl || !intra_idx) return EPN_ENULL;
+    if (intra_uses_mfma(na, kn, cin, cout) && !force_generic())
+        return launch_intra_bwd_weight_mfma(feats_cl, grad_out_cl, intra_idx, b, p, na, kn, cin, cout, grad_W, st);
+    return launch_intra_bwd_weight_generic(feats_cl, grad_out_cl, intra_idx, (size_t)b * p, na, kn, cin, cout, grad_W,
+                                           st);
+}

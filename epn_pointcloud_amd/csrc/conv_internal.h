@@ -1,0 +1,63 @@
+// Internal declarations shared by the convolution translation units of libepn_so3conv.so.
+#pragma once
+#include "epn_common.h"
+
+#define EPN_KS_MAX 32   // kernel points per anchor are padded to 32 slots (reference uses 24)
+#define EPN_NN_MAX 128  // neighbours per output point supported by the fused kernels
+
+namespace epn {
+
+// workspace carve-up (float offsets) for one inter descriptor
+struct InterWs {
+    size_t rk_off, rk4_off, beta_off, big_off, total_floats;
+};
+static inline size_t rnd64(size_t x) { return (x + 63) & ~(size_t)63; }
+static inline bool inter_mfma_shape_ok(const epn_inter_desc *d) {
+    return d->cin % 16 == 0 && d->cout % 16 == 0 && d->ks <= EPN_KS_MAX && d->nn <= EPN_NN_MAX && d->cin >= 16 &&
+           d->cout >= 16;
+}
+bool inter_mfma_available();  // false while only the stand-in TU is linked
+static inline bool inter_uses_mfma(const epn_inter_desc *d) { return inter_mfma_available() && inter_mfma_shape_ok(d); }
+static inline InterWs inter_ws(const epn_inter_desc *d) {
+    InterWs w;
+    w.rk_off = 0;
+    w.rk4_off = rnd64((size_t)d->na * d->ks * 3);
+    w.beta_off = w.rk4_off + rnd64((size_t)d->na * EPN_KS_MAX * 4);
+    w.big_off = w.beta_off + rnd64((size_t)d->na * EPN_KS_MAX);
+    const size_t big = inter_uses_mfma(d) ? 0 : (size_t)d->b * d->p2 * d->na * d->cin * d->ks;
+    w.total_floats = w.big_off + rnd64(big);
+    return w;
+}
+
+// conv_generic.hip
+int launch_rk_table(const epn_inter_desc *d, float *rk, hipStream_t st);
+int launch_inter_weights(const epn_inter_desc *d, float *w, hipStream_t st);
+int launch_inter_group(const epn_inter_desc *d, const float *rk, const float *feats, float *G, hipStream_t st);
+int launch_inter_scatter(const epn_inter_desc *d, const float *rk, const float *dG, float *dF, hipStream_t st);
+int launch_rowgemm_nt(const float *X, const float *W, size_t ncol, int ck, int cout, float *out, hipStream_t st);
+int launch_rowgemm_nn(const float *dOut, const float *W, size_t ncol, int ck, int cout, float *dX, hipStream_t st);
+int launch_colreduce_dw(const float *dOut, const float *X, size_t ncol, int ck, int cout, float *dW, hipStream_t st);
+int launch_intra_fwd_generic(const float *feats, const int32_t *iidx, const float *W, size_t npts, int na, int kn,
+                             int cin, int cout, float *out, hipStream_t st);
+int launch_intra_bwd_data_generic(const float *dOut, const int32_t *iidx, const float *W, size_t npts, int na, int kn,
+                                  int cin, int cout, float *dF, hipStream_t st);
+int launch_intra_bwd_weight_generic(const float *feats, const float *dOut, const int32_t *iidx, size_t npts, int na,
+                                    int kn, int cin, int cout, float *dW, hipStream_t st);
+
+// inter_mfma.hip / intra_mfma.hip (fused MFMA kernels; cin, cout multiples of 16)
+int launch_inter_tables_mfma(const epn_inter_desc *d, const float *rk, float *rk4, float *beta, hipStream_t st);
+int launch_inter_fwd_mfma(const epn_inter_desc *d, const float *rk4, const float *beta, const float *feats,
+                          const float *W, float *out, hipStream_t st);
+int launch_inter_bwd_data_mfma(const epn_inter_desc *d, const float *rk4, const float *beta, const float *dOut,
+                               const float *W, float *dF, hipStream_t st);
+int launch_inter_bwd_weight_mfma(const epn_inter_desc *d, const float *rk4, const float *beta, const float *feats,
+                                 const float *dOut, float *dW, hipStream_t st);
+bool intra_uses_mfma(int na, int kn, int cin, int cout);
+int launch_intra_fwd_mfma(const float *feats, const int32_t *iidx, const float *W, int b, int p, int na, int kn,
+                          int cin, int cout, float *out, hipStream_t st);
+int launch_intra_bwd_data_mfma(const float *dOut, const int32_t *iidx, const float *W, int b, int p, int na, int kn,
+                               int cin, int cout, float *dF, hipStream_t st);
+int launch_intra_bwd_weight_mfma(const float *feats, const float *dOut, const int32_t *iidx, int b, int p, int na,
+                                 int kn, int cin, int cout, float *dW, hipStream_t st);
+
+}  // namespace epn

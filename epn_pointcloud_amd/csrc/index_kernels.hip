@@ -1,0 +1,256 @@
+// Index kernels for gfx950: furthest point sampling, ball query, point gather fwd/bwd.
+//
+// Semantics follow the reference's CUDA-only kernels (restated on CPU in oracle/epn_oracle.c):
+//   vgtk/vgtk/cuda/grouping_cuda_kernel.cu:67-113   ball query
+//   vgtk/vgtk/cuda/grouping_cuda_kernel.cu:339-466  FPS (+ __update tie-breaking)
+//   vgtk/vgtk/cuda/gathering_cuda_kernel.cu:43-98   gather fwd / bwd
+// The launch geometry is NOT the reference's (one block per cloud, one thread per query):
+//   * FPS keeps every point and its running min-distance in REGISTERS, reduces (value, tie-key,
+//     index) as one 64-bit key with wave shuffles + one LDS hop and ONE barrier per round;
+//   * ball query gives each query a 64-lane wavefront that tests 64 support points per step and
+//     compacts hits in index order with ballot + prefix popcount (early exit once full);
+//   * gather maps the fastest thread index to the output index (coalesced writes).
+#include <cmath>
+
+#include "epn_common.h"
+
+namespace {
+
+// ------------------------------------------------------------------------------------ FPS
+// Reference tie-breaking, stated as a total order so any reduction tree reproduces it:
+// virtual thread t (0 <= t < block, block = min(1024, 2^floor(log2 n))) keeps the FIRST maximum
+// among k = t, t+block, ... (strict '>', starting from best=-1, besti=0).  The shared-memory tree
+// (offsets block/2 .. 1, "keep idx1 on ties") then prefers, among equal values, the thread whose
+// index has a 0 at the lowest differing bit, i.e. the smallest bit-reversed index.
+// key = [fkey(value):32][1023 - bitrev10(t):10][besti:22], reduced with max().
+__device__ __forceinline__ unsigned long long fps_key(float best, int besti, unsigned t) {
+    const unsigned fk = best < 0.0f ? 0u : (__float_as_uint(best) + 1u);
+    const unsigned pri = 1023u - (__brev(t) >> 22);
+    return ((unsigned long long)fk << 32) | ((unsigned long long)pri << 22) | (unsigned)besti;
+}
+
+__device__ __forceinline__ unsigned long long shfl_xor_u64(unsigned long long v, int mask) {
+    unsigned lo = (unsigned)v, hi = (unsigned)(v >> 32);
+    lo = __shfl_xor(lo, mask, 64);
+    hi = __shfl_xor(hi, mask, 64);
+    return ((unsigned long long)hi << 32) | lo;
+}
+
+template <int PPT>
+__global__ __launch_bounds__(1024) void fps_kernel(const float *__restrict__ xyz, int n, int m,
+                                                   int block, int cloud_in_lds,
+                                                   int32_t *__restrict__ idxs) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    unsigned long long *slots = reinterpret_cast<unsigned long long *>(smem);  // [2][16]
+    float *cloud_lds = reinterpret_cast<float *>(smem + 2 * 16 * sizeof(unsigned long long));  // [3][n]
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, wave = tid >> 6;
+    const int nwave = (blockDim.x + 63) >> 6;
+    const float *d = xyz + (size_t)blockIdx.x * 3 * n;
+    int32_t *out = idxs + (size_t)blockIdx.x * m;
+
+    // the cloud is re-read once per round (the last winner's coordinates): from LDS when it fits
+    const float *cloud = d;
+    if (cloud_in_lds) {
+        for (int i = tid; i < 3 * n; i += blockDim.x) cloud_lds[i] = d[i];
+        cloud = cloud_lds;
+    }
+
+    float px[PPT], py[PPT], pz[PPT], tmp[PPT];
+    bool live[PPT];
+#pragma unroll
+    for (int i = 0; i < PPT; ++i) {
+        const int k = tid + i * block;
+        const bool in = tid < block && k < n;
+        px[i] = in ? d[k] : 0.f;
+        py[i] = in ? d[n + k] : 0.f;
+        pz[i] = in ? d[2 * n + k] : 0.f;
+        tmp[i] = 1e10f;
+        // reference: `if (mag <= 1e-3) continue;` -- float mag promoted against a double literal
+        live[i] = in && !((double)epn_sq3(px[i], py[i], pz[i]) <= 1e-3);
+    }
+    if (tid == 0) out[0] = 0;
+    __syncthreads();
+
+    int old = 0;
+    for (int j = 1; j < m; ++j) {
+        const float x1 = cloud[old], y1 = cloud[n + old], z1 = cloud[2 * n + old];
+        float best = -1.0f;
+        int besti = 0;
+#pragma unroll
+        for (int i = 0; i < PPT; ++i) {
+            if (live[i]) {
+                const float dd = epn_sq3(px[i] - x1, py[i] - y1, pz[i] - z1);
+                const float d2 = dd < tmp[i] ? dd : tmp[i];
+                tmp[i] = d2;
+                if (d2 > best) {
+                    best = d2;
+                    besti = tid + i * block;
+                }
+            }
+        }
+        unsigned long long key = tid < block ? fps_key(best, besti, (unsigned)tid) : 0ull;
+#pragma unroll
+        for (int s = 32; s >= 1; s >>= 1) {
+            const unsigned long long o = shfl_xor_u64(key, s);
+            key = o > key ? o : key;
+        }
+        if (nwave > 1) {
+            unsigned long long *slot = slots + (j & 1) * 16;
+            if (lane == 0) slot[wave] = key;
+            __syncthreads();
+            key = (lane & 15) < nwave ? slot[lane & 15] : 0ull;
+#pragma unroll
+            for (int s = 8; s >= 1; s >>= 1) {
+                const unsigned long long o = shfl_xor_u64(key, s);
+                key = o > key ? o : key;
+            }
+        }
+        old = (int)(key & 0x3FFFFFu);
+        if (tid == 0) out[j] = old;
+    }
+}
+
+// ------------------------------------------------------------------------------------ ball query
+__global__ __launch_bounds__(256) void ball_query_kernel(const float *__restrict__ new_xyz,
+                                                         const float *__restrict__ xyz, int n, int m,
+                                                         float radius, int nsample,
+                                                         int32_t *__restrict__ idx) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    int32_t *row = reinterpret_cast<int32_t *>(smem) + wave * nsample;
+    const int bi = blockIdx.y;
+    const int j = blockIdx.x * (blockDim.x >> 6) + wave;
+    if (j >= m) return;  // whole wave exits together; no block-level barrier below
+
+    const float *q = new_xyz + (size_t)bi * 3 * m;
+    const float *s = xyz + (size_t)bi * 3 * n;
+    const float qx = q[j], qy = q[m + j], qz = q[2 * m + j];
+    const float radius2 = __fmul_rn(radius, radius);
+
+    for (int t = lane; t < nsample; t += 64) row[t] = 0;  // reference zero-initialises idx
+
+    int cnt = 0;
+    for (int base = 0; base < n && cnt < nsample; base += 64) {
+        const int k = base + lane;
+        bool hit = false;
+        if (k < n) {
+            const float d2 = epn_sq3(qx - s[k], qy - s[n + k], qz - s[2 * n + k]);
+            hit = d2 < radius2;
+        }
+        const unsigned long long mask = __ballot(hit);
+        const int pos = cnt + __popcll(mask & ((1ull << lane) - 1ull));
+        if (hit && pos < nsample) row[pos] = k;
+        cnt += __popcll(mask);
+    }
+    if (cnt > nsample) cnt = nsample;
+    __builtin_amdgcn_wave_barrier();
+    // reference :100-104 -- cyclic repeat of the first cnt hits, only when cnt < nsample-1
+    // (cnt == nsample-1 leaves the last slot 0, cnt == 0 leaves the row 0).
+    int32_t *o = idx + ((size_t)bi * m + j) * nsample;
+    for (int t = lane; t < nsample; t += 64) {
+        int v = row[t];
+        if (cnt > 0 && cnt < nsample - 1 && t >= cnt) v = row[t % cnt];
+        o[t] = v;
+    }
+}
+
+// ------------------------------------------------------------------------------------ gather
+__global__ __launch_bounds__(256) void gather_fwd_kernel(const float *__restrict__ points,
+                                                         const int32_t *__restrict__ idx, int c, int n,
+                                                         int m, float *__restrict__ out) {
+    const int bi = blockIdx.z, ci = blockIdx.y;
+    const int j = blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= m) return;
+    const int a = idx[(size_t)bi * m + j];
+    out[((size_t)bi * c + ci) * m + j] = points[((size_t)bi * c + ci) * n + a];
+}
+
+__global__ __launch_bounds__(256) void gather_bwd_kernel(const float *__restrict__ grad_out,
+                                                         const int32_t *__restrict__ idx, int c, int n,
+                                                         int m, float *__restrict__ grad_points) {
+    const int bi = blockIdx.z, ci = blockIdx.y;
+    const int j = blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= m) return;
+    const int a = idx[(size_t)bi * m + j];
+    atomicAdd(grad_points + ((size_t)bi * c + ci) * n + a, grad_out[((size_t)bi * c + ci) * m + j]);
+}
+
+int opt_n_threads(int work_size) {  // grouping_cuda_kernel.cu:29-33, same double-precision formula
+    const int pow_2 = (int)(std::log((double)work_size) / std::log(2.0));
+    int t = 1 << pow_2;
+    if (t > 1024) t = 1024;
+    return t < 1 ? 1 : t;
+}
+
+}  // namespace
+
+extern "C" int epn_ball_query_f32(const float *new_xyz, const float *xyz, int b, int n, int m,
+                                  float radius, int nsample, int32_t *idx, epn_stream_t stream) {
+    if (b < 0 || n < 1 || m < 0 || nsample < 1 || nsample > 4096) return EPN_EINVAL;
+    if (b == 0 || m == 0) return 0;
+    if (!new_xyz || !xyz || !idx) return EPN_ENULL;
+    if (b > 65535) return EPN_EINVAL;
+    const int waves = 4;
+    dim3 grid(epn_cdiv(m, waves), b);
+    hipLaunchKernelGGL(ball_query_kernel, grid, dim3(64 * waves), waves * nsample * sizeof(int32_t),
+                       epn_stream(stream), new_xyz, xyz, n, m, radius, nsample, idx);
+    EPN_CHECK_LAUNCH();
+    return 0;
+}
+
+extern "C" int epn_fps_f32(const float *xyz, int b, int n, int m, int32_t *idx, epn_stream_t stream) {
+    if (b < 0 || n < 1 || n > 32768 || m < 0) return EPN_EINVAL;
+    if (b == 0 || m == 0) return 0;
+    if (!xyz || !idx) return EPN_ENULL;
+    const int block = opt_n_threads(n);
+    const int threads = block < 64 ? 64 : block;
+    const int ppt = epn_cdiv(n, block);
+    const int in_lds = (size_t)3 * n * sizeof(float) <= 96 * 1024;
+    const size_t shmem = 2 * 16 * sizeof(unsigned long long) + (in_lds ? (size_t)3 * n * sizeof(float) : 0);
+    hipStream_t st = epn_stream(stream);
+#define EPN_FPS(P)                                                                                  \
+    do {                                                                                            \
+        EPN_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&fps_kernel<P>),                 \
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem));      \
+        hipLaunchKernelGGL(fps_kernel<P>, dim3(b), dim3(threads), shmem, st, xyz, n, m, block, in_lds, idx); \
+    } while (0)
+    if (ppt <= 1) EPN_FPS(1);
+    else if (ppt <= 2) EPN_FPS(2);
+    else if (ppt <= 4) EPN_FPS(4);
+    else if (ppt <= 8) EPN_FPS(8);
+    else if (ppt <= 16) EPN_FPS(16);
+    else EPN_FPS(32);
+#undef EPN_FPS
+    EPN_CHECK_LAUNCH();
+    return 0;
+}
+
+extern "C" int epn_gather_fwd_f32(const float *points, const int32_t *idx, int b, int c, int n, int m,
+                                  float *out, epn_stream_t stream) {
+    if (b < 0 || c < 0 || n < 1 || m < 0) return EPN_EINVAL;
+    if (b == 0 || c == 0 || m == 0) return 0;
+    if (!points || !idx || !out) return EPN_ENULL;
+    if (c > 65535 || b > 65535) return EPN_EINVAL;
+    dim3 grid(epn_cdiv(m, 256), c, b);
+    hipLaunchKernelGGL(gather_fwd_kernel, grid, dim3(256), 0, epn_stream(stream), points, idx, c, n, m, out);
+    EPN_CHECK_LAUNCH();
+    return 0;
+}
+
+extern "C" int epn_gather_bwd_f32(const float *grad_out, const int32_t *idx, int b, int c, int n, int m,
+                                  float *grad_points, epn_stream_t stream) {
+    if (b < 0 || c < 0 || n < 1 || m < 0) return EPN_EINVAL;
+    if (b == 0 || c == 0) return 0;
+    if (!grad_points) return EPN_ENULL;
+    EPN_HIP(hipMemsetAsync(grad_points, 0, sizeof(float) * (size_t)b * c * n, epn_stream(stream)));
+    if (m == 0) return 0;
+    if (!grad_out || !idx) return EPN_ENULL;
+    if (c > 65535 || b > 65535) return EPN_EINVAL;
+    dim3 grid(epn_cdiv(m, 256), c, b);
+    hipLaunchKernelGGL(gather_bwd_kernel, grid, dim3(256), 0, epn_stream(stream), grad_out, idx, c, n, m,
+                       grad_points);
+    EPN_CHECK_LAUNCH();
+    return 0;
+}

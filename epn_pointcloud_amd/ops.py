@@ -1,0 +1,199 @@
+"""Autograd Functions over the C ABI (include/epn_so3conv.h) for the fused SO(3) convolutions.
+
+Public feature tensors keep the reference's logical shape [b, c, p, a]; physically they are kept
+channels-last ([b][p][a][c], torch.channels_last), which is what the HIP kernels consume.  A tensor in
+any other layout is converted once on entry.
+"""
+import ctypes
+
+import torch
+
+from . import _lib
+
+
+def to_cl(t, name="feats"):
+    """Logical [b,c,p,a] float32 device tensor -> channels-last contiguous (no copy if already so)."""
+    if not t.is_cuda:
+        raise RuntimeError(f"{name} must be a CUDA tensor")
+    if t.dtype != torch.float32:
+        raise TypeError(f"{name} must be float32, got {t.dtype} (bf16 variants: later round)")
+    if t.dim() != 4:
+        raise ValueError(f"{name} must be [b,c,p,a]")
+    return t.contiguous(memory_format=torch.channels_last)
+
+
+def _cl_ptr(t):
+    assert t.is_contiguous(memory_format=torch.channels_last) or t.is_contiguous()
+    return ctypes.c_void_p(t.data_ptr())
+
+
+def empty_cl(b, c, p, a, device):
+    return torch.empty((b, c, p, a), dtype=torch.float32, device=device, memory_format=torch.channels_last)
+
+
+class InterGeometry:
+    """Lazy stand-in for the reference's materialised `inter_w` [b,p2,na,ks,nn] (3 GB at B=32 for the
+    first ModelNet layer).  It carries what the fused kernels need to regenerate the weights on the fly
+    (vgtk/vgtk/so3conv/functional.py:180-218); `dense()` materialises the reference tensor on demand so
+    `conv(x, inter_idx, inter_w)` round-trips."""
+
+    def __init__(self, xyz, new_xyz, ball_idx, anchors, kernels, sigma):
+        self.xyz, self.new_xyz, self.ball_idx = xyz, new_xyz, ball_idx
+        self.anchors, self.kernels, self.sigma = anchors, kernels, float(sigma)
+        self._dense = None
+
+    @property
+    def shape(self):
+        b, p2, nn = self.ball_idx.shape
+        return torch.Size((b, p2, self.anchors.shape[0], self.kernels.shape[0], nn))
+
+    @property
+    def device(self):
+        return self.ball_idx.device
+
+    def desc(self, cin, cout, dense_w=None):
+        b, p2, nn = self.ball_idx.shape
+        d = _lib.InterDesc()
+        d.xyz = _lib.dev_ptr(self.xyz, "xyz")
+        d.new_xyz = _lib.dev_ptr(self.new_xyz, "new_xyz")
+        d.ball_idx = _lib.dev_ptr(self.ball_idx, "inter_idx", torch.int32)
+        d.anchors = _lib.dev_ptr(self.anchors, "anchors")
+        d.kernels = _lib.dev_ptr(self.kernels, "kernels")
+        d.dense_w = _lib.dev_ptr(dense_w, "inter_w") if dense_w is not None else None
+        d.sigma = self.sigma
+        d.b, d.p1, d.p2, d.nn = b, self.xyz.shape[2], p2, nn
+        d.na, d.ks, d.cin, d.cout = self.anchors.shape[0], self.kernels.shape[0], int(cin), int(cout)
+        return d
+
+    def dense(self):
+        """Materialise w[b,p2,na,ks,nn] with the HIP kernel (API compatibility only)."""
+        if self._dense is None:
+            lib = _lib.get_lib()
+            w = torch.empty(tuple(self.shape), dtype=torch.float32, device=self.device)
+            d = self.desc(1, 1)
+            _lib.check(lib.epn_inter_weights_f32(ctypes.byref(d), _lib.dev_ptr(w, "w"), _lib.stream_of(w)),
+                       "inter_weights")
+            self._dense = w
+        return self._dense
+
+
+class DenseInterWeights:
+    """User-supplied dense inter_w + inter_idx (the reference's reuse path, functional.py:170-172)."""
+
+    def __init__(self, ball_idx, inter_w, p1):
+        self.ball_idx, self.w, self.p1 = ball_idx, inter_w.contiguous(), int(p1)
+
+    def desc(self, cin, cout, dense_w=None):
+        b, p2, na, ks, nn = self.w.shape
+        d = _lib.InterDesc()
+        d.ball_idx = _lib.dev_ptr(self.ball_idx, "inter_idx", torch.int32)
+        d.dense_w = _lib.dev_ptr(self.w, "inter_w")
+        d.sigma = 1.0
+        d.b, d.p1, d.p2, d.nn, d.na, d.ks, d.cin, d.cout = b, self.p1, p2, nn, na, ks, int(cin), int(cout)
+        return d
+
+
+def _workspace(lib, d, device):
+    nbytes = lib.epn_inter_workspace_bytes(ctypes.byref(d))
+    ws = torch.empty(max(int(nbytes), 16), dtype=torch.uint8, device=device)
+    return ws, ctypes.c_void_p(ws.data_ptr()), ctypes.c_size_t(ws.numel())
+
+
+class InterSO3ConvFn(torch.autograd.Function):
+    """out[b,o,p,a] = sum_{c,k} W[o,c*ks+k] sum_n feats[b,c,idx[b,p,n],a] w[b,p,a,k,n]
+    (InterSO3Conv.forward, vgtk/vgtk/so3conv/modules.py:157-174), fused; backward = SURVEY a17."""
+
+    @staticmethod
+    def forward(ctx, feats, W, geo):
+        lib = _lib.get_lib()
+        f = to_cl(feats)
+        Wc = W.contiguous()
+        cout, ck = Wc.shape
+        cin = f.shape[1]
+        d = geo.desc(cin, cout)
+        if ck != cin * d.ks or f.shape[2] != d.p1 or f.shape[3] != d.na or f.shape[0] != d.b:
+            raise ValueError(f"shape mismatch: feats {tuple(f.shape)}, W {tuple(Wc.shape)}, geometry "
+                             f"b={d.b} p1={d.p1} na={d.na} ks={d.ks}")
+        out = empty_cl(d.b, cout, d.p2, d.na, f.device)
+        ws, wsp, wsn = _workspace(lib, d, f.device)
+        _lib.check(lib.epn_inter_so3conv_fwd_f32(ctypes.byref(d), _cl_ptr(f), _lib.dev_ptr(Wc, "W"), _cl_ptr(out),
+                                                 wsp, wsn, _lib.stream_of(f)), "inter_so3conv_fwd")
+        ctx.save_for_backward(f, Wc)
+        ctx.geo = geo
+        return out
+
+    @staticmethod
+    def backward(ctx, grad_out):
+        lib = _lib.get_lib()
+        f, Wc = ctx.saved_tensors
+        geo = ctx.geo
+        g = to_cl(grad_out, "grad_out")
+        cout = Wc.shape[0]
+        cin = f.shape[1]
+        d = geo.desc(cin, cout)
+        ws, wsp, wsn = _workspace(lib, d, f.device)
+        gf = gW = None
+        if ctx.needs_input_grad[0]:
+            gf = empty_cl(d.b, cin, d.p1, d.na, f.device)
+            _lib.check(lib.epn_inter_so3conv_bwd_data_f32(ctypes.byref(d), _cl_ptr(g), _lib.dev_ptr(Wc, "W"),
+                                                          _cl_ptr(gf), wsp, wsn, _lib.stream_of(f)),
+                       "inter_so3conv_bwd_data")
+        if ctx.needs_input_grad[1]:
+            gW = torch.empty_like(Wc)
+            _lib.check(lib.epn_inter_so3conv_bwd_weight_f32(ctypes.byref(d), _cl_ptr(f), _cl_ptr(g),
+                                                            _lib.dev_ptr(gW, "grad_W"), wsp, wsn,
+                                                            _lib.stream_of(f)), "inter_so3conv_bwd_weight")
+        return gf, gW, None
+
+
+class IntraSO3ConvFn(torch.autograd.Function):
+    """out[b,o,p,a] = sum_{c,k} W[o,c*kn+k] feats[b,c,p,intra_idx[a,k]]
+    (IntraSO3Conv.forward, vgtk/vgtk/so3conv/modules.py:197-200), fused."""
+
+    @staticmethod
+    def forward(ctx, feats, W, intra_idx32):
+        lib = _lib.get_lib()
+        f = to_cl(feats)
+        Wc = W.contiguous()
+        b, cin, p, na = f.shape
+        cout = Wc.shape[0]
+        kn = intra_idx32.shape[1]
+        if Wc.shape[1] != cin * kn or intra_idx32.shape[0] != na:
+            raise ValueError(f"shape mismatch: feats {tuple(f.shape)}, W {tuple(Wc.shape)}, "
+                             f"intra_idx {tuple(intra_idx32.shape)}")
+        out = empty_cl(b, cout, p, na, f.device)
+        _lib.check(lib.epn_intra_so3conv_fwd_f32(_cl_ptr(f), _lib.dev_ptr(intra_idx32, "intra_idx", torch.int32),
+                                                 _lib.dev_ptr(Wc, "W"), b, p, na, kn, cin, cout, _cl_ptr(out),
+                                                 _lib.stream_of(f)), "intra_so3conv_fwd")
+        ctx.save_for_backward(f, Wc, intra_idx32)
+        return out
+
+    @staticmethod
+    def backward(ctx, grad_out):
+        lib = _lib.get_lib()
+        f, Wc, iidx = ctx.saved_tensors
+        g = to_cl(grad_out, "grad_out")
+        b, cin, p, na = f.shape
+        cout = Wc.shape[0]
+        kn = iidx.shape[1]
+        ip = _lib.dev_ptr(iidx, "intra_idx", torch.int32)
+        gf = gW = None
+        if ctx.needs_input_grad[0]:
+            gf = empty_cl(b, cin, p, na, f.device)
+            _lib.check(lib.epn_intra_so3conv_bwd_data_f32(_cl_ptr(g), ip, _lib.dev_ptr(Wc, "W"), b, p, na, kn, cin,
+                                                          cout, _cl_ptr(gf), _lib.stream_of(f)),
+                       "intra_so3conv_bwd_data")
+        if ctx.needs_input_grad[1]:
+            gW = torch.empty_like(Wc)
+            _lib.check(lib.epn_intra_so3conv_bwd_weight_f32(_cl_ptr(f), _cl_ptr(g), ip, b, p, na, kn, cin, cout,
+                                                            _lib.dev_ptr(gW, "grad_W"), _lib.stream_of(f)),
+                       "intra_so3conv_bwd_weight")
+        return gf, gW, None
+
+
+def inter_so3conv(feats, W, geo):
+    return InterSO3ConvFn.apply(feats, W, geo)
+
+
+def intra_so3conv(feats, W, intra_idx32):
+    return IntraSO3ConvFn.apply(feats, W, intra_idx32)

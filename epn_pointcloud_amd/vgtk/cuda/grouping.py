@@ -1,0 +1,38 @@
+"""`vgtk.cuda.grouping` -- same function names/signatures as vgtk/vgtk/cuda/grouping_cuda.cpp:176-181."""
+import torch
+
+from ... import _lib
+
+
+def ball_query(new_xyz, xyz, radius, nsample):
+    """(new_xyz f[b,3,m], xyz f[b,3,n], float radius, int nsample) -> int32 [b,m,nsample]
+    (grouping_cuda.cpp:71-86)."""
+    lib = _lib.get_lib()
+    q, s = _lib.dev_ptr(new_xyz, "new_xyz"), _lib.dev_ptr(xyz, "xyz")
+    b, _, m = new_xyz.shape
+    n = xyz.shape[2]
+    idx = torch.empty((b, m, int(nsample)), dtype=torch.int32, device=xyz.device)
+    _lib.check(lib.epn_ball_query_f32(q, s, b, n, m, float(radius), int(nsample),
+                                      _lib.dev_ptr(idx, "idx", torch.int32), _lib.stream_of(xyz)), "ball_query")
+    return idx
+
+
+def furthest_point_sampling(source_xyz, m):
+    """(xyz f[b,3,n], int m) -> int32 [b,m]  (grouping_cuda.cpp:160-174)."""
+    lib = _lib.get_lib()
+    p = _lib.dev_ptr(source_xyz, "source_xyz")
+    b, _, n = source_xyz.shape
+    idx = torch.empty((b, int(m)), dtype=torch.int32, device=source_xyz.device)
+    _lib.check(lib.epn_fps_f32(p, b, n, int(m), _lib.dev_ptr(idx, "sampled_idx", torch.int32),
+                               _lib.stream_of(source_xyz)), "furthest_point_sampling")
+    return idx
+
+
+def initial_anchor_query(centers, xyz, kernel_points, radius, sigma):
+    """grouping_cuda.cpp:140-158; only KernelPropagation uses it, no shipped model does -- SURVEY 8(f) "next"."""
+    raise NotImplementedError("initial_anchor_query: not on the hot path of any shipped model (SURVEY.md 8f.3)")
+
+
+def anchor_query(sample_idx, grouped_indices, grouped_xyz, anchors, kernel_points, nq):
+    """grouping_cuda.cpp:88-106; legacy ZPConv, every call site in the reference is commented out."""
+    raise NotImplementedError("anchor_query: legacy ZPConv kernel, out of scope (SURVEY.md section 2 row 1)")

@@ -1,0 +1,170 @@
+"""nn.Modules of the SO(3) separable convolution (vgtk/vgtk/so3conv/modules.py) -- same constructor
+signatures, return tuples and state_dict keys (anchors, kernels, intra_idx, basic_conv.W); forward
+runs the fused HIP kernels through epn_pointcloud_amd.ops instead of gather -> einsum -> matmul."""
+import math
+
+import numpy as np
+import torch
+import torch.nn as nn
+
+from ..spconv import SphericalPointCloud
+from .. import pc as pctk
+from . import functional as L
+from ... import ops
+
+__all__ = ["BasicSO3Conv", "KernelPropagation", "InterSO3Conv", "IntraSO3Conv", "PointnetSO3Conv",
+           "KERNEL_CONDENSE_RATIO"]
+
+KERNEL_CONDENSE_RATIO = 0.7
+
+
+class BasicSO3Conv(nn.Module):
+    """[b,c1,k,p,a] -> [b,c2,p,a]: W[c2, c1*k] applied at every (p,a); no bias (modules.py:21-55).
+    Inside Inter/IntraSO3Conv only `W` is used (the contraction is fused into the HIP kernel); calling
+    the module on a materialised tensor keeps the reference's semantics."""
+
+    def __init__(self, dim_in, dim_out, kernel_size, debug=False):
+        super(BasicSO3Conv, self).__init__()
+        self.dim_in = dim_in
+        self.dim_out = dim_out
+        self.kernel_size = kernel_size
+        if debug:
+            self.register_buffer('W', torch.ones(self.dim_out, self.dim_in * self.kernel_size))
+        else:
+            W = torch.empty(self.dim_out, self.dim_in, self.kernel_size)
+            nn.init.xavier_normal_(W, gain=nn.init.calculate_gain('relu'))
+            self.register_parameter('W', nn.Parameter(W.view(self.dim_out, self.dim_in * self.kernel_size)))
+
+    def forward(self, x):
+        bs, npt, na = x.shape[0], x.shape[3], x.shape[4]
+        x = x.reshape(bs, self.dim_in * self.kernel_size, npt * na)
+        return torch.matmul(self.W, x).view(bs, self.dim_out, npt, na)
+
+
+class KernelPropagation(nn.Module):
+    """modules.py:57-119.  Buffers/parameters as in the reference; forward needs `initial_anchor_query`,
+    which no shipped model reaches ("next")."""
+
+    def __init__(self, dim_in, dim_out, n_center, kernel_size, radius, sigma, kanchor=60):
+        super(KernelPropagation, self).__init__()
+        kernels = L.get_sphereical_kernel_points_from_ply(KERNEL_CONDENSE_RATIO * radius, kernel_size)
+        anchors = L.get_anchors(kanchor)
+        kernels = np.transpose(anchors @ kernels.T, (2, 0, 1))
+        self.radius = radius
+        self.sigma = sigma
+        self.n_center = n_center
+        self.register_buffer('anchors', torch.from_numpy(anchors))
+        self.register_buffer('kernels', torch.from_numpy(kernels))
+        self.basic_conv = BasicSO3Conv(dim_in, dim_out, kernels.shape[0])
+
+    def forward(self, frag, clouds):
+        if clouds.shape[2] == self.n_center:
+            centers = clouds
+        else:
+            _, centers = pctk.furthest_sample(clouds, self.n_center, False)
+        wts, nnctn = L.initial_anchor_query(frag, centers, self.kernels, self.radius, self.sigma)
+        wts = wts / (nnctn + 1.0)
+        feats = self.basic_conv(wts.unsqueeze(1))
+        return SphericalPointCloud(centers, feats, self.anchors)
+
+
+class InterSO3Conv(nn.Module):
+    """[b,c1,p1,a] -> [b,c2,p2,a]: convolution over the K spatial neighbours under every anchor rotation
+    (modules.py:125-174).  forward(x, inter_idx=None, inter_w=None) ->
+    (inter_idx, inter_w, sample_idx, SphericalPointCloud).  `inter_w` is returned as a lazy
+    ops.InterGeometry (call .dense() for the reference tensor); a dense tensor is accepted on input."""
+
+    def __init__(self, dim_in, dim_out, kernel_size, stride, radius, sigma, n_neighbor,
+                 lazy_sample=True, pooling=None, kanchor=60):
+        super(InterSO3Conv, self).__init__()
+        kernels = L.get_sphereical_kernel_points_from_ply(KERNEL_CONDENSE_RATIO * radius, kernel_size)
+        anchors = L.get_anchors(kanchor)
+        self.dim_in = dim_in
+        self.dim_out = dim_out
+        self.kernel_size = kernels.shape[0]
+        self.stride = stride
+        self.radius = radius
+        self.sigma = sigma
+        self.n_neighbor = n_neighbor
+        self.lazy_sample = lazy_sample
+        self.pooling = pooling
+        self.basic_conv = BasicSO3Conv(dim_in, dim_out, self.kernel_size)
+        self.register_buffer('anchors', torch.from_numpy(np.ascontiguousarray(anchors)))
+        self.register_buffer('kernels', torch.from_numpy(np.ascontiguousarray(kernels)))
+
+    def forward(self, x, inter_idx=None, inter_w=None):
+        xyz, feats = x.xyz, x.feats
+        stride = self.stride
+        if self.pooling is not None and stride > 1 and feats.shape[1] > 1:
+            # low-pass blurring before the strided conv (functional.py:133-148); torch glue, never taken
+            # by the shipped models (xyz_pooling=None)
+            if self.pooling == 'stride':
+                pool_stride, stride_nn, stride = stride, int(self.n_neighbor * stride ** 0.5), 1
+            elif self.pooling == 'no-stride':
+                pool_stride, stride_nn = 1, self.n_neighbor
+            else:
+                raise NotImplementedError(f"Pooling mode {self.pooling} is not implemented!")
+            feats, xyz = L.inter_so3conv_blurring(xyz, feats, stride_nn, self.radius, pool_stride, inter_idx,
+                                                  self.lazy_sample)
+            inter_idx = None
+        if inter_idx is None:
+            n_sample = math.ceil(xyz.shape[2] / stride)
+            sample_idx, new_xyz = pctk.furthest_sample(xyz, n_sample, self.lazy_sample)
+            inter_idx = pctk.ball_query_index(new_xyz, xyz, self.radius, self.n_neighbor)
+            inter_w = ops.InterGeometry(xyz, new_xyz, inter_idx, self.anchors, self.kernels, self.sigma)
+            handle = inter_w
+        else:
+            sample_idx, new_xyz = None, xyz
+            if isinstance(inter_w, ops.InterGeometry):
+                handle = inter_w
+            else:
+                handle = ops.DenseInterWeights(inter_idx.int().contiguous(), inter_w, xyz.shape[2])
+        out = ops.inter_so3conv(feats, self.basic_conv.W, handle)
+        return inter_idx, inter_w, sample_idx, SphericalPointCloud(new_xyz, out, self.anchors)
+
+
+class IntraSO3Conv(nn.Module):
+    """[b,c1,p,a] -> [b,c2,p,a]: convolution over the 12 nearest rotation anchors (modules.py:177-200).
+    Like the reference it always uses the 60-anchor table (get_anchors() without k)."""
+
+    def __init__(self, dim_in, dim_out):
+        super(IntraSO3Conv, self).__init__()
+        anchors = L.get_anchors()
+        intra_idx = L.get_intra_idx()
+        self.dim_in = dim_in
+        self.dim_out = dim_out
+        self.kernel_size = intra_idx.shape[1]
+        self.basic_conv = BasicSO3Conv(dim_in, dim_out, self.kernel_size)
+        self.register_buffer('anchors', torch.from_numpy(anchors))
+        self.register_buffer('intra_idx', torch.from_numpy(intra_idx).long())
+
+    def forward(self, x):
+        idx32 = self.intra_idx.int()
+        feats = ops.intra_so3conv(x.feats, self.basic_conv.W, idx32)
+        return SphericalPointCloud(x.xyz, feats, self.anchors)
+
+
+class PointnetSO3Conv(nn.Module):
+    """Equivariant pointnet aggregation over points (modules.py:203-235); tail of every model, torch ops
+    ("next" for fusion)."""
+
+    def __init__(self, dim_in, dim_out, kanchor=60):
+        super(PointnetSO3Conv, self).__init__()
+        anchors = L.get_anchors(kanchor)
+        self.dim_in = dim_in + 3
+        self.dim_out = dim_out
+        self.embed = nn.Conv2d(self.dim_in, self.dim_out, 1)
+        self.register_buffer('anchors', torch.from_numpy(np.ascontiguousarray(anchors)))
+
+    def forward(self, x):
+        xyz = x.xyz
+        feats = x.feats
+        na = feats.shape[3]
+        xyz = xyz - xyz.mean(2, keepdim=True)
+        if na == 1:
+            feats = torch.cat([x.feats, xyz[..., None]], 1)
+        else:
+            xyzr = torch.einsum('aji,bjn->bina', self.anchors, xyz)
+            feats = torch.cat([x.feats, xyzr], 1)
+        feats = self.embed(feats)
+        return torch.max(feats, 2)[0]

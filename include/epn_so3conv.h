@@ -1,0 +1,124 @@
+/*
+ * include/epn_so3conv.h -- C ABI of libepn_so3conv.so (MI355X / gfx950).
+ *
+ * Drop-in boundary for the EPN SE(3) separable point-convolution hot path.  Every entry point is
+ * `extern "C"`, takes plain DEVICE pointers + sizes + a HIP stream (passed as void*), launches
+ * asynchronously on that stream, owns no memory and keeps no global state (thread-safe).  Return
+ * value: 0 on success, otherwise a hipError_t code (launch errors) or a negative EPN_E* code
+ * (argument errors).  `epn_strerror` turns either into text.
+ *
+ * Each function names the reference interface it replaces (paths relative to the reference repo
+ * nintendops/EPN_PointCloud).  The reference's pybind functions allocate their outputs; here the
+ * CALLER allocates (the Python mirror in epn_pointcloud_amd/vgtk/cuda does it with torch).
+ *
+ * Layout notes
+ *   xyz tensors are channel-major  [b,3,n]  exactly as the reference passes them.
+ *   Feature tensors at THIS boundary are channels-last: feats_cl[b][p][a][c]  (the memory image of a
+ *   torch tensor of logical shape [b,c,p,a] in torch.channels_last format).  The public nn.Module
+ *   API keeps the reference's logical [b,c,p,a] shape.
+ */
+#ifndef EPN_SO3CONV_H
+#define EPN_SO3CONV_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define EPN_EINVAL (-1)      /* bad size / unsupported shape                      */
+#define EPN_EWORKSPACE (-2)  /* workspace pointer NULL or too small               */
+#define EPN_ENULL (-3)       /* required pointer is NULL                          */
+
+typedef void *epn_stream_t; /* hipStream_t; NULL = the null stream */
+
+const char *epn_version(void);
+const char *epn_strerror(int code);
+
+/* ------------------------------------------------------------------ index kernels ---------- */
+
+/* Replaces vgtk.cuda.grouping.ball_query  (vgtk/vgtk/cuda/grouping_cuda.cpp:71-86, kernel
+ * grouping_cuda_kernel.cu:67-113).  new_xyz f32[b,3,m], xyz f32[b,3,n] -> idx i32[b,m,nsample].
+ * The kernel writes every slot (the reference zero-fills first, grouping_cuda.cpp:80-82). */
+int epn_ball_query_f32(const float *new_xyz, const float *xyz, int b, int n, int m, float radius,
+                       int nsample, int32_t *idx, epn_stream_t stream);
+
+/* Replaces vgtk.cuda.grouping.furthest_point_sampling (grouping_cuda.cpp:160-174, kernel
+ * grouping_cuda_kernel.cu:351-466).  xyz f32[b,3,n] -> idx i32[b,m].  The 1e10 `temp` buffer of
+ * the reference lives in registers.  Requires 1 <= m, 1 <= n <= 32768. */
+int epn_fps_f32(const float *xyz, int b, int n, int m, int32_t *idx, epn_stream_t stream);
+
+/* Replace vgtk.cuda.gathering.gather_points_forward / _backward (gathering_cuda.cpp:29-60,
+ * kernels gathering_cuda_kernel.cu:43-98).  points f32[b,c,n], idx i32[b,m] -> out f32[b,c,m];
+ * grad_out f32[b,c,m] -> grad_points f32[b,c,n] (zero-filled here, then scatter-added). */
+int epn_gather_fwd_f32(const float *points, const int32_t *idx, int b, int c, int n, int m,
+                       float *out, epn_stream_t stream);
+int epn_gather_bwd_f32(const float *grad_out, const int32_t *idx, int b, int c, int n, int m,
+                       float *grad_points, epn_stream_t stream);
+
+/* ------------------------------------------------------------------ InterSO3Conv ------------ */
+
+/* Geometry + shapes of one inter convolution (vgtk/vgtk/so3conv/functional.py:118-178).
+ * The fused kernels regenerate the kernel-influence weights
+ *     w[b,p,a,k,n] = relu(1 - |xyz[:,idx[b,p,n]] - new_xyz[:,p] - R_a kappa_k|^2 / sigma)
+ * (functional.py:180-218) on the fly; they are never written to HBM. */
+typedef struct epn_inter_desc {
+    const float *xyz;        /* [b,3,p1] support coordinates                                   */
+    const float *new_xyz;    /* [b,3,p2] query (output) coordinates                            */
+    const int32_t *ball_idx; /* [b,p2,nn] neighbour indices into p1 (from epn_ball_query_f32)  */
+    const float *anchors;    /* [na,3,3] rotation matrices                                     */
+    const float *kernels;    /* [ks,3]   kernel points                                         */
+    const float *dense_w;    /* optional [b,p2,na,ks,nn]: use THESE weights instead of geometry */
+    float sigma;
+    int b, p1, p2, nn, na, ks, cin, cout;
+} epn_inter_desc;
+
+/* Bytes of scratch the inter kernels need for this descriptor (tables; plus the materialised
+ * grouped features on the generic path used when cin or cout is not a multiple of 16). */
+size_t epn_inter_workspace_bytes(const epn_inter_desc *d);
+
+/* Replaces InterSO3Conv.forward's compute (vgtk/vgtk/so3conv/modules.py:157-174 =
+ * inter_so3conv_grouping -> inter_zpconv_grouping_naive (vgtk/vgtk/spconv/functional.py:372-390)
+ * -> BasicSO3Conv (modules.py:48-55)):
+ *   out_cl[b,p,a,o] = sum_{c,k} W[o, c*ks+k] * sum_n feats_cl[b, idx[b,p,n], a, c] * w[b,p,a,k,n]
+ * feats_cl f32[b,p1,na,cin], W f32[cout, cin*ks] -> out_cl f32[b,p2,na,cout]. */
+int epn_inter_so3conv_fwd_f32(const epn_inter_desc *d, const float *feats_cl, const float *W,
+                              float *out_cl, void *workspace, size_t workspace_bytes,
+                              epn_stream_t stream);
+
+/* Autograd transposes (reference: torch autograd through gather/einsum/matmul).
+ * grad_out_cl f32[b,p2,na,cout].
+ *   bwd_data  : grad_feats_cl f32[b,p1,na,cin]  (zero-filled here, then accumulated)
+ *   bwd_weight: grad_W f32[cout, cin*ks]        (zero-filled here, then accumulated) */
+int epn_inter_so3conv_bwd_data_f32(const epn_inter_desc *d, const float *grad_out_cl,
+                                   const float *W, float *grad_feats_cl, void *workspace,
+                                   size_t workspace_bytes, epn_stream_t stream);
+int epn_inter_so3conv_bwd_weight_f32(const epn_inter_desc *d, const float *feats_cl,
+                                     const float *grad_out_cl, float *grad_W, void *workspace,
+                                     size_t workspace_bytes, epn_stream_t stream);
+
+/* Materialise the weights for API compatibility (InterSO3Conv returns inter_w):
+ * w f32[b,p2,na,ks,nn], formula of vgtk/vgtk/so3conv/functional.py:190-200. */
+int epn_inter_weights_f32(const epn_inter_desc *d, float *w, epn_stream_t stream);
+
+/* ------------------------------------------------------------------ IntraSO3Conv ------------ */
+
+/* Replaces IntraSO3Conv.forward's compute (vgtk/vgtk/so3conv/modules.py:197-200 =
+ * intra_so3conv_grouping (functional.py:221-233) -> BasicSO3Conv):
+ *   out_cl[b,p,a,o] = sum_{c,k} W[o, c*kn+k] * feats_cl[b, p, intra_idx[a,k], c]
+ * feats_cl f32[b,p,na,cin], intra_idx i32[na,kn], W f32[cout, cin*kn] -> out_cl f32[b,p,na,cout]. */
+int epn_intra_so3conv_fwd_f32(const float *feats_cl, const int32_t *intra_idx, const float *W,
+                              int b, int p, int na, int kn, int cin, int cout, float *out_cl,
+                              epn_stream_t stream);
+int epn_intra_so3conv_bwd_data_f32(const float *grad_out_cl, const int32_t *intra_idx,
+                                   const float *W, int b, int p, int na, int kn, int cin, int cout,
+                                   float *grad_feats_cl, epn_stream_t stream);
+int epn_intra_so3conv_bwd_weight_f32(const float *feats_cl, const float *grad_out_cl,
+                                     const int32_t *intra_idx, int b, int p, int na, int kn,
+                                     int cin, int cout, float *grad_W, epn_stream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* EPN_SO3CONV_H */

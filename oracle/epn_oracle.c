@@ -1,0 +1,154 @@
+/*
+ * oracle/epn_oracle.c -- TEST INFRASTRUCTURE, NOT PRODUCT CODE.
+ *
+ * Plain-C, single-threaded CPU restatement of the reference's index kernels
+ * (furthest point sampling, ball query, point gather fwd/bwd).  Only tests/,
+ * __graft_entry__.smoke() and bench.py's cpu_baseline leg may load this.
+ *
+ * The reference implements these ONLY as CUDA kernels (there is no CPU path,
+ * CHECK_CUDA rejects host tensors: vgtk/vgtk/cuda/grouping_cuda.cpp:66-68) and
+ * nvcc is not available, so this file restates the algorithm of
+ *   vgtk/vgtk/cuda/grouping_cuda_kernel.cu:67-113   (ball_query_cuda_kernel)
+ *   vgtk/vgtk/cuda/grouping_cuda_kernel.cu:339-466  (__update + furthest_point_sampling_cuda_kernel)
+ *   vgtk/vgtk/cuda/grouping_cuda_kernel.cu:29-33    (opt_n_threads)
+ *   vgtk/vgtk/cuda/gathering_cuda_kernel.cu:43-98   (gather fwd / bwd)
+ * PARITY UNPINNED vs the CUDA binary: the reference ships no golden vectors
+ * for these kernels and the .cu files cannot be built here.  What IS pinned:
+ * one canonical floating-point evaluation order (below), used identically by
+ * this oracle and by the HIP kernels, so "bit-exact" is well defined.
+ *
+ * Canonical squared distance (what nvcc's default -fmad=true most plausibly
+ * emits for  a*a + b*b + c*c):   t = a*a;  t = fma(b,b,t);  t = fma(c,c,t).
+ * Build with -ffp-contract=off so the compiler adds no contraction of its own.
+ */
+#include <math.h>
+#include <stdint.h>
+#include <stdlib.h>
+#include <string.h>
+
+static inline float sq3(float a, float b, float c) {
+    float t = a * a;
+    t = fmaf(b, b, t);
+    t = fmaf(c, c, t);
+    return t;
+}
+
+/* grouping_cuda_kernel.cu:29-33 : block = min(1024, 2^floor(log2(n))), >= 1 */
+int epn_oracle_opt_n_threads(int work_size) {
+    int pow_2 = (int)(log((double)work_size) / log(2.0));
+    int t = 1 << pow_2;
+    if (t > 1024) t = 1024;
+    if (t < 1) t = 1;
+    return t;
+}
+
+/*
+ * Ball query.  new_xyz (b,3,m), xyz (b,3,n) channel-major, idx (b,m,nsample).
+ * grouping_cuda.cpp:80-82 zero-initialises idx; grouping_cuda_kernel.cu:84-104:
+ * scan support points in index order, keep the first nsample with d2 < r^2
+ * (strict), then if cnt < nsample-1 cyclically repeat the first cnt hits.
+ * Quirks kept: cnt == nsample-1 leaves the last slot 0; cnt == 0 leaves all 0.
+ */
+void epn_oracle_ball_query_f32(const float *new_xyz, const float *xyz, int b, int n, int m,
+                               float radius, int nsample, int32_t *idx) {
+    const float radius2 = radius * radius;
+    memset(idx, 0, sizeof(int32_t) * (size_t)b * m * nsample);
+    for (int bi = 0; bi < b; ++bi) {
+        const float *q = new_xyz + (size_t)bi * 3 * m;
+        const float *s = xyz + (size_t)bi * 3 * n;
+        int32_t *o = idx + (size_t)bi * m * nsample;
+        for (int j = 0; j < m; ++j) {
+            const float qx = q[j], qy = q[m + j], qz = q[2 * m + j];
+            int cnt = 0;
+            for (int k = 0; k < n && cnt < nsample; ++k) {
+                const float d2 = sq3(qx - s[k], qy - s[n + k], qz - s[2 * n + k]);
+                if (d2 < radius2) {
+                    o[j * nsample + cnt] = k;
+                    ++cnt;
+                }
+            }
+            if (cnt < nsample - 1) {
+                for (int k = 0; k + cnt < nsample; ++k)
+                    o[j * nsample + k + cnt] = o[j * nsample + k];
+            }
+        }
+    }
+}
+
+/*
+ * Furthest point sampling.  dataset (b,3,n), temp (b,n) caller-initialised to
+ * 1e10 (grouping_cuda.cpp:167-168), idxs (b,m).
+ * grouping_cuda_kernel.cu:351-466 with block = opt_n_threads(n) "threads":
+ *   idxs[0] = 0; for each round: every thread tid scans k = tid, tid+block, ...
+ *   skipping points with |p|^2 <= 1e-3 (double compare, :385-387), updates
+ *   temp[k] = min(d, temp[k]) and keeps (best,besti) with strict '>' starting
+ *   from best=-1, besti=0; then the shared-memory tree (__update :339-346,
+ *   offsets block/2 ... 1) keeps idx1 on ties.  The tree is restated literally
+ *   so tie-breaking is the reference's, not an approximation of it.
+ */
+void epn_oracle_fps_f32(const float *dataset, int b, int n, int m, float *temp, int32_t *idxs) {
+    if (m <= 0) return;
+    const int block = epn_oracle_opt_n_threads(n);
+    float *dists = (float *)malloc(sizeof(float) * block);
+    int *dists_i = (int *)malloc(sizeof(int) * block);
+    for (int bi = 0; bi < b; ++bi) {
+        const float *d = dataset + (size_t)bi * 3 * n;
+        float *tmp = temp + (size_t)bi * n;
+        int32_t *out = idxs + (size_t)bi * m;
+        int old = 0;
+        out[0] = 0;
+        for (int j = 1; j < m; ++j) {
+            const float x1 = d[old], y1 = d[n + old], z1 = d[2 * n + old];
+            for (int tid = 0; tid < block; ++tid) {
+                int besti = 0;
+                float best = -1.0f;
+                for (int k = tid; k < n; k += block) {
+                    const float x2 = d[k], y2 = d[n + k], z2 = d[2 * n + k];
+                    const float mag = sq3(x2, y2, z2);
+                    if ((double)mag <= 1e-3) continue;
+                    const float dd = sq3(x2 - x1, y2 - y1, z2 - z1);
+                    const float d2 = dd < tmp[k] ? dd : tmp[k]; /* min(d, temp[k]) */
+                    tmp[k] = d2;
+                    besti = d2 > best ? k : besti;
+                    best = d2 > best ? d2 : best;
+                }
+                dists[tid] = best;
+                dists_i[tid] = besti;
+            }
+            for (int off = block / 2; off >= 1; off >>= 1) {
+                for (int tid = 0; tid < off; ++tid) {
+                    const float v1 = dists[tid], v2 = dists[tid + off];
+                    const int i1 = dists_i[tid], i2 = dists_i[tid + off];
+                    dists[tid] = v1 > v2 ? v1 : v2; /* max(v1, v2) */
+                    dists_i[tid] = v2 > v1 ? i2 : i1;
+                }
+            }
+            old = dists_i[0];
+            out[j] = old;
+        }
+    }
+    free(dists);
+    free(dists_i);
+}
+
+/* gathering_cuda_kernel.cu:43-68 : out[b,c,j] = points[b,c,idx[b,j]] */
+void epn_oracle_gather_fwd_f32(const float *points, const int32_t *idx, int b, int c, int n, int m,
+                               float *out) {
+    for (int bi = 0; bi < b; ++bi)
+        for (int ci = 0; ci < c; ++ci)
+            for (int j = 0; j < m; ++j)
+                out[((size_t)bi * c + ci) * m + j] =
+                    points[((size_t)bi * c + ci) * n + idx[(size_t)bi * m + j]];
+}
+
+/* gathering_cuda_kernel.cu:73-98 : grad_points[b,c,idx[b,j]] += grad_out[b,c,j]
+ * (reference uses atomicAdd, i.e. unspecified order; here j ascending). */
+void epn_oracle_gather_bwd_f32(const float *grad_out, const int32_t *idx, int b, int c, int n, int m,
+                               float *grad_points) {
+    memset(grad_points, 0, sizeof(float) * (size_t)b * c * n);
+    for (int bi = 0; bi < b; ++bi)
+        for (int ci = 0; ci < c; ++ci)
+            for (int j = 0; j < m; ++j)
+                grad_points[((size_t)bi * c + ci) * n + idx[(size_t)bi * m + j]] +=
+                    grad_out[((size_t)bi * c + ci) * m + j];
+}

@@ -1,0 +1,119 @@
+"""oracle/index_ref.py -- TEST INFRASTRUCTURE, NOT PRODUCT CODE.
+
+ctypes front-end to ``libepn_oracle.so`` (oracle/epn_oracle.c): the CPU
+restatement of the reference's CUDA-only index kernels
+
+* ``ball_query``               vgtk/vgtk/cuda/grouping_cuda.cpp:71-86
+* ``furthest_point_sampling``  vgtk/vgtk/cuda/grouping_cuda.cpp:160-174
+* ``gather_points_forward``    vgtk/vgtk/cuda/gathering_cuda.cpp:29-43
+* ``gather_points_backward``   vgtk/vgtk/cuda/gathering_cuda.cpp:45-60
+
+with the same call signatures as the pybind functions (torch CPU tensors in,
+freshly allocated torch CPU tensors out).  Parity vs the CUDA binary is
+UNPINNED (see the header of epn_oracle.c); parity HIP-vs-oracle is bit-exact.
+
+Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may
+import this module.
+"""
+import ctypes
+import os
+import subprocess
+
+import numpy as np
+import torch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_SO = os.path.join(_HERE, "libepn_oracle.so")
+
+
+def build(force=False):
+    """Compile the C restatement (gcc, seconds).  Building the checker is not using it."""
+    src = os.path.join(_HERE, "epn_oracle.c")
+    if force or not os.path.exists(_SO) or os.path.getmtime(_SO) < os.path.getmtime(src):
+        subprocess.check_call(["make", "-C", _HERE, "-B", "libepn_oracle.so"],
+                              stdout=subprocess.DEVNULL)
+    return _SO
+
+
+_lib = None
+
+
+def _load():
+    global _lib
+    if _lib is None:
+        build()
+        lib = ctypes.CDLL(_SO)
+        f32p = ctypes.POINTER(ctypes.c_float)
+        i32p = ctypes.POINTER(ctypes.c_int32)
+        ci = ctypes.c_int
+        lib.epn_oracle_ball_query_f32.argtypes = [f32p, f32p, ci, ci, ci, ctypes.c_float, ci, i32p]
+        lib.epn_oracle_fps_f32.argtypes = [f32p, ci, ci, ci, f32p, i32p]
+        lib.epn_oracle_gather_fwd_f32.argtypes = [f32p, i32p, ci, ci, ci, ci, f32p]
+        lib.epn_oracle_gather_bwd_f32.argtypes = [f32p, i32p, ci, ci, ci, ci, f32p]
+        lib.epn_oracle_opt_n_threads.argtypes = [ci]
+        lib.epn_oracle_opt_n_threads.restype = ci
+        _lib = lib
+    return _lib
+
+
+def _f32(t):
+    a = np.ascontiguousarray(t.detach().cpu().numpy(), dtype=np.float32)
+    return a, a.ctypes.data_as(ctypes.POINTER(ctypes.c_float))
+
+
+def _i32(t):
+    a = np.ascontiguousarray(t.detach().cpu().numpy(), dtype=np.int32)
+    return a, a.ctypes.data_as(ctypes.POINTER(ctypes.c_int32))
+
+
+def ball_query(new_xyz, xyz, radius, nsample):
+    """(new_xyz f[b,3,m], xyz f[b,3,n], radius, nsample) -> int32 [b,m,nsample]."""
+    lib = _load()
+    b, _, m = new_xyz.shape
+    n = xyz.shape[2]
+    qa, qp = _f32(new_xyz)
+    sa, sp = _f32(xyz)
+    out = np.zeros((b, m, nsample), dtype=np.int32)
+    lib.epn_oracle_ball_query_f32(qp, sp, b, n, m, float(radius), int(nsample),
+                                  out.ctypes.data_as(ctypes.POINTER(ctypes.c_int32)))
+    return torch.from_numpy(out)
+
+
+def furthest_point_sampling(xyz, m):
+    """(xyz f[b,3,n], m) -> int32 [b,m]; temp = 1e10 as grouping_cuda.cpp:167-168."""
+    lib = _load()
+    b, _, n = xyz.shape
+    xa, xp = _f32(xyz)
+    temp = np.full((b, n), 1e10, dtype=np.float32)
+    out = np.zeros((b, m), dtype=np.int32)
+    lib.epn_oracle_fps_f32(xp, b, n, int(m), temp.ctypes.data_as(ctypes.POINTER(ctypes.c_float)),
+                           out.ctypes.data_as(ctypes.POINTER(ctypes.c_int32)))
+    return torch.from_numpy(out)
+
+
+def gather_points_forward(points, idx):
+    """(points f[b,c,n], idx int32[b,m]) -> float32 [b,c,m]."""
+    lib = _load()
+    b, c, n = points.shape
+    m = idx.shape[1]
+    pa, pp = _f32(points)
+    ia, ip = _i32(idx)
+    out = np.zeros((b, c, m), dtype=np.float32)
+    lib.epn_oracle_gather_fwd_f32(pp, ip, b, c, n, m, out.ctypes.data_as(ctypes.POINTER(ctypes.c_float)))
+    return torch.from_numpy(out)
+
+
+def gather_points_backward(grad_out, idx, npoint):
+    """(grad_out f[b,c,m], idx int32[b,m], npoint) -> f[b,c,npoint]."""
+    lib = _load()
+    b, c, m = grad_out.shape
+    ga, gp = _f32(grad_out)
+    ia, ip = _i32(idx)
+    out = np.zeros((b, c, npoint), dtype=np.float32)
+    lib.epn_oracle_gather_bwd_f32(gp, ip, b, c, int(npoint), m,
+                                  out.ctypes.data_as(ctypes.POINTER(ctypes.c_float)))
+    return torch.from_numpy(out)
+
+
+def opt_n_threads(work_size):
+    return _load().epn_oracle_opt_n_threads(int(work_size))

@@ -1,0 +1,44 @@
+import os
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+GOLDEN = os.path.join(ROOT, "tests", "golden")
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+
+
+def golden(name):
+    return np.load(os.path.join(GOLDEN, name), allow_pickle=False)
+
+
+def unit_ball_cloud(rng, b, n, scale=1.0):
+    """Synthetic clouds of SURVEY.md 8(d): uniform in the unit ball, centred, max-norm 1; [b,3,n] float32."""
+    g = rng.standard_normal((b, n, 3))
+    u = rng.random((b, n, 1))
+    p = g / np.linalg.norm(g, axis=2, keepdims=True) * u ** (1.0 / 3.0)
+    p = p - p.mean(axis=1, keepdims=True)
+    p = p / np.linalg.norm(p, axis=2).max(axis=1)[:, None, None]
+    return np.ascontiguousarray((scale * p).transpose(0, 2, 1).astype(np.float32))
+
+
+@pytest.fixture(scope="session")
+def vgtk_alias():
+    import epn_pointcloud_amd
+    return epn_pointcloud_amd.install_vgtk_alias()
+
+
+@pytest.fixture(scope="session")
+def gpu():
+    import torch
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU visible")
+    from epn_pointcloud_amd import _lib
+    _lib.get_lib()  # the HIP library must be the thing that runs: fail loudly if it is missing
+    return torch.device("cuda:0")

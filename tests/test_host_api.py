@@ -1,0 +1,92 @@
+"""Host-side mirror of the reference's vgtk API for the hot path: names, constructor signatures,
+state_dict keys/shapes, return conventions and error behaviour (CPU tensors are rejected like CHECK_CUDA)."""
+import numpy as np
+import pytest
+import torch
+
+from conftest import golden
+
+
+def test_reference_import_names(vgtk_alias):
+    import vgtk
+    import vgtk.spconv as zptk
+    import vgtk.so3conv as sptk
+    import vgtk.cuda.grouping as cuda_nn
+    import vgtk.cuda.gathering as gather
+    import vgtk.cuda.zpconv as cuda_zpconv  # noqa: F401
+    import vgtk.pc as pctk
+    for name in ("InterSO3Conv", "IntraSO3Conv", "BasicSO3Conv", "PointnetSO3Conv", "KernelPropagation",
+                 "get_occupancy_features", "get_anchors", "get_intra_idx", "inter_so3conv_grouping",
+                 "intra_so3conv_grouping", "inter_so3conv_grouping_anchor", "SphericalPointCloud"):
+        assert hasattr(sptk, name), name
+    assert hasattr(zptk.functional, "batched_index_select") and hasattr(zptk, "SphericalPointCloud")
+    for name in ("ball_query", "furthest_point_sampling", "initial_anchor_query", "anchor_query"):
+        assert hasattr(cuda_nn, name)
+    assert hasattr(gather, "gather_points_forward") and hasattr(gather, "gather_points_backward")
+    for name in ("group_nd", "ball_query_index", "furthest_sample_index", "furthest_sample", "load_ply"):
+        assert hasattr(pctk, name)
+    assert callable(vgtk.batch_gather)
+
+
+def test_state_dict_layout_matches_reference(vgtk_alias):
+    import vgtk.so3conv as sptk
+    g = golden("inter_module_s2_fps.npz")
+    conv = sptk.InterSO3Conv(1, 8, 1, 2, 0.4, 0.08, 16, lazy_sample=False, kanchor=60)
+    sd = conv.state_dict()
+    assert sorted(sd.keys()) == list(g["state_keys"])
+    assert tuple(sd["anchors"].shape) == (60, 3, 3) and tuple(sd["kernels"].shape) == (24, 3)
+    assert tuple(sd["basic_conv.W"].shape) == (8, 24)
+    assert np.array_equal(sd["kernels"].numpy(), g["kernels"]) and np.array_equal(sd["anchors"].numpy(), g["anchors"])
+    conv.load_state_dict({"anchors": torch.from_numpy(g["anchors"]), "kernels": torch.from_numpy(g["kernels"]),
+                          "basic_conv.W": torch.from_numpy(g["W"])})
+    gi = golden("intra_module.npz")
+    intra = sptk.IntraSO3Conv(8, 8)
+    assert sorted(intra.state_dict().keys()) == list(gi["state_keys"])
+    assert intra.intra_idx.dtype == torch.int64 and tuple(intra.intra_idx.shape) == (60, 12)
+    assert tuple(intra.basic_conv.W.shape) == (8, 96)
+    # W init: xavier_normal_(gain=sqrt(2)) on [Cout, Cin, ks] (modules.py:35-41)
+    torch.manual_seed(0)
+    big = sptk.BasicSO3Conv(64, 64, 24)
+    std = (2.0 ** 0.5) * (2.0 / (64 * 24 + 64 * 24)) ** 0.5
+    assert abs(big.W.std().item() - std) / std < 0.05
+
+
+def test_cpu_tensors_are_rejected_like_check_cuda(vgtk_alias):
+    import vgtk.cuda.grouping as cuda_nn
+    import vgtk.cuda.gathering as gather
+    import vgtk.so3conv as sptk
+    import vgtk.spconv as zptk
+    x = torch.rand(1, 3, 32)
+    with pytest.raises(RuntimeError, match="must be a CUDA tensor"):
+        cuda_nn.ball_query(x, x, 0.2, 4)
+    with pytest.raises(RuntimeError, match="must be a CUDA tensor"):
+        cuda_nn.furthest_point_sampling(x, 8)
+    with pytest.raises(RuntimeError, match="must be a CUDA tensor"):
+        gather.gather_points_forward(x, torch.zeros(1, 4, dtype=torch.int32))
+    conv = sptk.IntraSO3Conv(4, 4)
+    with pytest.raises(RuntimeError, match="must be a CUDA tensor"):
+        conv(zptk.SphericalPointCloud(x, torch.rand(1, 4, 32, 60), None))
+    with pytest.raises(NotImplementedError):
+        cuda_nn.anchor_query(None, None, None, None, None, 0)
+
+
+def test_lazy_sample_index_and_occupancy(vgtk_alias):
+    import vgtk.pc as pctk
+    import vgtk.so3conv as sptk
+    x = torch.rand(2, 3, 16)
+    idx = pctk.furthest_sample_index(x, 16, False)       # nothing to drop -> arange, no kernel (sample.py:64-67)
+    assert idx.dtype == torch.int32 and torch.equal(idx, torch.arange(16, dtype=torch.int32).expand(2, -1))
+    idx = pctk.furthest_sample_index(x, 8, True)
+    assert torch.equal(idx[1], torch.arange(8, dtype=torch.int32))
+    f = sptk.get_occupancy_features(torch.rand(2, 16, 3), 60)
+    assert tuple(f.shape) == (2, 1, 16, 60) and (f == 1).all()
+    f = sptk.get_occupancy_features(torch.rand(2, 16, 3), 60, use_center=True)
+    assert (f[:, :, 0] == 0).all() and (f[:, :, 1:] == 1).all()
+
+
+def test_lr_scheduler(vgtk_alias):
+    import vgtk
+    opt = torch.optim.SGD([torch.nn.Parameter(torch.zeros(1))], lr=1e-3)
+    s = vgtk.LearningRateScheduler(opt, 1e-3, "exp_decay", 2, decay_rate=0.5)
+    lrs = [s.step() for _ in range(4)]
+    assert lrs == [1e-3, 5e-4, 5e-4, 2.5e-4] and opt.param_groups[0]["lr"] == 2.5e-4
