@@ -87,8 +87,8 @@ __global__ void inter_group_kernel(Geo geo, const float *__restrict__ rk, const 
         const int qq = geo.q(bi, p, n);
         const bool sh = qq < 0 || qq >= geo.p1;
         const float f = sh ? 0.f : feats[(((size_t)bi * geo.p1 + qq) * na + a) * cin + c];
-        float gx, gy, gz;
-        geo.g(bi, p, qq, gx, gy, gz);
+        float gx = 0.f, gy = 0.f, gz = 0.f;
+        if (!dense_w) geo.g(bi, p, qq, gx, gy, gz);
 #pragma unroll
         for (int k = 0; k < KS_MAX; ++k) {
             if (k < ks) {
@@ -163,8 +163,8 @@ __global__ void inter_scatter_kernel(Geo geo, const float *__restrict__ rk, cons
     for (int n = 0; n < geo.nn; ++n) {
         const int qq = geo.q(bi, p, n);
         if (qq < 0 || qq >= geo.p1) continue;
-        float gx, gy, gz;
-        geo.g(bi, p, qq, gx, gy, gz);
+        float gx = 0.f, gy = 0.f, gz = 0.f;
+        if (!dense_w) geo.g(bi, p, qq, gx, gy, gz);
         float t = 0.f;
 #pragma unroll
         for (int k = 0; k < KS_MAX; ++k) {

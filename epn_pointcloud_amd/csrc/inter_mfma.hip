@@ -1,0 +1,508 @@
+// Fused InterSO3Conv kernels for gfx950 (f32 MFMA, v_mfma_f32_16x16x4_f32).
+//
+// Work decomposition ("a wavefront owns 16 output columns"): a column is one (b, p, a) triple,
+// col = (b*p2 + p)*na + a, so the output tensor out_cl[col][o] is a plain row-major matrix.  For
+// every chunk of 16 input channels a wave
+//   1. regenerates the kernel-influence weights of each of its columns with ONE MFMA per 16x16 tile:
+//        S[n][k] = alpha_n + beta_k + (2/sigma) g_n . (R_a kappa_k),    w = max(S, 0)
+//      (= relu(1 - |g_n - R_a kappa_k|^2 / sigma), vgtk/vgtk/so3conv/functional.py:190-200, expanded),
+//      whose C/D fragment IS the A fragment of the next MFMA, so w never leaves registers;
+//   2. contracts over the K neighbours:  G[k][c] = sum_n w[k][n] F[idx[n], a, c]  (spconv/functional.py:384)
+//      with the feature rows read straight from L2 in channels-last layout (64-byte segments);
+//   3. transposes G through a wave-private LDS tile so that the 16 columns become the N dimension;
+//   4. contracts over (c,k) with the BasicSO3Conv weight (so3conv/modules.py:52), W staged through LDS
+//      and shared by the 4 waves of the workgroup:  out[o][col] += sum_ck W[o][ck] G[ck][col].
+// Nothing of size [.., ks, K] or [.., cin, ks] is ever written to HBM.
+//
+// Fragment layouts (verified on hardware by tools/mfma_probe.hip): lane l, x = l & 15, j = l >> 4:
+//   A[m = x][k = j],  B[k = j][n = x],  D[m = 4j + r][n = x]  (r = register 0..3).
+#include "conv_internal.h"
+
+namespace epn {
+
+bool inter_mfma_available() { return true; }
+
+namespace {
+
+constexpr int NW = 4;  // waves per workgroup
+
+struct InterArgs {
+    const float *xyz, *new_xyz;
+    const int32_t *idx;
+    const float *rk4;    // [na][32][4] = ((2/sigma) R_a kappa_k, beta_k), zero / -1e30 padded
+    const float *feats;  // fwd: feats_cl [b][p1][na][cin];  bwd_weight: same
+    const float *W;      // fwd: W [cout][cin*ks];           bwd_data: WT [cin*ks][cout]
+    const float *gout;   // bwd: grad_out_cl [ncol][cout]
+    float *out;          // fwd: out_cl [ncol][cout]; bwd_data: grad_feats_cl; bwd_weight: grad_W
+    float sigma_inv;
+    int b, p1, p2, nn, na, ks, cin, cout, wk;
+    long long ncol;
+    int col_tiles_per_wg;  // bwd_weight only
+};
+
+__device__ __forceinline__ f32x4 mfma4(float a, float b, f32x4 c) {
+    return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0);
+}
+
+// Per-point neighbourhood fragments, shared by all columns (anchors) of one output point.
+template <int NT>
+struct Hood {
+    float gA[NT];    // S-MFMA operand: lane (x, j) -> (g_x, g_y, g_z, alpha)[j] of neighbour 16t + x
+    int q[NT][4];    // neighbour index for n = 16t + 4j + r (feature-row gather), 0 when masked
+    bool ok[NT][4];
+};
+
+template <int NT>
+__device__ __forceinline__ void load_hood(const InterArgs &A, int bb, int pp, int x, int j, Hood<NT> &h) {
+    const int32_t *row = A.idx + ((size_t)bb * A.p2 + pp) * A.nn;
+    const float *s = A.xyz + (size_t)bb * 3 * A.p1;
+    const float *c = A.new_xyz + (size_t)bb * 3 * A.p2;
+    const float cx = c[pp], cy = c[A.p2 + pp], cz = c[2 * A.p2 + pp];
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+        const int n = 16 * t + x;
+        int qq = n < A.nn ? row[n] : -1;
+        const bool valid = qq >= 0 && qq < A.p1;
+        qq = valid ? qq : 0;
+        const float gx = s[qq] - cx, gy = s[A.p1 + qq] - cy, gz = s[2 * A.p1 + qq] - cz;
+        const float alpha = valid ? 1.0f - (gx * gx + gy * gy + gz * gz) * A.sigma_inv : -1e30f;
+        h.gA[t] = j == 0 ? gx : (j == 1 ? gy : (j == 2 ? gz : alpha));
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int n2 = 16 * t + 4 * j + r;
+            int q2 = n2 < A.nn ? row[n2] : -1;
+            h.ok[t][r] = q2 >= 0 && q2 < A.p1;
+            h.q[t][r] = h.ok[t][r] ? q2 : 0;
+        }
+    }
+}
+
+// w[kt][t] (4 registers each) for one column: lane (x, j), register r  ->  k = 16kt + x, n = 16t + 4j + r
+template <int NT, int KT>
+__device__ __forceinline__ void make_weights(const InterArgs &A, int a, int x, int j, const Hood<NT> &h,
+                                             f32x4 (&w)[KT][NT]) {
+#pragma unroll
+    for (int kt = 0; kt < KT; ++kt) {
+        const float *e = A.rk4 + ((size_t)a * EPN_KS_MAX + 16 * kt + x) * 4;
+        const float rk = j == 3 ? 1.0f : e[j];
+        const float beta = e[3];
+#pragma unroll
+        for (int t = 0; t < NT; ++t) {
+            f32x4 s = {beta, beta, beta, beta};
+            s = mfma4(h.gA[t], rk, s);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) s[r] = fmaxf(s[r], 0.0f);
+            w[kt][t] = s;
+        }
+    }
+}
+
+// Grouped features of 16 columns x 16 channels into the wave-private LDS tile Gs[col][c_local*ks + k].
+template <int NT, int KT>
+__device__ __forceinline__ void group_chunk(const InterArgs &A, long long col0, int ct, int x, int j, float *Gs,
+                                            int gss) {
+    Hood<NT> h;
+    int last_pt = -1;
+    for (int jc = 0; jc < 16; ++jc) {
+        long long col = col0 + jc;
+        col = col < A.ncol ? col : A.ncol - 1;
+        const int a = (int)(col % A.na);
+        const int pt = (int)(col / A.na);  // b*p2 + p
+        const int bb = pt / A.p2, pp = pt - bb * A.p2;
+        if (pt != last_pt) {
+            load_hood<NT>(A, bb, pp, x, j, h);
+            last_pt = pt;
+        }
+        float f[NT][4];
+        const float *fb = A.feats + (((size_t)bb * A.p1) * A.na + a) * A.cin + 16 * ct + x;
+#pragma unroll
+        for (int t = 0; t < NT; ++t)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const float v = fb[(size_t)h.q[t][r] * A.na * A.cin];
+                f[t][r] = h.ok[t][r] ? v : 0.0f;
+            }
+        f32x4 w[KT][NT];
+        make_weights<NT, KT>(A, a, x, j, h, w);
+#pragma unroll
+        for (int kt = 0; kt < KT; ++kt) {
+            f32x4 g = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int t = 0; t < NT; ++t)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) g = mfma4(w[kt][t][r], f[t][r], g);
+            if (16 * kt + 4 * j < A.ks)  // rows k = 16kt + 4j + r of channel x
+                *reinterpret_cast<f32x4 *>(Gs + jc * gss + x * A.ks + 16 * kt + 4 * j) = g;
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------ forward
+template <int NT, int KT>
+__global__ __launch_bounds__(64 * NW) void inter_fwd_kernel(InterArgs A) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int x = lane & 15, j = lane >> 4;
+    const int ckl = 16 * A.ks;  // contraction length of one 16-channel chunk
+    const int gss = ckl + 4;
+    float *Gs = smem + (size_t)wave * 16 * gss;
+    float *Ws = smem + (size_t)NW * 16 * gss;
+    const int wss = A.wk + 4;
+    const int MT = A.cout >> 4;
+    const long long col0 = ((long long)blockIdx.x * NW + wave) * 16;
+    const int CK = A.cin * A.ks;
+
+    f32x4 acc[16];
+#pragma unroll
+    for (int m = 0; m < 16; ++m) acc[m] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    for (int ct = 0; ct < (A.cin >> 4); ++ct) {
+        if (col0 < A.ncol) group_chunk<NT, KT>(A, col0, ct, x, j, Gs, gss);
+        for (int sub = 0; sub < ckl / A.wk; ++sub) {
+            __syncthreads();  // previous sub-chunk fully consumed (and Gs writes visible)
+            {   // stage W[:, ct*ckl + sub*wk .. +wk) -> Ws[o][wk(+4)]
+                const int vec_per_row = A.wk >> 2;
+                const float *src = A.W + (size_t)ct * ckl + (size_t)sub * A.wk;
+                for (int i = threadIdx.x; i < A.cout * vec_per_row; i += blockDim.x) {
+                    const int o = i / vec_per_row, v = i - o * vec_per_row;
+                    *reinterpret_cast<f32x4 *>(Ws + o * wss + 4 * v) =
+                        *reinterpret_cast<const f32x4 *>(src + (size_t)o * CK + 4 * v);
+                }
+            }
+            __syncthreads();
+            for (int g = 0; g < (A.wk >> 4); ++g) {
+                const f32x4 bf = *reinterpret_cast<const f32x4 *>(Gs + x * gss + sub * A.wk + 16 * g + 4 * j);
+#pragma unroll
+                for (int m = 0; m < 16; ++m) {
+                    if (m < MT) {
+                        const f32x4 af = *reinterpret_cast<const f32x4 *>(Ws + (16 * m + x) * wss + 16 * g + 4 * j);
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) acc[m] = mfma4(af[r], bf[r], acc[m]);
+                    }
+                }
+            }
+        }
+    }
+    const long long col = col0 + x;
+    if (col < A.ncol) {
+#pragma unroll
+        for (int m = 0; m < 16; ++m)
+            if (m < MT) *reinterpret_cast<f32x4 *>(A.out + col * A.cout + 16 * m + 4 * j) = acc[m];
+    }
+}
+
+// ------------------------------------------------------------------------------------ backward (data)
+// dG[ck][col] = sum_o W[o][ck] dOut[col][o]   (M = ck, N = col, contraction o; WT staged by o-groups)
+// T[n][c]     = sum_k w[n][k] dG[c,k]         per column, then  dF[b, idx[n], a, c] += T[n][c]
+template <int NT, int KT>
+__global__ __launch_bounds__(64 * NW) void inter_bwd_data_kernel(InterArgs A) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int x = lane & 15, j = lane >> 4;
+    const int ckl = 16 * A.ks;
+    const int gss = ckl + 4;
+    float *Gs = smem + (size_t)wave * 16 * gss;   // dG tile of this wave: [col][c_local*ks + k]
+    float *Ws = smem + (size_t)NW * 16 * gss;     // WT rows [ckl][16(+4)] for one group of 16 output channels
+    const int wss = 20;
+    const int MTK = ckl >> 4;                     // 16-row tiles of the chunk (24 for ks = 24)
+    const long long col0 = ((long long)blockIdx.x * NW + wave) * 16;
+    const bool active = col0 < A.ncol;
+    long long colx = col0 + x;
+    colx = colx < A.ncol ? colx : A.ncol - 1;
+
+    for (int ct = 0; ct < (A.cin >> 4); ++ct) {
+        f32x4 dg[32];
+#pragma unroll
+        for (int m = 0; m < 32; ++m) dg[m] = f32x4{0.f, 0.f, 0.f, 0.f};
+        for (int og = 0; og < (A.cout >> 4); ++og) {
+            __syncthreads();
+            for (int i = threadIdx.x; i < ckl * 4; i += blockDim.x) {  // WT[ct*ckl + row][16og .. +16)
+                const int row = i >> 2, v = i & 3;
+                *reinterpret_cast<f32x4 *>(Ws + row * wss + 4 * v) = *reinterpret_cast<const f32x4 *>(
+                    A.W + ((size_t)ct * ckl + row) * A.cout + 16 * og + 4 * v);
+            }
+            __syncthreads();
+            const f32x4 bf = *reinterpret_cast<const f32x4 *>(A.gout + colx * A.cout + 16 * og + 4 * j);
+#pragma unroll
+            for (int m = 0; m < 32; ++m) {
+                if (m < MTK) {
+                    const f32x4 af = *reinterpret_cast<const f32x4 *>(Ws + (16 * m + x) * wss + 4 * j);
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) dg[m] = mfma4(af[r], bf[r], dg[m]);
+                }
+            }
+        }
+        // dg[m]: lane (x = col, j), register r -> ck_local = 16m + 4j + r
+#pragma unroll
+        for (int m = 0; m < 32; ++m)
+            if (m < MTK) *reinterpret_cast<f32x4 *>(Gs + x * gss + 16 * m + 4 * j) = dg[m];
+        __builtin_amdgcn_wave_barrier();
+        if (!active) continue;
+
+        Hood<NT> h;
+        int last_pt = -1;
+        for (int jc = 0; jc < 16; ++jc) {
+            const long long col = col0 + jc;
+            if (col >= A.ncol) break;
+            const int a = (int)(col % A.na);
+            const int pt = (int)(col / A.na);
+            const int bb = pt / A.p2, pp = pt - bb * A.p2;
+            if (pt != last_pt) {
+                load_hood<NT>(A, bb, pp, x, j, h);
+                last_pt = pt;
+            }
+            // transposed weights: lane (x = n_local, j), register r -> k = 16kt + 4j + r
+            // S'[k][n] = beta_k + alpha_n + (2/sigma) (R_a kappa_k) . g_n   (A = rk4 row incl. beta, B = (g,1))
+            float gB[NT], alphaN[NT];
+#pragma unroll
+            for (int t = 0; t < NT; ++t) {
+                // gA holds (gx,gy,gz,alpha)[j] for neighbour 16t + x: B operand wants (gx,gy,gz,1)[j], C wants alpha
+                alphaN[t] = __shfl(h.gA[t], 48 + x, 64);
+                gB[t] = j == 3 ? 1.0f : h.gA[t];
+            }
+            float *drow = A.out + (((size_t)bb * A.p1) * A.na + a) * A.cin + 16 * ct + x;
+#pragma unroll
+            for (int t = 0; t < NT; ++t) {
+                f32x4 tt = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int kt = 0; kt < KT; ++kt) {
+                    const float rk = A.rk4[((size_t)a * EPN_KS_MAX + 16 * kt + x) * 4 + j];
+                    f32x4 s = {alphaN[t], alphaN[t], alphaN[t], alphaN[t]};
+                    s = mfma4(rk, gB[t], s);  // D[m = k_local = 4j + r][n = x]
+                    // B operand of the contraction over k: dG[k = 16kt + 4j + r][c = x]; rows past ks carry w = 0
+                    const int jj = 16 * kt + 4 * j < A.ks ? j : 0;
+                    const f32x4 dgc = *reinterpret_cast<const f32x4 *>(Gs + jc * gss + x * A.ks + 16 * kt + 4 * jj);
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) tt = mfma4(fmaxf(s[r], 0.0f), dgc[r], tt);
+                }
+                // tt: lane (x = c, j), register r -> n = 16t + 4j + r
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+                    if (h.ok[t][r]) atomicAdd(drow + (size_t)h.q[t][r] * A.na * A.cin, tt[r]);
+            }
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------ backward (weight)
+// dW[o][ck] = sum_col dOut[col][o] G[ck][col].  A workgroup owns one 16-channel chunk (ckl columns of dW)
+// and one block of up to 128 output channels, walks `col_tiles_per_wg` tiles of 64 columns, keeps its
+// dW block in registers (wave w owns ck tiles w, w+4, ...) and adds it to grad_W once at the end.
+template <int NT, int KT>
+__global__ __launch_bounds__(64 * NW) void inter_bwd_weight_kernel(InterArgs A) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int x = lane & 15, j = lane >> 4;
+    const int ckl = 16 * A.ks;
+    const int gss = ckl + 4;
+    float *Gs = smem + (size_t)wave * 16 * gss;
+    const int ct = blockIdx.y;
+    const int o0 = blockIdx.z * 128;
+    const int MO = (A.cout - o0 < 128 ? A.cout - o0 : 128) >> 4;  // 16-row tiles of this block (<= 8)
+    const int NTK = ckl >> 4;                                       // ck tiles in the chunk
+    const int my_tiles = (NTK - wave + NW - 1) / NW;                // tiles wave, wave+4, ...  (<= 8)
+
+    f32x4 acc[8][8];
+#pragma unroll
+    for (int m = 0; m < 8; ++m)
+#pragma unroll
+        for (int n = 0; n < 8; ++n) acc[m][n] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    const long long tile0 = (long long)blockIdx.x * A.col_tiles_per_wg;
+    for (int it = 0; it < A.col_tiles_per_wg; ++it) {
+        const long long wg_col0 = (tile0 + it) * (16 * NW);
+        if (wg_col0 >= A.ncol) break;
+        const long long col0 = wg_col0 + wave * 16;
+        __syncthreads();  // everyone done reading the previous Gs tiles
+        if (col0 < A.ncol) group_chunk<NT, KT>(A, col0, ct, x, j, Gs, gss);
+        __syncthreads();
+        for (int wsrc = 0; wsrc < NW; ++wsrc) {
+            const long long c0 = wg_col0 + wsrc * 16;
+            if (c0 >= A.ncol) break;
+            const float *Gsrc = smem + (size_t)wsrc * 16 * gss;
+#pragma unroll
+            for (int s = 0; s < 4; ++s) {  // contraction step: columns c0 + 4s + j
+                const long long col = c0 + 4 * s + j;
+                const bool okc = col < A.ncol;
+                float af[8];
+#pragma unroll
+                for (int m = 0; m < 8; ++m)
+                    af[m] = (m < MO && okc) ? A.gout[col * A.cout + o0 + 16 * m + x] : 0.0f;
+#pragma unroll
+                for (int n = 0; n < 8; ++n) {
+                    if (n < my_tiles) {
+                        const float bfv = okc ? Gsrc[(4 * s + j) * gss + 16 * (wave + NW * n) + x] : 0.0f;
+#pragma unroll
+                        for (int m = 0; m < 8; ++m)
+                            if (m < MO) acc[m][n] = mfma4(af[m], bfv, acc[m][n]);
+                    }
+                }
+            }
+        }
+    }
+    // acc[m][n]: lane (x = ck within tile, j), register r -> o = o0 + 16m + 4j + r
+    const int CK = A.cin * A.ks;
+#pragma unroll
+    for (int m = 0; m < 8; ++m)
+#pragma unroll
+        for (int n = 0; n < 8; ++n)
+            if (m < MO && n < my_tiles) {
+                const int ck = ct * ckl + 16 * (wave + NW * n) + x;
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+                    atomicAdd(A.out + (size_t)(o0 + 16 * m + 4 * j + r) * CK + ck, acc[m][n][r]);
+            }
+}
+
+__global__ void rk4_table_kernel(const float *__restrict__ rk, int na, int ks, float sigma_inv,
+                                 float *__restrict__ rk4) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= na * EPN_KS_MAX) return;
+    const int k = i % EPN_KS_MAX, a = i / EPN_KS_MAX;
+    f32x4 v = {0.f, 0.f, 0.f, -1e30f};
+    if (k < ks) {
+        const float *r = rk + ((size_t)a * ks + k) * 3;
+        v[0] = 2.0f * sigma_inv * r[0];
+        v[1] = 2.0f * sigma_inv * r[1];
+        v[2] = 2.0f * sigma_inv * r[2];
+        v[3] = -(r[0] * r[0] + r[1] * r[1] + r[2] * r[2]) * sigma_inv;
+    }
+    *reinterpret_cast<f32x4 *>(rk4 + (size_t)i * 4) = v;
+}
+
+__global__ void transpose_kernel(const float *__restrict__ src, int rows, int cols, float *__restrict__ dst) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;  // dst[c][r] = src[r][c]
+    if (i >= (size_t)rows * cols) return;
+    const int r = i % rows;
+    const int c = i / rows;
+    dst[i] = src[(size_t)r * cols + c];
+}
+
+InterArgs make_args(const epn_inter_desc *d, const float *rk4) {
+    InterArgs A;
+    A.xyz = d->xyz; A.new_xyz = d->new_xyz; A.idx = d->ball_idx; A.rk4 = rk4;
+    A.feats = nullptr; A.W = nullptr; A.gout = nullptr; A.out = nullptr;
+    A.sigma_inv = 1.0f / d->sigma;
+    A.b = d->b; A.p1 = d->p1; A.p2 = d->p2; A.nn = d->nn; A.na = d->na; A.ks = d->ks; A.cin = d->cin;
+    A.cout = d->cout; A.wk = 0;
+    A.ncol = (long long)d->b * d->p2 * d->na;
+    A.col_tiles_per_wg = 1;
+    return A;
+}
+
+size_t gs_bytes(const epn_inter_desc *d) { return (size_t)NW * 16 * (16 * d->ks + 4) * sizeof(float); }
+
+template <typename K>
+int set_lds(K kern, size_t bytes) {
+    EPN_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                (int)bytes));
+    return 0;
+}
+
+#define EPN_DISPATCH_NT_KT(FN, ...)                                              \
+    do {                                                                         \
+        const int nt_ = (d->nn + 15) / 16, kt_ = (d->ks + 15) / 16;              \
+        if (kt_ == 1) {                                                          \
+            if (nt_ <= 1) FN(1, 1, __VA_ARGS__);                                 \
+            else if (nt_ <= 2) FN(2, 1, __VA_ARGS__);                            \
+            else if (nt_ <= 4) FN(4, 1, __VA_ARGS__);                            \
+            else FN(8, 1, __VA_ARGS__);                                          \
+        } else {                                                                 \
+            if (nt_ <= 1) FN(1, 2, __VA_ARGS__);                                 \
+            else if (nt_ <= 2) FN(2, 2, __VA_ARGS__);                            \
+            else if (nt_ <= 4) FN(4, 2, __VA_ARGS__);                            \
+            else FN(8, 2, __VA_ARGS__);                                          \
+        }                                                                        \
+    } while (0)
+
+}  // namespace
+
+int launch_inter_tables_mfma(const epn_inter_desc *d, const float *rk, float *rk4, float *beta, hipStream_t st) {
+    (void)beta;
+    const int n = d->na * EPN_KS_MAX;
+    hipLaunchKernelGGL(rk4_table_kernel, dim3(epn_cdiv(n, 256)), dim3(256), 0, st, rk, d->na, d->ks, 1.0f / d->sigma,
+                       rk4);
+    EPN_CHECK_LAUNCH();
+    return 0;
+}
+
+int launch_inter_fwd_mfma(const epn_inter_desc *d, const float *rk4, const float *beta, const float *feats,
+                          const float *W, float *out, hipStream_t st) {
+    (void)beta;
+    InterArgs A = make_args(d, rk4);
+    A.feats = feats; A.W = W; A.out = out;
+    const int ckl = 16 * d->ks;
+    // W sub-chunk width: largest divisor of the chunk length (multiple of 16) that keeps Ws <= ~56 KB
+    int wk = 16;
+    for (int cand = 16; cand <= ckl; cand += 16)
+        if (ckl % cand == 0 && (size_t)d->cout * (cand + 4) * sizeof(float) <= 56 * 1024) wk = cand;
+    A.wk = wk;
+    const size_t lds = gs_bytes(d) + (size_t)d->cout * (wk + 4) * sizeof(float);
+    const unsigned grid = (unsigned)((A.ncol + 16 * NW - 1) / (16 * NW));
+#define EPN_FWD(NT_, KT_, dummy)                                                                      \
+    do {                                                                                              \
+        int rc_ = set_lds(inter_fwd_kernel<NT_, KT_>, lds);                                           \
+        if (rc_) return rc_;                                                                          \
+        hipLaunchKernelGGL((inter_fwd_kernel<NT_, KT_>), dim3(grid), dim3(64 * NW), lds, st, A);      \
+    } while (0)
+    EPN_DISPATCH_NT_KT(EPN_FWD, 0);
+#undef EPN_FWD
+    EPN_CHECK_LAUNCH();
+    return 0;
+}
+
+int launch_inter_bwd_data_mfma(const epn_inter_desc *d, const float *rk4, const float *WT, const float *dOut,
+                               const float *W, float *dF, hipStream_t st) {
+    // WT: scratch [cin*ks][cout] (the caller passes the workspace slot in the `beta` position)
+    float *wt = const_cast<float *>(WT);
+    const size_t nW = (size_t)d->cout * d->cin * d->ks;
+    hipLaunchKernelGGL(transpose_kernel, dim3((unsigned)((nW + 255) / 256)), dim3(256), 0, st, W, d->cout,
+                       d->cin * d->ks, wt);
+    EPN_CHECK_LAUNCH();
+    InterArgs A = make_args(d, rk4);
+    A.W = wt; A.gout = dOut; A.out = dF;
+    const size_t lds = gs_bytes(d) + (size_t)16 * d->ks * 20 * sizeof(float);
+    const unsigned grid = (unsigned)((A.ncol + 16 * NW - 1) / (16 * NW));
+#define EPN_BD(NT_, KT_, dummy)                                                                       \
+    do {                                                                                              \
+        int rc_ = set_lds(inter_bwd_data_kernel<NT_, KT_>, lds);                                      \
+        if (rc_) return rc_;                                                                          \
+        hipLaunchKernelGGL((inter_bwd_data_kernel<NT_, KT_>), dim3(grid), dim3(64 * NW), lds, st, A); \
+    } while (0)
+    EPN_DISPATCH_NT_KT(EPN_BD, 0);
+#undef EPN_BD
+    EPN_CHECK_LAUNCH();
+    return 0;
+}
+
+int launch_inter_bwd_weight_mfma(const epn_inter_desc *d, const float *rk4, const float *beta, const float *feats,
+                                 const float *dOut, float *dW, hipStream_t st) {
+    (void)beta;
+    InterArgs A = make_args(d, rk4);
+    A.feats = feats; A.gout = dOut; A.out = dW;
+    const long long tiles = (A.ncol + 16 * NW - 1) / (16 * NW);
+    const int chunks = d->cin / 16, oblocks = (d->cout + 127) / 128;
+    // enough workgroups to fill 256 CUs a few times over, each walking a contiguous run of column tiles
+    long long splits = (256 * 4 + chunks * oblocks - 1) / (chunks * oblocks);
+    if (splits > tiles) splits = tiles;
+    if (splits < 1) splits = 1;
+    A.col_tiles_per_wg = (int)((tiles + splits - 1) / splits);
+    const unsigned gx = (unsigned)((tiles + A.col_tiles_per_wg - 1) / A.col_tiles_per_wg);
+    const size_t lds = gs_bytes(d);
+#define EPN_BW(NT_, KT_, dummy)                                                                          \
+    do {                                                                                                 \
+        int rc_ = set_lds(inter_bwd_weight_kernel<NT_, KT_>, lds);                                       \
+        if (rc_) return rc_;                                                                             \
+        hipLaunchKernelGGL((inter_bwd_weight_kernel<NT_, KT_>), dim3(gx, chunks, oblocks), dim3(64 * NW), \
+                           lds, st, A);                                                                  \
+    } while (0)
+    EPN_DISPATCH_NT_KT(EPN_BW, 0);
+#undef EPN_BW
+    EPN_CHECK_LAUNCH();
+    return 0;
+}
+
+}  // namespace epn

@@ -1,0 +1,204 @@
+"""-m gpu: InterSO3Conv / IntraSO3Conv HIP kernels (forward + backward) through the C ABI.
+Bar (BASELINE north_star): features within 1e-3 (fp32) of the oracle; tolerance written per assert."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import golden, unit_ball_cloud
+from oracle import so3conv_ref as R
+
+pytestmark = pytest.mark.gpu
+T = torch.from_numpy
+TOL = 1e-3
+
+
+def _mods(vgtk_alias):
+    import vgtk.so3conv as sptk
+    import vgtk.spconv as zptk
+    return sptk, zptk
+
+
+def _rel(a, b):
+    return (a - b).abs().max().item() / max(b.abs().max().item(), 1e-12)
+
+
+def test_inter_module_golden(gpu, vgtk_alias):
+    sptk, zptk = _mods(vgtk_alias)
+    for tag, (cin, cout, stride, lazy) in {"s2_fps": (1, 8, 2, False), "s1_lazy": (6, 8, 1, True)}.items():
+        g = golden(f"inter_module_{tag}.npz")
+        conv = sptk.InterSO3Conv(cin, cout, 1, stride, 0.4, 0.08, 16, lazy_sample=lazy, kanchor=60)
+        conv.load_state_dict({"anchors": T(g["anchors"]), "kernels": T(g["kernels"]), "basic_conv.W": T(g["W"])})
+        conv = conv.to(gpu)
+        feats = T(g["feats"]).to(gpu).requires_grad_(True)
+        iidx, iw, sidx, y = conv(zptk.SphericalPointCloud(T(g["xyz"]).to(gpu), feats, None))
+        assert np.array_equal(iidx.cpu().numpy(), g["inter_idx"])           # bit-exact indices
+        assert np.array_equal(sidx.cpu().numpy(), g["sample_idx"])
+        assert np.array_equal(y.xyz.cpu().numpy(), g["new_xyz"])
+        assert tuple(iw.shape) == (2, g["inter_idx"].shape[1], 60, 24, 16)
+        assert torch.allclose(iw.dense()[:, ::16].cpu(), T(g["inter_w_sub"]), atol=1e-5)
+        assert torch.allclose(y.feats.detach().cpu(), T(g["out"]), atol=TOL)
+        assert y.feats.shape == (2, cout, g["inter_idx"].shape[1], 60)
+        dW, dF = torch.autograd.grad(y.feats, [conv.basic_conv.W, feats], T(g["gy"]).to(gpu))
+        assert _rel(dW.cpu(), T(g["dW"])) < TOL
+        assert torch.allclose(dF.cpu(), T(g["dF"]), atol=TOL)
+
+
+def test_intra_module_golden(gpu, vgtk_alias):
+    sptk, zptk = _mods(vgtk_alias)
+    g = golden("intra_module.npz")
+    conv = sptk.IntraSO3Conv(8, 8)
+    conv.load_state_dict({"anchors": T(g["anchors"]), "intra_idx": T(g["intra_idx"]), "basic_conv.W": T(g["W"])})
+    conv = conv.to(gpu)
+    feats = T(g["feats"]).to(gpu).requires_grad_(True)
+    y = conv(zptk.SphericalPointCloud(torch.zeros(2, 3, 128, device=gpu), feats, None))
+    assert torch.allclose(y.feats.detach().cpu(), T(g["out"]), atol=TOL)
+    dW, dF = torch.autograd.grad(y.feats, [conv.basic_conv.W, feats], T(g["gy"]).to(gpu))
+    assert _rel(dW.cpu(), T(g["dW"])) < TOL
+    assert torch.allclose(dF.cpu(), T(g["dF"]), atol=TOL)
+
+
+def test_functional_compat_golden(gpu, vgtk_alias):
+    """The materialising functional API (inter/intra grouping) against reference outputs."""
+    sptk, zptk = _mods(vgtk_alias)
+    import vgtk.so3conv.functional as L
+    g = golden("interw.npz")
+    w = L.inter_so3conv_grouping_anchor(T(g["grouped_xyz"]).to(gpu), T(g["anchors60"]).to(gpu),
+                                        T(g["kernels"]).to(gpu), float(g["sigma"]))
+    assert torch.allclose(w.cpu(), T(g["w60"]), atol=1e-5)
+    tet = g["tet_index"]                                  # A=12: tetrahedral subgroup
+    w12 = L.inter_so3conv_grouping_anchor(T(g["grouped_xyz"]).to(gpu), T(g["anchors60"][tet]).to(gpu),
+                                          T(g["kernels"]).to(gpu), float(g["sigma"]))
+    assert torch.allclose(w12.cpu(), T(g["w12"]), atol=1e-5)
+    g = golden("inter_group.npz")
+    G = zptk.inter_zpconv_grouping_naive(T(g["idx"]).to(gpu), T(g["w"]).to(gpu),
+                                         zptk.add_shadow_feature(T(g["feats"]).to(gpu)))
+    assert torch.allclose(G.cpu(), T(g["G"]), atol=1e-4)
+    g = golden("intra_group.npz")
+    G = L.intra_so3conv_grouping(T(g["intra_idx"]).to(gpu), T(g["feats"]).to(gpu))
+    assert torch.allclose(G.cpu(), T(g["G"]), atol=1e-6)
+
+
+def _inter_case(gpu, sptk, zptk, b, n, cin, cout, stride, radius, sigma, K, lazy, seed, na=60):
+    rng = np.random.default_rng(seed)
+    torch.manual_seed(seed)
+    xyz = T(unit_ball_cloud(rng, b, n))
+    conv = sptk.InterSO3Conv(cin, cout, 1, stride, radius, sigma, K, lazy_sample=lazy, kanchor=60)
+    feats = torch.randn(b, cin, n, 60)
+    gy = None
+    # oracle (CPU)
+    fo = feats.clone().requires_grad_(True)
+    Wo = conv.basic_conv.W.detach().clone().requires_grad_(True)
+    o_idx, o_w, o_sidx, o_xyz, o_y = R.inter_so3conv(xyz, fo, Wo, conv.anchors, conv.kernels, stride, radius, sigma,
+                                                     K, lazy)
+    gy = torch.randn_like(o_y)
+    o_dW, o_dF = torch.autograd.grad(o_y, [Wo, fo], gy)
+    conv = conv.to(gpu)
+    fg = feats.to(gpu).requires_grad_(True)
+    iidx, iw, sidx, y = conv(zptk.SphericalPointCloud(xyz.to(gpu), fg, None))
+    dW, dF = torch.autograd.grad(y.feats, [conv.basic_conv.W, fg], gy.to(gpu))
+    assert torch.equal(iidx.cpu(), o_idx) and torch.equal(sidx.cpu(), o_sidx)
+    return (y.feats.detach().cpu(), o_y.detach()), (dW.cpu(), o_dW), (dF.cpu(), o_dF)
+
+
+@pytest.mark.parametrize("cin,cout,stride,K,lazy", [(1, 8, 2, 16, False), (3, 5, 1, 7, True), (16, 16, 1, 16, True),
+                                                    (32, 48, 2, 32, True), (64, 64, 1, 16, True), (16, 32, 2, 20, False)])
+def test_inter_vs_oracle(gpu, vgtk_alias, cin, cout, stride, K, lazy):
+    sptk, zptk = _mods(vgtk_alias)
+    (y, oy), (dW, odW), (dF, odF) = _inter_case(gpu, sptk, zptk, 2, 128, cin, cout, stride, 0.4, 0.08, K, lazy, 100 + cin)
+    assert (y - oy).abs().max().item() < TOL * max(1.0, oy.abs().max().item())
+    assert _rel(dW, odW) < TOL
+    assert (dF - odF).abs().max().item() < TOL * max(1.0, odF.abs().max().item())
+
+
+@pytest.mark.parametrize("cin,cout,p", [(8, 8, 40), (5, 3, 17), (16, 16, 64), (32, 64, 33), (64, 64, 128), (128, 128, 16)])
+def test_intra_vs_oracle(gpu, vgtk_alias, cin, cout, p):
+    sptk, zptk = _mods(vgtk_alias)
+    torch.manual_seed(cin * 7 + p)
+    conv = sptk.IntraSO3Conv(cin, cout)
+    feats = torch.randn(2, cin, p, 60)
+    fo = feats.clone().requires_grad_(True)
+    Wo = conv.basic_conv.W.detach().clone().requires_grad_(True)
+    oy = R.intra_so3conv(fo, Wo, conv.intra_idx)
+    gy = torch.randn_like(oy)
+    odW, odF = torch.autograd.grad(oy, [Wo, fo], gy)
+    conv = conv.to(gpu)
+    fg = feats.to(gpu).requires_grad_(True)
+    y = conv(zptk.SphericalPointCloud(torch.zeros(2, 3, p, device=gpu), fg, None))
+    dW, dF = torch.autograd.grad(y.feats, [conv.basic_conv.W, fg], gy.to(gpu))
+    assert (y.feats.detach().cpu() - oy.detach()).abs().max().item() < TOL * max(1.0, oy.abs().max().item())
+    assert _rel(dW.cpu(), odW) < TOL
+    assert (dF.cpu() - odF).abs().max().item() < TOL * max(1.0, odF.abs().max().item())
+
+
+def test_reuse_of_returned_idx_and_weights(gpu, vgtk_alias):
+    """conv(x, inter_idx, inter_w) round-trips with both the lazy handle and a dense tensor."""
+    sptk, zptk = _mods(vgtk_alias)
+    rng = np.random.default_rng(4)
+    torch.manual_seed(4)
+    xyz = T(unit_ball_cloud(rng, 2, 96)).to(gpu)
+    a = sptk.InterSO3Conv(4, 6, 1, 1, 0.4, 0.08, 12).to(gpu)
+    feats = torch.randn(2, 4, 96, 60, device=gpu)
+    x = zptk.SphericalPointCloud(xyz, feats, None)
+    idx, w, sidx, y0 = a(x)
+    assert sidx is not None
+    idx1, w1, sidx1, y1 = a(x, idx, w)
+    assert sidx1 is None and idx1 is idx and torch.allclose(y1.feats, y0.feats, atol=1e-5)
+    _, _, _, y2 = a(x, idx, w.dense())
+    assert torch.allclose(y2.feats, y0.feats, atol=1e-4)
+
+
+def test_equivariance_known_answer(gpu, vgtk_alias):
+    """F(R_g x)[..., a] == F(x)[..., pi_g(a)], pi_g(a) = index(R_g^T R_a), on the HIP path
+    at ModelNet-like sizes, where no CPU oracle is needed."""
+    sptk, zptk = _mods(vgtk_alias)
+    rng = np.random.default_rng(11)
+    torch.manual_seed(11)
+    Rs = T(sptk.get_anchors(60))
+    xyz = T(unit_ball_cloud(rng, 4, 1024))
+    inter = sptk.InterSO3Conv(1, 32, 1, 2, 0.2, 0.02, 32, lazy_sample=False).to(gpu)
+    intra = sptk.IntraSO3Conv(32, 32).to(gpu)
+
+    def run(pts):
+        x = zptk.SphericalPointCloud(pts.to(gpu), torch.ones(4, 1, 1024, 60, device=gpu), None)
+        _, _, sidx, y = inter(x)
+        return sidx, y.feats, intra(y).feats
+
+    s0, y0, z0 = run(xyz)
+    for gidx in (7, 44):
+        Rg = Rs[gidx]
+        s1, y1, z1 = run(torch.einsum('ij,bjn->bin', Rg, xyz).contiguous())
+        perm = [int(((Rs - (Rg.t() @ Rs[a])[None]).abs().amax((1, 2))).argmin()) for a in range(60)]
+        same = (s1 == s0).all(1).cpu()                 # rotation by a float matrix can flip a borderline FPS pick
+        assert same.float().mean() >= 0.5
+        sel = same.nonzero().flatten().to(gpu)
+        assert (y1[sel] - y0[sel][..., perm]).abs().max().item() < 5e-4 * max(1.0, y0.abs().max().item())
+        assert (z1[sel] - z0[sel][..., perm]).abs().max().item() < 5e-4 * max(1.0, z0.abs().max().item())
+
+
+def test_generic_and_fused_kernels_agree(gpu, vgtk_alias):
+    """The any-shape generic HIP kernels and the fused MFMA kernels are independent implementations."""
+    sptk, zptk = _mods(vgtk_alias)
+    rng = np.random.default_rng(21)
+    torch.manual_seed(21)
+    xyz = T(unit_ball_cloud(rng, 2, 256)).to(gpu)
+    conv = sptk.InterSO3Conv(32, 32, 1, 1, 0.4, 0.08, 16).to(gpu)
+    intra = sptk.IntraSO3Conv(32, 32).to(gpu)
+    feats = torch.randn(2, 32, 256, 60, device=gpu, requires_grad=True)
+
+    def run():
+        _, _, _, y = conv(zptk.SphericalPointCloud(xyz, feats, None))
+        z = intra(y)
+        g = torch.autograd.grad((z.feats * torch.linspace(-1, 1, 60, device=gpu)).sum(),
+                                [feats, conv.basic_conv.W, intra.basic_conv.W])
+        return [y.feats.detach(), z.feats.detach()] + [t.detach() for t in g]
+
+    fused = run()
+    os.environ["EPN_FORCE_GENERIC"] = "1"
+    try:
+        generic = run()
+    finally:
+        del os.environ["EPN_FORCE_GENERIC"]
+    for a, b in zip(fused, generic):
+        assert (a - b).abs().max().item() < TOL * max(1.0, b.abs().max().item())

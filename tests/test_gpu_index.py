@@ -1,0 +1,122 @@
+"""-m gpu: FPS / ball query / gather HIP kernels through the C ABI vs the C oracle and the golden fixtures.
+Bar: bit-exact (int32 indices; gathered floats are copies)."""
+import numpy as np
+import pytest
+import torch
+
+from conftest import golden, unit_ball_cloud
+from oracle import index_ref
+
+pytestmark = pytest.mark.gpu
+T = torch.from_numpy
+
+
+@pytest.fixture(scope="module")
+def ext(gpu, vgtk_alias):
+    import vgtk.cuda.grouping as cuda_nn
+    import vgtk.cuda.gathering as gather
+    return cuda_nn, gather, gpu
+
+
+def test_fps_golden(ext):
+    cuda_nn, _, dev = ext
+    g = golden("fps.npz")
+    for tag in ("n256", "n1024", "n2048", "n300"):
+        x, m = T(g[f"{tag}_xyz"]), int(g[f"{tag}_m"])
+        idx = cuda_nn.furthest_point_sampling(x.to(dev), m)
+        assert idx.dtype == torch.int32 and idx.is_cuda
+        assert np.array_equal(idx.cpu().numpy(), g[f"{tag}_idx"]), tag
+
+
+@pytest.mark.parametrize("b,n,m", [(1, 1, 1), (2, 3, 2), (3, 63, 17), (2, 64, 64), (2, 100, 33), (4, 513, 200),
+                                   (2, 4096, 300), (1, 5000, 64), (1, 20000, 40)])
+def test_fps_vs_oracle_shapes(ext, b, n, m):
+    cuda_nn, _, dev = ext
+    rng = np.random.default_rng(n * 131 + m)
+    x = T(unit_ball_cloud(rng, b, n)) if n > 3 else T(rng.standard_normal((b, 3, n)).astype(np.float32))
+    got = cuda_nn.furthest_point_sampling(x.to(dev), m).cpu()
+    assert torch.equal(got, index_ref.furthest_point_sampling(x, m))
+
+
+def test_fps_ties_and_degenerate(ext):
+    cuda_nn, _, dev = ext
+    rng = np.random.default_rng(1)
+    # lattice points: massive distance ties exercise the reference's reduction-tree tie-break order
+    grid = np.stack(np.meshgrid(*[np.arange(8)] * 3, indexing="ij"), 0).reshape(3, -1).astype(np.float32) * 0.25 - 0.8
+    x = T(np.stack([grid, grid[:, rng.permutation(512)]], 0))
+    assert torch.equal(cuda_nn.furthest_point_sampling(x.to(dev), 256).cpu(), index_ref.furthest_point_sampling(x, 256))
+    # all points inside the |p|^2 <= 1e-3 dead zone -> every round returns 0
+    z = T((rng.standard_normal((1, 3, 128)) * 1e-3).astype(np.float32))
+    got = cuda_nn.furthest_point_sampling(z.to(dev), 16).cpu()
+    assert torch.equal(got, index_ref.furthest_point_sampling(z, 16)) and (got == 0).all()
+    # duplicated cloud
+    d = T(unit_ball_cloud(rng, 1, 256)).repeat(1, 1, 2)
+    assert torch.equal(cuda_nn.furthest_point_sampling(d.to(dev), 300).cpu(), index_ref.furthest_point_sampling(d, 300))
+
+
+def test_ball_query_golden(ext):
+    cuda_nn, _, dev = ext
+    g = golden("ballq.npz")
+    for tag in ("k16", "k32", "k128", "sparse", "ragged"):
+        x, q, r, k = T(g[f"{tag}_xyz"]), T(g[f"{tag}_query"]), float(g[f"{tag}_r"]), int(g[f"{tag}_k"])
+        idx = cuda_nn.ball_query(q.to(dev), x.to(dev), r, k)
+        assert idx.dtype == torch.int32 and tuple(idx.shape) == (x.shape[0], q.shape[2], k)
+        assert np.array_equal(idx.cpu().numpy(), g[f"{tag}_idx"]), tag
+
+
+@pytest.mark.parametrize("b,n,m,r,k", [(1, 1, 1, 0.5, 1), (2, 65, 9, 0.3, 5), (2, 500, 250, 0.15, 64),
+                                       (3, 1024, 1024, 0.2828, 16), (1, 2048, 512, 0.08, 128),
+                                       (2, 129, 129, 10.0, 130)])
+def test_ball_query_vs_oracle(ext, b, n, m, r, k):
+    cuda_nn, _, dev = ext
+    rng = np.random.default_rng(n + 7 * m + k)
+    x = T(unit_ball_cloud(rng, b, n)) if n > 3 else T(rng.standard_normal((b, 3, n)).astype(np.float32))
+    q = x[:, :, rng.permutation(n)[:m]].contiguous()
+    got = cuda_nn.ball_query(q.to(dev), x.to(dev), r, k).cpu()
+    assert torch.equal(got, index_ref.ball_query(q, x, r, k))
+
+
+def test_ball_query_full_size_properties(ext):
+    """BASELINE configs[1] first layer (B=32, N=1024 -> 512 queries, r=0.2, K=32): size-independent
+    properties + oracle on a slice."""
+    cuda_nn, _, dev = ext
+    rng = np.random.default_rng(2913)
+    x = T(unit_ball_cloud(rng, 32, 1024))
+    xd = x.to(dev)
+    sidx = cuda_nn.furthest_point_sampling(xd, 512)
+    q = torch.gather(xd, 2, sidx.long()[:, None].expand(-1, 3, -1)).contiguous()
+    idx = cuda_nn.ball_query(q, xd, 0.2, 32)
+    assert int(idx.min()) >= 0 and int(idx.max()) < 1024
+    nb = torch.gather(xd[:, :, None].expand(-1, -1, 512, -1), 3, idx.long()[:, None].expand(-1, 3, -1, -1))
+    d2 = ((nb - q[..., None]) ** 2).sum(1)
+    # every listed neighbour is inside the ball, except the zero-filled slots of the K-1 / empty quirk
+    assert bool(((d2 < 0.2 ** 2 + 1e-6) | (idx == 0)).all())
+    assert bool((idx[:, :, 0] == torch.minimum(idx[:, :, 0], sidx)).all())  # first hit is the lowest index; the query itself is a hit
+    assert torch.equal(idx[:2].cpu(), index_ref.ball_query(q[:2].cpu(), x[:2], 0.2, 32))
+    assert torch.equal(sidx[:2].cpu(), index_ref.furthest_point_sampling(x[:2], 512))
+
+
+def test_gather_fwd_bwd(ext):
+    _, gather, dev = ext
+    rng = np.random.default_rng(3)
+    for (b, c, n, m) in [(1, 1, 1, 1), (2, 3, 1025, 512 * 32), (3, 7, 300, 1000)]:
+        pts = T(rng.standard_normal((b, c, n)).astype(np.float32))
+        idx = T(rng.integers(0, n, (b, m)).astype(np.int32))
+        out = gather.gather_points_forward(pts.to(dev), idx.to(dev))
+        assert out.dtype == torch.float32 and torch.equal(out.cpu(), index_ref.gather_points_forward(pts, idx))
+        go = T(rng.standard_normal((b, c, m)).astype(np.float32))
+        back = gather.gather_points_backward(go.to(dev), idx.to(dev), n)
+        assert torch.allclose(back.cpu(), index_ref.gather_points_backward(go, idx, n), atol=1e-4, rtol=1e-5)
+
+
+def test_group_nd_and_furthest_sample(ext, vgtk_alias):
+    import vgtk.pc as pctk
+    _, _, dev = ext
+    rng = np.random.default_rng(9)
+    x = T(unit_ball_cloud(rng, 2, 256)).to(dev)
+    idx, sx = pctk.furthest_sample(x, 128, False)
+    assert torch.equal(sx, torch.gather(x, 2, idx.long()[:, None].expand(-1, 3, -1)))
+    bi = pctk.ball_query_index(sx, x, 0.4, 16)
+    grouped = pctk.group_nd(x, bi)
+    assert tuple(grouped.shape) == (2, 3, 128, 16)
+    assert torch.equal(grouped[1, :, 5, 3], x[1, :, bi[1, 5, 3].long()])
