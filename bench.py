@@ -1,0 +1,163 @@
+#!/usr/bin/env python3
+"""bench.py -- point-clouds/sec, forward + backward, of the EPN hot path on MI355X.
+
+    python bench.py --gpus N --steps K --warmup W
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 ... bench.py --gpus N ...
+
+Workload (BASELINE.json configs[1]): ModelNet40 classification backbone, B=32 clouds per GPU, N=1024 points,
+K=32/16 neighbours, A=60 anchors, fp32 -- the 7 separable blocks of cls_so3net_pn (FPS -> ball query ->
+gather -> InterSO3Conv -> IntraSO3Conv + the block's norm/activation/skip glue), random-init weights,
+synthetic unit-ball clouds already resident in HBM.  One step = forward + backward (+ gradient all-reduce
+over RCCL when N > 1) + Adam update.  Weak scaling: per-GPU batch fixed.  Prints ONE JSON line (rank 0).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+MFMA_F32_PEAK_TFLOPS = 157.3   # /opt/skills/guides/MI355X_MICROARCH.md, "Peak FP32 (matrix)"
+
+KERNEL_OF = {  # C-ABI call -> dominant device kernel symbol launched by it (csrc/*.hip)
+    "inter_fwd": "epn::inter_fwd_kernel", "inter_bwd_data": "epn::inter_bwd_data_kernel",
+    "inter_bwd_weight": "epn::inter_bwd_weight_kernel", "intra_fwd": "epn::intra_gemm_kernel",
+    "intra_bwd_data": "epn::intra_gemm_kernel", "intra_bwd_weight": "epn::intra_bwd_weight_kernel",
+}
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--batch", type=int, default=32, help="clouds per GPU")
+    ap.add_argument("--points", type=int, default=1024)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-clouds", type=int, default=2, help="sample size of the CPU baseline")
+    ap.add_argument("--cpu-threads", type=int, default=16,
+                    help="torch CPU threads of the baseline (16 measured fastest of {16,48,256} on the 2x EPYC 9575F "
+                         "GPU host: the materialising reference algorithm is memory-bound and slows down with more)")
+    ap.add_argument("--forward-only", action="store_true")
+    return ap.parse_args()
+
+
+def cpu_baseline(layers, product_sd, n_points, n_clouds, threads=16):
+    """The oracle's materialising restatement of the same backbone (kind "port"), fwd+bwd, on the host cores."""
+    from epn_pointcloud_amd import schedule as S
+    from epn_pointcloud_amd.vgtk.so3conv import functional as L
+    from epn_pointcloud_amd.vgtk import functional as fr
+    from oracle import backbone_ref
+    cores = max(1, min(threads, os.cpu_count() or 1))
+    torch.set_num_threads(cores)
+    ref = backbone_ref.RefBackbone(layers, torch.from_numpy(L.get_anchors(60)),
+                                   torch.from_numpy(fr.kernel_points_raw(24)),
+                                   torch.from_numpy(L.get_intra_idx()).long())
+    ref.load_from_product(product_sd)
+    ref.train()
+    pts = S.synthetic_clouds(n_clouds, n_points, "cpu", seed=2913)
+    t0 = time.perf_counter()
+    _, feats = ref(pts)
+    feats.square().mean().backward()
+    dt = time.perf_counter() - t0
+    return {"value": n_clouds / dt, "unit": "point-clouds/s", "cores": cores, "kind": "port",
+            "host_cpus": os.cpu_count(),
+            "sample": f"{n_clouds} clouds N={n_points} A=60, fwd+bwd once, oracle/backbone_ref.py (torch CPU "
+                      f"{torch.get_num_threads()} threads + C index kernels), {dt:.1f} s"}
+
+
+def main():
+    args = parse()
+    from epn_pointcloud_amd import _lib, dp, ops, schedule as S
+    _lib.get_lib()                                     # fail loudly if the HIP library is missing
+    rank, local_rank, world = dp.init_from_env()
+    assert world == args.gpus or world == 1 and args.gpus == 1, (world, args.gpus)
+    assert torch.cuda.is_available(), "bench.py needs an MI355X"
+    dev = torch.device("cuda", local_rank)
+    torch.cuda.set_device(dev)
+
+    layers = S.cls_so3net_schedule(args.points)
+    torch.manual_seed(2913)
+    model = S.HotPathBackbone(layers).to(dev).train()
+    dp.broadcast_parameters(model)
+    params = [p for p in model.parameters() if p.requires_grad]
+    opt = torch.optim.Adam(params, lr=1e-3)
+    pts = S.synthetic_clouds(args.batch, args.points, dev, seed=2913 + rank)   # resident in HBM before timing
+
+    def step():
+        opt.zero_grad(set_to_none=True)
+        if args.forward_only:
+            with torch.no_grad():
+                return model(pts).feats
+        x = model(pts)
+        loss = x.feats.square().mean()
+        loss.backward()
+        dp.allreduce_gradients(params, world)
+        opt.step()
+        return loss
+
+    def fence():
+        if world > 1:
+            torch.distributed.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    fence()
+    ops.profile_begin()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        last = step()
+    fence()
+    dt = time.perf_counter() - t0
+    records = ops.profile_end()
+    if world > 1:
+        t = torch.tensor([dt], dtype=torch.float64, device=dev)
+        torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
+        dt = float(t.item())
+    assert torch.isfinite(last.float()).all(), "non-finite output in the timed region"
+
+    if rank == 0:
+        # ---- roofline of the dominant kernel, from HIP events recorded around its launches in the timed region
+        agg = {}
+        for kind, key, flops, e0, e1 in records:
+            k = KERNEL_OF[kind]
+            a = agg.setdefault(k, {"ms": 0.0, "flops": 0.0, "launches": 0})
+            a["ms"] += e0.elapsed_time(e1)
+            a["flops"] += flops
+            a["launches"] += 1
+        dom = max(agg, key=lambda k: agg[k]["ms"])
+        d = agg[dom]
+        achieved = d["flops"] / (d["ms"] * 1e-3) / 1e12
+        roofline = {"bound": "mfma", "kernel": dom, "achieved": round(achieved, 2), "peak": MFMA_F32_PEAK_TFLOPS,
+                    "unit": "TFLOP/s", "frac": round(achieved / MFMA_F32_PEAK_TFLOPS, 4), "traffic": None,
+                    "launches": d["launches"], "avg_launch_ms": round(d["ms"] / d["launches"], 4),
+                    "per_kernel_ms_per_step": {k: round(v["ms"] / args.steps, 3) for k, v in sorted(agg.items())}}
+        out = {
+            "metric": "point-clouds/sec fwd+bwd, ModelNet40 N=1024 A=60" if not args.forward_only
+                      else "point-clouds/sec fwd, ModelNet40 N=1024 A=60",
+            "value": round(args.batch * world * args.steps / dt, 3), "unit": "point-clouds/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(dt / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": "ModelNet40 cls backbone (cls_so3net_pn, 7 separable SO3 blocks), "
+                                   f"B={args.batch}/GPU N={args.points} K=32/16 A=60 fp32, fwd+bwd+Adam",
+                       "global_batch": args.batch * world, "points": args.points, "anchors": 60,
+                       "parallelism": f"dp{world}"},
+            "roofline": roofline,
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(layers, model.state_dict(), args.points, args.cpu_clouds,
+                                               args.cpu_threads)
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        torch.distributed.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -17,7 +17,7 @@ EXPORTS = [
     "epn_ball_query_f32", "epn_fps_f32", "epn_gather_fwd_f32", "epn_gather_bwd_f32",
     "epn_inter_workspace_bytes", "epn_inter_so3conv_fwd_f32", "epn_inter_so3conv_bwd_data_f32",
     "epn_inter_so3conv_bwd_weight_f32", "epn_inter_weights_f32",
-    "epn_intra_so3conv_fwd_f32", "epn_intra_so3conv_bwd_data_f32", "epn_intra_so3conv_bwd_weight_f32",
+    "epn_inter_is_fused", "epn_intra_is_fused", "epn_intra_workspace_bytes", "epn_intra_so3conv_fwd_f32", "epn_intra_so3conv_bwd_data_f32", "epn_intra_so3conv_bwd_weight_f32",
 ]
 
 _vp, _ci, _cf, _sz = ctypes.c_void_p, ctypes.c_int, ctypes.c_float, ctypes.c_size_t
@@ -58,8 +58,15 @@ def get_lib():
     lib.epn_inter_so3conv_bwd_data_f32.argtypes = [dp, _vp, _vp, _vp, _vp, _sz, _vp]
     lib.epn_inter_so3conv_bwd_weight_f32.argtypes = [dp, _vp, _vp, _vp, _vp, _sz, _vp]
     lib.epn_inter_weights_f32.argtypes = [dp, _vp, _vp]
-    lib.epn_intra_so3conv_fwd_f32.argtypes = [_vp, _vp, _vp, _ci, _ci, _ci, _ci, _ci, _ci, _vp, _vp]
-    lib.epn_intra_so3conv_bwd_data_f32.argtypes = [_vp, _vp, _vp, _ci, _ci, _ci, _ci, _ci, _ci, _vp, _vp]
+    lib.epn_inter_is_fused.argtypes = [dp]
+    lib.epn_inter_is_fused.restype = _ci
+    lib.epn_intra_is_fused.argtypes = [_ci, _ci, _ci, _ci]
+    lib.epn_intra_is_fused.restype = _ci
+    lib.epn_intra_workspace_bytes.argtypes = [_ci, _ci, _ci, _ci]
+    lib.epn_intra_workspace_bytes.restype = _sz
+    lib.epn_intra_so3conv_fwd_f32.argtypes = [_vp, _vp, _vp, _ci, _ci, _ci, _ci, _ci, _ci, _vp, _vp, _sz, _vp]
+    lib.epn_intra_so3conv_bwd_data_f32.argtypes = [_vp, _vp, _vp, _vp, _ci, _ci, _ci, _ci, _ci, _ci, _vp, _vp, _sz,
+                                                   _vp]
     lib.epn_intra_so3conv_bwd_weight_f32.argtypes = [_vp, _vp, _vp, _ci, _ci, _ci, _ci, _ci, _ci, _vp, _vp]
     for name in EXPORTS:
         getattr(lib, name)  # AttributeError here = header/library mismatch

@@ -38,6 +38,12 @@ extern "C" const char *epn_strerror(int code) {
     }
 }
 
+extern "C" int epn_inter_is_fused(const epn_inter_desc *d) { return d && use_mfma(d) ? 1 : 0; }
+
+extern "C" int epn_intra_is_fused(int na, int kn, int cin, int cout) {
+    return intra_uses_mfma(na, kn, cin, cout) && !force_generic() ? 1 : 0;
+}
+
 extern "C" size_t epn_inter_workspace_bytes(const epn_inter_desc *d) {
     if (!d) return 0;
     InterWs w = inter_ws(d);
@@ -56,7 +62,8 @@ static int prep(const epn_inter_desc *d, void *workspace, size_t bytes, bool nee
     int rc = check_desc(d);
     if (rc) return rc;
     ws = inter_ws(d);
-    const size_t big = need_big ? rnd64((size_t)d->b * d->p2 * d->na * d->cin * d->ks) : 0;
+    const size_t big = need_big ? rnd64((size_t)d->b * d->p2 * d->na * d->cin * d->ks)
+                                : ws.total_floats - ws.big_off;
     if (!workspace || bytes < (ws.big_off + big) * sizeof(float)) return EPN_EWORKSPACE;
     base = static_cast<float *>(workspace);
     if (!d->dense_w) {
@@ -112,7 +119,7 @@ extern "C" int epn_inter_so3conv_bwd_data_f32(const epn_inter_desc *d, const flo
     if (mf) {
         rc = launch_inter_tables_mfma(d, base + ws.rk_off, base + ws.rk4_off, base + ws.beta_off, st);
         if (rc) return rc;
-        return launch_inter_bwd_data_mfma(d, base + ws.rk4_off, base + ws.beta_off, grad_out_cl, W, grad_feats_cl, st);
+        return launch_inter_bwd_data_mfma(d, base + ws.rk4_off, base + ws.big_off, grad_out_cl, W, grad_feats_cl, st);
     }
     float *dG = base + ws.big_off;
     rc = launch_rowgemm_nn(grad_out_cl, W, (size_t)d->b * d->p2 * d->na, d->cin * d->ks, d->cout, dG, st);
@@ -150,29 +157,44 @@ static int check_intra(int b, int p, int na, int kn, int cin, int cout) {
     return 0;
 }
 
+extern "C" size_t epn_intra_workspace_bytes(int na, int kn, int cin, int cout) {
+    (void)na;
+    if (kn < 1 || cin < 1 || cout < 1) return 0;
+    return intra_workspace_floats(kn, cin, cout) * sizeof(float);
+}
+
 extern "C" int epn_intra_so3conv_fwd_f32(const float *feats_cl, const int32_t *intra_idx, const float *W, int b,
                                          int p, int na, int kn, int cin, int cout, float *out_cl,
-                                         epn_stream_t stream) {
+                                         void *workspace, size_t workspace_bytes, epn_stream_t stream) {
     int rc = check_intra(b, p, na, kn, cin, cout);
     if (rc) return rc;
     if (b == 0 || p == 0) return 0;
     if (!feats_cl || !intra_idx || !W || !out_cl) return EPN_ENULL;
     hipStream_t st = epn_stream(stream);
-    if (intra_uses_mfma(na, kn, cin, cout) && !force_generic())
-        return launch_intra_fwd_mfma(feats_cl, intra_idx, W, b, p, na, kn, cin, cout, out_cl, st);
+    if (intra_uses_mfma(na, kn, cin, cout) && !force_generic()) {
+        if (!workspace || workspace_bytes < intra_workspace_floats(kn, cin, cout) * sizeof(float))
+            return EPN_EWORKSPACE;
+        return launch_intra_fwd_mfma(feats_cl, intra_idx, W, b, p, na, kn, cin, cout, out_cl,
+                                     static_cast<float *>(workspace), st);
+    }
     return launch_intra_fwd_generic(feats_cl, intra_idx, W, (size_t)b * p, na, kn, cin, cout, out_cl, st);
 }
 
-extern "C" int epn_intra_so3conv_bwd_data_f32(const float *grad_out_cl, const int32_t *intra_idx, const float *W,
-                                              int b, int p, int na, int kn, int cin, int cout,
-                                              float *grad_feats_cl, epn_stream_t stream) {
+extern "C" int epn_intra_so3conv_bwd_data_f32(const float *grad_out_cl, const int32_t *intra_idx,
+                                              const int32_t *inv_idx, const float *W, int b, int p, int na, int kn,
+                                              int cin, int cout, float *grad_feats_cl, void *workspace,
+                                              size_t workspace_bytes, epn_stream_t stream) {
     int rc = check_intra(b, p, na, kn, cin, cout);
     if (rc) return rc;
     if (b == 0 || p == 0) return 0;
     if (!grad_out_cl || !intra_idx || !W || !grad_feats_cl) return EPN_ENULL;
     hipStream_t st = epn_stream(stream);
-    if (intra_uses_mfma(na, kn, cin, cout) && !force_generic())
-        return launch_intra_bwd_data_mfma(grad_out_cl, intra_idx, W, b, p, na, kn, cin, cout, grad_feats_cl, st);
+    if (inv_idx && intra_uses_mfma(na, kn, cin, cout) && !force_generic()) {
+        if (!workspace || workspace_bytes < intra_workspace_floats(kn, cin, cout) * sizeof(float))
+            return EPN_EWORKSPACE;
+        return launch_intra_bwd_data_mfma(grad_out_cl, inv_idx, W, b, p, na, kn, cin, cout, grad_feats_cl,
+                                          static_cast<float *>(workspace), st);
+    }
     EPN_HIP(hipMemsetAsync(grad_feats_cl, 0, sizeof(float) * (size_t)b * p * na * cin, st));
     return launch_intra_bwd_data_generic(grad_out_cl, intra_idx, W, (size_t)b * p, na, kn, cin, cout, grad_feats_cl,
                                          st);

@@ -13,8 +13,8 @@ struct InterWs {
 };
 static inline size_t rnd64(size_t x) { return (x + 63) & ~(size_t)63; }
 static inline bool inter_mfma_shape_ok(const epn_inter_desc *d) {
-    return d->cin % 16 == 0 && d->cout % 16 == 0 && d->ks <= EPN_KS_MAX && d->nn <= EPN_NN_MAX && d->cin >= 16 &&
-           d->cout >= 16;
+    return d->cin % 16 == 0 && d->cout % 16 == 0 && d->cout <= 256 && d->ks <= EPN_KS_MAX && d->ks % 4 == 0 &&
+           d->nn <= EPN_NN_MAX && d->cin >= 16 && d->cout >= 16;
 }
 bool inter_mfma_available();  // false while only the stand-in TU is linked
 static inline bool inter_uses_mfma(const epn_inter_desc *d) { return inter_mfma_available() && inter_mfma_shape_ok(d); }
@@ -24,7 +24,9 @@ static inline InterWs inter_ws(const epn_inter_desc *d) {
     w.rk4_off = rnd64((size_t)d->na * d->ks * 3);
     w.beta_off = w.rk4_off + rnd64((size_t)d->na * EPN_KS_MAX * 4);
     w.big_off = w.beta_off + rnd64((size_t)d->na * EPN_KS_MAX);
-    const size_t big = inter_uses_mfma(d) ? 0 : (size_t)d->b * d->p2 * d->na * d->cin * d->ks;
+    // generic path: materialised grouped features; MFMA path: transposed weight for bwd_data
+    const size_t big = inter_uses_mfma(d) ? (size_t)d->cout * d->cin * d->ks
+                                          : (size_t)d->b * d->p2 * d->na * d->cin * d->ks;
     w.total_floats = w.big_off + rnd64(big);
     return w;
 }
@@ -48,15 +50,16 @@ int launch_intra_bwd_weight_generic(const float *feats, const float *dOut, const
 int launch_inter_tables_mfma(const epn_inter_desc *d, const float *rk, float *rk4, float *beta, hipStream_t st);
 int launch_inter_fwd_mfma(const epn_inter_desc *d, const float *rk4, const float *beta, const float *feats,
                           const float *W, float *out, hipStream_t st);
-int launch_inter_bwd_data_mfma(const epn_inter_desc *d, const float *rk4, const float *beta, const float *dOut,
+int launch_inter_bwd_data_mfma(const epn_inter_desc *d, const float *rk4, const float *wt_scratch, const float *dOut,
                                const float *W, float *dF, hipStream_t st);
 int launch_inter_bwd_weight_mfma(const epn_inter_desc *d, const float *rk4, const float *beta, const float *feats,
                                  const float *dOut, float *dW, hipStream_t st);
 bool intra_uses_mfma(int na, int kn, int cin, int cout);
+size_t intra_workspace_floats(int kn, int cin, int cout);
 int launch_intra_fwd_mfma(const float *feats, const int32_t *iidx, const float *W, int b, int p, int na, int kn,
-                          int cin, int cout, float *out, hipStream_t st);
-int launch_intra_bwd_data_mfma(const float *dOut, const int32_t *iidx, const float *W, int b, int p, int na, int kn,
-                               int cin, int cout, float *dF, hipStream_t st);
+                          int cin, int cout, float *out, float *ws, hipStream_t st);
+int launch_intra_bwd_data_mfma(const float *dOut, const int32_t *inv_idx, const float *W, int b, int p, int na,
+                               int kn, int cin, int cout, float *dF, float *ws, hipStream_t st);
 int launch_intra_bwd_weight_mfma(const float *feats, const float *dOut, const int32_t *iidx, int b, int p, int na,
                                  int kn, int cin, int cout, float *dW, hipStream_t st);
 

@@ -1,0 +1,223 @@
+// Fused IntraSO3Conv kernels for gfx950 (f32 MFMA 16x16x4).
+//
+// out[col][o] = sum_k sum_c W[o][c*kn + k] X[pt*na + idx[a][k]][c],   col = pt*na + a
+// (intra_so3conv_grouping + BasicSO3Conv, vgtk/vgtk/so3conv/functional.py:221-233, modules.py:48-55).
+// The reference materialises X gathered 12x ([b,c,12,p,a], 3 GB per layer at B=32) before the matmul;
+// here the anchor permutation is applied on the fly to the B-operand ADDRESS: a wave owns 16 output
+// columns, for each anchor neighbour k every lane points at its own source row and the contraction
+// over c runs as 16x16x4 MFMAs with W (re-packed k-major) staged through LDS for the 4 waves.
+// The data gradient is the same kernel with (X, idx, W) := (dOut, idx^-1, W^T re-packed): each column
+// of intra_idx is a permutation of the anchors, so the transpose is a gather, not a scatter.
+#include "conv_internal.h"
+
+namespace epn {
+namespace {
+
+constexpr int NW = 4;
+
+struct IntraArgs {
+    const float *X;        // [ncol][ci]
+    const int32_t *idx;    // [na][kn]
+    const float *Wp;       // [co][kn*ci]  (k-major)
+    const float *gout;     // bwd_weight: dOut [ncol][co]
+    float *out;            // [ncol][co]   (bwd_weight: dW [co][ci*kn])
+    int na, kn, ci, co, wk;
+    long long ncol;
+    int col_tiles_per_wg;
+};
+
+__device__ __forceinline__ f32x4 mfma4(float a, float b, f32x4 c) {
+    return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0);
+}
+
+__global__ __launch_bounds__(64 * NW) void intra_gemm_kernel(IntraArgs A) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float *Ws = smem;
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int x = lane & 15, j = lane >> 4;
+    const int wss = A.wk + 4;
+    const int MT = A.co >> 4;
+    const int CK = A.kn * A.ci;
+    const long long col0 = ((long long)blockIdx.x * NW + wave) * 16;
+    long long colx = col0 + x;
+    colx = colx < A.ncol ? colx : A.ncol - 1;
+    const int ax = (int)(colx % A.na);
+    const long long ptrow = colx - ax;  // pt*na
+    const int32_t *irow = A.idx + ax * A.kn;
+
+    f32x4 acc[16];
+#pragma unroll
+    for (int m = 0; m < 16; ++m) acc[m] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    for (int sub = 0; sub < CK / A.wk; ++sub) {
+        __syncthreads();
+        {
+            const int vec_per_row = A.wk >> 2;
+            const float *src = A.Wp + (size_t)sub * A.wk;
+            for (int i = threadIdx.x; i < A.co * vec_per_row; i += blockDim.x) {
+                const int o = i / vec_per_row, v = i - o * vec_per_row;
+                *reinterpret_cast<f32x4 *>(Ws + o * wss + 4 * v) =
+                    *reinterpret_cast<const f32x4 *>(src + (size_t)o * CK + 4 * v);
+            }
+        }
+        __syncthreads();
+        for (int g = 0; g < (A.wk >> 4); ++g) {
+            const int ck = sub * A.wk + 16 * g;  // k-major: ck = k*ci + c
+            const int k = ck / A.ci, c0 = ck - k * A.ci;
+            const f32x4 bf = *reinterpret_cast<const f32x4 *>(A.X + (size_t)(ptrow + irow[k]) * A.ci + c0 + 4 * j);
+#pragma unroll
+            for (int m = 0; m < 16; ++m) {
+                if (m < MT) {
+                    const f32x4 af = *reinterpret_cast<const f32x4 *>(Ws + (16 * m + x) * wss + 16 * g + 4 * j);
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) acc[m] = mfma4(af[r], bf[r], acc[m]);
+                }
+            }
+        }
+    }
+    if (col0 + x < A.ncol) {
+#pragma unroll
+        for (int m = 0; m < 16; ++m)
+            if (m < MT) *reinterpret_cast<f32x4 *>(A.out + (col0 + x) * A.co + 16 * m + 4 * j) = acc[m];
+    }
+}
+
+// dW[o][c*kn + k] = sum_col dOut[col][o] X[pt*na + idx[a][k]][c].  Wave = one k, one (<=64 x <=64) block of
+// (o, c); the 4 waves of a workgroup take 4 consecutive k over the SAME columns (shared dOut lines in L1).
+__global__ __launch_bounds__(64 * NW) void intra_bwd_weight_kernel(IntraArgs A) {
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int x = lane & 15, j = lane >> 4;
+    const int k = blockIdx.y * NW + wave;
+    const int cblocks = (A.ci + 63) / 64;
+    const int o0 = (blockIdx.z / cblocks) * 64, c0 = (blockIdx.z % cblocks) * 64;
+    const int MO = (A.co - o0 < 64 ? A.co - o0 : 64) >> 4;
+    const int NC = (A.ci - c0 < 64 ? A.ci - c0 : 64) >> 4;
+    if (k >= A.kn) return;  // no barriers in this kernel
+
+    f32x4 acc[4][4];
+#pragma unroll
+    for (int m = 0; m < 4; ++m)
+#pragma unroll
+        for (int n = 0; n < 4; ++n) acc[m][n] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    const long long t0 = (long long)blockIdx.x * A.col_tiles_per_wg;
+    for (int it = 0; it < A.col_tiles_per_wg; ++it) {
+        const long long c_base = (t0 + it) * 16;
+        if (c_base >= A.ncol) break;
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+            const long long col = c_base + 4 * s + j;
+            const bool ok = col < A.ncol;
+            const long long cc = ok ? col : A.ncol - 1;
+            const int a = (int)(cc % A.na);
+            const long long src = cc - a + A.idx[a * A.kn + k];
+            float af[4], bf[4];
+#pragma unroll
+            for (int m = 0; m < 4; ++m) af[m] = (m < MO && ok) ? A.gout[cc * A.co + o0 + 16 * m + x] : 0.0f;
+#pragma unroll
+            for (int n = 0; n < 4; ++n) bf[n] = (n < NC && ok) ? A.X[src * A.ci + c0 + 16 * n + x] : 0.0f;
+#pragma unroll
+            for (int m = 0; m < 4; ++m)
+#pragma unroll
+                for (int n = 0; n < 4; ++n)
+                    if (m < MO && n < NC) acc[m][n] = mfma4(af[m], bf[n], acc[m][n]);
+        }
+    }
+    // acc[m][n]: lane (x = c within tile, j), register r -> o = o0 + 16m + 4j + r
+#pragma unroll
+    for (int m = 0; m < 4; ++m)
+#pragma unroll
+        for (int n = 0; n < 4; ++n)
+            if (m < MO && n < NC)
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+                    atomicAdd(A.out + ((size_t)(o0 + 16 * m + 4 * j + r) * A.ci + c0 + 16 * n + x) * A.kn + k,
+                              acc[m][n][r]);
+}
+
+// Wp[o][k*ci + c] = W[o][c*kn + k]                     (forward pack)
+// Wq[c][k*co + o] = W[o][c*kn + k]                     (data-gradient pack: roles of o and c swapped)
+__global__ void pack_w_kernel(const float *__restrict__ W, int co, int ci, int kn, int transpose,
+                              float *__restrict__ dst) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (size_t)co * ci * kn) return;
+    if (!transpose) {
+        const int c = i % ci;
+        const int k = (i / ci) % kn;
+        const int o = i / ((size_t)ci * kn);
+        dst[i] = W[((size_t)o * ci + c) * kn + k];
+    } else {
+        const int o = i % co;
+        const int k = (i / co) % kn;
+        const int c = i / ((size_t)co * kn);
+        dst[i] = W[((size_t)o * ci + c) * kn + k];
+    }
+}
+
+int pick_wk(int ck, int co) {
+    int wk = 16;
+    for (int cand = 16; cand <= ck; cand += 16)
+        if (ck % cand == 0 && (size_t)co * (cand + 4) * sizeof(float) <= 32 * 1024) wk = cand;
+    return wk;
+}
+
+int run_gemm(const float *X, const int32_t *idx, const float *Wp, long long ncol, int na, int kn, int ci, int co,
+             float *out, hipStream_t st) {
+    IntraArgs A;
+    A.X = X; A.idx = idx; A.Wp = Wp; A.gout = nullptr; A.out = out;
+    A.na = na; A.kn = kn; A.ci = ci; A.co = co; A.ncol = ncol; A.col_tiles_per_wg = 1;
+    A.wk = pick_wk(kn * ci, co);
+    const size_t lds = (size_t)co * (A.wk + 4) * sizeof(float);
+    const unsigned grid = (unsigned)((ncol + 16 * NW - 1) / (16 * NW));
+    hipLaunchKernelGGL(intra_gemm_kernel, dim3(grid), dim3(64 * NW), lds, st, A);
+    EPN_CHECK_LAUNCH();
+    return 0;
+}
+
+}  // namespace
+
+bool intra_uses_mfma(int na, int kn, int cin, int cout) {
+    (void)na; (void)kn;
+    return cin % 16 == 0 && cout % 16 == 0 && cin >= 16 && cout >= 16 && cin <= 256 && cout <= 256;
+}
+
+size_t intra_workspace_floats(int kn, int cin, int cout) { return rnd64((size_t)cout * cin * kn); }
+
+int launch_intra_fwd_mfma(const float *feats, const int32_t *iidx, const float *W, int b, int p, int na, int kn,
+                          int cin, int cout, float *out, float *ws, hipStream_t st) {
+    const size_t n = (size_t)cout * cin * kn;
+    hipLaunchKernelGGL(pack_w_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, W, cout, cin, kn, 0, ws);
+    EPN_CHECK_LAUNCH();
+    return run_gemm(feats, iidx, ws, (long long)b * p * na, na, kn, cin, cout, out, st);
+}
+
+int launch_intra_bwd_data_mfma(const float *dOut, const int32_t *inv_idx, const float *W, int b, int p, int na,
+                               int kn, int cin, int cout, float *dF, float *ws, hipStream_t st) {
+    const size_t n = (size_t)cout * cin * kn;
+    hipLaunchKernelGGL(pack_w_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, W, cout, cin, kn, 1, ws);
+    EPN_CHECK_LAUNCH();
+    return run_gemm(dOut, inv_idx, ws, (long long)b * p * na, na, kn, cout, cin, dF, st);
+}
+
+int launch_intra_bwd_weight_mfma(const float *feats, const float *dOut, const int32_t *iidx, int b, int p, int na,
+                                 int kn, int cin, int cout, float *dW, hipStream_t st) {
+    IntraArgs A;
+    A.X = feats; A.idx = iidx; A.Wp = nullptr; A.gout = dOut; A.out = dW;
+    A.na = na; A.kn = kn; A.ci = cin; A.co = cout; A.wk = 0;
+    A.ncol = (long long)b * p * na;
+    const long long tiles = (A.ncol + 15) / 16;
+    const int kblocks = (kn + NW - 1) / NW;
+    const int tblocks = ((cout + 63) / 64) * ((cin + 63) / 64);
+    long long splits = (256 * 4 + kblocks * tblocks - 1) / (kblocks * tblocks);
+    if (splits > tiles) splits = tiles;
+    if (splits < 1) splits = 1;
+    A.col_tiles_per_wg = (int)((tiles + splits - 1) / splits);
+    const unsigned gx = (unsigned)((tiles + A.col_tiles_per_wg - 1) / A.col_tiles_per_wg);
+    hipLaunchKernelGGL(intra_bwd_weight_kernel, dim3(gx, kblocks, tblocks), dim3(64 * NW), 0, st, A);
+    EPN_CHECK_LAUNCH();
+    return 0;
+}
+
+}  // namespace epn

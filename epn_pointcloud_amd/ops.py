@@ -11,6 +11,44 @@ import torch
 from . import _lib
 
 
+# ---- optional per-launch timing (bench.py's roofline leg): HIP events on the launch stream ------------
+_PROFILE = None
+
+
+def profile_begin():
+    global _PROFILE
+    _PROFILE = []
+
+
+def profile_end():
+    """-> list of (kind, shape_key, algorithmic_flops, start_event, end_event)"""
+    global _PROFILE
+    rec, _PROFILE = _PROFILE, None
+    return rec
+
+
+def _launch(kind, key, flops, device, fn):
+    if _PROFILE is None:
+        return fn()
+    e0 = torch.cuda.Event(enable_timing=True)
+    e1 = torch.cuda.Event(enable_timing=True)
+    st = torch.cuda.current_stream(device)   # the stream the C ABI launches on (stream_of)
+    e0.record(st)
+    rc = fn()
+    e1.record(st)
+    _PROFILE.append((kind, key, flops, e0, e1))
+    return rc
+
+
+def _inter_flops(d):
+    cols = float(d.b) * d.p2 * d.na
+    return 9.0 * cols * d.ks * d.nn + 2.0 * cols * d.cin * d.ks * d.nn + 2.0 * cols * d.cout * d.cin * d.ks
+
+
+def _inter_key(d):
+    return (d.b, d.p1, d.p2, d.nn, d.na, d.ks, d.cin, d.cout)
+
+
 def to_cl(t, name="feats"):
     """Logical [b,c,p,a] float32 device tensor -> channels-last contiguous (no copy if already so)."""
     if not t.is_cuda:
@@ -116,8 +154,10 @@ class InterSO3ConvFn(torch.autograd.Function):
                              f"b={d.b} p1={d.p1} na={d.na} ks={d.ks}")
         out = empty_cl(d.b, cout, d.p2, d.na, f.device)
         ws, wsp, wsn = _workspace(lib, d, f.device)
-        _lib.check(lib.epn_inter_so3conv_fwd_f32(ctypes.byref(d), _cl_ptr(f), _lib.dev_ptr(Wc, "W"), _cl_ptr(out),
-                                                 wsp, wsn, _lib.stream_of(f)), "inter_so3conv_fwd")
+        _lib.check(_launch("inter_fwd", _inter_key(d), _inter_flops(d), f.device,
+                           lambda: lib.epn_inter_so3conv_fwd_f32(ctypes.byref(d), _cl_ptr(f), _lib.dev_ptr(Wc, "W"),
+                                                                 _cl_ptr(out), wsp, wsn, _lib.stream_of(f))),
+                   "inter_so3conv_fwd")
         ctx.save_for_backward(f, Wc)
         ctx.geo = geo
         return out
@@ -135,15 +175,46 @@ class InterSO3ConvFn(torch.autograd.Function):
         gf = gW = None
         if ctx.needs_input_grad[0]:
             gf = empty_cl(d.b, cin, d.p1, d.na, f.device)
-            _lib.check(lib.epn_inter_so3conv_bwd_data_f32(ctypes.byref(d), _cl_ptr(g), _lib.dev_ptr(Wc, "W"),
-                                                          _cl_ptr(gf), wsp, wsn, _lib.stream_of(f)),
+            _lib.check(_launch("inter_bwd_data", _inter_key(d), _inter_flops(d), f.device,
+                               lambda: lib.epn_inter_so3conv_bwd_data_f32(ctypes.byref(d), _cl_ptr(g),
+                                                                          _lib.dev_ptr(Wc, "W"), _cl_ptr(gf), wsp,
+                                                                          wsn, _lib.stream_of(f))),
                        "inter_so3conv_bwd_data")
         if ctx.needs_input_grad[1]:
             gW = torch.empty_like(Wc)
-            _lib.check(lib.epn_inter_so3conv_bwd_weight_f32(ctypes.byref(d), _cl_ptr(f), _cl_ptr(g),
-                                                            _lib.dev_ptr(gW, "grad_W"), wsp, wsn,
-                                                            _lib.stream_of(f)), "inter_so3conv_bwd_weight")
+            _lib.check(_launch("inter_bwd_weight", _inter_key(d), _inter_flops(d), f.device,
+                               lambda: lib.epn_inter_so3conv_bwd_weight_f32(ctypes.byref(d), _cl_ptr(f), _cl_ptr(g),
+                                                                            _lib.dev_ptr(gW, "grad_W"), wsp, wsn,
+                                                                            _lib.stream_of(f))),
+                       "inter_so3conv_bwd_weight")
         return gf, gW, None
+
+
+_INV_CACHE = {}
+
+
+def inverse_intra_idx(intra_idx32):
+    """inv[idx[a,k], k] = a when every column of intra_idx is a permutation of the anchors (true for the
+    icosahedral table, tests/test_tables.py); None otherwise.  Cached per index tensor."""
+    key = (intra_idx32.data_ptr(), intra_idx32._version, tuple(intra_idx32.shape), str(intra_idx32.device))
+    if key not in _INV_CACHE:
+        host = intra_idx32.cpu().long()
+        na, kn = host.shape
+        inv = None
+        if all(sorted(host[:, k].tolist()) == list(range(na)) for k in range(kn)):
+            inv = torch.empty_like(host)
+            inv.scatter_(0, host, torch.arange(na).view(-1, 1).expand(-1, kn))
+            inv = inv.int().to(intra_idx32.device)
+        if len(_INV_CACHE) > 64:
+            _INV_CACHE.clear()
+        _INV_CACHE[key] = inv
+    return _INV_CACHE[key]
+
+
+def _intra_ws(lib, na, kn, cin, cout, device):
+    nbytes = lib.epn_intra_workspace_bytes(na, kn, cin, cout)
+    ws = torch.empty(max(int(nbytes), 16), dtype=torch.uint8, device=device)
+    return ws, ctypes.c_void_p(ws.data_ptr()), ctypes.c_size_t(ws.numel())
 
 
 class IntraSO3ConvFn(torch.autograd.Function):
@@ -162,9 +233,13 @@ class IntraSO3ConvFn(torch.autograd.Function):
             raise ValueError(f"shape mismatch: feats {tuple(f.shape)}, W {tuple(Wc.shape)}, "
                              f"intra_idx {tuple(intra_idx32.shape)}")
         out = empty_cl(b, cout, p, na, f.device)
-        _lib.check(lib.epn_intra_so3conv_fwd_f32(_cl_ptr(f), _lib.dev_ptr(intra_idx32, "intra_idx", torch.int32),
-                                                 _lib.dev_ptr(Wc, "W"), b, p, na, kn, cin, cout, _cl_ptr(out),
-                                                 _lib.stream_of(f)), "intra_so3conv_fwd")
+        ws, wsp, wsn = _intra_ws(lib, na, kn, cin, cout, f.device)
+        fl = 2.0 * b * p * na * cout * cin * kn
+        _lib.check(_launch("intra_fwd", (b, p, na, kn, cin, cout), fl, f.device,
+                           lambda: lib.epn_intra_so3conv_fwd_f32(
+                               _cl_ptr(f), _lib.dev_ptr(intra_idx32, "intra_idx", torch.int32), _lib.dev_ptr(Wc, "W"),
+                               b, p, na, kn, cin, cout, _cl_ptr(out), wsp, wsn, _lib.stream_of(f))),
+                   "intra_so3conv_fwd")
         ctx.save_for_backward(f, Wc, intra_idx32)
         return out
 
@@ -177,16 +252,23 @@ class IntraSO3ConvFn(torch.autograd.Function):
         cout = Wc.shape[0]
         kn = iidx.shape[1]
         ip = _lib.dev_ptr(iidx, "intra_idx", torch.int32)
+        fl = 2.0 * b * p * na * cout * cin * kn
         gf = gW = None
         if ctx.needs_input_grad[0]:
             gf = empty_cl(b, cin, p, na, f.device)
-            _lib.check(lib.epn_intra_so3conv_bwd_data_f32(_cl_ptr(g), ip, _lib.dev_ptr(Wc, "W"), b, p, na, kn, cin,
-                                                          cout, _cl_ptr(gf), _lib.stream_of(f)),
+            inv = inverse_intra_idx(iidx)
+            ws, wsp, wsn = _intra_ws(lib, na, kn, cin, cout, f.device)
+            _lib.check(_launch("intra_bwd_data", (b, p, na, kn, cin, cout), fl, f.device,
+                               lambda: lib.epn_intra_so3conv_bwd_data_f32(
+                                   _cl_ptr(g), ip, _lib.dev_ptr(inv, "inv_idx", torch.int32), _lib.dev_ptr(Wc, "W"),
+                                   b, p, na, kn, cin, cout, _cl_ptr(gf), wsp, wsn, _lib.stream_of(f))),
                        "intra_so3conv_bwd_data")
         if ctx.needs_input_grad[1]:
             gW = torch.empty_like(Wc)
-            _lib.check(lib.epn_intra_so3conv_bwd_weight_f32(_cl_ptr(f), _cl_ptr(g), ip, b, p, na, kn, cin, cout,
-                                                            _lib.dev_ptr(gW, "grad_W"), _lib.stream_of(f)),
+            _lib.check(_launch("intra_bwd_weight", (b, p, na, kn, cin, cout), fl, f.device,
+                               lambda: lib.epn_intra_so3conv_bwd_weight_f32(
+                                   _cl_ptr(f), _cl_ptr(g), ip, b, p, na, kn, cin, cout, _lib.dev_ptr(gW, "grad_W"),
+                                   _lib.stream_of(f))),
                        "intra_so3conv_bwd_weight")
         return gf, gW, None
 

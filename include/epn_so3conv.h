@@ -98,6 +98,9 @@ int epn_inter_so3conv_bwd_weight_f32(const epn_inter_desc *d, const float *feats
                                      const float *grad_out_cl, float *grad_W, void *workspace,
                                      size_t workspace_bytes, epn_stream_t stream);
 
+/* 1 when the fused MFMA kernels serve this descriptor, 0 when the generic kernels do. */
+int epn_inter_is_fused(const epn_inter_desc *d);
+
 /* Materialise the weights for API compatibility (InterSO3Conv returns inter_w):
  * w f32[b,p2,na,ks,nn], formula of vgtk/vgtk/so3conv/functional.py:190-200. */
 int epn_inter_weights_f32(const epn_inter_desc *d, float *w, epn_stream_t stream);
@@ -108,12 +111,21 @@ int epn_inter_weights_f32(const epn_inter_desc *d, float *w, epn_stream_t stream
  * intra_so3conv_grouping (functional.py:221-233) -> BasicSO3Conv):
  *   out_cl[b,p,a,o] = sum_{c,k} W[o, c*kn+k] * feats_cl[b, p, intra_idx[a,k], c]
  * feats_cl f32[b,p,na,cin], intra_idx i32[na,kn], W f32[cout, cin*kn] -> out_cl f32[b,p,na,cout]. */
+size_t epn_intra_workspace_bytes(int na, int kn, int cin, int cout);
+int epn_intra_is_fused(int na, int kn, int cin, int cout);
+
 int epn_intra_so3conv_fwd_f32(const float *feats_cl, const int32_t *intra_idx, const float *W,
                               int b, int p, int na, int kn, int cin, int cout, float *out_cl,
-                              epn_stream_t stream);
+                              void *workspace, size_t workspace_bytes, epn_stream_t stream);
+
+/* Autograd transposes.  `inv_idx` i32[na,kn] (optional) is the column-wise inverse of intra_idx,
+ * inv_idx[intra_idx[a,k], k] = a; it exists when every column of intra_idx is a permutation of the
+ * anchors (true for the icosahedral table) and makes the data gradient an atomic-free gather.  With
+ * inv_idx == NULL a scatter-add kernel is used.  grad_feats_cl / grad_W are fully overwritten. */
 int epn_intra_so3conv_bwd_data_f32(const float *grad_out_cl, const int32_t *intra_idx,
-                                   const float *W, int b, int p, int na, int kn, int cin, int cout,
-                                   float *grad_feats_cl, epn_stream_t stream);
+                                   const int32_t *inv_idx, const float *W, int b, int p, int na,
+                                   int kn, int cin, int cout, float *grad_feats_cl, void *workspace,
+                                   size_t workspace_bytes, epn_stream_t stream);
 int epn_intra_so3conv_bwd_weight_f32(const float *feats_cl, const float *grad_out_cl,
                                      const int32_t *intra_idx, int b, int p, int na, int kn,
                                      int cin, int cout, float *grad_W, epn_stream_t stream);

@@ -1,0 +1,70 @@
+"""N > 1 path on CPU: world_size-2 gloo processes exercise the batch sharding and the bucketed gradient
+all-reduce that bench.py uses over RCCL (epn_pointcloud_amd/dp.py).  No GPU, no HIP library involved."""
+import os
+import socket
+import sys
+
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from conftest import ROOT
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def _worker(rank, world, port, out):
+    sys.path.insert(0, ROOT)
+    os.environ.update(RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1",
+                      MASTER_PORT=str(port))
+    from epn_pointcloud_amd import dp
+    r, lr, w = dp.init_from_env(backend="gloo")
+    assert (r, w) == (rank, world)
+    torch.manual_seed(0)
+    model = torch.nn.Sequential(torch.nn.Linear(6, 5), torch.nn.ReLU(), torch.nn.Linear(5, 3))
+    if rank == 1:                      # replicas diverge on purpose; broadcast must repair it
+        with torch.no_grad():
+            for p in model.parameters():
+                p.add_(1.0)
+    dp.broadcast_parameters(model)
+    data = torch.arange(7 * 6, dtype=torch.float32).view(7, 6) / 10.0
+    lo, hi = dp.shard_batch(7, rank, world)
+    loss = model(data[lo:hi]).square().sum() / 7.0          # global-mean loss, shard-local sum
+    loss.backward()
+    for p in model.parameters():                             # allreduce_gradients averages -> pre-scale by world
+        p.grad.mul_(world)
+    nb = dp.allreduce_gradients(list(model.parameters()), world, bucket_bytes=64)
+    torch.save({"grads": [p.grad.clone() for p in model.parameters()], "buckets": nb, "shard": (lo, hi)},
+               os.path.join(out, f"r{rank}.pt"))
+    dist.destroy_process_group()
+
+
+def test_two_rank_gradient_allreduce_matches_single_process(tmp_path):
+    port = _free_port()
+    mp.spawn(_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    r0 = torch.load(tmp_path / "r0.pt")
+    r1 = torch.load(tmp_path / "r1.pt")
+    assert r0["shard"] == (0, 4) and r1["shard"] == (4, 7)
+    assert r0["buckets"] > 1                                  # small bucket size forces several all-reduces
+    torch.manual_seed(0)
+    model = torch.nn.Sequential(torch.nn.Linear(6, 5), torch.nn.ReLU(), torch.nn.Linear(5, 3))
+    data = torch.arange(7 * 6, dtype=torch.float32).view(7, 6) / 10.0
+    (model(data).square().sum() / 7.0).backward()
+    for g0, g1, p in zip(r0["grads"], r1["grads"], model.parameters()):
+        assert torch.equal(g0, g1)
+        assert torch.allclose(g0, p.grad, atol=1e-6)
+
+
+def test_shard_batch_covers_everything():
+    from epn_pointcloud_amd import dp
+    for gb in (1, 7, 32, 256):
+        for world in (1, 2, 3, 8):
+            spans = [dp.shard_batch(gb, r, world) for r in range(world)]
+            assert spans[0][0] == 0 and spans[-1][1] == gb
+            assert all(spans[i][1] == spans[i + 1][0] for i in range(world - 1))
+            sizes = [b - a for a, b in spans]
+            assert max(sizes) - min(sizes) <= 1
