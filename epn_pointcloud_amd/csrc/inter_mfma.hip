@@ -48,7 +48,7 @@ __device__ __forceinline__ f32x4 mfma4(float a, float b, f32x4 c) {
 template <int NT>
 struct Hood {
     float gA[NT];    // S-MFMA operand: lane (x, j) -> (g_x, g_y, g_z, alpha)[j] of neighbour 16t + x
-    int q[NT][4];    // neighbour index for n = 16t + 4j + r (feature-row gather), 0 when masked
+    int q[NT][4];    // feature-row offset idx*na*cin (floats) for n = 16t + 4j + r, 0 when masked
     bool ok[NT][4];
 };
 
@@ -72,7 +72,7 @@ __device__ __forceinline__ void load_hood(const InterArgs &A, int bb, int pp, in
             const int n2 = 16 * t + 4 * j + r;
             int q2 = n2 < A.nn ? row[n2] : -1;
             h.ok[t][r] = q2 >= 0 && q2 < A.p1;
-            h.q[t][r] = h.ok[t][r] ? q2 : 0;
+            h.q[t][r] = h.ok[t][r] ? q2 * A.na * A.cin : 0;
         }
     }
 }
@@ -98,9 +98,10 @@ __device__ __forceinline__ void make_weights(const InterArgs &A, int a, int x, i
 }
 
 // Grouped features of 16 columns x 16 channels into the wave-private LDS tile Gs[col][c_local*ks + k].
+// Generic form (any na): neighbourhood fragments are re-derived whenever the output point changes.
 template <int NT, int KT>
-__device__ __forceinline__ void group_chunk(const InterArgs &A, long long col0, int ct, int x, int j, float *Gs,
-                                            int gss) {
+__device__ __forceinline__ void group_chunk_generic(const InterArgs &A, long long col0, int ct, int x, int j,
+                                                    float *Gs, int gss) {
     Hood<NT> h;
     int last_pt = -1;
     for (int jc = 0; jc < 16; ++jc) {
@@ -119,7 +120,7 @@ __device__ __forceinline__ void group_chunk(const InterArgs &A, long long col0, 
         for (int t = 0; t < NT; ++t)
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-                const float v = fb[(size_t)h.q[t][r] * A.na * A.cin];
+                const float v = fb[h.q[t][r]];
                 f[t][r] = h.ok[t][r] ? v : 0.0f;
             }
         f32x4 w[KT][NT];
@@ -137,7 +138,84 @@ __device__ __forceinline__ void group_chunk(const InterArgs &A, long long col0, 
     }
 }
 
+// Fast form (na >= 16: a 16-column tile touches at most two output points).  The two neighbourhoods are
+// derived ONCE per wave (outside the channel-chunk loop) and the feature rows of the next column are in
+// flight while the current column's MFMAs run.
+template <int NT>
+struct Seg {          // columns [jc0, jc0 + cnt) of the tile: anchors a0.. of one output point
+    Hood<NT> h;
+    const float *fbase;   // feats + ((b*p1)*na)*cin
+    int a0, jc0, cnt;
+};
+
+template <int NT>
+__device__ __forceinline__ void load_f(const InterArgs &A, const Seg<NT> &sg, int a, int coff, float (&f)[NT][4]) {
+    const float *fb = sg.fbase + (size_t)a * A.cin + coff;
+#pragma unroll
+    for (int t = 0; t < NT; ++t)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) f[t][r] = fb[sg.h.q[t][r]];
+}
+
+template <int NT, int KT>
+__device__ __forceinline__ void group_segment(const InterArgs &A, const Seg<NT> &sg, int ct, int x, int j,
+                                              float *Gs, int gss) {
+    if (sg.cnt <= 0) return;
+    const int coff = 16 * ct + x;
+    float fcur[NT][4], fnext[NT][4];
+    load_f<NT>(A, sg, sg.a0, coff, fcur);
+    for (int i = 0; i < sg.cnt; ++i) {
+        const int a = sg.a0 + i;
+        const int an = i + 1 < sg.cnt ? a + 1 : a;   // last column re-reads its own rows (cache hit, result unused)
+        load_f<NT>(A, sg, an, coff, fnext);
+        f32x4 w[KT][NT];
+        make_weights<NT, KT>(A, a, x, j, sg.h, w);
+#pragma unroll
+        for (int kt = 0; kt < KT; ++kt) {
+            f32x4 g = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int t = 0; t < NT; ++t)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) g = mfma4(w[kt][t][r], sg.h.ok[t][r] ? fcur[t][r] : 0.0f, g);
+            if (16 * kt + 4 * j < A.ks)
+                *reinterpret_cast<f32x4 *>(Gs + (sg.jc0 + i) * gss + x * A.ks + 16 * kt + 4 * j) = g;
+        }
+#pragma unroll
+        for (int t = 0; t < NT; ++t)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) fcur[t][r] = fnext[t][r];
+    }
+}
+
+template <int NT>
+__device__ __forceinline__ void make_segments(const InterArgs &A, long long col0, int x, int j, Seg<NT> &s0,
+                                              Seg<NT> &s1) {
+    long long c0 = col0 < A.ncol ? col0 : A.ncol - 1;
+    const int pt0 = (int)(c0 / A.na);
+    const int a0 = (int)(c0 - (long long)pt0 * A.na);
+    long long ncols = A.ncol - col0;
+    ncols = ncols > 16 ? 16 : (ncols < 1 ? 1 : ncols);
+    const int n0 = A.na - a0 < (int)ncols ? A.na - a0 : (int)ncols;
+    int bb = pt0 / A.p2, pp = pt0 - bb * A.p2;
+    load_hood<NT>(A, bb, pp, x, j, s0.h);
+    s0.fbase = A.feats + ((size_t)bb * A.p1) * A.na * A.cin;
+    s0.a0 = a0; s0.jc0 = 0; s0.cnt = n0;
+    const int pt1 = pt0 + 1;
+    s1.cnt = (int)ncols - n0;
+    s1.a0 = 0; s1.jc0 = n0;
+    if (s1.cnt > 0) {
+        bb = pt1 / A.p2; pp = pt1 - bb * A.p2;
+        load_hood<NT>(A, bb, pp, x, j, s1.h);
+        s1.fbase = A.feats + ((size_t)bb * A.p1) * A.na * A.cin;
+    } else {
+        s1.h = s0.h;
+        s1.fbase = s0.fbase;
+    }
+}
+
 // ------------------------------------------------------------------------------------ forward
+constexpr int WPF = 12;  // float4 registers per thread used to prefetch one W sub-chunk (cout*wk/4 <= 256*WPF)
+
 template <int NT, int KT>
 __global__ __launch_bounds__(64 * NW) void inter_fwd_kernel(InterArgs A) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -152,24 +230,59 @@ __global__ __launch_bounds__(64 * NW) void inter_fwd_kernel(InterArgs A) {
     const int MT = A.cout >> 4;
     const long long col0 = ((long long)blockIdx.x * NW + wave) * 16;
     const int CK = A.cin * A.ks;
+    const bool fast = A.na >= 16;
+    const int nsub = ckl / A.wk;
+    const int nchunk = A.cin >> 4;
+    const int vec_per_row = A.wk >> 2;
+    const int nvec = A.cout * vec_per_row;   // float4 elements of one W sub-chunk (<= 256 * WPF)
+
+    Seg<NT> s0, s1;
+    if (fast) make_segments<NT>(A, col0, x, j, s0, s1);
 
     f32x4 acc[16];
 #pragma unroll
     for (int m = 0; m < 16; ++m) acc[m] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-    for (int ct = 0; ct < (A.cin >> 4); ++ct) {
-        if (col0 < A.ncol) group_chunk<NT, KT>(A, col0, ct, x, j, Gs, gss);
-        for (int sub = 0; sub < ckl / A.wk; ++sub) {
-            __syncthreads();  // previous sub-chunk fully consumed (and Gs writes visible)
-            {   // stage W[:, ct*ckl + sub*wk .. +wk) -> Ws[o][wk(+4)]
-                const int vec_per_row = A.wk >> 2;
-                const float *src = A.W + (size_t)ct * ckl + (size_t)sub * A.wk;
-                for (int i = threadIdx.x; i < A.cout * vec_per_row; i += blockDim.x) {
-                    const int o = i / vec_per_row, v = i - o * vec_per_row;
-                    *reinterpret_cast<f32x4 *>(Ws + o * wss + 4 * v) =
-                        *reinterpret_cast<const f32x4 *>(src + (size_t)o * CK + 4 * v);
-                }
+    // W sub-chunk prefetch registers: element i = threadIdx.x + 256*u  ->  (o, v) = (i / vec_per_row, i % vec_per_row)
+    f32x4 wpre[WPF];
+    auto fetch_w = [&](int step) {   // step = ct*nsub + sub
+        const int ct = step / nsub, sub = step - ct * nsub;
+        const float *src = A.W + (size_t)ct * ckl + (size_t)sub * A.wk;
+#pragma unroll
+        for (int u = 0; u < WPF; ++u) {
+            const int i = threadIdx.x + 256 * u;
+            if (i < nvec) {
+                const int o = i / vec_per_row, v = i - o * vec_per_row;
+                wpre[u] = *reinterpret_cast<const f32x4 *>(src + (size_t)o * CK + 4 * v);
             }
+        }
+    };
+    auto store_w = [&]() {
+#pragma unroll
+        for (int u = 0; u < WPF; ++u) {
+            const int i = threadIdx.x + 256 * u;
+            if (i < nvec) {
+                const int o = i / vec_per_row, v = i - o * vec_per_row;
+                *reinterpret_cast<f32x4 *>(Ws + o * wss + 4 * v) = wpre[u];
+            }
+        }
+    };
+
+    fetch_w(0);
+    for (int ct = 0; ct < nchunk; ++ct) {
+        if (col0 < A.ncol) {
+            if (fast) {
+                group_segment<NT, KT>(A, s0, ct, x, j, Gs, gss);
+                group_segment<NT, KT>(A, s1, ct, x, j, Gs, gss);
+            } else {
+                group_chunk_generic<NT, KT>(A, col0, ct, x, j, Gs, gss);
+            }
+        }
+        for (int sub = 0; sub < nsub; ++sub) {
+            __syncthreads();  // previous sub-chunk fully consumed (and this wave's Gs writes are visible)
+            store_w();
+            const int next = ct * nsub + sub + 1;
+            if (next < nchunk * nsub) fetch_w(next);   // lands while this sub-chunk's MFMAs (and the next grouping) run
             __syncthreads();
             for (int g = 0; g < (A.wk >> 4); ++g) {
                 const f32x4 bf = *reinterpret_cast<const f32x4 *>(Gs + x * gss + sub * A.wk + 16 * g + 4 * j);
@@ -192,6 +305,48 @@ __global__ __launch_bounds__(64 * NW) void inter_fwd_kernel(InterArgs A) {
     }
 }
 
+// Data-gradient tail for the columns of one segment: T[n][c] = sum_k w[n][k] dG[c,k], then
+// dF[b, idx[n], a, c] += T[n][c].  dG of the wave's 16 columns sits in Gs[col][c_local*ks + k].
+template <int NT, int KT>
+__device__ __forceinline__ void scatter_segment(const InterArgs &A, const Seg<NT> &sg, int ct, int x, int j,
+                                                const float *Gs, int gss) {
+    if (sg.cnt <= 0) return;
+    // transposed weights: S'[k][n] = beta_k + alpha_n + (2/sigma)(R_a kappa_k).g_n  (A = rk4 row incl. beta, B = (g,1))
+    float gB[NT], alphaN[NT];
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+        alphaN[t] = __shfl(sg.h.gA[t], 48 + x, 64);   // lane (x, 3) holds alpha of neighbour 16t + x
+        gB[t] = j == 3 ? 1.0f : sg.h.gA[t];
+    }
+    float *dbase = const_cast<float *>(sg.fbase) + 16 * ct + x;   // fbase aliases grad_feats_cl in this kernel
+    for (int i = 0; i < sg.cnt; ++i) {
+        const int a = sg.a0 + i;
+        const int jc = sg.jc0 + i;
+        float rk[KT];
+#pragma unroll
+        for (int kt = 0; kt < KT; ++kt) rk[kt] = A.rk4[((size_t)a * EPN_KS_MAX + 16 * kt + x) * 4 + j];
+        float *drow = dbase + (size_t)a * A.cin;
+#pragma unroll
+        for (int t = 0; t < NT; ++t) {
+            f32x4 tt = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int kt = 0; kt < KT; ++kt) {
+                f32x4 s = {alphaN[t], alphaN[t], alphaN[t], alphaN[t]};
+                s = mfma4(rk[kt], gB[t], s);  // D[m = k_local = 4j + r][n = x]
+                // B operand of the contraction over k: dG[k = 16kt + 4j + r][c = x]; rows past ks carry w = 0
+                const int jj = 16 * kt + 4 * j < A.ks ? j : 0;
+                const f32x4 dgc = *reinterpret_cast<const f32x4 *>(Gs + jc * gss + x * A.ks + 16 * kt + 4 * jj);
+#pragma unroll
+                for (int r = 0; r < 4; ++r) tt = mfma4(fmaxf(s[r], 0.0f), dgc[r], tt);
+            }
+            // tt: lane (x = c, j), register r -> n = 16t + 4j + r
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+                if (sg.h.ok[t][r]) atomicAdd(drow + sg.h.q[t][r], tt[r]);
+        }
+    }
+}
+
 // ------------------------------------------------------------------------------------ backward (data)
 // dG[ck][col] = sum_o W[o][ck] dOut[col][o]   (M = ck, N = col, contraction o; WT staged by o-groups)
 // T[n][c]     = sum_k w[n][k] dG[c,k]         per column, then  dF[b, idx[n], a, c] += T[n][c]
@@ -211,20 +366,45 @@ __global__ __launch_bounds__(64 * NW) void inter_bwd_data_kernel(InterArgs A) {
     const bool active = col0 < A.ncol;
     long long colx = col0 + x;
     colx = colx < A.ncol ? colx : A.ncol - 1;
+    const bool fast = A.na >= 16;
+    Seg<NT> s0, s1;
+    if (fast) {
+        InterArgs B = A;
+        B.feats = A.out;   // segment base pointers address grad_feats_cl
+        make_segments<NT>(B, col0, x, j, s0, s1);
+    }
 
-    for (int ct = 0; ct < (A.cin >> 4); ++ct) {
+    // WT group prefetch: ckl rows x 16 floats = ckl*4 float4, element i = threadIdx.x + 256u -> (row, v) = (i>>2, i&3)
+    constexpr int WTP = 8;   // ckl*4 <= 256*WTP  (ks <= 32)
+    f32x4 wpre[WTP];
+    f32x4 bnext;
+    const int nog = A.cout >> 4, nchunk = A.cin >> 4;
+    auto fetch = [&](int step) {   // step = ct*nog + og
+        const int ct = step / nog, og = step - ct * nog;
+#pragma unroll
+        for (int u = 0; u < WTP; ++u) {
+            const int i = threadIdx.x + 256 * u;
+            if (i < ckl * 4)
+                wpre[u] = *reinterpret_cast<const f32x4 *>(A.W + ((size_t)ct * ckl + (i >> 2)) * A.cout + 16 * og +
+                                                           4 * (i & 3));
+        }
+        bnext = *reinterpret_cast<const f32x4 *>(A.gout + colx * A.cout + 16 * og + 4 * j);
+    };
+    fetch(0);
+    for (int ct = 0; ct < nchunk; ++ct) {
         f32x4 dg[32];
 #pragma unroll
         for (int m = 0; m < 32; ++m) dg[m] = f32x4{0.f, 0.f, 0.f, 0.f};
-        for (int og = 0; og < (A.cout >> 4); ++og) {
+        for (int og = 0; og < nog; ++og) {
             __syncthreads();
-            for (int i = threadIdx.x; i < ckl * 4; i += blockDim.x) {  // WT[ct*ckl + row][16og .. +16)
-                const int row = i >> 2, v = i & 3;
-                *reinterpret_cast<f32x4 *>(Ws + row * wss + 4 * v) = *reinterpret_cast<const f32x4 *>(
-                    A.W + ((size_t)ct * ckl + row) * A.cout + 16 * og + 4 * v);
+#pragma unroll
+            for (int u = 0; u < WTP; ++u) {
+                const int i = threadIdx.x + 256 * u;
+                if (i < ckl * 4) *reinterpret_cast<f32x4 *>(Ws + (i >> 2) * wss + 4 * (i & 3)) = wpre[u];
             }
+            const f32x4 bf = bnext;
+            if (ct * nog + og + 1 < nchunk * nog) fetch(ct * nog + og + 1);
             __syncthreads();
-            const f32x4 bf = *reinterpret_cast<const f32x4 *>(A.gout + colx * A.cout + 16 * og + 4 * j);
 #pragma unroll
             for (int m = 0; m < 32; ++m) {
                 if (m < MTK) {
@@ -240,47 +420,25 @@ __global__ __launch_bounds__(64 * NW) void inter_bwd_data_kernel(InterArgs A) {
             if (m < MTK) *reinterpret_cast<f32x4 *>(Gs + x * gss + 16 * m + 4 * j) = dg[m];
         __builtin_amdgcn_wave_barrier();
         if (!active) continue;
-
-        Hood<NT> h;
-        int last_pt = -1;
-        for (int jc = 0; jc < 16; ++jc) {
-            const long long col = col0 + jc;
-            if (col >= A.ncol) break;
-            const int a = (int)(col % A.na);
-            const int pt = (int)(col / A.na);
-            const int bb = pt / A.p2, pp = pt - bb * A.p2;
-            if (pt != last_pt) {
-                load_hood<NT>(A, bb, pp, x, j, h);
-                last_pt = pt;
-            }
-            // transposed weights: lane (x = n_local, j), register r -> k = 16kt + 4j + r
-            // S'[k][n] = beta_k + alpha_n + (2/sigma) (R_a kappa_k) . g_n   (A = rk4 row incl. beta, B = (g,1))
-            float gB[NT], alphaN[NT];
-#pragma unroll
-            for (int t = 0; t < NT; ++t) {
-                // gA holds (gx,gy,gz,alpha)[j] for neighbour 16t + x: B operand wants (gx,gy,gz,1)[j], C wants alpha
-                alphaN[t] = __shfl(h.gA[t], 48 + x, 64);
-                gB[t] = j == 3 ? 1.0f : h.gA[t];
-            }
-            float *drow = A.out + (((size_t)bb * A.p1) * A.na + a) * A.cin + 16 * ct + x;
-#pragma unroll
-            for (int t = 0; t < NT; ++t) {
-                f32x4 tt = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-                for (int kt = 0; kt < KT; ++kt) {
-                    const float rk = A.rk4[((size_t)a * EPN_KS_MAX + 16 * kt + x) * 4 + j];
-                    f32x4 s = {alphaN[t], alphaN[t], alphaN[t], alphaN[t]};
-                    s = mfma4(rk, gB[t], s);  // D[m = k_local = 4j + r][n = x]
-                    // B operand of the contraction over k: dG[k = 16kt + 4j + r][c = x]; rows past ks carry w = 0
-                    const int jj = 16 * kt + 4 * j < A.ks ? j : 0;
-                    const f32x4 dgc = *reinterpret_cast<const f32x4 *>(Gs + jc * gss + x * A.ks + 16 * kt + 4 * jj);
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) tt = mfma4(fmaxf(s[r], 0.0f), dgc[r], tt);
+        if (fast) {
+            scatter_segment<NT, KT>(A, s0, ct, x, j, Gs, gss);
+            scatter_segment<NT, KT>(A, s1, ct, x, j, Gs, gss);
+        } else {
+            Seg<NT> sg;
+            int last_pt = -1;
+            for (int jc = 0; jc < 16; ++jc) {
+                const long long col = col0 + jc;
+                if (col >= A.ncol) break;
+                const int a = (int)(col % A.na);
+                const int pt = (int)(col / A.na);
+                const int bb = pt / A.p2, pp = pt - bb * A.p2;
+                if (pt != last_pt) {
+                    load_hood<NT>(A, bb, pp, x, j, sg.h);
+                    last_pt = pt;
                 }
-                // tt: lane (x = c, j), register r -> n = 16t + 4j + r
-#pragma unroll
-                for (int r = 0; r < 4; ++r)
-                    if (h.ok[t][r]) atomicAdd(drow + (size_t)h.q[t][r] * A.na * A.cin, tt[r]);
+                sg.fbase = A.out + ((size_t)bb * A.p1) * A.na * A.cin;
+                sg.a0 = a; sg.jc0 = jc; sg.cnt = 1;
+                scatter_segment<NT, KT>(A, sg, ct, x, j, Gs, gss);
             }
         }
     }
@@ -317,7 +475,16 @@ __global__ __launch_bounds__(64 * NW) void inter_bwd_weight_kernel(InterArgs A) 
         if (wg_col0 >= A.ncol) break;
         const long long col0 = wg_col0 + wave * 16;
         __syncthreads();  // everyone done reading the previous Gs tiles
-        if (col0 < A.ncol) group_chunk<NT, KT>(A, col0, ct, x, j, Gs, gss);
+        if (col0 < A.ncol) {
+            if (A.na >= 16) {
+                Seg<NT> s0, s1;
+                make_segments<NT>(A, col0, x, j, s0, s1);
+                group_segment<NT, KT>(A, s0, ct, x, j, Gs, gss);
+                group_segment<NT, KT>(A, s1, ct, x, j, Gs, gss);
+            } else {
+                group_chunk_generic<NT, KT>(A, col0, ct, x, j, Gs, gss);
+            }
+        }
         __syncthreads();
         for (int wsrc = 0; wsrc < NW; ++wsrc) {
             const long long c0 = wg_col0 + wsrc * 16;
@@ -438,7 +605,9 @@ int launch_inter_fwd_mfma(const epn_inter_desc *d, const float *rk4, const float
     // W sub-chunk width: largest divisor of the chunk length (multiple of 16) that keeps Ws <= ~56 KB
     int wk = 16;
     for (int cand = 16; cand <= ckl; cand += 16)
-        if (ckl % cand == 0 && (size_t)d->cout * (cand + 4) * sizeof(float) <= 56 * 1024) wk = cand;
+        if (ckl % cand == 0 && (size_t)d->cout * (cand + 4) * sizeof(float) <= 56 * 1024 &&
+            d->cout * cand <= 256 * WPF * 4)
+            wk = cand;
     A.wk = wk;
     const size_t lds = gs_bytes(d) + (size_t)d->cout * (wk + 4) * sizeof(float);
     const unsigned grid = (unsigned)((A.ncol + 16 * NW - 1) / (16 * NW));
