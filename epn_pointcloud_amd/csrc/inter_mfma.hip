@@ -16,6 +16,8 @@
 //
 // Fragment layouts (verified on hardware by tools/mfma_probe.hip): lane l, x = l & 15, j = l >> 4:
 //   A[m = x][k = j],  B[k = j][n = x],  D[m = 4j + r][n = x]  (r = register 0..3).
+#include <cstdlib>
+
 #include "conv_internal.h"
 
 namespace epn {
@@ -524,6 +526,288 @@ __global__ __launch_bounds__(64 * NW) void inter_bwd_weight_kernel(InterArgs A) 
             }
 }
 
+// =====================================================================================================
+// 8-wave variants (forward, weight gradient) for na >= 16, 16 < ks <= 32, nn <= 32.
+// The 16-channel chunk is consumed in two passes over the kernel-point axis -- k in [0,16) and [16,ks) --
+// so the wave-private transposition tile shrinks from 16 x (16*ks) to 16 x 256 floats (16.6 KB): 8 waves
+// (2 per SIMD) fit beside the shared W tile in the 160 KB LDS.  The second pass's grouped features wait in
+// registers (R1) while the first pass runs.  The 16 columns are statically unrolled, so the compiler
+// overlaps one column's feature-row gathers with the previous columns' MFMAs.
+// =====================================================================================================
+constexpr int NW8 = 8;
+constexpr int GS0 = 16 * 16 + 4;   // pass-0 tile row stride (floats)
+
+template <int NT>
+__device__ __forceinline__ void group16(const InterArgs &A, const Seg<NT> &s0, const Seg<NT> &s1, int ct, int x,
+                                        int j, float *Gs, f32x4 (&R1)[16]) {
+    int n0 = s0.cnt;
+    // Opaque to the optimiser on purpose: otherwise every per-column scalar (anchor, offsets, table addresses
+    // of all 16 unrolled columns) is hoisted out of the caller's channel-chunk loop and spilled.
+    asm volatile("" : "+s"(n0));
+    // Feature rows are gathered with buffer loads: descriptor = the segment's cloud slab (wave-uniform),
+    // voffset = the neighbour's row offset + this lane's channel (column-independent, lives in the
+    // neighbourhood registers), soffset = anchor*cin + chunk (wave-uniform).  Nothing per column is left for
+    // the compiler to precompute and keep alive across the 16 unrolled columns.
+    const unsigned slab = (unsigned)A.p1 * A.na * A.cin * 4u;
+    const __amdgpu_buffer_rsrc_t r0 = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(s0.fbase), 0, slab, 0x00020000);
+    const __amdgpu_buffer_rsrc_t r1 = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(s1.fbase), 0, slab, 0x00020000);
+    int v0[NT][4], v1[NT][4];
+#pragma unroll
+    for (int t = 0; t < NT; ++t)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            v0[t][r] = (s0.h.q[t][r] + x) * 4;
+            v1[t][r] = (s1.h.q[t][r] + x) * 4;
+        }
+    // masked neighbours read row 0 and meet w == 0 (alpha = -1e30), so no select on the feature value
+    auto gather = [&](int jc, float (&f)[NT][4]) {
+        const bool first = jc < n0;   // wave-uniform
+        const int a = first ? s0.a0 + jc : jc - n0;
+        const int soff = (a * A.cin + 16 * ct) * 4;
+#pragma unroll
+        for (int t = 0; t < NT; ++t)
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+                f[t][r] = __uint_as_float(first ? __builtin_amdgcn_raw_buffer_load_b32(r0, v0[t][r], soff, 0)
+                                                : __builtin_amdgcn_raw_buffer_load_b32(r1, v1[t][r], soff, 0));
+    };
+    float fcur[NT][4], fnext[NT][4];
+    gather(0, fcur);
+#pragma unroll
+    for (int jc = 0; jc < 16; ++jc) {
+        if (jc + 1 < 16) gather(jc + 1, fnext);   // in flight while this column's MFMAs run
+        const bool first = jc < n0;
+        const int a = first ? s0.a0 + jc : jc - n0;
+        f32x4 g[2];
+#pragma unroll
+        for (int kt = 0; kt < 2; ++kt) {
+            const float *e = A.rk4 + ((size_t)a * EPN_KS_MAX + 16 * kt + x) * 4;
+            const float rk = j == 3 ? 1.0f : e[j];
+            const float beta = e[3];
+            g[kt] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int t = 0; t < NT; ++t) {
+                f32x4 sw = {beta, beta, beta, beta};
+                sw = mfma4(first ? s0.h.gA[t] : s1.h.gA[t], rk, sw);
+#pragma unroll
+                for (int r = 0; r < 4; ++r) g[kt] = mfma4(fmaxf(sw[r], 0.0f), fcur[t][r], g[kt]);
+            }
+        }
+        *reinterpret_cast<f32x4 *>(Gs + jc * GS0 + x * 16 + 4 * j) = g[0];   // k = 4j + r of channel x
+        R1[jc] = g[1];                                                      // k = 16 + 4j + r (valid while < ks)
+#pragma unroll
+        for (int t = 0; t < NT; ++t)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) fcur[t][r] = fnext[t][r];
+        __builtin_amdgcn_sched_barrier(0);   // keep the compiler from hoisting all 16 columns' gathers (spills)
+    }
+}
+
+__device__ __forceinline__ void spill_pass1(float *Gs, const f32x4 (&R1)[16], int kw1, int gs1, int x, int j) {
+    if (4 * j < kw1) {
+#pragma unroll
+        for (int jc = 0; jc < 16; ++jc) *reinterpret_cast<f32x4 *>(Gs + jc * gs1 + x * kw1 + 4 * j) = R1[jc];
+    }
+}
+
+template <int NT, int MTMAX>
+__global__ __launch_bounds__(64 * NW8) void inter_fwd8_kernel(InterArgs A) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int x = lane & 15, j = lane >> 4;
+    float *Gs = smem + (size_t)wave * 16 * GS0;
+    float *Ws = smem + (size_t)NW8 * 16 * GS0;
+    const int wss = A.wk + 4;
+    const int MT = A.cout >> 4;
+    const int kw1 = A.ks - 16, gs1 = 16 * kw1 + 4;
+    const long long col0 = ((long long)blockIdx.x * NW8 + wave) * 16;
+    const int CK = A.cin * A.ks;
+    const int n0s = 256 / A.wk, n1s = (16 * kw1) / A.wk, spc = n0s + n1s;   // W sub-chunks per pass / per chunk
+    const int nchunk = A.cin >> 4;
+    const int vpr = A.wk >> 2, nvec = A.cout * vpr;
+
+    Seg<NT> s0, s1;
+    make_segments<NT>(A, col0, x, j, s0, s1);
+
+    f32x4 acc[MTMAX];
+#pragma unroll
+    for (int m = 0; m < MTMAX; ++m) acc[m] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    constexpr int WPF8 = 4;   // cout*wk/4 <= 512*WPF8
+    f32x4 wpre[WPF8];
+    auto fetch_w = [&](int step) {
+        const int ct = step / spc, rem = step - ct * spc;
+        const int pass = rem >= n0s ? 1 : 0;
+        const int sub = pass ? rem - n0s : rem;
+        const int kw = pass ? kw1 : 16;
+#pragma unroll
+        for (int u = 0; u < WPF8; ++u) {
+            const int i = threadIdx.x + 64 * NW8 * u;
+            if (i < nvec) {
+                const int o = i / vpr, v = i - o * vpr;
+                const int L = sub * A.wk + 4 * v;          // position in the pass's contraction axis
+                const int cl = L / kw, kk = L - cl * kw;   // (channel, kernel point) of that position
+                wpre[u] = *reinterpret_cast<const f32x4 *>(A.W + (size_t)o * CK + (size_t)(16 * ct + cl) * A.ks +
+                                                           16 * pass + kk);
+            }
+        }
+    };
+    auto store_w = [&]() {
+#pragma unroll
+        for (int u = 0; u < WPF8; ++u) {
+            const int i = threadIdx.x + 64 * NW8 * u;
+            if (i < nvec) {
+                const int o = i / vpr, v = i - o * vpr;
+                *reinterpret_cast<f32x4 *>(Ws + o * wss + 4 * v) = wpre[u];
+            }
+        }
+    };
+    auto contract = [&](int nsub, int gstride, int step0) {
+        for (int sub = 0; sub < nsub; ++sub) {
+            __syncthreads();   // Ws free again; this wave's tile writes are ordered before its reads
+            store_w();
+            if (step0 + sub + 1 < nchunk * spc) fetch_w(step0 + sub + 1);
+            __syncthreads();
+            for (int g = 0; g < (A.wk >> 4); ++g) {
+                const f32x4 bf = *reinterpret_cast<const f32x4 *>(Gs + x * gstride + sub * A.wk + 16 * g + 4 * j);
+#pragma unroll
+                for (int m = 0; m < MTMAX; ++m) {
+                    if (m < MT) {
+                        const f32x4 af = *reinterpret_cast<const f32x4 *>(Ws + (16 * m + x) * wss + 16 * g + 4 * j);
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) acc[m] = mfma4(af[r], bf[r], acc[m]);
+                    }
+                    if ((m & 3) == 3) __builtin_amdgcn_sched_barrier(0);   // at most 4 W fragments in flight
+                }
+            }
+        }
+    };
+
+    fetch_w(0);
+    for (int ct = 0; ct < nchunk; ++ct) {
+        f32x4 R1[16];
+        group16<NT>(A, s0, s1, ct, x, j, Gs, R1);
+        contract(n0s, GS0, ct * spc);
+        spill_pass1(Gs, R1, kw1, gs1, x, j);   // own tile: LDS ops of one wave execute in order
+        contract(n1s, gs1, ct * spc + n0s);
+    }
+    const long long col = col0 + x;
+    if (col < A.ncol) {
+#pragma unroll
+        for (int m = 0; m < MTMAX; ++m)
+            if (m < MT) *reinterpret_cast<f32x4 *>(A.out + col * A.cout + 16 * m + 4 * j) = acc[m];
+    }
+}
+
+// dW[o][ck] = sum_col dOut[col][o] G[ck][col]: workgroup = (one 16-channel chunk, one block of <= 128 output
+// channels, a run of 128-column tiles).  Pass 0 (k < 16): 16 ck tiles, wave w owns channels 2w, 2w+1; pass 1
+// (k >= 16): 16*kw1/16 tiles, wave w owns tile w (if it exists).
+template <int NT>
+__global__ __launch_bounds__(64 * NW8) void inter_bwd_weight8_kernel(InterArgs A) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int x = lane & 15, j = lane >> 4;
+    float *Gs = smem + (size_t)wave * 16 * GS0;
+    const int kw1 = A.ks - 16, gs1 = 16 * kw1 + 4;
+    const int ct = blockIdx.y;
+    const int o0 = blockIdx.z * 128;
+    const int MO = (A.cout - o0 < 128 ? A.cout - o0 : 128) >> 4;
+    const int nt1 = kw1;                        // pass-1 tiles of 16 ck: 16*kw1/16
+    const int my1 = (nt1 - wave + NW8 - 1) / NW8 > 0 ? (nt1 - wave + NW8 - 1) / NW8 : 0;   // tiles wave, wave+8 (<= 2)
+
+    f32x4 acc0[8][2], acc1[8][2];
+#pragma unroll
+    for (int m = 0; m < 8; ++m)
+#pragma unroll
+        for (int n = 0; n < 2; ++n) {
+            acc0[m][n] = f32x4{0.f, 0.f, 0.f, 0.f};
+            acc1[m][n] = f32x4{0.f, 0.f, 0.f, 0.f};
+        }
+
+    const long long tile0 = (long long)blockIdx.x * A.col_tiles_per_wg;
+    for (int it = 0; it < A.col_tiles_per_wg; ++it) {
+        const long long wg_col0 = (tile0 + it) * (16 * NW8);
+        if (wg_col0 >= A.ncol) break;
+        const long long col0 = wg_col0 + wave * 16;
+        Seg<NT> s0, s1;
+        make_segments<NT>(A, col0, x, j, s0, s1);
+        f32x4 R1[16];
+        __syncthreads();   // all waves finished reading the previous tiles
+        group16<NT>(A, s0, s1, ct, x, j, Gs, R1);
+        __syncthreads();
+        for (int wsrc = 0; wsrc < NW8; ++wsrc) {
+            const long long c0 = wg_col0 + wsrc * 16;
+            if (c0 >= A.ncol) break;
+            const float *Gsrc = smem + (size_t)wsrc * 16 * GS0;
+#pragma unroll
+            for (int s = 0; s < 4; ++s) {
+                const long long col = c0 + 4 * s + j;
+                const bool okc = col < A.ncol;
+                float af[8];
+#pragma unroll
+                for (int m = 0; m < 8; ++m) af[m] = (m < MO && okc) ? A.gout[col * A.cout + o0 + 16 * m + x] : 0.0f;
+#pragma unroll
+                for (int n = 0; n < 2; ++n) {
+                    const float bfv = okc ? Gsrc[(4 * s + j) * GS0 + 16 * (2 * wave + n) + x] : 0.0f;
+#pragma unroll
+                    for (int m = 0; m < 8; ++m)
+                        if (m < MO) acc0[m][n] = mfma4(af[m], bfv, acc0[m][n]);
+                }
+            }
+        }
+        __syncthreads();
+        spill_pass1(Gs, R1, kw1, gs1, x, j);
+        __syncthreads();
+        for (int wsrc = 0; wsrc < NW8; ++wsrc) {
+            const long long c0 = wg_col0 + wsrc * 16;
+            if (c0 >= A.ncol) break;
+            const float *Gsrc = smem + (size_t)wsrc * 16 * GS0;
+#pragma unroll
+            for (int s = 0; s < 4; ++s) {
+                const long long col = c0 + 4 * s + j;
+                const bool okc = col < A.ncol;
+                float af[8];
+#pragma unroll
+                for (int m = 0; m < 8; ++m) af[m] = (m < MO && okc) ? A.gout[col * A.cout + o0 + 16 * m + x] : 0.0f;
+#pragma unroll
+                for (int n = 0; n < 2; ++n) {
+                    if (n < my1) {
+                        const float bfv = okc ? Gsrc[(4 * s + j) * gs1 + 16 * (wave + NW8 * n) + x] : 0.0f;
+#pragma unroll
+                        for (int m = 0; m < 8; ++m)
+                            if (m < MO) acc1[m][n] = mfma4(af[m], bfv, acc1[m][n]);
+                    }
+                }
+            }
+        }
+    }
+    // lane (x, j), register r -> o = o0 + 16m + 4j + r; pass 0 tile n -> channel 2*wave + n, k = x;
+    // pass 1 tile t = wave + 8n -> position L = 16t + x -> channel L / kw1, k = 16 + L % kw1
+    const int CK = A.cin * A.ks;
+#pragma unroll
+    for (int m = 0; m < 8; ++m) {
+        if (m < MO) {
+#pragma unroll
+            for (int n = 0; n < 2; ++n) {
+                const int ck0 = (16 * ct + 2 * wave + n) * A.ks + x;
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+                    atomicAdd(A.out + (size_t)(o0 + 16 * m + 4 * j + r) * CK + ck0, acc0[m][n][r]);
+                if (n < my1) {
+                    const int L = 16 * (wave + NW8 * n) + x;
+                    const int cl = L / kw1, kk = L - cl * kw1;
+                    const int ck1 = (16 * ct + cl) * A.ks + 16 + kk;
+#pragma unroll
+                    for (int r = 0; r < 4; ++r)
+                        atomicAdd(A.out + (size_t)(o0 + 16 * m + 4 * j + r) * CK + ck1, acc1[m][n][r]);
+                }
+            }
+        }
+    }
+}
+
 __global__ void rk4_table_kernel(const float *__restrict__ rk, int na, int ks, float sigma_inv,
                                  float *__restrict__ rk4) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -596,11 +880,44 @@ int launch_inter_tables_mfma(const epn_inter_desc *d, const float *rk, float *rk
     return 0;
 }
 
+static bool use8(const epn_inter_desc *d) {
+    const char *e = std::getenv("EPN_INTER_V2");
+    if (e && e[0] == '1') return false;
+    return d->na >= 16 && d->ks > 16 && d->ks <= 32 && d->nn <= 32;
+}
+
 int launch_inter_fwd_mfma(const epn_inter_desc *d, const float *rk4, const float *beta, const float *feats,
                           const float *W, float *out, hipStream_t st) {
     (void)beta;
     InterArgs A = make_args(d, rk4);
     A.feats = feats; A.W = W; A.out = out;
+    if (use8(d)) {
+        const int kw1 = d->ks - 16;
+        const size_t gsb = (size_t)NW8 * 16 * GS0 * sizeof(float);
+        int wk = 16;
+        for (int cand = 16; cand <= 256; cand += 16)
+            if (256 % cand == 0 && (16 * kw1) % cand == 0 &&
+                gsb + (size_t)d->cout * (cand + 4) * sizeof(float) <= 160 * 1024 && d->cout * cand <= 512 * 4 * 4)
+                wk = cand;
+        A.wk = wk;
+        const size_t lds = gsb + (size_t)d->cout * (wk + 4) * sizeof(float);
+        const unsigned grid = (unsigned)((A.ncol + 16 * NW8 - 1) / (16 * NW8));
+#define EPN_FWD8(NT_, MT_)                                                                              \
+    do {                                                                                                \
+        int rc_ = set_lds(inter_fwd8_kernel<NT_, MT_>, lds);                                            \
+        if (rc_) return rc_;                                                                            \
+        hipLaunchKernelGGL((inter_fwd8_kernel<NT_, MT_>), dim3(grid), dim3(64 * NW8), lds, st, A);      \
+    } while (0)
+        const int mt = d->cout / 16;
+        if (d->nn <= 16) {
+            if (mt <= 4) EPN_FWD8(1, 4); else if (mt <= 8) EPN_FWD8(1, 8); else EPN_FWD8(1, 16);
+        } else {
+            if (mt <= 4) EPN_FWD8(2, 4); else if (mt <= 8) EPN_FWD8(2, 8); else EPN_FWD8(2, 16);
+        }
+#undef EPN_FWD8
+        EPN_CHECK_LAUNCH();
+        return 0;
+    }
     const int ckl = 16 * d->ks;
     // W sub-chunk width: largest divisor of the chunk length (multiple of 16) that keeps Ws <= ~56 KB
     int wk = 16;
@@ -652,6 +969,27 @@ int launch_inter_bwd_weight_mfma(const epn_inter_desc *d, const float *rk4, cons
     (void)beta;
     InterArgs A = make_args(d, rk4);
     A.feats = feats; A.gout = dOut; A.out = dW;
+    if (use8(d)) {
+        const long long tiles8 = (A.ncol + 16 * NW8 - 1) / (16 * NW8);
+        const int chunks8 = d->cin / 16, oblocks8 = (d->cout + 127) / 128;
+        long long splits8 = (256 * 2 + chunks8 * oblocks8 - 1) / (chunks8 * oblocks8);
+        if (splits8 > tiles8) splits8 = tiles8;
+        if (splits8 < 1) splits8 = 1;
+        A.col_tiles_per_wg = (int)((tiles8 + splits8 - 1) / splits8);
+        const unsigned gx8 = (unsigned)((tiles8 + A.col_tiles_per_wg - 1) / A.col_tiles_per_wg);
+        const size_t lds8 = (size_t)NW8 * 16 * GS0 * sizeof(float);
+        if (d->nn <= 16) {
+            int rc_ = set_lds(inter_bwd_weight8_kernel<1>, lds8);
+            if (rc_) return rc_;
+            hipLaunchKernelGGL((inter_bwd_weight8_kernel<1>), dim3(gx8, chunks8, oblocks8), dim3(64 * NW8), lds8, st, A);
+        } else {
+            int rc_ = set_lds(inter_bwd_weight8_kernel<2>, lds8);
+            if (rc_) return rc_;
+            hipLaunchKernelGGL((inter_bwd_weight8_kernel<2>), dim3(gx8, chunks8, oblocks8), dim3(64 * NW8), lds8, st, A);
+        }
+        EPN_CHECK_LAUNCH();
+        return 0;
+    }
     const long long tiles = (A.ncol + 16 * NW - 1) / (16 * NW);
     const int chunks = d->cin / 16, oblocks = (d->cout + 127) / 128;
     // enough workgroups to fill 256 CUs a few times over, each walking a contiguous run of column tiles
