@@ -808,6 +808,102 @@ __global__ __launch_bounds__(64 * NW8) void inter_bwd_weight8_kernel(InterArgs A
     }
 }
 
+// Data gradient, 8 waves: a workgroup owns 4 column tiles, TWO waves per tile.  Each wave computes half of the
+// dG rows of its tile (dG = W^T dOut), the pair meets at a barrier, then each wave runs the per-column tail
+// (regenerated weights, contraction over k, atomic scatter) for 8 of the 16 columns.  Same work as the 4-wave
+// kernel, but 2 waves per SIMD and W^T staged once for 64 columns.
+template <int NT, int KT>
+__global__ __launch_bounds__(64 * NW8) void inter_bwd_data8_kernel(InterArgs A) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int tile = wave >> 1, half = wave & 1;
+    const int x = lane & 15, j = lane >> 4;
+    const int ckl = 16 * A.ks;
+    const int gss = ckl + 4;
+    float *Gs = smem + (size_t)tile * 16 * gss;
+    float *Ws = smem + (size_t)4 * 16 * gss;
+    const int wss = 20;
+    const int MTK = ckl >> 4;
+    const int MH = (MTK + 1) >> 1;                 // dG row tiles per wave (<= 16)
+    const int m0 = half * MH;
+    const int mcnt = MTK - m0 < MH ? MTK - m0 : MH;
+    const long long col0 = ((long long)blockIdx.x * 4 + tile) * 16;
+    const bool active = col0 < A.ncol;
+    long long colx = col0 + x;
+    colx = colx < A.ncol ? colx : A.ncol - 1;
+
+    Seg<NT> s0, s1;
+    {
+        InterArgs B = A;
+        B.feats = A.out;   // segment base pointers address grad_feats_cl
+        make_segments<NT>(B, col0, x, j, s0, s1);
+    }
+    // this wave's 8 columns [8*half, 8*half + 8) as (at most) two sub-segments
+    const int lo = 8 * half, hi = lo + 8;
+    {
+        const int e0 = s0.cnt < hi ? s0.cnt : hi;          // s0 covers [0, s0.cnt)
+        const int b0 = lo < e0 ? lo : e0;
+        const int c0n = e0 - b0;
+        const int tot = s0.cnt + s1.cnt;
+        const int b1 = lo > s0.cnt ? lo : s0.cnt;          // s1 covers [s0.cnt, tot)
+        const int e1 = hi < tot ? hi : tot;
+        const int c1n = e1 > b1 ? e1 - b1 : 0;
+        s1.a0 = b1 - s0.cnt; s1.jc0 = b1; s1.cnt = c1n;
+        s0.a0 = s0.a0 + b0; s0.jc0 = b0; s0.cnt = c0n > 0 ? c0n : 0;
+    }
+
+    constexpr int WTP8 = 4;   // ckl*4 <= 512*WTP8
+    f32x4 wpre[WTP8];
+    f32x4 bnext;
+    const int nog = A.cout >> 4, nchunk = A.cin >> 4;
+    auto fetch = [&](int step) {
+        const int ct = step / nog, og = step - ct * nog;
+#pragma unroll
+        for (int u = 0; u < WTP8; ++u) {
+            const int i = threadIdx.x + 64 * NW8 * u;
+            if (i < ckl * 4)
+                wpre[u] = *reinterpret_cast<const f32x4 *>(A.W + ((size_t)ct * ckl + (i >> 2)) * A.cout + 16 * og +
+                                                           4 * (i & 3));
+        }
+        bnext = *reinterpret_cast<const f32x4 *>(A.gout + colx * A.cout + 16 * og + 4 * j);
+    };
+    fetch(0);
+    for (int ct = 0; ct < nchunk; ++ct) {
+        f32x4 dg[16];
+#pragma unroll
+        for (int m = 0; m < 16; ++m) dg[m] = f32x4{0.f, 0.f, 0.f, 0.f};
+        for (int og = 0; og < nog; ++og) {
+            __syncthreads();
+#pragma unroll
+            for (int u = 0; u < WTP8; ++u) {
+                const int i = threadIdx.x + 64 * NW8 * u;
+                if (i < ckl * 4) *reinterpret_cast<f32x4 *>(Ws + (i >> 2) * wss + 4 * (i & 3)) = wpre[u];
+            }
+            const f32x4 bf = bnext;
+            if (ct * nog + og + 1 < nchunk * nog) fetch(ct * nog + og + 1);
+            __syncthreads();
+#pragma unroll
+            for (int m = 0; m < 16; ++m) {
+                if (m < mcnt) {
+                    const f32x4 af = *reinterpret_cast<const f32x4 *>(Ws + (16 * (m0 + m) + x) * wss + 4 * j);
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) dg[m] = mfma4(af[r], bf[r], dg[m]);
+                }
+            }
+        }
+#pragma unroll
+        for (int m = 0; m < 16; ++m)
+            if (m < mcnt) *reinterpret_cast<f32x4 *>(Gs + x * gss + 16 * (m0 + m) + 4 * j) = dg[m];
+        __syncthreads();   // both halves of every tile are in LDS
+        if (active) {
+            scatter_segment<NT, KT>(A, s0, ct, x, j, Gs, gss);
+            scatter_segment<NT, KT>(A, s1, ct, x, j, Gs, gss);
+        }
+        // the next chunk's first barrier (og = 0) orders these reads before the tile is overwritten
+    }
+}
+
 __global__ void rk4_table_kernel(const float *__restrict__ rk, int na, int ks, float sigma_inv,
                                  float *__restrict__ rk4) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -950,6 +1046,25 @@ int launch_inter_bwd_data_mfma(const epn_inter_desc *d, const float *rk4, const 
     EPN_CHECK_LAUNCH();
     InterArgs A = make_args(d, rk4);
     A.W = wt; A.gout = dOut; A.out = dF;
+    {
+        const char *e8 = std::getenv("EPN_INTER_V2");
+        if (!(e8 && e8[0] == '1') && d->na >= 16 && d->nn <= 32) {
+            const size_t lds8 = (size_t)4 * 16 * (16 * d->ks + 4) * sizeof(float) + (size_t)16 * d->ks * 20 * sizeof(float);
+            const unsigned grid8 = (unsigned)((A.ncol + 63) / 64);
+#define EPN_BD8(NT_, KT_)                                                                                 \
+    do {                                                                                                  \
+        int rc_ = set_lds(inter_bwd_data8_kernel<NT_, KT_>, lds8);                                        \
+        if (rc_) return rc_;                                                                              \
+        hipLaunchKernelGGL((inter_bwd_data8_kernel<NT_, KT_>), dim3(grid8), dim3(64 * NW8), lds8, st, A); \
+    } while (0)
+            const int kt8 = (d->ks + 15) / 16;
+            if (d->nn <= 16) { if (kt8 == 1) EPN_BD8(1, 1); else EPN_BD8(1, 2); }
+            else { if (kt8 == 1) EPN_BD8(2, 1); else EPN_BD8(2, 2); }
+#undef EPN_BD8
+            EPN_CHECK_LAUNCH();
+            return 0;
+        }
+    }
     const size_t lds = gs_bytes(d) + (size_t)16 * d->ks * 20 * sizeof(float);
     const unsigned grid = (unsigned)((A.ncol + 16 * NW - 1) / (16 * NW));
 #define EPN_BD(NT_, KT_, dummy)                                                                       \
