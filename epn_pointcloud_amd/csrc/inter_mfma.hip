@@ -713,17 +713,23 @@ __global__ __launch_bounds__(64 * NW8) void inter_bwd_weight8_kernel(InterArgs A
     const int kw1 = A.ks - 16, gs1 = 16 * kw1 + 4;
     const int ct = blockIdx.y;
     const int o0 = blockIdx.z * 128;
-    const int MO = (A.cout - o0 < 128 ? A.cout - o0 : 128) >> 4;
-    const int nt1 = kw1;                        // pass-1 tiles of 16 ck: 16*kw1/16
-    const int my1 = (nt1 - wave + NW8 - 1) / NW8 > 0 ? (nt1 - wave + NW8 - 1) / NW8 : 0;   // tiles wave, wave+8 (<= 2)
+    const int MO = (A.cout - o0 < 128 ? A.cout - o0 : 128) >> 4;   // row tiles of this block: 2, 4 or 8 (launcher)
+    // Tile ownership: wave = (one row tile mi, one group ng of ck positions), so ONE dOut fragment per contraction
+    // step feeds all of the wave's MFMAs, and the G fragments of four tiles come from one ds_read_b128: tile t of a
+    // 64-position quad q covers the positions {64q + 4i + t}.
+    const int msplit = MO, nsplit = NW8 / MO;             // nsplit in {1, 2, 4}
+    const int mi = wave % msplit, ng = wave / msplit;
+    const int q0n = 4 / nsplit;                           // pass-0 quads per wave (4, 2, 1)
+    const int nq1 = (16 * kw1) / 64;                      // pass-1 quads in total (2 for ks = 24)
+    const int q1n = (nq1 + nsplit - 1) / nsplit;          // per wave
 
-    f32x4 acc0[8][2], acc1[8][2];
+    f32x4 acc0[4][4], acc1[4][4];   // [quad][tile in quad]
 #pragma unroll
-    for (int m = 0; m < 8; ++m)
+    for (int q = 0; q < 4; ++q)
 #pragma unroll
-        for (int n = 0; n < 2; ++n) {
-            acc0[m][n] = f32x4{0.f, 0.f, 0.f, 0.f};
-            acc1[m][n] = f32x4{0.f, 0.f, 0.f, 0.f};
+        for (int t = 0; t < 4; ++t) {
+            acc0[q][t] = f32x4{0.f, 0.f, 0.f, 0.f};
+            acc1[q][t] = f32x4{0.f, 0.f, 0.f, 0.f};
         }
 
     const long long tile0 = (long long)blockIdx.x * A.col_tiles_per_wg;
@@ -745,16 +751,15 @@ __global__ __launch_bounds__(64 * NW8) void inter_bwd_weight8_kernel(InterArgs A
             for (int s = 0; s < 4; ++s) {
                 const long long col = c0 + 4 * s + j;
                 const bool okc = col < A.ncol;
-                float af[8];
+                const float af = okc ? A.gout[col * A.cout + o0 + 16 * mi + x] : 0.0f;
 #pragma unroll
-                for (int m = 0; m < 8; ++m) af[m] = (m < MO && okc) ? A.gout[col * A.cout + o0 + 16 * m + x] : 0.0f;
+                for (int q = 0; q < 4; ++q)
+                    if (q < q0n) {
+                        const f32x4 bf = *reinterpret_cast<const f32x4 *>(Gsrc + (4 * s + j) * GS0 +
+                                                                          64 * (ng * q0n + q) + 4 * x);
 #pragma unroll
-                for (int n = 0; n < 2; ++n) {
-                    const float bfv = okc ? Gsrc[(4 * s + j) * GS0 + 16 * (2 * wave + n) + x] : 0.0f;
-#pragma unroll
-                    for (int m = 0; m < 8; ++m)
-                        if (m < MO) acc0[m][n] = mfma4(af[m], bfv, acc0[m][n]);
-                }
+                        for (int t = 0; t < 4; ++t) acc0[q][t] = mfma4(af, okc ? bf[t] : 0.0f, acc0[q][t]);
+                    }
             }
         }
         __syncthreads();
@@ -768,44 +773,43 @@ __global__ __launch_bounds__(64 * NW8) void inter_bwd_weight8_kernel(InterArgs A
             for (int s = 0; s < 4; ++s) {
                 const long long col = c0 + 4 * s + j;
                 const bool okc = col < A.ncol;
-                float af[8];
+                const float af = okc ? A.gout[col * A.cout + o0 + 16 * mi + x] : 0.0f;
 #pragma unroll
-                for (int m = 0; m < 8; ++m) af[m] = (m < MO && okc) ? A.gout[col * A.cout + o0 + 16 * m + x] : 0.0f;
+                for (int q = 0; q < 4; ++q) {
+                    const int qq = ng * q1n + q;
+                    if (q < q1n && qq < nq1) {
+                        const f32x4 bf = *reinterpret_cast<const f32x4 *>(Gsrc + (4 * s + j) * gs1 + 64 * qq + 4 * x);
 #pragma unroll
-                for (int n = 0; n < 2; ++n) {
-                    if (n < my1) {
-                        const float bfv = okc ? Gsrc[(4 * s + j) * gs1 + 16 * (wave + NW8 * n) + x] : 0.0f;
-#pragma unroll
-                        for (int m = 0; m < 8; ++m)
-                            if (m < MO) acc1[m][n] = mfma4(af[m], bfv, acc1[m][n]);
+                        for (int t = 0; t < 4; ++t) acc1[q][t] = mfma4(af, okc ? bf[t] : 0.0f, acc1[q][t]);
                     }
                 }
             }
         }
     }
-    // lane (x, j), register r -> o = o0 + 16m + 4j + r; pass 0 tile n -> channel 2*wave + n, k = x;
-    // pass 1 tile t = wave + 8n -> position L = 16t + x -> channel L / kw1, k = 16 + L % kw1
+    // lane (x, j), register r -> o = o0 + 16*mi + 4j + r;  tile (q, t), lane x -> position p = 64*quad + 4x + t;
+    // pass 0: channel p / 16, k = p % 16;   pass 1: channel p / kw1, k = 16 + p % kw1
     const int CK = A.cin * A.ks;
 #pragma unroll
-    for (int m = 0; m < 8; ++m) {
-        if (m < MO) {
+    for (int q = 0; q < 4; ++q)
 #pragma unroll
-            for (int n = 0; n < 2; ++n) {
-                const int ck0 = (16 * ct + 2 * wave + n) * A.ks + x;
+        for (int t = 0; t < 4; ++t) {
+            if (q < q0n) {
+                const int p = 64 * (ng * q0n + q) + 4 * x + t;
+                const int ck0 = (16 * ct + (p >> 4)) * A.ks + (p & 15);
 #pragma unroll
                 for (int r = 0; r < 4; ++r)
-                    atomicAdd(A.out + (size_t)(o0 + 16 * m + 4 * j + r) * CK + ck0, acc0[m][n][r]);
-                if (n < my1) {
-                    const int L = 16 * (wave + NW8 * n) + x;
-                    const int cl = L / kw1, kk = L - cl * kw1;
-                    const int ck1 = (16 * ct + cl) * A.ks + 16 + kk;
+                    atomicAdd(A.out + (size_t)(o0 + 16 * mi + 4 * j + r) * CK + ck0, acc0[q][t][r]);
+            }
+            const int qq = ng * q1n + q;
+            if (q < q1n && qq < nq1) {
+                const int p = 64 * qq + 4 * x + t;
+                const int cl = p / kw1, kk = p - cl * kw1;
+                const int ck1 = (16 * ct + cl) * A.ks + 16 + kk;
 #pragma unroll
-                    for (int r = 0; r < 4; ++r)
-                        atomicAdd(A.out + (size_t)(o0 + 16 * m + 4 * j + r) * CK + ck1, acc1[m][n][r]);
-                }
+                for (int r = 0; r < 4; ++r)
+                    atomicAdd(A.out + (size_t)(o0 + 16 * mi + 4 * j + r) * CK + ck1, acc1[q][t][r]);
             }
         }
-    }
 }
 
 // Data gradient, 8 waves: a workgroup owns 4 column tiles, TWO waves per tile.  Each wave computes half of the
@@ -1084,7 +1088,8 @@ int launch_inter_bwd_weight_mfma(const epn_inter_desc *d, const float *rk4, cons
     (void)beta;
     InterArgs A = make_args(d, rk4);
     A.feats = feats; A.gout = dOut; A.out = dW;
-    if (use8(d)) {
+    const int tail_tiles = (d->cout % 128) / 16;   // row tiles of the last (partial) block of output channels
+    if (use8(d) && (16 * (d->ks - 16)) % 64 == 0 && (tail_tiles == 0 || tail_tiles == 2 || tail_tiles == 4)) {
         const long long tiles8 = (A.ncol + 16 * NW8 - 1) / (16 * NW8);
         const int chunks8 = d->cin / 16, oblocks8 = (d->cout + 127) / 128;
         long long splits8 = (256 * 2 + chunks8 * oblocks8 - 1) / (chunks8 * oblocks8);

@@ -137,6 +137,55 @@ __global__ __launch_bounds__(64 * NW) void intra_bwd_weight_kernel(IntraArgs A) 
                               acc[m][n][r]);
 }
 
+// Same contraction with 16-byte operand loads (co, ci multiples of 64): lane (x, j) reads dOut[col][o0+4x..+3] and
+// X[src][c0+4x..+3]; component t of those vectors feeds row/column tile t, i.e. tile t covers the channels
+// {4*i + t}.  One dwordx4 per operand per contraction step instead of four dwords.
+__global__ __launch_bounds__(64 * NW) void intra_bwd_weight_v4_kernel(IntraArgs A) {
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int x = lane & 15, j = lane >> 4;
+    const int k = blockIdx.y * NW + wave;
+    const int cblocks = A.ci / 64;
+    const int o0 = (blockIdx.z / cblocks) * 64, c0 = (blockIdx.z % cblocks) * 64;
+    if (k >= A.kn) return;  // no barriers in this kernel
+
+    f32x4 acc[4][4];
+#pragma unroll
+    for (int m = 0; m < 4; ++m)
+#pragma unroll
+        for (int n = 0; n < 4; ++n) acc[m][n] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    const long long t0 = (long long)blockIdx.x * A.col_tiles_per_wg;
+    for (int it = 0; it < A.col_tiles_per_wg; ++it) {
+        const long long c_base = (t0 + it) * 16;
+        if (c_base >= A.ncol) break;
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+            const long long col = c_base + 4 * s + j;
+            const bool ok = col < A.ncol;
+            const long long cc = ok ? col : A.ncol - 1;
+            const int a = (int)(cc % A.na);
+            const long long src = cc - a + A.idx[a * A.kn + k];
+            f32x4 af = *reinterpret_cast<const f32x4 *>(A.gout + cc * A.co + o0 + 4 * x);
+            const f32x4 bf = *reinterpret_cast<const f32x4 *>(A.X + src * A.ci + c0 + 4 * x);
+            if (!ok) af = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int m = 0; m < 4; ++m)
+#pragma unroll
+                for (int n = 0; n < 4; ++n) acc[m][n] = mfma4(af[m], bf[n], acc[m][n]);
+        }
+    }
+    // acc[m][n]: lane (x, j), register r -> o = o0 + 4*(4j + r) + m,  c = c0 + 4x + n
+#pragma unroll
+    for (int m = 0; m < 4; ++m)
+#pragma unroll
+        for (int n = 0; n < 4; ++n)
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+                atomicAdd(A.out + ((size_t)(o0 + 4 * (4 * j + r) + m) * A.ci + c0 + 4 * x + n) * A.kn + k,
+                          acc[m][n][r]);
+}
+
 // Wp[o][k*ci + c] = W[o][c*kn + k]                     (forward pack)
 // Wq[c][k*co + o] = W[o][c*kn + k]                     (data-gradient pack: roles of o and c swapped)
 __global__ void pack_w_kernel(const float *__restrict__ W, int co, int ci, int kn, int transpose,
@@ -215,7 +264,10 @@ int launch_intra_bwd_weight_mfma(const float *feats, const float *dOut, const in
     if (splits < 1) splits = 1;
     A.col_tiles_per_wg = (int)((tiles + splits - 1) / splits);
     const unsigned gx = (unsigned)((tiles + A.col_tiles_per_wg - 1) / A.col_tiles_per_wg);
-    hipLaunchKernelGGL(intra_bwd_weight_kernel, dim3(gx, kblocks, tblocks), dim3(64 * NW), 0, st, A);
+    if (cout % 64 == 0 && cin % 64 == 0)
+        hipLaunchKernelGGL(intra_bwd_weight_v4_kernel, dim3(gx, kblocks, tblocks), dim3(64 * NW), 0, st, A);
+    else
+        hipLaunchKernelGGL(intra_bwd_weight_kernel, dim3(gx, kblocks, tblocks), dim3(64 * NW), 0, st, A);
     EPN_CHECK_LAUNCH();
     return 0;
 }
