@@ -77,7 +77,7 @@ class InterGeometry:
 
     def __init__(self, xyz, new_xyz, ball_idx, anchors, kernels, sigma):
         self.xyz, self.new_xyz, self.ball_idx = xyz, new_xyz, ball_idx
-        self.anchors, self.kernels, self.sigma = anchors, kernels, float(sigma)
+        self.anchors, self.kernels, self.sigma = anchors.contiguous(), kernels.contiguous(), float(sigma)
         self._dense = None
 
     @property

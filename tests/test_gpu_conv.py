@@ -202,3 +202,71 @@ def test_generic_and_fused_kernels_agree(gpu, vgtk_alias):
         del os.environ["EPN_FORCE_GENERIC"]
     for a, b in zip(fused, generic):
         assert (a - b).abs().max().item() < TOL * max(1.0, b.abs().max().item())
+
+
+def test_plumbing_config_a12_tetrahedral_subgroup(gpu, vgtk_alias):
+    """BASELINE configs[0] second reading: B=2 N=256 K=16 with the order-12 tetrahedral subgroup of
+    the 60 anchors and the subgroup's own Cayley table as intra index; the functional ops are parametric in A."""
+    sptk, zptk = _mods(vgtk_alias)
+    from epn_pointcloud_amd import ops
+    import vgtk.pc as pctk
+    tet = [3, 4, 5, 27, 28, 29, 39, 40, 41, 48, 49, 50]
+    Rs = T(sptk.get_anchors(60))[tet].contiguous()
+    cay = torch.empty(12, 12, dtype=torch.int32)
+    for a in range(12):
+        for k in range(12):
+            cay[a, k] = int((Rs - (Rs[a] @ Rs[k])[None]).abs().amax((1, 2)).argmin())
+    assert all(sorted(cay[:, k].tolist()) == list(range(12)) for k in range(12))    # closed subgroup
+    rng = np.random.default_rng(12)
+    torch.manual_seed(12)
+    xyz = T(unit_ball_cloud(rng, 2, 256))
+    kernels = T(sptk.get_sphereical_kernel_points_from_ply(0.7 * 0.4, 1))
+    for cin, cout in ((1, 8), (16, 16)):
+        feats = torch.randn(2, cin, 256, 12)
+        W1 = torch.randn(cout, cin * 24) * 0.2
+        W2 = torch.randn(cout, cout * 12) * 0.1
+        fo, W1o, W2o = feats.clone().requires_grad_(True), W1.clone().requires_grad_(True), W2.clone().requires_grad_(True)
+        idx, w, sidx, nxyz, y = R.inter_so3conv(xyz, fo, W1o, Rs, kernels, 2, 0.4, 0.08, 16, False)
+        z = R.intra_so3conv(y, W2o, cay.long())
+        gz = torch.randn_like(z)
+        g_ref = torch.autograd.grad(z, [fo, W1o, W2o], gz)
+        xg = xyz.to(gpu)
+        s_idx, new_xyz = pctk.furthest_sample(xg, 128, False)
+        b_idx = pctk.ball_query_index(new_xyz, xg, 0.4, 16)
+        assert torch.equal(s_idx.cpu(), sidx) and torch.equal(b_idx.cpu(), idx)
+        geo = ops.InterGeometry(xg, new_xyz, b_idx, Rs.to(gpu), kernels.to(gpu), 0.08)
+        fg, W1g, W2g = (t.to(gpu).requires_grad_(True) for t in (feats, W1, W2))
+        yg = ops.inter_so3conv(fg, W1g, geo)
+        zg = ops.intra_so3conv(yg, W2g, cay.to(gpu))
+        g_gpu = torch.autograd.grad(zg, [fg, W1g, W2g], gz.to(gpu))
+        assert (zg.detach().cpu() - z.detach()).abs().max().item() < TOL * max(1.0, z.abs().max().item())
+        for a, b in zip(g_gpu, g_ref):
+            assert (a.cpu() - b).abs().max().item() < TOL * max(1.0, b.abs().max().item())
+
+
+@pytest.mark.parametrize("cin,cout,stride,K,radius,sigma", [(32, 64, 2, 64, 0.16, 0.0256), (32, 32, 1, 128, 0.25, 0.05),
+                                                             (48, 80, 1, 24, 0.3, 0.06)])
+def test_inter_large_neighbourhoods_and_odd_widths(gpu, vgtk_alias, cin, cout, stride, K, radius, sigma):
+    """3DMatch-style neighbourhoods (K = 64 / 128, inv_so3net_pn schedule) and channel widths that are multiples
+    of 16 but not of 64 take the 4-wave kernels."""
+    sptk, zptk = _mods(vgtk_alias)
+    (y, oy), (dW, odW), (dF, odF) = _inter_case(gpu, sptk, zptk, 1, 512, cin, cout, stride, radius, sigma, K, True,
+                                                500 + K)
+    assert (y - oy).abs().max().item() < TOL * max(1.0, oy.abs().max().item())
+    assert _rel(dW, odW) < TOL
+    assert (dF - odF).abs().max().item() < TOL * max(1.0, odF.abs().max().item())
+
+
+def test_fused_dispatch_covers_the_modelnet_schedule(gpu):
+    """Every cin >= 16 layer of the cls schedule must run on the fused MFMA kernels, not the generic fallback."""
+    import ctypes
+    from epn_pointcloud_amd import _lib, schedule as S
+    lib = _lib.get_lib()
+    p = 1024
+    for l in S.cls_so3net_schedule(1024):
+        d = _lib.InterDesc()
+        d.b, d.p1, d.p2, d.nn, d.na, d.ks, d.cin, d.cout = 32, p, p // l.stride, l.nn, 60, 24, l.cin, l.cout
+        d.sigma = l.sigma
+        assert lib.epn_inter_is_fused(ctypes.byref(d)) == (1 if l.cin >= 16 else 0)
+        assert lib.epn_intra_is_fused(60, 12, l.cout, l.cout) == 1
+        p //= l.stride
