@@ -10,7 +10,7 @@ import os
 import torch
 
 _PKG = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_PKG, "libepn_so3conv.so")
+LIB_PATH = os.environ.get("EPN_LIB", os.path.join(_PKG, "libepn_so3conv.so"))   # EPN_LIB: A/B builds (tools/)
 
 EXPORTS = [
     "epn_version", "epn_strerror",

@@ -20,6 +20,10 @@
 
 #include "conv_internal.h"
 
+#ifndef EPN_ABLATE
+#define EPN_ABLATE 0   // perf ablations only (tools/ablate.sh): 1 = skip grouping, 2 = skip W contraction
+#endif
+
 namespace epn {
 
 bool inter_mfma_available() { return true; }
@@ -571,34 +575,49 @@ __device__ __forceinline__ void group16(const InterArgs &A, const Seg<NT> &s0, c
                 f[t][r] = __uint_as_float(first ? __builtin_amdgcn_raw_buffer_load_b32(r0, v0[t][r], soff, 0)
                                                 : __builtin_amdgcn_raw_buffer_load_b32(r1, v1[t][r], soff, 0));
     };
-    float fcur[NT][4], fnext[NT][4];
-    gather(0, fcur);
-#pragma unroll
-    for (int jc = 0; jc < 16; ++jc) {
-        if (jc + 1 < 16) gather(jc + 1, fnext);   // in flight while this column's MFMAs run
+    auto table = [&](int jc, float (&rk)[2], float (&beta)[2]) {
         const bool first = jc < n0;
         const int a = first ? s0.a0 + jc : jc - n0;
-        f32x4 g[2];
 #pragma unroll
         for (int kt = 0; kt < 2; ++kt) {
             const float *e = A.rk4 + ((size_t)a * EPN_KS_MAX + 16 * kt + x) * 4;
-            const float rk = j == 3 ? 1.0f : e[j];
-            const float beta = e[3];
+            rk[kt] = e[j];
+            beta[kt] = e[3];
+        }
+    };
+    // Software pipeline of depth PD over the 16 statically unrolled columns: the feature rows and the rotated
+    // kernel-point table of column jc + PD are requested before column jc is computed (L2 latency is several
+    // columns' worth of MFMAs).  The arrays are indexed by compile-time constants only.
+    constexpr int PD = 3;
+    float f[16][NT][4], rk[16][2], beta[16][2];
+#pragma unroll
+    for (int jc = 0; jc < PD; ++jc) {
+        gather(jc, f[jc]);
+        table(jc, rk[jc], beta[jc]);
+    }
+#pragma unroll
+    for (int jc = 0; jc < 16; ++jc) {
+        if (jc + PD < 16) {
+            gather(jc + PD, f[jc + PD]);
+            table(jc + PD, rk[jc + PD], beta[jc + PD]);
+        }
+        const bool first = jc < n0;
+        f32x4 g[2];
+#pragma unroll
+        for (int kt = 0; kt < 2; ++kt) {
+            const float rkv = j == 3 ? 1.0f : rk[jc][kt];
+            const float bt = beta[jc][kt];
             g[kt] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
             for (int t = 0; t < NT; ++t) {
-                f32x4 sw = {beta, beta, beta, beta};
-                sw = mfma4(first ? s0.h.gA[t] : s1.h.gA[t], rk, sw);
+                f32x4 sw = {bt, bt, bt, bt};
+                sw = mfma4(first ? s0.h.gA[t] : s1.h.gA[t], rkv, sw);
 #pragma unroll
-                for (int r = 0; r < 4; ++r) g[kt] = mfma4(fmaxf(sw[r], 0.0f), fcur[t][r], g[kt]);
+                for (int r = 0; r < 4; ++r) g[kt] = mfma4(fmaxf(sw[r], 0.0f), f[jc][t][r], g[kt]);
             }
         }
         *reinterpret_cast<f32x4 *>(Gs + jc * GS0 + x * 16 + 4 * j) = g[0];   // k = 4j + r of channel x
         R1[jc] = g[1];                                                      // k = 16 + 4j + r (valid while < ks)
-#pragma unroll
-        for (int t = 0; t < NT; ++t)
-#pragma unroll
-            for (int r = 0; r < 4; ++r) fcur[t][r] = fnext[t][r];
         __builtin_amdgcn_sched_barrier(0);   // keep the compiler from hoisting all 16 columns' gathers (spills)
     }
 }
@@ -669,17 +688,28 @@ __global__ __launch_bounds__(64 * NW8) void inter_fwd8_kernel(InterArgs A) {
             store_w();
             if (step0 + sub + 1 < nchunk * spc) fetch_w(step0 + sub + 1);
             __syncthreads();
-            for (int g = 0; g < (A.wk >> 4); ++g) {
-                const f32x4 bf = *reinterpret_cast<const f32x4 *>(Gs + x * gstride + sub * A.wk + 16 * g + 4 * j);
+            // software-pipelined over the (g, m) sequence: the W fragment of the next step (and the G fragment of
+            // the next g) are read from LDS while the current step's four MFMAs issue
+            const int ng = A.wk >> 4;
+            const float *gsrc = Gs + x * gstride + sub * A.wk + 4 * j;
+            const float *wsrc = Ws + x * wss + 4 * j;
+            f32x4 bf = *reinterpret_cast<const f32x4 *>(gsrc);
+            f32x4 af = *reinterpret_cast<const f32x4 *>(wsrc);
+            for (int g = 0; g < ng; ++g) {
+                const int gn = g + 1 < ng ? g + 1 : g;
+                const f32x4 bfn = *reinterpret_cast<const f32x4 *>(gsrc + 16 * gn);
 #pragma unroll
                 for (int m = 0; m < MTMAX; ++m) {
                     if (m < MT) {
-                        const f32x4 af = *reinterpret_cast<const f32x4 *>(Ws + (16 * m + x) * wss + 16 * g + 4 * j);
+                        const bool last = m + 1 == MT;
+                        const f32x4 afn = *reinterpret_cast<const f32x4 *>(
+                            wsrc + (last ? 16 * gn : 16 * g) + (last ? 0 : 16 * (m + 1)) * wss);
 #pragma unroll
                         for (int r = 0; r < 4; ++r) acc[m] = mfma4(af[r], bf[r], acc[m]);
+                        af = afn;
                     }
-                    if ((m & 3) == 3) __builtin_amdgcn_sched_barrier(0);   // at most 4 W fragments in flight
                 }
+                bf = bfn;
             }
         }
     };
@@ -687,10 +717,19 @@ __global__ __launch_bounds__(64 * NW8) void inter_fwd8_kernel(InterArgs A) {
     fetch_w(0);
     for (int ct = 0; ct < nchunk; ++ct) {
         f32x4 R1[16];
+#if EPN_ABLATE != 1
         group16<NT>(A, s0, s1, ct, x, j, Gs, R1);
+#else
+#pragma unroll
+        for (int jc = 0; jc < 16; ++jc) R1[jc] = f32x4{0.f, 0.f, 0.f, 0.f};
+#endif
+#if EPN_ABLATE != 2
         contract(n0s, GS0, ct * spc);
         spill_pass1(Gs, R1, kw1, gs1, x, j);   // own tile: LDS ops of one wave execute in order
         contract(n1s, gs1, ct * spc + n0s);
+#else
+        spill_pass1(Gs, R1, kw1, gs1, x, j);
+#endif
     }
     const long long col = col0 + x;
     if (col < A.ncol) {
