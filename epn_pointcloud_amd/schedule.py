@@ -60,7 +60,10 @@ def scaled(layers, width_div):
 
 
 class SeparableBlock(nn.Module):
-    """One SeparableSO3ConvBlock of the cls model (norm='BatchNorm2d', activation='leaky_relu')."""
+    """One SeparableSO3ConvBlock of the cls model (norm='BatchNorm2d', activation='leaky_relu',
+    SPConvNets/utils/base_so3conv.py:168-212).  The norm / activation / skip glue are stock torch modules (MIOpen
+    batch-norm and 1x1 convolution: measured faster than hand-composed channels-last torch ops; fusing them into the
+    conv epilogues is SURVEY 8f.1, "next")."""
 
     def __init__(self, l, kanchor=60):
         super().__init__()
@@ -77,12 +80,12 @@ class SeparableBlock(nn.Module):
         skip = x.feats
         _, _, sample_idx, y = self.inter(x)
         feat = F.leaky_relu(self.inter_norm(y.feats))
-        y = self.intra(zptk.SphericalPointCloud(y.xyz, feat, y.anchors))
-        feat = F.leaky_relu(self.intra_norm(y.feats))
+        z = self.intra(zptk.SphericalPointCloud(y.xyz, feat, y.anchors))
+        feat = F.leaky_relu(self.intra_norm(z.feats))
         if self.stride > 1:
             skip = zptk.functional.batched_index_select(skip, 2, sample_idx.long())
         skip = F.leaky_relu(self.norm(self.skip_conv(skip)))
-        return zptk.SphericalPointCloud(y.xyz, feat + skip, y.anchors)
+        return zptk.SphericalPointCloud(z.xyz, feat + skip, z.anchors)
 
 
 class HotPathBackbone(nn.Module):

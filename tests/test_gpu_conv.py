@@ -270,3 +270,31 @@ def test_fused_dispatch_covers_the_modelnet_schedule(gpu):
         assert lib.epn_inter_is_fused(ctypes.byref(d)) == (1 if l.cin >= 16 else 0)
         assert lib.epn_intra_is_fused(60, 12, l.cout, l.cout) == 1
         p //= l.stride
+
+
+def test_separable_block_vs_reference_golden(gpu, vgtk_alias):
+    """schedule.SeparableBlock (channels-last glue around the fused convs) against the output of the reference's
+    SeparableSO3ConvBlock built by the unmodified SPConvNets code (tests/golden/sepblock_tiny.npz), train mode."""
+    from epn_pointcloud_amd import schedule as S
+    g = golden("sepblock_tiny.npz")
+    l = S.Layer(1, 8, 2, 0.4, 0.08, 16, False)
+    blk = S.SeparableBlock(l).train()
+    sd = {k[3:]: T(g[k]) for k in g.files if k.startswith("sd/")}
+    mapped = {
+        "inter.anchors": sd["inter_conv.conv.anchors"], "inter.kernels": sd["inter_conv.conv.kernels"],
+        "inter.basic_conv.W": sd["inter_conv.conv.basic_conv.W"],
+        "inter_norm.weight": sd["inter_conv.norm.weight"], "inter_norm.bias": sd["inter_conv.norm.bias"],
+        "intra.anchors": sd["intra_conv.conv.anchors"], "intra.intra_idx": sd["intra_conv.conv.intra_idx"],
+        "intra.basic_conv.W": sd["intra_conv.conv.basic_conv.W"],
+        "skip_conv.weight": sd["skip_conv.weight"], "skip_conv.bias": sd["skip_conv.bias"],
+        "norm.weight": sd["norm.weight"], "norm.bias": sd["norm.bias"],
+    }
+    missing, unexpected = blk.load_state_dict(mapped, strict=False)
+    assert not unexpected and all("running" in m or "num_batches" in m for m in missing)
+    blk = blk.to(gpu)
+    xyz = T(g["xyz"]).to(gpu)
+    import vgtk.spconv as zptk
+    x = zptk.SphericalPointCloud(xyz, torch.ones(2, 1, 256, 60, device=gpu), None)
+    y = blk(x)
+    assert tuple(y.feats.shape) == (2, 8, 128, 60)
+    assert (y.feats.detach().cpu() - T(g["out"])).abs().max().item() < TOL
