@@ -782,47 +782,60 @@ __global__ __launch_bounds__(64 * NW8) void inter_bwd_weight8_kernel(InterArgs A
         __syncthreads();   // all waves finished reading the previous tiles
         group16<NT>(A, s0, s1, ct, x, j, Gs, R1);
         __syncthreads();
+        // dOut fragments of source tile wsrc + 1 are requested while tile wsrc is contracted (global latency ~ one tile)
+        auto load_af = [&](int wsrc, float (&af)[4]) {
+#pragma unroll
+            for (int s = 0; s < 4; ++s) {
+                const long long col = wg_col0 + wsrc * 16 + 4 * s + j;
+                af[s] = col < A.ncol ? A.gout[col * A.cout + o0 + 16 * mi + x] : 0.0f;
+            }
+        };
+        float afc[4], afn[4];
+        load_af(0, afc);
         for (int wsrc = 0; wsrc < NW8; ++wsrc) {
             const long long c0 = wg_col0 + wsrc * 16;
             if (c0 >= A.ncol) break;
+            load_af(wsrc + 1 < NW8 ? wsrc + 1 : wsrc, afn);
             const float *Gsrc = smem + (size_t)wsrc * 16 * GS0;
 #pragma unroll
             for (int s = 0; s < 4; ++s) {
-                const long long col = c0 + 4 * s + j;
-                const bool okc = col < A.ncol;
-                const float af = okc ? A.gout[col * A.cout + o0 + 16 * mi + x] : 0.0f;
+                const bool okc = c0 + 4 * s + j < A.ncol;
 #pragma unroll
                 for (int q = 0; q < 4; ++q)
                     if (q < q0n) {
                         const f32x4 bf = *reinterpret_cast<const f32x4 *>(Gsrc + (4 * s + j) * GS0 +
                                                                           64 * (ng * q0n + q) + 4 * x);
 #pragma unroll
-                        for (int t = 0; t < 4; ++t) acc0[q][t] = mfma4(af, okc ? bf[t] : 0.0f, acc0[q][t]);
+                        for (int t = 0; t < 4; ++t) acc0[q][t] = mfma4(afc[s], okc ? bf[t] : 0.0f, acc0[q][t]);
                     }
             }
+#pragma unroll
+            for (int s = 0; s < 4; ++s) afc[s] = afn[s];
         }
         __syncthreads();
         spill_pass1(Gs, R1, kw1, gs1, x, j);
         __syncthreads();
+        load_af(0, afc);
         for (int wsrc = 0; wsrc < NW8; ++wsrc) {
             const long long c0 = wg_col0 + wsrc * 16;
             if (c0 >= A.ncol) break;
+            load_af(wsrc + 1 < NW8 ? wsrc + 1 : wsrc, afn);
             const float *Gsrc = smem + (size_t)wsrc * 16 * GS0;
 #pragma unroll
             for (int s = 0; s < 4; ++s) {
-                const long long col = c0 + 4 * s + j;
-                const bool okc = col < A.ncol;
-                const float af = okc ? A.gout[col * A.cout + o0 + 16 * mi + x] : 0.0f;
+                const bool okc = c0 + 4 * s + j < A.ncol;
 #pragma unroll
                 for (int q = 0; q < 4; ++q) {
                     const int qq = ng * q1n + q;
                     if (q < q1n && qq < nq1) {
                         const f32x4 bf = *reinterpret_cast<const f32x4 *>(Gsrc + (4 * s + j) * gs1 + 64 * qq + 4 * x);
 #pragma unroll
-                        for (int t = 0; t < 4; ++t) acc1[q][t] = mfma4(af, okc ? bf[t] : 0.0f, acc1[q][t]);
+                        for (int t = 0; t < 4; ++t) acc1[q][t] = mfma4(afc[s], okc ? bf[t] : 0.0f, acc1[q][t]);
                     }
                 }
             }
+#pragma unroll
+            for (int s = 0; s < 4; ++s) afc[s] = afn[s];
         }
     }
     // lane (x, j), register r -> o = o0 + 16*mi + 4j + r;  tile (q, t), lane x -> position p = 64*quad + 4x + t;
