@@ -38,7 +38,9 @@ extern "C" const char *epn_strerror(int code) {
     }
 }
 
-extern "C" int epn_inter_is_fused(const epn_inter_desc *d) { return d && use_mfma(d) ? 1 : 0; }
+extern "C" int epn_inter_is_fused(const epn_inter_desc *d) {
+    return d && (use_mfma(d) || (inter_c1_fwd_ok(d) && !force_generic())) ? 1 : 0;
+}
 
 extern "C" int epn_intra_is_fused(int na, int kn, int cin, int cout) {
     return intra_uses_mfma(na, kn, cin, cout) && !force_generic() ? 1 : 0;
@@ -97,6 +99,8 @@ extern "C" int epn_inter_so3conv_fwd_f32(const epn_inter_desc *d, const float *f
         if (rc) return rc;
         return launch_inter_fwd_mfma(d, base + ws.rk4_off, base + ws.beta_off, feats_cl, W, out_cl, st);
     }
+    if (inter_c1_fwd_ok(d) && !force_generic())
+        return launch_inter_c1_fwd(d, base + ws.rk_off, feats_cl, W, out_cl, st);
     float *G = base + ws.big_off;
     rc = launch_inter_group(d, base + ws.rk_off, feats_cl, G, st);
     if (rc) return rc;
@@ -146,6 +150,8 @@ extern "C" int epn_inter_so3conv_bwd_weight_f32(const epn_inter_desc *d, const f
         return launch_inter_bwd_weight_mfma(d, base + ws.rk4_off, base + ws.beta_off, feats_cl, grad_out_cl, grad_W,
                                             st);
     }
+    if (inter_c1_bwd_weight_ok(d) && !force_generic())
+        return launch_inter_c1_bwd_weight(d, base + ws.rk_off, feats_cl, grad_out_cl, grad_W, st);
     float *G = base + ws.big_off;
     rc = launch_inter_group(d, base + ws.rk_off, feats_cl, G, st);
     if (rc) return rc;

@@ -46,6 +46,14 @@ int launch_intra_bwd_data_generic(const float *dOut, const int32_t *iidx, const 
 int launch_intra_bwd_weight_generic(const float *feats, const float *dOut, const int32_t *iidx, size_t npts, int na,
                                     int kn, int cin, int cout, float *dW, hipStream_t st);
 
+// inter_c1.hip (single input channel: the first layer of every shipped model)
+bool inter_c1_fwd_ok(const epn_inter_desc *d);
+bool inter_c1_bwd_weight_ok(const epn_inter_desc *d);
+int launch_inter_c1_fwd(const epn_inter_desc *d, const float *rk, const float *feats, const float *W, float *out,
+                        hipStream_t st);
+int launch_inter_c1_bwd_weight(const epn_inter_desc *d, const float *rk, const float *feats, const float *dOut,
+                               float *dW, hipStream_t st);
+
 // inter_mfma.hip / intra_mfma.hip (fused MFMA kernels; cin, cout multiples of 16)
 int launch_inter_tables_mfma(const epn_inter_desc *d, const float *rk, float *rk4, float *beta, hipStream_t st);
 int launch_inter_fwd_mfma(const epn_inter_desc *d, const float *rk4, const float *beta, const float *feats,

@@ -1,0 +1,191 @@
+// InterSO3Conv for a single input channel (cin = 1): the first layer of every shipped model, whose input is the
+// occupancy feature of get_occupancy_features (vgtk/vgtk/so3conv/functional.py:25-44).  With one channel the layer
+// is not matrix work (24 grouped values and a [cout x 24] weight per column): it is bound by the weight generation
+// on the VALU and by the output write.  One lane owns one column (b, p, a):
+//   G[k]   = sum_n F[idx[n], a] * relu(1 - |g_n - R_a kappa_k|^2 / sigma)        (functional.py:190-200, as written)
+//   out[o] = sum_k W[o][k] * G[k]                                                  (modules.py:52)
+// The weight gradient reduces dOut (x) G over all columns with MFMAs (M = kernel point, N = output channel,
+// contraction = columns), the grouped values passing through LDS once.
+#include "conv_internal.h"
+
+namespace epn {
+namespace {
+
+struct C1Args {
+    const float *xyz, *new_xyz;
+    const int32_t *idx;
+    const float *rk;      // [na][ks][3]
+    const float *feats;   // [b][p1][na]  (cin = 1)
+    const float *W;       // fwd: [cout][ks]
+    const float *gout;    // bwd: [ncol][cout]
+    float *out;           // fwd: [ncol][cout];  bwd: dW [cout][ks]
+    float sigma_inv;
+    int p1, p2, nn, na, ks, cout;
+    long long ncol;
+    int groups_per_wg;
+};
+
+// grouped values of one column into g[0..ks)
+__device__ __forceinline__ void group_column(const C1Args &A, long long col, float (&g)[EPN_KS_MAX]) {
+    const int a = (int)(col % A.na);
+    const long long pt = col / A.na;
+    const int bb = (int)(pt / A.p2), pp = (int)(pt - (long long)bb * A.p2);
+    float rx[EPN_KS_MAX], ry[EPN_KS_MAX], rz[EPN_KS_MAX];
+#pragma unroll
+    for (int k = 0; k < EPN_KS_MAX; ++k) {
+        const float *e = A.rk + ((size_t)a * A.ks + (k < A.ks ? k : 0)) * 3;
+        rx[k] = e[0]; ry[k] = e[1]; rz[k] = e[2];
+        g[k] = 0.f;
+    }
+    const int32_t *row = A.idx + ((size_t)bb * A.p2 + pp) * A.nn;
+    const float *s = A.xyz + (size_t)bb * 3 * A.p1;
+    const float *c = A.new_xyz + (size_t)bb * 3 * A.p2;
+    const float cx = c[pp], cy = c[A.p2 + pp], cz = c[2 * A.p2 + pp];
+    const float *f = A.feats + ((size_t)bb * A.p1) * A.na + a;
+    for (int n = 0; n < A.nn; ++n) {
+        const int q = row[n];
+        if (q < 0 || q >= A.p1) continue;   // shadow index: zero feature row (spconv/functional.py:91-95)
+        const float gx = s[q] - cx, gy = s[A.p1 + q] - cy, gz = s[2 * A.p1 + q] - cz;
+        const float fv = f[(size_t)q * A.na];
+#pragma unroll
+        for (int k = 0; k < EPN_KS_MAX; ++k) {
+            if (k < A.ks) {
+                const float dx = gx - rx[k], dy = gy - ry[k], dz = gz - rz[k];
+                const float w = fmaxf(1.0f - (dx * dx + dy * dy + dz * dz) * A.sigma_inv, 0.0f);
+                g[k] += fv * w;
+            }
+        }
+    }
+}
+
+__global__ __launch_bounds__(256) void inter_c1_fwd_kernel(C1Args A) {
+    extern __shared__ __attribute__((aligned(16))) float Ws[];   // [cout][ks]
+    for (int i = threadIdx.x; i < A.cout * A.ks; i += blockDim.x) Ws[i] = A.W[i];
+    __syncthreads();
+    const long long col = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (col >= A.ncol) return;
+    float g[EPN_KS_MAX];
+    group_column(A, col, g);
+    float *o = A.out + col * A.cout;
+    for (int o4 = 0; o4 < A.cout; o4 += 4) {   // cout % 4 == 0 (launcher)
+        f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int k = 0; k < EPN_KS_MAX; ++k) {
+            if (k < A.ks) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) acc[r] += Ws[(o4 + r) * A.ks + k] * g[k];   // LDS broadcast reads
+            }
+        }
+        *reinterpret_cast<f32x4 *>(o + o4) = acc;
+    }
+}
+
+__device__ __forceinline__ f32x4 mfma4(float a, float b, f32x4 c) {
+    return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0);
+}
+
+// dW[o][k] = sum_col dOut[col][o] * G[col][k];  4 waves, each wave contracts its own 64 columns per group.
+__global__ __launch_bounds__(256) void inter_c1_bwd_weight_kernel(C1Args A) {
+    __shared__ float Gs[256][EPN_KS_MAX + 1];   // [column of the group][kernel point], zero padded to 32
+    const int lane = threadIdx.x & 63;
+    const int wave = threadIdx.x >> 6;
+    const int x = lane & 15, j = lane >> 4;
+    const int NTO = A.cout >> 4;   // <= 4 (launcher)
+    f32x4 acc[2][4];
+#pragma unroll
+    for (int m = 0; m < 2; ++m)
+#pragma unroll
+        for (int n = 0; n < 4; ++n) acc[m][n] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    for (int it = 0; it < A.groups_per_wg; ++it) {
+        const long long base = ((long long)blockIdx.x * A.groups_per_wg + it) * 256;
+        if (base >= A.ncol) break;
+        const long long col = base + threadIdx.x;
+        float g[EPN_KS_MAX];
+        if (col < A.ncol) {
+            group_column(A, col, g);
+        } else {
+#pragma unroll
+            for (int k = 0; k < EPN_KS_MAX; ++k) g[k] = 0.f;
+        }
+        // only this wave reads the rows it writes: wave-level ordering is enough
+#pragma unroll
+        for (int k = 0; k < EPN_KS_MAX; ++k) Gs[threadIdx.x][k] = k < A.ks ? g[k] : 0.f;
+        __builtin_amdgcn_wave_barrier();
+        const long long wbase = base + wave * 64;
+#pragma unroll 4
+        for (int s = 0; s < 16; ++s) {   // contraction step: columns wbase + 4s + j
+            const long long cc = wbase + 4 * s + j;
+            const bool ok = cc < A.ncol;
+            float bf[4];
+#pragma unroll
+            for (int n = 0; n < 4; ++n) bf[n] = (n < NTO && ok) ? A.gout[cc * A.cout + 16 * n + x] : 0.0f;
+#pragma unroll
+            for (int m = 0; m < 2; ++m) {
+                const float af = Gs[wave * 64 + 4 * s + j][16 * m + x];
+#pragma unroll
+                for (int n = 0; n < 4; ++n)
+                    if (n < NTO) acc[m][n] = mfma4(af, bf[n], acc[m][n]);
+            }
+        }
+        __builtin_amdgcn_wave_barrier();
+    }
+    // acc[m][n]: lane (x = o within tile n, j), register r -> k = 16m + 4j + r
+#pragma unroll
+    for (int m = 0; m < 2; ++m)
+#pragma unroll
+        for (int n = 0; n < 4; ++n)
+            if (n < NTO)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int k = 16 * m + 4 * j + r;
+                    if (k < A.ks) atomicAdd(A.out + (size_t)(16 * n + x) * A.ks + k, acc[m][n][r]);
+                }
+}
+
+C1Args make_c1(const epn_inter_desc *d, const float *rk) {
+    C1Args A;
+    A.xyz = d->xyz; A.new_xyz = d->new_xyz; A.idx = d->ball_idx; A.rk = rk;
+    A.feats = nullptr; A.W = nullptr; A.gout = nullptr; A.out = nullptr;
+    A.sigma_inv = 1.0f / d->sigma;
+    A.p1 = d->p1; A.p2 = d->p2; A.nn = d->nn; A.na = d->na; A.ks = d->ks; A.cout = d->cout;
+    A.ncol = (long long)d->b * d->p2 * d->na;
+    A.groups_per_wg = 1;
+    return A;
+}
+
+}  // namespace
+
+bool inter_c1_fwd_ok(const epn_inter_desc *d) {
+    return d->cin == 1 && !d->dense_w && d->ks <= EPN_KS_MAX && d->cout % 4 == 0 &&
+           (size_t)d->cout * d->ks * sizeof(float) <= 48 * 1024;
+}
+
+bool inter_c1_bwd_weight_ok(const epn_inter_desc *d) {
+    return d->cin == 1 && !d->dense_w && d->ks <= EPN_KS_MAX && d->cout % 16 == 0 && d->cout <= 64;
+}
+
+int launch_inter_c1_fwd(const epn_inter_desc *d, const float *rk, const float *feats, const float *W, float *out,
+                        hipStream_t st) {
+    C1Args A = make_c1(d, rk);
+    A.feats = feats; A.W = W; A.out = out;
+    const unsigned grid = (unsigned)((A.ncol + 255) / 256);
+    hipLaunchKernelGGL(inter_c1_fwd_kernel, dim3(grid), dim3(256), (size_t)d->cout * d->ks * sizeof(float), st, A);
+    EPN_CHECK_LAUNCH();
+    return 0;
+}
+
+int launch_inter_c1_bwd_weight(const epn_inter_desc *d, const float *rk, const float *feats, const float *dOut,
+                               float *dW, hipStream_t st) {
+    C1Args A = make_c1(d, rk);
+    A.feats = feats; A.gout = dOut; A.out = dW;
+    const long long groups = (A.ncol + 255) / 256;
+    long long wgs = groups < 2048 ? groups : 2048;
+    A.groups_per_wg = (int)((groups + wgs - 1) / wgs);
+    const unsigned grid = (unsigned)((groups + A.groups_per_wg - 1) / A.groups_per_wg);
+    hipLaunchKernelGGL(inter_c1_bwd_weight_kernel, dim3(grid), dim3(256), 0, st, A);
+    EPN_CHECK_LAUNCH();
+    return 0;
+}
+
+}  // namespace epn

@@ -258,7 +258,7 @@ def test_inter_large_neighbourhoods_and_odd_widths(gpu, vgtk_alias, cin, cout, s
 
 
 def test_fused_dispatch_covers_the_modelnet_schedule(gpu):
-    """Every cin >= 16 layer of the cls schedule must run on the fused MFMA kernels, not the generic fallback."""
+    """Every layer of the cls schedule must run on a dedicated fused kernel, not the generic fallback."""
     import ctypes
     from epn_pointcloud_amd import _lib, schedule as S
     lib = _lib.get_lib()
@@ -267,7 +267,7 @@ def test_fused_dispatch_covers_the_modelnet_schedule(gpu):
         d = _lib.InterDesc()
         d.b, d.p1, d.p2, d.nn, d.na, d.ks, d.cin, d.cout = 32, p, p // l.stride, l.nn, 60, 24, l.cin, l.cout
         d.sigma = l.sigma
-        assert lib.epn_inter_is_fused(ctypes.byref(d)) == (1 if l.cin >= 16 else 0)
+        assert lib.epn_inter_is_fused(ctypes.byref(d)) == 1      # cin = 1 -> dedicated kernel, cin >= 16 -> MFMA
         assert lib.epn_intra_is_fused(60, 12, l.cout, l.cout) == 1
         p //= l.stride
 
