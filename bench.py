@@ -44,6 +44,9 @@ def parse():
                     help="torch CPU threads of the baseline (16 measured fastest of {16,48,256} on the 2x EPYC 9575F "
                          "GPU host: the materialising reference algorithm is memory-bound and slows down with more)")
     ap.add_argument("--forward-only", action="store_true")
+    ap.add_argument("--model", default="cls", choices=["cls", "reg", "inv"],
+                    help="cls = BASELINE configs[1] (the headline metric); reg / inv = the layer schedules of configs[2] / "
+                         "[3] in fp32 (their bf16 variants are not implemented yet)")
     return ap.parse_args()
 
 
@@ -81,13 +84,17 @@ def main():
     dev = torch.device("cuda", local_rank)
     torch.cuda.set_device(dev)
 
-    layers = S.cls_so3net_schedule(args.points)
+    if args.model == "inv" and args.points == 1024:
+        args.points = 2048                                  # 3DMatch patches (generate_eval.py:26,68)
+    layers = {"cls": S.cls_so3net_schedule, "reg": S.reg_so3net_schedule,
+              "inv": S.inv_so3net_schedule}[args.model](args.points)
     torch.manual_seed(2913)
-    model = S.HotPathBackbone(layers).to(dev).train()
+    model = S.HotPathBackbone(layers, norm="BatchNorm2d" if args.model == "cls" else None).to(dev).train()
     dp.broadcast_parameters(model)
     params = [p for p in model.parameters() if p.requires_grad]
     opt = torch.optim.Adam(params, lr=1e-3)
-    pts = S.synthetic_clouds(args.batch, args.points, dev, seed=2913 + rank)   # resident in HBM before timing
+    scale = 0.4 if args.model == "inv" else 1.0            # 3DMatch search_radius (options.py:30)
+    pts = S.synthetic_clouds(args.batch, args.points, dev, seed=2913 + rank, scale=scale)   # resident in HBM
 
     def step():
         opt.zero_grad(set_to_none=True)
@@ -139,19 +146,22 @@ def main():
                     "launches": d["launches"], "avg_launch_ms": round(d["ms"] / d["launches"], 4),
                     "per_kernel_ms_per_step": {k: round(v["ms"] / args.steps, 3) for k, v in sorted(agg.items())}}
         out = {
-            "metric": "point-clouds/sec fwd+bwd, ModelNet40 N=1024 A=60" if not args.forward_only
-                      else "point-clouds/sec fwd, ModelNet40 N=1024 A=60",
+            "metric": (f"point-clouds/sec {'fwd' if args.forward_only else 'fwd+bwd'}, "
+                       + ("ModelNet40" if args.model != "inv" else "3DMatch") + f" N={args.points} A=60"),
             "value": round(args.batch * world * args.steps / dt, 3), "unit": "point-clouds/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(dt / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": "ModelNet40 cls backbone (cls_so3net_pn, 7 separable SO3 blocks), "
-                                   f"B={args.batch}/GPU N={args.points} K=32/16 A=60 fp32, fwd+bwd+Adam",
+            "config": {"workload": {"cls": "ModelNet40 cls backbone (cls_so3net_pn, 7 separable SO3 blocks)",
+                                    "reg": "ModelNet40 rotation backbone (reg_so3net, 7 separable SO3 blocks)",
+                                    "inv": "3DMatch descriptor backbone (inv_so3net_pn, 8 separable SO3 blocks)"}[args.model]
+                                   + f", B={args.batch}/GPU N={args.points} K={'/'.join(str(k) for k in sorted({l.nn for l in layers}, reverse=True))} "
+                                   + f"A=60 fp32, {'fwd' if args.forward_only else 'fwd+bwd+Adam'}",
                        "global_batch": args.batch * world, "points": args.points, "anchors": 60,
                        "parallelism": f"dp{world}"},
             "roofline": roofline,
         }
-        if world == 1 and not args.no_cpu_baseline:
+        if world == 1 and not args.no_cpu_baseline and args.model == "cls":
             out["cpu_baseline"] = cpu_baseline(layers, model.state_dict(), args.points, args.cpu_clouds,
                                                args.cpu_threads)
         print(json.dumps(out), flush=True)

@@ -684,10 +684,14 @@ __global__ __launch_bounds__(64 * NW8) void inter_fwd8_kernel(InterArgs A) {
     };
     auto contract = [&](int nsub, int gstride, int step0) {
         for (int sub = 0; sub < nsub; ++sub) {
+#if EPN_ABLATE != 3
             __syncthreads();   // Ws free again; this wave's tile writes are ordered before its reads
+#endif
             store_w();
             if (step0 + sub + 1 < nchunk * spc) fetch_w(step0 + sub + 1);
+#if EPN_ABLATE != 3
             __syncthreads();
+#endif
             // software-pipelined over the (g, m) sequence: the W fragment of the next step (and the G fragment of
             // the next g) are read from LDS while the current step's four MFMAs issue
             const int ng = A.wk >> 4;

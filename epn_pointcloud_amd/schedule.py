@@ -21,10 +21,10 @@ from .vgtk import spconv as zptk
 Layer = namedtuple("Layer", "cin cout stride radius sigma nn lazy")
 
 
-def cls_so3net_schedule(input_num=1024, mlps=((64, 64), (128, 128), (256, 256), (256,)), strides=(2, 2, 2, 2),
-                        initial_radius_ratio=0.2, sampling_ratio=0.4, sampling_density=0.5, sigma_ratio=0.5,
-                        input_radius=1.0):
-    """cls_so3net_pn.build_model (SPConvNets/models/cls_so3net_pn.py:43-150), ModelNet40 classification."""
+def _schedule(input_num, mlps, strides, initial_radius_ratio, sampling_ratio, sampling_density, sigma_ratio,
+              input_radius, sigma_by_stride, scale_first_neighbor):
+    """Common arithmetic of the three model builders (SPConvNets/models/{cls_so3net_pn,reg_so3net,inv_so3net_pn}.py):
+    radii / sigmas / neighbour counts per layer from a handful of ratios."""
     strides = list(strides)
     if input_num > 1024:
         sampling_ratio /= (input_num / 1024)
@@ -34,12 +34,14 @@ def cls_so3net_schedule(input_num=1024, mlps=((64, 64), (128, 128), (256, 256), 
     radius_ratio = [initial_radius_ratio * m ** sampling_density for m in mult]
     radii = [r * input_radius for r in radius_ratio]
     sigma = [sigma_ratio * radii[0] ** 2]
-    for i in range(len(strides)):
-        sigma.append(sigma[i] * 2)
+    for i, st in enumerate(strides):
+        sigma.append(sigma[i] * (st if sigma_by_stride else 2))
     layers, dim_in = [], 1
     for i, block in enumerate(mlps):
         for j, dim_out in enumerate(block):
             neighbor = int(sampling_ratio * num_centers[i] * radius_ratio[i] ** (1 / sampling_density))
+            if scale_first_neighbor and i == 0 and j == 0:
+                neighbor *= int(input_num / 1024)
             if j == 0:
                 stride, nidx, neighbor = strides[i], (i if i == 0 else i + 1), neighbor * 2
             else:
@@ -47,6 +49,25 @@ def cls_so3net_schedule(input_num=1024, mlps=((64, 64), (128, 128), (256, 256), 
             layers.append(Layer(dim_in, dim_out, stride, radii[nidx], sigma[nidx], neighbor, i != 0 or j != 0))
             dim_in = dim_out
     return layers
+
+
+def cls_so3net_schedule(input_num=1024):
+    """cls_so3net_pn.build_model (SPConvNets/models/cls_so3net_pn.py:43-150), ModelNet40 classification."""
+    return _schedule(input_num, ((64, 64), (128, 128), (256, 256), (256,)), (2, 2, 2, 2), 0.2, 0.4, 0.5, 0.5, 1.0,
+                     False, False)
+
+
+def reg_so3net_schedule(input_num=1024):
+    """reg_so3net.build_model (SPConvNets/models/reg_so3net.py:52-150), ModelNet40 rotation estimation (pairs of
+    clouds are concatenated along the batch axis, reg_so3net.py:31-33)."""
+    return _schedule(input_num, ((32, 32), (64, 64), (128, 128), (256,)), (2, 2, 2, 2), 0.2, 0.8, 0.5, 0.5, 1.0,
+                     False, False)
+
+
+def inv_so3net_schedule(input_num=2048, search_radius=0.4):
+    """inv_so3net_pn.build_model (SPConvNets/models/inv_so3net_pn.py:43-150), 3DMatch local-patch descriptor."""
+    return _schedule(input_num, ((32, 32), (64, 64), (128, 128), (128, 128)), (2, 2, 2, 2), 0.2, 0.8, 0.5, 0.5,
+                     search_radius, True, True)
 
 
 def scaled(layers, width_div):
@@ -65,16 +86,19 @@ class SeparableBlock(nn.Module):
     batch-norm and 1x1 convolution: measured faster than hand-composed channels-last torch ops; fusing them into the
     conv epilogues is SURVEY 8f.1, "next")."""
 
-    def __init__(self, l, kanchor=60):
+    def __init__(self, l, kanchor=60, norm="BatchNorm2d"):
         super().__init__()
+        # norm=None -> InstanceNorm2d(affine=False), the default of InterSO3ConvBlock / SeparableSO3ConvBlock
+        # (base_so3conv.py:107,191) used by the rotation and 3DMatch models; the cls model passes 'BatchNorm2d'
+        mk = (lambda c: nn.InstanceNorm2d(c, affine=False)) if norm is None else getattr(nn, norm)
         self.stride = l.stride
         self.inter = sptk.InterSO3Conv(l.cin, l.cout, 1, l.stride, l.radius, l.sigma, l.nn,
                                        lazy_sample=l.lazy, kanchor=kanchor)
-        self.inter_norm = nn.BatchNorm2d(l.cout)
+        self.inter_norm = mk(l.cout)
         self.intra = sptk.IntraSO3Conv(l.cout, l.cout)
         self.intra_norm = nn.InstanceNorm2d(l.cout, affine=False)
         self.skip_conv = nn.Conv2d(l.cin, l.cout, 1)
-        self.norm = nn.BatchNorm2d(l.cout)
+        self.norm = mk(l.cout)
 
     def forward(self, x):
         skip = x.feats
@@ -91,10 +115,10 @@ class SeparableBlock(nn.Module):
 class HotPathBackbone(nn.Module):
     """preprocess_input (ones features) -> chain of separable blocks.  Input [b, n, 3] point clouds."""
 
-    def __init__(self, layers, kanchor=60):
+    def __init__(self, layers, kanchor=60, norm="BatchNorm2d"):
         super().__init__()
         self.kanchor = kanchor
-        self.blocks = nn.ModuleList([SeparableBlock(l, kanchor) for l in layers])
+        self.blocks = nn.ModuleList([SeparableBlock(l, kanchor, norm) for l in layers])
 
     def forward(self, pts):
         xyz = pts.permute(0, 2, 1).contiguous()

@@ -298,3 +298,20 @@ def test_separable_block_vs_reference_golden(gpu, vgtk_alias):
     y = blk(x)
     assert tuple(y.feats.shape) == (2, 8, 128, 60)
     assert (y.feats.detach().cpu() - T(g["out"])).abs().max().item() < TOL
+
+
+@pytest.mark.parametrize("name,n,scale", [("reg", 1024, 1.0), ("inv", 2048, 0.4)])
+def test_other_model_schedules_run(gpu, vgtk_alias, name, n, scale):
+    """Layer schedules of BASELINE configs[2]/[3] (rotation estimation, 3DMatch; fp32 here): K = 64/128 neighbourhoods,
+    stride-4 first layer, InstanceNorm blocks -- one forward + backward, finite and correctly shaped."""
+    from epn_pointcloud_amd import schedule as S
+    layers = S.scaled({"reg": S.reg_so3net_schedule, "inv": S.inv_so3net_schedule}[name](n), 2)
+    torch.manual_seed(3)
+    model = S.HotPathBackbone(layers, norm=None).to(gpu).train()
+    pts = S.synthetic_clouds(2, n, gpu, seed=77, scale=scale)
+    y = model(pts)
+    assert tuple(y.feats.shape) == (2, layers[-1].cout, 64, 60)
+    y.feats.square().mean().backward()
+    for p in model.parameters():
+        assert p.grad is not None and torch.isfinite(p.grad).all()
+    assert torch.isfinite(y.feats).all() and float(y.feats.detach().abs().max()) > 0
