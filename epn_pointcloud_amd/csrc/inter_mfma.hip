@@ -638,7 +638,7 @@ __global__ __launch_bounds__(64 * NW8) void inter_fwd8_kernel(InterArgs A) {
     float *Gs = smem + (size_t)wave * 16 * GS0;
     float *Ws = smem + (size_t)NW8 * 16 * GS0;
     const int wss = A.wk + 4;
-    const int MT = A.cout >> 4;
+    constexpr int MT = MTMAX;   // the launcher only takes cout == 16 * MTMAX: straight-line MFMA code, no per-tile branch
     const int kw1 = A.ks - 16, gs1 = 16 * kw1 + 4;
     const long long col0 = ((long long)blockIdx.x * NW8 + wave) * 16;
     const int CK = A.cin * A.ks;
@@ -695,8 +695,13 @@ __global__ __launch_bounds__(64 * NW8) void inter_fwd8_kernel(InterArgs A) {
             // software-pipelined over the (g, m) sequence: the W fragment of the next step (and the G fragment of
             // the next g) are read from LDS while the current step's four MFMAs issue
             const int ng = A.wk >> 4;
+#if EPN_ABLATE == 4   // timing only: bank-conflict-free (wrong) fragment addresses
+            const float *gsrc = Gs + lane * 4;
+            const float *wsrc = Ws + lane * 4;
+#else
             const float *gsrc = Gs + x * gstride + sub * A.wk + 4 * j;
             const float *wsrc = Ws + x * wss + 4 * j;
+#endif
             f32x4 bf = *reinterpret_cast<const f32x4 *>(gsrc);
             f32x4 af = *reinterpret_cast<const f32x4 *>(wsrc);
             for (int g = 0; g < ng; ++g) {
@@ -1047,7 +1052,8 @@ int launch_inter_fwd_mfma(const epn_inter_desc *d, const float *rk4, const float
     (void)beta;
     InterArgs A = make_args(d, rk4);
     A.feats = feats; A.W = W; A.out = out;
-    if (use8(d)) {
+    const int mt_ = d->cout / 16;
+    if (use8(d) && (mt_ == 1 || mt_ == 2 || mt_ == 4 || mt_ == 8 || mt_ == 16)) {
         const int kw1 = d->ks - 16;
         const size_t gsb = (size_t)NW8 * 16 * GS0 * sizeof(float);
         int wk = 16;
@@ -1066,9 +1072,11 @@ int launch_inter_fwd_mfma(const epn_inter_desc *d, const float *rk4, const float
     } while (0)
         const int mt = d->cout / 16;
         if (d->nn <= 16) {
-            if (mt <= 4) EPN_FWD8(1, 4); else if (mt <= 8) EPN_FWD8(1, 8); else EPN_FWD8(1, 16);
+            if (mt == 4) EPN_FWD8(1, 4); else if (mt == 8) EPN_FWD8(1, 8); else if (mt == 16) EPN_FWD8(1, 16);
+            else if (mt == 2) EPN_FWD8(1, 2); else EPN_FWD8(1, 1);
         } else {
-            if (mt <= 4) EPN_FWD8(2, 4); else if (mt <= 8) EPN_FWD8(2, 8); else EPN_FWD8(2, 16);
+            if (mt == 4) EPN_FWD8(2, 4); else if (mt == 8) EPN_FWD8(2, 8); else if (mt == 16) EPN_FWD8(2, 16);
+            else if (mt == 2) EPN_FWD8(2, 2); else EPN_FWD8(2, 1);
         }
 #undef EPN_FWD8
         EPN_CHECK_LAUNCH();
