@@ -877,7 +877,7 @@ __global__ __launch_bounds__(64 * NW8) void inter_bwd_weight8_kernel(InterArgs A
 // dG rows of its tile (dG = W^T dOut), the pair meets at a barrier, then each wave runs the per-column tail
 // (regenerated weights, contraction over k, atomic scatter) for 8 of the 16 columns.  Same work as the 4-wave
 // kernel, but 2 waves per SIMD and W^T staged once for 64 columns.
-template <int NT, int KT>
+template <int NT, int KT, int MH>   // MH = dG row tiles per wave = ks/2 (launcher: ks even), compile-time -> branch-free MFMA block
 __global__ __launch_bounds__(64 * NW8) void inter_bwd_data8_kernel(InterArgs A) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int lane = threadIdx.x & 63;
@@ -889,10 +889,7 @@ __global__ __launch_bounds__(64 * NW8) void inter_bwd_data8_kernel(InterArgs A) 
     float *Gs = smem + (size_t)tile * 16 * gss;
     float *Ws = smem + (size_t)4 * 16 * gss;
     const int wss = 20;
-    const int MTK = ckl >> 4;
-    const int MH = (MTK + 1) >> 1;                 // dG row tiles per wave (<= 16)
     const int m0 = half * MH;
-    const int mcnt = MTK - m0 < MH ? MTK - m0 : MH;
     const long long col0 = ((long long)blockIdx.x * 4 + tile) * 16;
     const bool active = col0 < A.ncol;
     long long colx = col0 + x;
@@ -935,9 +932,9 @@ __global__ __launch_bounds__(64 * NW8) void inter_bwd_data8_kernel(InterArgs A) 
     };
     fetch(0);
     for (int ct = 0; ct < nchunk; ++ct) {
-        f32x4 dg[16];
+        f32x4 dg[MH];
 #pragma unroll
-        for (int m = 0; m < 16; ++m) dg[m] = f32x4{0.f, 0.f, 0.f, 0.f};
+        for (int m = 0; m < MH; ++m) dg[m] = f32x4{0.f, 0.f, 0.f, 0.f};
         for (int og = 0; og < nog; ++og) {
             __syncthreads();
 #pragma unroll
@@ -949,17 +946,14 @@ __global__ __launch_bounds__(64 * NW8) void inter_bwd_data8_kernel(InterArgs A) 
             if (ct * nog + og + 1 < nchunk * nog) fetch(ct * nog + og + 1);
             __syncthreads();
 #pragma unroll
-            for (int m = 0; m < 16; ++m) {
-                if (m < mcnt) {
-                    const f32x4 af = *reinterpret_cast<const f32x4 *>(Ws + (16 * (m0 + m) + x) * wss + 4 * j);
+            for (int m = 0; m < MH; ++m) {
+                const f32x4 af = *reinterpret_cast<const f32x4 *>(Ws + (16 * (m0 + m) + x) * wss + 4 * j);
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) dg[m] = mfma4(af[r], bf[r], dg[m]);
-                }
+                for (int r = 0; r < 4; ++r) dg[m] = mfma4(af[r], bf[r], dg[m]);
             }
         }
 #pragma unroll
-        for (int m = 0; m < 16; ++m)
-            if (m < mcnt) *reinterpret_cast<f32x4 *>(Gs + x * gss + 16 * (m0 + m) + 4 * j) = dg[m];
+        for (int m = 0; m < MH; ++m) *reinterpret_cast<f32x4 *>(Gs + x * gss + 16 * (m0 + m) + 4 * j) = dg[m];
         __syncthreads();   // both halves of every tile are in LDS
         if (active) {
             scatter_segment<NT, KT>(A, s0, ct, x, j, Gs, gss);
@@ -1116,18 +1110,20 @@ int launch_inter_bwd_data_mfma(const epn_inter_desc *d, const float *rk4, const 
     A.W = wt; A.gout = dOut; A.out = dF;
     {
         const char *e8 = std::getenv("EPN_INTER_V2");
-        if (!(e8 && e8[0] == '1') && d->na >= 16 && d->nn <= 32) {
+        if (!(e8 && e8[0] == '1') && d->na >= 16 && d->nn <= 32 && (d->ks == 24 || d->ks == 32 || d->ks == 16)) {
             const size_t lds8 = (size_t)4 * 16 * (16 * d->ks + 4) * sizeof(float) + (size_t)16 * d->ks * 20 * sizeof(float);
             const unsigned grid8 = (unsigned)((A.ncol + 63) / 64);
-#define EPN_BD8(NT_, KT_)                                                                                 \
-    do {                                                                                                  \
-        int rc_ = set_lds(inter_bwd_data8_kernel<NT_, KT_>, lds8);                                        \
-        if (rc_) return rc_;                                                                              \
-        hipLaunchKernelGGL((inter_bwd_data8_kernel<NT_, KT_>), dim3(grid8), dim3(64 * NW8), lds8, st, A); \
+#define EPN_BD8(NT_, KT_, MH_)                                                                                 \
+    do {                                                                                                       \
+        int rc_ = set_lds(inter_bwd_data8_kernel<NT_, KT_, MH_>, lds8);                                        \
+        if (rc_) return rc_;                                                                                   \
+        hipLaunchKernelGGL((inter_bwd_data8_kernel<NT_, KT_, MH_>), dim3(grid8), dim3(64 * NW8), lds8, st, A); \
     } while (0)
-            const int kt8 = (d->ks + 15) / 16;
-            if (d->nn <= 16) { if (kt8 == 1) EPN_BD8(1, 1); else EPN_BD8(1, 2); }
-            else { if (kt8 == 1) EPN_BD8(2, 1); else EPN_BD8(2, 2); }
+            if (d->nn <= 16) {
+                if (d->ks == 16) EPN_BD8(1, 1, 8); else if (d->ks == 24) EPN_BD8(1, 2, 12); else EPN_BD8(1, 2, 16);
+            } else {
+                if (d->ks == 16) EPN_BD8(2, 1, 8); else if (d->ks == 24) EPN_BD8(2, 2, 12); else EPN_BD8(2, 2, 16);
+            }
 #undef EPN_BD8
             EPN_CHECK_LAUNCH();
             return 0;
