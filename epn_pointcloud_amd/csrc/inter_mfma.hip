@@ -751,34 +751,33 @@ __global__ __launch_bounds__(64 * NW8) void inter_fwd8_kernel(InterArgs A) {
 // dW[o][ck] = sum_col dOut[col][o] G[ck][col]: workgroup = (one 16-channel chunk, one block of <= 128 output
 // channels, a run of 128-column tiles).  Pass 0 (k < 16): 16 ck tiles, wave w owns channels 2w, 2w+1; pass 1
 // (k >= 16): 16*kw1/16 tiles, wave w owns tile w (if it exists).
-template <int NT>
+template <int NT, int MO>   // MO = row tiles of the output-channel block (2, 4 or 8); ks == 24 (launcher)
 __global__ __launch_bounds__(64 * NW8) void inter_bwd_weight8_kernel(InterArgs A) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int x = lane & 15, j = lane >> 4;
     float *Gs = smem + (size_t)wave * 16 * GS0;
-    const int kw1 = A.ks - 16, gs1 = 16 * kw1 + 4;
+    constexpr int kw1 = 8, gs1 = 16 * kw1 + 4;
     const int ct = blockIdx.y;
     const int o0 = blockIdx.z * 128;
-    const int MO = (A.cout - o0 < 128 ? A.cout - o0 : 128) >> 4;   // row tiles of this block: 2, 4 or 8 (launcher)
     // Tile ownership: wave = (one row tile mi, one group ng of ck positions), so ONE dOut fragment per contraction
     // step feeds all of the wave's MFMAs, and the G fragments of four tiles come from one ds_read_b128: tile t of a
     // 64-position quad q covers the positions {64q + 4i + t}.
-    const int msplit = MO, nsplit = NW8 / MO;             // nsplit in {1, 2, 4}
+    constexpr int msplit = MO, nsplit = NW8 / MO;         // nsplit in {1, 2, 4}
     const int mi = wave % msplit, ng = wave / msplit;
-    const int q0n = 4 / nsplit;                           // pass-0 quads per wave (4, 2, 1)
-    const int nq1 = (16 * kw1) / 64;                      // pass-1 quads in total (2 for ks = 24)
-    const int q1n = (nq1 + nsplit - 1) / nsplit;          // per wave
+    constexpr int q0n = 4 / nsplit;                       // pass-0 quads per wave (4, 2, 1)
+    constexpr int nq1 = (16 * kw1) / 64;                  // pass-1 quads in total (2 for ks = 24)
+    constexpr int q1n = (nq1 + nsplit - 1) / nsplit;      // per wave
 
-    f32x4 acc0[4][4], acc1[4][4];   // [quad][tile in quad]
+    f32x4 acc0[q0n][4], acc1[q1n][4];   // [quad][tile in quad]
 #pragma unroll
-    for (int q = 0; q < 4; ++q)
+    for (int t = 0; t < 4; ++t) {
 #pragma unroll
-        for (int t = 0; t < 4; ++t) {
-            acc0[q][t] = f32x4{0.f, 0.f, 0.f, 0.f};
-            acc1[q][t] = f32x4{0.f, 0.f, 0.f, 0.f};
-        }
+        for (int q = 0; q < q0n; ++q) acc0[q][t] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int q = 0; q < q1n; ++q) acc1[q][t] = f32x4{0.f, 0.f, 0.f, 0.f};
+    }
 
     const long long tile0 = (long long)blockIdx.x * A.col_tiles_per_wg;
     for (int it = 0; it < A.col_tiles_per_wg; ++it) {
@@ -810,13 +809,12 @@ __global__ __launch_bounds__(64 * NW8) void inter_bwd_weight8_kernel(InterArgs A
             for (int s = 0; s < 4; ++s) {
                 const bool okc = c0 + 4 * s + j < A.ncol;
 #pragma unroll
-                for (int q = 0; q < 4; ++q)
-                    if (q < q0n) {
-                        const f32x4 bf = *reinterpret_cast<const f32x4 *>(Gsrc + (4 * s + j) * GS0 +
-                                                                          64 * (ng * q0n + q) + 4 * x);
+                for (int q = 0; q < q0n; ++q) {
+                    const f32x4 bf = *reinterpret_cast<const f32x4 *>(Gsrc + (4 * s + j) * GS0 +
+                                                                      64 * (ng * q0n + q) + 4 * x);
 #pragma unroll
-                        for (int t = 0; t < 4; ++t) acc0[q][t] = mfma4(afc[s], okc ? bf[t] : 0.0f, acc0[q][t]);
-                    }
+                    for (int t = 0; t < 4; ++t) acc0[q][t] = mfma4(afc[s], okc ? bf[t] : 0.0f, acc0[q][t]);
+                }
             }
 #pragma unroll
             for (int s = 0; s < 4; ++s) afc[s] = afn[s];
@@ -834,9 +832,9 @@ __global__ __launch_bounds__(64 * NW8) void inter_bwd_weight8_kernel(InterArgs A
             for (int s = 0; s < 4; ++s) {
                 const bool okc = c0 + 4 * s + j < A.ncol;
 #pragma unroll
-                for (int q = 0; q < 4; ++q) {
+                for (int q = 0; q < q1n; ++q) {
                     const int qq = ng * q1n + q;
-                    if (q < q1n && qq < nq1) {
+                    if (qq < nq1) {
                         const f32x4 bf = *reinterpret_cast<const f32x4 *>(Gsrc + (4 * s + j) * gs1 + 64 * qq + 4 * x);
 #pragma unroll
                         for (int t = 0; t < 4; ++t) acc1[q][t] = mfma4(afc[s], okc ? bf[t] : 0.0f, acc1[q][t]);
@@ -851,18 +849,19 @@ __global__ __launch_bounds__(64 * NW8) void inter_bwd_weight8_kernel(InterArgs A
     // pass 0: channel p / 16, k = p % 16;   pass 1: channel p / kw1, k = 16 + p % kw1
     const int CK = A.cin * A.ks;
 #pragma unroll
-    for (int q = 0; q < 4; ++q)
+    for (int t = 0; t < 4; ++t) {
 #pragma unroll
-        for (int t = 0; t < 4; ++t) {
-            if (q < q0n) {
-                const int p = 64 * (ng * q0n + q) + 4 * x + t;
-                const int ck0 = (16 * ct + (p >> 4)) * A.ks + (p & 15);
+        for (int q = 0; q < q0n; ++q) {
+            const int p = 64 * (ng * q0n + q) + 4 * x + t;
+            const int ck0 = (16 * ct + (p >> 4)) * A.ks + (p & 15);
 #pragma unroll
-                for (int r = 0; r < 4; ++r)
-                    atomicAdd(A.out + (size_t)(o0 + 16 * mi + 4 * j + r) * CK + ck0, acc0[q][t][r]);
-            }
+            for (int r = 0; r < 4; ++r)
+                atomicAdd(A.out + (size_t)(o0 + 16 * mi + 4 * j + r) * CK + ck0, acc0[q][t][r]);
+        }
+#pragma unroll
+        for (int q = 0; q < q1n; ++q) {
             const int qq = ng * q1n + q;
-            if (q < q1n && qq < nq1) {
+            if (qq < nq1) {
                 const int p = 64 * qq + 4 * x + t;
                 const int cl = p / kw1, kk = p - cl * kw1;
                 const int ck1 = (16 * ct + cl) * A.ks + 16 + kk;
@@ -871,6 +870,7 @@ __global__ __launch_bounds__(64 * NW8) void inter_bwd_weight8_kernel(InterArgs A
                     atomicAdd(A.out + (size_t)(o0 + 16 * mi + 4 * j + r) * CK + ck1, acc1[q][t][r]);
             }
         }
+    }
 }
 
 // Data gradient, 8 waves: a workgroup owns 4 column tiles, TWO waves per tile.  Each wave computes half of the
@@ -1148,8 +1148,9 @@ int launch_inter_bwd_weight_mfma(const epn_inter_desc *d, const float *rk4, cons
     (void)beta;
     InterArgs A = make_args(d, rk4);
     A.feats = feats; A.gout = dOut; A.out = dW;
-    const int tail_tiles = (d->cout % 128) / 16;   // row tiles of the last (partial) block of output channels
-    if (use8(d) && (16 * (d->ks - 16)) % 64 == 0 && (tail_tiles == 0 || tail_tiles == 2 || tail_tiles == 4)) {
+    // 8-wave kernel: every block of output channels must hold the same power-of-two number of row tiles
+    const int mo8 = d->cout >= 128 ? 8 : d->cout / 16;
+    if (use8(d) && d->ks == 24 && (d->cout % 128 == 0 || d->cout == 64 || d->cout == 32)) {
         const long long tiles8 = (A.ncol + 16 * NW8 - 1) / (16 * NW8);
         const int chunks8 = d->cin / 16, oblocks8 = (d->cout + 127) / 128;
         long long splits8 = (256 * 2 + chunks8 * oblocks8 - 1) / (chunks8 * oblocks8);
@@ -1158,15 +1159,19 @@ int launch_inter_bwd_weight_mfma(const epn_inter_desc *d, const float *rk4, cons
         A.col_tiles_per_wg = (int)((tiles8 + splits8 - 1) / splits8);
         const unsigned gx8 = (unsigned)((tiles8 + A.col_tiles_per_wg - 1) / A.col_tiles_per_wg);
         const size_t lds8 = (size_t)NW8 * 16 * GS0 * sizeof(float);
+#define EPN_BW8(NT_, MO_)                                                                                        \
+    do {                                                                                                         \
+        int rc_ = set_lds(inter_bwd_weight8_kernel<NT_, MO_>, lds8);                                             \
+        if (rc_) return rc_;                                                                                     \
+        hipLaunchKernelGGL((inter_bwd_weight8_kernel<NT_, MO_>), dim3(gx8, chunks8, oblocks8), dim3(64 * NW8),   \
+                           lds8, st, A);                                                                         \
+    } while (0)
         if (d->nn <= 16) {
-            int rc_ = set_lds(inter_bwd_weight8_kernel<1>, lds8);
-            if (rc_) return rc_;
-            hipLaunchKernelGGL((inter_bwd_weight8_kernel<1>), dim3(gx8, chunks8, oblocks8), dim3(64 * NW8), lds8, st, A);
+            if (mo8 == 8) EPN_BW8(1, 8); else if (mo8 == 4) EPN_BW8(1, 4); else EPN_BW8(1, 2);
         } else {
-            int rc_ = set_lds(inter_bwd_weight8_kernel<2>, lds8);
-            if (rc_) return rc_;
-            hipLaunchKernelGGL((inter_bwd_weight8_kernel<2>), dim3(gx8, chunks8, oblocks8), dim3(64 * NW8), lds8, st, A);
+            if (mo8 == 8) EPN_BW8(2, 8); else if (mo8 == 4) EPN_BW8(2, 4); else EPN_BW8(2, 2);
         }
+#undef EPN_BW8
         EPN_CHECK_LAUNCH();
         return 0;
     }
