@@ -24,11 +24,27 @@ if ROOT not in sys.path:
 
 MFMA_F32_PEAK_TFLOPS = 157.3   # /opt/skills/guides/MI355X_MICROARCH.md, "Peak FP32 (matrix)"
 
-KERNEL_OF = {  # C-ABI call -> dominant device kernel symbol launched by it (csrc/*.hip)
-    "inter_fwd": "epn::inter_fwd_kernel", "inter_bwd_data": "epn::inter_bwd_data_kernel",
-    "inter_bwd_weight": "epn::inter_bwd_weight_kernel", "intra_fwd": "epn::intra_gemm_kernel",
-    "intra_bwd_data": "epn::intra_gemm_kernel", "intra_bwd_weight": "epn::intra_bwd_weight_kernel",
+KERNEL_OF = {  # C-ABI call -> device kernel family it launches on this workload (csrc/*.hip; template variants summed)
+    "inter_fwd": "epn::inter_fwd8_kernel", "inter_bwd_data": "epn::inter_bwd_data8_kernel",
+    "inter_bwd_weight": "epn::inter_bwd_weight8_kernel", "intra_fwd": "epn::intra_gemm_kernel",
+    "intra_bwd_data": "epn::intra_gemm_kernel", "intra_bwd_weight": "epn::intra_bwd_weight_v4_kernel",
 }
+PMC_FILE = os.path.join(ROOT, "profiles", "r01_pmc_per_kernel.json")   # tools/collect_profiles.sh + pmc_summary.py
+
+
+def recorded_traffic(kernel_family):
+    """HBM bytes per launch of one kernel family from the committed rocprofv3 --pmc passes (FETCH_SIZE and WRITE_SIZE
+    in separate runs, x1024, read side doubled per MI355X_MICROARCH.md): PMC counters cannot be read live here."""
+    try:
+        pmc = json.load(open(PMC_FILE))
+    except OSError:
+        return None
+    tot = n = 0.0
+    for name, e in pmc.items():
+        if name.split("<")[0] == kernel_family and "hbm_bytes_per_launch" in e:
+            tot += e["hbm_bytes_per_launch"] * e["launches"]
+            n += e["launches"]
+    return round(tot / n) if n else None
 
 
 def parse():
@@ -142,7 +158,10 @@ def main():
         d = agg[dom]
         achieved = d["flops"] / (d["ms"] * 1e-3) / 1e12
         roofline = {"bound": "mfma", "kernel": dom, "achieved": round(achieved, 2), "peak": MFMA_F32_PEAK_TFLOPS,
-                    "unit": "TFLOP/s", "frac": round(achieved / MFMA_F32_PEAK_TFLOPS, 4), "traffic": None,
+                    "unit": "TFLOP/s", "frac": round(achieved / MFMA_F32_PEAK_TFLOPS, 4),
+                    "traffic": recorded_traffic(dom) if args.model == "cls" and args.batch == 32 else None,
+                    "traffic_note": "HBM bytes/launch (avg over the family's launches) from the committed rocprofv3 "
+                                    "--pmc passes, profiles/r01_pmc_per_kernel.json",
                     "launches": d["launches"], "avg_launch_ms": round(d["ms"] / d["launches"], 4),
                     "per_kernel_ms_per_step": {k: round(v["ms"] / args.steps, 3) for k, v in sorted(agg.items())}}
         out = {

@@ -1,0 +1,48 @@
+#!/usr/bin/env python3
+"""rocprofv3 --pmc CSV directories -> per-kernel JSON (per-launch averages).
+usage: tools/pmc_summary.py <dir containing pmc_*/p_counter_collection.csv> <out.json>
+
+HBM traffic follows /opt/skills/guides/MI355X_MICROARCH.md section "HBM": FETCH_SIZE / WRITE_SIZE are in KB (x1024),
+collected in separate passes; on gfx950 FETCH_SIZE tallies 128-B requests at 64 B, i.e. reads HALF the bytes of a wide
+coalesced stream -> the read side is doubled (an upper bound for this path's 64-B gather segments, which the guide
+lists as uncalibrated)."""
+import collections
+import csv
+import glob
+import json
+import os
+import sys
+
+
+def short(n):
+    return n.replace("void ", "").replace("epn::(anonymous namespace)::", "epn::").split("(")[0]
+
+
+root, out = sys.argv[1], sys.argv[2]
+res = {}
+for d in sorted(glob.glob(os.path.join(root, "pmc_*"))):
+    f = os.path.join(d, "p_counter_collection.csv")
+    if not os.path.exists(f):
+        continue
+    agg = collections.defaultdict(lambda: collections.defaultdict(float))
+    disp = collections.defaultdict(set)
+    for r in csv.DictReader(open(f)):
+        k = short(r["Kernel_Name"])
+        if not k.startswith("epn::"):
+            continue
+        agg[k][r["Counter_Name"]] += float(r["Counter_Value"])
+        disp[k].add(r["Dispatch_Id"])
+    for k in agg:
+        e = res.setdefault(k, {})
+        e["launches"] = len(disp[k])
+        for c, v in agg[k].items():
+            e[c] = v / len(disp[k])
+for k, e in res.items():
+    if "FETCH_SIZE" in e and "WRITE_SIZE" in e:
+        e["hbm_bytes_per_launch"] = (2.0 * e["FETCH_SIZE"] + e["WRITE_SIZE"]) * 1024.0
+    if "SQ_WAVE_CYCLES" in e:
+        for c in ("SQ_WAIT_ANY", "SQ_WAIT_INST_ANY", "SQ_ACTIVE_INST_ANY"):
+            if c in e:
+                e[c + "_frac"] = e[c] / e["SQ_WAVE_CYCLES"]
+json.dump(res, open(out, "w"), indent=1, sort_keys=True)
+print(f"{len(res)} kernels -> {out}")
