@@ -32,5 +32,15 @@ __device__ __forceinline__ float epn_sq3(float a, float b, float c) {
     return t;
 }
 
+// XCD-aware workgroup remap (cdna_hip_programming.md T1, bijective form).  Workgroup b is observed to run on XCD
+// b % 8, each XCD with a private 4 MB L2.  Column tiles are ordered cloud-major, and the feature rows a tile gathers
+// all lie in its own cloud's slab, so giving every XCD one CONTIGUOUS range of tiles keeps a slab's re-reads inside
+// one L2.  Placement only affects speed, never results.
+__device__ __forceinline__ unsigned epn_xcd_tile(unsigned bid, unsigned nb) {
+    const unsigned xcd = bid & 7u, local = bid >> 3;
+    const unsigned q = nb >> 3, r = nb & 7u;
+    return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + local;
+}
+
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));

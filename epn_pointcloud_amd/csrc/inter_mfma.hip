@@ -640,7 +640,7 @@ __global__ __launch_bounds__(64 * NW8) void inter_fwd8_kernel(InterArgs A) {
     const int wss = A.wk + 4;
     constexpr int MT = MTMAX;   // the launcher only takes cout == 16 * MTMAX: straight-line MFMA code, no per-tile branch
     const int kw1 = A.ks - 16, gs1 = 16 * kw1 + 4;
-    const long long col0 = ((long long)blockIdx.x * NW8 + wave) * 16;
+    const long long col0 = ((long long)epn_xcd_tile(blockIdx.x, gridDim.x) * NW8 + wave) * 16;
     const int CK = A.cin * A.ks;
     const int n0s = 256 / A.wk, n1s = (16 * kw1) / A.wk, spc = n0s + n1s;   // W sub-chunks per pass / per chunk
     const int nchunk = A.cin >> 4;
@@ -890,7 +890,7 @@ __global__ __launch_bounds__(64 * NW8) void inter_bwd_data8_kernel(InterArgs A) 
     float *Ws = smem + (size_t)4 * 16 * gss;
     const int wss = 20;
     const int m0 = half * MH;
-    const long long col0 = ((long long)blockIdx.x * 4 + tile) * 16;
+    const long long col0 = ((long long)epn_xcd_tile(blockIdx.x, gridDim.x) * 4 + tile) * 16;
     const bool active = col0 < A.ncol;
     long long colx = col0 + x;
     colx = colx < A.ncol ? colx : A.ncol - 1;

@@ -39,7 +39,7 @@ __global__ __launch_bounds__(64 * NW) void intra_gemm_kernel(IntraArgs A) {
     const int wss = A.wk + 4;
     const int MT = A.co >> 4;
     const int CK = A.kn * A.ci;
-    const long long col0 = ((long long)blockIdx.x * NW + wave) * 16;
+    const long long col0 = ((long long)epn_xcd_tile(blockIdx.x, gridDim.x) * NW + wave) * 16;
     long long colx = col0 + x;
     colx = colx < A.ncol ? colx : A.ncol - 1;
     const int ax = (int)(colx % A.na);
