@@ -150,6 +150,8 @@ def main():
         agg = {}
         for kind, key, flops, e0, e1 in records:
             k = KERNEL_OF[kind]
+            if kind.startswith("inter") and key[6] == 1:      # cin = 1 (first layer): dedicated kernels
+                k = {"inter_fwd": "epn::inter_c1_fwd_kernel", "inter_bwd_weight": "epn::inter_c1_bwd_weight_kernel"}.get(kind, k)
             a = agg.setdefault(k, {"ms": 0.0, "flops": 0.0, "launches": 0})
             a["ms"] += e0.elapsed_time(e1)
             a["flops"] += flops
