@@ -8,6 +8,8 @@
 // over c runs as 16x16x4 MFMAs with W (re-packed k-major) staged through LDS for the 4 waves.
 // The data gradient is the same kernel with (X, idx, W) := (dOut, idx^-1, W^T re-packed): each column
 // of intra_idx is a permutation of the anchors, so the transpose is a gather, not a scatter.
+#include <cstdlib>
+
 #include "conv_internal.h"
 
 namespace epn {
@@ -186,6 +188,117 @@ __global__ __launch_bounds__(64 * NW) void intra_bwd_weight_v4_kernel(IntraArgs 
                           acc[m][n][r]);
 }
 
+// Weight gradient with point tiles in LDS (co, ci multiples of 64; kn <= 16; na <= 64).
+// For one point, dOut_pt [na x co] and X_pt [na x ci] are all any anchor-neighbour k needs:
+//   dW_k[o][c] += sum_a dOut_pt[a][o] * X_pt[idx[a][k]][c].
+// A workgroup = kn waves (one per k) sharing a 64 x 64 block of (o, c): the two point tiles are staged ONCE per
+// point (double-buffered, register-prefetched) and read kn times from LDS; the contraction runs over the anchors
+// (na = 60 -> 15 MFMA steps, no padding).  12x less global traffic than one-wave-per-k with private loads.
+constexpr int PT_LD = 68;   // LDS row stride (floats) of a 64-wide point tile
+
+__global__ __launch_bounds__(768) void intra_bwd_weight_pt_kernel(IntraArgs A, long long npts, int pts_per_wg) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int lane = threadIdx.x & 63;
+    const int k = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);   // wave = anchor neighbour
+    const int x = lane & 15, j = lane >> 4;
+    const int cblocks = A.ci / 64;
+    const int o0 = (blockIdx.y / cblocks) * 64, c0 = (blockIdx.y % cblocks) * 64;
+    const int na4 = (A.na + 3) & ~3;                 // anchor rows padded to a multiple of 4 (pad rows are zero)
+    const int tile = na4 * PT_LD;                    // floats per tile
+    float *Ds = smem;                                // [2][na4][PT_LD]  dOut_pt[:, o0:o0+64]
+    float *Fs = smem + 2 * tile;                     // [2][na4][PT_LD]  X_pt[:, c0:c0+64]
+    const int nthreads = blockDim.x;
+    const int nsteps = na4 >> 2;
+
+    // source row (within the point) of this lane's contraction slot, per step: idx[4s + j][k]
+    int srow[16];
+#pragma unroll
+    for (int s = 0; s < 16; ++s) {
+        const int a = 4 * s + j;
+        srow[s] = (s < nsteps && a < A.na) ? A.idx[a * A.kn + k] : 0;
+    }
+
+    f32x4 acc[4][4];
+#pragma unroll
+    for (int m = 0; m < 4; ++m)
+#pragma unroll
+        for (int n = 0; n < 4; ++n) acc[m][n] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    // staging: 2 tiles x na x 16 float4 per point
+    const int nvec = 2 * A.na * 16;
+    constexpr int SP = 4;   // nvec <= 1024-thread-independent bound: 2*64*16 = 2048 <= nthreads * SP for >= 512 threads
+    f32x4 pre[SP];
+    auto fetch = [&](long long pt) {
+#pragma unroll
+        for (int u = 0; u < SP; ++u) {
+            const int i = threadIdx.x + nthreads * u;
+            if (i < nvec) {
+                const int which = i >= A.na * 16;
+                const int r = (which ? i - A.na * 16 : i) >> 4, v = i & 15;
+                const float *src = which ? A.X + ((size_t)pt * A.na + r) * A.ci + c0 + 4 * v
+                                         : A.gout + ((size_t)pt * A.na + r) * A.co + o0 + 4 * v;
+                pre[u] = *reinterpret_cast<const f32x4 *>(src);
+            }
+        }
+    };
+    auto store = [&](int buf) {
+#pragma unroll
+        for (int u = 0; u < SP; ++u) {
+            const int i = threadIdx.x + nthreads * u;
+            if (i < nvec) {
+                const int which = i >= A.na * 16;
+                const int r = (which ? i - A.na * 16 : i) >> 4, v = i & 15;
+                float *dst = (which ? Fs : Ds) + buf * tile + r * PT_LD + 4 * v;
+                *reinterpret_cast<f32x4 *>(dst) = pre[u];
+            }
+        }
+    };
+    // zero the pad rows of both buffers once
+    for (int i = threadIdx.x; i < 2 * 2 * (na4 - A.na) * PT_LD; i += nthreads) {
+        const int per = (na4 - A.na) * PT_LD;
+        const int t = i / per, off = i - t * per;          // t: 0..3 -> (Ds,Fs) x (buf 0,1)
+        ((t & 1) ? Fs : Ds)[(t >> 1) * tile + A.na * PT_LD + off] = 0.0f;
+    }
+
+    const long long pt0 = (long long)blockIdx.x * pts_per_wg;
+    long long pt1 = pt0 + pts_per_wg;
+    pt1 = pt1 < npts ? pt1 : npts;
+    if (pt0 < pt1) fetch(pt0);
+    int buf = 0;
+    for (long long pt = pt0; pt < pt1; ++pt) {
+        store(buf);
+        if (pt + 1 < pt1) fetch(pt + 1);   // lands while this point's 16 * nsteps MFMAs run
+        __syncthreads();
+        if (k < A.kn) {
+            const float *D = Ds + buf * tile + 4 * x;
+            const float *F = Fs + buf * tile + 4 * x;
+#pragma unroll
+            for (int s = 0; s < 16; ++s) {
+                if (s < nsteps) {
+                    const f32x4 af = *reinterpret_cast<const f32x4 *>(D + (4 * s + j) * PT_LD);
+                    const f32x4 bf = *reinterpret_cast<const f32x4 *>(F + srow[s] * PT_LD);
+#pragma unroll
+                    for (int m = 0; m < 4; ++m)
+#pragma unroll
+                        for (int n = 0; n < 4; ++n) acc[m][n] = mfma4(af[m], bf[n], acc[m][n]);
+                }
+            }
+        }
+        buf ^= 1;   // the barrier of the next iteration orders these reads before buffer `buf` is rewritten
+    }
+    if (k < A.kn) {
+        // acc[m][n]: lane (x, j), register r -> o = o0 + 4*(4j + r) + m,  c = c0 + 4x + n
+#pragma unroll
+        for (int m = 0; m < 4; ++m)
+#pragma unroll
+            for (int n = 0; n < 4; ++n)
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+                    atomicAdd(A.out + ((size_t)(o0 + 4 * (4 * j + r) + m) * A.ci + c0 + 4 * x + n) * A.kn + k,
+                              acc[m][n][r]);
+    }
+}
+
 // Wp[o][k*ci + c] = W[o][c*kn + k]                     (forward pack)
 // Wq[c][k*co + o] = W[o][c*kn + k]                     (data-gradient pack: roles of o and c swapped)
 __global__ void pack_w_kernel(const float *__restrict__ W, int co, int ci, int kn, int transpose,
@@ -264,7 +377,21 @@ int launch_intra_bwd_weight_mfma(const float *feats, const float *dOut, const in
     if (splits < 1) splits = 1;
     A.col_tiles_per_wg = (int)((tiles + splits - 1) / splits);
     const unsigned gx = (unsigned)((tiles + A.col_tiles_per_wg - 1) / A.col_tiles_per_wg);
-    if (cout % 64 == 0 && cin % 64 == 0)
+    const char *ev = std::getenv("EPN_INTRA_BW_V4");
+    if (cout % 64 == 0 && cin % 64 == 0 && kn <= 12 && na <= 64 && !(ev && ev[0] == '1')) {
+        const long long npts = (long long)b * p;
+        const int blocks = (cout / 64) * (cin / 64);
+        long long wgs = (256 * 2 + blocks - 1) / blocks;            // ~2 workgroups per CU in total
+        if (wgs > npts) wgs = npts;
+        const int per = (int)((npts + wgs - 1) / wgs);
+        const unsigned gxp = (unsigned)((npts + per - 1) / per);
+        const int na4 = (na + 3) & ~3;
+        const size_t lds = (size_t)4 * na4 * PT_LD * sizeof(float);
+        const int threads = 64 * kn < 512 ? 512 : (64 * kn > 768 ? 768 : 64 * kn);   // staging assumes >= 512 threads
+        EPN_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&intra_bwd_weight_pt_kernel),
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        hipLaunchKernelGGL(intra_bwd_weight_pt_kernel, dim3(gxp, blocks), dim3(threads), lds, st, A, npts, per);
+    } else if (cout % 64 == 0 && cin % 64 == 0)
         hipLaunchKernelGGL(intra_bwd_weight_v4_kernel, dim3(gx, kblocks, tblocks), dim3(64 * NW), 0, st, A);
     else
         hipLaunchKernelGGL(intra_bwd_weight_kernel, dim3(gx, kblocks, tblocks), dim3(64 * NW), 0, st, A);
