@@ -27,7 +27,7 @@ MFMA_F32_PEAK_TFLOPS = 157.3   # /opt/skills/guides/MI355X_MICROARCH.md, "Peak F
 KERNEL_OF = {  # C-ABI call -> device kernel family it launches on this workload (csrc/*.hip; template variants summed)
     "inter_fwd": "epn::inter_fwd8_kernel", "inter_bwd_data": "epn::inter_bwd_data8_kernel",
     "inter_bwd_weight": "epn::inter_bwd_weight8_kernel", "intra_fwd": "epn::intra_gemm_kernel",
-    "intra_bwd_data": "epn::intra_gemm_kernel", "intra_bwd_weight": "epn::intra_bwd_weight_v4_kernel",
+    "intra_bwd_data": "epn::intra_gemm_kernel", "intra_bwd_weight": "epn::intra_bwd_weight_pt_kernel",
 }
 PMC_FILE = os.path.join(ROOT, "profiles", "r01_pmc_per_kernel.json")   # tools/collect_profiles.sh + pmc_summary.py
 

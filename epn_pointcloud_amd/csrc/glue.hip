@@ -1,0 +1,285 @@
+// Block glue of SeparableSO3ConvBlock on channels-last tensors: norm + leaky_relu (+ residual),
+// forward and backward, as HBM-bound streaming kernels.  x_cl is [groups][rows][c]; every thread owns 4 consecutive
+// channels (one 16-byte access per row) and walks rows with a fixed stride, so all global accesses are full-width
+// and coalesced and the per-channel reductions stay in registers until one LDS hop + one atomic per block.
+#include "conv_internal.h"
+
+namespace epn {
+namespace {
+
+constexpr int GT = 256;   // threads per block
+
+struct NormArgs {
+    const float *x, *dy, *sums, *dsums, *gamma, *beta, *res;
+    float *y, *out_sums, *dgamma, *dbeta;
+    long long rows;
+    int c, rows_per_block;
+    float eps, slope, inv_rows;
+};
+
+__device__ __forceinline__ void load_param4(const float *p, int c4, f32x4 &v, float dflt) {
+    v = p ? *reinterpret_cast<const f32x4 *>(p + c4) : f32x4{dflt, dflt, dflt, dflt};
+}
+
+// mean / rstd of this thread's 4 channels from sums[g][c][2]
+__device__ __forceinline__ void stats4(const NormArgs &A, int g, int c4, f32x4 &mean, f32x4 &rstd) {
+    const float *s = A.sums + ((size_t)g * A.c + c4) * 2;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const float m = s[2 * i] * A.inv_rows;
+        const float var = fmaxf(s[2 * i + 1] * A.inv_rows - m * m, 0.0f);
+        mean[i] = m;
+        rstd[i] = rsqrtf(var + A.eps);
+    }
+}
+
+// block = (C/4 channel lanes) x (GT / (C/4) row lanes);  grid = (row blocks, groups)
+__global__ __launch_bounds__(GT) void chan_stats_kernel(NormArgs A) {
+    __shared__ float red[GT][8];
+    const int lanes = A.c >> 2, cl = threadIdx.x % lanes, rl = threadIdx.x / lanes, rstep = GT / lanes;
+    const int g = blockIdx.y;
+    const long long r0 = (long long)blockIdx.x * A.rows_per_block;
+    long long r1 = r0 + A.rows_per_block;
+    r1 = r1 < A.rows ? r1 : A.rows;
+    const float *x = A.x + ((size_t)g * A.rows) * A.c + 4 * cl;
+    f32x4 s1 = {0.f, 0.f, 0.f, 0.f}, s2 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll 4
+    for (long long r = r0 + rl; r < r1; r += rstep) {
+        const f32x4 v = *reinterpret_cast<const f32x4 *>(x + r * A.c);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            s1[i] += v[i];
+            s2[i] += v[i] * v[i];
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        red[threadIdx.x][i] = s1[i];
+        red[threadIdx.x][4 + i] = s2[i];
+    }
+    __syncthreads();
+    if (rl == 0) {
+        for (int t = 1; t < rstep; ++t)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                s1[i] += red[t * lanes + cl][i];
+                s2[i] += red[t * lanes + cl][4 + i];
+            }
+        float *o = A.out_sums + ((size_t)g * A.c + 4 * cl) * 2;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            atomicAdd(o + 2 * i, s1[i]);
+            atomicAdd(o + 2 * i + 1, s2[i]);
+        }
+    }
+}
+
+__global__ __launch_bounds__(GT) void norm_act_fwd_kernel(NormArgs A) {
+    const int lanes = A.c >> 2, cl = threadIdx.x % lanes, rl = threadIdx.x / lanes, rstep = GT / lanes;
+    const int g = blockIdx.y, c4 = 4 * cl;
+    f32x4 mean, rstd, ga, be;
+    stats4(A, g, c4, mean, rstd);
+    load_param4(A.gamma, c4, ga, 1.0f);
+    load_param4(A.beta, c4, be, 0.0f);
+    const long long r0 = (long long)blockIdx.x * A.rows_per_block;
+    long long r1 = r0 + A.rows_per_block;
+    r1 = r1 < A.rows ? r1 : A.rows;
+    const size_t base = ((size_t)g * A.rows) * A.c + c4;
+    for (long long r = r0 + rl; r < r1; r += rstep) {
+        const size_t off = base + (size_t)r * A.c;
+        const f32x4 v = *reinterpret_cast<const f32x4 *>(A.x + off);
+        f32x4 o;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const float n = (v[i] - mean[i]) * rstd[i] * ga[i] + be[i];
+            o[i] = n > 0.0f ? n : n * A.slope;
+        }
+        if (A.res) {
+            const f32x4 rr = *reinterpret_cast<const f32x4 *>(A.res + off);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) o[i] += rr[i];
+        }
+        *reinterpret_cast<f32x4 *>(A.y + off) = o;
+    }
+}
+
+// dsums[g][c] = (sum dn, sum dn * xhat), dn = dy * leaky'(n) * gamma;  dgamma += sum dy*leaky'*xhat, dbeta += sum dy*leaky'
+__global__ __launch_bounds__(GT) void norm_act_bwd_reduce_kernel(NormArgs A) {
+    __shared__ float red[GT][8];
+    const int lanes = A.c >> 2, cl = threadIdx.x % lanes, rl = threadIdx.x / lanes, rstep = GT / lanes;
+    const int g = blockIdx.y, c4 = 4 * cl;
+    f32x4 mean, rstd, ga, be;
+    stats4(A, g, c4, mean, rstd);
+    load_param4(A.gamma, c4, ga, 1.0f);
+    load_param4(A.beta, c4, be, 0.0f);
+    const long long r0 = (long long)blockIdx.x * A.rows_per_block;
+    long long r1 = r0 + A.rows_per_block;
+    r1 = r1 < A.rows ? r1 : A.rows;
+    const size_t base = ((size_t)g * A.rows) * A.c + c4;
+    f32x4 sa = {0.f, 0.f, 0.f, 0.f}, sb = {0.f, 0.f, 0.f, 0.f};   // sum d, sum d*xhat with d = dy*leaky'
+#pragma unroll 4
+    for (long long r = r0 + rl; r < r1; r += rstep) {
+        const size_t off = base + (size_t)r * A.c;
+        const f32x4 v = *reinterpret_cast<const f32x4 *>(A.x + off);
+        const f32x4 d = *reinterpret_cast<const f32x4 *>(A.dy + off);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const float xh = (v[i] - mean[i]) * rstd[i];
+            const float n = xh * ga[i] + be[i];
+            const float dd = n > 0.0f ? d[i] : d[i] * A.slope;
+            sa[i] += dd;
+            sb[i] += dd * xh;
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        red[threadIdx.x][i] = sa[i];
+        red[threadIdx.x][4 + i] = sb[i];
+    }
+    __syncthreads();
+    if (rl == 0) {
+        for (int t = 1; t < rstep; ++t)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                sa[i] += red[t * lanes + cl][i];
+                sb[i] += red[t * lanes + cl][4 + i];
+            }
+        float *o = A.out_sums + ((size_t)g * A.c + c4) * 2;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            atomicAdd(o + 2 * i, sa[i] * ga[i]);       // sum dn
+            atomicAdd(o + 2 * i + 1, sb[i] * ga[i]);   // sum dn * xhat
+            if (A.dgamma) atomicAdd(A.dgamma + c4 + i, sb[i]);
+            if (A.dbeta) atomicAdd(A.dbeta + c4 + i, sa[i]);
+        }
+    }
+}
+
+__global__ __launch_bounds__(GT) void norm_act_bwd_apply_kernel(NormArgs A) {
+    const int lanes = A.c >> 2, cl = threadIdx.x % lanes, rl = threadIdx.x / lanes, rstep = GT / lanes;
+    const int g = blockIdx.y, c4 = 4 * cl;
+    f32x4 mean, rstd, ga, be, m1, m2;
+    stats4(A, g, c4, mean, rstd);
+    load_param4(A.gamma, c4, ga, 1.0f);
+    load_param4(A.beta, c4, be, 0.0f);
+    const float *ds = A.dsums + ((size_t)g * A.c + c4) * 2;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        m1[i] = ds[2 * i] * A.inv_rows;       // mean(dn)
+        m2[i] = ds[2 * i + 1] * A.inv_rows;   // mean(dn * xhat)
+    }
+    const long long r0 = (long long)blockIdx.x * A.rows_per_block;
+    long long r1 = r0 + A.rows_per_block;
+    r1 = r1 < A.rows ? r1 : A.rows;
+    const size_t base = ((size_t)g * A.rows) * A.c + c4;
+    for (long long r = r0 + rl; r < r1; r += rstep) {
+        const size_t off = base + (size_t)r * A.c;
+        const f32x4 v = *reinterpret_cast<const f32x4 *>(A.x + off);
+        const f32x4 d = *reinterpret_cast<const f32x4 *>(A.dy + off);
+        f32x4 o;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const float xh = (v[i] - mean[i]) * rstd[i];
+            const float n = xh * ga[i] + be[i];
+            const float dn = (n > 0.0f ? d[i] : d[i] * A.slope) * ga[i];
+            o[i] = rstd[i] * (dn - m1[i] - xh * m2[i]);
+        }
+        *reinterpret_cast<f32x4 *>(A.y + off) = o;
+    }
+}
+
+int check_norm(int groups, long long rows, int c) {
+    if (groups < 0 || rows < 0 || c < 4 || c % 4 != 0 || c > 4 * GT || GT % (c / 4) != 0) return EPN_EINVAL;
+    if (groups > 65535) return EPN_EINVAL;
+    return 0;
+}
+
+NormArgs make_norm(long long rows, int c, float eps, float slope, dim3 &grid, int groups) {
+    NormArgs A = {};
+    A.rows = rows; A.c = c; A.eps = eps; A.slope = slope;
+    A.inv_rows = rows > 0 ? 1.0f / (float)rows : 0.0f;
+    // ~1024 blocks in total (4 per CU): enough loads in flight to stream HBM, few enough that the per-block atomics
+    // onto the [groups][c] sums do not serialise (2048 blocks cost 0.3 ms of L2 atomic contention per call)
+    long long per_group = (1024 + groups - 1) / (groups > 0 ? groups : 1);
+    if (per_group < 1) per_group = 1;
+    long long rpb = (rows + per_group - 1) / per_group;
+    if (rpb < 64) rpb = 64;
+    A.rows_per_block = (int)rpb;
+    grid = dim3((unsigned)((rows + rpb - 1) / rpb), (unsigned)groups);
+    return A;
+}
+
+}  // namespace
+}  // namespace epn
+
+using namespace epn;
+
+extern "C" int epn_chan_stats_f32(const float *x_cl, int groups, long long rows, int c, float *sums,
+                                  epn_stream_t stream) {
+    int rc = check_norm(groups, rows, c);
+    if (rc) return rc;
+    if (!sums) return EPN_ENULL;
+    hipStream_t st = epn_stream(stream);
+    EPN_HIP(hipMemsetAsync(sums, 0, sizeof(float) * (size_t)groups * c * 2, st));
+    if (groups == 0 || rows == 0) return 0;
+    if (!x_cl) return EPN_ENULL;
+    dim3 grid;
+    NormArgs A = make_norm(rows, c, 0.f, 0.f, grid, groups);
+    A.x = x_cl; A.out_sums = sums;
+    hipLaunchKernelGGL(chan_stats_kernel, grid, dim3(GT), 0, st, A);
+    EPN_CHECK_LAUNCH();
+    return 0;
+}
+
+extern "C" int epn_norm_act_fwd_f32(const float *x_cl, int groups, long long rows, int c, const float *sums,
+                                    const float *gamma, const float *beta, const float *residual_cl, float eps,
+                                    float slope, float *y_cl, epn_stream_t stream) {
+    int rc = check_norm(groups, rows, c);
+    if (rc) return rc;
+    if (groups == 0 || rows == 0) return 0;
+    if (!x_cl || !sums || !y_cl) return EPN_ENULL;
+    dim3 grid;
+    NormArgs A = make_norm(rows, c, eps, slope, grid, groups);
+    A.x = x_cl; A.sums = sums; A.gamma = gamma; A.beta = beta; A.res = residual_cl; A.y = y_cl;
+    hipLaunchKernelGGL(norm_act_fwd_kernel, grid, dim3(GT), 0, epn_stream(stream), A);
+    EPN_CHECK_LAUNCH();
+    return 0;
+}
+
+extern "C" int epn_norm_act_bwd_reduce_f32(const float *x_cl, const float *dy_cl, int groups, long long rows, int c,
+                                           const float *sums, const float *gamma, const float *beta, float eps,
+                                           float slope, float *dsums, float *dgamma, float *dbeta,
+                                           epn_stream_t stream) {
+    int rc = check_norm(groups, rows, c);
+    if (rc) return rc;
+    if (!dsums) return EPN_ENULL;
+    hipStream_t st = epn_stream(stream);
+    EPN_HIP(hipMemsetAsync(dsums, 0, sizeof(float) * (size_t)groups * c * 2, st));
+    if (dgamma) EPN_HIP(hipMemsetAsync(dgamma, 0, sizeof(float) * c, st));
+    if (dbeta) EPN_HIP(hipMemsetAsync(dbeta, 0, sizeof(float) * c, st));
+    if (groups == 0 || rows == 0) return 0;
+    if (!x_cl || !dy_cl || !sums) return EPN_ENULL;
+    dim3 grid;
+    NormArgs A = make_norm(rows, c, eps, slope, grid, groups);
+    A.x = x_cl; A.dy = dy_cl; A.sums = sums; A.gamma = gamma; A.beta = beta;
+    A.out_sums = dsums; A.dgamma = dgamma; A.dbeta = dbeta;
+    hipLaunchKernelGGL(norm_act_bwd_reduce_kernel, grid, dim3(GT), 0, st, A);
+    EPN_CHECK_LAUNCH();
+    return 0;
+}
+
+extern "C" int epn_norm_act_bwd_apply_f32(const float *x_cl, const float *dy_cl, int groups, long long rows, int c,
+                                          const float *sums, const float *dsums, const float *gamma,
+                                          const float *beta, float eps, float slope, float *dx_cl,
+                                          epn_stream_t stream) {
+    int rc = check_norm(groups, rows, c);
+    if (rc) return rc;
+    if (groups == 0 || rows == 0) return 0;
+    if (!x_cl || !dy_cl || !sums || !dsums || !dx_cl) return EPN_ENULL;
+    dim3 grid;
+    NormArgs A = make_norm(rows, c, eps, slope, grid, groups);
+    A.x = x_cl; A.dy = dy_cl; A.sums = sums; A.dsums = dsums; A.gamma = gamma; A.beta = beta; A.y = dx_cl;
+    hipLaunchKernelGGL(norm_act_bwd_apply_kernel, grid, dim3(GT), 0, epn_stream(stream), A);
+    EPN_CHECK_LAUNCH();
+    return 0;
+}

@@ -273,6 +273,83 @@ class IntraSO3ConvFn(torch.autograd.Function):
         return gf, gW, None
 
 
+def norm_act_supported(c):
+    """Channel counts the fused norm kernels take (4 channels per lane, C/4 lanes dividing a 256-thread block)."""
+    return c >= 4 and c % 4 == 0 and c <= 1024 and 256 % (c // 4) == 0
+
+
+class NormActFn(torch.autograd.Function):
+    """y = leaky_relu(norm(x)) (+ residual) on a [b,c,p,a] tensor, norm = BatchNorm2d (groups=1, optional affine) or
+    InstanceNorm2d(affine=False) (groups=b) -- `relu(norm(x))` of SPConvNets/utils/base_so3conv.py:116-126,52-62,208-211
+    -- two streaming HIP passes forward, two backward (include/epn_so3conv.h, "block glue").
+    Returns (y, sums) with sums[g][c] = (sum x, sum x^2) for the caller's running-statistics update."""
+
+    @staticmethod
+    def forward(ctx, x, gamma, beta, residual, instance, eps, slope):
+        lib = _lib.get_lib()
+        xc = to_cl(x, "x")
+        b, c, p, a = xc.shape
+        groups, rows = (b, p * a) if instance else (1, b * p * a)
+        sums = torch.empty((groups, c, 2), dtype=torch.float32, device=xc.device)
+        st = _lib.stream_of(xc)
+        _lib.check(lib.epn_chan_stats_f32(_cl_ptr(xc), groups, rows, c, _lib.dev_ptr(sums, "sums"), st), "chan_stats")
+        y = empty_cl(b, c, p, a, xc.device)
+        g = gamma.contiguous() if gamma is not None else None
+        bt = beta.contiguous() if beta is not None else None
+        r = to_cl(residual, "residual") if residual is not None else None
+        _lib.check(lib.epn_norm_act_fwd_f32(_cl_ptr(xc), groups, rows, c, _lib.dev_ptr(sums, "sums"),
+                                            _lib.dev_ptr(g, "gamma"), _lib.dev_ptr(bt, "beta"),
+                                            _cl_ptr(r) if r is not None else ctypes.c_void_p(0), float(eps),
+                                            float(slope), _cl_ptr(y), st), "norm_act_fwd")
+        ctx.save_for_backward(xc, sums, g, bt)
+        ctx.cfg = (groups, rows, c, float(eps), float(slope), residual is not None)
+        ctx.mark_non_differentiable(sums)
+        return y, sums
+
+    @staticmethod
+    def backward(ctx, grad_y, _grad_sums):
+        lib = _lib.get_lib()
+        xc, sums, g, bt = ctx.saved_tensors
+        groups, rows, c, eps, slope, has_res = ctx.cfg
+        dy = to_cl(grad_y, "grad_y")
+        st = _lib.stream_of(xc)
+        dsums = torch.empty_like(sums)
+        dg = torch.empty(c, dtype=torch.float32, device=xc.device) if g is not None else None
+        db = torch.empty(c, dtype=torch.float32, device=xc.device) if bt is not None else None
+        gp, bp = _lib.dev_ptr(g, "gamma"), _lib.dev_ptr(bt, "beta")
+        _lib.check(lib.epn_norm_act_bwd_reduce_f32(_cl_ptr(xc), _cl_ptr(dy), groups, rows, c,
+                                                   _lib.dev_ptr(sums, "sums"), gp, bp, eps, slope,
+                                                   _lib.dev_ptr(dsums, "dsums"), _lib.dev_ptr(dg, "dgamma"),
+                                                   _lib.dev_ptr(db, "dbeta"), st), "norm_act_bwd_reduce")
+        dx = None
+        if ctx.needs_input_grad[0]:
+            dx = torch.empty_like(xc)
+            _lib.check(lib.epn_norm_act_bwd_apply_f32(_cl_ptr(xc), _cl_ptr(dy), groups, rows, c,
+                                                      _lib.dev_ptr(sums, "sums"), _lib.dev_ptr(dsums, "dsums"), gp, bp,
+                                                      eps, slope, _cl_ptr(dx), st), "norm_act_bwd_apply")
+        return dx, dg, db, (dy if has_res else None), None, None, None
+
+
+def norm_act(x, norm, residual=None, slope=0.01):
+    """leaky_relu(norm(x)) (+ residual) with `norm` an nn.BatchNorm2d or nn.InstanceNorm2d(affine=False) module whose
+    parameters / running statistics are used and updated exactly as the module would (training mode)."""
+    import torch.nn as nn
+    instance = isinstance(norm, nn.InstanceNorm2d)
+    gamma = getattr(norm, "weight", None)
+    beta = getattr(norm, "bias", None)
+    y, sums = NormActFn.apply(x, gamma, beta, residual, instance, norm.eps, slope)
+    if not instance and norm.track_running_stats and norm.running_mean is not None:
+        with torch.no_grad():
+            n = x.shape[0] * x.shape[2] * x.shape[3]
+            mean = sums[0, :, 0] / n
+            var = (sums[0, :, 1] / n - mean * mean).clamp_min_(0) * (n / max(n - 1, 1))   # unbiased, as BatchNorm stores
+            m = norm.momentum if norm.momentum is not None else 0.1
+            norm.running_mean.mul_(1 - m).add_(mean, alpha=m)
+            norm.running_var.mul_(1 - m).add_(var, alpha=m)
+            norm.num_batches_tracked += 1
+    return y
+
+
 def inter_so3conv(feats, W, geo):
     return InterSO3ConvFn.apply(feats, W, geo)
 

@@ -15,6 +15,7 @@ import torch
 import torch.nn as nn
 import torch.nn.functional as F
 
+from . import ops
 from .vgtk import so3conv as sptk
 from .vgtk import spconv as zptk
 
@@ -112,13 +113,46 @@ class SeparableBlock(nn.Module):
         return zptk.SphericalPointCloud(z.xyz, feat + skip, z.anchors)
 
 
+class FusedSeparableBlock(SeparableBlock):
+    """Same module tree / state_dict as SeparableBlock, with the glue on the HIP "block glue" kernels:
+    norm + leaky_relu (+ the residual add) are two streaming passes each, the 1x1 skip convolution runs on the intra
+    GEMM kernel (one anchor "neighbour", identity index) -- everything stays channels-last, no layout copies.
+    Training-mode semantics (batch statistics); eval mode falls back to the stock modules."""
+
+    def forward(self, x):
+        c_out = self.intra.dim_out
+        if (not self.training) or not ops.norm_act_supported(c_out):
+            return super().forward(x)
+        skip = x.feats
+        _, _, sample_idx, y = self.inter(x)
+        feat = ops.norm_act(y.feats, self.inter_norm)
+        z = self.intra(zptk.SphericalPointCloud(y.xyz, feat, y.anchors))
+        if self.stride > 1:                                    # batched_index_select(skip, 2, sample_idx) on rows
+            s_cl = ops.to_cl(skip).permute(0, 2, 3, 1)           # [b,p1,a,c] view of the channels-last image
+            b, p1, a, c = s_cl.shape
+            idx = sample_idx.long().view(b, -1, 1).expand(-1, -1, a * c)
+            skip = torch.gather(s_cl.reshape(b, p1, a * c), 1, idx).view(b, -1, a, c).permute(0, 3, 1, 2)
+        na = skip.shape[3]
+        ident = torch.arange(na, dtype=torch.int32, device=skip.device).view(na, 1)
+        w = self.skip_conv.weight.view(self.skip_conv.out_channels, -1)
+        if skip.shape[1] % 16 == 0:
+            s = ops.intra_so3conv(skip, w, ident)               # 1x1 conv = intra GEMM with kn = 1
+        else:
+            s = F.conv2d(skip, self.skip_conv.weight)           # cin = 1 (first block): trivial
+        s = s + self.skip_conv.bias.view(1, -1, 1, 1)
+        s = ops.norm_act(s, self.norm)
+        out = ops.norm_act(z.feats, self.intra_norm, residual=s)   # leaky(IN(z)) + skip in the same pass
+        return zptk.SphericalPointCloud(z.xyz, out, z.anchors)
+
+
 class HotPathBackbone(nn.Module):
     """preprocess_input (ones features) -> chain of separable blocks.  Input [b, n, 3] point clouds."""
 
-    def __init__(self, layers, kanchor=60, norm="BatchNorm2d"):
+    def __init__(self, layers, kanchor=60, norm="BatchNorm2d", fused_glue=True):
         super().__init__()
         self.kanchor = kanchor
-        self.blocks = nn.ModuleList([SeparableBlock(l, kanchor, norm) for l in layers])
+        blk = FusedSeparableBlock if fused_glue else SeparableBlock
+        self.blocks = nn.ModuleList([blk(l, kanchor, norm) for l in layers])
 
     def forward(self, pts):
         xyz = pts.permute(0, 2, 1).contiguous()

@@ -272,13 +272,14 @@ def test_fused_dispatch_covers_the_modelnet_schedule(gpu):
         p //= l.stride
 
 
-def test_separable_block_vs_reference_golden(gpu, vgtk_alias):
+@pytest.mark.parametrize("fused", [False, True])
+def test_separable_block_vs_reference_golden(gpu, vgtk_alias, fused):
     """schedule.SeparableBlock (channels-last glue around the fused convs) against the output of the reference's
     SeparableSO3ConvBlock built by the unmodified SPConvNets code (tests/golden/sepblock_tiny.npz), train mode."""
     from epn_pointcloud_amd import schedule as S
     g = golden("sepblock_tiny.npz")
     l = S.Layer(1, 8, 2, 0.4, 0.08, 16, False)
-    blk = S.SeparableBlock(l).train()
+    blk = (S.FusedSeparableBlock if fused else S.SeparableBlock)(l).train()
     sd = {k[3:]: T(g[k]) for k in g.files if k.startswith("sd/")}
     mapped = {
         "inter.anchors": sd["inter_conv.conv.anchors"], "inter.kernels": sd["inter_conv.conv.kernels"],
@@ -315,3 +316,56 @@ def test_other_model_schedules_run(gpu, vgtk_alias, name, n, scale):
     for p in model.parameters():
         assert p.grad is not None and torch.isfinite(p.grad).all()
     assert torch.isfinite(y.feats).all() and float(y.feats.detach().abs().max()) > 0
+
+
+@pytest.mark.parametrize("c,instance,affine,res", [(64, False, True, False), (128, True, False, True),
+                                                   (8, False, True, True), (256, True, False, False)])
+def test_norm_act_kernels_vs_torch(gpu, c, instance, affine, res):
+    """Block-glue kernels (norm + leaky_relu (+ residual), fwd + bwd) against the stock torch modules."""
+    from epn_pointcloud_amd import ops
+    torch.manual_seed(c)
+    x = (torch.randn(3, c, 37, 60, device=gpu) * 2 + 0.5).requires_grad_(True)
+    r = torch.randn(3, c, 37, 60, device=gpu).requires_grad_(True) if res else None
+    norm = (torch.nn.InstanceNorm2d(c, affine=False) if instance else torch.nn.BatchNorm2d(c)).to(gpu).train()
+    if affine:
+        with torch.no_grad():
+            norm.weight.uniform_(0.5, 1.5); norm.bias.uniform_(-0.5, 0.5)
+    ref_norm = __import__("copy").deepcopy(norm)
+    y_ref = torch.nn.functional.leaky_relu(ref_norm(x)) + (r if res else 0)
+    gy = torch.randn_like(y_ref)
+    ins = [x] + ([r] if res else []) + (list(ref_norm.parameters()) if affine else [])
+    g_ref = torch.autograd.grad(y_ref, ins, gy)
+    y = ops.norm_act(x, norm, residual=r)
+    ins2 = [x] + ([r] if res else []) + (list(norm.parameters()) if affine else [])
+    g = torch.autograd.grad(y, ins2, gy)
+    assert y.is_contiguous(memory_format=torch.channels_last)
+    assert (y - y_ref).abs().max().item() < 1e-4
+    for a, b in zip(g, g_ref):
+        assert (a - b).abs().max().item() < 1e-3 * max(1.0, b.abs().max().item())
+    if not instance:
+        assert torch.allclose(norm.running_mean, ref_norm.running_mean, atol=1e-5)
+        assert torch.allclose(norm.running_var, ref_norm.running_var, atol=1e-4)
+
+
+def test_fused_block_matches_stock_block(gpu, vgtk_alias):
+    """FusedSeparableBlock (HIP glue) == SeparableBlock (torch glue): outputs and every parameter gradient, for a
+    strided BatchNorm block and a stride-1 InstanceNorm block; and the reference golden for the first one."""
+    from epn_pointcloud_amd import schedule as S
+    import vgtk.spconv as zptk
+    rng = np.random.default_rng(5)
+    xyz = T(unit_ball_cloud(rng, 2, 256)).to(gpu)
+    for l, norm in ((S.Layer(16, 32, 2, 0.4, 0.08, 16, False), "BatchNorm2d"), (S.Layer(32, 32, 1, 0.4, 0.08, 16, True), None)):
+        torch.manual_seed(9)
+        a = S.SeparableBlock(l, norm=norm).to(gpu).train()
+        b = S.FusedSeparableBlock(l, norm=norm).to(gpu).train()
+        b.load_state_dict(a.state_dict())
+        feats = torch.randn(2, l.cin, 256, 60, device=gpu)
+        fa, fb = feats.clone().requires_grad_(True), feats.clone().requires_grad_(True)
+        ya = a(zptk.SphericalPointCloud(xyz, fa, None)).feats
+        yb = b(zptk.SphericalPointCloud(xyz, fb, None)).feats
+        gy = torch.randn_like(ya)
+        ga = torch.autograd.grad(ya, [fa] + list(a.parameters()), gy)
+        gb = torch.autograd.grad(yb, [fb] + list(b.parameters()), gy)
+        assert (ya - yb).abs().max().item() < TOL
+        for (n, _), u, v in zip([("feats", None)] + list(a.named_parameters()), ga, gb):
+            assert (u - v).abs().max().item() < TOL * max(1.0, u.abs().max().item()), n
