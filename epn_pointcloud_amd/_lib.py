@@ -19,7 +19,7 @@ EXPORTS = [
     "epn_inter_so3conv_bwd_data_f32", "epn_inter_so3conv_bwd_weight_f32", "epn_inter_weights_f32",
     "epn_intra_workspace_bytes", "epn_intra_is_fused", "epn_intra_so3conv_fwd_f32",
     "epn_intra_so3conv_bwd_data_f32", "epn_intra_so3conv_bwd_weight_f32",
-    "epn_chan_stats_f32", "epn_norm_act_fwd_f32", "epn_norm_act_bwd_reduce_f32", "epn_norm_act_bwd_apply_f32",
+    "epn_norm_workspace_bytes", "epn_chan_stats_f32", "epn_norm_act_fwd_f32", "epn_norm_act_bwd_reduce_f32", "epn_norm_act_bwd_apply_f32",
 ]
 
 _vp, _ci, _cf, _sz = ctypes.c_void_p, ctypes.c_int, ctypes.c_float, ctypes.c_size_t
@@ -71,9 +71,12 @@ def get_lib():
                                                    _vp]
     lib.epn_intra_so3conv_bwd_weight_f32.argtypes = [_vp, _vp, _vp, _ci, _ci, _ci, _ci, _ci, _ci, _vp, _vp]
     _ll = ctypes.c_longlong
-    lib.epn_chan_stats_f32.argtypes = [_vp, _ci, _ll, _ci, _vp, _vp]
+    lib.epn_norm_workspace_bytes.argtypes = [_ci, _ll, _ci]
+    lib.epn_norm_workspace_bytes.restype = _sz
+    lib.epn_chan_stats_f32.argtypes = [_vp, _ci, _ll, _ci, _vp, _vp, _sz, _vp]
     lib.epn_norm_act_fwd_f32.argtypes = [_vp, _ci, _ll, _ci, _vp, _vp, _vp, _vp, _cf, _cf, _vp, _vp]
-    lib.epn_norm_act_bwd_reduce_f32.argtypes = [_vp, _vp, _ci, _ll, _ci, _vp, _vp, _vp, _cf, _cf, _vp, _vp, _vp, _vp]
+    lib.epn_norm_act_bwd_reduce_f32.argtypes = [_vp, _vp, _ci, _ll, _ci, _vp, _vp, _vp, _cf, _cf, _vp, _vp, _vp, _vp,
+                                                _sz, _vp]
     lib.epn_norm_act_bwd_apply_f32.argtypes = [_vp, _vp, _ci, _ll, _ci, _vp, _vp, _vp, _vp, _cf, _cf, _vp, _vp]
     for name in EXPORTS:
         getattr(lib, name)  # AttributeError here = header/library mismatch

@@ -65,12 +65,62 @@ __global__ __launch_bounds__(GT) void chan_stats_kernel(NormArgs A) {
                 s1[i] += red[t * lanes + cl][i];
                 s2[i] += red[t * lanes + cl][4 + i];
             }
-        float *o = A.out_sums + ((size_t)g * A.c + 4 * cl) * 2;
+        // per-block partial (no atomics: 1024 blocks hammering [groups][c] addresses cost more than the streaming)
+        float *o = A.out_sums + (((size_t)g * gridDim.x + blockIdx.x) * A.c + 4 * cl) * 2;
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
-            atomicAdd(o + 2 * i, s1[i]);
-            atomicAdd(o + 2 * i + 1, s2[i]);
+            o[2 * i] = s1[i];
+            o[2 * i + 1] = s2[i];
         }
+    }
+}
+
+// Finishing kernels: 256 threads = 16 entries x 16 slices of the block-partial axis, LDS tree over the slices.
+// sums[g][e] = sum_b part[g][b][e],  e in [0, 2c)
+__global__ __launch_bounds__(256) void stats_finish_kernel(const float *__restrict__ part, int nb, int c2,
+                                                           float *__restrict__ sums) {
+    __shared__ float red[16][17];
+    const int el = threadIdx.x & 15, sl = threadIdx.x >> 4;
+    const int g = blockIdx.y, e = blockIdx.x * 16 + el;
+    float acc = 0.f;
+    if (e < c2)
+        for (int b = sl; b < nb; b += 16) acc += part[((size_t)g * nb + b) * c2 + e];
+    red[sl][el] = acc;
+    __syncthreads();
+    if (sl == 0 && e < c2) {
+        for (int t = 1; t < 16; ++t) acc += red[t][el];
+        sums[(size_t)g * c2 + e] = acc;
+    }
+}
+
+// backward: per (g, ch): (sa, sb) = sum_b part;  dsums = gamma * (sa, sb);  dgamma / dbeta accumulate over groups
+// (groups > 1 only for InstanceNorm, which has no affine parameters -> plain stores suffice when groups == 1)
+__global__ __launch_bounds__(256) void bwd_finish_kernel(const float *__restrict__ part, int nb, int c,
+                                                         const float *__restrict__ gamma, float *__restrict__ dsums,
+                                                         float *__restrict__ dgamma, float *__restrict__ dbeta) {
+    __shared__ float red[16][2][17];
+    const int el = threadIdx.x & 15, sl = threadIdx.x >> 4;
+    const int g = blockIdx.y, ch = blockIdx.x * 16 + el;
+    float sa = 0.f, sb = 0.f;
+    if (ch < c)
+        for (int b = sl; b < nb; b += 16) {
+            const float *p = part + (((size_t)g * nb + b) * c + ch) * 2;
+            sa += p[0];
+            sb += p[1];
+        }
+    red[sl][0][el] = sa;
+    red[sl][1][el] = sb;
+    __syncthreads();
+    if (sl == 0 && ch < c) {
+        for (int t = 1; t < 16; ++t) {
+            sa += red[t][0][el];
+            sb += red[t][1][el];
+        }
+        const float ga = gamma ? gamma[ch] : 1.0f;
+        dsums[((size_t)g * c + ch) * 2] = sa * ga;
+        dsums[((size_t)g * c + ch) * 2 + 1] = sb * ga;
+        if (dgamma) atomicAdd(dgamma + ch, sb);
+        if (dbeta) atomicAdd(dbeta + ch, sa);
     }
 }
 
@@ -144,13 +194,11 @@ __global__ __launch_bounds__(GT) void norm_act_bwd_reduce_kernel(NormArgs A) {
                 sa[i] += red[t * lanes + cl][i];
                 sb[i] += red[t * lanes + cl][4 + i];
             }
-        float *o = A.out_sums + ((size_t)g * A.c + c4) * 2;
+        float *o = A.out_sums + (((size_t)g * gridDim.x + blockIdx.x) * A.c + c4) * 2;   // per-block partial
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
-            atomicAdd(o + 2 * i, sa[i] * ga[i]);       // sum dn
-            atomicAdd(o + 2 * i + 1, sb[i] * ga[i]);   // sum dn * xhat
-            if (A.dgamma) atomicAdd(A.dgamma + c4 + i, sb[i]);
-            if (A.dbeta) atomicAdd(A.dbeta + c4 + i, sa[i]);
+            o[2 * i] = sa[i];
+            o[2 * i + 1] = sb[i];
         }
     }
 }
@@ -214,19 +262,32 @@ NormArgs make_norm(long long rows, int c, float eps, float slope, dim3 &grid, in
 
 using namespace epn;
 
-extern "C" int epn_chan_stats_f32(const float *x_cl, int groups, long long rows, int c, float *sums,
-                                  epn_stream_t stream) {
+extern "C" size_t epn_norm_workspace_bytes(int groups, long long rows, int c) {
+    if (check_norm(groups, rows, c) || groups == 0 || rows == 0) return 0;
+    dim3 grid;
+    make_norm(rows, c, 0.f, 0.f, grid, groups);
+    return sizeof(float) * (size_t)groups * grid.x * c * 2;   // one (s1, s2) pair per block and channel
+}
+
+extern "C" int epn_chan_stats_f32(const float *x_cl, int groups, long long rows, int c, float *sums, void *workspace,
+                                  size_t workspace_bytes, epn_stream_t stream) {
     int rc = check_norm(groups, rows, c);
     if (rc) return rc;
     if (!sums) return EPN_ENULL;
     hipStream_t st = epn_stream(stream);
-    EPN_HIP(hipMemsetAsync(sums, 0, sizeof(float) * (size_t)groups * c * 2, st));
-    if (groups == 0 || rows == 0) return 0;
+    if (groups == 0 || rows == 0) {
+        EPN_HIP(hipMemsetAsync(sums, 0, sizeof(float) * (size_t)groups * c * 2, st));
+        return 0;
+    }
     if (!x_cl) return EPN_ENULL;
+    if (!workspace || workspace_bytes < epn_norm_workspace_bytes(groups, rows, c)) return EPN_EWORKSPACE;
     dim3 grid;
     NormArgs A = make_norm(rows, c, 0.f, 0.f, grid, groups);
-    A.x = x_cl; A.out_sums = sums;
+    A.x = x_cl; A.out_sums = static_cast<float *>(workspace);
     hipLaunchKernelGGL(chan_stats_kernel, grid, dim3(GT), 0, st, A);
+    EPN_CHECK_LAUNCH();
+    hipLaunchKernelGGL(stats_finish_kernel, dim3(epn_cdiv(2 * c, 16), groups), dim3(256), 0, st, A.out_sums, (int)grid.x,
+                       c * 2, sums);
     EPN_CHECK_LAUNCH();
     return 0;
 }
@@ -248,22 +309,30 @@ extern "C" int epn_norm_act_fwd_f32(const float *x_cl, int groups, long long row
 
 extern "C" int epn_norm_act_bwd_reduce_f32(const float *x_cl, const float *dy_cl, int groups, long long rows, int c,
                                            const float *sums, const float *gamma, const float *beta, float eps,
-                                           float slope, float *dsums, float *dgamma, float *dbeta,
-                                           epn_stream_t stream) {
+                                           float slope, float *dsums, float *dgamma, float *dbeta, void *workspace,
+                                           size_t workspace_bytes, epn_stream_t stream) {
     int rc = check_norm(groups, rows, c);
     if (rc) return rc;
     if (!dsums) return EPN_ENULL;
     hipStream_t st = epn_stream(stream);
-    EPN_HIP(hipMemsetAsync(dsums, 0, sizeof(float) * (size_t)groups * c * 2, st));
-    if (dgamma) EPN_HIP(hipMemsetAsync(dgamma, 0, sizeof(float) * c, st));
-    if (dbeta) EPN_HIP(hipMemsetAsync(dbeta, 0, sizeof(float) * c, st));
-    if (groups == 0 || rows == 0) return 0;
+    if (groups == 0 || rows == 0) {
+        EPN_HIP(hipMemsetAsync(dsums, 0, sizeof(float) * (size_t)groups * c * 2, st));
+        if (dgamma) EPN_HIP(hipMemsetAsync(dgamma, 0, sizeof(float) * c, st));
+        if (dbeta) EPN_HIP(hipMemsetAsync(dbeta, 0, sizeof(float) * c, st));
+        return 0;
+    }
     if (!x_cl || !dy_cl || !sums) return EPN_ENULL;
+    if (!workspace || workspace_bytes < epn_norm_workspace_bytes(groups, rows, c)) return EPN_EWORKSPACE;
     dim3 grid;
     NormArgs A = make_norm(rows, c, eps, slope, grid, groups);
     A.x = x_cl; A.dy = dy_cl; A.sums = sums; A.gamma = gamma; A.beta = beta;
-    A.out_sums = dsums; A.dgamma = dgamma; A.dbeta = dbeta;
+    A.out_sums = static_cast<float *>(workspace);
     hipLaunchKernelGGL(norm_act_bwd_reduce_kernel, grid, dim3(GT), 0, st, A);
+    EPN_CHECK_LAUNCH();
+    if (dgamma) EPN_HIP(hipMemsetAsync(dgamma, 0, sizeof(float) * c, st));
+    if (dbeta) EPN_HIP(hipMemsetAsync(dbeta, 0, sizeof(float) * c, st));
+    hipLaunchKernelGGL(bwd_finish_kernel, dim3(epn_cdiv(c, 16), groups), dim3(256), 0, st, A.out_sums, (int)grid.x, c, gamma,
+                       dsums, dgamma, dbeta);
     EPN_CHECK_LAUNCH();
     return 0;
 }

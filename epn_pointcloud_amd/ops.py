@@ -292,7 +292,9 @@ class NormActFn(torch.autograd.Function):
         groups, rows = (b, p * a) if instance else (1, b * p * a)
         sums = torch.empty((groups, c, 2), dtype=torch.float32, device=xc.device)
         st = _lib.stream_of(xc)
-        _lib.check(lib.epn_chan_stats_f32(_cl_ptr(xc), groups, rows, c, _lib.dev_ptr(sums, "sums"), st), "chan_stats")
+        ws = torch.empty(max(int(lib.epn_norm_workspace_bytes(groups, rows, c)), 16), dtype=torch.uint8, device=xc.device)
+        _lib.check(lib.epn_chan_stats_f32(_cl_ptr(xc), groups, rows, c, _lib.dev_ptr(sums, "sums"),
+                                          ctypes.c_void_p(ws.data_ptr()), ctypes.c_size_t(ws.numel()), st), "chan_stats")
         y = empty_cl(b, c, p, a, xc.device)
         g = gamma.contiguous() if gamma is not None else None
         bt = beta.contiguous() if beta is not None else None
@@ -317,10 +319,12 @@ class NormActFn(torch.autograd.Function):
         dg = torch.empty(c, dtype=torch.float32, device=xc.device) if g is not None else None
         db = torch.empty(c, dtype=torch.float32, device=xc.device) if bt is not None else None
         gp, bp = _lib.dev_ptr(g, "gamma"), _lib.dev_ptr(bt, "beta")
+        ws = torch.empty(max(int(lib.epn_norm_workspace_bytes(groups, rows, c)), 16), dtype=torch.uint8, device=xc.device)
         _lib.check(lib.epn_norm_act_bwd_reduce_f32(_cl_ptr(xc), _cl_ptr(dy), groups, rows, c,
                                                    _lib.dev_ptr(sums, "sums"), gp, bp, eps, slope,
                                                    _lib.dev_ptr(dsums, "dsums"), _lib.dev_ptr(dg, "dgamma"),
-                                                   _lib.dev_ptr(db, "dbeta"), st), "norm_act_bwd_reduce")
+                                                   _lib.dev_ptr(db, "dbeta"), ctypes.c_void_p(ws.data_ptr()),
+                                                   ctypes.c_size_t(ws.numel()), st), "norm_act_bwd_reduce")
         dx = None
         if ctx.needs_input_grad[0]:
             dx = torch.empty_like(xc)

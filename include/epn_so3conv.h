@@ -137,19 +137,23 @@ int epn_intra_so3conv_bwd_weight_f32(const float *feats_cl, const float *grad_ou
  * tensors, as two memory-bound passes instead of torch's 4-6 (+ layout copies).  x_cl f32[groups][rows][c]:
  *   BatchNorm2d   : groups = 1, rows = b*p*a  (statistics per channel over every other axis)
  *   InstanceNorm2d: groups = b, rows = p*a    (statistics per (sample, channel))
- * sums f32[groups][c][2] = (sum x, sum x^2) is produced by epn_chan_stats_f32 (zero-filled there) and consumed by the
+ * sums f32[groups][c][2] = (sum x, sum x^2) is produced by epn_chan_stats_f32 (block partials in the workspace, then a
+ * small finishing kernel: no atomics, deterministic) and consumed by the
  * apply passes: mean = s1/rows, var = s2/rows - mean^2 (biased, as both torch norms use for normalisation).
  *   y = leaky(((x - mean) * rsqrt(var + eps)) * gamma + beta, slope) (+ residual)      gamma/beta/residual optional
  * Backward: dsums f32[groups][c][2] = (sum dn, sum dn*xhat) with dn = dy * leaky'(.) * gamma, from
- * epn_norm_act_bwd_reduce_f32 (also accumulates dgamma / dbeta when given, zero-filled there), then
+ * epn_norm_act_bwd_reduce_f32 (also writes dgamma / dbeta when given), then
  *   dx = rstd * (dn - mean(dn) - xhat * mean(dn * xhat))                               epn_norm_act_bwd_apply_f32 */
-int epn_chan_stats_f32(const float *x_cl, int groups, long long rows, int c, float *sums, epn_stream_t stream);
+size_t epn_norm_workspace_bytes(int groups, long long rows, int c);   /* scratch of the two reduction entry points */
+int epn_chan_stats_f32(const float *x_cl, int groups, long long rows, int c, float *sums, void *workspace,
+                       size_t workspace_bytes, epn_stream_t stream);
 int epn_norm_act_fwd_f32(const float *x_cl, int groups, long long rows, int c, const float *sums,
                          const float *gamma, const float *beta, const float *residual_cl, float eps, float slope,
                          float *y_cl, epn_stream_t stream);
 int epn_norm_act_bwd_reduce_f32(const float *x_cl, const float *dy_cl, int groups, long long rows, int c,
                                 const float *sums, const float *gamma, const float *beta, float eps, float slope,
-                                float *dsums, float *dgamma, float *dbeta, epn_stream_t stream);
+                                float *dsums, float *dgamma, float *dbeta, void *workspace,
+                                size_t workspace_bytes, epn_stream_t stream);
 int epn_norm_act_bwd_apply_f32(const float *x_cl, const float *dy_cl, int groups, long long rows, int c,
                                const float *sums, const float *dsums, const float *gamma, const float *beta,
                                float eps, float slope, float *dx_cl, epn_stream_t stream);
