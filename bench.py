@@ -4,11 +4,12 @@
     python bench.py --gpus N --steps K --warmup W
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 ... bench.py --gpus N ...
 
-Workload (BASELINE.json configs[1]): ModelNet40 classification backbone, B=32 clouds per GPU, N=1024 points,
-K=32/16 neighbours, A=60 anchors, fp32 -- the 7 separable blocks of cls_so3net_pn (FPS -> ball query ->
-gather -> InterSO3Conv -> IntraSO3Conv + the block's norm/activation/skip glue), random-init weights,
-synthetic unit-ball clouds already resident in HBM.  One step = forward + backward (+ gradient all-reduce
-over RCCL when N > 1) + Adam update.  Weak scaling: per-GPU batch fixed.  Prints ONE JSON line (rank 0).
+Workload (BASELINE.json configs[1]): the ModelNet40 classification network cls_so3net_pn, B=32 clouds per GPU, N=1024
+points, K=32/16 neighbours, A=60 anchors, fp32 -- 7 separable blocks (FPS -> ball query -> gather -> InterSO3Conv ->
+IntraSO3Conv + the block's norm/activation/skip glue) and the ClsOutBlockPointnet head (1x1 conv, PointnetSO3Conv,
+attention over the anchors, 40-way logits), random-init weights, synthetic unit-ball clouds and labels already resident
+in HBM.  One step = forward + cross-entropy + backward (+ gradient all-reduce over RCCL when N > 1) + Adam update.
+--backbone-only drops the head (loss = mean square of the last feature map).  Weak scaling: per-GPU batch fixed.  Prints ONE JSON line (rank 0).
 """
 import argparse
 import json
@@ -28,6 +29,8 @@ KERNEL_OF = {  # C-ABI call -> device kernel family it launches on this workload
     "inter_fwd": "epn::inter_fwd8_kernel", "inter_bwd_data": "epn::inter_bwd_data8_kernel",
     "inter_bwd_weight": "epn::inter_bwd_weight8_kernel", "intra_fwd": "epn::intra_gemm_kernel",
     "intra_bwd_data": "epn::intra_gemm_kernel", "intra_bwd_weight": "epn::intra_bwd_weight_pt_kernel",
+    "pointnet_fwd": "epn::pointnet_fwd_kernel", "pointnet_bwd_data": "epn::pointnet_bwd_data_kernel",
+    "pointnet_bwd_weight": "epn::pointnet_bwd_weight_kernel",
 }
 PMC_FILE = os.path.join(ROOT, "profiles", "r01_pmc_per_kernel.json")   # tools/collect_profiles.sh + pmc_summary.py
 
@@ -60,29 +63,36 @@ def parse():
                     help="torch CPU threads of the baseline (16 measured fastest of {16,48,256} on the 2x EPYC 9575F "
                          "GPU host: the materialising reference algorithm is memory-bound and slows down with more)")
     ap.add_argument("--forward-only", action="store_true")
+    ap.add_argument("--backbone-only", action="store_true", help="without the output head")
     ap.add_argument("--model", default="cls", choices=["cls", "reg", "inv"],
                     help="cls = BASELINE configs[1] (the headline metric); reg / inv = the layer schedules of configs[2] / "
                          "[3] in fp32 (their bf16 variants are not implemented yet)")
     return ap.parse_args()
 
 
-def cpu_baseline(layers, product_sd, n_points, n_clouds, threads=16):
-    """The oracle's materialising restatement of the same backbone (kind "port"), fwd+bwd, on the host cores."""
+def cpu_baseline(layers, product_sd, n_points, n_clouds, threads=16, head=True):
+    """The oracle's materialising restatement of the same network (kind "port"), fwd+bwd, on the host cores."""
     from epn_pointcloud_amd import schedule as S
     from epn_pointcloud_amd.vgtk.so3conv import functional as L
     from epn_pointcloud_amd.vgtk import functional as fr
     from oracle import backbone_ref
     cores = max(1, min(threads, os.cpu_count() or 1))
     torch.set_num_threads(cores)
-    ref = backbone_ref.RefBackbone(layers, torch.from_numpy(L.get_anchors(60)),
-                                   torch.from_numpy(fr.kernel_points_raw(24)),
-                                   torch.from_numpy(L.get_intra_idx()).long())
+    tables = (torch.from_numpy(L.get_anchors(60)), torch.from_numpy(fr.kernel_points_raw(24)),
+              torch.from_numpy(L.get_intra_idx()).long())
+    ref = (backbone_ref.RefClsModel(layers, tables, out_mlps=(256,), pooling="attention") if head
+           else backbone_ref.RefBackbone(layers, *tables))
     ref.load_from_product(product_sd)
     ref.train()
     pts = S.synthetic_clouds(n_clouds, n_points, "cpu", seed=2913)
+    labels = torch.arange(n_clouds) % 40
     t0 = time.perf_counter()
-    _, feats = ref(pts)
-    feats.square().mean().backward()
+    if head:
+        logits, _ = ref(pts)
+        torch.nn.functional.cross_entropy(logits, labels).backward()
+    else:
+        _, feats = ref(pts)
+        feats.square().mean().backward()
     dt = time.perf_counter() - t0
     return {"value": n_clouds / dt, "unit": "point-clouds/s", "cores": cores, "kind": "port",
             "host_cpus": os.cpu_count(),
@@ -92,7 +102,7 @@ def cpu_baseline(layers, product_sd, n_points, n_clouds, threads=16):
 
 def main():
     args = parse()
-    from epn_pointcloud_amd import _lib, dp, ops, schedule as S
+    from epn_pointcloud_amd import _lib, dp, models as M, ops, schedule as S
     _lib.get_lib()                                     # fail loudly if the HIP library is missing
     rank, local_rank, world = dp.init_from_env()
     assert world == args.gpus or world == 1 and args.gpus == 1, (world, args.gpus)
@@ -105,20 +115,40 @@ def main():
     layers = {"cls": S.cls_so3net_schedule, "reg": S.reg_so3net_schedule,
               "inv": S.inv_so3net_schedule}[args.model](args.points)
     torch.manual_seed(2913)
-    model = S.HotPathBackbone(layers, norm="BatchNorm2d" if args.model == "cls" else None).to(dev).train()
+    head = not args.backbone_only
+    if not head:
+        model = S.HotPathBackbone(layers, norm="BatchNorm2d" if args.model == "cls" else None)
+    elif args.model == "cls":
+        model = M.ClsSO3ConvModel(layers, out_mlps=(256,), pooling="attention")
+    elif args.model == "reg":
+        model = M.RegSO3ConvModel(layers)
+    else:
+        model = M.InvSO3ConvModel(layers)
+    model = model.to(dev).train()
     dp.broadcast_parameters(model)
     params = [p for p in model.parameters() if p.requires_grad]
     opt = torch.optim.Adam(params, lr=1e-3)
     scale = 0.4 if args.model == "inv" else 1.0            # 3DMatch search_radius (options.py:30)
     pts = S.synthetic_clouds(args.batch, args.points, dev, seed=2913 + rank, scale=scale)   # resident in HBM
+    labels = (torch.arange(args.batch, device=dev) + rank) % 40
+    if head and args.model == "reg":                        # pairs of clouds [b/2, 2, n, 3] (reg_so3net.py:31-33)
+        pts = pts.view(args.batch // 2, 2, args.points, 3)
+
+    def loss_of(out):
+        if not head:
+            return out.feats.square().mean()
+        if args.model == "cls":
+            return torch.nn.functional.cross_entropy(out[0], labels)
+        if args.model == "inv":                             # descriptors are unit vectors: push them apart
+            return (out[0] @ out[0].t()).square().mean()
+        return out[0].square().mean() + out[1].square().mean()
 
     def step():
         opt.zero_grad(set_to_none=True)
         if args.forward_only:
             with torch.no_grad():
-                return model(pts).feats
-        x = model(pts)
-        loss = x.feats.square().mean()
+                return loss_of(model(pts))
+        loss = loss_of(model(pts))
         loss.backward()
         dp.allreduce_gradients(params, world)
         opt.step()
@@ -173,9 +203,11 @@ def main():
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(dt / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": {"cls": "ModelNet40 cls backbone (cls_so3net_pn, 7 separable SO3 blocks)",
-                                    "reg": "ModelNet40 rotation backbone (reg_so3net, 7 separable SO3 blocks)",
-                                    "inv": "3DMatch descriptor backbone (inv_so3net_pn, 8 separable SO3 blocks)"}[args.model]
+            "config": {"workload": {"cls": "ModelNet40 classification (cls_so3net_pn: 7 separable SO3 blocks",
+                                    "reg": "ModelNet40 relative rotation (reg_so3net: 7 separable SO3 blocks",
+                                    "inv": "3DMatch descriptor (inv_so3net_pn: 8 separable SO3 blocks"}[args.model]
+                                   + ({"cls": " + ClsOutBlockPointnet head)", "reg": " + RelSO3OutBlockR head)",
+                                       "inv": " + InvOutBlockMVD head)"}[args.model] if head else ", backbone only)")
                                    + f", B={args.batch}/GPU N={args.points} K={'/'.join(str(k) for k in sorted({l.nn for l in layers}, reverse=True))} "
                                    + f"A=60 fp32, {'fwd' if args.forward_only else 'fwd+bwd+Adam'}",
                        "global_batch": args.batch * world, "points": args.points, "anchors": 60,
@@ -184,7 +216,7 @@ def main():
         }
         if world == 1 and not args.no_cpu_baseline and args.model == "cls":
             out["cpu_baseline"] = cpu_baseline(layers, model.state_dict(), args.points, args.cpu_clouds,
-                                               args.cpu_threads)
+                                               args.cpu_threads, head)
         print(json.dumps(out), flush=True)
     if world > 1:
         torch.distributed.destroy_process_group()

@@ -1,0 +1,238 @@
+// PointnetSO3Conv (vgtk/vgtk/so3conv/modules.py:203-235), the aggregation tail of every shipped model:
+//   xyzc      = xyz - mean_p(xyz)
+//   ext[c..]  = R_a^T xyzc          (einsum 'aji,bjn->bina'; na == 1: xyzc itself)
+//   out[b,o,a]= max_p ( sum_c W[o][c] F[b,c,p,a] + sum_j W[o][C+j] ext_j + bias[o] )
+// fused into one pass: the concatenated [C+3]-channel tensor and the [b,co,p,a] embedding never exist in HBM.  The
+// layer is small (4 GFLOP at the cls head) and runs on the VALU in exact fp32: one workgroup per (cloud, anchor) and
+// block of 128 output channels, thread = output channel, W^T and a 32-point feature tile staged in LDS.
+// The backward pass routes dOut through the arg-max point (torch.max backward) without materialising the embedding.
+#include "conv_internal.h"
+
+namespace epn {
+namespace {
+
+constexpr int PN_T = 128;    // threads = output channels per workgroup
+constexpr int PN_P = 32;     // points per tile
+constexpr int PN_C = 64;     // channels per tile
+
+struct PnArgs {
+    const float *feats, *xyz, *anchors, *W, *bias, *gout, *centre_in;
+    const int32_t *arg_in;
+    float *out, *centre, *dfeats, *dW, *dbias;
+    int32_t *arg;
+    int b, p, a, c, co, slices;
+};
+
+// rotated, centred coordinate of point pp for anchor ai (anchors == nullptr: identity)
+__device__ __forceinline__ void ext_xyz(const PnArgs &A, int bb, int ai, int pp, const float (&ctr)[3], float (&e)[3]) {
+    const float *s = A.xyz + (size_t)bb * 3 * A.p;
+    const float v0 = s[pp] - ctr[0], v1 = s[A.p + pp] - ctr[1], v2 = s[2 * A.p + pp] - ctr[2];
+    if (A.anchors) {
+        const float *R = A.anchors + (size_t)ai * 9;   // e_i = sum_j R[j][i] v_j
+#pragma unroll
+        for (int i = 0; i < 3; ++i) e[i] = R[i] * v0 + R[3 + i] * v1 + R[6 + i] * v2;
+    } else {
+        e[0] = v0; e[1] = v1; e[2] = v2;
+    }
+}
+
+__global__ __launch_bounds__(PN_T) void pointnet_fwd_kernel(PnArgs A) {
+    __shared__ float Ws[PN_C][PN_T + 1];                          // W^T tile: [channel][output channel]
+    __shared__ __attribute__((aligned(16))) float Fs[PN_P][PN_C + 4];
+    __shared__ float Es[PN_P][4];
+    __shared__ float ctr_s[3];
+    const int t = threadIdx.x;
+    const int bb = blockIdx.x / A.a, ai = blockIdx.x % A.a;
+    const int o = blockIdx.y * PN_T + t;
+    const bool o_ok = o < A.co;
+    const int ce = A.c + 3;
+
+    if (t < 3) {   // centre of the cloud: plain sequential mean (every workgroup of this cloud gets the same bits)
+        const float *s = A.xyz + ((size_t)bb * 3 + t) * A.p;
+        float m = 0.f;
+        for (int i = 0; i < A.p; ++i) m += s[i];
+        m /= (float)A.p;
+        ctr_s[t] = m;
+        if (ai == 0 && blockIdx.y == 0) A.centre[bb * 3 + t] = m;
+    }
+    __syncthreads();
+    const float ctr[3] = {ctr_s[0], ctr_s[1], ctr_s[2]};
+    const float w3[3] = {o_ok ? A.W[(size_t)o * ce + A.c] : 0.f, o_ok ? A.W[(size_t)o * ce + A.c + 1] : 0.f,
+                         o_ok ? A.W[(size_t)o * ce + A.c + 2] : 0.f};
+    const float bias = (o_ok && A.bias) ? A.bias[o] : 0.f;
+
+    float best = -INFINITY;
+    int best_p = 0;
+    for (int p0 = 0; p0 < A.p; p0 += PN_P) {
+        __syncthreads();
+        if (t < PN_P) {
+            float e[3] = {0.f, 0.f, 0.f};
+            if (p0 + t < A.p) ext_xyz(A, bb, ai, p0 + t, ctr, e);
+            Es[t][0] = e[0]; Es[t][1] = e[1]; Es[t][2] = e[2];
+        }
+        __syncthreads();
+        float acc[PN_P];
+#pragma unroll
+        for (int i = 0; i < PN_P; ++i) acc[i] = bias + w3[0] * Es[i][0] + w3[1] * Es[i][1] + w3[2] * Es[i][2];
+        for (int c0 = 0; c0 < A.c; c0 += PN_C) {
+            __syncthreads();
+            // W^T tile and feature tile: consecutive threads read consecutive channels (coalesced), the padded LDS
+            // rows keep the transposed writes conflict-free
+            for (int e = t; e < PN_C * PN_T; e += PN_T) {
+                const int cl = e % PN_C, j = e / PN_C;
+                const int cc = c0 + cl, oo = blockIdx.y * PN_T + j;
+                Ws[cl][j] = (cc < A.c && oo < A.co) ? A.W[(size_t)oo * ce + cc] : 0.f;
+            }
+            for (int e = t; e < PN_C * PN_P; e += PN_T) {
+                const int cl = e % PN_C, i = e / PN_C;
+                const int cc = c0 + cl, pp = p0 + i;
+                Fs[i][cl] = (cc < A.c && pp < A.p) ? A.feats[(((size_t)bb * A.p + pp) * A.a + ai) * A.c + cc] : 0.f;
+            }
+            __syncthreads();
+            for (int c4 = 0; c4 < PN_C; c4 += 4) {
+                const float w0 = Ws[c4][t], w1 = Ws[c4 + 1][t], w2 = Ws[c4 + 2][t], w3c = Ws[c4 + 3][t];
+#pragma unroll
+                for (int i = 0; i < PN_P; ++i) {
+                    const f32x4 f = *reinterpret_cast<const f32x4 *>(&Fs[i][c4]);   // LDS broadcast
+                    acc[i] += w0 * f[0] + w1 * f[1] + w2 * f[2] + w3c * f[3];
+                }
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < PN_P; ++i)
+            if (p0 + i < A.p && acc[i] > best) { best = acc[i]; best_p = p0 + i; }   // first maximum wins
+    }
+    if (o_ok) {
+        const size_t at = ((size_t)bb * A.a + ai) * A.co + o;
+        A.out[at] = best;
+        A.arg[at] = best_p;
+    }
+}
+
+// dF[b,p,a,c] = sum_{o : arg[b,a,o] == p} dOut[b,a,o] * W[o][c];  workgroup = (cloud, anchor) x 128-channel block,
+// thread = channel, the point tile accumulates in LDS in output-channel order (deterministic, no atomics).
+__global__ __launch_bounds__(PN_T) void pointnet_bwd_data_kernel(PnArgs A) {
+    constexpr int PT = 64;
+    __shared__ float dFs[PT][PN_T];
+    const int t = threadIdx.x;
+    const int bb = blockIdx.x / A.a, ai = blockIdx.x % A.a;
+    const int cc = blockIdx.y * PN_T + t;
+    const int ce = A.c + 3;
+    const size_t at = ((size_t)bb * A.a + ai) * A.co;
+    for (int p0 = 0; p0 < A.p; p0 += PT) {
+        for (int i = 0; i < PT; ++i) dFs[i][t] = 0.f;
+        // only this thread touches column t: no barrier needed
+        for (int o = 0; o < A.co; ++o) {
+            const int ps = A.arg_in[at + o] - p0;          // wave-uniform
+            if (ps < 0 || ps >= PT) continue;
+            const float g = A.gout[at + o];
+            if (cc < A.c) dFs[ps][t] += g * A.W[(size_t)o * ce + cc];
+        }
+        if (cc < A.c)
+            for (int i = 0; i < PT && p0 + i < A.p; ++i)
+                A.dfeats[(((size_t)bb * A.p + p0 + i) * A.a + ai) * A.c + cc] = dFs[i][t];
+    }
+}
+
+// dW[o][ce] = sum_{b,a} dOut[b,a,o] * ext_feature[b, arg[b,a,o], a, ce];  dbias[o] = sum_{b,a} dOut[b,a,o].
+// grid = (output channel, slice of the (b,a) range); thread = (extended) input channel; one atomic per slice.
+__global__ __launch_bounds__(256) void pointnet_bwd_weight_kernel(PnArgs A) {
+    const int o = blockIdx.x;
+    const int ce = A.c + 3;
+    const long long nba = (long long)A.b * A.a;
+    const long long per = (nba + A.slices - 1) / A.slices;
+    const long long q0 = blockIdx.y * per;
+    long long q1 = q0 + per;
+    q1 = q1 < nba ? q1 : nba;
+    for (int e0 = 0; e0 < ce; e0 += 256) {
+        const int e = e0 + threadIdx.x;
+        float acc = 0.f, accb = 0.f;
+        for (long long q = q0; q < q1; ++q) {
+            const int bb = (int)(q / A.a), ai = (int)(q % A.a);
+            const float g = A.gout[q * A.co + o];
+            const int ps = A.arg_in[q * A.co + o];
+            accb += g;
+            if (e < A.c) {
+                acc += g * A.feats[(((size_t)bb * A.p + ps) * A.a + ai) * A.c + e];
+            } else if (e < ce) {
+                const float ctr[3] = {A.centre_in[bb * 3], A.centre_in[bb * 3 + 1], A.centre_in[bb * 3 + 2]};
+                float x3[3];
+                ext_xyz(A, bb, ai, ps, ctr, x3);
+                acc += g * x3[e - A.c];
+            }
+        }
+        if (e < ce) atomicAdd(A.dW + (size_t)o * ce + e, acc);
+        if (e == 0 && A.dbias) atomicAdd(A.dbias + o, accb);
+    }
+}
+
+PnArgs make_pn(int b, int p, int a, int c, int co) {
+    PnArgs A = {};
+    A.b = b; A.p = p; A.a = a; A.c = c; A.co = co; A.slices = 1;
+    return A;
+}
+
+}  // namespace
+}  // namespace epn
+
+using namespace epn;
+
+static int check_pn(int b, int p, int a, int c, int co) {
+    if (b < 0 || p < 1 || a < 1 || c < 1 || co < 1) return EPN_EINVAL;
+    if ((long long)b * p * a * c >= (1LL << 40) || (long long)b * a > 0x7fffffffLL) return EPN_EINVAL;
+    return 0;
+}
+
+extern "C" int epn_pointnet_so3conv_fwd_f32(const float *feats_cl, const float *xyz, const float *anchors,
+                                            const float *W, const float *bias, float *out, int32_t *argmax,
+                                            float *centre, int b, int p, int a, int c, int co,
+                                            epn_stream_t stream) {
+    int rc = check_pn(b, p, a, c, co);
+    if (rc) return rc;
+    if (b == 0) return 0;
+    if (!feats_cl || !xyz || !W || !out || !argmax || !centre) return EPN_ENULL;
+    PnArgs A = make_pn(b, p, a, c, co);
+    A.feats = feats_cl; A.xyz = xyz; A.anchors = anchors; A.W = W; A.bias = bias; A.out = out; A.arg = argmax;
+    A.centre = centre;
+    hipLaunchKernelGGL(pointnet_fwd_kernel, dim3((unsigned)(b * a), (unsigned)epn_cdiv(co, PN_T)), dim3(PN_T), 0,
+                       epn_stream(stream), A);
+    EPN_CHECK_LAUNCH();
+    return 0;
+}
+
+extern "C" int epn_pointnet_so3conv_bwd_data_f32(const float *grad_out, const int32_t *argmax, const float *W,
+                                                 float *grad_feats_cl, int b, int p, int a, int c, int co,
+                                                 epn_stream_t stream) {
+    int rc = check_pn(b, p, a, c, co);
+    if (rc) return rc;
+    if (b == 0) return 0;
+    if (!grad_out || !argmax || !W || !grad_feats_cl) return EPN_ENULL;
+    PnArgs A = make_pn(b, p, a, c, co);
+    A.gout = grad_out; A.arg_in = argmax; A.W = W; A.dfeats = grad_feats_cl;
+    hipLaunchKernelGGL(pointnet_bwd_data_kernel, dim3((unsigned)(b * a), (unsigned)epn_cdiv(c, PN_T)), dim3(PN_T), 0,
+                       epn_stream(stream), A);
+    EPN_CHECK_LAUNCH();
+    return 0;
+}
+
+extern "C" int epn_pointnet_so3conv_bwd_weight_f32(const float *grad_out, const int32_t *argmax, const float *feats_cl,
+                                                   const float *xyz, const float *anchors, const float *centre,
+                                                   float *grad_W, float *grad_bias, int b, int p, int a, int c, int co,
+                                                   epn_stream_t stream) {
+    int rc = check_pn(b, p, a, c, co);
+    if (rc) return rc;
+    if (!grad_W) return EPN_ENULL;
+    hipStream_t st = epn_stream(stream);
+    EPN_HIP(hipMemsetAsync(grad_W, 0, (size_t)co * (c + 3) * sizeof(float), st));
+    if (grad_bias) EPN_HIP(hipMemsetAsync(grad_bias, 0, (size_t)co * sizeof(float), st));
+    if (b == 0) return 0;
+    if (!grad_out || !argmax || !feats_cl || !xyz || !centre) return EPN_ENULL;
+    PnArgs A = make_pn(b, p, a, c, co);
+    A.gout = grad_out; A.arg_in = argmax; A.feats = feats_cl; A.xyz = xyz; A.anchors = anchors; A.centre_in = centre;
+    A.dW = grad_W; A.dbias = grad_bias;
+    const long long nba = (long long)b * a;
+    A.slices = (int)(nba < 16 ? nba : 16);
+    hipLaunchKernelGGL(pointnet_bwd_weight_kernel, dim3((unsigned)co, (unsigned)A.slices), dim3(256), 0, st, A);
+    EPN_CHECK_LAUNCH();
+    return 0;
+}

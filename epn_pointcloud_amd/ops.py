@@ -360,3 +360,79 @@ def inter_so3conv(feats, W, geo):
 
 def intra_so3conv(feats, W, intra_idx32):
     return IntraSO3ConvFn.apply(feats, W, intra_idx32)
+
+
+class PointnetSO3ConvFn(torch.autograd.Function):
+    """max_p(embed(cat(feats, R_a^T (xyz - mean)))) of PointnetSO3Conv.forward (vgtk/vgtk/so3conv/modules.py:219-235)
+    in one fused HIP pass; returns [b, co, a] (a channels-last view of the [b][a][co] buffer the kernel writes).
+    Gradients flow to feats / weight / bias through the arg-max point, as torch.max's backward does."""
+
+    @staticmethod
+    def forward(ctx, feats, xyz, anchors, weight, bias):
+        lib = _lib.get_lib()
+        fc = to_cl(feats, "feats")
+        b, c, p, a = fc.shape
+        co = weight.shape[0]
+        if weight.numel() != co * (c + 3):
+            raise ValueError(f"embed weight must be [co, c+3, 1, 1] with c={c}, got {tuple(weight.shape)}")
+        if tuple(xyz.shape) != (b, 3, p):
+            raise ValueError(f"xyz must be [b,3,p]=({b},3,{p}), got {tuple(xyz.shape)}")
+        w = weight.reshape(co, c + 3).contiguous()
+        xyz = xyz.contiguous()
+        anc = anchors.contiguous() if (anchors is not None and a > 1) else None
+        out = torch.empty((b, a, co), dtype=torch.float32, device=fc.device)
+        arg = torch.empty((b, a, co), dtype=torch.int32, device=fc.device)
+        ctr = torch.empty((b, 3), dtype=torch.float32, device=fc.device)
+        bs = bias.contiguous() if bias is not None else None
+        _launch("pointnet_fwd", ("pointnet", b, p, a, c, co), 2.0 * b * p * a * co * (c + 3), fc.device,
+                lambda: _lib.check(lib.epn_pointnet_so3conv_fwd_f32(
+                    _cl_ptr(fc), _lib.dev_ptr(xyz, "xyz"), _lib.dev_ptr(anc, "anchors"), _lib.dev_ptr(w, "weight"),
+                    _lib.dev_ptr(bs, "bias"), _lib.dev_ptr(out, "out"), _lib.dev_ptr(arg, "argmax", torch.int32),
+                    _lib.dev_ptr(ctr, "centre"), b, p, a, c, co, _lib.stream_of(fc)), "pointnet_so3conv_fwd"))
+        ctx.save_for_backward(fc, xyz, anc, w, arg, ctr)
+        ctx.cfg = (b, p, a, c, co, tuple(weight.shape), bias is not None)
+        return out.permute(0, 2, 1)
+
+    @staticmethod
+    def backward(ctx, grad_out):
+        lib = _lib.get_lib()
+        fc, xyz, anc, w, arg, ctr = ctx.saved_tensors
+        b, p, a, c, co, wshape, has_bias = ctx.cfg
+        g = grad_out.permute(0, 2, 1).contiguous()           # [b][a][co]
+        st = _lib.stream_of(fc)
+        dF = dW = db = None
+        if ctx.needs_input_grad[0]:
+            dF = torch.empty_like(fc)
+            _launch("pointnet_bwd_data", ("pointnet", b, p, a, c, co), 2.0 * b * a * co * c, fc.device,
+                    lambda: _lib.check(lib.epn_pointnet_so3conv_bwd_data_f32(
+                        _lib.dev_ptr(g, "grad_out"), _lib.dev_ptr(arg, "argmax", torch.int32), _lib.dev_ptr(w, "weight"),
+                        _cl_ptr(dF), b, p, a, c, co, st), "pointnet_so3conv_bwd_data"))
+        if ctx.needs_input_grad[3] or (has_bias and ctx.needs_input_grad[4]):
+            dW = torch.empty((co, c + 3), dtype=torch.float32, device=fc.device)
+            db = torch.empty(co, dtype=torch.float32, device=fc.device) if has_bias else None
+            _launch("pointnet_bwd_weight", ("pointnet", b, p, a, c, co), 2.0 * b * a * co * (c + 3), fc.device,
+                    lambda: _lib.check(lib.epn_pointnet_so3conv_bwd_weight_f32(
+                        _lib.dev_ptr(g, "grad_out"), _lib.dev_ptr(arg, "argmax", torch.int32), _cl_ptr(fc),
+                        _lib.dev_ptr(xyz, "xyz"), _lib.dev_ptr(anc, "anchors"), _lib.dev_ptr(ctr, "centre"),
+                        _lib.dev_ptr(dW, "grad_W"), _lib.dev_ptr(db, "grad_bias"), b, p, a, c, co, st),
+                        "pointnet_so3conv_bwd_weight"))
+            dW = dW.view(wshape)
+        return dF, None, None, dW, db
+
+
+def conv1x1(x, weight, bias=None):
+    """nn.Conv2d(cin, cout, 1) on a [b,c,p,a] tensor: the intra GEMM kernel with a single, identity anchor neighbour
+    (channels-last in and out, no layout copy); shapes the MFMA kernel does not take (cin = 1 of the first block, the
+    few-channel heads) go to torch."""
+    cout, cin = weight.shape[0], weight.shape[1]
+    if x.is_cuda and cin % 16 == 0 and cout % 16 == 0:
+        na = x.shape[3]
+        ident = torch.arange(na, dtype=torch.int32, device=x.device).view(na, 1)
+        y = IntraSO3ConvFn.apply(x, weight.reshape(cout, cin), ident)
+    else:
+        y = torch.nn.functional.conv2d(x, weight.reshape(cout, cin, 1, 1))
+    return y if bias is None else y + bias.view(1, -1, 1, 1)
+
+
+def pointnet_so3conv(feats, xyz, anchors, weight, bias):
+    return PointnetSO3ConvFn.apply(feats, xyz, anchors, weight, bias)

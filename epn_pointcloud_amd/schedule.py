@@ -19,7 +19,7 @@ from . import ops
 from .vgtk import so3conv as sptk
 from .vgtk import spconv as zptk
 
-Layer = namedtuple("Layer", "cin cout stride radius sigma nn lazy")
+Layer = namedtuple("Layer", "cin cout stride radius sigma nn lazy stage", defaults=(0,))
 
 
 def _schedule(input_num, mlps, strides, initial_radius_ratio, sampling_ratio, sampling_density, sigma_ratio,
@@ -47,28 +47,26 @@ def _schedule(input_num, mlps, strides, initial_radius_ratio, sampling_ratio, sa
                 stride, nidx, neighbor = strides[i], (i if i == 0 else i + 1), neighbor * 2
             else:
                 stride, nidx = 1, i + 1
-            layers.append(Layer(dim_in, dim_out, stride, radii[nidx], sigma[nidx], neighbor, i != 0 or j != 0))
+            layers.append(Layer(dim_in, dim_out, stride, radii[nidx], sigma[nidx], neighbor, i != 0 or j != 0, i))
             dim_in = dim_out
     return layers
 
 
-def cls_so3net_schedule(input_num=1024):
+def cls_so3net_schedule(input_num=1024, mlps=((64, 64), (128, 128), (256, 256), (256,)), strides=(2, 2, 2, 2)):
     """cls_so3net_pn.build_model (SPConvNets/models/cls_so3net_pn.py:43-150), ModelNet40 classification."""
-    return _schedule(input_num, ((64, 64), (128, 128), (256, 256), (256,)), (2, 2, 2, 2), 0.2, 0.4, 0.5, 0.5, 1.0,
-                     False, False)
+    return _schedule(input_num, mlps, strides, 0.2, 0.4, 0.5, 0.5, 1.0, False, False)
 
 
-def reg_so3net_schedule(input_num=1024):
+def reg_so3net_schedule(input_num=1024, mlps=((32, 32), (64, 64), (128, 128), (256,)), strides=(2, 2, 2, 2)):
     """reg_so3net.build_model (SPConvNets/models/reg_so3net.py:52-150), ModelNet40 rotation estimation (pairs of
     clouds are concatenated along the batch axis, reg_so3net.py:31-33)."""
-    return _schedule(input_num, ((32, 32), (64, 64), (128, 128), (256,)), (2, 2, 2, 2), 0.2, 0.8, 0.5, 0.5, 1.0,
-                     False, False)
+    return _schedule(input_num, mlps, strides, 0.2, 0.8, 0.5, 0.5, 1.0, False, False)
 
 
-def inv_so3net_schedule(input_num=2048, search_radius=0.4):
+def inv_so3net_schedule(input_num=2048, search_radius=0.4, mlps=((32, 32), (64, 64), (128, 128), (128, 128)),
+                        strides=(2, 2, 2, 2)):
     """inv_so3net_pn.build_model (SPConvNets/models/inv_so3net_pn.py:43-150), 3DMatch local-patch descriptor."""
-    return _schedule(input_num, ((32, 32), (64, 64), (128, 128), (128, 128)), (2, 2, 2, 2), 0.2, 0.8, 0.5, 0.5,
-                     search_radius, True, True)
+    return _schedule(input_num, mlps, strides, 0.2, 0.8, 0.5, 0.5, search_radius, True, True)
 
 
 def scaled(layers, width_div):
@@ -81,85 +79,125 @@ def scaled(layers, width_div):
     return out
 
 
-class SeparableBlock(nn.Module):
-    """One SeparableSO3ConvBlock of the cls model (norm='BatchNorm2d', activation='leaky_relu',
-    SPConvNets/utils/base_so3conv.py:168-212).  The norm / activation / skip glue are stock torch modules (MIOpen
-    batch-norm and 1x1 convolution: measured faster than hand-composed channels-last torch ops; fusing them into the
-    conv epilogues is SURVEY 8f.1, "next")."""
+class _ConvNorm(nn.Module):
+    """Attribute layout of InterSO3ConvBlock / IntraSO3ConvBlock (base_so3conv.py:32-62, 93-126): `.conv`, `.norm`."""
 
-    def __init__(self, l, kanchor=60, norm="BatchNorm2d"):
+    def __init__(self, conv, norm):
+        super().__init__()
+        self.conv = conv
+        self.norm = norm
+
+
+class SeparableBlock(nn.Module):
+    """One SeparableSO3ConvBlock (SPConvNets/utils/base_so3conv.py:168-212) with the reference's module tree, so a
+    reference checkpoint's keys (`inter_conv.conv.basic_conv.W`, `inter_conv.norm.*`, `intra_conv.conv.*`,
+    `skip_conv.*`, `norm.*`) load unchanged.  This class runs the glue (norm, leaky_relu, skip) on stock torch modules
+    around the fused HIP convolutions; FusedSeparableBlock below moves the glue onto HIP kernels as well.
+    forward(x, inter_idx=None, inter_w=None) -> (inter_idx, inter_w, sample_idx, x_out) like the reference."""
+
+    def __init__(self, l, kanchor=60, norm="BatchNorm2d", dropout_rate=0.0):
         super().__init__()
         # norm=None -> InstanceNorm2d(affine=False), the default of InterSO3ConvBlock / SeparableSO3ConvBlock
         # (base_so3conv.py:107,191) used by the rotation and 3DMatch models; the cls model passes 'BatchNorm2d'
         mk = (lambda c: nn.InstanceNorm2d(c, affine=False)) if norm is None else getattr(nn, norm)
         self.stride = l.stride
-        self.inter = sptk.InterSO3Conv(l.cin, l.cout, 1, l.stride, l.radius, l.sigma, l.nn,
-                                       lazy_sample=l.lazy, kanchor=kanchor)
-        self.inter_norm = mk(l.cout)
-        self.intra = sptk.IntraSO3Conv(l.cout, l.cout)
-        self.intra_norm = nn.InstanceNorm2d(l.cout, affine=False)
+        self.inter_conv = _ConvNorm(sptk.InterSO3Conv(l.cin, l.cout, 1, l.stride, l.radius, l.sigma, l.nn,
+                                                      lazy_sample=l.lazy, kanchor=kanchor), mk(l.cout))
+        self.intra_conv = _ConvNorm(sptk.IntraSO3Conv(l.cout, l.cout), nn.InstanceNorm2d(l.cout, affine=False))
         self.skip_conv = nn.Conv2d(l.cin, l.cout, 1)
         self.norm = mk(l.cout)
+        self.dropout = nn.Dropout(dropout_rate) if dropout_rate > 0 else None
 
-    def forward(self, x):
+    def _drop(self, t):
+        return self.dropout(t) if (self.dropout is not None and self.training) else t
+
+    def forward(self, x, inter_idx=None, inter_w=None):
         skip = x.feats
-        _, _, sample_idx, y = self.inter(x)
-        feat = F.leaky_relu(self.inter_norm(y.feats))
-        z = self.intra(zptk.SphericalPointCloud(y.xyz, feat, y.anchors))
-        feat = F.leaky_relu(self.intra_norm(z.feats))
+        inter_idx, inter_w, sample_idx, y = self.inter_conv.conv(x, inter_idx, inter_w)
+        feat = self._drop(F.leaky_relu(self.inter_conv.norm(y.feats)))
+        z = self.intra_conv.conv(zptk.SphericalPointCloud(y.xyz, feat, y.anchors))
+        feat = self._drop(F.leaky_relu(self.intra_conv.norm(z.feats)))
         if self.stride > 1:
             skip = zptk.functional.batched_index_select(skip, 2, sample_idx.long())
         skip = F.leaky_relu(self.norm(self.skip_conv(skip)))
-        return zptk.SphericalPointCloud(z.xyz, feat + skip, z.anchors)
+        return inter_idx, inter_w, sample_idx, zptk.SphericalPointCloud(z.xyz, feat + skip, z.anchors)
 
 
 class FusedSeparableBlock(SeparableBlock):
     """Same module tree / state_dict as SeparableBlock, with the glue on the HIP "block glue" kernels:
     norm + leaky_relu (+ the residual add) are two streaming passes each, the 1x1 skip convolution runs on the intra
     GEMM kernel (one anchor "neighbour", identity index) -- everything stays channels-last, no layout copies.
-    Training-mode semantics (batch statistics); eval mode falls back to the stock modules."""
+    Training-mode semantics (batch statistics); eval mode and dropout fall back to the stock modules."""
 
-    def forward(self, x):
-        c_out = self.intra.dim_out
-        if (not self.training) or not ops.norm_act_supported(c_out):
-            return super().forward(x)
+    def forward(self, x, inter_idx=None, inter_w=None):
+        c_out = self.intra_conv.conv.dim_out
+        if (not self.training) or self.dropout is not None or not ops.norm_act_supported(c_out):
+            return super().forward(x, inter_idx, inter_w)
         skip = x.feats
-        _, _, sample_idx, y = self.inter(x)
-        feat = ops.norm_act(y.feats, self.inter_norm)
-        z = self.intra(zptk.SphericalPointCloud(y.xyz, feat, y.anchors))
+        inter_idx, inter_w, sample_idx, y = self.inter_conv.conv(x, inter_idx, inter_w)
+        feat = ops.norm_act(y.feats, self.inter_conv.norm)
+        z = self.intra_conv.conv(zptk.SphericalPointCloud(y.xyz, feat, y.anchors))
         if self.stride > 1:                                    # batched_index_select(skip, 2, sample_idx) on rows
             s_cl = ops.to_cl(skip).permute(0, 2, 3, 1)           # [b,p1,a,c] view of the channels-last image
             b, p1, a, c = s_cl.shape
             idx = sample_idx.long().view(b, -1, 1).expand(-1, -1, a * c)
             skip = torch.gather(s_cl.reshape(b, p1, a * c), 1, idx).view(b, -1, a, c).permute(0, 3, 1, 2)
-        na = skip.shape[3]
-        ident = torch.arange(na, dtype=torch.int32, device=skip.device).view(na, 1)
-        w = self.skip_conv.weight.view(self.skip_conv.out_channels, -1)
-        if skip.shape[1] % 16 == 0:
-            s = ops.intra_so3conv(skip, w, ident)               # 1x1 conv = intra GEMM with kn = 1
-        else:
-            s = F.conv2d(skip, self.skip_conv.weight)           # cin = 1 (first block): trivial
-        s = s + self.skip_conv.bias.view(1, -1, 1, 1)
+        s = ops.conv1x1(skip, self.skip_conv.weight, self.skip_conv.bias)
         s = ops.norm_act(s, self.norm)
-        out = ops.norm_act(z.feats, self.intra_norm, residual=s)   # leaky(IN(z)) + skip in the same pass
-        return zptk.SphericalPointCloud(z.xyz, out, z.anchors)
+        out = ops.norm_act(z.feats, self.intra_conv.norm, residual=s)   # leaky(IN(z)) + skip in the same pass
+        return inter_idx, inter_w, sample_idx, zptk.SphericalPointCloud(z.xyz, out, z.anchors)
+
+
+class BasicBlock(nn.Module):
+    """One resolution stage = BasicSO3ConvBlock (base_so3conv.py:129-166): `.blocks`, the (inter_idx, inter_w) of a
+    block handed to the next one until a strided block resets them."""
+
+    def __init__(self, layers, kanchor=60, norm="BatchNorm2d", fused_glue=True, dropout_rate=0.0):
+        super().__init__()
+        blk = FusedSeparableBlock if fused_glue else SeparableBlock
+        self.blocks = nn.ModuleList([blk(l, kanchor, norm, dropout_rate) for l in layers])
+
+    def forward(self, x):
+        inter_idx, inter_w = None, None
+        for blk in self.blocks:
+            inter_idx, inter_w, _, x = blk(x, inter_idx, inter_w)
+            if blk.stride > 1:
+                inter_idx, inter_w = None, None
+        return x
+
+
+def stages(layers):
+    """Split a flat schedule into its resolution stages (Layer.stage = index of the mlps row it came from)."""
+    out, last = [], None
+    for l in layers:
+        if last is None or l.stage != last:
+            out.append([])
+            last = l.stage
+        out[-1].append(l)
+    return out
+
+
+def preprocess_input(pts, kanchor):
+    """preprocess_input(x, na, add_center=False) (base_so3conv.py:16-23): [b, n, 3] -> SphericalPointCloud with the
+    all-ones occupancy feature [b, 1, n, na] (get_occupancy_features, vgtk/vgtk/so3conv/functional.py:25-44)."""
+    xyz = pts[:, :, :3].permute(0, 2, 1).contiguous()
+    feats = torch.ones(pts.shape[0], 1, pts.shape[1], kanchor, dtype=torch.float32, device=pts.device)
+    return zptk.SphericalPointCloud(xyz, feats, None)
 
 
 class HotPathBackbone(nn.Module):
-    """preprocess_input (ones features) -> chain of separable blocks.  Input [b, n, 3] point clouds."""
+    """preprocess_input (ones features) -> stages of separable blocks, with the reference models' `backbone.{i}.blocks.{j}`
+    module tree.  Input [b, n, 3] point clouds."""
 
-    def __init__(self, layers, kanchor=60, norm="BatchNorm2d", fused_glue=True):
+    def __init__(self, layers, kanchor=60, norm="BatchNorm2d", fused_glue=True, dropout_rate=0.0):
         super().__init__()
         self.kanchor = kanchor
-        blk = FusedSeparableBlock if fused_glue else SeparableBlock
-        self.blocks = nn.ModuleList([blk(l, kanchor, norm) for l in layers])
+        self.backbone = nn.ModuleList([BasicBlock(st, kanchor, norm, fused_glue, dropout_rate) for st in stages(layers)])
 
     def forward(self, pts):
-        xyz = pts.permute(0, 2, 1).contiguous()
-        feats = torch.ones(pts.shape[0], 1, pts.shape[1], self.kanchor, dtype=torch.float32, device=pts.device)
-        x = zptk.SphericalPointCloud(xyz, feats, None)
-        for blk in self.blocks:
-            x = blk(x)
+        x = preprocess_input(pts, self.kanchor)
+        for stage in self.backbone:
+            x = stage(x)
         return x
 
 

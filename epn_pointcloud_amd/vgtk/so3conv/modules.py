@@ -145,8 +145,10 @@ class IntraSO3Conv(nn.Module):
 
 
 class PointnetSO3Conv(nn.Module):
-    """Equivariant pointnet aggregation over points (modules.py:203-235); tail of every model, torch ops
-    ("next" for fusion)."""
+    """Equivariant pointnet aggregation over points (modules.py:203-235), the tail of every model: centre xyz, rotate
+    it into each anchor frame, concatenate to the features, 1x1 `embed` convolution, max over points -- one fused HIP
+    pass (epn_pointnet_so3conv_*_f32); same parameters / state_dict (embed.weight [co, c+3, 1, 1], embed.bias,
+    anchors buffer) and the same [nb, nc, na] result."""
 
     def __init__(self, dim_in, dim_out, kanchor=60):
         super(PointnetSO3Conv, self).__init__()
@@ -157,14 +159,4 @@ class PointnetSO3Conv(nn.Module):
         self.register_buffer('anchors', torch.from_numpy(np.ascontiguousarray(anchors)))
 
     def forward(self, x):
-        xyz = x.xyz
-        feats = x.feats
-        na = feats.shape[3]
-        xyz = xyz - xyz.mean(2, keepdim=True)
-        if na == 1:
-            feats = torch.cat([x.feats, xyz[..., None]], 1)
-        else:
-            xyzr = torch.einsum('aji,bjn->bina', self.anchors, xyz)
-            feats = torch.cat([x.feats, xyzr], 1)
-        feats = self.embed(feats)
-        return torch.max(feats, 2)[0]
+        return ops.pointnet_so3conv(x.feats, x.xyz, self.anchors, self.embed.weight, self.embed.bias)

@@ -158,6 +158,28 @@ int epn_norm_act_bwd_apply_f32(const float *x_cl, const float *dy_cl, int groups
                                const float *sums, const float *dsums, const float *gamma, const float *beta,
                                float eps, float slope, float *dx_cl, epn_stream_t stream);
 
+/* ---------------------------------------------------------------------------------------------------------------------
+ * PointnetSO3Conv: the aggregation tail of every shipped model
+ * replaces vgtk/vgtk/so3conv/modules.py:203-235 (PointnetSO3Conv.forward: centre xyz, rotate it into every anchor frame
+ * with einsum 'aji,bjn->bina', concatenate to the features, 1x1 Conv2d "embed", torch.max over the point axis) -- one
+ * fused pass, neither the concatenated tensor nor the per-point embedding is written to HBM.
+ *   feats_cl f32[b][p][a][c]   channels-last features          xyz   f32[b][3][p]
+ *   anchors  f32[a][3][3] or NULL (a == 1: no rotation, modules.py:227-228)
+ *   W        f32[co][c+3]      embed.weight (feature channels first, then the 3 coordinates)     bias f32[co] or NULL
+ *   out      f32[b][a][co]     = logical [b, co, a] viewed channels-last
+ *   argmax   i32[b][a][co]     point index of the maximum (first maximum wins), consumed by the backward entry points
+ *   centre   f32[b][3]         per-cloud mean of xyz, consumed by epn_pointnet_so3conv_bwd_weight_f32
+ * Backward = torch.max backward composed with the 1x1 convolution: gradients flow through the arg-max point only.
+ * xyz receives no gradient (the reference never asks for one: coordinates are inputs). */
+int epn_pointnet_so3conv_fwd_f32(const float *feats_cl, const float *xyz, const float *anchors, const float *W,
+                                 const float *bias, float *out, int32_t *argmax, float *centre, int b, int p, int a,
+                                 int c, int co, epn_stream_t stream);
+int epn_pointnet_so3conv_bwd_data_f32(const float *grad_out, const int32_t *argmax, const float *W,
+                                      float *grad_feats_cl, int b, int p, int a, int c, int co, epn_stream_t stream);
+int epn_pointnet_so3conv_bwd_weight_f32(const float *grad_out, const int32_t *argmax, const float *feats_cl,
+                                        const float *xyz, const float *anchors, const float *centre, float *grad_W,
+                                        float *grad_bias, int b, int p, int a, int c, int co, epn_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

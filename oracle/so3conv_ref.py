@@ -143,3 +143,16 @@ def scaled_kernel_points(raw_kernel_points, radius, ratio=0.7):
     kpsphere points so the largest norm equals ratio*radius."""
     r = (raw_kernel_points ** 2).sum(1).max().sqrt()
     return (raw_kernel_points * (ratio * radius) / r).float()
+
+
+def pointnet_so3conv(xyz, feats, anchors, weight, bias):
+    """PointnetSO3Conv.forward (vgtk/vgtk/so3conv/modules.py:219-235): centre xyz, rotate into every anchor frame
+    (einsum 'aji,bjn->bina'), concatenate behind the features, 1x1 embed, max over the point axis -> [b, co, a]."""
+    na = feats.shape[3]
+    xyz = xyz - xyz.mean(2, keepdim=True)
+    if na == 1:
+        ext = xyz[..., None]
+    else:
+        ext = torch.einsum('aji,bjn->bina', anchors, xyz)
+    z = torch.nn.functional.conv2d(torch.cat([feats, ext], 1), weight.reshape(weight.shape[0], -1, 1, 1), bias)
+    return z.max(2)[0]

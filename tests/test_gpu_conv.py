@@ -290,22 +290,14 @@ def test_separable_block_vs_reference_golden(gpu, vgtk_alias, fused):
     l = S.Layer(1, 8, 2, 0.4, 0.08, 16, False)
     blk = (S.FusedSeparableBlock if fused else S.SeparableBlock)(l).train()
     sd = {k[3:]: T(g[k]) for k in g.files if k.startswith("sd/")}
-    mapped = {
-        "inter.anchors": sd["inter_conv.conv.anchors"], "inter.kernels": sd["inter_conv.conv.kernels"],
-        "inter.basic_conv.W": sd["inter_conv.conv.basic_conv.W"],
-        "inter_norm.weight": sd["inter_conv.norm.weight"], "inter_norm.bias": sd["inter_conv.norm.bias"],
-        "intra.anchors": sd["intra_conv.conv.anchors"], "intra.intra_idx": sd["intra_conv.conv.intra_idx"],
-        "intra.basic_conv.W": sd["intra_conv.conv.basic_conv.W"],
-        "skip_conv.weight": sd["skip_conv.weight"], "skip_conv.bias": sd["skip_conv.bias"],
-        "norm.weight": sd["norm.weight"], "norm.bias": sd["norm.bias"],
-    }
-    missing, unexpected = blk.load_state_dict(mapped, strict=False)
-    assert not unexpected and all("running" in m or "num_batches" in m for m in missing)
+    missing, unexpected = blk.load_state_dict(sd, strict=False)      # the reference's own keys
+    assert not unexpected and not missing
     blk = blk.to(gpu)
     xyz = T(g["xyz"]).to(gpu)
     import vgtk.spconv as zptk
     x = zptk.SphericalPointCloud(xyz, torch.ones(2, 1, 256, 60, device=gpu), None)
-    y = blk(x)
+    _, _, sidx, y = blk(x)
+    assert torch.equal(sidx.cpu().long(), T(g["sample_idx"]).long())
     assert tuple(y.feats.shape) == (2, 8, 128, 60)
     assert (y.feats.detach().cpu() - T(g["out"])).abs().max().item() < TOL
 
@@ -370,8 +362,8 @@ def test_fused_block_matches_stock_block(gpu, vgtk_alias):
         b.load_state_dict(a.state_dict())
         feats = torch.randn(2, l.cin, 256, 60, device=gpu)
         fa, fb = feats.clone().requires_grad_(True), feats.clone().requires_grad_(True)
-        ya = a(zptk.SphericalPointCloud(xyz, fa, None)).feats
-        yb = b(zptk.SphericalPointCloud(xyz, fb, None)).feats
+        ya = a(zptk.SphericalPointCloud(xyz, fa, None))[3].feats
+        yb = b(zptk.SphericalPointCloud(xyz, fb, None))[3].feats
         gy = torch.randn_like(ya)
         ga = torch.autograd.grad(ya, [fa] + list(a.parameters()), gy)
         gb = torch.autograd.grad(yb, [fb] + list(b.parameters()), gy)

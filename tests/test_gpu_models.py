@@ -1,0 +1,152 @@
+"""GPU parity of the model tails and of whole networks, through the C ABI:
+PointnetSO3Conv (one fused HIP pass) against reference goldens and the oracle on awkward shapes; the three shipped
+networks (tiny widths, weights filled from their state_dict keys) against outputs of the unmodified reference builders
+(tests/golden/gen_golden_models.py), with the HIP block glue and with stock torch glue."""
+import numpy as np
+import pytest
+import torch
+
+from conftest import golden, unit_ball_cloud
+from test_models_cpu import TOL, fill_state_dict, filled_oracle, product_model
+
+pytestmark = pytest.mark.gpu
+T = torch.from_numpy
+
+
+def close(got, want, tol=TOL):
+    """|got - want| <= tol * max(1, max|want|): 1e-3 in units of the tensor's own scale (logits reach +-6)."""
+    want = want if torch.is_tensor(want) else T(want)
+    return (got.detach().cpu() - want).abs().max().item() <= tol * max(1.0, want.abs().max().item())
+
+
+@pytest.fixture(scope="module")
+def gpu():
+    assert torch.cuda.is_available()
+    from epn_pointcloud_amd import _lib
+    _lib.get_lib()
+    return torch.device("cuda", 0)
+
+
+@pytest.mark.parametrize("tag", ["a60", "a1"])
+def test_pointnet_vs_reference_golden(gpu, tag):
+    from epn_pointcloud_amd.vgtk import so3conv as sptk, spconv as zptk
+    g = golden(f"pointnet_{tag}.npz")
+    f = T(g["feats"]).to(gpu).requires_grad_(True)
+    m = fill_state_dict(sptk.PointnetSO3Conv(f.shape[1], g["out"].shape[1], 60)).to(gpu)
+    y = m(zptk.SphericalPointCloud(T(g["xyz"]).to(gpu), f, None))
+    assert tuple(y.shape) == g["out"].shape
+    assert (y.detach().cpu() - T(g["out"])).abs().max().item() < TOL
+    dF, dW, dB = torch.autograd.grad(y, [f, m.embed.weight, m.embed.bias], T(g["gy"]).to(gpu))
+    assert (dF.cpu() - T(g["dF"])).abs().max().item() < TOL
+    assert (dW.cpu() - T(g["dW"])).abs().max().item() < TOL
+    assert (dB.cpu() - T(g["dB"])).abs().max().item() < TOL
+
+
+@pytest.mark.parametrize("b,c,co,p,na", [(2, 128, 128, 64, 60), (1, 70, 200, 33, 60), (3, 16, 8, 129, 1),
+                                         (2, 256, 300, 40, 12)])
+def test_pointnet_vs_oracle(gpu, b, c, co, p, na):
+    """Tile edges: channels not a multiple of the 64-channel tile, more than 128 outputs, ragged point counts."""
+    from oracle import so3conv_ref as R
+    from epn_pointcloud_amd import ops
+    rng = np.random.default_rng(b * 1000 + c)
+    torch.manual_seed(c)
+    xyz = T(unit_ball_cloud(rng, b, p))
+    f = torch.randn(b, c, p, na)
+    anchors = torch.linalg.qr(torch.randn(na, 3, 3))[0].contiguous()
+    w, bias, gy = torch.randn(co, c + 3, 1, 1) / (c ** 0.5), torch.randn(co), torch.randn(b, co, na)
+    fr, wr, br = f.clone().requires_grad_(True), w.clone().requires_grad_(True), bias.clone().requires_grad_(True)
+    yr = R.pointnet_so3conv(xyz, fr, anchors if na > 1 else None, wr, br)
+    ref = torch.autograd.grad(yr, [fr, wr, br], gy)
+    fg, wg, bg = (t.to(gpu).requires_grad_(True) for t in (f, w, bias))
+    y = ops.pointnet_so3conv(fg, xyz.to(gpu), anchors.to(gpu), wg, bg)
+    got = torch.autograd.grad(y, [fg, wg, bg], gy.to(gpu))
+    assert (y.detach().cpu() - yr.detach()).abs().max().item() < TOL
+    for u, v, n in zip(got, ref, ("dF", "dW", "dB")):
+        assert (u.cpu() - v).abs().max().item() < TOL * max(1.0, v.abs().max().item()), n
+
+
+def test_pointnet_rejects_bad_arguments(gpu):
+    from epn_pointcloud_amd import ops
+    f = torch.randn(1, 8, 5, 4, device=gpu)
+    with pytest.raises(ValueError):
+        ops.pointnet_so3conv(f, torch.randn(1, 3, 6, device=gpu), None, torch.randn(4, 11, 1, 1, device=gpu), None)
+    with pytest.raises(ValueError):
+        ops.pointnet_so3conv(f, torch.randn(1, 3, 5, device=gpu), None, torch.randn(4, 8, 1, 1, device=gpu), None)
+    with pytest.raises(RuntimeError):
+        ops.pointnet_so3conv(f.cpu(), torch.randn(1, 3, 5), None, torch.randn(4, 11, 1, 1), None)
+
+
+def _set_glue(model, fused):
+    from epn_pointcloud_amd import schedule as S
+    for m in model.modules():
+        if isinstance(m, S.SeparableBlock):
+            m.__class__ = S.FusedSeparableBlock if fused else S.SeparableBlock
+    return model
+
+
+@pytest.mark.parametrize("fused", [True, False])
+def test_cls_model_vs_reference_golden(gpu, fused):
+    g = golden("model_cls_tiny.npz")
+    m = _set_glue(fill_state_dict(product_model("cls")), fused).to(gpu).train()
+    logits, att = m(T(g["pts"]).to(gpu))
+    assert close(logits, g["logits"])
+    assert close(att, g["attention"])
+    loss = torch.nn.functional.cross_entropy(logits, T(g["labels"]).to(gpu))
+    assert abs(loss.item() - float(g["loss"])) < TOL
+    pd = dict(m.named_parameters())
+    names = g["grad_names"].tolist()
+    grads = torch.autograd.grad(loss, [pd[n] for n in names])
+    for i, (n, gr) in enumerate(zip(names, grads)):
+        want = T(g[f"grad{i}"]).reshape(gr.shape)
+        assert (gr.cpu() - want).abs().max().item() < TOL * max(1.0, want.abs().max().item()), n
+    # eval mode (running statistics): stock modules around the HIP convolutions
+    m = fill_state_dict(m.cpu()).to(gpu).eval()
+    with torch.no_grad():
+        logits_eval, _ = m(T(g["pts"]).to(gpu))
+    assert close(logits_eval, g["logits_eval"])
+
+
+@pytest.mark.parametrize("fused", [True, False])
+def test_reg_model_vs_reference_golden(gpu, fused):
+    g = golden("model_reg_tiny.npz")
+    m = _set_glue(fill_state_dict(product_model("reg")), fused).to(gpu).train()
+    conf, quats = m(T(g["pairs"]).to(gpu))
+    assert close(conf, g["confidence"])
+    assert close(quats, g["quats"])
+
+
+@pytest.mark.parametrize("fused", [True, False])
+def test_inv_model_vs_reference_golden(gpu, fused):
+    g = golden("model_inv_tiny.npz")
+    m = _set_glue(fill_state_dict(product_model("inv")), fused).to(gpu).train()
+    desc, attn = m(T(g["pts"]).to(gpu))
+    assert close(desc, g["descriptor"])
+    assert close(attn[:, :, ::8], g["attention_sub"])
+    (desc @ desc.t()).square().sum().backward()
+    assert all(torch.isfinite(p.grad).all() for p in m.parameters() if p.grad is not None)
+
+
+def test_full_width_cls_step_matches_oracle_loss(gpu):
+    """Full-width classification network on 2 clouds: loss and a head / backbone gradient against the CPU oracle."""
+    from epn_pointcloud_amd import models as M, schedule as S
+    from oracle import backbone_ref as B
+    from test_models_cpu import tables
+    layers = S.cls_so3net_schedule(1024)
+    torch.manual_seed(5)
+    m = M.ClsSO3ConvModel(layers, out_mlps=(256,), pooling="attention").train()
+    ref = B.RefClsModel(layers, tables(), out_mlps=(256,), pooling="attention").train()
+    ref.load_from_product(m.state_dict())
+    pts = S.synthetic_clouds(2, 1024, "cpu", seed=11)
+    labels = torch.tensor([7, 31])
+    lr, _ = ref(pts)
+    loss_r = torch.nn.functional.cross_entropy(lr, labels)
+    names = ["outblock.fc2.weight", "backbone.3.blocks.0.inter_conv.conv.basic_conv.W"]
+    gr = torch.autograd.grad(loss_r, [dict(ref.named_parameters())[n] for n in names])
+    m = m.to(gpu)
+    lg, _ = m(pts.to(gpu))
+    loss_g = torch.nn.functional.cross_entropy(lg, labels.to(gpu))
+    gg = torch.autograd.grad(loss_g, [dict(m.named_parameters())[n] for n in names])
+    assert (lg.detach().cpu() - lr.detach()).abs().max().item() < TOL * max(1.0, lr.abs().max().item())
+    assert abs(loss_g.item() - loss_r.item()) < TOL
+    for n, u, v in zip(names, gg, gr):
+        assert (u.cpu() - v).abs().max().item() < TOL * max(1.0, v.abs().max().item()), n
