@@ -29,6 +29,8 @@ KERNEL_OF = {  # C-ABI call -> device kernel family it launches on this workload
     "inter_fwd": "epn::inter_fwd8_kernel", "inter_bwd_data": "epn::inter_bwd_data8_kernel",
     "inter_bwd_weight": "epn::inter_bwd_weight8_kernel", "intra_fwd": "epn::intra_gemm_kernel",
     "intra_bwd_data": "epn::intra_gemm_kernel", "intra_bwd_weight": "epn::intra_bwd_weight_pt_kernel",
+    "inter_group": "epn::inter_group_kernel", "inter_ungroup": "epn::inter_ungroup_kernel",
+    "inter_gemm": "rocBLAS fp32 GEMM (Cijk_*)",
     "pointnet_fwd": "epn::pointnet_fwd_kernel", "pointnet_bwd_data": "epn::pointnet_bwd_data_kernel",
     "pointnet_bwd_weight": "epn::pointnet_bwd_weight_kernel",
 }

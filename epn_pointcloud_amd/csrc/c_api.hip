@@ -158,6 +158,60 @@ extern "C" int epn_inter_so3conv_bwd_weight_f32(const epn_inter_desc *d, const f
     return launch_colreduce_dw(grad_out_cl, G, (size_t)d->b * d->p2 * d->na, d->cin * d->ks, d->cout, grad_W, st);
 }
 
+// ---- grouping only: G[col][c*ks + k] and its transpose; the caller runs the weight contraction as a plain GEMM
+extern "C" size_t epn_inter_group_workspace_bytes(const epn_inter_desc *d) {
+    if (!d) return 0;
+    InterWs w = inter_ws(d);
+    return w.big_off * sizeof(float);   // the rotated-kernel tables only
+}
+
+static int prep_tables(const epn_inter_desc *d, void *workspace, size_t bytes, InterWs &ws, float *&base,
+                       hipStream_t st) {
+    int rc = check_desc(d);
+    if (rc) return rc;
+    if (d->dense_w) return EPN_EINVAL;
+    ws = inter_ws(d);
+    if (!workspace || bytes < ws.big_off * sizeof(float)) return EPN_EWORKSPACE;
+    base = static_cast<float *>(workspace);
+    return launch_rk_table(d, base + ws.rk_off, st);
+}
+
+extern "C" int epn_inter_group_f32(const epn_inter_desc *d, const float *feats_cl, float *grouped, void *workspace,
+                                   size_t workspace_bytes, epn_stream_t stream) {
+    hipStream_t st = epn_stream(stream);
+    InterWs ws;
+    float *base = nullptr;
+    int rc = prep_tables(d, workspace, workspace_bytes, ws, base, st);
+    if (rc) return rc;
+    if (d->b == 0 || d->p2 == 0) return 0;
+    if (!feats_cl || !grouped) return EPN_ENULL;
+    if (inter_group_mfma_ok(d) && !force_generic()) {
+        rc = launch_inter_tables_mfma(d, base + ws.rk_off, base + ws.rk4_off, base + ws.beta_off, st);
+        if (rc) return rc;
+        return launch_inter_group_mfma(d, base + ws.rk4_off, feats_cl, grouped, st);
+    }
+    return launch_inter_group(d, base + ws.rk_off, feats_cl, grouped, st);
+}
+
+extern "C" int epn_inter_ungroup_f32(const epn_inter_desc *d, const float *grad_grouped, float *grad_feats_cl,
+                                     void *workspace, size_t workspace_bytes, epn_stream_t stream) {
+    hipStream_t st = epn_stream(stream);
+    InterWs ws;
+    float *base = nullptr;
+    int rc = prep_tables(d, workspace, workspace_bytes, ws, base, st);
+    if (rc) return rc;
+    if (!grad_feats_cl) return EPN_ENULL;
+    EPN_HIP(hipMemsetAsync(grad_feats_cl, 0, sizeof(float) * (size_t)d->b * d->p1 * d->na * d->cin, st));
+    if (d->b == 0 || d->p2 == 0) return 0;
+    if (!grad_grouped) return EPN_ENULL;
+    if (inter_group_mfma_ok(d) && !force_generic()) {
+        rc = launch_inter_tables_mfma(d, base + ws.rk_off, base + ws.rk4_off, base + ws.beta_off, st);
+        if (rc) return rc;
+        return launch_inter_ungroup_mfma(d, base + ws.rk4_off, grad_grouped, grad_feats_cl, st);
+    }
+    return launch_inter_scatter(d, base + ws.rk_off, grad_grouped, grad_feats_cl, st);
+}
+
 static int check_intra(int b, int p, int na, int kn, int cin, int cout) {
     if (b < 0 || p < 0 || na < 1 || kn < 1 || cin < 1 || cout < 1) return EPN_EINVAL;
     return 0;

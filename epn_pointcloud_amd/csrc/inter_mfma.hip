@@ -963,6 +963,74 @@ __global__ __launch_bounds__(64 * NW8) void inter_bwd_data8_kernel(InterArgs A) 
     }
 }
 
+// ------------------------------------------------------------------------------------ grouping only
+// "Split" path: the grouped features G[col][c*ks + k] go to HBM once (kept for the backward pass) and the weight
+// contraction is a plain [cols x cin*ks] x [cin*ks x cout] GEMM for the BLAS library (measured 110-150 TFLOP/s fp32 on
+// these shapes, tools/gemm_probe.py, against 67-84 for the fused kernels above).  A wave owns one 16-column tile; no
+// LDS, no barriers: weight generation + neighbour contraction exactly as in the fused kernels, the D fragment of
+// the contraction (4 consecutive kernel points of one channel) is one 16-byte global store.
+template <int NT, int KT>
+__global__ __launch_bounds__(64 * NW) void inter_group_kernel(InterArgs A) {
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int x = lane & 15, j = lane >> 4;
+    const long long col0 = ((long long)epn_xcd_tile(blockIdx.x, gridDim.x) * NW + wave) * 16;
+    if (col0 >= A.ncol) return;
+    const int gss = A.cin * A.ks;
+    float *G = A.out + (size_t)col0 * gss;
+    const int nchunk = A.cin >> 4;
+    if (A.na >= 16) {
+        Seg<NT> s0, s1;
+        make_segments<NT>(A, col0, x, j, s0, s1);
+        for (int ct = 0; ct < nchunk; ++ct) {
+            group_segment<NT, KT>(A, s0, ct, x, j, G + 16 * ct * A.ks, gss);
+            group_segment<NT, KT>(A, s1, ct, x, j, G + 16 * ct * A.ks, gss);
+        }
+    } else {
+        for (int ct = 0; ct < nchunk; ++ct) group_chunk_generic<NT, KT>(A, col0, ct, x, j, G + 16 * ct * A.ks, gss);
+    }
+}
+
+// Transpose of the grouping: dF[b, idx[n], a, c] += sum_k w[k][n] dG[col][c*ks + k]  (scatter_segment reads dG from HBM).
+template <int NT, int KT>
+__global__ __launch_bounds__(64 * NW) void inter_ungroup_kernel(InterArgs A) {
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int x = lane & 15, j = lane >> 4;
+    const long long col0 = ((long long)epn_xcd_tile(blockIdx.x, gridDim.x) * NW + wave) * 16;
+    if (col0 >= A.ncol) return;
+    const int gss = A.cin * A.ks;
+    const float *dG = A.gout + (size_t)col0 * gss;
+    const int nchunk = A.cin >> 4;
+    InterArgs B = A;
+    B.feats = A.out;   // segment base pointers address grad_feats_cl
+    if (A.na >= 16) {
+        Seg<NT> s0, s1;
+        make_segments<NT>(B, col0, x, j, s0, s1);
+        for (int ct = 0; ct < nchunk; ++ct) {
+            scatter_segment<NT, KT>(A, s0, ct, x, j, dG + 16 * ct * A.ks, gss);
+            scatter_segment<NT, KT>(A, s1, ct, x, j, dG + 16 * ct * A.ks, gss);
+        }
+    } else {
+        Seg<NT> sg;
+        int last_pt = -1;
+        for (int jc = 0; jc < 16; ++jc) {
+            const long long col = col0 + jc;
+            if (col >= A.ncol) break;
+            const int a = (int)(col % A.na);
+            const int pt = (int)(col / A.na);
+            const int bb = pt / A.p2, pp = pt - bb * A.p2;
+            if (pt != last_pt) {
+                load_hood<NT>(A, bb, pp, x, j, sg.h);
+                last_pt = pt;
+            }
+            sg.fbase = A.out + ((size_t)bb * A.p1) * A.na * A.cin;
+            sg.a0 = a; sg.jc0 = jc; sg.cnt = 1;
+            for (int ct = 0; ct < nchunk; ++ct) scatter_segment<NT, KT>(A, sg, ct, x, j, dG + 16 * ct * A.ks, gss);
+        }
+    }
+}
+
 __global__ void rk4_table_kernel(const float *__restrict__ rk, int na, int ks, float sigma_inv,
                                  float *__restrict__ rk4) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -1193,6 +1261,28 @@ int launch_inter_bwd_weight_mfma(const epn_inter_desc *d, const float *rk4, cons
     } while (0)
     EPN_DISPATCH_NT_KT(EPN_BW, 0);
 #undef EPN_BW
+    EPN_CHECK_LAUNCH();
+    return 0;
+}
+
+int launch_inter_group_mfma(const epn_inter_desc *d, const float *rk4, const float *feats, float *G, hipStream_t st) {
+    InterArgs A = make_args(d, rk4);
+    A.feats = feats; A.out = G;
+    const unsigned grid = (unsigned)((A.ncol + 16 * NW - 1) / (16 * NW));
+#define EPN_GRP(NT_, KT_, dummy) hipLaunchKernelGGL((inter_group_kernel<NT_, KT_>), dim3(grid), dim3(64 * NW), 0, st, A)
+    EPN_DISPATCH_NT_KT(EPN_GRP, 0);
+#undef EPN_GRP
+    EPN_CHECK_LAUNCH();
+    return 0;
+}
+
+int launch_inter_ungroup_mfma(const epn_inter_desc *d, const float *rk4, const float *dG, float *dF, hipStream_t st) {
+    InterArgs A = make_args(d, rk4);
+    A.gout = dG; A.out = dF;
+    const unsigned grid = (unsigned)((A.ncol + 16 * NW - 1) / (16 * NW));
+#define EPN_UGRP(NT_, KT_, dummy) hipLaunchKernelGGL((inter_ungroup_kernel<NT_, KT_>), dim3(grid), dim3(64 * NW), 0, st, A)
+    EPN_DISPATCH_NT_KT(EPN_UGRP, 0);
+#undef EPN_UGRP
     EPN_CHECK_LAUNCH();
     return 0;
 }

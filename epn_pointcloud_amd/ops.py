@@ -190,6 +190,116 @@ class InterSO3ConvFn(torch.autograd.Function):
         return gf, gW, None
 
 
+def _group_workspace(lib, d, device):
+    nbytes = lib.epn_inter_group_workspace_bytes(ctypes.byref(d))
+    ws = torch.empty(max(int(nbytes), 16), dtype=torch.uint8, device=device)
+    return ws, ctypes.c_void_p(ws.data_ptr()), ctypes.c_size_t(ws.numel())
+
+
+class InterGroupFn(torch.autograd.Function):
+    """inter_so3conv_grouping's feature part (vgtk/vgtk/so3conv/functional.py:118-140 ->
+    inter_zpconv_grouping_naive, vgtk/vgtk/spconv/functional.py:372-421) as a tensor: [b, c, p1, a] features ->
+    grouped [b*p2*na, c*ks] (the reference's [b, c, ks, p2, na] with the (c, ks) axes last); backward = the transpose
+    (epn_inter_ungroup_f32)."""
+
+    @staticmethod
+    def forward(ctx, feats, geo):
+        lib = _lib.get_lib()
+        f = to_cl(feats)
+        cin = f.shape[1]
+        d = geo.desc(cin, 16)
+        if f.shape[2] != d.p1 or f.shape[3] != d.na or f.shape[0] != d.b:
+            raise ValueError(f"shape mismatch: feats {tuple(f.shape)}, geometry b={d.b} p1={d.p1} na={d.na}")
+        cols = d.b * d.p2 * d.na
+        G = torch.empty((cols, cin * d.ks), dtype=torch.float32, device=f.device)
+        ws, wsp, wsn = _group_workspace(lib, d, f.device)
+        _lib.check(lib.epn_inter_group_f32(ctypes.byref(d), _cl_ptr(f), _lib.dev_ptr(G, "grouped"), wsp, wsn,
+                                           _lib.stream_of(f)), "inter_group")
+        ctx.geo, ctx.cin = geo, cin
+        return G
+
+    @staticmethod
+    def backward(ctx, dG):
+        lib = _lib.get_lib()
+        d = ctx.geo.desc(ctx.cin, 16)
+        dG = dG.contiguous()
+        gf = empty_cl(d.b, ctx.cin, d.p1, d.na, dG.device)
+        ws, wsp, wsn = _group_workspace(lib, d, dG.device)
+        _lib.check(lib.epn_inter_ungroup_f32(ctypes.byref(d), _lib.dev_ptr(dG, "grad_grouped"), _cl_ptr(gf), wsp, wsn,
+                                             _lib.stream_of(dG)), "inter_ungroup")
+        return gf, None
+
+
+def inter_group(feats, geo):
+    return InterGroupFn.apply(feats, geo)
+
+
+class InterSO3ConvSplitFn(torch.autograd.Function):
+    """The same convolution as InterSO3ConvFn in the reference's own two steps -- inter_so3conv_grouping, then
+    BasicSO3Conv's matmul (vgtk/vgtk/so3conv/modules.py:38-52,157-174) -- with the grouping as ONE HIP kernel that
+    writes only the grouped features G[col][cin*ks] (no inter_w, no gathered neighbours) and the three weight
+    contractions (out = G W^T, dW = dOut^T G, dG = dOut W) as plain fp32 GEMMs on the BLAS library, which runs these
+    shapes at 110-150 TFLOP/s (tools/gemm_probe.py).  G (cin*ks*4 bytes per column) is kept for the backward pass:
+    the training-time choice on a 288 GB part; InterSO3ConvFn is the memory-lean fused form."""
+
+    @staticmethod
+    def forward(ctx, feats, W, geo):
+        lib = _lib.get_lib()
+        f = to_cl(feats)
+        Wc = W.contiguous()
+        cout, ck = Wc.shape
+        cin = f.shape[1]
+        d = geo.desc(cin, cout)
+        if ck != cin * d.ks or f.shape[2] != d.p1 or f.shape[3] != d.na or f.shape[0] != d.b:
+            raise ValueError(f"shape mismatch: feats {tuple(f.shape)}, W {tuple(Wc.shape)}, geometry "
+                             f"b={d.b} p1={d.p1} na={d.na} ks={d.ks}")
+        cols = d.b * d.p2 * d.na
+        G = torch.empty((cols, ck), dtype=torch.float32, device=f.device)
+        ws, wsp, wsn = _group_workspace(lib, d, f.device)
+        gflops = 9.0 * cols * d.ks * d.nn + 2.0 * cols * cin * d.ks * d.nn
+        _lib.check(_launch("inter_group", _inter_key(d), gflops, f.device,
+                           lambda: lib.epn_inter_group_f32(ctypes.byref(d), _cl_ptr(f), _lib.dev_ptr(G, "grouped"), wsp,
+                                                           wsn, _lib.stream_of(f))), "inter_group")
+        out2d = _launch("inter_gemm", _inter_key(d), 2.0 * cols * cout * ck, f.device, lambda: torch.mm(G, Wc.t()))
+        ctx.save_for_backward(G, Wc)
+        ctx.geo, ctx.cin = geo, cin
+        return out2d.view(d.b, d.p2, d.na, cout).permute(0, 3, 1, 2)
+
+    @staticmethod
+    def backward(ctx, grad_out):
+        lib = _lib.get_lib()
+        G, Wc = ctx.saved_tensors
+        geo, cin = ctx.geo, ctx.cin
+        cout, ck = Wc.shape
+        d = geo.desc(cin, cout)
+        cols = d.b * d.p2 * d.na
+        g2d = to_cl(grad_out, "grad_out").permute(0, 2, 3, 1).reshape(cols, cout)   # view of the channels-last buffer
+        gf = gW = None
+        if ctx.needs_input_grad[1]:
+            gW = _launch("inter_gemm", _inter_key(d), 2.0 * cols * cout * ck, G.device, lambda: torch.mm(g2d.t(), G))
+        if ctx.needs_input_grad[0]:
+            gf = empty_cl(d.b, cin, d.p1, d.na, G.device)
+            if lib.epn_inter_is_fused(ctypes.byref(d)) and cin >= 16:
+                # the fused data-gradient kernel (W^T dOut + per-column tail in one pass) beats dG-GEMM + ungroup:
+                # both end in the same atomic scatter, and it never writes / re-reads the [cols, cin*ks] dG
+                g = to_cl(grad_out, "grad_out")
+                ws, wsp, wsn = _workspace(lib, d, G.device)
+                _lib.check(_launch("inter_bwd_data", _inter_key(d), _inter_flops(d), G.device,
+                                   lambda: lib.epn_inter_so3conv_bwd_data_f32(ctypes.byref(d), _cl_ptr(g),
+                                                                              _lib.dev_ptr(Wc, "W"), _cl_ptr(gf), wsp,
+                                                                              wsn, _lib.stream_of(G))),
+                           "inter_so3conv_bwd_data")
+            else:
+                dG = _launch("inter_gemm", _inter_key(d), 2.0 * cols * cout * ck, G.device, lambda: torch.mm(g2d, Wc))
+                ws, wsp, wsn = _group_workspace(lib, d, G.device)
+                gflops = 9.0 * cols * d.ks * d.nn + 2.0 * cols * cin * d.ks * d.nn
+                _lib.check(_launch("inter_ungroup", _inter_key(d), gflops, G.device,
+                                   lambda: lib.epn_inter_ungroup_f32(ctypes.byref(d), _lib.dev_ptr(dG, "grad_grouped"),
+                                                                     _cl_ptr(gf), wsp, wsn, _lib.stream_of(G))),
+                           "inter_ungroup")
+        return gf, gW, None
+
+
 _INV_CACHE = {}
 
 
@@ -354,7 +464,21 @@ def norm_act(x, norm, residual=None, slope=0.01):
     return y
 
 
+def inter_mode():
+    """EPN_INTER_MODE = fused | split | auto (default).  auto: the split form (grouped features to HBM + library GEMMs)
+    whenever a gradient will be needed -- it is the faster training path -- and the fused, memory-lean kernels for
+    inference."""
+    import os
+    return os.environ.get("EPN_INTER_MODE", "auto")
+
+
 def inter_so3conv(feats, W, geo):
+    mode = inter_mode()
+    if isinstance(geo, DenseInterWeights):
+        return InterSO3ConvFn.apply(feats, W, geo)
+    training = torch.is_grad_enabled() and (feats.requires_grad or W.requires_grad)
+    if mode == "split" or (mode == "auto" and training and feats.shape[1] % 16 == 0):
+        return InterSO3ConvSplitFn.apply(feats, W, geo)
     return InterSO3ConvFn.apply(feats, W, geo)
 
 

@@ -159,6 +159,23 @@ int epn_norm_act_bwd_apply_f32(const float *x_cl, const float *dy_cl, int groups
                                float eps, float slope, float *dx_cl, epn_stream_t stream);
 
 /* ---------------------------------------------------------------------------------------------------------------------
+ * Grouping only ("split" convolution): the grouped features as a tensor, the weight contraction left to the caller's
+ * BLAS.  replaces vgtk/vgtk/so3conv/functional.py:118-140 (inter_so3conv_grouping: ball grouping + anchor weights +
+ * inter_zpconv_grouping_naive, vgtk/vgtk/spconv/functional.py:372-421) and its autograd backward; what follows it in the
+ * reference, BasicSO3Conv.forward (vgtk/vgtk/so3conv/modules.py:38-52: W @ feats.view(b, c*ks, p*a)), stays a matmul.
+ *   grouped f32[b*p2*na][cin*ks]   row = column (b, p, a), element c*ks + k  -- the reference's [b, c, ks, p2, na] tensor
+ *                                  with the (c, ks) axes last, so  out_cl[col][o] = grouped[col][:] . W[o][:]
+ * epn_inter_ungroup_f32 is the transpose: grad_feats_cl[b][idx][a][c] += sum_k w * grad_grouped (zero-fills first).
+ * cout / dense_w of the descriptor are ignored (dense_w must be NULL).  Neither inter_w nor the gathered neighbour
+ * features are materialised; the fused entry points above additionally avoid `grouped` itself (inference, or when
+ * HBM is short: `grouped` is cin*ks*4 bytes per column, 6 GB for a 64-channel layer at B=32). */
+size_t epn_inter_group_workspace_bytes(const epn_inter_desc *d);
+int epn_inter_group_f32(const epn_inter_desc *d, const float *feats_cl, float *grouped, void *workspace,
+                        size_t workspace_bytes, epn_stream_t stream);
+int epn_inter_ungroup_f32(const epn_inter_desc *d, const float *grad_grouped, float *grad_feats_cl, void *workspace,
+                          size_t workspace_bytes, epn_stream_t stream);
+
+/* ---------------------------------------------------------------------------------------------------------------------
  * PointnetSO3Conv: the aggregation tail of every shipped model
  * replaces vgtk/vgtk/so3conv/modules.py:203-235 (PointnetSO3Conv.forward: centre xyz, rotate it into every anchor frame
  * with einsum 'aji,bjn->bina', concatenate to the features, 1x1 Conv2d "embed", torch.max over the point axis) -- one

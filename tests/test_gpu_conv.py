@@ -33,7 +33,7 @@ def _close_except_kinks(a, b, tol, max_frac=1e-4):
     return bad <= max_frac
 
 
-def test_inter_module_golden(gpu, vgtk_alias):
+def test_inter_module_golden(gpu, vgtk_alias, inter_mode):
     sptk, zptk = _mods(vgtk_alias)
     for tag, (cin, cout, stride, lazy) in {"s2_fps": (1, 8, 2, False), "s1_lazy": (6, 8, 1, True)}.items():
         g = golden(f"inter_module_{tag}.npz")
@@ -89,6 +89,19 @@ def test_functional_compat_golden(gpu, vgtk_alias):
     assert torch.allclose(G.cpu(), T(g["G"]), atol=1e-6)
 
 
+@pytest.fixture(params=["fused", "split"])
+def inter_mode(request):
+    """Both forms of InterSO3Conv: the fused kernels (memory-lean) and the split form (HIP grouping kernel writing the
+    grouped features + BLAS GEMMs), selected through EPN_INTER_MODE."""
+    old = os.environ.get("EPN_INTER_MODE")
+    os.environ["EPN_INTER_MODE"] = request.param
+    yield request.param
+    if old is None:
+        del os.environ["EPN_INTER_MODE"]
+    else:
+        os.environ["EPN_INTER_MODE"] = old
+
+
 def _inter_case(gpu, sptk, zptk, b, n, cin, cout, stride, radius, sigma, K, lazy, seed, na=60):
     rng = np.random.default_rng(seed)
     torch.manual_seed(seed)
@@ -113,7 +126,7 @@ def _inter_case(gpu, sptk, zptk, b, n, cin, cout, stride, radius, sigma, K, lazy
 
 @pytest.mark.parametrize("cin,cout,stride,K,lazy", [(1, 8, 2, 16, False), (3, 5, 1, 7, True), (16, 16, 1, 16, True),
                                                     (32, 48, 2, 32, True), (64, 64, 1, 16, True), (16, 32, 2, 20, False)])
-def test_inter_vs_oracle(gpu, vgtk_alias, cin, cout, stride, K, lazy):
+def test_inter_vs_oracle(gpu, vgtk_alias, inter_mode, cin, cout, stride, K, lazy):
     sptk, zptk = _mods(vgtk_alias)
     (y, oy), (dW, odW), (dF, odF) = _inter_case(gpu, sptk, zptk, 2, 128, cin, cout, stride, 0.4, 0.08, K, lazy, 100 + cin)
     assert (y - oy).abs().max().item() < TOL * max(1.0, oy.abs().max().item())
@@ -186,7 +199,7 @@ def test_equivariance_known_answer(gpu, vgtk_alias):
         assert (z1[sel] - z0[sel][..., perm]).abs().max().item() < 5e-4 * max(1.0, z0.abs().max().item())
 
 
-def test_generic_and_fused_kernels_agree(gpu, vgtk_alias):
+def test_generic_and_fused_kernels_agree(gpu, vgtk_alias, inter_mode):
     """The any-shape generic HIP kernels and the fused MFMA kernels are independent implementations."""
     sptk, zptk = _mods(vgtk_alias)
     rng = np.random.default_rng(21)
@@ -255,7 +268,7 @@ def test_plumbing_config_a12_tetrahedral_subgroup(gpu, vgtk_alias):
 
 @pytest.mark.parametrize("cin,cout,stride,K,radius,sigma", [(32, 64, 2, 64, 0.16, 0.0256), (32, 32, 1, 128, 0.25, 0.05),
                                                              (48, 80, 1, 24, 0.3, 0.06)])
-def test_inter_large_neighbourhoods_and_odd_widths(gpu, vgtk_alias, cin, cout, stride, K, radius, sigma):
+def test_inter_large_neighbourhoods_and_odd_widths(gpu, vgtk_alias, inter_mode, cin, cout, stride, K, radius, sigma):
     """3DMatch-style neighbourhoods (K = 64 / 128, inv_so3net_pn schedule) and channel widths that are multiples
     of 16 but not of 64 take the 4-wave kernels."""
     sptk, zptk = _mods(vgtk_alias)
@@ -370,3 +383,37 @@ def test_fused_block_matches_stock_block(gpu, vgtk_alias):
         assert (ya - yb).abs().max().item() < TOL
         for (n, _), u, v in zip([("feats", None)] + list(a.named_parameters()), ga, gb):
             assert _close_except_kinks(v, u, TOL), n
+
+
+@pytest.mark.parametrize("cin,K,na_sel,stride", [(16, 16, None, 1), (32, 32, None, 2), (48, 100, None, 2), (5, 9, None, 1),
+                                                 (16, 16, 12, 1)])
+def test_group_ungroup_abi_vs_oracle(gpu, vgtk_alias, cin, K, na_sel, stride):
+    """epn_inter_group_f32 / epn_inter_ungroup_f32 (the grouping-only ABI of the split convolution) against the
+    oracle's inter_grouping and its autograd transpose: MFMA kernels for cin % 16 == 0 (K up to 128, also fewer than 16
+    anchors), generic kernels otherwise."""
+    from epn_pointcloud_amd import ops
+    from epn_pointcloud_amd.vgtk import pc as pctk
+    from epn_pointcloud_amd.vgtk.so3conv import functional as L
+    from epn_pointcloud_amd.vgtk import functional as fr
+    rng = np.random.default_rng(cin + K)
+    torch.manual_seed(cin + K)
+    b, n, radius, sigma = 2, 200, 0.45, 0.09
+    xyz = T(unit_ball_cloud(rng, b, n))
+    anchors = T(L.get_anchors(60))
+    if na_sel:
+        anchors = anchors[:na_sel].contiguous()
+    na = anchors.shape[0]
+    kernels = R.scaled_kernel_points(T(fr.kernel_points_raw(24)), radius)
+    feats = torch.randn(b, cin, n, na)
+    fo = feats.clone().requires_grad_(True)
+    o_idx, o_w, o_xyz, o_g, o_sidx = R.inter_grouping(xyz, fo, stride, K, anchors, kernels, radius, sigma, None, None, False)
+    want = o_g.permute(0, 3, 4, 1, 2).reshape(-1, cin * 24)              # [b,c,ks,p2,a] -> [(b,p2,a), c*ks]
+    gG = torch.randn_like(want)
+    (o_dF,) = torch.autograd.grad(want, fo, gG)
+    geo = ops.InterGeometry(xyz.to(gpu), o_xyz.to(gpu), o_idx.to(gpu), anchors.to(gpu), kernels.to(gpu), sigma)
+    fg = feats.to(gpu).requires_grad_(True)
+    G = ops.inter_group(fg, geo)
+    assert tuple(G.shape) == tuple(want.shape)
+    assert (G.detach().cpu() - want.detach()).abs().max().item() < TOL * max(1.0, want.abs().max().item())
+    (dF,) = torch.autograd.grad(G, fg, gG.to(gpu))
+    assert (dF.cpu() - o_dF).abs().max().item() < TOL * max(1.0, o_dF.abs().max().item())

@@ -28,6 +28,7 @@ def main():
     ap.add_argument("--iters", type=int, default=10)
     ap.add_argument("--batch", type=int, default=32)
     ap.add_argument("--only", default="")
+    ap.add_argument("--split", action="store_true", help="also time the split form: grouping kernels + BLAS GEMMs")
     args = ap.parse_args()
     dev = torch.device("cuda:0")
     layers = S.cls_so3net_schedule(1024)
@@ -65,6 +66,26 @@ def main():
             t_w = timeit(lambda: torch.autograd.grad(o, Wr, gout, retain_graph=True), args.iters)
             res["inter_bwd_data"] = (t_f, inter_fl)
             res["inter_bwd_weight"] = (t_w, inter_fl)
+        if args.split and l.cin >= 16:
+            import ctypes
+            from epn_pointcloud_amd import _lib
+            lib = _lib.get_lib()
+            d = geo.desc(l.cin, l.cout)
+            cols, ck = d.b * d.p2 * d.na, l.cin * d.ks
+            G = torch.empty(cols, ck, device=dev)
+            ws, wsp, wsn = ops._group_workspace(lib, d, dev)
+            g2d = gout.permute(0, 2, 3, 1).reshape(cols, l.cout)
+            gf = torch.empty_like(feats)
+            grp = f["wgen"] + f["group"]
+            res["group"] = (timeit(lambda: lib.epn_inter_group_f32(ctypes.byref(d), ops._cl_ptr(feats), G.data_ptr(), wsp, wsn,
+                                                                   _lib.stream_of(feats)), args.iters), grp)
+            res["gemm_out"] = (timeit(lambda: torch.mm(G, W.t()), args.iters), f["gemm"])
+            res["gemm_dW"] = (timeit(lambda: torch.mm(g2d.t(), G), args.iters), f["gemm"])
+            dG = torch.mm(g2d, W)
+            res["gemm_dG"] = (timeit(lambda: torch.mm(g2d, W), args.iters), f["gemm"])
+            res["ungroup"] = (timeit(lambda: lib.epn_inter_ungroup_f32(ctypes.byref(d), dG.data_ptr(), ops._cl_ptr(gf), wsp, wsn,
+                                                                       _lib.stream_of(feats)), args.iters), grp)
+            del G, dG
         fi = out.detach()
         Wi = intra.basic_conv.W.detach()
         i32 = intra.intra_idx.int()
