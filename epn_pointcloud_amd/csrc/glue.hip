@@ -352,3 +352,46 @@ extern "C" int epn_norm_act_bwd_apply_f32(const float *x_cl, const float *dy_cl,
     EPN_CHECK_LAUNCH();
     return 0;
 }
+
+// ---- IntraSO3Conv grouping as a tensor (the "split" form): grouped[col][k*c + ci] = x[(pt*na + idx[a][k])*c + ci].
+// Pure HBM copy: one 16-byte element per thread, consecutive threads walk one gathered row, so reads and writes are
+// full-width coalesced.  c % 4 == 0 (launcher falls back to the scalar kernel otherwise).
+namespace epn {
+namespace {
+
+template <typename V>
+__global__ __launch_bounds__(256) void intra_group_kernel(const V *__restrict__ x, const int32_t *__restrict__ idx,
+                                                          V *__restrict__ g, long long nelem, int na, int kn, int cv) {
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= nelem) return;
+    const int c = (int)(i % cv);
+    const long long r = i / cv;
+    const int k = (int)(r % kn);
+    const long long col = r / kn;
+    const int a = (int)(col % na);
+    const long long pt = col / na;
+    g[i] = x[(pt * na + idx[a * kn + k]) * cv + c];
+}
+
+}  // namespace
+}  // namespace epn
+
+extern "C" int epn_intra_group_f32(const float *feats_cl, const int32_t *intra_idx, float *grouped, int b, int p,
+                                   int na, int kn, int c, epn_stream_t stream) {
+    if (b < 0 || p < 0 || na < 1 || kn < 1 || c < 1) return EPN_EINVAL;
+    if (b == 0 || p == 0) return 0;
+    if (!feats_cl || !intra_idx || !grouped) return EPN_ENULL;
+    const long long cols = (long long)b * p * na;
+    if (c % 4 == 0) {
+        const long long n = cols * kn * (c / 4);
+        hipLaunchKernelGGL((intra_group_kernel<f32x4>), dim3((unsigned)((n + 255) / 256)), dim3(256), 0,
+                           epn_stream(stream), reinterpret_cast<const f32x4 *>(feats_cl), intra_idx,
+                           reinterpret_cast<f32x4 *>(grouped), n, na, kn, c / 4);
+    } else {
+        const long long n = cols * kn * c;
+        hipLaunchKernelGGL((intra_group_kernel<float>), dim3((unsigned)((n + 255) / 256)), dim3(256), 0,
+                           epn_stream(stream), feats_cl, intra_idx, grouped, n, na, kn, c);
+    }
+    EPN_CHECK_LAUNCH();
+    return 0;
+}

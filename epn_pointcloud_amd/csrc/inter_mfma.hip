@@ -978,16 +978,20 @@ __global__ __launch_bounds__(64 * NW) void inter_group_kernel(InterArgs A) {
     if (col0 >= A.ncol) return;
     const int gss = A.cin * A.ks;
     float *G = A.out + (size_t)col0 * gss;
-    const int nchunk = A.cin >> 4;
+    // blockIdx.y walks the 16-channel chunks in groups of col_tiles_per_wg (here: chunks per workgroup): with one
+    // chunk per launch row, all tiles of a cloud touch the same 64-byte slice of every feature row at about the same
+    // time, so the working set per cloud (p1*na*64 B) fits the XCD's L2
+    const int ct0 = blockIdx.y * A.col_tiles_per_wg;
+    const int ct1 = min(ct0 + A.col_tiles_per_wg, A.cin >> 4);
     if (A.na >= 16) {
         Seg<NT> s0, s1;
         make_segments<NT>(A, col0, x, j, s0, s1);
-        for (int ct = 0; ct < nchunk; ++ct) {
+        for (int ct = ct0; ct < ct1; ++ct) {
             group_segment<NT, KT>(A, s0, ct, x, j, G + 16 * ct * A.ks, gss);
             group_segment<NT, KT>(A, s1, ct, x, j, G + 16 * ct * A.ks, gss);
         }
     } else {
-        for (int ct = 0; ct < nchunk; ++ct) group_chunk_generic<NT, KT>(A, col0, ct, x, j, G + 16 * ct * A.ks, gss);
+        for (int ct = ct0; ct < ct1; ++ct) group_chunk_generic<NT, KT>(A, col0, ct, x, j, G + 16 * ct * A.ks, gss);
     }
 }
 
@@ -1001,13 +1005,14 @@ __global__ __launch_bounds__(64 * NW) void inter_ungroup_kernel(InterArgs A) {
     if (col0 >= A.ncol) return;
     const int gss = A.cin * A.ks;
     const float *dG = A.gout + (size_t)col0 * gss;
-    const int nchunk = A.cin >> 4;
+    const int ct0 = blockIdx.y * A.col_tiles_per_wg;          // chunk-major launch order, see inter_group_kernel
+    const int ct1 = min(ct0 + A.col_tiles_per_wg, A.cin >> 4);
     InterArgs B = A;
     B.feats = A.out;   // segment base pointers address grad_feats_cl
     if (A.na >= 16) {
         Seg<NT> s0, s1;
         make_segments<NT>(B, col0, x, j, s0, s1);
-        for (int ct = 0; ct < nchunk; ++ct) {
+        for (int ct = ct0; ct < ct1; ++ct) {
             scatter_segment<NT, KT>(A, s0, ct, x, j, dG + 16 * ct * A.ks, gss);
             scatter_segment<NT, KT>(A, s1, ct, x, j, dG + 16 * ct * A.ks, gss);
         }
@@ -1026,7 +1031,7 @@ __global__ __launch_bounds__(64 * NW) void inter_ungroup_kernel(InterArgs A) {
             }
             sg.fbase = A.out + ((size_t)bb * A.p1) * A.na * A.cin;
             sg.a0 = a; sg.jc0 = jc; sg.cnt = 1;
-            for (int ct = 0; ct < nchunk; ++ct) scatter_segment<NT, KT>(A, sg, ct, x, j, dG + 16 * ct * A.ks, gss);
+            for (int ct = ct0; ct < ct1; ++ct) scatter_segment<NT, KT>(A, sg, ct, x, j, dG + 16 * ct * A.ks, gss);
         }
     }
 }
@@ -1265,11 +1270,19 @@ int launch_inter_bwd_weight_mfma(const epn_inter_desc *d, const float *rk4, cons
     return 0;
 }
 
+static int chunks_per_row() {   // EPN_GROUP_CPR: 16-channel chunks per launch row of the grouping kernels (tuning knob)
+    const char *e = std::getenv("EPN_GROUP_CPR");
+    const int v = e ? std::atoi(e) : 1;
+    return v >= 1 ? v : 1;
+}
+
 int launch_inter_group_mfma(const epn_inter_desc *d, const float *rk4, const float *feats, float *G, hipStream_t st) {
     InterArgs A = make_args(d, rk4);
     A.feats = feats; A.out = G;
     const unsigned grid = (unsigned)((A.ncol + 16 * NW - 1) / (16 * NW));
-#define EPN_GRP(NT_, KT_, dummy) hipLaunchKernelGGL((inter_group_kernel<NT_, KT_>), dim3(grid), dim3(64 * NW), 0, st, A)
+    A.col_tiles_per_wg = chunks_per_row();
+    const unsigned gy = (unsigned)(((d->cin >> 4) + A.col_tiles_per_wg - 1) / A.col_tiles_per_wg);
+#define EPN_GRP(NT_, KT_, dummy) hipLaunchKernelGGL((inter_group_kernel<NT_, KT_>), dim3(grid, gy), dim3(64 * NW), 0, st, A)
     EPN_DISPATCH_NT_KT(EPN_GRP, 0);
 #undef EPN_GRP
     EPN_CHECK_LAUNCH();
@@ -1280,7 +1293,9 @@ int launch_inter_ungroup_mfma(const epn_inter_desc *d, const float *rk4, const f
     InterArgs A = make_args(d, rk4);
     A.gout = dG; A.out = dF;
     const unsigned grid = (unsigned)((A.ncol + 16 * NW - 1) / (16 * NW));
-#define EPN_UGRP(NT_, KT_, dummy) hipLaunchKernelGGL((inter_ungroup_kernel<NT_, KT_>), dim3(grid), dim3(64 * NW), 0, st, A)
+    A.col_tiles_per_wg = chunks_per_row();
+    const unsigned gy = (unsigned)(((d->cin >> 4) + A.col_tiles_per_wg - 1) / A.col_tiles_per_wg);
+#define EPN_UGRP(NT_, KT_, dummy) hipLaunchKernelGGL((inter_ungroup_kernel<NT_, KT_>), dim3(grid, gy), dim3(64 * NW), 0, st, A)
     EPN_DISPATCH_NT_KT(EPN_UGRP, 0);
 #undef EPN_UGRP
     EPN_CHECK_LAUNCH();

@@ -383,6 +383,63 @@ class IntraSO3ConvFn(torch.autograd.Function):
         return gf, gW, None
 
 
+class IntraSO3ConvSplitFn(torch.autograd.Function):
+    """IntraSO3Conv in the reference's two steps (intra_so3conv_grouping, then BasicSO3Conv's matmul): the anchor
+    gather as one streaming HIP kernel writing grouped[col][kn*cin], `out = grouped Wp^T` and `dW = dOut^T grouped` as
+    library fp32 GEMMs; the data gradient stays on the fused kernel (no grouped-gradient tensor).  `grouped` is kept
+    for the backward pass (training-time choice, like InterSO3ConvSplitFn)."""
+
+    @staticmethod
+    def forward(ctx, feats, W, intra_idx32):
+        lib = _lib.get_lib()
+        f = to_cl(feats)
+        Wc = W.contiguous()
+        b, cin, p, na = f.shape
+        cout = Wc.shape[0]
+        kn = intra_idx32.shape[1]
+        if Wc.shape[1] != cin * kn or intra_idx32.shape[0] != na:
+            raise ValueError(f"shape mismatch: feats {tuple(f.shape)}, W {tuple(Wc.shape)}, "
+                             f"intra_idx {tuple(intra_idx32.shape)}")
+        cols = b * p * na
+        G = torch.empty((cols, kn * cin), dtype=torch.float32, device=f.device)
+        _lib.check(_launch("intra_group", (b, p, na, kn, cin, cout), 0.0, f.device,
+                           lambda: lib.epn_intra_group_f32(_cl_ptr(f), _lib.dev_ptr(intra_idx32, "intra_idx", torch.int32),
+                                                           _lib.dev_ptr(G, "grouped"), b, p, na, kn, cin,
+                                                           _lib.stream_of(f))), "intra_group")
+        Wp = Wc.view(cout, cin, kn).permute(0, 2, 1).reshape(cout, kn * cin)      # [o][k*cin + c]
+        fl = 2.0 * cols * cout * cin * kn
+        out2d = _launch("intra_gemm", (b, p, na, kn, cin, cout), fl, f.device, lambda: torch.mm(G, Wp.t()))
+        ctx.save_for_backward(G, Wc, intra_idx32)
+        ctx.dims = (b, cin, p, na)
+        return out2d.view(b, p, na, cout).permute(0, 3, 1, 2)
+
+    @staticmethod
+    def backward(ctx, grad_out):
+        lib = _lib.get_lib()
+        G, Wc, iidx = ctx.saved_tensors
+        b, cin, p, na = ctx.dims
+        cout, kn = Wc.shape[0], iidx.shape[1]
+        cols = b * p * na
+        g = to_cl(grad_out, "grad_out")
+        fl = 2.0 * cols * cout * cin * kn
+        gf = gW = None
+        if ctx.needs_input_grad[1]:
+            g2d = g.permute(0, 2, 3, 1).reshape(cols, cout)
+            gWp = _launch("intra_gemm", (b, p, na, kn, cin, cout), fl, G.device, lambda: torch.mm(g2d.t(), G))
+            gW = gWp.view(cout, kn, cin).permute(0, 2, 1).reshape(cout, cin * kn)
+        if ctx.needs_input_grad[0]:
+            gf = empty_cl(b, cin, p, na, G.device)
+            inv = inverse_intra_idx(iidx)
+            ws, wsp, wsn = _intra_ws(lib, na, kn, cin, cout, G.device)
+            _lib.check(_launch("intra_bwd_data", (b, p, na, kn, cin, cout), fl, G.device,
+                               lambda: lib.epn_intra_so3conv_bwd_data_f32(
+                                   _cl_ptr(g), _lib.dev_ptr(iidx, "intra_idx", torch.int32),
+                                   _lib.dev_ptr(inv, "inv_idx", torch.int32), _lib.dev_ptr(Wc, "W"),
+                                   b, p, na, kn, cin, cout, _cl_ptr(gf), wsp, wsn, _lib.stream_of(G))),
+                       "intra_so3conv_bwd_data")
+        return gf, gW, None
+
+
 def norm_act_supported(c):
     """Channel counts the fused norm kernels take (4 channels per lane, C/4 lanes dividing a 256-thread block)."""
     return c >= 4 and c % 4 == 0 and c <= 1024 and 256 % (c // 4) == 0
@@ -482,7 +539,21 @@ def inter_so3conv(feats, W, geo):
     return InterSO3ConvFn.apply(feats, W, geo)
 
 
+def intra_mode():
+    """EPN_INTRA_MODE = fused | split | auto (default): as inter_mode()."""
+    import os
+    return os.environ.get("EPN_INTRA_MODE", "auto")
+
+
+def intra_so3conv_fused(feats, W, intra_idx32):
+    return IntraSO3ConvFn.apply(feats, W, intra_idx32)
+
+
 def intra_so3conv(feats, W, intra_idx32):
+    mode = intra_mode()
+    training = torch.is_grad_enabled() and (feats.requires_grad or W.requires_grad)
+    if mode == "split" or (mode == "auto" and training and feats.shape[1] % 16 == 0 and W.shape[0] % 16 == 0):
+        return IntraSO3ConvSplitFn.apply(feats, W, intra_idx32)
     return IntraSO3ConvFn.apply(feats, W, intra_idx32)
 
 
@@ -545,11 +616,18 @@ class PointnetSO3ConvFn(torch.autograd.Function):
 
 
 def conv1x1(x, weight, bias=None):
-    """nn.Conv2d(cin, cout, 1) on a [b,c,p,a] tensor: the intra GEMM kernel with a single, identity anchor neighbour
-    (channels-last in and out, no layout copy); shapes the MFMA kernel does not take (cin = 1 of the first block, the
-    few-channel heads) go to torch."""
+    """nn.Conv2d(cin, cout, 1) on a [b,c,p,a] tensor, channels-last in and out with no layout copy.
+    EPN_CONV1X1 = kernel (default): the intra GEMM kernel with a single, identity anchor neighbour;
+                  blas: a plain row-major GEMM [cols, cin] x [cin, cout] (+ bias) on a zero-copy 2-D view.
+    Shapes the MFMA kernel does not take (cin = 1 of the first block, the few-channel heads) go to torch."""
+    import os
     cout, cin = weight.shape[0], weight.shape[1]
     if x.is_cuda and cin % 16 == 0 and cout % 16 == 0:
+        if os.environ.get("EPN_CONV1X1", "kernel") == "blas":
+            xc = to_cl(x)
+            b, c, p, a = xc.shape
+            y2d = torch.nn.functional.linear(xc.permute(0, 2, 3, 1).reshape(-1, c), weight.reshape(cout, cin), bias)
+            return y2d.view(b, p, a, cout).permute(0, 3, 1, 2)
         na = x.shape[3]
         ident = torch.arange(na, dtype=torch.int32, device=x.device).view(na, 1)
         y = IntraSO3ConvFn.apply(x, weight.reshape(cout, cin), ident)

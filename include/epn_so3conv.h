@@ -175,6 +175,14 @@ int epn_inter_group_f32(const epn_inter_desc *d, const float *feats_cl, float *g
 int epn_inter_ungroup_f32(const epn_inter_desc *d, const float *grad_grouped, float *grad_feats_cl, void *workspace,
                           size_t workspace_bytes, epn_stream_t stream);
 
+/* IntraSO3Conv grouping as a tensor: replaces L.intra_so3conv_grouping (vgtk/vgtk/so3conv/functional.py:255-268,
+ * feats[..., intra_idx]); IntraSO3Conv's BasicSO3Conv matmul (modules.py:197-200) then runs on the caller's BLAS.
+ *   grouped f32[b*p*na][kn*c]   element k*c + ci = feats_cl[b][p][intra_idx[a][k]][ci]   (anchor-neighbour major, so
+ *   the matching weight is W[o][ci*kn + k] re-ordered to [o][k*c + ci]; the reference tensor is [b, c, kn, p, na]).
+ * Its transpose is the same gather through the inverse permutation (epn_intra_so3conv_bwd_data_f32 covers it fused). */
+int epn_intra_group_f32(const float *feats_cl, const int32_t *intra_idx, float *grouped, int b, int p, int na, int kn,
+                        int c, epn_stream_t stream);
+
 /* ---------------------------------------------------------------------------------------------------------------------
  * PointnetSO3Conv: the aggregation tail of every shipped model
  * replaces vgtk/vgtk/so3conv/modules.py:203-235 (PointnetSO3Conv.forward: centre xyz, rotate it into every anchor frame

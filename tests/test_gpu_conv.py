@@ -54,7 +54,7 @@ def test_inter_module_golden(gpu, vgtk_alias, inter_mode):
         assert torch.allclose(dF.cpu(), T(g["dF"]), atol=TOL)
 
 
-def test_intra_module_golden(gpu, vgtk_alias):
+def test_intra_module_golden(gpu, vgtk_alias, intra_mode):
     sptk, zptk = _mods(vgtk_alias)
     g = golden("intra_module.npz")
     conv = sptk.IntraSO3Conv(8, 8)
@@ -102,6 +102,17 @@ def inter_mode(request):
         os.environ["EPN_INTER_MODE"] = old
 
 
+@pytest.fixture(params=["fused", "split"])
+def intra_mode(request):
+    old = os.environ.get("EPN_INTRA_MODE")
+    os.environ["EPN_INTRA_MODE"] = request.param
+    yield request.param
+    if old is None:
+        del os.environ["EPN_INTRA_MODE"]
+    else:
+        os.environ["EPN_INTRA_MODE"] = old
+
+
 def _inter_case(gpu, sptk, zptk, b, n, cin, cout, stride, radius, sigma, K, lazy, seed, na=60):
     rng = np.random.default_rng(seed)
     torch.manual_seed(seed)
@@ -135,7 +146,7 @@ def test_inter_vs_oracle(gpu, vgtk_alias, inter_mode, cin, cout, stride, K, lazy
 
 
 @pytest.mark.parametrize("cin,cout,p", [(8, 8, 40), (5, 3, 17), (16, 16, 64), (32, 64, 33), (64, 64, 128), (128, 128, 16)])
-def test_intra_vs_oracle(gpu, vgtk_alias, cin, cout, p):
+def test_intra_vs_oracle(gpu, vgtk_alias, intra_mode, cin, cout, p):
     sptk, zptk = _mods(vgtk_alias)
     torch.manual_seed(cin * 7 + p)
     conv = sptk.IntraSO3Conv(cin, cout)
