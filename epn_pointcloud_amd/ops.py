@@ -190,6 +190,41 @@ class InterSO3ConvFn(torch.autograd.Function):
         return gf, gW, None
 
 
+_TUNED = False
+
+
+def use_tuned_gemms():
+    """The split convolutions hand their weight contractions to the BLAS library through torch.mm.  PyTorch's TunableOp
+    picks, per GEMM shape, the fastest rocBLAS / hipBLASLt solution; `gemm_tuning_gfx950.csv` (next to this file) holds
+    the selections for the ModelNet40 B=32 shapes, recorded on an MI355X with tools/tune_gemms.sh (+7 % on the GEMMs
+    over the default heuristic).  Loaded once, read-only (no tuning at run time, no write-back); a library-version
+    mismatch makes PyTorch ignore the file.  EPN_TUNED_GEMM=0, or any PYTORCH_TUNABLEOP_* setting of the user's own,
+    turns this off."""
+    global _TUNED
+    if _TUNED:
+        return
+    _TUNED = True
+    import os
+    if os.environ.get("EPN_TUNED_GEMM", "1") != "1" or any(k.startswith("PYTORCH_TUNABLEOP_") for k in os.environ):
+        return
+    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "gemm_tuning_gfx950.csv")
+    if not os.path.exists(path) or not torch.cuda.is_available():
+        return
+    try:
+        import shutil
+        import tempfile
+        tun = torch.cuda.tunable
+        tun.enable(True)
+        tun.tuning_enable(False)
+        # TunableOp re-writes its results file at exit: give it a private copy, the in-tree table stays read-only
+        tmp = os.path.join(tempfile.mkdtemp(prefix="epn_gemm_"), "gemm_tuning.csv")
+        shutil.copyfile(path, tmp)
+        tun.set_filename(tmp, insert_device_ordinal=False)
+    except Exception as e:  # an older / differently built torch: the default GEMM heuristics still apply
+        import warnings
+        warnings.warn(f"epn_pointcloud_amd: tuned GEMM table not loaded ({e})")
+
+
 def _group_workspace(lib, d, device):
     nbytes = lib.epn_inter_group_workspace_bytes(ctypes.byref(d))
     ws = torch.empty(max(int(nbytes), 16), dtype=torch.uint8, device=device)
@@ -254,6 +289,7 @@ class InterSO3ConvSplitFn(torch.autograd.Function):
             raise ValueError(f"shape mismatch: feats {tuple(f.shape)}, W {tuple(Wc.shape)}, geometry "
                              f"b={d.b} p1={d.p1} na={d.na} ks={d.ks}")
         cols = d.b * d.p2 * d.na
+        use_tuned_gemms()
         G = torch.empty((cols, ck), dtype=torch.float32, device=f.device)
         ws, wsp, wsn = _group_workspace(lib, d, f.device)
         gflops = 9.0 * cols * d.ks * d.nn + 2.0 * cols * cin * d.ks * d.nn
@@ -279,9 +315,14 @@ class InterSO3ConvSplitFn(torch.autograd.Function):
             gW = _launch("inter_gemm", _inter_key(d), 2.0 * cols * cout * ck, G.device, lambda: torch.mm(g2d.t(), G))
         if ctx.needs_input_grad[0]:
             gf = empty_cl(d.b, cin, d.p1, d.na, G.device)
-            if lib.epn_inter_is_fused(ctypes.byref(d)) and cin >= 16:
-                # the fused data-gradient kernel (W^T dOut + per-column tail in one pass) beats dG-GEMM + ungroup:
-                # both end in the same atomic scatter, and it never writes / re-reads the [cols, cin*ks] dG
+            import os
+            if (os.environ.get("EPN_INTER_BWD_DATA", "fused") == "fused" and lib.epn_inter_is_fused(ctypes.byref(d))
+                    and cin >= 16):
+                # the fused data-gradient kernel (W^T dOut + per-column tail in one pass) beats dG-GEMM + ungroup
+                # (measured 36 vs 39 ms per step): both end in the same fp32 atomic scatter (cols*K*cin = 1.0e9 atomics
+                # per layer, bound by the L2 atomic units at ~3.3 ms per layer), and the fused kernel hides most of it
+                # under its MFMA phases and never writes / re-reads the [cols, cin*ks] dG.  (An atomic-free CSR-gather
+                # transpose was tried and dropped: it re-reads every 96-byte dG row K times, 3x slower.)
                 g = to_cl(grad_out, "grad_out")
                 ws, wsp, wsn = _workspace(lib, d, G.device)
                 _lib.check(_launch("inter_bwd_data", _inter_key(d), _inter_flops(d), G.device,
@@ -401,6 +442,7 @@ class IntraSO3ConvSplitFn(torch.autograd.Function):
             raise ValueError(f"shape mismatch: feats {tuple(f.shape)}, W {tuple(Wc.shape)}, "
                              f"intra_idx {tuple(intra_idx32.shape)}")
         cols = b * p * na
+        use_tuned_gemms()
         G = torch.empty((cols, kn * cin), dtype=torch.float32, device=f.device)
         _lib.check(_launch("intra_group", (b, p, na, kn, cin, cout), 0.0, f.device,
                            lambda: lib.epn_intra_group_f32(_cl_ptr(f), _lib.dev_ptr(intra_idx32, "intra_idx", torch.int32),

@@ -1,0 +1,11 @@
+#!/bin/bash
+# Re-record epn_pointcloud_amd/gemm_tuning_gfx950.csv on an MI355X (about 10 minutes: every GEMM shape of the cls
+# B=32 step is timed against all rocBLAS / hipBLASLt solutions during bench.py's warm-up):
+#   gpurun --timeout 1500 -- 'bash tools/tune_gemms.sh'     -> gpurun_out/tunableop0.csv, copy it over the in-tree file
+set -e
+R=$(cd "$(dirname "$0")/.." && pwd)
+mkdir -p $R/gpurun_out
+export PYTORCH_TUNABLEOP_ENABLED=1 PYTORCH_TUNABLEOP_TUNING=1 PYTORCH_TUNABLEOP_FILENAME=$R/gpurun_out/tunableop.csv
+export PYTORCH_TUNABLEOP_MAX_TUNING_DURATION_MS=100 PYTORCH_TUNABLEOP_MAX_WARMUP_DURATION_MS=10
+python $R/bench.py --steps 3 --warmup 2 --no-cpu-baseline "$@"
+ls -la $R/gpurun_out/tunableop*
