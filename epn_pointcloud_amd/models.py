@@ -44,11 +44,11 @@ class ClsOutBlockPointnet(nn.Module):
     def forward(self, x, label=None):
         f = x.feats
         for lin, norm in zip(self.linear, self.norm):
-            f = ops.conv1x1(f, lin.weight, lin.bias)
-            if self.training and ops.norm_act_supported(f.shape[1]):
-                f = ops.norm_act(f, norm, slope=0.0)                       # relu(BatchNorm2d(.)) on the HIP glue
+            if self.training and ops.norm_act_supported(lin.out_channels):
+                f = ops.conv1x1(f, lin.weight, None)                       # BatchNorm cancels the bias (ops.norm_act)
+                f = ops.norm_act(f, norm, slope=0.0, conv_bias=lin.bias)   # relu(BatchNorm2d(.)) on the HIP glue
             else:
-                f = F.relu(norm(f))
+                f = F.relu(norm(ops.conv1x1(f, lin.weight, lin.bias)))
         out_feat = f
         y = self.pointnet(zptk.SphericalPointCloud(x.xyz, f, x.anchors))   # [b, c, a]
         y = F.relu(self.norm[len(self.linear)](y))

@@ -303,27 +303,30 @@ class InterSO3ConvSplitFn(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, grad_out):
+        import os
         lib = _lib.get_lib()
         G, Wc = ctx.saved_tensors
         geo, cin = ctx.geo, ctx.cin
         cout, ck = Wc.shape
         d = geo.desc(cin, cout)
         cols = d.b * d.p2 * d.na
-        g2d = to_cl(grad_out, "grad_out").permute(0, 2, 3, 1).reshape(cols, cout)   # view of the channels-last buffer
+        g = to_cl(grad_out, "grad_out")
+        g2d = g.permute(0, 2, 3, 1).reshape(cols, cout)   # view of the channels-last buffer
+        need_f, need_w = ctx.needs_input_grad[0], ctx.needs_input_grad[1]
+        gemm_fl = 2.0 * cols * cout * ck
         gf = gW = None
-        if ctx.needs_input_grad[1]:
-            gW = _launch("inter_gemm", _inter_key(d), 2.0 * cols * cout * ck, G.device, lambda: torch.mm(g2d.t(), G))
-        if ctx.needs_input_grad[0]:
+        if need_w:
+            gW = _launch("inter_gemm", _inter_key(d), gemm_fl, G.device, lambda: torch.mm(g2d.t(), G))
+        if need_f:
             gf = empty_cl(d.b, cin, d.p1, d.na, G.device)
-            import os
             if (os.environ.get("EPN_INTER_BWD_DATA", "fused") == "fused" and lib.epn_inter_is_fused(ctypes.byref(d))
                     and cin >= 16):
-                # the fused data-gradient kernel (W^T dOut + per-column tail in one pass) beats dG-GEMM + ungroup
-                # (measured 36 vs 39 ms per step): both end in the same fp32 atomic scatter (cols*K*cin = 1.0e9 atomics
-                # per layer, bound by the L2 atomic units at ~3.3 ms per layer), and the fused kernel hides most of it
-                # under its MFMA phases and never writes / re-reads the [cols, cin*ks] dG.  (An atomic-free CSR-gather
-                # transpose was tried and dropped: it re-reads every 96-byte dG row K times, 3x slower.)
-                g = to_cl(grad_out, "grad_out")
+                # The fused data-gradient kernel (W^T dOut + per-column tail in one pass, no dG tensor) beats
+                # dG-GEMM + ungroup (36 vs 39 ms per step).  Both end in the same fp32 atomic scatter -- cols*K*cin =
+                # 1.0e9 atomics for every layer, ~3.3 ms per layer at the L2 atomic units -- and the fused kernel hides
+                # most of it under its MFMA phases.  Also measured and dropped: an atomic-free CSR-gather transpose
+                # (re-reads every 96-byte dG row K times: 3x slower) and running the weight-gradient GEMM on a side
+                # stream underneath the scatter (no overlap materialises: +-1 ms).
                 ws, wsp, wsn = _workspace(lib, d, G.device)
                 _lib.check(_launch("inter_bwd_data", _inter_key(d), _inter_flops(d), G.device,
                                    lambda: lib.epn_inter_so3conv_bwd_data_f32(ctypes.byref(d), _cl_ptr(g),
@@ -331,7 +334,7 @@ class InterSO3ConvSplitFn(torch.autograd.Function):
                                                                               wsn, _lib.stream_of(G))),
                            "inter_so3conv_bwd_data")
             else:
-                dG = _launch("inter_gemm", _inter_key(d), 2.0 * cols * cout * ck, G.device, lambda: torch.mm(g2d, Wc))
+                dG = _launch("inter_gemm", _inter_key(d), gemm_fl, G.device, lambda: torch.mm(g2d, Wc))
                 ws, wsp, wsn = _group_workspace(lib, d, G.device)
                 gflops = 9.0 * cols * d.ks * d.nn + 2.0 * cols * cin * d.ks * d.nn
                 _lib.check(_launch("inter_ungroup", _inter_key(d), gflops, G.device,
@@ -494,7 +497,7 @@ class NormActFn(torch.autograd.Function):
     Returns (y, sums) with sums[g][c] = (sum x, sum x^2) for the caller's running-statistics update."""
 
     @staticmethod
-    def forward(ctx, x, gamma, beta, residual, instance, eps, slope):
+    def forward(ctx, x, gamma, beta, residual, conv_bias, instance, eps, slope):
         lib = _lib.get_lib()
         xc = to_cl(x, "x")
         b, c, p, a = xc.shape
@@ -513,7 +516,7 @@ class NormActFn(torch.autograd.Function):
                                             _cl_ptr(r) if r is not None else ctypes.c_void_p(0), float(eps),
                                             float(slope), _cl_ptr(y), st), "norm_act_fwd")
         ctx.save_for_backward(xc, sums, g, bt)
-        ctx.cfg = (groups, rows, c, float(eps), float(slope), residual is not None)
+        ctx.cfg = (groups, rows, c, float(eps), float(slope), residual is not None, conv_bias is not None)
         ctx.mark_non_differentiable(sums)
         return y, sums
 
@@ -521,7 +524,7 @@ class NormActFn(torch.autograd.Function):
     def backward(ctx, grad_y, _grad_sums):
         lib = _lib.get_lib()
         xc, sums, g, bt = ctx.saved_tensors
-        groups, rows, c, eps, slope, has_res = ctx.cfg
+        groups, rows, c, eps, slope, has_res, has_cb = ctx.cfg
         dy = to_cl(grad_y, "grad_y")
         st = _lib.stream_of(xc)
         dsums = torch.empty_like(sums)
@@ -540,22 +543,29 @@ class NormActFn(torch.autograd.Function):
             _lib.check(lib.epn_norm_act_bwd_apply_f32(_cl_ptr(xc), _cl_ptr(dy), groups, rows, c,
                                                       _lib.dev_ptr(sums, "sums"), _lib.dev_ptr(dsums, "dsums"), gp, bp,
                                                       eps, slope, _cl_ptr(dx), st), "norm_act_bwd_apply")
-        return dx, dg, db, (dy if has_res else None), None, None, None
+        # conv_bias (a bias the normalisation cancels, see norm_act): exact gradient = 0
+        dcb = torch.zeros(c, dtype=torch.float32, device=xc.device) if has_cb else None
+        return dx, dg, db, (dy if has_res else None), dcb, None, None, None
 
 
-def norm_act(x, norm, residual=None, slope=0.01):
+def norm_act(x, norm, residual=None, slope=0.01, conv_bias=None):
     """leaky_relu(norm(x)) (+ residual) with `norm` an nn.BatchNorm2d or nn.InstanceNorm2d(affine=False) module whose
-    parameters / running statistics are used and updated exactly as the module would (training mode)."""
+    parameters / running statistics are used and updated exactly as the module would (training mode).
+    conv_bias: per-channel bias of the convolution that produced x, NOT yet added to x.  Both norms subtract the
+    per-channel mean, so norm(x + b) == norm(x) and d/db == 0 exactly: the add (a full read + write of the tensor) and
+    the bias-gradient reduction are skipped, only BatchNorm's running_mean needs b."""
     import torch.nn as nn
     instance = isinstance(norm, nn.InstanceNorm2d)
     gamma = getattr(norm, "weight", None)
     beta = getattr(norm, "bias", None)
-    y, sums = NormActFn.apply(x, gamma, beta, residual, instance, norm.eps, slope)
+    y, sums = NormActFn.apply(x, gamma, beta, residual, conv_bias, instance, norm.eps, slope)
     if not instance and norm.track_running_stats and norm.running_mean is not None:
         with torch.no_grad():
             n = x.shape[0] * x.shape[2] * x.shape[3]
             mean = sums[0, :, 0] / n
             var = (sums[0, :, 1] / n - mean * mean).clamp_min_(0) * (n / max(n - 1, 1))   # unbiased, as BatchNorm stores
+            if conv_bias is not None:
+                mean = mean + conv_bias
             m = norm.momentum if norm.momentum is not None else 0.1
             norm.running_mean.mul_(1 - m).add_(mean, alpha=m)
             norm.running_var.mul_(1 - m).add_(var, alpha=m)

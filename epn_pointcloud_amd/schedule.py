@@ -142,8 +142,8 @@ class FusedSeparableBlock(SeparableBlock):
             b, p1, a, c = s_cl.shape
             idx = sample_idx.long().view(b, -1, 1).expand(-1, -1, a * c)
             skip = torch.gather(s_cl.reshape(b, p1, a * c), 1, idx).view(b, -1, a, c).permute(0, 3, 1, 2)
-        s = ops.conv1x1(skip, self.skip_conv.weight, self.skip_conv.bias)
-        s = ops.norm_act(s, self.norm)
+        s = ops.conv1x1(skip, self.skip_conv.weight, None)           # the norm cancels the bias: see ops.norm_act
+        s = ops.norm_act(s, self.norm, conv_bias=self.skip_conv.bias)
         out = ops.norm_act(z.feats, self.intra_conv.norm, residual=s)   # leaky(IN(z)) + skip in the same pass
         return inter_idx, inter_w, sample_idx, zptk.SphericalPointCloud(z.xyz, out, z.anchors)
 

@@ -394,6 +394,10 @@ def test_fused_block_matches_stock_block(gpu, vgtk_alias):
         assert (ya - yb).abs().max().item() < TOL
         for (n, _), u, v in zip([("feats", None)] + list(a.named_parameters()), ga, gb):
             assert _close_except_kinks(v, u, TOL), n
+        # running statistics (the fused block skips the skip-conv bias the norm cancels, but must track it)
+        for (n, u), (_, v) in zip(a.named_buffers(), b.named_buffers()):
+            if "running" in n:
+                assert torch.allclose(u, v, atol=1e-4), n
 
 
 @pytest.mark.parametrize("cin,K,na_sel,stride", [(16, 16, None, 1), (32, 32, None, 2), (48, 100, None, 2), (5, 9, None, 1),
