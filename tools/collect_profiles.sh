@@ -16,4 +16,8 @@ for C in FETCH_SIZE WRITE_SIZE "SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES GRBM_GUI
   rocprofv3 --pmc $C --kernel-trace --output-format csv -d $OUT/pmc_$N -o p -- $BENCH > $OUT/pmc_$N.log 2>&1
 done
 grep -v "^[WE]2026" $OUT/stats.log | tail -1 > $OUT/bench_under_rocprof.json
+# summarise on the box and drop the raw traces (gpurun copies back at most 64 MiB)
+python $R/tools/rocprof_summary.py $(find $OUT/stats -name "*.db" | head -1) $OUT/kernel_stats.csv
+python $R/tools/pmc_summary.py $OUT $OUT/pmc_per_kernel.json
+rm -rf $OUT/stats $OUT/pmc_*/
 ls $OUT
