@@ -14,7 +14,7 @@ LIB_PATH = os.environ.get("EPN_LIB", os.path.join(_PKG, "libepn_so3conv.so"))   
 
 EXPORTS = [
     "epn_version", "epn_strerror",
-    "epn_ball_query_f32", "epn_fps_f32", "epn_gather_fwd_f32", "epn_gather_bwd_f32",
+    "epn_ball_query_f32", "epn_fps_f32", "epn_gather_fwd_f32", "epn_gather_bwd_f32", "epn_initial_anchor_query_f32",
     "epn_inter_workspace_bytes", "epn_inter_is_fused", "epn_inter_so3conv_fwd_f32",
     "epn_inter_so3conv_bwd_data_f32", "epn_inter_so3conv_bwd_weight_f32", "epn_inter_weights_f32",
     "epn_intra_workspace_bytes", "epn_intra_is_fused", "epn_intra_so3conv_fwd_f32",
@@ -53,6 +53,7 @@ def get_lib():
     lib.epn_strerror.argtypes = [_ci]
     lib.epn_ball_query_f32.argtypes = [_vp, _vp, _ci, _ci, _ci, _cf, _ci, _vp, _vp]
     lib.epn_fps_f32.argtypes = [_vp, _ci, _ci, _ci, _vp, _vp]
+    lib.epn_initial_anchor_query_f32.argtypes = [_vp, _vp, _vp, _ci, _ci, _ci, _ci, _ci, _cf, _cf, _vp, _vp, _vp]
     lib.epn_gather_fwd_f32.argtypes = [_vp, _vp, _ci, _ci, _ci, _ci, _vp, _vp]
     lib.epn_gather_bwd_f32.argtypes = [_vp, _vp, _ci, _ci, _ci, _ci, _vp, _vp]
     dp = ctypes.POINTER(InterDesc)

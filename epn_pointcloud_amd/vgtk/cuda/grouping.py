@@ -29,8 +29,19 @@ def furthest_point_sampling(source_xyz, m):
 
 
 def initial_anchor_query(centers, xyz, kernel_points, radius, sigma):
-    """grouping_cuda.cpp:140-158; only KernelPropagation uses it, no shipped model does -- SURVEY 8(f) "next"."""
-    raise NotImplementedError("initial_anchor_query: not on the hot path of any shipped model (SURVEY.md 8f.3)")
+    """(centers f[b,3,nc], xyz f[m,3], kernel_points f[ks,na,3], radius, sigma) ->
+    [anchor_weights f[b,ks,nc,na], anchor_ctn f[b,ks,nc,na]]  (grouping_cuda.cpp:138-158; KernelPropagation)."""
+    lib = _lib.get_lib()
+    c, x, k = _lib.dev_ptr(centers, "centers"), _lib.dev_ptr(xyz, "xyz"), _lib.dev_ptr(kernel_points, "kernel_points")
+    b, _, nc = centers.shape
+    m = xyz.shape[0]
+    ks, na = kernel_points.shape[0], kernel_points.shape[1]
+    wts = torch.empty((b, ks, nc, na), dtype=torch.float32, device=xyz.device)
+    ctn = torch.empty((b, ks, nc, na), dtype=torch.float32, device=xyz.device)
+    _lib.check(lib.epn_initial_anchor_query_f32(c, x, k, b, nc, m, na, ks, float(radius), float(sigma),
+                                                _lib.dev_ptr(wts, "anchor_weights"), _lib.dev_ptr(ctn, "anchor_ctn"),
+                                                _lib.stream_of(xyz)), "initial_anchor_query")
+    return [wts, ctn]
 
 
 def anchor_query(sample_idx, grouped_indices, grouped_xyz, anchors, kernel_points, nq):

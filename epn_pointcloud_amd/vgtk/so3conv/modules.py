@@ -42,14 +42,14 @@ class BasicSO3Conv(nn.Module):
 
 
 class KernelPropagation(nn.Module):
-    """modules.py:57-119.  Buffers/parameters as in the reference; forward needs `initial_anchor_query`,
-    which no shipped model reaches ("next")."""
+    """modules.py:57-119.  Buffers/parameters as in the reference; forward = FPS centres, `initial_anchor_query` (HIP,
+    atomic-free), normalisation by the point count, BasicSO3Conv.  No shipped model reaches it."""
 
     def __init__(self, dim_in, dim_out, n_center, kernel_size, radius, sigma, kanchor=60):
         super(KernelPropagation, self).__init__()
         kernels = L.get_sphereical_kernel_points_from_ply(KERNEL_CONDENSE_RATIO * radius, kernel_size)
         anchors = L.get_anchors(kanchor)
-        kernels = np.transpose(anchors @ kernels.T, (2, 0, 1))
+        kernels = np.ascontiguousarray(np.transpose(anchors @ kernels.T, (2, 0, 1)))   # [ks, na, 3], contiguous for the kernel
         self.radius = radius
         self.sigma = sigma
         self.n_center = n_center

@@ -158,6 +158,18 @@ int epn_norm_act_bwd_apply_f32(const float *x_cl, const float *dy_cl, int groups
                                const float *sums, const float *dsums, const float *gamma, const float *beta,
                                float eps, float slope, float *dx_cl, epn_stream_t stream);
 
+/* replaces vgtk.cuda.grouping.initial_anchor_query (vgtk/vgtk/cuda/grouping_cuda.cpp:138-158, kernel
+ * grouping_cuda_kernel.cu:116-167; only consumer: KernelPropagation, vgtk/vgtk/so3conv/modules.py:57-119).
+ *   centers f32[b][3][nc]   xyz f32[m][3] (fragment points, shared by the batch)   kernel_points f32[ks][na][3]
+ *   anchor_weights f32[b][ks][nc][na] = sum over fragment points within `radius` of the centre (sqrt distance, <=) of
+ *                                       max(1 - |centre + kernel_point - x|^2 / sigma, 0)
+ *   anchor_ctn     f32[b][ks][nc][na] = number of such points (same value for every ks, na)
+ * Both outputs are fully written (the reference zero-fills and accumulates with atomics, and reads xyz[3*pm] past the
+ * end for its padding threads; neither is reproduced).  ks*na <= 2048. */
+int epn_initial_anchor_query_f32(const float *centers, const float *xyz, const float *kernel_points, int b, int nc,
+                                 int m, int na, int ks, float radius, float sigma, float *anchor_weights,
+                                 float *anchor_ctn, epn_stream_t stream);
+
 /* ---------------------------------------------------------------------------------------------------------------------
  * Grouping only ("split" convolution): the grouped features as a tensor, the weight contraction left to the caller's
  * BLAS.  replaces vgtk/vgtk/so3conv/functional.py:118-140 (inter_so3conv_grouping: ball grouping + anchor weights +

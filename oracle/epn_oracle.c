@@ -152,3 +152,37 @@ void epn_oracle_gather_bwd_f32(const float *grad_out, const int32_t *idx, int b,
                 grad_points[((size_t)bi * c + ci) * n + idx[(size_t)bi * m + j]] +=
                     grad_out[((size_t)bi * c + ci) * m + j];
 }
+
+/*
+ * initial_anchor_query, grouping_cuda_kernel.cu:116-167 (+ wrapper grouping_cuda.cpp:138-158): centers (b,3,nc),
+ * xyz (m,3), kernel_points (ks,na,3) -> anchor_weights / anchor_ctn (b,ks,nc,na), zero-initialised by the wrapper.
+ * For every fragment point within `radius` of a centre (sqrt distance, <=): ctn += 1 for every (kernel, anchor), and
+ * weights += max(1 - d*d/sigma, 0) with d = sqrt(|centre + kernel_point - x|^2) (sqrt then square, as written).
+ * The CUDA kernel accumulates with atomics in arbitrary order; here fragment-point order.
+ */
+void epn_oracle_initial_anchor_query_f32(const float *centers, const float *xyz, const float *kp, int b, int nc, int m,
+                                         int na, int ks, float radius, float sigma, float *wts, float *ctn) {
+    memset(wts, 0, sizeof(float) * (size_t)b * ks * nc * na);
+    memset(ctn, 0, sizeof(float) * (size_t)b * ks * nc * na);
+    for (int bn = 0; bn < b; ++bn) {
+        const float *c = centers + (size_t)bn * 3 * nc;
+        for (int pn = 0; pn < nc; ++pn) {
+            const float cx = c[pn], cy = c[nc + pn], cz = c[2 * nc + pn];
+            for (int pm = 0; pm < m; ++pm) {
+                const float x = xyz[3 * pm], y = xyz[3 * pm + 1], z = xyz[3 * pm + 2];
+                const float d2c = sqrtf((cx - x) * (cx - x) + (cy - y) * (cy - y) + (cz - z) * (cz - z));
+                if (!(d2c <= radius)) continue;
+                for (int kn = 0; kn < ks; ++kn)
+                    for (int an = 0; an < na; ++an) {
+                        const float kx = kp[(kn * na + an) * 3] + cx, ky = kp[(kn * na + an) * 3 + 1] + cy,
+                                    kz = kp[(kn * na + an) * 3 + 2] + cz;
+                        const float d = sqrtf((kx - x) * (kx - x) + (ky - y) * (ky - y) + (kz - z) * (kz - z));
+                        const float w = 1.0f - (d * d / sigma);
+                        const size_t at = (((size_t)bn * ks + kn) * nc + pn) * na + an;
+                        if (w > 0.0f) wts[at] += w;
+                        ctn[at] += 1.0f;
+                    }
+            }
+        }
+    }
+}

@@ -7,6 +7,7 @@ restatement of the reference's CUDA-only index kernels
 * ``furthest_point_sampling``  vgtk/vgtk/cuda/grouping_cuda.cpp:160-174
 * ``gather_points_forward``    vgtk/vgtk/cuda/gathering_cuda.cpp:29-43
 * ``gather_points_backward``   vgtk/vgtk/cuda/gathering_cuda.cpp:45-60
+* ``initial_anchor_query``     vgtk/vgtk/cuda/grouping_cuda.cpp:138-158
 
 with the same call signatures as the pybind functions (torch CPU tensors in,
 freshly allocated torch CPU tensors out).  Parity vs the CUDA binary is
@@ -50,6 +51,8 @@ def _load():
         lib.epn_oracle_fps_f32.argtypes = [f32p, ci, ci, ci, f32p, i32p]
         lib.epn_oracle_gather_fwd_f32.argtypes = [f32p, i32p, ci, ci, ci, ci, f32p]
         lib.epn_oracle_gather_bwd_f32.argtypes = [f32p, i32p, ci, ci, ci, ci, f32p]
+        lib.epn_oracle_initial_anchor_query_f32.argtypes = [f32p, f32p, f32p, ci, ci, ci, ci, ci, ctypes.c_float,
+                                                            ctypes.c_float, f32p, f32p]
         lib.epn_oracle_opt_n_threads.argtypes = [ci]
         lib.epn_oracle_opt_n_threads.restype = ci
         _lib = lib
@@ -113,6 +116,24 @@ def gather_points_backward(grad_out, idx, npoint):
     lib.epn_oracle_gather_bwd_f32(gp, ip, b, c, int(npoint), m,
                                   out.ctypes.data_as(ctypes.POINTER(ctypes.c_float)))
     return torch.from_numpy(out)
+
+
+def initial_anchor_query(centers, xyz, kernel_points, radius, sigma):
+    """(centers f[b,3,nc], xyz f[m,3], kernel_points f[ks,na,3], radius, sigma) -> [weights, counts] f[b,ks,nc,na]
+    (vgtk/vgtk/cuda/grouping_cuda.cpp:138-158)."""
+    lib = _load()
+    b, _, nc = centers.shape
+    m = xyz.shape[0]
+    ks, na = kernel_points.shape[0], kernel_points.shape[1]
+    ca, cp = _f32(centers)
+    xa, xp = _f32(xyz)
+    ka, kpp = _f32(kernel_points)
+    w = np.zeros((b, ks, nc, na), dtype=np.float32)
+    c = np.zeros((b, ks, nc, na), dtype=np.float32)
+    f32p = ctypes.POINTER(ctypes.c_float)
+    lib.epn_oracle_initial_anchor_query_f32(cp, xp, kpp, b, nc, m, na, ks, float(radius), float(sigma),
+                                            w.ctypes.data_as(f32p), c.ctypes.data_as(f32p))
+    return [torch.from_numpy(w), torch.from_numpy(c)]
 
 
 def opt_n_threads(work_size):

@@ -120,3 +120,41 @@ def test_group_nd_and_furthest_sample(ext, vgtk_alias):
     grouped = pctk.group_nd(x, bi)
     assert tuple(grouped.shape) == (2, 3, 128, 16)
     assert torch.equal(grouped[1, :, 5, 3], x[1, :, bi[1, 5, 3].long()])
+
+
+@pytest.mark.parametrize("b,nc,m,na,ks,radius,sigma", [(2, 16, 500, 60, 24, 0.4, 0.08), (1, 5, 1, 12, 24, 0.3, 0.05),
+                                                        (3, 7, 777, 60, 13, 0.25, 0.03), (1, 4, 300, 1, 24, 0.01, 0.02)])
+def test_initial_anchor_query_vs_oracle(gpu, vgtk_alias, b, nc, m, na, ks, radius, sigma):
+    """vgtk.cuda.grouping.initial_anchor_query (grouping_cuda.cpp:138-158): counts exact, weights to fp32 rounding of
+    the same summation order; includes a chunk boundary (m > 256), a single fragment point and an (almost) empty ball."""
+    import vgtk.cuda.grouping as cuda_nn
+    from oracle import index_ref
+    rng = np.random.default_rng(m + nc)
+    centers = torch.from_numpy(unit_ball_cloud(rng, b, nc))
+    frag = torch.from_numpy(np.ascontiguousarray(unit_ball_cloud(rng, 1, m)[0].T))        # [m, 3]
+    kp = torch.from_numpy((rng.standard_normal((ks, na, 3)) * 0.2).astype(np.float32))
+    w_ref, c_ref = index_ref.initial_anchor_query(centers, frag, kp, radius, sigma)
+    w, c = cuda_nn.initial_anchor_query(centers.to(gpu), frag.to(gpu), kp.to(gpu), radius, sigma)
+    assert tuple(w.shape) == (b, ks, nc, na) and tuple(c.shape) == (b, ks, nc, na)
+    assert torch.equal(c.cpu(), c_ref)
+    assert (w.cpu() - w_ref).abs().max().item() <= 1e-5 * max(1.0, w_ref.abs().max().item())
+
+
+def test_kernel_propagation_module(gpu, vgtk_alias):
+    """KernelPropagation.forward (vgtk/vgtk/so3conv/modules.py:57-119) end to end against the oracle pieces."""
+    import vgtk.so3conv as sptk
+    from oracle import index_ref
+    rng = np.random.default_rng(3)
+    torch.manual_seed(3)
+    clouds = torch.from_numpy(unit_ball_cloud(rng, 2, 64))
+    frag = torch.from_numpy(np.ascontiguousarray(unit_ball_cloud(rng, 1, 400)[0].T))
+    mod = sptk.KernelPropagation(1, 8, 16, 1, 0.4, 0.08).to(gpu)
+    y = mod(frag.to(gpu), clouds.to(gpu))
+    assert tuple(y.feats.shape) == (2, 8, 16, 60) and tuple(y.xyz.shape) == (2, 3, 16)
+    sidx = index_ref.furthest_point_sampling(clouds, 16).long()
+    centers = torch.gather(clouds, 2, sidx[:, None, :].expand(-1, 3, -1)).contiguous()
+    assert torch.equal(y.xyz.cpu(), centers)
+    w, c = index_ref.initial_anchor_query(centers, frag, mod.kernels.cpu(), 0.4, 0.08)
+    g = (w / (c + 1.0)).unsqueeze(1)                                         # [b, 1, ks, nc, na]
+    want = torch.matmul(mod.basic_conv.W.detach().cpu(), g.reshape(2, 24, 16 * 60)).view(2, 8, 16, 60)
+    assert (y.feats.detach().cpu() - want).abs().max().item() < 1e-4 * max(1.0, want.abs().max().item())

@@ -66,6 +66,8 @@ def test_cpu_tensors_are_rejected_like_check_cuda(vgtk_alias):
     conv = sptk.IntraSO3Conv(4, 4)
     with pytest.raises(RuntimeError, match="must be a CUDA tensor"):
         conv(zptk.SphericalPointCloud(x, torch.rand(1, 4, 32, 60), None))
+    with pytest.raises(RuntimeError, match="must be a CUDA tensor"):
+        cuda_nn.initial_anchor_query(x, torch.rand(8, 3), torch.rand(24, 60, 3), 0.4, 0.08)
     with pytest.raises(NotImplementedError):
         cuda_nn.anchor_query(None, None, None, None, None, 0)
 

@@ -139,3 +139,22 @@ def test_kernel_point_scaling():
     g = golden("tables.npz")
     k = R.scaled_kernel_points(T(g["kpsphere24"]), 0.4)
     assert torch.allclose(k, T(g["kernels_r0p4"]), atol=1e-7)
+
+
+def test_initial_anchor_query_oracle_properties():
+    """The C restatement of initial_anchor_query (no golden vectors exist for it: parity unpinned vs the CUDA binary):
+    counts equal a brute-force numpy count, weights equal the closed form on a case small enough to enumerate."""
+    from oracle import index_ref
+    rng = np.random.default_rng(1)
+    centers = torch.from_numpy(rng.uniform(-0.5, 0.5, (2, 3, 4)).astype(np.float32))
+    frag = torch.from_numpy(rng.uniform(-0.7, 0.7, (50, 3)).astype(np.float32))
+    kp = torch.from_numpy(rng.uniform(-0.2, 0.2, (3, 5, 3)).astype(np.float32))
+    w, c = index_ref.initial_anchor_query(centers, frag, kp, 0.5, 0.1)
+    C = centers.numpy().transpose(0, 2, 1)[:, :, None, :]                    # [b, nc, 1, 3]
+    X = frag.numpy()[None, None]                                             # [1, 1, m, 3]
+    inside = np.sqrt(((C - X) ** 2).sum(-1)) <= 0.5                          # [b, nc, m]
+    assert np.array_equal(c.numpy(), np.broadcast_to(inside.sum(-1)[:, None, :, None], c.shape).astype(np.float32))
+    K = kp.numpy()[None, :, None, :, None, :] + C[:, None, :, None, :, :]    # [b, ks, nc, na, 1, 3]
+    d2 = ((K - X[:, None, :, None]) ** 2).sum(-1)                            # [b, ks, nc, na, m]
+    ww = np.maximum(1.0 - d2 / 0.1, 0.0) * inside[:, None, :, None, :]
+    assert np.allclose(w.numpy(), ww.sum(-1), atol=1e-4)
