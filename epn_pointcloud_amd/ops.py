@@ -5,6 +5,7 @@ channels-last ([b][p][a][c], torch.channels_last), which is what the HIP kernels
 any other layout is converted once on entry.
 """
 import ctypes
+import os
 
 import torch
 
@@ -204,7 +205,6 @@ def use_tuned_gemms():
     if _TUNED:
         return
     _TUNED = True
-    import os
     if os.environ.get("EPN_TUNED_GEMM", "1") != "1" or any(k.startswith("PYTORCH_TUNABLEOP_") for k in os.environ):
         return
     path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "gemm_tuning_gfx950.csv")
@@ -303,7 +303,6 @@ class InterSO3ConvSplitFn(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, grad_out):
-        import os
         lib = _lib.get_lib()
         G, Wc = ctx.saved_tensors
         geo, cin = ctx.geo, ctx.cin
@@ -577,7 +576,6 @@ def inter_mode():
     """EPN_INTER_MODE = fused | split | auto (default).  auto: the split form (grouped features to HBM + library GEMMs)
     for every layer the MFMA grouping kernel takes (cin % 16 == 0) -- measured faster for training and for inference;
     the fused kernels are the memory-lean choice (no [cols, cin*ks] tensor) and serve cin = 1 and dense inter_w."""
-    import os
     return os.environ.get("EPN_INTER_MODE", "auto")
 
 
@@ -592,7 +590,6 @@ def inter_so3conv(feats, W, geo):
 
 def intra_mode():
     """EPN_INTRA_MODE = fused | split | auto (default): as inter_mode()."""
-    import os
     return os.environ.get("EPN_INTRA_MODE", "auto")
 
 
@@ -670,7 +667,6 @@ def conv1x1(x, weight, bias=None):
     EPN_CONV1X1 = kernel (default): the intra GEMM kernel with a single, identity anchor neighbour;
                   blas: a plain row-major GEMM [cols, cin] x [cin, cout] (+ bias) on a zero-copy 2-D view.
     Shapes the MFMA kernel does not take (cin = 1 of the first block, the few-channel heads) go to torch."""
-    import os
     cout, cin = weight.shape[0], weight.shape[1]
     if x.is_cuda and cin % 16 == 0 and cout % 16 == 0:
         if os.environ.get("EPN_CONV1X1", "kernel") == "blas":
