@@ -318,8 +318,10 @@ class InterSO3ConvSplitFn(torch.autograd.Function):
             gW = _launch("inter_gemm", _inter_key(d), gemm_fl, G.device, lambda: torch.mm(g2d.t(), G))
         if need_f:
             gf = empty_cl(d.b, cin, d.p1, d.na, G.device)
-            if (os.environ.get("EPN_INTER_BWD_DATA", "fused") == "fused" and lib.epn_inter_is_fused(ctypes.byref(d))
-                    and cin >= 16):
+            mode = os.environ.get("EPN_INTER_BWD_DATA", "auto")
+            if mode == "auto":          # widest layers: library dG GEMM + scatter beats the fused kernel (measured)
+                mode = "split" if cin * cout >= 65536 else "fused"
+            if mode == "fused" and lib.epn_inter_is_fused(ctypes.byref(d)) and cin >= 16:
                 # The fused data-gradient kernel (W^T dOut + per-column tail in one pass, no dG tensor) beats
                 # dG-GEMM + ungroup (36 vs 39 ms per step).  Both end in the same fp32 atomic scatter -- cols*K*cin =
                 # 1.0e9 atomics for every layer, ~3.3 ms per layer at the L2 atomic units -- and the fused kernel hides
