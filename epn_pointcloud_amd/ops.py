@@ -679,6 +679,9 @@ def conv1x1(x, weight, bias=None):
         na = x.shape[3]
         ident = torch.arange(na, dtype=torch.int32, device=x.device).view(na, 1)
         y = IntraSO3ConvFn.apply(x, weight.reshape(cout, cin), ident)
+    elif x.is_cuda and cin == 1:
+        # single input channel (the occupancy feature of the first block): an outer product, written channels-last
+        y = (to_cl(x).permute(0, 2, 3, 1) * weight.reshape(cout)).permute(0, 3, 1, 2)
     else:
         y = torch.nn.functional.conv2d(x, weight.reshape(cout, cin, 1, 1))
     return y if bias is None else y + bias.view(1, -1, 1, 1)
