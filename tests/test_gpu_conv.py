@@ -432,3 +432,68 @@ def test_group_ungroup_abi_vs_oracle(gpu, vgtk_alias, cin, K, na_sel, stride):
     assert (G.detach().cpu() - want.detach()).abs().max().item() < TOL * max(1.0, want.abs().max().item())
     (dF,) = torch.autograd.grad(G, fg, gG.to(gpu))
     assert (dF.cpu() - o_dF).abs().max().item() < TOL * max(1.0, o_dF.abs().max().item())
+
+
+def test_arbitrary_index_rows_are_not_deduplicated(gpu, vgtk_alias, inter_mode):
+    """The data-gradient scatter merges the cyclically padded slots of a ball-query row.  Index tensors handed in by a
+    caller need not be cyclic (here: random rows with accidental repeats of slot 0, shadow indices, a constant row);
+    those must take the plain path.  Forward and both gradients against the oracle."""
+    from epn_pointcloud_amd import ops
+    from epn_pointcloud_amd.vgtk.so3conv import functional as L
+    from epn_pointcloud_amd.vgtk import functional as fr
+    torch.manual_seed(12)
+    rng = np.random.default_rng(12)
+    b, p1, p2, nn, cin, cout, radius, sigma = 2, 40, 24, 16, 16, 32, 0.5, 0.1
+    xyz = T(unit_ball_cloud(rng, b, p1))
+    new_xyz = xyz[:, :, :p2].contiguous()
+    idx = torch.randint(0, 6, (b, p2, nn), dtype=torch.int32)          # few distinct values: many repeats of slot 0
+    idx[0, 0] = 3                                                       # constant row
+    idx[0, 1, 5:] = p1                                                  # shadow (out of range) entries
+    idx[1, 2] = torch.arange(nn) % 5                                    # a genuinely cyclic row among the arbitrary ones
+    anchors = T(L.get_anchors(60))
+    kernels = R.scaled_kernel_points(T(fr.kernel_points_raw(24)), radius)
+    feats, W = torch.randn(b, cin, p1, 60), torch.randn(cout, cin * 24) / (cin * 24) ** 0.5
+    fo, Wo = feats.clone().requires_grad_(True), W.clone().requires_grad_(True)
+    g = R.batched_index_select(xyz, 2, idx.long().clamp(0, p1 - 1).view(b, -1)).view(b, 3, p2, nn) - new_xyz[..., None]
+    w = R.inter_weights(g, anchors, kernels, sigma)
+    w = w * (idx < p1)[:, :, None, None, :].float()                     # shadow entries carry a zero feature row
+    G = R.inter_feat_grouping(idx.clamp(0, p1), w, R.add_shadow_feature(fo))
+    y_ref = R.basic_conv(Wo, G)
+    gy = torch.randn_like(y_ref)
+    dW_ref, dF_ref = torch.autograd.grad(y_ref, [Wo, fo], gy)
+    geo = ops.InterGeometry(xyz.to(gpu), new_xyz.to(gpu), idx.to(gpu), anchors.to(gpu), kernels.to(gpu), sigma)
+    fg, Wg = feats.to(gpu).requires_grad_(True), W.to(gpu).requires_grad_(True)
+    y = ops.inter_so3conv(fg, Wg, geo)
+    dW, dF = torch.autograd.grad(y, [Wg, fg], gy.to(gpu))
+    assert (y.detach().cpu() - y_ref.detach()).abs().max().item() < TOL * max(1.0, y_ref.abs().max().item())
+    assert _rel(dW.cpu(), dW_ref) < TOL
+    assert (dF.cpu() - dF_ref).abs().max().item() < TOL * max(1.0, dF_ref.abs().max().item())
+
+
+def test_split_and_fused_forms_agree_at_full_size(gpu, vgtk_alias):
+    """BASELINE configs[1] size (B=32, N=512 -> 512 points, 64 -> 64 channels, K=16, A=60: 983 040 columns, a 6 GB
+    grouped-feature tensor): the split form (grouping kernel + library GEMMs) and the fused kernels are independent
+    implementations of the same layer; outputs and both gradients must agree."""
+    from epn_pointcloud_amd import ops, schedule as S
+    from epn_pointcloud_amd.vgtk import pc as pctk, so3conv as sptk
+    l = S.cls_so3net_schedule(1024)[1]
+    torch.manual_seed(1)
+    pts = S.synthetic_clouds(32, 512, gpu, seed=5)
+    xyz = pts.permute(0, 2, 1).contiguous()
+    conv = sptk.InterSO3Conv(l.cin, l.cout, 1, l.stride, l.radius, l.sigma, l.nn, lazy_sample=True).to(gpu)
+    idx = pctk.ball_query_index(xyz, xyz, l.radius, l.nn)
+    geo = ops.InterGeometry(xyz, xyz, idx, conv.anchors, conv.kernels, l.sigma)
+    feats = torch.randn(32, l.cin, 512, 60, device=gpu).contiguous(memory_format=torch.channels_last)
+    W = conv.basic_conv.W.detach()
+    outs = []
+    for fn in (ops.InterSO3ConvFn, ops.InterSO3ConvSplitFn):
+        f, w = feats.clone().requires_grad_(True), W.clone().requires_grad_(True)
+        y = fn.apply(f, w, geo)
+        gy = torch.ones_like(y) * torch.linspace(-1, 1, 60, device=gpu)
+        dW, dF = torch.autograd.grad(y, [w, f], gy)
+        outs.append((y.detach(), dW, dF))
+        del y, gy
+    (y0, dW0, dF0), (y1, dW1, dF1) = outs
+    assert (y0 - y1).abs().max().item() < TOL * max(1.0, y0.abs().max().item())
+    assert _rel(dW1, dW0) < TOL
+    assert (dF0 - dF1).abs().max().item() < TOL * max(1.0, dF0.abs().max().item())
