@@ -32,7 +32,7 @@ KERNEL_OF = {  # C-ABI call -> device kernel family it launches on this workload
     "intra_bwd_data": "epn::intra_gemm_kernel", "intra_bwd_weight": "epn::intra_bwd_weight_pt_kernel",
     "inter_group": "epn::inter_group_kernel", "inter_ungroup": "epn::inter_ungroup_kernel",
     "inter_gemm": BLAS_FAMILY, "intra_gemm": BLAS_FAMILY,
-    "intra_group": "epn::intra_group_kernel",
+    "intra_group": "epn::intra_group_kernel", "so3_basis": "epn::so3_basis_kernel",
     "pointnet_fwd": "epn::pointnet_fwd_kernel", "pointnet_bwd_data": "epn::pointnet_bwd_data_kernel",
     "pointnet_bwd_weight": "epn::pointnet_bwd_weight_kernel",
 }

@@ -1,0 +1,113 @@
+// Change of anchor basis for IntraSO3Conv in its block-diagonal ("group Fourier") form, epn_pointcloud_amd/so3_fourier.py:
+//     Out[pt][r][ch] = sum_s M[r][s] * In[pt][s][ch]          M: na x na (na = 60 anchors), one matrix for every point
+// either side being the plain channels-last layout [pt][anchor][c] or the "spectral" layout, where row f of a point lives
+// in the buffer of its irreducible block:  ((base_f * pts + pt * d2_f + (f - base_f)) * c + ch), so that every block is
+// a dense row-major [pts * d][d * c] GEMM operand for the BLAS library.
+// HBM-bound streaming kernel (17 flop/byte): a wave owns one (point, 64-channel block); M sits zero-padded in LDS as
+// the MFMA A operand, the input rows are the B operand straight from global memory as one 16-byte load per lane and
+// contraction step (lane x holds channels 4x..4x+3 = column x of four N tiles), 240 MFMAs, 16-byte stores.
+#include "conv_internal.h"
+
+namespace epn {
+namespace {
+
+constexpr int SB_WAVES = 4;
+constexpr int SB_LD = 65;     // LDS row pitch of M (floats)
+constexpr int SB_TPW = 4;     // (point, channel block) tasks per wave: amortises the 16 KB load of M
+
+struct SbArgs {
+    const float *in, *M;
+    const int32_t *blk;       // [na][2] = (base row of the irreducible block, d*d) per spectral row
+    float *out;
+    long long pts;
+    int na, c, in_spec, out_spec;
+};
+
+__device__ __forceinline__ f32x4 mfma4(float a, float b, f32x4 c) {
+    return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0);
+}
+
+__global__ __launch_bounds__(64 * SB_WAVES) void so3_basis_kernel(SbArgs A) {
+    __shared__ float Ms[64 * SB_LD];
+    __shared__ int bs[64], d2s[64];
+    for (int i = threadIdx.x; i < 64 * 64; i += blockDim.x) {
+        const int r = i >> 6, s = i & 63;
+        Ms[r * SB_LD + s] = (r < A.na && s < A.na) ? A.M[r * A.na + s] : 0.0f;
+    }
+    if (threadIdx.x < 64) {
+        const int f = threadIdx.x < A.na ? threadIdx.x : 0;
+        bs[threadIdx.x] = A.blk[2 * f];
+        d2s[threadIdx.x] = A.blk[2 * f + 1];
+    }
+    __syncthreads();
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int x = lane & 15, j = lane >> 4;
+    const int ncb = A.c >> 6;
+    const int nst = A.na >> 2;        // contraction steps of 4 rows (na % 4 == 0, launcher)
+    for (int it = 0; it < SB_TPW; ++it) {
+        const long long task = ((long long)blockIdx.x * SB_WAVES + wave) * SB_TPW + it;
+        if (task >= A.pts * ncb) return;
+        const long long pt = task / ncb;
+        const int cb = (int)(task - pt * ncb);
+        const int choff = 64 * cb + 4 * x;
+
+        auto row_addr = [&](int spec, int r) -> size_t {   // float offset of row r of this point
+            if (spec) return ((size_t)bs[r] * A.pts + (size_t)pt * d2s[r] + (r - bs[r])) * A.c + choff;
+            return ((size_t)pt * A.na + r) * A.c + choff;
+        };
+
+        f32x4 acc[4][4];
+#pragma unroll
+        for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+            for (int nt = 0; nt < 4; ++nt) acc[mt][nt] = f32x4{0.f, 0.f, 0.f, 0.f};
+        f32x4 bv[16];
+#pragma unroll
+        for (int st = 0; st < 16; ++st)
+            if (st < nst) bv[st] = *reinterpret_cast<const f32x4 *>(A.in + row_addr(A.in_spec, 4 * st + j));
+#pragma unroll
+        for (int st = 0; st < 16; ++st) {
+            if (st < nst) {
+#pragma unroll
+                for (int mt = 0; mt < 4; ++mt) {
+                    const float a = Ms[(16 * mt + x) * SB_LD + 4 * st + j];
+#pragma unroll
+                    for (int nt = 0; nt < 4; ++nt) acc[mt][nt] = mfma4(a, bv[st][nt], acc[mt][nt]);
+                }
+            }
+        }
+        // acc[mt][nt][rr]: output row 16 mt + 4 j + rr, channel 4 x + nt
+#pragma unroll
+        for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+            for (int rr = 0; rr < 4; ++rr) {
+                const int r = 16 * mt + 4 * j + rr;
+                if (r < A.na) {
+                    const f32x4 v = {acc[mt][0][rr], acc[mt][1][rr], acc[mt][2][rr], acc[mt][3][rr]};
+                    *reinterpret_cast<f32x4 *>(A.out + row_addr(A.out_spec, r)) = v;
+                }
+            }
+    }
+}
+
+}  // namespace
+}  // namespace epn
+
+using namespace epn;
+
+extern "C" int epn_so3_basis_f32(const float *in, const float *M, const int32_t *blocks, long long pts, int na, int c,
+                                 int in_spectral, int out_spectral, float *out, epn_stream_t stream) {
+    if (pts < 0 || na < 4 || na > 64 || (na & 3) || c < 64 || (c & 63)) return EPN_EINVAL;
+    if (pts == 0) return 0;
+    if (!in || !M || !blocks || !out) return EPN_ENULL;
+    SbArgs A;
+    A.in = in; A.M = M; A.blk = blocks; A.out = out; A.pts = pts; A.na = na; A.c = c;
+    A.in_spec = in_spectral; A.out_spec = out_spectral;
+    const long long tasks = pts * (c >> 6);
+    const long long per_wg = (long long)SB_WAVES * SB_TPW;
+    hipLaunchKernelGGL(so3_basis_kernel, dim3((unsigned)((tasks + per_wg - 1) / per_wg)), dim3(64 * SB_WAVES), 0,
+                       epn_stream(stream), A);
+    EPN_CHECK_LAUNCH();
+    return 0;
+}

@@ -486,6 +486,141 @@ class IntraSO3ConvSplitFn(torch.autograd.Function):
         return gf, gW, None
 
 
+# ------------------------------------------------------------------------------------------------------------------
+# IntraSO3Conv in the block-diagonalising anchor basis (so3_fourier.py): U^T, one GEMM per irreducible block, U.
+_BASIS_CACHE = {}
+
+
+class _SpectralBasis:
+    """Device-side tables of so3_fourier.build() for one intra_idx tensor."""
+
+    def __init__(self, intra_idx32):
+        from . import so3_fourier
+        import numpy as np
+        bz = so3_fourier.build(intra_idx32.detach().cpu().numpy())
+        dev = intra_idx32.device
+        U = bz["U"].astype(np.float32)
+        self.na = U.shape[0]
+        self.U = torch.from_numpy(np.ascontiguousarray(U)).to(dev)            # [a][f]
+        self.Ut = torch.from_numpy(np.ascontiguousarray(U.T)).to(dev)         # [f][a]
+        self.dims = list(bz["dims"])
+        self.bases, blocks, base = [], [], 0
+        for d in self.dims:
+            self.bases.append(base)
+            blocks += [(base, d * d)] * (d * d)
+            base += d * d
+        self.blocks = torch.tensor(blocks, dtype=torch.int32, device=dev)     # [na][2]
+        self.rho = [torch.from_numpy(r.astype(np.float32)).to(dev) for r in bz["rho"]]   # [kn, d, d] each
+
+
+def spectral_basis(intra_idx32):
+    """Cached per index tensor; None when the table is not a regular permutation group action (then the 12-neighbour
+    forms are used) or the anchor count does not fit the transform kernel."""
+    key = (intra_idx32.data_ptr(), intra_idx32._version, tuple(intra_idx32.shape), str(intra_idx32.device))
+    if key not in _BASIS_CACHE:
+        na = intra_idx32.shape[0]
+        try:
+            _BASIS_CACHE[key] = _SpectralBasis(intra_idx32) if (na <= 64 and na % 4 == 0) else None
+        except ValueError:
+            _BASIS_CACHE[key] = None
+    return _BASIS_CACHE[key]
+
+
+def _basis_call(lib, src, M, basis, pts, c, in_spec, out_spec, dst, kind):
+    _lib.check(_launch(kind, ("so3_basis", pts, c), 2.0 * pts * basis.na * basis.na * c, src.device,
+                       lambda: lib.epn_so3_basis_f32(ctypes.c_void_p(src.data_ptr()), _lib.dev_ptr(M, "M"),
+                                                     _lib.dev_ptr(basis.blocks, "blocks", torch.int32),
+                                                     ctypes.c_longlong(pts), basis.na, c, in_spec, out_spec,
+                                                     ctypes.c_void_p(dst.data_ptr()), _lib.stream_of(src))),
+               "so3_basis")
+
+
+class ToSpectralFn(torch.autograd.Function):
+    """[b,c,p,a] channels-last -> flat spectral buffer [na * b*p * c] (block rho at offset base_rho * pts * c, laid out
+    [pts * d][d * c]); backward is the inverse transform (U is orthogonal)."""
+
+    @staticmethod
+    def forward(ctx, feats, basis):
+        lib = _lib.get_lib()
+        f = to_cl(feats)
+        b, c, p, na = f.shape
+        y = torch.empty(na * b * p * c, dtype=torch.float32, device=f.device)
+        _basis_call(lib, f, basis.Ut, basis, b * p, c, 0, 1, y, "so3_basis")
+        ctx.basis, ctx.dims = basis, (b, c, p, na)
+        return y
+
+    @staticmethod
+    def backward(ctx, gy):
+        lib = _lib.get_lib()
+        b, c, p, na = ctx.dims
+        gf = empty_cl(b, c, p, na, gy.device)
+        _basis_call(lib, gy.contiguous(), ctx.basis.U, ctx.basis, b * p, c, 1, 0, gf, "so3_basis")
+        return gf, None
+
+
+class FromSpectralFn(torch.autograd.Function):
+    """flat spectral buffer -> [b,c,p,a] channels-last (out[a] = sum_f U[a,f] y[f]); backward is ToSpectral."""
+
+    @staticmethod
+    def forward(ctx, y, basis, b, p, c):
+        lib = _lib.get_lib()
+        out = empty_cl(b, c, p, basis.na, y.device)
+        _basis_call(lib, y.contiguous(), basis.U, basis, b * p, c, 1, 0, out, "so3_basis")
+        ctx.basis, ctx.dims = basis, (b, c, p)
+        return out
+
+    @staticmethod
+    def backward(ctx, gout):
+        lib = _lib.get_lib()
+        b, c, p = ctx.dims
+        g = to_cl(gout, "grad_out")
+        gy = torch.empty(ctx.basis.na * b * p * c, dtype=torch.float32, device=g.device)
+        _basis_call(lib, g, ctx.basis.Ut, ctx.basis, b * p, c, 0, 1, gy, "so3_basis")
+        return gy, None, None, None, None
+
+
+class _MmFn(torch.autograd.Function):
+    """A @ B on the BLAS library, forward and both gradients timed like every other kernel of the path."""
+
+    @staticmethod
+    def forward(ctx, A, B):
+        ctx.save_for_backward(A, B)
+        return _launch("intra_gemm", ("mm",) + tuple(A.shape) + tuple(B.shape), 2.0 * A.shape[0] * A.shape[1] * B.shape[1],
+                       A.device, lambda: torch.mm(A, B))
+
+    @staticmethod
+    def backward(ctx, g):
+        A, B = ctx.saved_tensors
+        fl = 2.0 * A.shape[0] * A.shape[1] * B.shape[1]
+        gA = gB = None
+        if ctx.needs_input_grad[0]:
+            gA = _launch("intra_gemm", ("mm_dA",) + tuple(A.shape), fl, A.device, lambda: torch.mm(g, B.t()))
+        if ctx.needs_input_grad[1]:
+            gB = _launch("intra_gemm", ("mm_dB",) + tuple(A.shape), fl, A.device, lambda: torch.mm(A.t(), g))
+        return gA, gB
+
+
+def intra_so3conv_spectral(feats, W, intra_idx32, basis):
+    """IntraSO3Conv.forward (vgtk/vgtk/so3conv/modules.py:197-200) in the block-diagonal anchor basis: same result up to
+    fp32 rounding, 244 instead of 720 multiply-adds per (point, cin, cout), no [cols, 12*cin] grouped tensor; gradients
+    by autograd through the same pieces (GEMMs on the library, transforms on the HIP kernel)."""
+    use_tuned_gemms()
+    f = to_cl(feats)
+    b, cin, p, na = f.shape
+    cout, kn = W.shape[0], intra_idx32.shape[1]
+    if W.shape[1] != cin * kn or intra_idx32.shape[0] != na:
+        raise ValueError(f"shape mismatch: feats {tuple(f.shape)}, W {tuple(W.shape)}, intra_idx {tuple(intra_idx32.shape)}")
+    pts = b * p
+    y = ToSpectralFn.apply(f, basis)
+    Wv = W.reshape(cout, cin, kn)
+    outs = []
+    for d, base, rho in zip(basis.dims, basis.bases, basis.rho):
+        A = y[base * pts * cin:(base + d * d) * pts * cin].view(pts * d, d * cin)
+        What = torch.einsum('ock,kij->jcio', Wv, rho).reshape(d * cin, d * cout)   # sum_k W_k (x) rho(g_k)
+        outs.append(_MmFn.apply(A, What).reshape(-1))
+    return FromSpectralFn.apply(torch.cat(outs), basis, b, p, cout)
+
+
 def norm_act_supported(c):
     """Channel counts the fused norm kernels take (4 channels per lane, C/4 lanes dividing a 256-thread block)."""
     return c >= 4 and c % 4 == 0 and c <= 1024 and 256 % (c // 4) == 0
@@ -591,7 +726,9 @@ def inter_so3conv(feats, W, geo):
 
 
 def intra_mode():
-    """EPN_INTRA_MODE = fused | split | auto (default): as inter_mode()."""
+    """EPN_INTRA_MODE = fused | split | spectral | auto (default).  auto: the block-diagonal ("spectral") form when both
+    widths are multiples of 64 and the index table is a regular group action, else the split form (gather kernel +
+    library GEMMs) for multiples of 16, else the fused / generic kernels."""
     return os.environ.get("EPN_INTRA_MODE", "auto")
 
 
@@ -601,7 +738,12 @@ def intra_so3conv_fused(feats, W, intra_idx32):
 
 def intra_so3conv(feats, W, intra_idx32):
     mode = intra_mode()
-    if mode == "split" or (mode == "auto" and feats.shape[1] % 16 == 0 and W.shape[0] % 16 == 0):
+    cin, cout = feats.shape[1], W.shape[0]
+    if mode in ("auto", "spectral") and feats.is_cuda and cin % 64 == 0 and cout % 64 == 0 and intra_idx32.shape[1] > 1:
+        basis = spectral_basis(intra_idx32)
+        if basis is not None:
+            return intra_so3conv_spectral(feats, W, intra_idx32, basis)
+    if mode == "split" or (mode in ("auto", "spectral") and cin % 16 == 0 and cout % 16 == 0):
         return IntraSO3ConvSplitFn.apply(feats, W, intra_idx32)
     return IntraSO3ConvFn.apply(feats, W, intra_idx32)
 

@@ -102,7 +102,7 @@ def inter_mode(request):
         os.environ["EPN_INTER_MODE"] = old
 
 
-@pytest.fixture(params=["fused", "split"])
+@pytest.fixture(params=["fused", "split", "spectral"])
 def intra_mode(request):
     old = os.environ.get("EPN_INTRA_MODE")
     os.environ["EPN_INTRA_MODE"] = request.param
@@ -145,7 +145,8 @@ def test_inter_vs_oracle(gpu, vgtk_alias, inter_mode, cin, cout, stride, K, lazy
     assert (dF - odF).abs().max().item() < TOL * max(1.0, odF.abs().max().item())
 
 
-@pytest.mark.parametrize("cin,cout,p", [(8, 8, 40), (5, 3, 17), (16, 16, 64), (32, 64, 33), (64, 64, 128), (128, 128, 16)])
+@pytest.mark.parametrize("cin,cout,p", [(8, 8, 40), (5, 3, 17), (16, 16, 64), (32, 64, 33), (64, 64, 128), (128, 128, 16),
+                                        (64, 192, 21)])
 def test_intra_vs_oracle(gpu, vgtk_alias, intra_mode, cin, cout, p):
     sptk, zptk = _mods(vgtk_alias)
     torch.manual_seed(cin * 7 + p)

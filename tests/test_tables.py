@@ -1,5 +1,6 @@
 """Structural known-answer tests of the shipped icosahedral tables (SURVEY.md section 4 "property" rows)."""
 import numpy as np
+import pytest
 
 from conftest import golden
 
@@ -63,3 +64,31 @@ def test_select_anchor():
     assert L.get_anchors(12).shape == (60, 3, 3)   # anything else -> all 60 (functional.py:281-289)
     k = L.get_sphereical_kernel_points_from_ply(0.7 * 0.4, 1)
     assert k.dtype == np.float32 and np.array_equal(k, g["kernels_r0p4"])
+
+
+def test_spectral_basis_block_diagonalises_the_anchor_permutations():
+    """so3_fourier.build: derived from intra_idx alone; U orthogonal, U^T P_k U = blockdiag(rho(g_k) repeated d times)
+    for the 1 + 3 + 3 + 4 + 5 dimensional irreducibles, and the block-diagonal form reproduces the 12-neighbour
+    convolution (float64, 1e-10)."""
+    from epn_pointcloud_amd import so3_fourier as sf
+    from epn_pointcloud_amd.vgtk.so3conv import functional as L
+    idx = L.get_intra_idx()
+    bz = sf.build(idx)
+    assert bz["dims"] == [1, 3, 3, 4, 5]
+    sf.check(bz, tol=1e-9)
+    rng = np.random.default_rng(0)
+    cin, cout = 3, 2
+    F, W = rng.standard_normal((60, cin)), rng.standard_normal((cout, cin, 12))
+    direct = sum(F[idx[:, k]] @ W[:, :, k].T for k in range(12))
+    Fh, out_h, off = bz["U"].T @ F, np.zeros((60, cout)), 0
+    for d, r in zip(bz["dims"], bz["rho"]):
+        What = np.einsum('ock,kij->jcio', W, r).reshape(d * cin, d * cout)
+        for _ in range(d):
+            out_h[off:off + d] = (Fh[off:off + d].reshape(1, d * cin) @ What).reshape(d, cout)
+            off += d
+    assert np.abs(bz["U"] @ out_h - direct).max() < 1e-10
+    # a table that is not a regular group action is refused (callers then keep the 12-neighbour forms)
+    bad = idx.copy()
+    bad[:, 0] = np.roll(np.arange(60), 1)
+    with pytest.raises((ValueError, AssertionError)):
+        sf.build(bad)
