@@ -511,6 +511,7 @@ class _SpectralBasis:
             base += d * d
         self.blocks = torch.tensor(blocks, dtype=torch.int32, device=dev)     # [na][2]
         self.rho = [torch.from_numpy(r.astype(np.float32)).to(dev) for r in bz["rho"]]   # [kn, d, d] each
+        self.rho_all = torch.cat([r.reshape(r.shape[0], -1) for r in self.rho], dim=1).contiguous()   # [kn, na], (i, j)
 
 
 def spectral_basis(intra_idx32):
@@ -579,25 +580,44 @@ class FromSpectralFn(torch.autograd.Function):
         return gy, None, None, None, None
 
 
-class _MmFn(torch.autograd.Function):
-    """A @ B on the BLAS library, forward and both gradients timed like every other kernel of the path."""
+class _BlockGemmsFn(torch.autograd.Function):
+    """All irreducible blocks of one layer: Z^rho = Y^rho @ What^rho on the BLAS library, written straight into the
+    slices of ONE spectral output buffer (no concatenation), and likewise for the data gradient; forward and both
+    gradients are timed like every other kernel of the path."""
 
     @staticmethod
-    def forward(ctx, A, B):
-        ctx.save_for_backward(A, B)
-        return _launch("intra_gemm", ("mm",) + tuple(A.shape) + tuple(B.shape), 2.0 * A.shape[0] * A.shape[1] * B.shape[1],
-                       A.device, lambda: torch.mm(A, B))
+    def forward(ctx, y, basis, pts, cin, cout, *whats):
+        z = torch.empty(basis.na * pts * cout, dtype=torch.float32, device=y.device)
+        for d, base, wh in zip(basis.dims, basis.bases, whats):
+            A = y[base * pts * cin:(base + d * d) * pts * cin].view(pts * d, d * cin)
+            O = z[base * pts * cout:(base + d * d) * pts * cout].view(pts * d, d * cout)
+            _launch("intra_gemm", ("mm", pts * d, d * cin, d * cout), 2.0 * pts * d * d * cin * d * cout, y.device,
+                    lambda: torch.mm(A, wh, out=O))
+        ctx.save_for_backward(y, *whats)
+        ctx.cfg = (basis, pts, cin, cout)
+        return z
 
     @staticmethod
-    def backward(ctx, g):
-        A, B = ctx.saved_tensors
-        fl = 2.0 * A.shape[0] * A.shape[1] * B.shape[1]
-        gA = gB = None
-        if ctx.needs_input_grad[0]:
-            gA = _launch("intra_gemm", ("mm_dA",) + tuple(A.shape), fl, A.device, lambda: torch.mm(g, B.t()))
-        if ctx.needs_input_grad[1]:
-            gB = _launch("intra_gemm", ("mm_dB",) + tuple(A.shape), fl, A.device, lambda: torch.mm(A.t(), g))
-        return gA, gB
+    def backward(ctx, gz):
+        y, *whats = ctx.saved_tensors
+        basis, pts, cin, cout = ctx.cfg
+        gz = gz.contiguous()
+        gy = torch.empty_like(y) if ctx.needs_input_grad[0] else None
+        gws = []
+        for bi, (d, base, wh) in enumerate(zip(basis.dims, basis.bases, whats)):
+            A = y[base * pts * cin:(base + d * d) * pts * cin].view(pts * d, d * cin)
+            G = gz[base * pts * cout:(base + d * d) * pts * cout].view(pts * d, d * cout)
+            fl = 2.0 * pts * d * d * cin * d * cout
+            if gy is not None:
+                gA = gy[base * pts * cin:(base + d * d) * pts * cin].view(pts * d, d * cin)
+                _launch("intra_gemm", ("mm_dA", pts * d, d * cin, d * cout), fl, y.device,
+                        lambda: torch.mm(G, wh.t(), out=gA))
+            if ctx.needs_input_grad[5 + bi]:
+                gws.append(_launch("intra_gemm", ("mm_dB", pts * d, d * cin, d * cout), fl, y.device,
+                                   lambda: torch.mm(A.t(), G)))
+            else:
+                gws.append(None)
+        return (gy, None, None, None, None, *gws)
 
 
 def intra_so3conv_spectral(feats, W, intra_idx32, basis):
@@ -612,13 +632,12 @@ def intra_so3conv_spectral(feats, W, intra_idx32, basis):
         raise ValueError(f"shape mismatch: feats {tuple(f.shape)}, W {tuple(W.shape)}, intra_idx {tuple(intra_idx32.shape)}")
     pts = b * p
     y = ToSpectralFn.apply(f, basis)
-    Wv = W.reshape(cout, cin, kn)
-    outs = []
-    for d, base, rho in zip(basis.dims, basis.bases, basis.rho):
-        A = y[base * pts * cin:(base + d * d) * pts * cin].view(pts * d, d * cin)
-        What = torch.einsum('ock,kij->jcio', Wv, rho).reshape(d * cin, d * cout)   # sum_k W_k (x) rho(g_k)
-        outs.append(_MmFn.apply(A, What).reshape(-1))
-    return FromSpectralFn.apply(torch.cat(outs), basis, b, p, cout)
+    # What^rho[(j, c), (i, o)] = sum_k W[o, c, k] rho(g_k)[i, j]: one small GEMM for all blocks, then a re-layout each
+    wh_all = torch.mm(W.reshape(cout * cin, kn), basis.rho_all)              # [cout*cin, na]
+    whats = [wh_all[:, base:base + d * d].reshape(cout, cin, d, d).permute(3, 1, 2, 0).reshape(d * cin, d * cout)
+             for d, base in zip(basis.dims, basis.bases)]
+    z = _BlockGemmsFn.apply(y, basis, pts, cin, cout, *whats)
+    return FromSpectralFn.apply(z, basis, b, p, cout)
 
 
 def norm_act_supported(c):

@@ -1,0 +1,35 @@
+#!/usr/bin/env python3
+"""Per-call breakdown of one training step of the cls network (HIP events around every C-ABI call and library GEMM):
+which layer / shape costs what.  usage: tools/step_breakdown.py [substring filter]"""
+import collections
+import os
+import sys
+
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from epn_pointcloud_amd import models as M, schedule as S, ops  # noqa: E402
+
+flt = sys.argv[1] if len(sys.argv) > 1 else ""
+dev = torch.device("cuda", 0)
+model = M.ClsSO3ConvModel(S.cls_so3net_schedule(1024), out_mlps=(256,), pooling="attention").to(dev).train()
+pts = S.synthetic_clouds(32, 1024, dev)
+labels = torch.arange(32, device=dev) % 40
+
+
+def step():
+    torch.nn.functional.cross_entropy(model(pts)[0], labels).backward()
+
+
+step(); step(); torch.cuda.synchronize()
+ops.profile_begin(); step(); torch.cuda.synchronize()
+rec = ops.profile_end()
+agg, fam = collections.defaultdict(lambda: [0, 0.0]), collections.defaultdict(float)
+for kind, key, fl, e0, e1 in rec:
+    ms = e0.elapsed_time(e1)
+    k = (kind,) + tuple(key)[:8]
+    agg[k][0] += 1; agg[k][1] += ms; fam[kind] += ms
+print({k: round(v, 2) for k, v in sorted(fam.items(), key=lambda kv: -kv[1])}, "sum", round(sum(fam.values()), 1))
+for k, v in sorted(agg.items(), key=lambda kv: -kv[1][1]):
+    if flt in k[0]:
+        print(f"{v[1]:7.3f} ms x{v[0]}  {k}")
