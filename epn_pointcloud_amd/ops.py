@@ -825,6 +825,18 @@ class PointnetSO3ConvFn(torch.autograd.Function):
         return dF, None, None, dW, db
 
 
+_IDENT = {}
+
+
+def _identity_index(na, device):
+    """[na, 1] identity neighbour table, one tensor per (na, device): the tables derived from an index tensor are
+    cached per tensor."""
+    key = (na, str(device))
+    if key not in _IDENT:
+        _IDENT[key] = torch.arange(na, dtype=torch.int32, device=device).view(na, 1)
+    return _IDENT[key]
+
+
 def conv1x1(x, weight, bias=None):
     """nn.Conv2d(cin, cout, 1) on a [b,c,p,a] tensor, channels-last in and out with no layout copy.
     EPN_CONV1X1 = kernel (default): the intra GEMM kernel with a single, identity anchor neighbour;
@@ -837,9 +849,7 @@ def conv1x1(x, weight, bias=None):
             b, c, p, a = xc.shape
             y2d = torch.nn.functional.linear(xc.permute(0, 2, 3, 1).reshape(-1, c), weight.reshape(cout, cin), bias)
             return y2d.view(b, p, a, cout).permute(0, 3, 1, 2)
-        na = x.shape[3]
-        ident = torch.arange(na, dtype=torch.int32, device=x.device).view(na, 1)
-        y = IntraSO3ConvFn.apply(x, weight.reshape(cout, cin), ident)
+        y = IntraSO3ConvFn.apply(x, weight.reshape(cout, cin), _identity_index(x.shape[3], x.device))
     elif x.is_cuda and cin == 1:
         # single input channel (the occupancy feature of the first block): an outer product, written channels-last
         y = (to_cl(x).permute(0, 2, 3, 1) * weight.reshape(cout)).permute(0, 3, 1, 2)

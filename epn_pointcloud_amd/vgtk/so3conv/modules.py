@@ -138,9 +138,17 @@ class IntraSO3Conv(nn.Module):
         self.register_buffer('anchors', torch.from_numpy(anchors))
         self.register_buffer('intra_idx', torch.from_numpy(intra_idx).long())
 
+    def _idx32(self):
+        """int32 copy of the index buffer, made once per (buffer, device): the derived tables (inverse permutation,
+        block-diagonalising basis) are cached per tensor, and nothing is re-derived inside a captured graph."""
+        src = self.intra_idx
+        key = (src.data_ptr(), src._version, str(src.device))
+        if getattr(self, "_idx32_key", None) != key:
+            self._idx32_cache, self._idx32_key = src.int().contiguous(), key
+        return self._idx32_cache
+
     def forward(self, x):
-        idx32 = self.intra_idx.int()
-        feats = ops.intra_so3conv(x.feats, self.basic_conv.W, idx32)
+        feats = ops.intra_so3conv(x.feats, self.basic_conv.W, self._idx32())
         return SphericalPointCloud(x.xyz, feats, self.anchors)
 
 
