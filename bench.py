@@ -183,11 +183,13 @@ def main():
     # HIP graph and replayed: same kernels, same work, no per-launch host latency / inter-kernel bubbles.  Gradient
     # all-reduce and the Adam update stay outside the graph (identical path for every world size).
     launch, graph, static_loss = "eager", None, None
-    if not args.no_graph:
+    # single-process runs only: with a process group alive, RCCL's watchdog thread issues HIP calls of its own, which a
+    # capture in progress does not tolerate on every stack -- not worth 1 % to the multi-GPU runs
+    if not args.no_graph and world == 1:
         try:
             opt.zero_grad(set_to_none=True)      # gradients are (re)materialised inside the graph's memory pool
             graph = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(graph):
+            with torch.cuda.graph(graph, capture_error_mode="thread_local"):
                 static_loss = compute()
             launch = "hipgraph"
         except Exception as e:                   # capture is an optimisation, never a requirement
