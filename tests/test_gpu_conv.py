@@ -498,3 +498,36 @@ def test_split_and_fused_forms_agree_at_full_size(gpu, vgtk_alias):
     assert (y0 - y1).abs().max().item() < TOL * max(1.0, y0.abs().max().item())
     assert _rel(dW1, dW0) < TOL
     assert (dF0 - dF1).abs().max().item() < TOL * max(1.0, dF0.abs().max().item())
+
+
+def test_so3_basis_kernel_and_block_layout(gpu, vgtk_alias):
+    """epn_so3_basis_f32: U^T into the spectral layout (every irreducible block a dense [pts*d, d*c] matrix), U back;
+    against torch.einsum, plus the round trip (U orthogonal) and the tetrahedral table (12 anchors: not a group with
+    only real-type irreducibles of full multiplicity -> no spectral basis, callers keep the 12-neighbour forms)."""
+    from epn_pointcloud_amd import ops
+    from epn_pointcloud_amd.vgtk.so3conv import functional as L
+    idx32 = T(L.get_intra_idx()).int().to(gpu)
+    basis = ops.spectral_basis(idx32)
+    assert basis is not None and basis.dims == [1, 3, 3, 4, 5]
+    torch.manual_seed(4)
+    b, c, p = 2, 128, 37
+    x = torch.randn(b, c, p, 60, device=gpu).contiguous(memory_format=torch.channels_last).requires_grad_(True)
+    y = ops.ToSpectralFn.apply(x, basis)
+    pts = b * p
+    want = torch.einsum('af,qac->qfc', basis.U, x.detach().permute(0, 2, 3, 1).reshape(pts, 60, c))   # [pts, f, c]
+    for d, base in zip(basis.dims, basis.bases):
+        blk = y[base * pts * c:(base + d * d) * pts * c].view(pts, d * d, c)
+        assert (blk - want[:, base:base + d * d]).abs().max().item() < 1e-4
+    back = ops.FromSpectralFn.apply(y, basis, b, p, c)
+    assert (back - x).abs().max().item() < 1e-4
+    (gx,) = torch.autograd.grad(back, x, torch.ones_like(back))
+    assert (gx - 1.0).abs().max().item() < 1e-4                      # d(U U^T x)/dx = I
+    tet = [3, 4, 5, 27, 28, 29, 39, 40, 41, 48, 49, 50]
+    anchors = L.get_anchors(60)[tet]
+    # right-multiplication table of the 12-element subgroup by 4 of its own elements
+    tab = np.zeros((12, 4), dtype=np.int64)
+    for a in range(12):
+        for k, g in enumerate((1, 2, 5, 9)):
+            prod = anchors[a] @ anchors[g]
+            tab[a, k] = int(np.argmin([np.abs(prod - anchors[t]).max() for t in range(12)]))
+    assert ops.spectral_basis(T(tab).int().to(gpu)) is None
