@@ -531,3 +531,35 @@ def test_so3_basis_kernel_and_block_layout(gpu, vgtk_alias):
             prod = anchors[a] @ anchors[g]
             tab[a, k] = int(np.argmin([np.abs(prod - anchors[t]).max() for t in range(12)]))
     assert ops.spectral_basis(T(tab).int().to(gpu)) is None
+
+
+def test_intra_forms_agree_at_full_size(gpu, vgtk_alias):
+    """BASELINE configs[1] size (B=32, 512 points, 64 channels, A=60: 983 040 columns): the block-diagonal (spectral)
+    form, the split form and the fused kernels of IntraSO3Conv are three independent implementations; outputs and
+    both gradients must agree."""
+    from epn_pointcloud_amd import ops
+    from epn_pointcloud_amd.vgtk import so3conv as sptk
+    torch.manual_seed(2)
+    conv = sptk.IntraSO3Conv(64, 64).to(gpu)
+    idx32 = conv._idx32()
+    basis = ops.spectral_basis(idx32)
+    feats = torch.randn(32, 64, 512, 60, device=gpu).contiguous(memory_format=torch.channels_last)
+    W = conv.basic_conv.W.detach()
+    outs = []
+    for form in ("fused", "split", "spectral"):
+        f, w = feats.clone().requires_grad_(True), W.clone().requires_grad_(True)
+        if form == "fused":
+            y = ops.IntraSO3ConvFn.apply(f, w, idx32)
+        elif form == "split":
+            y = ops.IntraSO3ConvSplitFn.apply(f, w, idx32)
+        else:
+            y = ops.intra_so3conv_spectral(f, w, idx32, basis)
+        gy = torch.ones_like(y) * torch.linspace(-1, 1, 60, device=gpu)
+        dW, dF = torch.autograd.grad(y, [w, f], gy)
+        outs.append((y.detach(), dW, dF))
+        del y, gy
+    y0, dW0, dF0 = outs[0]
+    for y1, dW1, dF1 in outs[1:]:
+        assert (y0 - y1).abs().max().item() < TOL * max(1.0, y0.abs().max().item())
+        assert _rel(dW1, dW0) < TOL
+        assert (dF0 - dF1).abs().max().item() < TOL * max(1.0, dF0.abs().max().item())
