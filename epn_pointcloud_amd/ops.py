@@ -345,6 +345,16 @@ class InterSO3ConvSplitFn(torch.autograd.Function):
         return gf, gW, None
 
 
+_SIDE = {}
+
+
+def _side_stream(device):
+    key = str(torch.device(device))
+    if key not in _SIDE:
+        _SIDE[key] = torch.cuda.Stream(device=device)
+    return _SIDE[key]
+
+
 _INV_CACHE = {}
 
 

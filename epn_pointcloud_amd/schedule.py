@@ -133,17 +133,36 @@ class FusedSeparableBlock(SeparableBlock):
         c_out = self.intra_conv.conv.dim_out
         if (not self.training) or self.dropout is not None or not ops.norm_act_supported(c_out):
             return super().forward(x, inter_idx, inter_w)
+        import os
         skip = x.feats
         inter_idx, inter_w, sample_idx, y = self.inter_conv.conv(x, inter_idx, inter_w)
+
+        def skip_branch():
+            sk = skip
+            if self.stride > 1:                                    # batched_index_select(skip, 2, sample_idx) on rows
+                s_cl = ops.to_cl(sk).permute(0, 2, 3, 1)           # [b,p1,a,c] view of the channels-last image
+                b, p1, a, c = s_cl.shape
+                idx = sample_idx.long().view(b, -1, 1).expand(-1, -1, a * c)
+                sk = torch.gather(s_cl.reshape(b, p1, a * c), 1, idx).view(b, -1, a, c).permute(0, 3, 1, 2)
+            sk = ops.conv1x1(sk, self.skip_conv.weight, None)       # the norm cancels the bias: see ops.norm_act
+            return ops.norm_act(sk, self.norm, conv_bias=self.skip_conv.bias)
+
+        side = None
+        if os.environ.get("EPN_SKIP_STREAM", "1") == "1" and skip.is_cuda:
+            # the skip branch (row gather, 1x1 conv, norm: small HBM-bound kernels) is independent of the main branch
+            # until the final add: issue it on a second stream so it can fill in under the GEMMs
+            main = torch.cuda.current_stream(skip.device)
+            side = ops._side_stream(skip.device)
+            side.wait_stream(main)
+            with torch.cuda.stream(side):
+                s = skip_branch()
         feat = ops.norm_act(y.feats, self.inter_conv.norm)
         z = self.intra_conv.conv(zptk.SphericalPointCloud(y.xyz, feat, y.anchors))
-        if self.stride > 1:                                    # batched_index_select(skip, 2, sample_idx) on rows
-            s_cl = ops.to_cl(skip).permute(0, 2, 3, 1)           # [b,p1,a,c] view of the channels-last image
-            b, p1, a, c = s_cl.shape
-            idx = sample_idx.long().view(b, -1, 1).expand(-1, -1, a * c)
-            skip = torch.gather(s_cl.reshape(b, p1, a * c), 1, idx).view(b, -1, a, c).permute(0, 3, 1, 2)
-        s = ops.conv1x1(skip, self.skip_conv.weight, None)           # the norm cancels the bias: see ops.norm_act
-        s = ops.norm_act(s, self.norm, conv_bias=self.skip_conv.bias)
+        if side is None:
+            s = skip_branch()
+        else:
+            main.wait_stream(side)
+            s.record_stream(main)
         out = ops.norm_act(z.feats, self.intra_conv.norm, residual=s)   # leaky(IN(z)) + skip in the same pass
         return inter_idx, inter_w, sample_idx, zptk.SphericalPointCloud(z.xyz, out, z.anchors)
 
