@@ -131,7 +131,9 @@ def test_initial_anchor_query_vs_oracle(gpu, vgtk_alias, b, nc, m, na, ks, radiu
     from oracle import index_ref
     rng = np.random.default_rng(m + nc)
     centers = torch.from_numpy(unit_ball_cloud(rng, b, nc))
-    frag = torch.from_numpy(np.ascontiguousarray(unit_ball_cloud(rng, 1, m)[0].T))        # [m, 3]
+    frag = torch.from_numpy(rng.uniform(-0.6, 0.6, (m, 3)).astype(np.float32))              # [m, 3]
+    if m == 1:
+        frag[0] = centers[0, :, 0] + 0.05                                                  # inside the first ball
     kp = torch.from_numpy((rng.standard_normal((ks, na, 3)) * 0.2).astype(np.float32))
     w_ref, c_ref = index_ref.initial_anchor_query(centers, frag, kp, radius, sigma)
     w, c = cuda_nn.initial_anchor_query(centers.to(gpu), frag.to(gpu), kp.to(gpu), radius, sigma)
