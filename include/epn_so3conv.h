@@ -229,6 +229,27 @@ int epn_pointnet_so3conv_bwd_weight_f32(const float *grad_out, const int32_t *ar
                                         const float *xyz, const float *anchors, const float *centre, float *grad_W,
                                         float *grad_bias, int b, int p, int a, int c, int co, epn_stream_t stream);
 
+/* ---------------------------------------------------------------------------------------------------------------------
+ * vgtk.cuda.zpconv: grouping functions of the legacy ZPConv path (unreachable from the shipped models,
+ * provided for API completeness).  Layouts are the reference's (channel-major, contiguous).
+ * replaces inter_zpconv_forward / inter_zpconv_backward / intra_zpconv_forward / intra_zpconv_backward
+ * (vgtk/vgtk/cuda/zpconv_cuda.cpp:41-112; kernels zpconv_cuda_kernel.cu:33-195).
+ *   inter: anchor_neighbors i32[b][np][na][ks][ann], anchor_weights f32 (same shape), feats f32[b][c][nq][na]
+ *          anchor_feats f32[b][c][ks][np][na] = sum_ni feats[b][c][nbr][a] * w      (forward: gather, no atomics)
+ *          grad_feats   f32[b][c][nq][na]  (zero-filled here, fp32 atomic scatter)
+ *   intra: anchor_neighbors i32[na_out][ann], anchor_weights f32[na_out][ks][ann], feats f32[b][c][np][na_in]
+ *          anchor_feats f32[b][c][ks][np][na_out];  grad_feats f32[b][c][np][na_in]
+ * Indices outside [0, nq) / [0, na_in) contribute nothing (the reference reads out of bounds). */
+int epn_zp_inter_fwd_f32(const int32_t *anchor_neighbors, const float *anchor_weights, const float *feats, int b, int c,
+                         int np, int nq, int na, int ks, int ann, float *anchor_feats, epn_stream_t stream);
+int epn_zp_inter_bwd_f32(const int32_t *anchor_neighbors, const float *anchor_weights, const float *grad_anchor_feats,
+                         int b, int c, int np, int nq, int na, int ks, int ann, float *grad_feats, epn_stream_t stream);
+int epn_zp_intra_fwd_f32(const int32_t *anchor_neighbors, const float *anchor_weights, const float *feats, int b, int c,
+                         int np, int na_in, int na_out, int ks, int ann, float *anchor_feats, epn_stream_t stream);
+int epn_zp_intra_bwd_f32(const int32_t *anchor_neighbors, const float *anchor_weights, const float *grad_anchor_feats,
+                         int b, int c, int np, int na_in, int na_out, int ks, int ann, float *grad_feats,
+                         epn_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

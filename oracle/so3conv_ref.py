@@ -156,3 +156,29 @@ def pointnet_so3conv(xyz, feats, anchors, weight, bias):
         ext = torch.einsum('aji,bjn->bina', anchors, xyz)
     z = torch.nn.functional.conv2d(torch.cat([feats, ext], 1), weight.reshape(weight.shape[0], -1, 1, 1), bias)
     return z.max(2)[0]
+
+
+# ---------------------------------------------------------------- legacy ZPConv grouping (vgtk.cuda.zpconv)
+def zp_inter_forward(nbr, w, feats):
+    """spherical_conv_forward_cuda_kernel, vgtk/vgtk/cuda/zpconv_cuda_kernel.cu:33-72 (wrapper zpconv_cuda.cpp:41-56):
+    out[b,c,k,p,a] = sum_ni feats[b,c,nbr[b,p,a,k,ni],a] * w[b,p,a,k,ni].  Differentiable (autograd = the backward
+    kernel :75-116)."""
+    b, npts, na, ks, ann = nbr.shape
+    nq = feats.shape[2]
+    valid = ((nbr >= 0) & (nbr < nq)).to(feats.dtype)
+    idx = nbr.long().clamp(0, nq - 1)
+    f = feats.permute(0, 3, 2, 1)                                                   # [b, a, q, c]
+    bi = torch.arange(b)[:, None, None, None, None]
+    ai = torch.arange(na)[None, None, :, None, None]
+    g = f[bi, ai, idx]                                                              # [b, p, a, k, ni, c]
+    out = (g * (w * valid)[..., None]).sum(4)                                       # [b, p, a, k, c]
+    return out.permute(0, 4, 3, 1, 2).contiguous()
+
+
+def zp_intra_forward(nbr, w, feats):
+    """intraspherical_conv_forward_cuda_kernel, zpconv_cuda_kernel.cu:119-155 (wrapper zpconv_cuda.cpp:77-93):
+    out[b,c,k,p,ao] = sum_ni feats[b,c,p,nbr[ao,ni]] * w[ao,k,ni]."""
+    na_in = feats.shape[3]
+    valid = ((nbr >= 0) & (nbr < na_in)).to(feats.dtype)
+    g = feats[..., nbr.long().clamp(0, na_in - 1)]                                  # [b, c, p, ao, ni]
+    return torch.einsum('bcpan,akn->bckpa', g, w * valid[:, None, :]).contiguous()

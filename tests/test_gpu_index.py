@@ -160,3 +160,39 @@ def test_kernel_propagation_module(gpu, vgtk_alias):
     g = (w / (c + 1.0)).unsqueeze(1)                                         # [b, 1, ks, nc, na]
     want = torch.matmul(mod.basic_conv.W.detach().cpu(), g.reshape(2, 24, 16 * 60)).view(2, 8, 16, 60)
     assert (y.feats.detach().cpu() - want).abs().max().item() < 1e-4 * max(1.0, want.abs().max().item())
+
+
+def test_legacy_zpconv_grouping_functions(gpu, vgtk_alias):
+    """vgtk.cuda.zpconv.{inter,intra}_zpconv_{forward,backward} (zpconv_cuda.cpp:41-112) against the oracle's
+    restatement and its autograd; out-of-range neighbour indices contribute nothing."""
+    import vgtk.cuda.zpconv as zp
+    from oracle import so3conv_ref as R
+    torch.manual_seed(8)
+    b, c, npts, nq, na, ks, ann = 2, 5, 9, 14, 12, 3, 4
+    nbr = torch.randint(0, nq, (b, npts, na, ks, ann), dtype=torch.int32)
+    nbr[0, 0, 0, 0, 0] = nq                    # a shadow / out-of-range slot
+    w = torch.rand(b, npts, na, ks, ann)
+    feats = torch.randn(b, c, nq, na, requires_grad=True)
+    want = R.zp_inter_forward(nbr, w, feats)
+    gy = torch.randn_like(want)
+    (dwant,) = torch.autograd.grad(want, feats, gy)
+    got = zp.inter_zpconv_forward(nbr.to(gpu), w.to(gpu), feats.detach().to(gpu))
+    assert tuple(got.shape) == (b, c, ks, npts, na)
+    assert (got.cpu() - want.detach()).abs().max().item() < 1e-5
+    dgot = zp.inter_zpconv_backward(nbr.to(gpu), w.to(gpu), gy.to(gpu), nq)
+    assert tuple(dgot.shape) == (b, c, nq, na)
+    assert (dgot.cpu() - dwant).abs().max().item() < 1e-4
+
+    na_in, na_out = 12, 20
+    inbr = torch.randint(0, na_in, (na_out, ann), dtype=torch.int32)
+    iw = torch.rand(na_out, ks, ann)
+    f2 = torch.randn(b, c, npts, na_in, requires_grad=True)
+    want = R.zp_intra_forward(inbr, iw, f2)
+    gy = torch.randn_like(want)
+    (dwant,) = torch.autograd.grad(want, f2, gy)
+    got = zp.intra_zpconv_forward(inbr.to(gpu), iw.to(gpu), f2.detach().to(gpu))
+    assert tuple(got.shape) == (b, c, ks, npts, na_out)
+    assert (got.cpu() - want.detach()).abs().max().item() < 1e-5
+    dgot = zp.intra_zpconv_backward(inbr.to(gpu), iw.to(gpu), gy.to(gpu), na_in)
+    assert tuple(dgot.shape) == (b, c, npts, na_in)
+    assert (dgot.cpu() - dwant).abs().max().item() < 1e-4

@@ -158,3 +158,16 @@ def test_initial_anchor_query_oracle_properties():
     d2 = ((K - X[:, None, :, None]) ** 2).sum(-1)                            # [b, ks, nc, na, m]
     ww = np.maximum(1.0 - d2 / 0.1, 0.0) * inside[:, None, :, None, :]
     assert np.allclose(w.numpy(), ww.sum(-1), atol=1e-4)
+
+
+def test_legacy_zpconv_oracle_against_reference_naive_golden():
+    """The oracle's restatement of the legacy CUDA grouping kernel, specialised to neighbour lists that do not depend on
+    (anchor, kernel point), must reproduce the reference's own torch implementation inter_zpconv_grouping_naive
+    (tests/golden/inter_group.npz was generated from it)."""
+    g = golden("inter_group.npz")
+    idx, w, feats = T(g["idx"]), T(g["w"]), T(g["feats"])
+    b, p2, nn = idx.shape
+    na, ks = w.shape[2], w.shape[3]
+    nbr = idx[:, :, None, None, :].expand(b, p2, na, ks, nn).contiguous()
+    out = R.zp_inter_forward(nbr, w.contiguous(), feats)
+    assert torch.allclose(out, T(g["G"]), atol=1e-4)
