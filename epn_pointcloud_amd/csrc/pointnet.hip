@@ -109,6 +109,122 @@ __global__ __launch_bounds__(PN_T) void pointnet_fwd_kernel(PnArgs A) {
     }
 }
 
+// MFMA form of the forward pass (c % 16 == 0): workgroup = (cloud, anchor) x 128 output channels, 4 waves x 32 channels.
+// The [64 points x c] feature slab is the A operand straight from global memory (one 16-byte load per lane covers the
+// four contraction steps k = 16s + 4j + t), W^T comes through LDS in 64-channel chunks with the same k mapping, the
+// three coordinate channels and the bias are added on the VALU, and the max / arg-max over points is a register scan
+// plus two cross-lane steps.  Same result as the VALU kernel up to fp32 summation order.
+__global__ __launch_bounds__(256) void pointnet_fwd_mfma_kernel(PnArgs A) {
+    constexpr int KC = 64, WLD = KC + 4;
+    __shared__ __attribute__((aligned(16))) float Ws[128 * WLD];     // [output channel][channel of the chunk]
+    __shared__ float Es[64][4];
+    __shared__ float ctr_s[3];
+    const int t = threadIdx.x, lane = t & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
+    const int x = lane & 15, j = lane >> 4;
+    const int bb = blockIdx.x / A.a, ai = blockIdx.x % A.a;
+    const int co0 = blockIdx.y * 128;
+    const int ce = A.c + 3;
+    if (t < 3) {
+        const float *s = A.xyz + ((size_t)bb * 3 + t) * A.p;
+        float m = 0.f;
+        for (int i = 0; i < A.p; ++i) m += s[i];
+        m /= (float)A.p;
+        ctr_s[t] = m;
+        if (ai == 0 && blockIdx.y == 0) A.centre[bb * 3 + t] = m;
+    }
+    __syncthreads();
+    const float ctr[3] = {ctr_s[0], ctr_s[1], ctr_s[2]};
+    // this lane's output channels: co0 + 32 wave + 16 nt + x
+    float w3[2][3], bias[2];
+    bool cok[2];
+#pragma unroll
+    for (int nt = 0; nt < 2; ++nt) {
+        const int o = co0 + 32 * wave + 16 * nt + x;
+        cok[nt] = o < A.co;
+        const int oo = cok[nt] ? o : 0;
+#pragma unroll
+        for (int u = 0; u < 3; ++u) w3[nt][u] = cok[nt] ? A.W[(size_t)oo * ce + A.c + u] : 0.f;
+        bias[nt] = (cok[nt] && A.bias) ? A.bias[oo] : 0.f;
+    }
+    float best[2] = {-INFINITY, -INFINITY};
+    int bestp[2] = {0, 0};
+    const float *fb = A.feats + ((size_t)bb * A.p * A.a + ai) * A.c;      // + p * a * c
+    for (int p0 = 0; p0 < A.p; p0 += 64) {
+        __syncthreads();
+        if (t < 64) {
+            float e[3] = {0.f, 0.f, 0.f};
+            if (p0 + t < A.p) ext_xyz(A, bb, ai, p0 + t, ctr, e);
+            Es[t][0] = e[0]; Es[t][1] = e[1]; Es[t][2] = e[2];
+        }
+        f32x4 acc[4][2];
+#pragma unroll
+        for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+            for (int nt = 0; nt < 2; ++nt) acc[mt][nt] = f32x4{0.f, 0.f, 0.f, 0.f};
+        const float *frow[4];
+#pragma unroll
+        for (int mt = 0; mt < 4; ++mt) {
+            int pp = p0 + 16 * mt + x;
+            pp = pp < A.p ? pp : A.p - 1;                                   // masked below (acc -> -inf)
+            frow[mt] = fb + (size_t)pp * A.a * A.c + 4 * j;
+        }
+        for (int c0 = 0; c0 < A.c; c0 += KC) {
+            const int cc = min(KC, A.c - c0);                                // multiple of 16 (launcher)
+            __syncthreads();
+            for (int e = t; e < 128 * KC; e += 256) {
+                const int cl = e % KC, ol = e / KC;
+                const int o = co0 + ol;
+                Ws[ol * WLD + cl] = (cl < cc && o < A.co) ? A.W[(size_t)o * ce + c0 + cl] : 0.f;
+            }
+            __syncthreads();
+            for (int s16 = 0; s16 < cc; s16 += 16) {
+                f32x4 af[4], bf[2];
+#pragma unroll
+                for (int mt = 0; mt < 4; ++mt) af[mt] = *reinterpret_cast<const f32x4 *>(frow[mt] + c0 + s16);
+#pragma unroll
+                for (int nt = 0; nt < 2; ++nt)
+                    bf[nt] = *reinterpret_cast<const f32x4 *>(Ws + (32 * wave + 16 * nt + x) * WLD + s16 + 4 * j);
+#pragma unroll
+                for (int u = 0; u < 4; ++u)
+#pragma unroll
+                    for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+                        for (int nt = 0; nt < 2; ++nt)
+                            acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[mt][u], bf[nt][u], acc[mt][nt], 0, 0, 0);
+            }
+        }
+        // acc[mt][nt][r]: point p0 + 16 mt + 4 j + r, channel co0 + 32 wave + 16 nt + x
+#pragma unroll
+        for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int pl = 16 * mt + 4 * j + r;
+                const float e0 = Es[pl][0], e1 = Es[pl][1], e2 = Es[pl][2];
+#pragma unroll
+                for (int nt = 0; nt < 2; ++nt) {
+                    const float v = acc[mt][nt][r] + bias[nt] + w3[nt][0] * e0 + w3[nt][1] * e1 + w3[nt][2] * e2;
+                    if (p0 + pl < A.p && v > best[nt]) { best[nt] = v; bestp[nt] = p0 + pl; }   // ascending p: first max
+                }
+            }
+    }
+    // combine the four lane groups j (disjoint point sets): larger value wins, ties go to the smaller point index
+#pragma unroll
+    for (int nt = 0; nt < 2; ++nt) {
+#pragma unroll
+        for (int d = 16; d < 64; d <<= 1) {
+            const float ov = __shfl_xor(best[nt], d, 64);
+            const int op = __shfl_xor(bestp[nt], d, 64);
+            if (ov > best[nt] || (ov == best[nt] && op < bestp[nt])) { best[nt] = ov; bestp[nt] = op; }
+        }
+        if (j == 0 && cok[nt]) {
+            const size_t at = ((size_t)bb * A.a + ai) * A.co + co0 + 32 * wave + 16 * nt + x;
+            A.out[at] = best[nt];
+            A.arg[at] = bestp[nt];
+        }
+    }
+}
+
 // dF[b,p,a,c] = sum_{o : arg[b,a,o] == p} dOut[b,a,o] * W[o][c];  workgroup = (cloud, anchor) x 128-channel block,
 // thread = channel, the point tile accumulates in LDS in output-channel order (deterministic, no atomics).
 __global__ __launch_bounds__(PN_T) void pointnet_bwd_data_kernel(PnArgs A) {
@@ -194,8 +310,12 @@ extern "C" int epn_pointnet_so3conv_fwd_f32(const float *feats_cl, const float *
     PnArgs A = make_pn(b, p, a, c, co);
     A.feats = feats_cl; A.xyz = xyz; A.anchors = anchors; A.W = W; A.bias = bias; A.out = out; A.arg = argmax;
     A.centre = centre;
-    hipLaunchKernelGGL(pointnet_fwd_kernel, dim3((unsigned)(b * a), (unsigned)epn_cdiv(co, PN_T)), dim3(PN_T), 0,
-                       epn_stream(stream), A);
+    if (c % 16 == 0)
+        hipLaunchKernelGGL(pointnet_fwd_mfma_kernel, dim3((unsigned)(b * a), (unsigned)epn_cdiv(co, 128)), dim3(256), 0,
+                           epn_stream(stream), A);
+    else
+        hipLaunchKernelGGL(pointnet_fwd_kernel, dim3((unsigned)(b * a), (unsigned)epn_cdiv(co, PN_T)), dim3(PN_T), 0,
+                           epn_stream(stream), A);
     EPN_CHECK_LAUNCH();
     return 0;
 }
