@@ -2,6 +2,8 @@
 # Re-record epn_pointcloud_amd/gemm_tuning_gfx950.csv on an MI355X (about 10 minutes: every GEMM shape of the cls
 # B=32 step is timed against all rocBLAS / hipBLASLt solutions during bench.py's warm-up):
 #   gpurun --timeout 1500 -- 'bash tools/tune_gemms.sh'     -> gpurun_out/tunableop0.csv, copy it over the in-tree file
+# CAUTION: every NEW GEMM shape is timed against every library solution; shapes with a ~1e6-long contraction take
+# minutes each (a run that added the 1x1 skip-convolution weight gradients exceeded 30 minutes) -- always bound the call.
 set -e
 R=$(cd "$(dirname "$0")/.." && pwd)
 mkdir -p $R/gpurun_out
