@@ -280,6 +280,7 @@ def main():
                                    + f", B={args.batch}/GPU N={args.points} K={'/'.join(str(k) for k in sorted({l.nn for l in layers}, reverse=True))} "
                                    + f"A=60 fp32, {'fwd' if args.forward_only else 'fwd+bwd+Adam'}",
                        "global_batch": args.batch * world, "points": args.points, "anchors": 60, "launch": launch,
+                       "hbm_peak_gb": round(torch.cuda.max_memory_allocated(dev) / 2 ** 30, 1),
                        "parallelism": f"dp{world}"},
             "roofline": roofline,
         }
