@@ -146,9 +146,12 @@ __global__ __launch_bounds__(64 * NW) void intra_bwd_weight_v4_kernel(IntraArgs 
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int x = lane & 15, j = lane >> 4;
-    const int k = blockIdx.y * NW + wave;
     const int cblocks = A.ci / 64;
     const int o0 = (blockIdx.z / cblocks) * 64, c0 = (blockIdx.z % cblocks) * 64;
+    // one wave per anchor neighbour; with a single neighbour (the 1x1 skip convolution) the four waves split the
+    // workgroup's column tiles instead of three of them idling
+    const bool single = A.kn == 1;
+    const int k = single ? 0 : blockIdx.y * NW + wave;
     if (k >= A.kn) return;  // no barriers in this kernel
 
     f32x4 acc[4][4];
@@ -158,24 +161,27 @@ __global__ __launch_bounds__(64 * NW) void intra_bwd_weight_v4_kernel(IntraArgs 
         for (int n = 0; n < 4; ++n) acc[m][n] = f32x4{0.f, 0.f, 0.f, 0.f};
 
     const long long t0 = (long long)blockIdx.x * A.col_tiles_per_wg;
-    for (int it = 0; it < A.col_tiles_per_wg; ++it) {
+    for (int it = single ? wave : 0; it < A.col_tiles_per_wg; it += single ? NW : 1) {
         const long long c_base = (t0 + it) * 16;
         if (c_base >= A.ncol) break;
+        f32x4 af[4], bf[4];
 #pragma unroll
-        for (int s = 0; s < 4; ++s) {
+        for (int s = 0; s < 4; ++s) {      // all eight 16-byte loads of the tile in flight before the first MFMA
             const long long col = c_base + 4 * s + j;
             const bool ok = col < A.ncol;
             const long long cc = ok ? col : A.ncol - 1;
             const int a = (int)(cc % A.na);
             const long long src = cc - a + A.idx[a * A.kn + k];
-            f32x4 af = *reinterpret_cast<const f32x4 *>(A.gout + cc * A.co + o0 + 4 * x);
-            const f32x4 bf = *reinterpret_cast<const f32x4 *>(A.X + src * A.ci + c0 + 4 * x);
-            if (!ok) af = f32x4{0.f, 0.f, 0.f, 0.f};
+            af[s] = *reinterpret_cast<const f32x4 *>(A.gout + cc * A.co + o0 + 4 * x);
+            bf[s] = *reinterpret_cast<const f32x4 *>(A.X + src * A.ci + c0 + 4 * x);
+            if (!ok) af[s] = f32x4{0.f, 0.f, 0.f, 0.f};
+        }
+#pragma unroll
+        for (int s = 0; s < 4; ++s)
 #pragma unroll
             for (int m = 0; m < 4; ++m)
 #pragma unroll
-                for (int n = 0; n < 4; ++n) acc[m][n] = mfma4(af[m], bf[n], acc[m][n]);
-        }
+                for (int n = 0; n < 4; ++n) acc[m][n] = mfma4(af[s][m], bf[s][n], acc[m][n]);
     }
     // acc[m][n]: lane (x, j), register r -> o = o0 + 4*(4j + r) + m,  c = c0 + 4x + n
 #pragma unroll
@@ -373,6 +379,8 @@ int launch_intra_bwd_weight_mfma(const float *feats, const float *dOut, const in
     const int kblocks = (kn + NW - 1) / NW;
     const int tblocks = ((cout + 63) / 64) * ((cin + 63) / 64);
     long long splits = (256 * 4 + kblocks * tblocks - 1) / (kblocks * tblocks);
+    if (kn == 1) splits = (splits + NW - 1) / NW;   // all four waves of a workgroup work on the single neighbour: same
+                                                    // number of partial results (final atomics) as one wave per workgroup
     if (splits > tiles) splits = tiles;
     if (splits < 1) splits = 1;
     A.col_tiles_per_wg = (int)((tiles + splits - 1) / splits);
