@@ -23,6 +23,8 @@ EXPORTS = [
     "epn_inter_group_workspace_bytes", "epn_inter_group_f32", "epn_inter_ungroup_f32", "epn_intra_group_f32", "epn_so3_basis_f32",
     "epn_zp_inter_fwd_f32", "epn_zp_inter_bwd_f32", "epn_zp_intra_fwd_f32", "epn_zp_intra_bwd_f32",
     "epn_pointnet_so3conv_fwd_f32", "epn_pointnet_so3conv_bwd_data_f32", "epn_pointnet_so3conv_bwd_weight_f32",
+    "epn_gemm_nt_f32", "epn_gemm_nt_bf16", "epn_gemm_tn_workspace_bytes", "epn_gemm_tn_f32", "epn_gemm_tn_bf16",
+    "epn_transpose_cast", "epn_cast",
 ]
 
 _vp, _ci, _cf, _sz = ctypes.c_void_p, ctypes.c_int, ctypes.c_float, ctypes.c_size_t
@@ -33,6 +35,12 @@ class InterDesc(ctypes.Structure):
     _fields_ = [("xyz", _vp), ("new_xyz", _vp), ("ball_idx", _vp), ("anchors", _vp), ("kernels", _vp),
                 ("dense_w", _vp), ("sigma", _cf), ("b", _ci), ("p1", _ci), ("p2", _ci), ("nn", _ci),
                 ("na", _ci), ("ks", _ci), ("cin", _ci), ("cout", _ci)]
+
+
+class GemmNtProblem(ctypes.Structure):
+    """struct epn_gemm_nt_problem (include/epn_so3conv.h)."""
+    _fields_ = [("A", _vp), ("Bt", _vp), ("C", _vp), ("M", ctypes.c_longlong), ("lda", ctypes.c_longlong),
+                ("ldb", ctypes.c_longlong), ("ldc", ctypes.c_longlong), ("N", _ci), ("K", _ci)]
 
 
 _lib = None
@@ -90,10 +98,19 @@ def get_lib():
     lib.epn_norm_act_bwd_reduce_f32.argtypes = [_vp, _vp, _ci, _ll, _ci, _vp, _vp, _vp, _cf, _cf, _vp, _vp, _vp, _vp,
                                                 _sz, _vp]
     lib.epn_norm_act_bwd_apply_f32.argtypes = [_vp, _vp, _ci, _ll, _ci, _vp, _vp, _vp, _vp, _cf, _cf, _vp, _vp]
+    gp = ctypes.POINTER(GemmNtProblem)
+    lib.epn_gemm_nt_f32.argtypes = [_ci, gp, _vp]
+    lib.epn_gemm_nt_bf16.argtypes = [_ci, gp, _ci, _vp]
+    lib.epn_gemm_tn_workspace_bytes.argtypes = [_ci, _ll, _ci, _ci]
+    lib.epn_gemm_tn_f32.argtypes = [_vp, _ll, _vp, _ll, _vp, _ll, _ll, _ci, _ci, _vp, _sz, _vp]
+    lib.epn_gemm_tn_bf16.argtypes = [_vp, _ll, _vp, _ll, _vp, _ll, _ll, _ci, _ci, _vp, _sz, _vp]
+    lib.epn_transpose_cast.argtypes = [_vp, _vp, _ci, _ci, _ci, _ci, _vp]
+    lib.epn_cast.argtypes = [_vp, _vp, _sz, _ci, _ci, _vp]
     for name in EXPORTS:
         getattr(lib, name)  # AttributeError here = header/library mismatch
-        if name.endswith("_f32"):
+        if name.endswith("_f32") or name.endswith("_bf16") or name in ("epn_transpose_cast", "epn_cast"):
             getattr(lib, name).restype = _ci
+    lib.epn_gemm_tn_workspace_bytes.restype = _sz
     _lib = lib
     return lib
 

@@ -1,0 +1,41 @@
+// Internal interface of gemm.hip (the BasicSO3Conv weight contractions as MFMA GEMMs).
+#pragma once
+#include "epn_common.h"
+
+namespace epn {
+
+constexpr int GEMM_MAX_PROB = 6;   // problems per grouped NT launch (the five irreducible blocks of IntraSO3Conv + 1)
+
+struct GemmNtProb {        // C[M][N] = A[M][K] . Bt[N][K]^T
+    const void *A, *Bt;
+    void *C;
+    long long M, lda, ldb, ldc;
+    int N, K;
+    int tiles_n;           // filled by the launcher
+    unsigned tile0;        // first tile id of this problem inside the grouped launch
+};
+struct GemmNtBatch {
+    int nprob;
+    unsigned ntiles;
+    GemmNtProb p[GEMM_MAX_PROB];
+};
+
+struct GemmTnArgs {        // C[N1][N2] = X[R][N1]^T . Y[R][N2]
+    const void *X, *Y;
+    void *C, *part;        // part: split partials [nsplit][N1][N2] fp32 (workspace)
+    size_t part_bytes;
+    long long R, ldx, ldy, ldc;
+    int N1, N2;
+    unsigned ntiles;
+    int tiles_n2, nsplit;
+};
+
+// dtype / out_dtype: 0 = fp32, 1 = bf16
+int launch_gemm_nt(GemmNtBatch &B, int dtype, int out_dtype, hipStream_t st);
+int launch_gemm_tn(GemmTnArgs &G, int dtype, hipStream_t st);
+void gemm_tn_tile(bool bf16, int N1, int N2, int *bn1, int *bn2);
+int gemm_tn_splits(bool bf16, long long R, int N1, int N2);
+int launch_transpose_cast(const void *src, void *dst, int rows, int cols, int src_bf16, int dst_bf16, hipStream_t st);
+int launch_cast(const void *src, void *dst, size_t n, int src_bf16, int dst_bf16, hipStream_t st);
+
+}  // namespace epn

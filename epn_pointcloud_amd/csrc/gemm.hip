@@ -1,0 +1,686 @@
+// Weight contractions of BasicSO3Conv (vgtk/vgtk/so3conv/modules.py:48-55: `W @ feats.view(b, c*ks, p*a)`) and of its
+// autograd transposes, as hand-written MFMA GEMMs for gfx950 -- round 1 handed these to the BLAS library.
+//
+//   NT   C[M][N]   = A[M][K] . Bt[N][K]^T      activation x weight: out = G W^T, dG = dOut (W^T)^T, the spectral blocks
+//   TN   C[N1][N2] = X[R][N1]^T . Y[R][N2]     weight gradients: dW = dOut^T G (contraction over the R = b*p*a columns)
+//
+// Both stream 128-byte row segments through a double-buffered LDS ring with direct-to-LDS loads
+// (global_load_lds_dwordx4, one 1 KiB wave instruction = 8 row segments), one barrier per K step.  The NT image is
+// XOR-swizzled on the SOURCE address (16-byte slot ^ ((row >> 1) & 7)) so that the ds_read_b128 fragment reads are
+// bank-conflict free (cdna_hip_programming.md T2 / rule 21); the TN image is read along its rows and needs none.
+// fp32 uses v_mfma_f32_32x32x2_f32 (exact f32, 64 FLOP/clk/SIMD): one ds_read_b128 per operand tile feeds FOUR MFMAs
+// because the contraction index may be visited in any order as long as both operands agree (lane group j of a step
+// holds k = 8s + 4j .. +3).  bf16 uses v_mfma_f32_32x32x16_bf16 (NT, one b128 = one operand) and
+// v_mfma_f32_16x16x32_bf16 fed by ds_read_b64_tr_b16 transposed reads (TN), fp32 accumulation throughout.
+#include "conv_internal.h"
+#include "gemm.h"
+
+namespace epn {
+namespace {
+
+typedef __attribute__((address_space(3))) void lds_void;
+typedef __attribute__((address_space(1))) const void glb_void;
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+typedef short s16x4 __attribute__((ext_vector_type(4)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+
+template <typename T> struct ElemOf;
+template <> struct ElemOf<float> { static constexpr int PER16 = 4; };
+template <> struct ElemOf<__bf16> { static constexpr int PER16 = 8; };
+
+__device__ __forceinline__ void glds16(const void *g, char *lds_wave_base) {
+    __builtin_amdgcn_global_load_lds((glb_void *)g, (lds_void *)lds_wave_base, 16, 0, 0);
+}
+
+__device__ __forceinline__ void store_out(float *p, float v) { *p = v; }
+__device__ __forceinline__ void store_out(__bf16 *p, float v) { *p = (__bf16)v; }
+
+// ------------------------------------------------------------------------------------------------ NT
+// Block tile BM x BN = (WGM*TM*32) x (WGN*TN*32), WGM*WGN waves, each wave TM x TN MFMA tiles of 32x32.
+// K step = 128 bytes of a row (32 floats / 64 bf16).
+template <typename T, typename TO, int WGM, int WGN, int TM, int TN>
+__global__ __launch_bounds__(64 * WGM * WGN) void gemm_nt_kernel(GemmNtBatch B) {
+    constexpr int NW = WGM * WGN;
+    constexpr int BM = WGM * TM * 32, BN = WGN * TN * 32;
+    constexpr int ROWS = BM + BN;                  // LDS rows per stage (A rows, then Bt rows), 128 B each
+    constexpr int NG = ROWS / 8;                   // 8-row groups = wave-level load instructions per stage
+    constexpr int GPW = (NG + NW - 1) / NW;        // groups per wave
+    constexpr int E16 = ElemOf<T>::PER16;          // elements per 16-byte slot
+    constexpr int BKE = 8 * E16;                   // elements per K step
+    __shared__ __attribute__((aligned(1024))) char smem[2 * ROWS * 128];
+
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    // ---- which problem / tile
+    unsigned t = epn_xcd_tile(blockIdx.x, B.ntiles);
+    int pi = 0;
+#pragma unroll
+    for (int i = 1; i < GEMM_MAX_PROB; ++i)
+        if (i < B.nprob && t >= B.p[i].tile0) pi = i;
+    const GemmNtProb &P = B.p[pi];
+    t -= P.tile0;
+    const long long m0 = (long long)(t / P.tiles_n) * BM;
+    const int n0 = (int)(t % P.tiles_n) * BN;
+    const T *__restrict__ A = static_cast<const T *>(P.A);
+    const T *__restrict__ Bt = static_cast<const T *>(P.Bt);
+    const int nk = P.K / BKE;
+
+    // ---- staging pointers: group g covers LDS rows 8g .. 8g+7; lane -> (row 8g + lane/8, physical slot lane%8)
+    const T *src[GPW];
+#pragma unroll
+    for (int i = 0; i < GPW; ++i) {
+        const int g = wave + i * NW;
+        const int r = 8 * g + (lane >> 3);                     // LDS row
+        const int slot = (lane & 7) ^ ((r >> 1) & 7);          // logical 16-byte slot stored at physical lane%8
+        if (r < BM) {
+            long long gr = m0 + r;
+            gr = gr < P.M ? gr : P.M - 1;
+            src[i] = A + gr * P.lda + slot * E16;
+        } else {
+            int gn = n0 + (r - BM);
+            gn = gn < P.N ? gn : P.N - 1;
+            src[i] = Bt + (long long)gn * P.ldb + slot * E16;
+        }
+    }
+    auto stage = [&](int buf) {
+#pragma unroll
+        for (int i = 0; i < GPW; ++i) {
+            const int g = wave + i * NW;
+            if (NG % NW == 0 || g < NG) {
+                glds16(src[i], smem + buf * (ROWS * 128) + g * 1024);
+                src[i] += BKE;
+            }
+        }
+    };
+
+    const int wm = wave / WGN, wn = wave % WGN;
+    const int li = lane & 31, lj = lane >> 5;
+    const int fsw = (li >> 1) & 7;
+    // byte offsets of this lane's fragment rows inside a stage
+    int aoff[TM], boff[TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i) aoff[i] = ((wm * TM + i) * 32 + li) * 128;
+#pragma unroll
+    for (int i = 0; i < TN; ++i) boff[i] = (BM + (wn * TN + i) * 32 + li) * 128;
+
+    f32x16 acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    stage(0);
+    for (int kt = 0; kt < nk; ++kt) {
+        __syncthreads();                       // stage kt has landed (vmcnt(0) rides on the barrier); buffer (kt+1)&1 is free
+        if (kt + 1 < nk) stage((kt + 1) & 1);
+        const char *base = smem + (kt & 1) * (ROWS * 128);
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+            const int so = ((2 * s + lj) ^ fsw) * 16;
+            if constexpr (sizeof(T) == 4) {
+                f32x4 a[TM], b[TN];
+#pragma unroll
+                for (int i = 0; i < TM; ++i) a[i] = *reinterpret_cast<const f32x4 *>(base + aoff[i] + so);
+#pragma unroll
+                for (int i = 0; i < TN; ++i) b[i] = *reinterpret_cast<const f32x4 *>(base + boff[i] + so);
+#pragma unroll
+                for (int e = 0; e < 4; ++e)
+#pragma unroll
+                    for (int i = 0; i < TM; ++i)
+#pragma unroll
+                        for (int j = 0; j < TN; ++j)
+                            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i][e], b[j][e], acc[i][j], 0, 0, 0);
+            } else {
+                bf16x8 a[TM], b[TN];
+#pragma unroll
+                for (int i = 0; i < TM; ++i) a[i] = *reinterpret_cast<const bf16x8 *>(base + aoff[i] + so);
+#pragma unroll
+                for (int i = 0; i < TN; ++i) b[i] = *reinterpret_cast<const bf16x8 *>(base + boff[i] + so);
+#pragma unroll
+                for (int i = 0; i < TM; ++i)
+#pragma unroll
+                    for (int j = 0; j < TN; ++j)
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i], b[j], acc[i][j], 0, 0, 0);
+            }
+        }
+    }
+
+    // ---- epilogue: D[row = (r&3) + 8 (r>>2) + 4 lj][col = li]
+    TO *__restrict__ C = static_cast<TO *>(P.C);
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+            const int n = n0 + (wn * TN + j) * 32 + li;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const long long m = m0 + (wm * TM + i) * 32 + (r & 3) + 8 * (r >> 2) + 4 * lj;
+                if (m < P.M && n < P.N) store_out(C + m * P.ldc + n, acc[i][j][r]);
+            }
+        }
+}
+
+// ------------------------------------------------------------------------------------------------ TN (fp32)
+// C[N1][N2] (+ split partials) = sum_r X[r][n1] Y[r][n2].  Block tile BN1 x BN2 = (WGM*TM*32) x (WGN*TN*32); stage =
+// BR rows of both operands, row-contiguous in LDS.  MFMA tile tm of a wave covers rows n1 = base + TM*i + tm (i = MFMA
+// row) so that ONE ds_read of TM floats at [r][base + TM*i] serves all TM tiles (likewise columns): output rows are a
+// permutation the epilogue undoes.
+struct TnGeom {
+    long long r0, r1;     // row range of this split
+};
+
+template <int WGM, int WGN, int TM, int TN, int BR>
+__global__ __launch_bounds__(64 * WGM * WGN) void gemm_tn_f32_kernel(GemmTnArgs G) {
+    constexpr int NW = WGM * WGN;
+    constexpr int BN1 = WGM * TM * 32, BN2 = WGN * TN * 32;
+    constexpr int ROWF = BN1 + BN2;                 // floats per staged row (X part, then Y part)
+    constexpr int STAGE_B = BR * ROWF * 4;
+    constexpr int NI = STAGE_B / 1024;              // wave-level 1 KiB load instructions per stage
+    constexpr int IPW = (NI + NW - 1) / NW;
+    static_assert(STAGE_B % 1024 == 0, "stage must be a whole number of 1 KiB pieces");
+    __shared__ __attribute__((aligned(1024))) char smem[2 * STAGE_B];
+
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const unsigned tile = blockIdx.x % G.ntiles, split = blockIdx.x / G.ntiles;
+    const int n1_0 = (int)(tile / G.tiles_n2) * BN1, n2_0 = (int)(tile % G.tiles_n2) * BN2;
+    const long long nchunk = G.R / BR;
+    const long long c0 = nchunk * split / G.nsplit, c1 = nchunk * (split + 1) / G.nsplit;
+    const int nk = (int)(c1 - c0);
+    const float *__restrict__ X = static_cast<const float *>(G.X);
+    const float *__restrict__ Y = static_cast<const float *>(G.Y);
+
+    // piece q (1 KiB = 256 floats) of a stage: float offset 256 q + 4 lane -> (row, col) of the [BR][ROWF] image
+    const float *src[IPW];
+    long long sstep[IPW];
+#pragma unroll
+    for (int i = 0; i < IPW; ++i) {
+        const int q = wave + i * NW;
+        const int fo = 256 * q + 4 * lane;
+        const int r = fo / ROWF, c = fo % ROWF;
+        if (c < BN1) {
+            int n = n1_0 + c;
+            n = n < G.N1 - 4 ? n : G.N1 - 4;
+            src[i] = X + (c0 * BR + r) * G.ldx + n;
+            sstep[i] = (long long)BR * G.ldx;
+        } else {
+            int n = n2_0 + (c - BN1);
+            n = n < G.N2 - 4 ? n : G.N2 - 4;
+            src[i] = Y + (c0 * BR + r) * G.ldy + n;
+            sstep[i] = (long long)BR * G.ldy;
+        }
+    }
+    auto stage = [&](int buf) {
+#pragma unroll
+        for (int i = 0; i < IPW; ++i) {
+            const int q = wave + i * NW;
+            if (NI % NW == 0 || q < NI) {
+                glds16(src[i], smem + buf * STAGE_B + q * 1024);
+                src[i] += sstep[i];
+            }
+        }
+    };
+
+    const int wm = wave / WGN, wn = wave % WGN;
+    const int li = lane & 31, lj = lane >> 5;
+    const int xo = (wm * TM * 32 + TM * li) * 4;                 // byte offset inside a staged row
+    const int yo = (BN1 + wn * TN * 32 + TN * li) * 4;
+
+    f32x16 acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    if (nk > 0) stage(0);
+    for (int kt = 0; kt < nk; ++kt) {
+        __syncthreads();
+        if (kt + 1 < nk) stage((kt + 1) & 1);
+        const char *base = smem + (kt & 1) * STAGE_B;
+#pragma unroll
+        for (int s = 0; s < BR / 2; ++s) {
+            const char *row = base + (2 * s + lj) * (ROWF * 4);
+            float a[TM], b[TN];
+            if constexpr (TM == 4) {
+                const f32x4 v = *reinterpret_cast<const f32x4 *>(row + xo);
+                a[0] = v[0]; a[1] = v[1]; a[2] = v[2]; a[3] = v[3];
+            } else if constexpr (TM == 2) {
+                const f32x2 v = *reinterpret_cast<const f32x2 *>(row + xo);
+                a[0] = v[0]; a[1] = v[1];
+            } else {
+                a[0] = *reinterpret_cast<const float *>(row + xo);
+            }
+            if constexpr (TN == 4) {
+                const f32x4 v = *reinterpret_cast<const f32x4 *>(row + yo);
+                b[0] = v[0]; b[1] = v[1]; b[2] = v[2]; b[3] = v[3];
+            } else if constexpr (TN == 2) {
+                const f32x2 v = *reinterpret_cast<const f32x2 *>(row + yo);
+                b[0] = v[0]; b[1] = v[1];
+            } else {
+                b[0] = *reinterpret_cast<const float *>(row + yo);
+            }
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int j = 0; j < TN; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i], b[j], acc[i][j], 0, 0, 0);
+        }
+    }
+
+    // ---- epilogue: MFMA row ri of tile tm = output row base1 + TM*ri + tm; column li of tile tn = base2 + TN*li + tn
+    float *__restrict__ C = G.nsplit > 1 ? static_cast<float *>(G.part) + (size_t)split * G.N1 * G.N2
+                                         : static_cast<float *>(G.C);
+    const long long ldc = G.nsplit > 1 ? G.N2 : G.ldc;
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int ri = (r & 3) + 8 * (r >> 2) + 4 * lj;
+            const int n1 = n1_0 + wm * TM * 32 + TM * ri + i;
+            const int n2 = n2_0 + wn * TN * 32 + TN * li;
+            if (n1 < G.N1) {
+#pragma unroll
+                for (int j = 0; j < TN; ++j)
+                    if (n2 + j < G.N2) C[(long long)n1 * ldc + n2 + j] = acc[i][j][r];
+            }
+        }
+}
+
+// ------------------------------------------------------------------------------------------------ TN (bf16)
+// Same problem with bf16 operands, fp32 result: v_mfma_f32_16x16x32_bf16, both fragments by ds_read_b64_tr_b16 (a
+// 16-lane group reads a [4 rows][16 columns] block and receives it column-per-lane: lane i gets rows 0..3 of column i).
+// Wave tile = (TM*16) x (TN*16); stage = 32 rows (= one MFMA contraction step) of [BN1 + BN2] bf16.
+template <int WGM, int WGN, int TM, int TN>
+__global__ __launch_bounds__(64 * WGM * WGN) void gemm_tn_bf16_kernel(GemmTnArgs G) {
+    constexpr int NW = WGM * WGN;
+    constexpr int BR = 32;
+    constexpr int BN1 = WGM * TM * 16, BN2 = WGN * TN * 16;
+    constexpr int ROWE = BN1 + BN2;                 // bf16 per staged row
+    constexpr int STAGE_B = BR * ROWE * 2;
+    constexpr int NI = STAGE_B / 1024;
+    constexpr int IPW = (NI + NW - 1) / NW;
+    static_assert(STAGE_B % 1024 == 0, "stage must be a whole number of 1 KiB pieces");
+    __shared__ __attribute__((aligned(1024))) char smem[2 * STAGE_B];
+
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const unsigned tile = blockIdx.x % G.ntiles, split = blockIdx.x / G.ntiles;
+    const int n1_0 = (int)(tile / G.tiles_n2) * BN1, n2_0 = (int)(tile % G.tiles_n2) * BN2;
+    const long long nchunk = G.R / BR;
+    const long long c0 = nchunk * split / G.nsplit, c1 = nchunk * (split + 1) / G.nsplit;
+    const int nk = (int)(c1 - c0);
+    const __bf16 *__restrict__ X = static_cast<const __bf16 *>(G.X);
+    const __bf16 *__restrict__ Y = static_cast<const __bf16 *>(G.Y);
+
+    const __bf16 *src[IPW];
+    long long sstep[IPW];
+#pragma unroll
+    for (int i = 0; i < IPW; ++i) {
+        const int q = wave + i * NW;
+        const int eo = 512 * q + 8 * lane;            // bf16 offset inside the [BR][ROWE] image
+        const int r = eo / ROWE, c = eo % ROWE;
+        if (c < BN1) {
+            int n = n1_0 + c;
+            n = n < G.N1 - 8 ? n : G.N1 - 8;
+            src[i] = X + (c0 * BR + r) * G.ldx + n;
+            sstep[i] = (long long)BR * G.ldx;
+        } else {
+            int n = n2_0 + (c - BN1);
+            n = n < G.N2 - 8 ? n : G.N2 - 8;
+            src[i] = Y + (c0 * BR + r) * G.ldy + n;
+            sstep[i] = (long long)BR * G.ldy;
+        }
+    }
+    auto stage = [&](int buf) {
+#pragma unroll
+        for (int i = 0; i < IPW; ++i) {
+            const int q = wave + i * NW;
+            if (NI % NW == 0 || q < NI) {
+                glds16(src[i], smem + buf * STAGE_B + q * 1024);
+                src[i] += sstep[i];
+            }
+        }
+    };
+
+    const int wm = wave / WGN, wn = wave % WGN;
+    const int li = lane & 15, lg = lane >> 4;
+    // transposed read: lane i of a 16-lane group supplies the address of chunk i of the [4][16] block:
+    // row i/4, columns 4 (i%4) .. +3; the group g handles contraction rows 8g .. 8g+7 (two reads of 4 rows)
+    const int tr_row = 8 * lg + (li >> 2), tr_col = 4 * (li & 3);
+
+    f32x4 acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    if (nk > 0) stage(0);
+    for (int kt = 0; kt < nk; ++kt) {
+        __syncthreads();
+        if (kt + 1 < nk) stage((kt + 1) & 1);
+        const char *base = smem + (kt & 1) * STAGE_B;
+        bf16x8 a[TM], b[TN];
+#pragma unroll
+        for (int i = 0; i < TM; ++i) {
+            const int col = (wm * TM + i) * 16 + tr_col;
+            const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+                (__attribute__((address_space(3))) s16x4 *)(base + ((tr_row)*ROWE + col) * 2));
+            const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+                (__attribute__((address_space(3))) s16x4 *)(base + ((tr_row + 4) * ROWE + col) * 2));
+            typedef short s16x8 __attribute__((ext_vector_type(8)));
+            const s16x8 v = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+            a[i] = __builtin_bit_cast(bf16x8, v);
+        }
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+            const int col = BN1 + (wn * TN + j) * 16 + tr_col;
+            const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+                (__attribute__((address_space(3))) s16x4 *)(base + ((tr_row)*ROWE + col) * 2));
+            const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+                (__attribute__((address_space(3))) s16x4 *)(base + ((tr_row + 4) * ROWE + col) * 2));
+            typedef short s16x8 __attribute__((ext_vector_type(8)));
+            const s16x8 v = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+            b[j] = __builtin_bit_cast(bf16x8, v);
+        }
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int j = 0; j < TN; ++j)
+                acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[i], b[j], acc[i][j], 0, 0, 0);
+    }
+
+    // D[row = 4 lg + r][col = li]
+    float *__restrict__ C = G.nsplit > 1 ? static_cast<float *>(G.part) + (size_t)split * G.N1 * G.N2
+                                         : static_cast<float *>(G.C);
+    const long long ldc = G.nsplit > 1 ? G.N2 : G.ldc;
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int n1 = n1_0 + (wm * TM + i) * 16 + 4 * lg + r;
+                const int n2 = n2_0 + (wn * TN + j) * 16 + li;
+                if (n1 < G.N1 && n2 < G.N2) C[(long long)n1 * ldc + n2] = acc[i][j][r];
+            }
+}
+
+// sum the split partials in a fixed order (deterministic): C[i] = sum_s part[s][i]
+__global__ void gemm_tn_reduce_kernel(const float *__restrict__ part, float *__restrict__ C, int N1, int N2,
+                                      long long ldc, int nsplit) {
+    const size_t n = (size_t)N1 * N2;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+        float s = 0.f;
+        for (int k = 0; k < nsplit; ++k) s += part[(size_t)k * n + i];
+        C[(i / N2) * ldc + (i % N2)] = s;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------ small helpers
+// dst[c][r] = (TO) src[r][c]   (weights only: a few MB at most)
+template <typename TI, typename TO>
+__global__ void transpose_cast_kernel(const TI *__restrict__ src, TO *__restrict__ dst, int rows, int cols) {
+    __shared__ float tile[32][33];
+    const int bx = blockIdx.x * 32, by = blockIdx.y * 32;
+    for (int i = threadIdx.y; i < 32; i += blockDim.y) {
+        const int r = by + i, c = bx + threadIdx.x;
+        tile[i][threadIdx.x] = (r < rows && c < cols) ? (float)src[(size_t)r * cols + c] : 0.f;
+    }
+    __syncthreads();
+    for (int i = threadIdx.y; i < 32; i += blockDim.y) {
+        const int c = bx + i, r = by + threadIdx.x;
+        if (r < rows && c < cols) dst[(size_t)c * rows + r] = (TO)tile[threadIdx.x][i];
+    }
+}
+
+template <typename TI, typename TO>
+__global__ void cast_kernel(const TI *__restrict__ src, TO *__restrict__ dst, size_t n) {
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x)
+        dst[i] = (TO)(float)src[i];
+}
+
+// generic fallbacks (any shape, VALU): one thread per output element
+template <typename T, typename TO>
+__global__ void gemm_nt_generic_kernel(const T *__restrict__ A, const T *__restrict__ Bt, TO *__restrict__ C, long long M,
+                                       int N, int K, long long lda, long long ldb, long long ldc) {
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= M * N) return;
+    const long long m = i / N;
+    const int n = (int)(i % N);
+    float s = 0.f;
+    for (int k = 0; k < K; ++k) s = fmaf((float)A[m * lda + k], (float)Bt[(long long)n * ldb + k], s);
+    store_out(C + m * ldc + n, s);
+}
+template <typename T>
+__global__ void gemm_tn_generic_kernel(const T *__restrict__ X, const T *__restrict__ Y, float *__restrict__ C,
+                                       long long R, int N1, int N2, long long ldx, long long ldy, long long ldc) {
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (long long)N1 * N2) return;
+    const int n1 = (int)(i / N2), n2 = (int)(i % N2);
+    float s = 0.f;
+    for (long long r = 0; r < R; ++r) s = fmaf((float)X[r * ldx + n1], (float)Y[r * ldy + n2], s);
+    C[(long long)n1 * ldc + n2] = s;
+}
+
+template <typename T, typename TO, int WGM, int WGN, int TM, int TN>
+int launch_nt_cfg(GemmNtBatch &B, hipStream_t st) {
+    constexpr int BM = WGM * TM * 32, BN = WGN * TN * 32;
+    unsigned total = 0;
+    for (int i = 0; i < B.nprob; ++i) {
+        GemmNtProb &p = B.p[i];
+        p.tiles_n = (p.N + BN - 1) / BN;
+        p.tile0 = total;
+        total += (unsigned)((p.M + BM - 1) / BM) * p.tiles_n;
+    }
+    B.ntiles = total;
+    if (total == 0) return 0;
+    hipLaunchKernelGGL((gemm_nt_kernel<T, TO, WGM, WGN, TM, TN>), dim3(total), dim3(64 * WGM * WGN), 0, st, B);
+    EPN_CHECK_LAUNCH();
+    return 0;
+}
+
+template <typename T, typename TO>
+int launch_nt_typed(GemmNtBatch &B, hipStream_t st) {
+    constexpr int E16 = ElemOf<T>::PER16;
+    bool fast = true;
+    int maxn = 0;
+    for (int i = 0; i < B.nprob; ++i) {
+        const GemmNtProb &p = B.p[i];
+        if (p.M < 0 || p.N < 1 || p.K < 1) return EPN_EINVAL;
+        if (!p.A || !p.Bt || !p.C) return EPN_ENULL;
+        if (p.K % (8 * E16) || p.lda % E16 || p.ldb % E16 || ((uintptr_t)p.A & 15) || ((uintptr_t)p.Bt & 15)) fast = false;
+        maxn = p.N > maxn ? p.N : maxn;
+    }
+    if (!fast) {
+        for (int i = 0; i < B.nprob; ++i) {
+            const GemmNtProb &p = B.p[i];
+            if (p.M == 0) continue;
+            const long long n = p.M * p.N;
+            hipLaunchKernelGGL((gemm_nt_generic_kernel<T, TO>), dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st,
+                               static_cast<const T *>(p.A), static_cast<const T *>(p.Bt), static_cast<TO *>(p.C), p.M,
+                               p.N, p.K, p.lda, p.ldb, p.ldc);
+            EPN_CHECK_LAUNCH();
+        }
+        return 0;
+    }
+    if (maxn <= 32) return launch_nt_cfg<T, TO, 8, 1, 2, 1>(B, st);      // 512 x 32
+    if (maxn <= 64) return launch_nt_cfg<T, TO, 8, 1, 2, 2>(B, st);      // 512 x 64
+    return launch_nt_cfg<T, TO, 4, 2, 2, 2>(B, st);                      // 256 x 128
+}
+
+template <typename T>
+int launch_tn_typed(GemmTnArgs &G, hipStream_t st) {
+    if (G.R < 0 || G.N1 < 1 || G.N2 < 1) return EPN_EINVAL;
+    if (!G.C) return EPN_ENULL;
+    constexpr int E16 = ElemOf<T>::PER16;
+    const int BR = sizeof(T) == 4 ? 16 : 32;
+    const bool fast = G.R > 0 && G.R % BR == 0 && G.N1 >= E16 && G.N2 >= E16 && G.ldx % E16 == 0 && G.ldy % E16 == 0 &&
+                      !((uintptr_t)G.X & 15) && !((uintptr_t)G.Y & 15) && G.N1 % E16 == 0 && G.N2 % E16 == 0;
+    if (!fast) {
+        if (G.R > 0 && (!G.X || !G.Y)) return EPN_ENULL;
+        const long long n = (long long)G.N1 * G.N2;
+        hipLaunchKernelGGL((gemm_tn_generic_kernel<T>), dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st,
+                           static_cast<const T *>(G.X), static_cast<const T *>(G.Y), static_cast<float *>(G.C), G.R, G.N1,
+                           G.N2, G.ldx, G.ldy, G.ldc);
+        EPN_CHECK_LAUNCH();
+        return 0;
+    }
+    if (!G.X || !G.Y) return EPN_ENULL;
+    int bn1, bn2;
+    gemm_tn_tile(sizeof(T) == 2, G.N1, G.N2, &bn1, &bn2);
+    G.tiles_n2 = (G.N2 + bn2 - 1) / bn2;
+    G.ntiles = (unsigned)((G.N1 + bn1 - 1) / bn1) * G.tiles_n2;
+    G.nsplit = gemm_tn_splits(sizeof(T) == 2, G.R, G.N1, G.N2);
+    if (G.nsplit > 1 && (!G.part || G.part_bytes < (size_t)G.nsplit * G.N1 * G.N2 * sizeof(float))) return EPN_EWORKSPACE;
+    const dim3 grid(G.ntiles * G.nsplit);
+    if constexpr (sizeof(T) == 4) {
+        if (bn1 == 32) hipLaunchKernelGGL((gemm_tn_f32_kernel<1, 8, 1, 2, 16>), grid, dim3(512), 0, st, G);
+        else if (bn1 == 64) hipLaunchKernelGGL((gemm_tn_f32_kernel<1, 8, 2, 2, 16>), grid, dim3(512), 0, st, G);
+        else hipLaunchKernelGGL((gemm_tn_f32_kernel<2, 4, 2, 2, 16>), grid, dim3(512), 0, st, G);
+    } else {
+        if (bn1 == 32) hipLaunchKernelGGL((gemm_tn_bf16_kernel<1, 8, 2, 2>), grid, dim3(512), 0, st, G);
+        else if (bn1 == 64) hipLaunchKernelGGL((gemm_tn_bf16_kernel<1, 8, 4, 2>), grid, dim3(512), 0, st, G);
+        else hipLaunchKernelGGL((gemm_tn_bf16_kernel<2, 4, 4, 4>), grid, dim3(512), 0, st, G);
+    }
+    EPN_CHECK_LAUNCH();
+    if (G.nsplit > 1) {
+        const size_t n = (size_t)G.N1 * G.N2;
+        hipLaunchKernelGGL(gemm_tn_reduce_kernel, dim3((unsigned)((n + 255) / 256 < 2048 ? (n + 255) / 256 : 2048)),
+                           dim3(256), 0, st, static_cast<const float *>(G.part), static_cast<float *>(G.C), G.N1, G.N2,
+                           G.ldc, G.nsplit);
+        EPN_CHECK_LAUNCH();
+    }
+    return 0;
+}
+
+}  // namespace
+
+// block tile of the TN kernels for an output of N1 x N2 (shared with the workspace query)
+void gemm_tn_tile(bool bf16, int N1, int N2, int *bn1, int *bn2) {
+    (void)N2;
+    if (bf16) {
+        if (N1 <= 32) { *bn1 = 32; *bn2 = 256; }
+        else if (N1 <= 64) { *bn1 = 64; *bn2 = 256; }
+        else { *bn1 = 128; *bn2 = 256; }
+    } else {
+        if (N1 <= 32) { *bn1 = 32; *bn2 = 512; }
+        else if (N1 <= 64) { *bn1 = 64; *bn2 = 512; }
+        else { *bn1 = 128; *bn2 = 256; }
+    }
+}
+
+int gemm_tn_splits(bool bf16, long long R, int N1, int N2) {
+    int bn1, bn2;
+    gemm_tn_tile(bf16, N1, N2, &bn1, &bn2);
+    const long long tiles = (long long)((N1 + bn1 - 1) / bn1) * ((N2 + bn2 - 1) / bn2);
+    const long long chunks = R / (bf16 ? 32 : 16);
+    long long s = (1024 + tiles - 1) / tiles;          // ~4 workgroups per CU in flight
+    const long long smax = chunks / 8 > 1 ? chunks / 8 : 1;   // at least 8 K steps per split
+    if (s > smax) s = smax;
+    if (s > 512) s = 512;
+    return (int)(s < 1 ? 1 : s);
+}
+
+int launch_gemm_nt(GemmNtBatch &B, int dtype, int out_dtype, hipStream_t st) {
+    if (B.nprob < 1 || B.nprob > GEMM_MAX_PROB) return EPN_EINVAL;
+    if (dtype == 0 && out_dtype == 0) return launch_nt_typed<float, float>(B, st);
+    if (dtype == 1 && out_dtype == 1) return launch_nt_typed<__bf16, __bf16>(B, st);
+    if (dtype == 1 && out_dtype == 0) return launch_nt_typed<__bf16, float>(B, st);
+    return EPN_EINVAL;
+}
+
+int launch_gemm_tn(GemmTnArgs &G, int dtype, hipStream_t st) {
+    return dtype == 0 ? launch_tn_typed<float>(G, st) : launch_tn_typed<__bf16>(G, st);
+}
+
+int launch_transpose_cast(const void *src, void *dst, int rows, int cols, int src_bf16, int dst_bf16, hipStream_t st) {
+    if (rows < 1 || cols < 1) return EPN_EINVAL;
+    if (!src || !dst) return EPN_ENULL;
+    const dim3 grid((cols + 31) / 32, (rows + 31) / 32), blk(32, 8);
+    if (!src_bf16 && !dst_bf16)
+        hipLaunchKernelGGL((transpose_cast_kernel<float, float>), grid, blk, 0, st, (const float *)src, (float *)dst, rows, cols);
+    else if (!src_bf16 && dst_bf16)
+        hipLaunchKernelGGL((transpose_cast_kernel<float, __bf16>), grid, blk, 0, st, (const float *)src, (__bf16 *)dst, rows, cols);
+    else if (src_bf16 && !dst_bf16)
+        hipLaunchKernelGGL((transpose_cast_kernel<__bf16, float>), grid, blk, 0, st, (const __bf16 *)src, (float *)dst, rows, cols);
+    else
+        hipLaunchKernelGGL((transpose_cast_kernel<__bf16, __bf16>), grid, blk, 0, st, (const __bf16 *)src, (__bf16 *)dst, rows, cols);
+    EPN_CHECK_LAUNCH();
+    return 0;
+}
+
+int launch_cast(const void *src, void *dst, size_t n, int src_bf16, int dst_bf16, hipStream_t st) {
+    if (n == 0) return 0;
+    if (!src || !dst) return EPN_ENULL;
+    const dim3 grid((unsigned)((n + 255) / 256 < 4096 ? (n + 255) / 256 : 4096)), blk(256);
+    if (!src_bf16 && dst_bf16) hipLaunchKernelGGL((cast_kernel<float, __bf16>), grid, blk, 0, st, (const float *)src, (__bf16 *)dst, n);
+    else if (src_bf16 && !dst_bf16) hipLaunchKernelGGL((cast_kernel<__bf16, float>), grid, blk, 0, st, (const __bf16 *)src, (float *)dst, n);
+    else return EPN_EINVAL;
+    EPN_CHECK_LAUNCH();
+    return 0;
+}
+
+}  // namespace epn
+
+using namespace epn;
+
+static int nt_entry(int nprob, const epn_gemm_nt_problem *probs, int dtype, int out_dtype, epn_stream_t stream) {
+    if (!probs) return EPN_ENULL;
+    if (nprob < 1) return EPN_EINVAL;
+    hipStream_t st = epn_stream(stream);
+    for (int i0 = 0; i0 < nprob; i0 += GEMM_MAX_PROB) {
+        GemmNtBatch B;
+        B.nprob = nprob - i0 < GEMM_MAX_PROB ? nprob - i0 : GEMM_MAX_PROB;
+        for (int i = 0; i < B.nprob; ++i) {
+            const epn_gemm_nt_problem &q = probs[i0 + i];
+            GemmNtProb &p = B.p[i];
+            p.A = q.A; p.Bt = q.Bt; p.C = q.C; p.M = q.M; p.N = q.N; p.K = q.K; p.lda = q.lda; p.ldb = q.ldb; p.ldc = q.ldc;
+            p.tiles_n = 0; p.tile0 = 0;
+        }
+        int rc = launch_gemm_nt(B, dtype, out_dtype, st);
+        if (rc) return rc;
+    }
+    return 0;
+}
+
+extern "C" int epn_gemm_nt_f32(int nprob, const epn_gemm_nt_problem *probs, epn_stream_t stream) {
+    return nt_entry(nprob, probs, 0, 0, stream);
+}
+extern "C" int epn_gemm_nt_bf16(int nprob, const epn_gemm_nt_problem *probs, int out_f32, epn_stream_t stream) {
+    return nt_entry(nprob, probs, 1, out_f32 ? 0 : 1, stream);
+}
+
+extern "C" size_t epn_gemm_tn_workspace_bytes(int bf16, long long R, int N1, int N2) {
+    if (R < 1 || N1 < 1 || N2 < 1) return 0;
+    const int s = gemm_tn_splits(bf16 != 0, R, N1, N2);
+    return s > 1 ? (size_t)s * N1 * N2 * sizeof(float) : 0;
+}
+
+static int tn_entry(const void *X, long long ldx, const void *Y, long long ldy, float *C, long long ldc, long long R, int N1,
+                    int N2, void *ws, size_t ws_bytes, int dtype, epn_stream_t stream) {
+    GemmTnArgs G;
+    G.X = X; G.Y = Y; G.C = C; G.part = ws; G.part_bytes = ws_bytes; G.R = R; G.N1 = N1; G.N2 = N2;
+    G.ldx = ldx; G.ldy = ldy; G.ldc = ldc; G.ntiles = 0; G.tiles_n2 = 0; G.nsplit = 1;
+    return launch_gemm_tn(G, dtype, epn_stream(stream));
+}
+extern "C" int epn_gemm_tn_f32(const float *X, long long ldx, const float *Y, long long ldy, float *C, long long ldc,
+                               long long R, int N1, int N2, void *workspace, size_t workspace_bytes, epn_stream_t stream) {
+    return tn_entry(X, ldx, Y, ldy, C, ldc, R, N1, N2, workspace, workspace_bytes, 0, stream);
+}
+extern "C" int epn_gemm_tn_bf16(const void *X, long long ldx, const void *Y, long long ldy, float *C, long long ldc,
+                                long long R, int N1, int N2, void *workspace, size_t workspace_bytes, epn_stream_t stream) {
+    return tn_entry(X, ldx, Y, ldy, C, ldc, R, N1, N2, workspace, workspace_bytes, 1, stream);
+}
+
+extern "C" int epn_transpose_cast(const void *src, void *dst, int rows, int cols, int src_bf16, int dst_bf16,
+                                  epn_stream_t stream) {
+    return launch_transpose_cast(src, dst, rows, cols, src_bf16, dst_bf16, epn_stream(stream));
+}
+extern "C" int epn_cast(const void *src, void *dst, size_t n, int src_bf16, int dst_bf16, epn_stream_t stream) {
+    return launch_cast(src, dst, n, src_bf16, dst_bf16, epn_stream(stream));
+}

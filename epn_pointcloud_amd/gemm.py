@@ -1,0 +1,148 @@
+"""BasicSO3Conv's weight contraction (vgtk/vgtk/so3conv/modules.py:48-55) and its autograd transposes on the library's
+own MFMA GEMM kernels (csrc/gemm.hip) -- no torch.mm / BLAS on the path.
+
+    gemm_nt(A [M,K], Bt [N,K])  -> A @ Bt.T       activations x weights (fp32, or bf16 with fp32 accumulation)
+    gemm_tn(X [R,N1], Y [R,N2]) -> X.T @ Y (fp32) weight gradients: deterministic split over R
+    matmul_nt(A, W)             -> autograd Function over the two (dA = dC @ W as NT on W^T, dW = dC^T A as TN)
+"""
+import ctypes
+
+import torch
+
+from . import _lib
+
+
+def _is_bf16(t):
+    if t.dtype == torch.bfloat16:
+        return 1
+    if t.dtype == torch.float32:
+        return 0
+    raise TypeError(f"GEMM operands must be float32 or bfloat16, got {t.dtype}")
+
+
+def _rowmajor(t, name):
+    if not t.is_cuda:
+        raise RuntimeError(f"{name} must be a CUDA tensor")
+    if t.dim() != 2:
+        raise ValueError(f"{name} must be 2-D")
+    if t.stride(1) != 1 or (t.shape[0] > 1 and t.stride(0) < t.shape[1]):
+        t = t.contiguous()
+    return t
+
+
+def _problem(A, Bt, C):
+    p = _lib.GemmNtProblem()
+    p.A, p.Bt, p.C = A.data_ptr(), Bt.data_ptr(), C.data_ptr()
+    p.M, p.N, p.K = A.shape[0], Bt.shape[0], A.shape[1]
+    p.lda = A.stride(0) if A.shape[0] > 1 else A.shape[1]
+    p.ldb = Bt.stride(0) if Bt.shape[0] > 1 else Bt.shape[1]
+    p.ldc = C.stride(0) if C.shape[0] > 1 else C.shape[1]
+    return p
+
+
+def gemm_nt_grouped(problems, out_dtype=None):
+    """problems: list of (A [M,K], Bt [N,K], C [M,N] or None); one grouped launch per 6 problems.  Returns the C list.
+    All operands share one dtype (fp32 or bf16); C is that dtype unless out_dtype says float32."""
+    lib = _lib.get_lib()
+    arr = (_lib.GemmNtProblem * len(problems))()
+    outs, keep = [], []
+    bf = None
+    for i, (A, Bt, C) in enumerate(problems):
+        A, Bt = _rowmajor(A, "A"), _rowmajor(Bt, "Bt")
+        if A.shape[1] != Bt.shape[1]:
+            raise ValueError(f"gemm_nt: K mismatch {tuple(A.shape)} x {tuple(Bt.shape)}^T")
+        b = _is_bf16(A)
+        if _is_bf16(Bt) != b or (bf is not None and bf != b):
+            raise TypeError("gemm_nt: mixed operand dtypes")
+        bf = b
+        odt = out_dtype or A.dtype
+        if C is None:
+            C = torch.empty((A.shape[0], Bt.shape[0]), dtype=odt, device=A.device)
+        elif C.dtype != odt or C.stride(1) != 1 or tuple(C.shape) != (A.shape[0], Bt.shape[0]):
+            raise ValueError("gemm_nt: output must be row-major [M,N] of the output dtype")
+        arr[i] = _problem(A, Bt, C)
+        outs.append(C)
+        keep += [A, Bt]
+    st = _lib.stream_of(outs[0])
+    if bf:
+        out_f32 = 1 if outs[0].dtype == torch.float32 else 0
+        _lib.check(lib.epn_gemm_nt_bf16(len(problems), arr, out_f32, st), "gemm_nt_bf16")
+    else:
+        _lib.check(lib.epn_gemm_nt_f32(len(problems), arr, st), "gemm_nt_f32")
+    return outs
+
+
+def gemm_nt(A, Bt, out=None, out_dtype=None):
+    return gemm_nt_grouped([(A, Bt, out)], out_dtype)[0]
+
+
+def gemm_tn(X, Y, out=None):
+    """X [R,N1], Y [R,N2] (same dtype) -> X^T Y fp32 [N1,N2]."""
+    lib = _lib.get_lib()
+    X, Y = _rowmajor(X, "X"), _rowmajor(Y, "Y")
+    if X.shape[0] != Y.shape[0]:
+        raise ValueError(f"gemm_tn: row mismatch {tuple(X.shape)} vs {tuple(Y.shape)}")
+    bf = _is_bf16(X)
+    if _is_bf16(Y) != bf:
+        raise TypeError("gemm_tn: mixed operand dtypes")
+    R, N1, N2 = X.shape[0], X.shape[1], Y.shape[1]
+    if out is None:
+        out = torch.empty((N1, N2), dtype=torch.float32, device=X.device)
+    elif out.dtype != torch.float32 or out.stride(1) != 1 or tuple(out.shape) != (N1, N2):
+        raise ValueError("gemm_tn: output must be row-major fp32 [N1,N2]")
+    nbytes = int(lib.epn_gemm_tn_workspace_bytes(bf, R, N1, N2))
+    ws = torch.empty(max(nbytes, 16), dtype=torch.uint8, device=X.device)
+    fn = lib.epn_gemm_tn_bf16 if bf else lib.epn_gemm_tn_f32
+    ldx = X.stride(0) if R > 1 else N1
+    ldy = Y.stride(0) if R > 1 else N2
+    ldc = out.stride(0) if N1 > 1 else N2
+    _lib.check(fn(X.data_ptr(), ldx, Y.data_ptr(), ldy, out.data_ptr(), ldc, R, N1, N2, ws.data_ptr(), ws.numel(),
+                  _lib.stream_of(X)), "gemm_tn")
+    return out
+
+
+def transpose_cast(W, dtype):
+    """[r,c] -> [c,r] contiguous in `dtype` (fp32 / bf16) with the library's kernel (weights only)."""
+    lib = _lib.get_lib()
+    W = W.contiguous()
+    out = torch.empty((W.shape[1], W.shape[0]), dtype=dtype, device=W.device)
+    _lib.check(lib.epn_transpose_cast(W.data_ptr(), out.data_ptr(), W.shape[0], W.shape[1], _is_bf16(W), _is_bf16(out),
+                                      _lib.stream_of(W)), "transpose_cast")
+    return out
+
+
+def cast(t, dtype):
+    """fp32 <-> bf16 copy of a contiguous tensor with the library's kernel."""
+    if t.dtype == dtype:
+        return t
+    lib = _lib.get_lib()
+    t = t.contiguous()
+    out = torch.empty_like(t, dtype=dtype)
+    _lib.check(lib.epn_cast(t.data_ptr(), out.data_ptr(), t.numel(), _is_bf16(t), _is_bf16(out), _lib.stream_of(t)), "cast")
+    return out
+
+
+class MatmulNT(torch.autograd.Function):
+    """C = A @ W^T with A [M,K] activations (fp32 or bf16) and W [N,K] fp32 master weights (cast per call for bf16).
+    dA = dC @ W (NT against W^T), dW = dC^T @ A (TN, fp32)."""
+
+    @staticmethod
+    def forward(ctx, A, W):
+        Wc = W if W.dtype == A.dtype else cast(W, A.dtype)
+        ctx.save_for_backward(A, W)
+        return gemm_nt(A, Wc)
+
+    @staticmethod
+    def backward(ctx, dC):
+        A, W = ctx.saved_tensors
+        dC = dC if dC.dtype == A.dtype else dC.to(A.dtype)
+        dA = dW = None
+        if ctx.needs_input_grad[0]:
+            dA = gemm_nt(dC, transpose_cast(W, A.dtype))
+        if ctx.needs_input_grad[1]:
+            dW = gemm_tn(dC, A)
+        return dA, dW
+
+
+def matmul_nt(A, W):
+    return MatmulNT.apply(A, W)

@@ -250,6 +250,36 @@ int epn_zp_intra_bwd_f32(const int32_t *anchor_neighbors, const float *anchor_we
                          int b, int c, int np, int na_in, int na_out, int ks, int ann, float *grad_feats,
                          epn_stream_t stream);
 
+/* ---------------------------------------------------------------------------------------------------------------------
+ * BasicSO3Conv's weight contraction and its autograd transposes as hand-written MFMA GEMMs
+ * replaces BasicSO3Conv.forward (vgtk/vgtk/so3conv/modules.py:48-55: `torch.matmul(self.W, x.view(b, c*ks, p*a))`) and
+ * the two matmul gradients torch autograd derives from it.  Operands are row-major with explicit leading dimensions.
+ *   NT: C[M][N]   = A[M][K] . Bt[N][K]^T   (activations x weights: out = grouped W^T, grad_grouped = grad_out (W^T)^T,
+ *                                           the irreducible blocks of the spectral IntraSO3Conv); up to any number of
+ *                                           problems per call (one grouped launch per 6).
+ *   TN: C[N1][N2] = X[R][N1]^T . Y[R][N2]  (weight gradients: contraction over the R = b*p*a columns; split over R into
+ *                                           fp32 partials in `workspace`, summed in a fixed order: deterministic).
+ * fp32: v_mfma_f32_32x32x2_f32, exact f32.  bf16: bf16 operands, fp32 accumulation; NT writes bf16 (or fp32 when
+ * out_f32 != 0), TN always writes fp32.  Fast path: K % 32 == 0 (fp32) / 64 (bf16), 16-byte aligned rows; anything
+ * else runs on a generic kernel.  C is fully overwritten. */
+typedef struct epn_gemm_nt_problem {
+    const void *A, *Bt;
+    void *C;
+    long long M, lda, ldb, ldc;
+    int N, K;
+} epn_gemm_nt_problem;
+int epn_gemm_nt_f32(int nprob, const epn_gemm_nt_problem *probs, epn_stream_t stream);
+int epn_gemm_nt_bf16(int nprob, const epn_gemm_nt_problem *probs, int out_f32, epn_stream_t stream);
+size_t epn_gemm_tn_workspace_bytes(int bf16, long long R, int N1, int N2);
+int epn_gemm_tn_f32(const float *X, long long ldx, const float *Y, long long ldy, float *C, long long ldc, long long R,
+                    int N1, int N2, void *workspace, size_t workspace_bytes, epn_stream_t stream);
+int epn_gemm_tn_bf16(const void *X, long long ldx, const void *Y, long long ldy, float *C, long long ldc, long long R,
+                     int N1, int N2, void *workspace, size_t workspace_bytes, epn_stream_t stream);
+/* dst[cols][rows] = src[rows][cols]^T with an optional fp32 <-> bf16 conversion (weights: W^T for the data gradient,
+ * bf16 copies of the fp32 master weights); epn_cast converts a flat array. */
+int epn_transpose_cast(const void *src, void *dst, int rows, int cols, int src_bf16, int dst_bf16, epn_stream_t stream);
+int epn_cast(const void *src, void *dst, size_t n, int src_bf16, int dst_bf16, epn_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif
