@@ -13,7 +13,7 @@ _PKG = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("EPN_LIB", os.path.join(_PKG, "libepn_so3conv.so"))   # EPN_LIB: A/B builds (tools/)
 
 EXPORTS = [
-    "epn_version", "epn_strerror",
+    "epn_version", "epn_strerror", "epn_set_kernel_policy",
     "epn_ball_query_f32", "epn_fps_f32", "epn_gather_fwd_f32", "epn_gather_bwd_f32", "epn_initial_anchor_query_f32",
     "epn_inter_workspace_bytes", "epn_inter_is_fused", "epn_inter_so3conv_fwd_f32",
     "epn_inter_so3conv_bwd_data_f32", "epn_inter_so3conv_bwd_weight_f32", "epn_inter_weights_f32",
@@ -60,6 +60,8 @@ def get_lib():
     lib.epn_version.restype = ctypes.c_char_p
     lib.epn_strerror.restype = ctypes.c_char_p
     lib.epn_strerror.argtypes = [_ci]
+    lib.epn_set_kernel_policy.argtypes = [_ci]
+    lib.epn_set_kernel_policy.restype = _ci
     lib.epn_ball_query_f32.argtypes = [_vp, _vp, _ci, _ci, _ci, _cf, _ci, _vp, _vp]
     lib.epn_fps_f32.argtypes = [_vp, _ci, _ci, _ci, _vp, _vp]
     lib.epn_initial_anchor_query_f32.argtypes = [_vp, _vp, _vp, _ci, _ci, _ci, _ci, _ci, _cf, _cf, _vp, _vp, _vp]
@@ -115,6 +117,16 @@ def get_lib():
     return lib
 
 
+class generic_kernels:
+    """`with _lib.generic_kernels():` -- run on the any-shape generic kernels (cross-check tests only)."""
+
+    def __enter__(self):
+        check(get_lib().epn_set_kernel_policy(1), "set_kernel_policy")
+
+    def __exit__(self, *exc):
+        check(get_lib().epn_set_kernel_policy(0), "set_kernel_policy")
+
+
 def check(rc, what):
     if rc != 0:
         msg = get_lib().epn_strerror(int(rc)).decode()
@@ -122,7 +134,20 @@ def check(rc, what):
 
 
 def stream_of(t):
-    return ctypes.c_void_p(torch.cuda.current_stream(t.device).cuda_stream)
+    """Current torch stream of t's device.  The HIP runtime launches on ITS current device, so that is switched to t's
+    device first when it differs (the reference's extensions get the same from ATen's device guard): a tensor on cuda:1
+    while cuda:0 is current must not launch on cuda:0.  The switch persists, like torch.cuda.set_device."""
+    dev = t.device
+    if dev.index is not None and torch.cuda.current_device() != dev.index:
+        torch.cuda.set_device(dev)
+    return ctypes.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
+
+
+def same_device(*tensors):
+    """All device tensors of one call must live on one device (checked where several tensors meet)."""
+    devs = {t.device for t in tensors if t is not None}
+    if len(devs) > 1:
+        raise RuntimeError(f"tensors of one call are on different devices: {sorted(str(d) for d in devs)}")
 
 
 def dev_ptr(t, name, dtype=torch.float32):

@@ -1,16 +1,20 @@
 // extern "C" entry points of libepn_so3conv.so for the convolution path (see include/epn_so3conv.h).
 // Dispatch: fused MFMA kernels when cin and cout are multiples of 16, generic kernels otherwise
-// (EPN_FORCE_GENERIC=1 in the environment forces the generic path; used by the cross-check tests).
-#include <cstdlib>
+// (epn_set_kernel_policy(1) forces the generic path; used by the cross-check tests).
+#include <atomic>
 #include <cstring>
 
 #include "conv_internal.h"
 
 using namespace epn;
 
-static bool force_generic() {
-    const char *e = std::getenv("EPN_FORCE_GENERIC");
-    return e && e[0] == '1';
+static std::atomic<int> g_policy{0};   // the library's only process-wide state: 0 = best kernel, 1 = generic kernels
+static bool force_generic() { return g_policy.load(std::memory_order_relaxed) == 1; }
+
+extern "C" int epn_set_kernel_policy(int policy) {
+    if (policy != 0 && policy != 1) return EPN_EINVAL;
+    g_policy.store(policy, std::memory_order_relaxed);
+    return 0;
 }
 
 static int check_desc(const epn_inter_desc *d) {

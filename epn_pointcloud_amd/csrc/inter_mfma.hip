@@ -20,9 +20,6 @@
 
 #include "conv_internal.h"
 
-#ifndef EPN_ABLATE
-#define EPN_ABLATE 0   // perf ablations only (tools/ablate.sh): 1 = skip grouping, 2 = skip W contraction
-#endif
 
 namespace epn {
 
@@ -710,24 +707,15 @@ __global__ __launch_bounds__(64 * NW8) void inter_fwd8_kernel(InterArgs A) {
     };
     auto contract = [&](int nsub, int gstride, int step0) {
         for (int sub = 0; sub < nsub; ++sub) {
-#if EPN_ABLATE != 3
             __syncthreads();   // Ws free again; this wave's tile writes are ordered before its reads
-#endif
             store_w();
             if (step0 + sub + 1 < nchunk * spc) fetch_w(step0 + sub + 1);
-#if EPN_ABLATE != 3
             __syncthreads();
-#endif
             // software-pipelined over the (g, m) sequence: the W fragment of the next step (and the G fragment of
             // the next g) are read from LDS while the current step's four MFMAs issue
             const int ng = A.wk >> 4;
-#if EPN_ABLATE == 4   // timing only: bank-conflict-free (wrong) fragment addresses
-            const float *gsrc = Gs + lane * 4;
-            const float *wsrc = Ws + lane * 4;
-#else
             const float *gsrc = Gs + x * gstride + sub * A.wk + 4 * j;
             const float *wsrc = Ws + x * wss + 4 * j;
-#endif
             f32x4 bf = *reinterpret_cast<const f32x4 *>(gsrc);
             f32x4 af = *reinterpret_cast<const f32x4 *>(wsrc);
             for (int g = 0; g < ng; ++g) {
@@ -752,19 +740,10 @@ __global__ __launch_bounds__(64 * NW8) void inter_fwd8_kernel(InterArgs A) {
     fetch_w(0);
     for (int ct = 0; ct < nchunk; ++ct) {
         f32x4 R1[16];
-#if EPN_ABLATE != 1
         group16<NT>(A, s0, s1, ct, x, j, Gs, R1);
-#else
-#pragma unroll
-        for (int jc = 0; jc < 16; ++jc) R1[jc] = f32x4{0.f, 0.f, 0.f, 0.f};
-#endif
-#if EPN_ABLATE != 2
         contract(n0s, GS0, ct * spc);
         spill_pass1(Gs, R1, kw1, gs1, x, j);   // own tile: LDS ops of one wave execute in order
         contract(n1s, gs1, ct * spc + n0s);
-#else
-        spill_pass1(Gs, R1, kw1, gs1, x, j);
-#endif
     }
     const long long col = col0 + x;
     if (col < A.ncol) {
@@ -1135,8 +1114,6 @@ int launch_inter_tables_mfma(const epn_inter_desc *d, const float *rk, float *rk
 }
 
 static bool use8(const epn_inter_desc *d) {
-    const char *e = std::getenv("EPN_INTER_V2");
-    if (e && e[0] == '1') return false;
     return d->na >= 16 && d->ks > 16 && d->ks <= 32 && d->nn <= 32;
 }
 
@@ -1208,8 +1185,7 @@ int launch_inter_bwd_data_mfma(const epn_inter_desc *d, const float *rk4, const 
     InterArgs A = make_args(d, rk4);
     A.W = wt; A.gout = dOut; A.out = dF;
     {
-        const char *e8 = std::getenv("EPN_INTER_V2");
-        if (!(e8 && e8[0] == '1') && d->na >= 16 && d->nn <= 32 && (d->ks == 24 || d->ks == 32 || d->ks == 16)) {
+        if (d->na >= 16 && d->nn <= 32 && (d->ks == 24 || d->ks == 32 || d->ks == 16)) {
             const size_t lds8 = (size_t)4 * 16 * (16 * d->ks + 4) * sizeof(float) + (size_t)16 * d->ks * 20 * sizeof(float);
             const unsigned grid8 = (unsigned)((A.ncol + 63) / 64);
 #define EPN_BD8(NT_, KT_, MH_)                                                                                 \
@@ -1296,11 +1272,7 @@ int launch_inter_bwd_weight_mfma(const epn_inter_desc *d, const float *rk4, cons
     return 0;
 }
 
-static int chunks_per_row() {   // EPN_GROUP_CPR: 16-channel chunks per launch row of the grouping kernels (tuning knob)
-    const char *e = std::getenv("EPN_GROUP_CPR");
-    const int v = e ? std::atoi(e) : 1;
-    return v >= 1 ? v : 1;
-}
+static int chunks_per_row() { return 1; }   // 16-channel chunks per launch row of the grouping kernels
 
 int launch_inter_group_mfma(const epn_inter_desc *d, const float *rk4, const float *feats, float *G, hipStream_t st) {
     InterArgs A = make_args(d, rk4);

@@ -385,8 +385,7 @@ int launch_intra_bwd_weight_mfma(const float *feats, const float *dOut, const in
     if (splits < 1) splits = 1;
     A.col_tiles_per_wg = (int)((tiles + splits - 1) / splits);
     const unsigned gx = (unsigned)((tiles + A.col_tiles_per_wg - 1) / A.col_tiles_per_wg);
-    const char *ev = std::getenv("EPN_INTRA_BW_V4");
-    if (cout % 64 == 0 && cin % 64 == 0 && kn >= 4 && kn <= 12 && na <= 64 && !(ev && ev[0] == '1')) {   // one wave per k
+    if (cout % 64 == 0 && cin % 64 == 0 && kn >= 4 && kn <= 12 && na <= 64) {   // one wave per k
         const long long npts = (long long)b * p;
         const int blocks = (cout / 64) * (cin / 64);
         long long wgs = (256 * 2 + blocks - 1) / blocks;            // ~2 workgroups per CU in total

@@ -126,9 +126,12 @@ class RelSO3OutBlockR(nn.Module):
 
 
 class _SO3ConvModel(nn.Module):
+    MODEL = "cls"
+
     def __init__(self, layers, kanchor, norm, fused_glue, dropout_rate):
         super().__init__()
-        self.backbone = nn.ModuleList([S.BasicBlock(st, kanchor, norm, fused_glue, dropout_rate)
+        btype = S.block_type(kanchor, self.MODEL)
+        self.backbone = nn.ModuleList([S.BasicBlock(st, kanchor, norm, fused_glue, dropout_rate, btype)
                                        for st in S.stages(layers)])
         self.na_in = kanchor
         self.invariance = True
@@ -140,7 +143,8 @@ class _SO3ConvModel(nn.Module):
         return x
 
     def get_anchor(self):
-        return self.backbone[-1].blocks[-1].inter_conv.conv.anchors
+        last = self.backbone[-1].blocks[-1]
+        return (last.inter_conv.conv if hasattr(last, "inter_conv") else last.conv).anchors
 
 
 class ClsSO3ConvModel(_SO3ConvModel):
@@ -158,6 +162,7 @@ class ClsSO3ConvModel(_SO3ConvModel):
 
 class InvSO3ConvModel(_SO3ConvModel):
     """forward(x [b, n, 3]) -> (unit descriptor [b, c_out], per-point anchor attention)."""
+    MODEL = "inv"
 
     def __init__(self, layers, out_mlps=(128, 64), kanchor=60, pooling='attention', temperature=3.0, fused_glue=True,
                  dropout_rate=0.0):
@@ -172,6 +177,7 @@ class InvSO3ConvModel(_SO3ConvModel):
 class RegSO3ConvModel(_SO3ConvModel):
     """forward(x [b, 2, n, 3]) -> (confidence [b, na, na], rotations [b, 4 | 6, na, na]); the two clouds of a pair go
     through the backbone as one batch of 2b (reg_so3net.py:31-33)."""
+    MODEL = "reg"
 
     def __init__(self, layers, out_mlps=(256, 128, 64), kanchor=60, representation='quat', temperature=3.0,
                  fused_glue=True, dropout_rate=0.0):

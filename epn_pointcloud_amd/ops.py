@@ -9,7 +9,7 @@ import os
 
 import torch
 
-from . import _lib
+from . import _lib, gemm
 
 
 # ---- optional per-launch timing (bench.py's roofline leg): HIP events on the launch stream ------------
@@ -191,40 +191,6 @@ class InterSO3ConvFn(torch.autograd.Function):
         return gf, gW, None
 
 
-_TUNED = False
-
-
-def use_tuned_gemms():
-    """The split convolutions hand their weight contractions to the BLAS library through torch.mm.  PyTorch's TunableOp
-    picks, per GEMM shape, the fastest rocBLAS / hipBLASLt solution; `gemm_tuning_gfx950.csv` (next to this file) holds
-    the selections for the ModelNet40 B=32 shapes, recorded on an MI355X with tools/tune_gemms.sh (+7 % on the GEMMs
-    over the default heuristic).  Loaded once, read-only (no tuning at run time, no write-back); a library-version
-    mismatch makes PyTorch ignore the file.  EPN_TUNED_GEMM=0, or any PYTORCH_TUNABLEOP_* setting of the user's own,
-    turns this off."""
-    global _TUNED
-    if _TUNED:
-        return
-    _TUNED = True
-    if os.environ.get("EPN_TUNED_GEMM", "1") != "1" or any(k.startswith("PYTORCH_TUNABLEOP_") for k in os.environ):
-        return
-    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "gemm_tuning_gfx950.csv")
-    if not os.path.exists(path) or not torch.cuda.is_available():
-        return
-    try:
-        import shutil
-        import tempfile
-        tun = torch.cuda.tunable
-        tun.enable(True)
-        tun.tuning_enable(False)
-        # TunableOp re-writes its results file at exit: give it a private copy, the in-tree table stays read-only
-        tmp = os.path.join(tempfile.mkdtemp(prefix="epn_gemm_"), "gemm_tuning.csv")
-        shutil.copyfile(path, tmp)
-        tun.set_filename(tmp, insert_device_ordinal=False)
-    except Exception as e:  # an older / differently built torch: the default GEMM heuristics still apply
-        import warnings
-        warnings.warn(f"epn_pointcloud_amd: tuned GEMM table not loaded ({e})")
-
-
 def _group_workspace(lib, d, device):
     nbytes = lib.epn_inter_group_workspace_bytes(ctypes.byref(d))
     ws = torch.empty(max(int(nbytes), 16), dtype=torch.uint8, device=device)
@@ -289,14 +255,13 @@ class InterSO3ConvSplitFn(torch.autograd.Function):
             raise ValueError(f"shape mismatch: feats {tuple(f.shape)}, W {tuple(Wc.shape)}, geometry "
                              f"b={d.b} p1={d.p1} na={d.na} ks={d.ks}")
         cols = d.b * d.p2 * d.na
-        use_tuned_gemms()
         G = torch.empty((cols, ck), dtype=torch.float32, device=f.device)
         ws, wsp, wsn = _group_workspace(lib, d, f.device)
         gflops = 9.0 * cols * d.ks * d.nn + 2.0 * cols * cin * d.ks * d.nn
         _lib.check(_launch("inter_group", _inter_key(d), gflops, f.device,
                            lambda: lib.epn_inter_group_f32(ctypes.byref(d), _cl_ptr(f), _lib.dev_ptr(G, "grouped"), wsp,
                                                            wsn, _lib.stream_of(f))), "inter_group")
-        out2d = _launch("inter_gemm", _inter_key(d), 2.0 * cols * cout * ck, f.device, lambda: torch.mm(G, Wc.t()))
+        out2d = _launch("inter_gemm", _inter_key(d), 2.0 * cols * cout * ck, f.device, lambda: gemm.gemm_nt(G, Wc))
         ctx.save_for_backward(G, Wc)
         ctx.geo, ctx.cin = geo, cin
         return out2d.view(d.b, d.p2, d.na, cout).permute(0, 3, 1, 2)
@@ -315,7 +280,7 @@ class InterSO3ConvSplitFn(torch.autograd.Function):
         gemm_fl = 2.0 * cols * cout * ck
         gf = gW = None
         if need_w:
-            gW = _launch("inter_gemm", _inter_key(d), gemm_fl, G.device, lambda: torch.mm(g2d.t(), G))
+            gW = _launch("inter_gemm_dw", _inter_key(d), gemm_fl, G.device, lambda: gemm.gemm_tn(g2d, G))
         if need_f:
             gf = empty_cl(d.b, cin, d.p1, d.na, G.device)
             mode = os.environ.get("EPN_INTER_BWD_DATA", "auto")
@@ -335,7 +300,8 @@ class InterSO3ConvSplitFn(torch.autograd.Function):
                                                                               wsn, _lib.stream_of(G))),
                            "inter_so3conv_bwd_data")
             else:
-                dG = _launch("inter_gemm", _inter_key(d), gemm_fl, G.device, lambda: torch.mm(g2d, Wc))
+                Wt = gemm.transpose_cast(Wc, Wc.dtype)                       # [ck, cout]: dG = dOut W as an NT GEMM
+                dG = _launch("inter_gemm", _inter_key(d), gemm_fl, G.device, lambda: gemm.gemm_nt(g2d, Wt))
                 ws, wsp, wsn = _group_workspace(lib, d, G.device)
                 gflops = 9.0 * cols * d.ks * d.nn + 2.0 * cols * cin * d.ks * d.nn
                 _lib.check(_launch("inter_ungroup", _inter_key(d), gflops, G.device,
@@ -355,25 +321,46 @@ def _side_stream(device):
     return _SIDE[key]
 
 
-_INV_CACHE = {}
+class _TensorCache:
+    """Values derived from an index tensor, cached per LIVE tensor object: an entry holds a weak reference to the tensor it
+    was derived from and its in-place version, and is used only while that very object is alive and unmodified (a key
+    made of data_ptr() alone would hand a recycled address the previous table's entry).  Bounded."""
+
+    def __init__(self, maxlen=32):
+        self._d, self._maxlen = {}, maxlen
+
+    def get(self, t, make):
+        import weakref
+        k = id(t)
+        e = self._d.get(k)
+        if e is not None and e[0]() is t and e[1] == t._version:
+            return e[2]
+        if len(self._d) >= self._maxlen:
+            self._d = {kk: ee for kk, ee in self._d.items() if ee[0]() is not None}
+            if len(self._d) >= self._maxlen:
+                self._d.clear()
+        v = make(t)
+        self._d[k] = (weakref.ref(t), t._version, v)
+        return v
+
+
+_INV_CACHE = _TensorCache()
+
+
+def _make_inverse(intra_idx32):
+    host = intra_idx32.cpu().long()
+    na, kn = host.shape
+    if not all(sorted(host[:, k].tolist()) == list(range(na)) for k in range(kn)):
+        return None
+    inv = torch.empty_like(host)
+    inv.scatter_(0, host, torch.arange(na).view(-1, 1).expand(-1, kn))
+    return inv.int().to(intra_idx32.device)
 
 
 def inverse_intra_idx(intra_idx32):
     """inv[idx[a,k], k] = a when every column of intra_idx is a permutation of the anchors (true for the
-    icosahedral table, tests/test_tables.py); None otherwise.  Cached per index tensor."""
-    key = (intra_idx32.data_ptr(), intra_idx32._version, tuple(intra_idx32.shape), str(intra_idx32.device))
-    if key not in _INV_CACHE:
-        host = intra_idx32.cpu().long()
-        na, kn = host.shape
-        inv = None
-        if all(sorted(host[:, k].tolist()) == list(range(na)) for k in range(kn)):
-            inv = torch.empty_like(host)
-            inv.scatter_(0, host, torch.arange(na).view(-1, 1).expand(-1, kn))
-            inv = inv.int().to(intra_idx32.device)
-        if len(_INV_CACHE) > 64:
-            _INV_CACHE.clear()
-        _INV_CACHE[key] = inv
-    return _INV_CACHE[key]
+    icosahedral table, tests/test_tables.py); None otherwise.  Cached per live index tensor."""
+    return _INV_CACHE.get(intra_idx32, _make_inverse)
 
 
 def _intra_ws(lib, na, kn, cin, cout, device):
@@ -456,7 +443,6 @@ class IntraSO3ConvSplitFn(torch.autograd.Function):
             raise ValueError(f"shape mismatch: feats {tuple(f.shape)}, W {tuple(Wc.shape)}, "
                              f"intra_idx {tuple(intra_idx32.shape)}")
         cols = b * p * na
-        use_tuned_gemms()
         G = torch.empty((cols, kn * cin), dtype=torch.float32, device=f.device)
         _lib.check(_launch("intra_group", (b, p, na, kn, cin, cout), 0.0, f.device,
                            lambda: lib.epn_intra_group_f32(_cl_ptr(f), _lib.dev_ptr(intra_idx32, "intra_idx", torch.int32),
@@ -464,7 +450,7 @@ class IntraSO3ConvSplitFn(torch.autograd.Function):
                                                            _lib.stream_of(f))), "intra_group")
         Wp = Wc.view(cout, cin, kn).permute(0, 2, 1).reshape(cout, kn * cin)      # [o][k*cin + c]
         fl = 2.0 * cols * cout * cin * kn
-        out2d = _launch("intra_gemm", (b, p, na, kn, cin, cout), fl, f.device, lambda: torch.mm(G, Wp.t()))
+        out2d = _launch("intra_gemm", (b, p, na, kn, cin, cout), fl, f.device, lambda: gemm.gemm_nt(G, Wp))
         ctx.save_for_backward(G, Wc, intra_idx32)
         ctx.dims = (b, cin, p, na)
         return out2d.view(b, p, na, cout).permute(0, 3, 1, 2)
@@ -481,7 +467,7 @@ class IntraSO3ConvSplitFn(torch.autograd.Function):
         gf = gW = None
         if ctx.needs_input_grad[1]:
             g2d = g.permute(0, 2, 3, 1).reshape(cols, cout)
-            gWp = _launch("intra_gemm", (b, p, na, kn, cin, cout), fl, G.device, lambda: torch.mm(g2d.t(), G))
+            gWp = _launch("intra_gemm_dw", (b, p, na, kn, cin, cout), fl, G.device, lambda: gemm.gemm_tn(g2d, G))
             gW = gWp.view(cout, kn, cin).permute(0, 2, 1).reshape(cout, cin * kn)
         if ctx.needs_input_grad[0]:
             gf = empty_cl(b, cin, p, na, G.device)
@@ -498,7 +484,7 @@ class IntraSO3ConvSplitFn(torch.autograd.Function):
 
 # ------------------------------------------------------------------------------------------------------------------
 # IntraSO3Conv in the block-diagonalising anchor basis (so3_fourier.py): U^T, one GEMM per irreducible block, U.
-_BASIS_CACHE = {}
+_BASIS_CACHE = _TensorCache()
 
 
 class _SpectralBasis:
@@ -522,19 +508,23 @@ class _SpectralBasis:
         self.blocks = torch.tensor(blocks, dtype=torch.int32, device=dev)     # [na][2]
         self.rho = [torch.from_numpy(r.astype(np.float32)).to(dev) for r in bz["rho"]]   # [kn, d, d] each
         self.rho_all = torch.cat([r.reshape(r.shape[0], -1) for r in self.rho], dim=1).contiguous()   # [kn, na], (i, j)
+        self.rho_all_t = self.rho_all.t().contiguous()                                                 # [na, kn]
+
+
+def _make_basis(intra_idx32):
+    na = intra_idx32.shape[0]
+    if not (na <= 64 and na % 4 == 0):
+        return None
+    try:
+        return _SpectralBasis(intra_idx32)
+    except ValueError:
+        return None
 
 
 def spectral_basis(intra_idx32):
-    """Cached per index tensor; None when the table is not a regular permutation group action (then the 12-neighbour
-    forms are used) or the anchor count does not fit the transform kernel."""
-    key = (intra_idx32.data_ptr(), intra_idx32._version, tuple(intra_idx32.shape), str(intra_idx32.device))
-    if key not in _BASIS_CACHE:
-        na = intra_idx32.shape[0]
-        try:
-            _BASIS_CACHE[key] = _SpectralBasis(intra_idx32) if (na <= 64 and na % 4 == 0) else None
-        except ValueError:
-            _BASIS_CACHE[key] = None
-    return _BASIS_CACHE[key]
+    """Cached per live index tensor; None when the table is not a regular permutation group action (then the
+    12-neighbour forms are used) or the anchor count does not fit the transform kernel."""
+    return _BASIS_CACHE.get(intra_idx32, _make_basis)
 
 
 def _basis_call(lib, src, M, basis, pts, c, in_spec, out_spec, dst, kind):
@@ -591,18 +581,21 @@ class FromSpectralFn(torch.autograd.Function):
 
 
 class _BlockGemmsFn(torch.autograd.Function):
-    """All irreducible blocks of one layer: Z^rho = Y^rho @ What^rho on the BLAS library, written straight into the
-    slices of ONE spectral output buffer (no concatenation), and likewise for the data gradient; forward and both
-    gradients are timed like every other kernel of the path."""
+    """All irreducible blocks of one layer: Z^rho = Y^rho @ What^rho as ONE grouped launch of the library's NT GEMM
+    kernel (csrc/gemm.hip), written straight into the slices of one spectral output buffer (no concatenation), and
+    likewise for the data gradient; the weight gradients are TN GEMMs (deterministic split over the points).
+    whats[i]: What^rho [d*cin, d*cout]."""
 
     @staticmethod
     def forward(ctx, y, basis, pts, cin, cout, *whats):
-        z = torch.empty(basis.na * pts * cout, dtype=torch.float32, device=y.device)
+        z = torch.empty(basis.na * pts * cout, dtype=y.dtype, device=y.device)
+        probs, fl = [], 0.0
         for d, base, wh in zip(basis.dims, basis.bases, whats):
             A = y[base * pts * cin:(base + d * d) * pts * cin].view(pts * d, d * cin)
             O = z[base * pts * cout:(base + d * d) * pts * cout].view(pts * d, d * cout)
-            _launch("intra_gemm", ("mm", pts * d, d * cin, d * cout), 2.0 * pts * d * d * cin * d * cout, y.device,
-                    lambda: torch.mm(A, wh, out=O))
+            probs.append((A, gemm.transpose_cast(wh, y.dtype), O))          # Bt = What^T [d*cout, d*cin]
+            fl += 2.0 * pts * d * d * cin * d * cout
+        _launch("intra_gemm", ("spectral", pts, cin, cout), fl, y.device, lambda: gemm.gemm_nt_grouped(probs))
         ctx.save_for_backward(y, *whats)
         ctx.cfg = (basis, pts, cin, cout)
         return z
@@ -613,28 +606,29 @@ class _BlockGemmsFn(torch.autograd.Function):
         basis, pts, cin, cout = ctx.cfg
         gz = gz.contiguous()
         gy = torch.empty_like(y) if ctx.needs_input_grad[0] else None
-        gws = []
+        gws, probs, fl = [], [], 0.0
         for bi, (d, base, wh) in enumerate(zip(basis.dims, basis.bases, whats)):
             A = y[base * pts * cin:(base + d * d) * pts * cin].view(pts * d, d * cin)
             G = gz[base * pts * cout:(base + d * d) * pts * cout].view(pts * d, d * cout)
-            fl = 2.0 * pts * d * d * cin * d * cout
+            f1 = 2.0 * pts * d * d * cin * d * cout
             if gy is not None:
                 gA = gy[base * pts * cin:(base + d * d) * pts * cin].view(pts * d, d * cin)
-                _launch("intra_gemm", ("mm_dA", pts * d, d * cin, d * cout), fl, y.device,
-                        lambda: torch.mm(G, wh.t(), out=gA))
+                probs.append((G, gemm.cast(wh, y.dtype), gA))               # dY = dZ What^T: Bt = What [d*cin, d*cout]
+                fl += f1
             if ctx.needs_input_grad[5 + bi]:
-                gws.append(_launch("intra_gemm", ("mm_dB", pts * d, d * cin, d * cout), fl, y.device,
-                                   lambda: torch.mm(A.t(), G)))
+                gws.append(_launch("intra_gemm_dw", ("spectral_dw", pts * d, d * cin, d * cout), f1, y.device,
+                                   lambda: gemm.gemm_tn(A, G)))
             else:
                 gws.append(None)
+        if probs:
+            _launch("intra_gemm", ("spectral_dA", pts, cin, cout), fl, y.device, lambda: gemm.gemm_nt_grouped(probs))
         return (gy, None, None, None, None, *gws)
 
 
 def intra_so3conv_spectral(feats, W, intra_idx32, basis):
     """IntraSO3Conv.forward (vgtk/vgtk/so3conv/modules.py:197-200) in the block-diagonal anchor basis: same result up to
     fp32 rounding, 244 instead of 720 multiply-adds per (point, cin, cout), no [cols, 12*cin] grouped tensor; gradients
-    by autograd through the same pieces (GEMMs on the library, transforms on the HIP kernel)."""
-    use_tuned_gemms()
+    by autograd through the same pieces (GEMMs and transforms on this library's HIP kernels)."""
     f = to_cl(feats)
     b, cin, p, na = f.shape
     cout, kn = W.shape[0], intra_idx32.shape[1]
@@ -643,7 +637,7 @@ def intra_so3conv_spectral(feats, W, intra_idx32, basis):
     pts = b * p
     y = ToSpectralFn.apply(f, basis)
     # What^rho[(j, c), (i, o)] = sum_k W[o, c, k] rho(g_k)[i, j]: one small GEMM for all blocks, then a re-layout each
-    wh_all = torch.mm(W.reshape(cout * cin, kn), basis.rho_all)              # [cout*cin, na]
+    wh_all = gemm.matmul_nt(W.reshape(cout * cin, kn), basis.rho_all_t)     # [cout*cin, na]
     whats = [wh_all[:, base:base + d * d].reshape(cout, cin, d, d).permute(3, 1, 2, 0).reshape(d * cin, d * cout)
              for d, base in zip(basis.dims, basis.bases)]
     z = _BlockGemmsFn.apply(y, basis, pts, cin, cout, *whats)
@@ -731,10 +725,15 @@ def norm_act(x, norm, residual=None, slope=0.01, conv_bias=None):
             var = (sums[0, :, 1] / n - mean * mean).clamp_min_(0) * (n / max(n - 1, 1))   # unbiased, as BatchNorm stores
             if conv_bias is not None:
                 mean = mean + conv_bias
-            m = norm.momentum if norm.momentum is not None else 0.1
-            norm.running_mean.mul_(1 - m).add_(mean, alpha=m)
-            norm.running_var.mul_(1 - m).add_(var, alpha=m)
             norm.num_batches_tracked += 1
+            # momentum=None: cumulative moving average, as torch.nn.modules.batchnorm._BatchNorm.forward
+            if norm.momentum is not None:
+                norm.running_mean.mul_(1 - norm.momentum).add_(mean, alpha=norm.momentum)
+                norm.running_var.mul_(1 - norm.momentum).add_(var, alpha=norm.momentum)
+            else:                                                  # device-side weight: no host sync (graph capture)
+                m = norm.num_batches_tracked.to(mean.dtype).reciprocal()
+                norm.running_mean.lerp_(mean, m)
+                norm.running_var.lerp_(var, m)
     return y
 
 
@@ -849,16 +848,10 @@ def _identity_index(na, device):
 
 def conv1x1(x, weight, bias=None):
     """nn.Conv2d(cin, cout, 1) on a [b,c,p,a] tensor, channels-last in and out with no layout copy.
-    EPN_CONV1X1 = kernel (default): the intra GEMM kernel with a single, identity anchor neighbour;
-                  blas: a plain row-major GEMM [cols, cin] x [cin, cout] (+ bias) on a zero-copy 2-D view.
+    Runs on the intra GEMM kernel with a single, identity anchor neighbour.
     Shapes the MFMA kernel does not take (cin = 1 of the first block, the few-channel heads) go to torch."""
     cout, cin = weight.shape[0], weight.shape[1]
     if x.is_cuda and cin % 16 == 0 and cout % 16 == 0:
-        if os.environ.get("EPN_CONV1X1", "kernel") == "blas":
-            xc = to_cl(x)
-            b, c, p, a = xc.shape
-            y2d = torch.nn.functional.linear(xc.permute(0, 2, 3, 1).reshape(-1, c), weight.reshape(cout, cin), bias)
-            return y2d.view(b, p, a, cout).permute(0, 3, 1, 2)
         y = IntraSO3ConvFn.apply(x, weight.reshape(cout, cin), _identity_index(x.shape[3], x.device))
     elif x.is_cuda and cin == 1:
         # single input channel (the occupancy feature of the first block): an outer product, written channels-last

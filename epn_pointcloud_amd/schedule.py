@@ -5,8 +5,8 @@ numbers below restate that arithmetic (SURVEY.md 8a "per-layer schedule", verifi
 instantiated reference builders).  `HotPathBackbone` chains InterSO3Conv -> IntraSO3Conv exactly as
 SeparableSO3ConvBlock does (SPConvNets/utils/base_so3conv.py:168-212: inter conv, norm, leaky_relu,
 intra conv, InstanceNorm, leaky_relu, strided skip + 1x1 conv + norm + leaky_relu, add) so that bench.py
-and the tests exercise the real call pattern; the norm / activation / skip glue are plain torch ops
-(fusing them is a "next" row), the convolutions are the fused HIP kernels.
+and the tests exercise the real call pattern; the norm / activation / skip glue run
+on the HIP block-glue kernels (csrc/glue.hip) in FusedSeparableBlock, stock torch modules in SeparableBlock.
 """
 import math
 from collections import namedtuple
@@ -103,7 +103,13 @@ class SeparableBlock(nn.Module):
         self.stride = l.stride
         self.inter_conv = _ConvNorm(sptk.InterSO3Conv(l.cin, l.cout, 1, l.stride, l.radius, l.sigma, l.nn,
                                                       lazy_sample=l.lazy, kanchor=kanchor), mk(l.cout))
-        self.intra_conv = _ConvNorm(sptk.IntraSO3Conv(l.cout, l.cout), nn.InstanceNorm2d(l.cout, affine=False))
+        self.use_intra = kanchor > 1           # SeparableSO3ConvBlock.use_intra (base_so3conv.py:177)
+        if self.use_intra:
+            if kanchor != 60:
+                raise NotImplementedError(
+                    f"SeparableSO3ConvBlock with kanchor={kanchor}: IntraSO3Conv always uses the 60-anchor table "
+                    "(vgtk/vgtk/so3conv/modules.py:186); the reference builders pick 'inter_block' for kanchor != 60")
+            self.intra_conv = _ConvNorm(sptk.IntraSO3Conv(l.cout, l.cout), nn.InstanceNorm2d(l.cout, affine=False))
         self.skip_conv = nn.Conv2d(l.cin, l.cout, 1)
         self.norm = mk(l.cout)
         self.dropout = nn.Dropout(dropout_rate) if dropout_rate > 0 else None
@@ -115,8 +121,10 @@ class SeparableBlock(nn.Module):
         skip = x.feats
         inter_idx, inter_w, sample_idx, y = self.inter_conv.conv(x, inter_idx, inter_w)
         feat = self._drop(F.leaky_relu(self.inter_conv.norm(y.feats)))
-        z = self.intra_conv.conv(zptk.SphericalPointCloud(y.xyz, feat, y.anchors))
-        feat = self._drop(F.leaky_relu(self.intra_conv.norm(z.feats)))
+        z = y
+        if self.use_intra:
+            z = self.intra_conv.conv(zptk.SphericalPointCloud(y.xyz, feat, y.anchors))
+            feat = self._drop(F.leaky_relu(self.intra_conv.norm(z.feats)))
         if self.stride > 1:
             skip = zptk.functional.batched_index_select(skip, 2, sample_idx.long())
         skip = F.leaky_relu(self.norm(self.skip_conv(skip)))
@@ -130,8 +138,8 @@ class FusedSeparableBlock(SeparableBlock):
     Training-mode semantics (batch statistics); eval mode and dropout fall back to the stock modules."""
 
     def forward(self, x, inter_idx=None, inter_w=None):
-        c_out = self.intra_conv.conv.dim_out
-        if (not self.training) or self.dropout is not None or not ops.norm_act_supported(c_out):
+        c_out = self.inter_conv.conv.dim_out
+        if (not self.training) or self.dropout is not None or not ops.norm_act_supported(c_out) or not self.use_intra:
             return super().forward(x, inter_idx, inter_w)
         import os
         skip = x.feats
@@ -167,13 +175,50 @@ class FusedSeparableBlock(SeparableBlock):
         return inter_idx, inter_w, sample_idx, zptk.SphericalPointCloud(z.xyz, out, z.anchors)
 
 
+class InterBlock(nn.Module):
+    """InterSO3ConvBlock (SPConvNets/utils/base_so3conv.py:87-126): InterSO3Conv -> norm -> leaky_relu (-> dropout), no
+    intra convolution and no skip branch -- the block type the reference builders choose when kanchor != 60
+    (cls_so3net_pn.py:127 `na < 60`, reg_so3net.py:139 / inv_so3net_pn.py:139 `na != 60`).  state_dict: `conv.*`, `norm.*`."""
+
+    def __init__(self, l, kanchor=60, norm="BatchNorm2d", dropout_rate=0.0):
+        super().__init__()
+        self.stride = l.stride
+        self.conv = sptk.InterSO3Conv(l.cin, l.cout, 1, l.stride, l.radius, l.sigma, l.nn, lazy_sample=l.lazy,
+                                      kanchor=kanchor)
+        self.norm = nn.InstanceNorm2d(l.cout, affine=False) if norm is None else getattr(nn, norm)(l.cout)
+        self.dropout = nn.Dropout(dropout_rate) if dropout_rate > 0 else None
+
+    def forward(self, x, inter_idx=None, inter_w=None):
+        inter_idx, inter_w, sample_idx, y = self.conv(x, inter_idx, inter_w)
+        if self.training and self.dropout is None and y.feats.is_cuda and ops.norm_act_supported(y.feats.shape[1]):
+            feat = ops.norm_act(y.feats, self.norm)
+        else:
+            feat = F.leaky_relu(self.norm(y.feats))
+            if self.training and self.dropout is not None:
+                feat = self.dropout(feat)
+        return inter_idx, inter_w, sample_idx, zptk.SphericalPointCloud(y.xyz, feat, y.anchors)
+
+
+def block_type(kanchor, model="cls"):
+    """'inter_block' | 'separable_block' exactly as the reference builders decide (cls_so3net_pn.py:127: na < 60;
+    reg_so3net.py:139, inv_so3net_pn.py:139: na != 60)."""
+    inter_only = kanchor < 60 if model == "cls" else kanchor != 60
+    return "inter_block" if inter_only else "separable_block"
+
+
 class BasicBlock(nn.Module):
     """One resolution stage = BasicSO3ConvBlock (base_so3conv.py:129-166): `.blocks`, the (inter_idx, inter_w) of a
     block handed to the next one until a strided block resets them."""
 
-    def __init__(self, layers, kanchor=60, norm="BatchNorm2d", fused_glue=True, dropout_rate=0.0):
+    def __init__(self, layers, kanchor=60, norm="BatchNorm2d", fused_glue=True, dropout_rate=0.0,
+                 btype="separable_block"):
         super().__init__()
-        blk = FusedSeparableBlock if fused_glue else SeparableBlock
+        if btype == "inter_block":
+            blk = InterBlock
+        elif btype == "separable_block":
+            blk = FusedSeparableBlock if fused_glue else SeparableBlock
+        else:
+            raise ValueError(f"No such type of SO3Conv {btype}")
         self.blocks = nn.ModuleList([blk(l, kanchor, norm, dropout_rate) for l in layers])
 
     def forward(self, x):
@@ -208,10 +253,11 @@ class HotPathBackbone(nn.Module):
     """preprocess_input (ones features) -> stages of separable blocks, with the reference models' `backbone.{i}.blocks.{j}`
     module tree.  Input [b, n, 3] point clouds."""
 
-    def __init__(self, layers, kanchor=60, norm="BatchNorm2d", fused_glue=True, dropout_rate=0.0):
+    def __init__(self, layers, kanchor=60, norm="BatchNorm2d", fused_glue=True, dropout_rate=0.0, model="cls"):
         super().__init__()
         self.kanchor = kanchor
-        self.backbone = nn.ModuleList([BasicBlock(st, kanchor, norm, fused_glue, dropout_rate) for st in stages(layers)])
+        self.backbone = nn.ModuleList([BasicBlock(st, kanchor, norm, fused_glue, dropout_rate,
+                                                  block_type(kanchor, model)) for st in stages(layers)])
 
     def forward(self, pts):
         x = preprocess_input(pts, self.kanchor)

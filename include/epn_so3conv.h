@@ -3,7 +3,7 @@
  *
  * Drop-in boundary for the EPN SE(3) separable point-convolution hot path.  Every entry point is
  * `extern "C"`, takes plain DEVICE pointers + sizes + a HIP stream (passed as void*), launches
- * asynchronously on that stream, owns no memory and keeps no global state (thread-safe).  Return
+ * asynchronously on that stream, owns no memory and keeps no global state other than epn_set_kernel_policy (thread-safe).  Return
  * value: 0 on success, otherwise a hipError_t code (launch errors) or a negative EPN_E* code
  * (argument errors).  `epn_strerror` turns either into text.
  *
@@ -35,6 +35,10 @@ typedef void *epn_stream_t; /* hipStream_t; NULL = the null stream */
 
 const char *epn_version(void);
 const char *epn_strerror(int code);
+/* Cross-check switch, the library's only process-wide state (a relaxed atomic; default 0): 0 = every entry point picks
+ * its best kernel, 1 = the any-shape generic kernels everywhere (an independent on-device implementation used by the
+ * parity tests).  Not for production use; set it before launching from other threads. */
+int epn_set_kernel_policy(int policy);
 
 /* ------------------------------------------------------------------ index kernels ---------- */
 

@@ -229,11 +229,9 @@ def test_generic_and_fused_kernels_agree(gpu, vgtk_alias, inter_mode):
         return [y.feats.detach(), z.feats.detach()] + [t.detach() for t in g]
 
     fused = run()
-    os.environ["EPN_FORCE_GENERIC"] = "1"
-    try:
+    from epn_pointcloud_amd import _lib
+    with _lib.generic_kernels():
         generic = run()
-    finally:
-        del os.environ["EPN_FORCE_GENERIC"]
     for a, b in zip(fused, generic):
         assert (a - b).abs().max().item() < TOL * max(1.0, b.abs().max().item())
 

@@ -19,14 +19,6 @@ def close(got, want, tol=TOL):
     return (got.detach().cpu() - want).abs().max().item() <= tol * max(1.0, want.abs().max().item())
 
 
-@pytest.fixture(scope="module")
-def gpu():
-    assert torch.cuda.is_available()
-    from epn_pointcloud_amd import _lib
-    _lib.get_lib()
-    return torch.device("cuda", 0)
-
-
 def grad_close(got, want, rel=3e-2):
     """Network-level gradients cross discrete routing decisions -- the arg-max point of PointnetSO3Conv, the sign of
     every leaky_relu input -- and a 1e-4 feature difference flips a few near-ties, each moving the gradient by a finite

@@ -84,11 +84,3 @@ def test_lazy_sample_index_and_occupancy(vgtk_alias):
     assert tuple(f.shape) == (2, 1, 16, 60) and (f == 1).all()
     f = sptk.get_occupancy_features(torch.rand(2, 16, 3), 60, use_center=True)
     assert (f[:, :, 0] == 0).all() and (f[:, :, 1:] == 1).all()
-
-
-def test_lr_scheduler(vgtk_alias):
-    import vgtk
-    opt = torch.optim.SGD([torch.nn.Parameter(torch.zeros(1))], lr=1e-3)
-    s = vgtk.LearningRateScheduler(opt, 1e-3, "exp_decay", 2, decay_rate=0.5)
-    lrs = [s.step() for _ in range(4)]
-    assert lrs == [1e-3, 5e-4, 5e-4, 2.5e-4] and opt.param_groups[0]["lr"] == 2.5e-4
