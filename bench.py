@@ -31,7 +31,8 @@ KERNEL_OF = {  # C-ABI call -> device kernel family it launches on this workload
     "inter_bwd_weight": "epn::inter_bwd_weight8_kernel", "intra_fwd": "epn::intra_gemm_kernel",
     "intra_bwd_data": "epn::intra_gemm_kernel", "intra_bwd_weight": "epn::intra_bwd_weight_pt_kernel",
     "inter_group": "epn::inter_group_kernel", "inter_ungroup": "epn::inter_ungroup_kernel",
-    "inter_gemm": BLAS_FAMILY, "intra_gemm": BLAS_FAMILY,
+    "inter_gemm": "epn::gemm_nt_kernel", "intra_gemm": "epn::gemm_nt_kernel",
+    "inter_gemm_dw": "epn::gemm_tn_f32_kernel", "intra_gemm_dw": "epn::gemm_tn_f32_kernel",
     "intra_group": "epn::intra_group_kernel", "so3_basis": "epn::so3_basis_kernel",
     "pointnet_fwd": "epn::pointnet_fwd_kernel", "pointnet_bwd_data": "epn::pointnet_bwd_data_kernel",
     "pointnet_bwd_weight": "epn::pointnet_bwd_weight_kernel",
@@ -241,7 +242,7 @@ def main():
         # ---- roofline of the dominant kernel, from HIP events recorded around its launches in the timed region
         agg = {}
         for kind, key, flops, e0, e1 in records:
-            k = KERNEL_OF[kind]
+            k = KERNEL_OF.get(kind, kind)
             if kind.startswith("inter") and key[6] == 1:      # cin = 1 (first layer): dedicated kernels
                 k = {"inter_fwd": "epn::inter_c1_fwd_kernel", "inter_bwd_weight": "epn::inter_c1_bwd_weight_kernel"}.get(kind, k)
             a = agg.setdefault(k, {"ms": 0.0, "flops": 0.0, "launches": 0})

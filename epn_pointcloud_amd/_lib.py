@@ -25,6 +25,8 @@ EXPORTS = [
     "epn_pointnet_so3conv_fwd_f32", "epn_pointnet_so3conv_bwd_data_f32", "epn_pointnet_so3conv_bwd_weight_f32",
     "epn_gemm_nt_f32", "epn_gemm_nt_bf16", "epn_gemm_tn_workspace_bytes", "epn_gemm_tn_f32", "epn_gemm_tn_bf16",
     "epn_transpose_cast", "epn_cast",
+    "epn_inter_group_bf16", "epn_inter_ungroup_bf16", "epn_intra_group_bf16", "epn_so3_basis_bf16",
+    "epn_chan_stats_bf16", "epn_norm_act_fwd_bf16", "epn_norm_act_bwd_reduce_bf16", "epn_norm_act_bwd_apply_bf16",
 ]
 
 _vp, _ci, _cf, _sz = ctypes.c_void_p, ctypes.c_int, ctypes.c_float, ctypes.c_size_t
@@ -108,6 +110,15 @@ def get_lib():
     lib.epn_gemm_tn_bf16.argtypes = [_vp, _ll, _vp, _ll, _vp, _ll, _ll, _ci, _ci, _vp, _sz, _vp]
     lib.epn_transpose_cast.argtypes = [_vp, _vp, _ci, _ci, _ci, _ci, _vp]
     lib.epn_cast.argtypes = [_vp, _vp, _sz, _ci, _ci, _vp]
+    # the bf16 twins share their fp32 counterparts' signatures (void* feature pointers)
+    lib.epn_inter_group_bf16.argtypes = lib.epn_inter_group_f32.argtypes
+    lib.epn_inter_ungroup_bf16.argtypes = lib.epn_inter_ungroup_f32.argtypes
+    lib.epn_intra_group_bf16.argtypes = lib.epn_intra_group_f32.argtypes
+    lib.epn_so3_basis_bf16.argtypes = lib.epn_so3_basis_f32.argtypes
+    lib.epn_chan_stats_bf16.argtypes = lib.epn_chan_stats_f32.argtypes
+    lib.epn_norm_act_fwd_bf16.argtypes = lib.epn_norm_act_fwd_f32.argtypes
+    lib.epn_norm_act_bwd_reduce_bf16.argtypes = lib.epn_norm_act_bwd_reduce_f32.argtypes
+    lib.epn_norm_act_bwd_apply_bf16.argtypes = lib.epn_norm_act_bwd_apply_f32.argtypes
     for name in EXPORTS:
         getattr(lib, name)  # AttributeError here = header/library mismatch
         if name.endswith("_f32") or name.endswith("_bf16") or name in ("epn_transpose_cast", "epn_cast"):

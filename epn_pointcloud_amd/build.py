@@ -42,7 +42,8 @@ def build(force=False, verbose=False):
     with concurrent.futures.ThreadPoolExecutor(max_workers=min(8, len(srcs))) as ex:
         results = list(ex.map(lambda s: _compile(s, force), srcs))
     objs = [o for o, _ in results]
-    if force or any(c for _, c in results) or not os.path.exists(LIB):
+    stale = not os.path.exists(LIB) or any(os.path.getmtime(o) > os.path.getmtime(LIB) for o in objs)
+    if force or stale or any(c for _, c in results):
         subprocess.check_call([HIPCC, "--offload-arch=" + ARCH, "-shared", "-fPIC", "-o", LIB] + objs)
         if verbose:
             print("linked", LIB)

@@ -11,8 +11,10 @@ using namespace epn;
 static std::atomic<int> g_policy{0};   // the library's only process-wide state: 0 = best kernel, 1 = generic kernels
 static bool force_generic() { return g_policy.load(std::memory_order_relaxed) == 1; }
 
+namespace epn { int kernel_policy() { return g_policy.load(std::memory_order_relaxed); } }
+
 extern "C" int epn_set_kernel_policy(int policy) {
-    if (policy != 0 && policy != 1) return EPN_EINVAL;
+    if (policy != 0 && policy != 1 && (policy & ~0xff) != 0x100) return EPN_EINVAL;   // 0x100 | cfg: tools/gemm_bench.py
     g_policy.store(policy, std::memory_order_relaxed);
     return 0;
 }
@@ -180,8 +182,8 @@ static int prep_tables(const epn_inter_desc *d, void *workspace, size_t bytes, I
     return launch_rk_table(d, base + ws.rk_off, st);
 }
 
-extern "C" int epn_inter_group_f32(const epn_inter_desc *d, const float *feats_cl, float *grouped, void *workspace,
-                                   size_t workspace_bytes, epn_stream_t stream) {
+static int inter_group_any(const epn_inter_desc *d, const void *feats_cl, void *grouped, void *workspace,
+                           size_t workspace_bytes, int bf16, epn_stream_t stream) {
     hipStream_t st = epn_stream(stream);
     InterWs ws;
     float *base = nullptr;
@@ -192,13 +194,14 @@ extern "C" int epn_inter_group_f32(const epn_inter_desc *d, const float *feats_c
     if (inter_group_mfma_ok(d) && !force_generic()) {
         rc = launch_inter_tables_mfma(d, base + ws.rk_off, base + ws.rk4_off, base + ws.beta_off, st);
         if (rc) return rc;
-        return launch_inter_group_mfma(d, base + ws.rk4_off, feats_cl, grouped, st);
+        return launch_inter_group_mfma(d, base + ws.rk4_off, feats_cl, grouped, bf16, st);
     }
-    return launch_inter_group(d, base + ws.rk_off, feats_cl, grouped, st);
+    if (bf16) return EPN_EINVAL;   // the bf16 feature path needs cin % 16 == 0 (every layer but the first, which is c1)
+    return launch_inter_group(d, base + ws.rk_off, static_cast<const float *>(feats_cl), static_cast<float *>(grouped), st);
 }
 
-extern "C" int epn_inter_ungroup_f32(const epn_inter_desc *d, const float *grad_grouped, float *grad_feats_cl,
-                                     void *workspace, size_t workspace_bytes, epn_stream_t stream) {
+static int inter_ungroup_any(const epn_inter_desc *d, const void *grad_grouped, float *grad_feats_cl, void *workspace,
+                             size_t workspace_bytes, int bf16, epn_stream_t stream) {
     hipStream_t st = epn_stream(stream);
     InterWs ws;
     float *base = nullptr;
@@ -211,9 +214,27 @@ extern "C" int epn_inter_ungroup_f32(const epn_inter_desc *d, const float *grad_
     if (inter_group_mfma_ok(d) && !force_generic()) {
         rc = launch_inter_tables_mfma(d, base + ws.rk_off, base + ws.rk4_off, base + ws.beta_off, st);
         if (rc) return rc;
-        return launch_inter_ungroup_mfma(d, base + ws.rk4_off, grad_grouped, grad_feats_cl, st);
+        return launch_inter_ungroup_mfma(d, base + ws.rk4_off, grad_grouped, grad_feats_cl, bf16, st);
     }
-    return launch_inter_scatter(d, base + ws.rk_off, grad_grouped, grad_feats_cl, st);
+    if (bf16) return EPN_EINVAL;
+    return launch_inter_scatter(d, base + ws.rk_off, static_cast<const float *>(grad_grouped), grad_feats_cl, st);
+}
+
+extern "C" int epn_inter_group_f32(const epn_inter_desc *d, const float *feats_cl, float *grouped, void *workspace,
+                                   size_t workspace_bytes, epn_stream_t stream) {
+    return inter_group_any(d, feats_cl, grouped, workspace, workspace_bytes, 0, stream);
+}
+extern "C" int epn_inter_group_bf16(const epn_inter_desc *d, const void *feats_cl, void *grouped, void *workspace,
+                                    size_t workspace_bytes, epn_stream_t stream) {
+    return inter_group_any(d, feats_cl, grouped, workspace, workspace_bytes, 1, stream);
+}
+extern "C" int epn_inter_ungroup_f32(const epn_inter_desc *d, const float *grad_grouped, float *grad_feats_cl,
+                                     void *workspace, size_t workspace_bytes, epn_stream_t stream) {
+    return inter_ungroup_any(d, grad_grouped, grad_feats_cl, workspace, workspace_bytes, 0, stream);
+}
+extern "C" int epn_inter_ungroup_bf16(const epn_inter_desc *d, const void *grad_grouped, float *grad_feats_cl,
+                                      void *workspace, size_t workspace_bytes, epn_stream_t stream) {
+    return inter_ungroup_any(d, grad_grouped, grad_feats_cl, workspace, workspace_bytes, 1, stream);
 }
 
 static int check_intra(int b, int p, int na, int kn, int cin, int cout) {

@@ -67,8 +67,11 @@ static inline bool inter_group_mfma_ok(const epn_inter_desc *d) {
     return inter_mfma_available() && !d->dense_w && d->cin % 16 == 0 && d->ks <= EPN_KS_MAX && d->ks % 4 == 0 &&
            d->nn <= EPN_NN_MAX && (long long)d->p1 * d->na * d->cin < (1LL << 31);
 }
-int launch_inter_group_mfma(const epn_inter_desc *d, const float *rk4, const float *feats, float *G, hipStream_t st);
-int launch_inter_ungroup_mfma(const epn_inter_desc *d, const float *rk4, const float *dG, float *dF, hipStream_t st);
+// bf16 != 0: feats / G (group) and dG (ungroup) are bf16; the scatter target dF is fp32 either way
+int launch_inter_group_mfma(const epn_inter_desc *d, const float *rk4, const void *feats, void *G, int bf16,
+                            hipStream_t st);
+int launch_inter_ungroup_mfma(const epn_inter_desc *d, const float *rk4, const void *dG, float *dF, int bf16,
+                              hipStream_t st);
 bool intra_uses_mfma(int na, int kn, int cin, int cout);
 size_t intra_workspace_floats(int kn, int cin, int cout);
 int launch_intra_fwd_mfma(const float *feats, const int32_t *iidx, const float *W, int b, int p, int na, int kn,

@@ -30,6 +30,8 @@ struct GemmTnArgs {        // C[N1][N2] = X[R][N1]^T . Y[R][N2]
     int tiles_n2, nsplit;
 };
 
+int kernel_policy();   // c_api.hip: epn_set_kernel_policy (0x100 | cfg = NT tile override of the tuning tool)
+
 // dtype / out_dtype: 0 = fp32, 1 = bf16
 int launch_gemm_nt(GemmNtBatch &B, int dtype, int out_dtype, hipStream_t st);
 int launch_gemm_tn(GemmTnArgs &G, int dtype, hipStream_t st);

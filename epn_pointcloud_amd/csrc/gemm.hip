@@ -83,16 +83,19 @@ __global__ __launch_bounds__(64 * WGM * WGN) void gemm_nt_kernel(GemmNtBatch B) 
             src[i] = Bt + (long long)gn * P.ldb + slot * E16;
         }
     }
-    auto stage = [&](int buf) {
-#pragma unroll
-        for (int i = 0; i < GPW; ++i) {
-            const int g = wave + i * NW;
-            if (NG % NW == 0 || g < NG) {
-                glds16(src[i], smem + buf * (ROWS * 128) + g * 1024);
-                src[i] += BKE;
-            }
+    auto stage_one = [&](int buf, int i) {
+        const int g = wave + i * NW;
+        if (NG % NW == 0 || g < NG) {
+            glds16(src[i], smem + buf * (ROWS * 128) + g * 1024);
+            src[i] += BKE;
         }
     };
+    auto stage = [&](int buf) {
+#pragma unroll
+        for (int i = 0; i < GPW; ++i) stage_one(buf, i);
+    };
+    // waves w and w + 4 of an 8-wave workgroup share a SIMD: their loads go to alternating MFMA groups (below)
+    const int wpar = NW == 8 ? __builtin_amdgcn_readfirstlane(wave >> 2) : 0;
 
     const int wm = wave / WGN, wn = wave % WGN;
     const int li = lane & 31, lj = lane >> 5;
@@ -112,28 +115,59 @@ __global__ __launch_bounds__(64 * WGM * WGN) void gemm_nt_kernel(GemmNtBatch B) 
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
+    // One barrier per K step.  A direct-to-LDS load costs its wave ~60-180 cycles of issue during which it feeds no MFMA,
+    // and the two waves of a SIMD leave the barrier together: issued as one burst (wherever in the step) both waves
+    // stall at once and the matrix pipe idles ~7 % (measured, tools/gemm_lab).  So the next stage's loads are spread
+    // one per MFMA group over the step, the partner waves on alternating groups (sched_barrier pins the placement; left
+    // alone the compiler hoists all of them in front of the first ds_read).  fp32: +3 % over the burst; bf16 is
+    // HBM-bound on these shapes and keeps the burst.
+    constexpr int NGRP = 16;                   // fp32: MFMA groups per K step (4 fragment steps x 4 contraction pairs)
     stage(0);
     for (int kt = 0; kt < nk; ++kt) {
         __syncthreads();                       // stage kt has landed (vmcnt(0) rides on the barrier); buffer (kt+1)&1 is free
-        if (kt + 1 < nk) stage((kt + 1) & 1);
         const char *base = smem + (kt & 1) * (ROWS * 128);
+        const bool more = kt + 1 < nk;
+        if constexpr (sizeof(T) != 4) {
+            if (more) stage((kt + 1) & 1);
+        }
+        if constexpr (sizeof(T) == 4) {
+            // fragments of step s+1 are read while the MFMAs of step s issue (two register sets, static indices)
+            f32x4 a[2][TM], b[2][TN];
+            auto rd = [&](int s, int set) {
+                const int so = ((2 * s + lj) ^ fsw) * 16;
 #pragma unroll
-        for (int s = 0; s < 4; ++s) {
-            const int so = ((2 * s + lj) ^ fsw) * 16;
-            if constexpr (sizeof(T) == 4) {
-                f32x4 a[TM], b[TN];
+                for (int i = 0; i < TM; ++i) a[set][i] = *reinterpret_cast<const f32x4 *>(base + aoff[i] + so);
 #pragma unroll
-                for (int i = 0; i < TM; ++i) a[i] = *reinterpret_cast<const f32x4 *>(base + aoff[i] + so);
+                for (int i = 0; i < TN; ++i) b[set][i] = *reinterpret_cast<const f32x4 *>(base + boff[i] + so);
+            };
+            rd(0, 0);
 #pragma unroll
-                for (int i = 0; i < TN; ++i) b[i] = *reinterpret_cast<const f32x4 *>(base + boff[i] + so);
+            for (int s = 0; s < 4; ++s) {
+                if (s + 1 < 4) rd(s + 1, (s + 1) & 1);
 #pragma unroll
-                for (int e = 0; e < 4; ++e)
+                for (int e = 0; e < 4; ++e) {
+                    __builtin_amdgcn_sched_barrier(0);
+                    if (more) {
+                        const int grp = 4 * s + e;
+#pragma unroll
+                        for (int i = 0; i < GPW; ++i) {
+                            const int g0 = 1 + (i * (NGRP - 2)) / GPW;             // group of load i, first wave of a SIMD
+                            const int g1 = g0 + 1 < NGRP ? g0 + 1 : NGRP - 1;      // ... its partner, one group later
+                            if ((g0 == grp && wpar == 0) || (g1 == grp && wpar != 0)) stage_one((kt + 1) & 1, i);
+                        }
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
                     for (int i = 0; i < TM; ++i)
 #pragma unroll
                         for (int j = 0; j < TN; ++j)
-                            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i][e], b[j][e], acc[i][j], 0, 0, 0);
-            } else {
+                            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[s & 1][i][e], b[s & 1][j][e], acc[i][j], 0, 0, 0);
+                }
+            }
+        } else {
+#pragma unroll
+            for (int s = 0; s < 4; ++s) {
+                const int so = ((2 * s + lj) ^ fsw) * 16;
                 bf16x8 a[TM], b[TN];
 #pragma unroll
                 for (int i = 0; i < TM; ++i) a[i] = *reinterpret_cast<const bf16x8 *>(base + aoff[i] + so);
@@ -213,16 +247,18 @@ __global__ __launch_bounds__(64 * WGM * WGN) void gemm_tn_f32_kernel(GemmTnArgs 
             sstep[i] = (long long)BR * G.ldy;
         }
     }
-    auto stage = [&](int buf) {
-#pragma unroll
-        for (int i = 0; i < IPW; ++i) {
-            const int q = wave + i * NW;
-            if (NI % NW == 0 || q < NI) {
-                glds16(src[i], smem + buf * STAGE_B + q * 1024);
-                src[i] += sstep[i];
-            }
+    auto stage_one = [&](int buf, int i) {
+        const int q = wave + i * NW;
+        if (NI % NW == 0 || q < NI) {
+            glds16(src[i], smem + buf * STAGE_B + q * 1024);
+            src[i] += sstep[i];
         }
     };
+    auto stage = [&](int buf) {
+#pragma unroll
+        for (int i = 0; i < IPW; ++i) stage_one(buf, i);
+    };
+    const int wpar = NW == 8 ? __builtin_amdgcn_readfirstlane(wave >> 2) : 0;   // SIMD partner parity (gemm_nt_kernel)
 
     const int wm = wave / WGN, wn = wave % WGN;
     const int li = lane & 31, lj = lane >> 5;
@@ -240,35 +276,51 @@ __global__ __launch_bounds__(64 * WGM * WGN) void gemm_tn_f32_kernel(GemmTnArgs 
     if (nk > 0) stage(0);
     for (int kt = 0; kt < nk; ++kt) {
         __syncthreads();
-        if (kt + 1 < nk) stage((kt + 1) & 1);
         const char *base = smem + (kt & 1) * STAGE_B;
-#pragma unroll
-        for (int s = 0; s < BR / 2; ++s) {
+        const bool more = kt + 1 < nk;
+        // fragments of k-pair s+1 are read while the MFMAs of pair s issue (two register sets, static indices)
+        float a[2][TM], b[2][TN];
+        auto rd = [&](int s, int set) {
             const char *row = base + (2 * s + lj) * (ROWF * 4);
-            float a[TM], b[TN];
             if constexpr (TM == 4) {
                 const f32x4 v = *reinterpret_cast<const f32x4 *>(row + xo);
-                a[0] = v[0]; a[1] = v[1]; a[2] = v[2]; a[3] = v[3];
+                a[set][0] = v[0]; a[set][1] = v[1]; a[set][2] = v[2]; a[set][3] = v[3];
             } else if constexpr (TM == 2) {
                 const f32x2 v = *reinterpret_cast<const f32x2 *>(row + xo);
-                a[0] = v[0]; a[1] = v[1];
+                a[set][0] = v[0]; a[set][1] = v[1];
             } else {
-                a[0] = *reinterpret_cast<const float *>(row + xo);
+                a[set][0] = *reinterpret_cast<const float *>(row + xo);
             }
             if constexpr (TN == 4) {
                 const f32x4 v = *reinterpret_cast<const f32x4 *>(row + yo);
-                b[0] = v[0]; b[1] = v[1]; b[2] = v[2]; b[3] = v[3];
+                b[set][0] = v[0]; b[set][1] = v[1]; b[set][2] = v[2]; b[set][3] = v[3];
             } else if constexpr (TN == 2) {
                 const f32x2 v = *reinterpret_cast<const f32x2 *>(row + yo);
-                b[0] = v[0]; b[1] = v[1];
+                b[set][0] = v[0]; b[set][1] = v[1];
             } else {
-                b[0] = *reinterpret_cast<const float *>(row + yo);
+                b[set][0] = *reinterpret_cast<const float *>(row + yo);
             }
+        };
+        rd(0, 0);
+#pragma unroll
+        for (int s = 0; s < BR / 2; ++s) {
+            if (s + 1 < BR / 2) rd(s + 1, (s + 1) & 1);
+            __builtin_amdgcn_sched_barrier(0);
+            if (more) {                         // next stage's loads spread over the step (see gemm_nt_kernel)
+                constexpr int NGRP = BR / 2;
+#pragma unroll
+                for (int i = 0; i < IPW; ++i) {
+                    const int g0 = (i * (NGRP - 1)) / IPW;
+                    const int g1 = g0 + 1 < NGRP ? g0 + 1 : NGRP - 1;
+                    if ((g0 == s && wpar == 0) || (g1 == s && wpar != 0)) stage_one((kt + 1) & 1, i);
+                }
+            }
+            __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
             for (int i = 0; i < TM; ++i)
 #pragma unroll
                 for (int j = 0; j < TN; ++j)
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i], b[j], acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[s & 1][i], b[s & 1][j], acc[i][j], 0, 0, 0);
         }
     }
 
@@ -362,7 +414,6 @@ __global__ __launch_bounds__(64 * WGM * WGN) void gemm_tn_bf16_kernel(GemmTnArgs
     if (nk > 0) stage(0);
     for (int kt = 0; kt < nk; ++kt) {
         __syncthreads();
-        if (kt + 1 < nk) stage((kt + 1) & 1);
         const char *base = smem + (kt & 1) * STAGE_B;
         bf16x8 a[TM], b[TN];
 #pragma unroll
@@ -390,8 +441,14 @@ __global__ __launch_bounds__(64 * WGM * WGN) void gemm_tn_bf16_kernel(GemmTnArgs
 #pragma unroll
         for (int i = 0; i < TM; ++i)
 #pragma unroll
-            for (int j = 0; j < TN; ++j)
+            for (int j = 0; j < TN; ++j) {
                 acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[i], b[j], acc[i][j], 0, 0, 0);
+                if (i == 0 && j == 0) {
+                    __builtin_amdgcn_sched_barrier(0);
+                    if (kt + 1 < nk) stage((kt + 1) & 1);
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+            }
     }
 
     // D[row = 4 lg + r][col = li]
@@ -488,13 +545,14 @@ template <typename T, typename TO>
 int launch_nt_typed(GemmNtBatch &B, hipStream_t st) {
     constexpr int E16 = ElemOf<T>::PER16;
     bool fast = true;
-    int maxn = 0;
+    int maxn = 0, minn = 1 << 30;
     for (int i = 0; i < B.nprob; ++i) {
         const GemmNtProb &p = B.p[i];
         if (p.M < 0 || p.N < 1 || p.K < 1) return EPN_EINVAL;
         if (!p.A || !p.Bt || !p.C) return EPN_ENULL;
         if (p.K % (8 * E16) || p.lda % E16 || p.ldb % E16 || ((uintptr_t)p.A & 15) || ((uintptr_t)p.Bt & 15)) fast = false;
         maxn = p.N > maxn ? p.N : maxn;
+        minn = p.N < minn ? p.N : minn;
     }
     if (!fast) {
         for (int i = 0; i < B.nprob; ++i) {
@@ -508,8 +566,21 @@ int launch_nt_typed(GemmNtBatch &B, hipStream_t st) {
         }
         return 0;
     }
+    const int pol = kernel_policy();
+    if ((pol & ~0xff) == 0x100) {           // tuning override (tools/gemm_bench.py --cfg)
+        switch (pol & 0xff) {
+            case 1: return launch_nt_cfg<T, TO, 4, 2, 2, 2>(B, st);      // 256 x 128, 8 waves
+            case 2: return launch_nt_cfg<T, TO, 4, 2, 2, 4>(B, st);      // 256 x 256, 8 waves
+            case 3: return launch_nt_cfg<T, TO, 2, 2, 2, 2>(B, st);      // 128 x 128, 4 waves (2 workgroups / CU)
+            case 4: return launch_nt_cfg<T, TO, 2, 4, 2, 2>(B, st);      // 128 x 256, 8 waves
+            case 5: return launch_nt_cfg<T, TO, 4, 1, 2, 2>(B, st);      // 256 x 64, 4 waves
+            case 6: return launch_nt_cfg<T, TO, 2, 2, 4, 2>(B, st);      // 256 x 128, 4 waves, 128 x 64 per wave
+            default: break;
+        }
+    }
     if (maxn <= 32) return launch_nt_cfg<T, TO, 8, 1, 2, 1>(B, st);      // 512 x 32
     if (maxn <= 64) return launch_nt_cfg<T, TO, 8, 1, 2, 2>(B, st);      // 512 x 64
+    if (minn >= 256 && sizeof(T) == 4) return launch_nt_cfg<T, TO, 4, 2, 2, 4>(B, st);   // 256 x 256 (fewer loads / MFMA)
     return launch_nt_cfg<T, TO, 4, 2, 2, 2>(B, st);                      // 256 x 128
 }
 
@@ -518,7 +589,7 @@ int launch_tn_typed(GemmTnArgs &G, hipStream_t st) {
     if (G.R < 0 || G.N1 < 1 || G.N2 < 1) return EPN_EINVAL;
     if (!G.C) return EPN_ENULL;
     constexpr int E16 = ElemOf<T>::PER16;
-    const int BR = sizeof(T) == 4 ? 16 : 32;
+    const int BR = 32;
     const bool fast = G.R > 0 && G.R % BR == 0 && G.N1 >= E16 && G.N2 >= E16 && G.ldx % E16 == 0 && G.ldy % E16 == 0 &&
                       !((uintptr_t)G.X & 15) && !((uintptr_t)G.Y & 15) && G.N1 % E16 == 0 && G.N2 % E16 == 0;
     if (!fast) {
@@ -539,9 +610,11 @@ int launch_tn_typed(GemmTnArgs &G, hipStream_t st) {
     if (G.nsplit > 1 && (!G.part || G.part_bytes < (size_t)G.nsplit * G.N1 * G.N2 * sizeof(float))) return EPN_EWORKSPACE;
     const dim3 grid(G.ntiles * G.nsplit);
     if constexpr (sizeof(T) == 4) {
-        if (bn1 == 32) hipLaunchKernelGGL((gemm_tn_f32_kernel<1, 8, 1, 2, 16>), grid, dim3(512), 0, st, G);
-        else if (bn1 == 64) hipLaunchKernelGGL((gemm_tn_f32_kernel<1, 8, 2, 2, 16>), grid, dim3(512), 0, st, G);
-        else hipLaunchKernelGGL((gemm_tn_f32_kernel<2, 4, 2, 2, 16>), grid, dim3(512), 0, st, G);
+        if (bn1 == 32) hipLaunchKernelGGL((gemm_tn_f32_kernel<1, 8, 1, 2, 32>), grid, dim3(512), 0, st, G);
+        else if (bn1 == 64 && bn2 == 512) hipLaunchKernelGGL((gemm_tn_f32_kernel<1, 4, 2, 4, 16>), grid, dim3(256), 0, st, G);
+        else if (bn1 == 64) hipLaunchKernelGGL((gemm_tn_f32_kernel<1, 8, 2, 1, 32>), grid, dim3(512), 0, st, G);
+        else if (bn2 == 512) hipLaunchKernelGGL((gemm_tn_f32_kernel<1, 8, 4, 2, 32>), grid, dim3(512), 0, st, G);
+        else hipLaunchKernelGGL((gemm_tn_f32_kernel<2, 4, 2, 2, 32>), grid, dim3(512), 0, st, G);
     } else {
         if (bn1 == 32) hipLaunchKernelGGL((gemm_tn_bf16_kernel<1, 8, 2, 2>), grid, dim3(512), 0, st, G);
         else if (bn1 == 64) hipLaunchKernelGGL((gemm_tn_bf16_kernel<1, 8, 4, 2>), grid, dim3(512), 0, st, G);
@@ -562,15 +635,16 @@ int launch_tn_typed(GemmTnArgs &G, hipStream_t st) {
 
 // block tile of the TN kernels for an output of N1 x N2 (shared with the workspace query)
 void gemm_tn_tile(bool bf16, int N1, int N2, int *bn1, int *bn2) {
-    (void)N2;
     if (bf16) {
         if (N1 <= 32) { *bn1 = 32; *bn2 = 256; }
         else if (N1 <= 64) { *bn1 = 64; *bn2 = 256; }
         else { *bn1 = 128; *bn2 = 256; }
     } else {
+        // wide outputs (dW of the inter convolutions: N2 = cin*ks): 512-column tiles, 8 MFMAs per pair of LDS reads;
+        // narrow ones (spectral blocks, 1x1 convolutions): 256-column tiles
         if (N1 <= 32) { *bn1 = 32; *bn2 = 512; }
-        else if (N1 <= 64) { *bn1 = 64; *bn2 = 512; }
-        else { *bn1 = 128; *bn2 = 256; }
+        else if (N1 <= 64) { *bn1 = 64; *bn2 = N2 >= 512 ? 512 : 256; }
+        else { *bn1 = 128; *bn2 = N2 >= 512 ? 512 : 256; }
     }
 }
 
@@ -578,7 +652,7 @@ int gemm_tn_splits(bool bf16, long long R, int N1, int N2) {
     int bn1, bn2;
     gemm_tn_tile(bf16, N1, N2, &bn1, &bn2);
     const long long tiles = (long long)((N1 + bn1 - 1) / bn1) * ((N2 + bn2 - 1) / bn2);
-    const long long chunks = R / (bf16 ? 32 : 16);
+    const long long chunks = R / 32;
     long long s = (1024 + tiles - 1) / tiles;          // ~4 workgroups per CU in flight
     const long long smax = chunks / 8 > 1 ? chunks / 8 : 1;   // at least 8 K steps per split
     if (s > smax) s = smax;

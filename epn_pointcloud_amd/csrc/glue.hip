@@ -9,13 +9,28 @@ namespace {
 
 constexpr int GT = 256;   // threads per block
 
+// Activation tensors (x, dy, residual, y / dx) are float or __bf16 (template parameter T of the streaming kernels);
+// statistics, affine parameters and all arithmetic are fp32.
 struct NormArgs {
-    const float *x, *dy, *sums, *dsums, *gamma, *beta, *res;
-    float *y, *out_sums, *dgamma, *dbeta;
+    const void *x, *dy, *res;
+    void *y;
+    const float *sums, *dsums, *gamma, *beta;
+    float *out_sums, *dgamma, *dbeta;
     long long rows;
     int c, rows_per_block;
     float eps, slope, inv_rows;
 };
+
+typedef __bf16 gbf16x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ f32x4 ld4(const float *p) { return *reinterpret_cast<const f32x4 *>(p); }
+__device__ __forceinline__ f32x4 ld4(const __bf16 *p) {
+    const gbf16x4 v = *reinterpret_cast<const gbf16x4 *>(p);
+    return f32x4{(float)v[0], (float)v[1], (float)v[2], (float)v[3]};
+}
+__device__ __forceinline__ void st4(float *p, f32x4 v) { *reinterpret_cast<f32x4 *>(p) = v; }
+__device__ __forceinline__ void st4(__bf16 *p, f32x4 v) {
+    *reinterpret_cast<gbf16x4 *>(p) = gbf16x4{(__bf16)v[0], (__bf16)v[1], (__bf16)v[2], (__bf16)v[3]};
+}
 
 __device__ __forceinline__ void load_param4(const float *p, int c4, f32x4 &v, float dflt) {
     v = p ? *reinterpret_cast<const f32x4 *>(p + c4) : f32x4{dflt, dflt, dflt, dflt};
@@ -34,6 +49,7 @@ __device__ __forceinline__ void stats4(const NormArgs &A, int g, int c4, f32x4 &
 }
 
 // block = (C/4 channel lanes) x (GT / (C/4) row lanes);  grid = (row blocks, groups)
+template <typename T>
 __global__ __launch_bounds__(GT) void chan_stats_kernel(NormArgs A) {
     __shared__ float red[GT][8];
     const int lanes = A.c >> 2, cl = threadIdx.x % lanes, rl = threadIdx.x / lanes, rstep = GT / lanes;
@@ -41,11 +57,11 @@ __global__ __launch_bounds__(GT) void chan_stats_kernel(NormArgs A) {
     const long long r0 = (long long)blockIdx.x * A.rows_per_block;
     long long r1 = r0 + A.rows_per_block;
     r1 = r1 < A.rows ? r1 : A.rows;
-    const float *x = A.x + ((size_t)g * A.rows) * A.c + 4 * cl;
+    const T *x = static_cast<const T *>(A.x) + ((size_t)g * A.rows) * A.c + 4 * cl;
     f32x4 s1 = {0.f, 0.f, 0.f, 0.f}, s2 = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll 4
     for (long long r = r0 + rl; r < r1; r += rstep) {
-        const f32x4 v = *reinterpret_cast<const f32x4 *>(x + r * A.c);
+        const f32x4 v = ld4(x + r * A.c);
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             s1[i] += v[i];
@@ -124,6 +140,7 @@ __global__ __launch_bounds__(256) void bwd_finish_kernel(const float *__restrict
     }
 }
 
+template <typename T>
 __global__ __launch_bounds__(GT) void norm_act_fwd_kernel(NormArgs A) {
     const int lanes = A.c >> 2, cl = threadIdx.x % lanes, rl = threadIdx.x / lanes, rstep = GT / lanes;
     const int g = blockIdx.y, c4 = 4 * cl;
@@ -137,7 +154,7 @@ __global__ __launch_bounds__(GT) void norm_act_fwd_kernel(NormArgs A) {
     const size_t base = ((size_t)g * A.rows) * A.c + c4;
     for (long long r = r0 + rl; r < r1; r += rstep) {
         const size_t off = base + (size_t)r * A.c;
-        const f32x4 v = *reinterpret_cast<const f32x4 *>(A.x + off);
+        const f32x4 v = ld4(static_cast<const T *>(A.x) + off);
         f32x4 o;
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
@@ -145,15 +162,16 @@ __global__ __launch_bounds__(GT) void norm_act_fwd_kernel(NormArgs A) {
             o[i] = n > 0.0f ? n : n * A.slope;
         }
         if (A.res) {
-            const f32x4 rr = *reinterpret_cast<const f32x4 *>(A.res + off);
+            const f32x4 rr = ld4(static_cast<const T *>(A.res) + off);
 #pragma unroll
             for (int i = 0; i < 4; ++i) o[i] += rr[i];
         }
-        *reinterpret_cast<f32x4 *>(A.y + off) = o;
+        st4(static_cast<T *>(A.y) + off, o);
     }
 }
 
 // dsums[g][c] = (sum dn, sum dn * xhat), dn = dy * leaky'(n) * gamma;  dgamma += sum dy*leaky'*xhat, dbeta += sum dy*leaky'
+template <typename T>
 __global__ __launch_bounds__(GT) void norm_act_bwd_reduce_kernel(NormArgs A) {
     __shared__ float red[GT][8];
     const int lanes = A.c >> 2, cl = threadIdx.x % lanes, rl = threadIdx.x / lanes, rstep = GT / lanes;
@@ -170,8 +188,8 @@ __global__ __launch_bounds__(GT) void norm_act_bwd_reduce_kernel(NormArgs A) {
 #pragma unroll 4
     for (long long r = r0 + rl; r < r1; r += rstep) {
         const size_t off = base + (size_t)r * A.c;
-        const f32x4 v = *reinterpret_cast<const f32x4 *>(A.x + off);
-        const f32x4 d = *reinterpret_cast<const f32x4 *>(A.dy + off);
+        const f32x4 v = ld4(static_cast<const T *>(A.x) + off);
+        const f32x4 d = ld4(static_cast<const T *>(A.dy) + off);
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             const float xh = (v[i] - mean[i]) * rstd[i];
@@ -203,6 +221,7 @@ __global__ __launch_bounds__(GT) void norm_act_bwd_reduce_kernel(NormArgs A) {
     }
 }
 
+template <typename T>
 __global__ __launch_bounds__(GT) void norm_act_bwd_apply_kernel(NormArgs A) {
     const int lanes = A.c >> 2, cl = threadIdx.x % lanes, rl = threadIdx.x / lanes, rstep = GT / lanes;
     const int g = blockIdx.y, c4 = 4 * cl;
@@ -222,8 +241,8 @@ __global__ __launch_bounds__(GT) void norm_act_bwd_apply_kernel(NormArgs A) {
     const size_t base = ((size_t)g * A.rows) * A.c + c4;
     for (long long r = r0 + rl; r < r1; r += rstep) {
         const size_t off = base + (size_t)r * A.c;
-        const f32x4 v = *reinterpret_cast<const f32x4 *>(A.x + off);
-        const f32x4 d = *reinterpret_cast<const f32x4 *>(A.dy + off);
+        const f32x4 v = ld4(static_cast<const T *>(A.x) + off);
+        const f32x4 d = ld4(static_cast<const T *>(A.dy) + off);
         f32x4 o;
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
@@ -232,7 +251,7 @@ __global__ __launch_bounds__(GT) void norm_act_bwd_apply_kernel(NormArgs A) {
             const float dn = (n > 0.0f ? d[i] : d[i] * A.slope) * ga[i];
             o[i] = rstd[i] * (dn - m1[i] - xh * m2[i]);
         }
-        *reinterpret_cast<f32x4 *>(A.y + off) = o;
+        st4(static_cast<T *>(A.y) + off, o);
     }
 }
 
@@ -269,8 +288,8 @@ extern "C" size_t epn_norm_workspace_bytes(int groups, long long rows, int c) {
     return sizeof(float) * (size_t)groups * grid.x * c * 2;   // one (s1, s2) pair per block and channel
 }
 
-extern "C" int epn_chan_stats_f32(const float *x_cl, int groups, long long rows, int c, float *sums, void *workspace,
-                                  size_t workspace_bytes, epn_stream_t stream) {
+static int chan_stats_any(const void *x_cl, int groups, long long rows, int c, float *sums, void *workspace,
+                          size_t workspace_bytes, int bf16, epn_stream_t stream) {
     int rc = check_norm(groups, rows, c);
     if (rc) return rc;
     if (!sums) return EPN_ENULL;
@@ -284,7 +303,8 @@ extern "C" int epn_chan_stats_f32(const float *x_cl, int groups, long long rows,
     dim3 grid;
     NormArgs A = make_norm(rows, c, 0.f, 0.f, grid, groups);
     A.x = x_cl; A.out_sums = static_cast<float *>(workspace);
-    hipLaunchKernelGGL(chan_stats_kernel, grid, dim3(GT), 0, st, A);
+    if (bf16) hipLaunchKernelGGL(chan_stats_kernel<__bf16>, grid, dim3(GT), 0, st, A);
+    else hipLaunchKernelGGL(chan_stats_kernel<float>, grid, dim3(GT), 0, st, A);
     EPN_CHECK_LAUNCH();
     hipLaunchKernelGGL(stats_finish_kernel, dim3(epn_cdiv(2 * c, 16), groups), dim3(256), 0, st, A.out_sums, (int)grid.x,
                        c * 2, sums);
@@ -292,9 +312,9 @@ extern "C" int epn_chan_stats_f32(const float *x_cl, int groups, long long rows,
     return 0;
 }
 
-extern "C" int epn_norm_act_fwd_f32(const float *x_cl, int groups, long long rows, int c, const float *sums,
-                                    const float *gamma, const float *beta, const float *residual_cl, float eps,
-                                    float slope, float *y_cl, epn_stream_t stream) {
+static int norm_act_fwd_any(const void *x_cl, int groups, long long rows, int c, const float *sums, const float *gamma,
+                            const float *beta, const void *residual_cl, float eps, float slope, void *y_cl, int bf16,
+                            epn_stream_t stream) {
     int rc = check_norm(groups, rows, c);
     if (rc) return rc;
     if (groups == 0 || rows == 0) return 0;
@@ -302,15 +322,16 @@ extern "C" int epn_norm_act_fwd_f32(const float *x_cl, int groups, long long row
     dim3 grid;
     NormArgs A = make_norm(rows, c, eps, slope, grid, groups);
     A.x = x_cl; A.sums = sums; A.gamma = gamma; A.beta = beta; A.res = residual_cl; A.y = y_cl;
-    hipLaunchKernelGGL(norm_act_fwd_kernel, grid, dim3(GT), 0, epn_stream(stream), A);
+    if (bf16) hipLaunchKernelGGL(norm_act_fwd_kernel<__bf16>, grid, dim3(GT), 0, epn_stream(stream), A);
+    else hipLaunchKernelGGL(norm_act_fwd_kernel<float>, grid, dim3(GT), 0, epn_stream(stream), A);
     EPN_CHECK_LAUNCH();
     return 0;
 }
 
-extern "C" int epn_norm_act_bwd_reduce_f32(const float *x_cl, const float *dy_cl, int groups, long long rows, int c,
-                                           const float *sums, const float *gamma, const float *beta, float eps,
-                                           float slope, float *dsums, float *dgamma, float *dbeta, void *workspace,
-                                           size_t workspace_bytes, epn_stream_t stream) {
+static int norm_act_bwd_reduce_any(const void *x_cl, const void *dy_cl, int groups, long long rows, int c,
+                                   const float *sums, const float *gamma, const float *beta, float eps, float slope,
+                                   float *dsums, float *dgamma, float *dbeta, void *workspace, size_t workspace_bytes,
+                                   int bf16, epn_stream_t stream) {
     int rc = check_norm(groups, rows, c);
     if (rc) return rc;
     if (!dsums) return EPN_ENULL;
@@ -327,7 +348,8 @@ extern "C" int epn_norm_act_bwd_reduce_f32(const float *x_cl, const float *dy_cl
     NormArgs A = make_norm(rows, c, eps, slope, grid, groups);
     A.x = x_cl; A.dy = dy_cl; A.sums = sums; A.gamma = gamma; A.beta = beta;
     A.out_sums = static_cast<float *>(workspace);
-    hipLaunchKernelGGL(norm_act_bwd_reduce_kernel, grid, dim3(GT), 0, st, A);
+    if (bf16) hipLaunchKernelGGL(norm_act_bwd_reduce_kernel<__bf16>, grid, dim3(GT), 0, st, A);
+    else hipLaunchKernelGGL(norm_act_bwd_reduce_kernel<float>, grid, dim3(GT), 0, st, A);
     EPN_CHECK_LAUNCH();
     if (dgamma) EPN_HIP(hipMemsetAsync(dgamma, 0, sizeof(float) * c, st));
     if (dbeta) EPN_HIP(hipMemsetAsync(dbeta, 0, sizeof(float) * c, st));
@@ -337,10 +359,9 @@ extern "C" int epn_norm_act_bwd_reduce_f32(const float *x_cl, const float *dy_cl
     return 0;
 }
 
-extern "C" int epn_norm_act_bwd_apply_f32(const float *x_cl, const float *dy_cl, int groups, long long rows, int c,
-                                          const float *sums, const float *dsums, const float *gamma,
-                                          const float *beta, float eps, float slope, float *dx_cl,
-                                          epn_stream_t stream) {
+static int norm_act_bwd_apply_any(const void *x_cl, const void *dy_cl, int groups, long long rows, int c,
+                                  const float *sums, const float *dsums, const float *gamma, const float *beta, float eps,
+                                  float slope, void *dx_cl, int bf16, epn_stream_t stream) {
     int rc = check_norm(groups, rows, c);
     if (rc) return rc;
     if (groups == 0 || rows == 0) return 0;
@@ -348,9 +369,54 @@ extern "C" int epn_norm_act_bwd_apply_f32(const float *x_cl, const float *dy_cl,
     dim3 grid;
     NormArgs A = make_norm(rows, c, eps, slope, grid, groups);
     A.x = x_cl; A.dy = dy_cl; A.sums = sums; A.dsums = dsums; A.gamma = gamma; A.beta = beta; A.y = dx_cl;
-    hipLaunchKernelGGL(norm_act_bwd_apply_kernel, grid, dim3(GT), 0, epn_stream(stream), A);
+    if (bf16) hipLaunchKernelGGL(norm_act_bwd_apply_kernel<__bf16>, grid, dim3(GT), 0, epn_stream(stream), A);
+    else hipLaunchKernelGGL(norm_act_bwd_apply_kernel<float>, grid, dim3(GT), 0, epn_stream(stream), A);
     EPN_CHECK_LAUNCH();
     return 0;
+}
+
+extern "C" int epn_chan_stats_f32(const float *x_cl, int groups, long long rows, int c, float *sums, void *workspace,
+                                  size_t workspace_bytes, epn_stream_t stream) {
+    return chan_stats_any(x_cl, groups, rows, c, sums, workspace, workspace_bytes, 0, stream);
+}
+extern "C" int epn_chan_stats_bf16(const void *x_cl, int groups, long long rows, int c, float *sums, void *workspace,
+                                   size_t workspace_bytes, epn_stream_t stream) {
+    return chan_stats_any(x_cl, groups, rows, c, sums, workspace, workspace_bytes, 1, stream);
+}
+extern "C" int epn_norm_act_fwd_f32(const float *x_cl, int groups, long long rows, int c, const float *sums,
+                                    const float *gamma, const float *beta, const float *residual_cl, float eps,
+                                    float slope, float *y_cl, epn_stream_t stream) {
+    return norm_act_fwd_any(x_cl, groups, rows, c, sums, gamma, beta, residual_cl, eps, slope, y_cl, 0, stream);
+}
+extern "C" int epn_norm_act_fwd_bf16(const void *x_cl, int groups, long long rows, int c, const float *sums,
+                                     const float *gamma, const float *beta, const void *residual_cl, float eps,
+                                     float slope, void *y_cl, epn_stream_t stream) {
+    return norm_act_fwd_any(x_cl, groups, rows, c, sums, gamma, beta, residual_cl, eps, slope, y_cl, 1, stream);
+}
+extern "C" int epn_norm_act_bwd_reduce_f32(const float *x_cl, const float *dy_cl, int groups, long long rows, int c,
+                                           const float *sums, const float *gamma, const float *beta, float eps,
+                                           float slope, float *dsums, float *dgamma, float *dbeta, void *workspace,
+                                           size_t workspace_bytes, epn_stream_t stream) {
+    return norm_act_bwd_reduce_any(x_cl, dy_cl, groups, rows, c, sums, gamma, beta, eps, slope, dsums, dgamma, dbeta,
+                                   workspace, workspace_bytes, 0, stream);
+}
+extern "C" int epn_norm_act_bwd_reduce_bf16(const void *x_cl, const void *dy_cl, int groups, long long rows, int c,
+                                            const float *sums, const float *gamma, const float *beta, float eps,
+                                            float slope, float *dsums, float *dgamma, float *dbeta, void *workspace,
+                                            size_t workspace_bytes, epn_stream_t stream) {
+    return norm_act_bwd_reduce_any(x_cl, dy_cl, groups, rows, c, sums, gamma, beta, eps, slope, dsums, dgamma, dbeta,
+                                   workspace, workspace_bytes, 1, stream);
+}
+extern "C" int epn_norm_act_bwd_apply_f32(const float *x_cl, const float *dy_cl, int groups, long long rows, int c,
+                                          const float *sums, const float *dsums, const float *gamma,
+                                          const float *beta, float eps, float slope, float *dx_cl,
+                                          epn_stream_t stream) {
+    return norm_act_bwd_apply_any(x_cl, dy_cl, groups, rows, c, sums, dsums, gamma, beta, eps, slope, dx_cl, 0, stream);
+}
+extern "C" int epn_norm_act_bwd_apply_bf16(const void *x_cl, const void *dy_cl, int groups, long long rows, int c,
+                                           const float *sums, const float *dsums, const float *gamma, const float *beta,
+                                           float eps, float slope, void *dx_cl, epn_stream_t stream) {
+    return norm_act_bwd_apply_any(x_cl, dy_cl, groups, rows, c, sums, dsums, gamma, beta, eps, slope, dx_cl, 1, stream);
 }
 
 // ---- IntraSO3Conv grouping as a tensor (the "split" form): grouped[col][k*c + ci] = x[(pt*na + idx[a][k])*c + ci].
@@ -375,6 +441,14 @@ __global__ __launch_bounds__(256) void intra_group_kernel(const V *__restrict__ 
 
 }  // namespace
 }  // namespace epn
+
+extern "C" int epn_intra_group_bf16(const void *feats_cl, const int32_t *intra_idx, void *grouped, int b, int p, int na,
+                                    int kn, int c, epn_stream_t stream) {
+    // a pure copy: 8 bf16 channels are one 16-byte element, exactly like 4 floats
+    if (c < 8 || c % 8 != 0) return EPN_EINVAL;
+    return epn_intra_group_f32(static_cast<const float *>(feats_cl), intra_idx, static_cast<float *>(grouped), b, p, na,
+                               kn, c / 2, stream);
+}
 
 extern "C" int epn_intra_group_f32(const float *feats_cl, const int32_t *intra_idx, float *grouped, int b, int p,
                                    int na, int kn, int c, epn_stream_t stream) {

@@ -47,6 +47,19 @@ __device__ __forceinline__ f32x4 mfma4(float a, float b, f32x4 c) {
     return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0);
 }
 
+// Feature / grouped-feature storage type of the grouping kernels: float, or __bf16 for the bf16 feature path (weights
+// w and the neighbour contraction stay fp32: "bf16 features, fp32 accumulate").
+typedef __bf16 bf16x4_t __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ f32x4 ld4f(const float *p) { return *reinterpret_cast<const f32x4 *>(p); }
+__device__ __forceinline__ f32x4 ld4f(const __bf16 *p) {
+    const bf16x4_t v = *reinterpret_cast<const bf16x4_t *>(p);
+    return f32x4{(float)v[0], (float)v[1], (float)v[2], (float)v[3]};
+}
+__device__ __forceinline__ void st4f(float *p, f32x4 v) { *reinterpret_cast<f32x4 *>(p) = v; }
+__device__ __forceinline__ void st4f(__bf16 *p, f32x4 v) {
+    *reinterpret_cast<bf16x4_t *>(p) = bf16x4_t{(__bf16)v[0], (__bf16)v[1], (__bf16)v[2], (__bf16)v[3]};
+}
+
 // Per-point neighbourhood fragments, shared by all columns (anchors) of one output point.
 template <int NT>
 struct Hood {
@@ -128,9 +141,9 @@ __device__ __forceinline__ void make_weights(const InterArgs &A, int a, int x, i
 
 // Grouped features of 16 columns x 16 channels into the wave-private LDS tile Gs[col][c_local*ks + k].
 // Generic form (any na): neighbourhood fragments are re-derived whenever the output point changes.
-template <int NT, int KT>
+template <int NT, int KT, typename TF = float>
 __device__ __forceinline__ void group_chunk_generic(const InterArgs &A, long long col0, int ct, int x, int j,
-                                                    float *Gs, int gss) {
+                                                    TF *Gs, int gss) {
     Hood<NT> h;
     int last_pt = -1;
     for (int jc = 0; jc < 16; ++jc) {
@@ -144,12 +157,12 @@ __device__ __forceinline__ void group_chunk_generic(const InterArgs &A, long lon
             last_pt = pt;
         }
         float f[NT][4];
-        const float *fb = A.feats + (((size_t)bb * A.p1) * A.na + a) * A.cin + 16 * ct + x;
+        const TF *fb = reinterpret_cast<const TF *>(A.feats) + (((size_t)bb * A.p1) * A.na + a) * A.cin + 16 * ct + x;
 #pragma unroll
         for (int t = 0; t < NT; ++t)
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-                const float v = fb[h.q[t][r]];
+                const float v = (float)fb[h.q[t][r]];
                 f[t][r] = h.ok[t][r] ? v : 0.0f;
             }
         f32x4 w[KT][NT];
@@ -162,7 +175,7 @@ __device__ __forceinline__ void group_chunk_generic(const InterArgs &A, long lon
 #pragma unroll
                 for (int r = 0; r < 4; ++r) g = mfma4(w[kt][t][r], f[t][r], g);
             if (16 * kt + 4 * j < A.ks)  // rows k = 16kt + 4j + r of channel x
-                *reinterpret_cast<f32x4 *>(Gs + jc * gss + x * A.ks + 16 * kt + 4 * j) = g;
+                st4f(Gs + jc * gss + x * A.ks + 16 * kt + 4 * j, g);
         }
     }
 }
@@ -173,30 +186,30 @@ __device__ __forceinline__ void group_chunk_generic(const InterArgs &A, long lon
 template <int NT>
 struct Seg {          // columns [jc0, jc0 + cnt) of the tile: anchors a0.. of one output point
     Hood<NT> h;
-    const float *fbase;   // feats + ((b*p1)*na)*cin
+    const float *fbase;   // feats + ((b*p1)*na)*cin  (element type TF of the kernel: an opaque base for bf16)
     int a0, jc0, cnt;
 };
 
-template <int NT>
+template <int NT, typename TF = float>
 __device__ __forceinline__ void load_f(const InterArgs &A, const Seg<NT> &sg, int a, int coff, float (&f)[NT][4]) {
-    const float *fb = sg.fbase + (size_t)a * A.cin + coff;
+    const TF *fb = reinterpret_cast<const TF *>(sg.fbase) + (size_t)a * A.cin + coff;
 #pragma unroll
     for (int t = 0; t < NT; ++t)
 #pragma unroll
-        for (int r = 0; r < 4; ++r) f[t][r] = fb[sg.h.q[t][r]];
+        for (int r = 0; r < 4; ++r) f[t][r] = (float)fb[sg.h.q[t][r]];
 }
 
-template <int NT, int KT>
+template <int NT, int KT, typename TF = float>
 __device__ __forceinline__ void group_segment(const InterArgs &A, const Seg<NT> &sg, int ct, int x, int j,
-                                              float *Gs, int gss) {
+                                              TF *Gs, int gss) {
     if (sg.cnt <= 0) return;
     const int coff = 16 * ct + x;
     float fcur[NT][4], fnext[NT][4];
-    load_f<NT>(A, sg, sg.a0, coff, fcur);
+    load_f<NT, TF>(A, sg, sg.a0, coff, fcur);
     for (int i = 0; i < sg.cnt; ++i) {
         const int a = sg.a0 + i;
         const int an = i + 1 < sg.cnt ? a + 1 : a;   // last column re-reads its own rows (cache hit, result unused)
-        load_f<NT>(A, sg, an, coff, fnext);
+        load_f<NT, TF>(A, sg, an, coff, fnext);
         f32x4 w[KT][NT];
         make_weights<NT, KT>(A, a, x, j, sg.h, w);
 #pragma unroll
@@ -207,7 +220,7 @@ __device__ __forceinline__ void group_segment(const InterArgs &A, const Seg<NT> 
 #pragma unroll
                 for (int r = 0; r < 4; ++r) g = mfma4(w[kt][t][r], sg.h.ok[t][r] ? fcur[t][r] : 0.0f, g);
             if (16 * kt + 4 * j < A.ks)
-                *reinterpret_cast<f32x4 *>(Gs + (sg.jc0 + i) * gss + x * A.ks + 16 * kt + 4 * j) = g;
+                st4f(Gs + (sg.jc0 + i) * gss + x * A.ks + 16 * kt + 4 * j, g);
         }
 #pragma unroll
         for (int t = 0; t < NT; ++t)
@@ -216,7 +229,7 @@ __device__ __forceinline__ void group_segment(const InterArgs &A, const Seg<NT> 
     }
 }
 
-template <int NT>
+template <int NT, typename TF = float>
 __device__ __forceinline__ void make_segments(const InterArgs &A, long long col0, int x, int j, Seg<NT> &s0,
                                               Seg<NT> &s1) {
     long long c0 = col0 < A.ncol ? col0 : A.ncol - 1;
@@ -227,7 +240,7 @@ __device__ __forceinline__ void make_segments(const InterArgs &A, long long col0
     const int n0 = A.na - a0 < (int)ncols ? A.na - a0 : (int)ncols;
     int bb = pt0 / A.p2, pp = pt0 - bb * A.p2;
     load_hood<NT>(A, bb, pp, x, j, s0.h);
-    s0.fbase = A.feats + ((size_t)bb * A.p1) * A.na * A.cin;
+    s0.fbase = reinterpret_cast<const float *>(reinterpret_cast<const TF *>(A.feats) + ((size_t)bb * A.p1) * A.na * A.cin);
     s0.a0 = a0; s0.jc0 = 0; s0.cnt = n0;
     const int pt1 = pt0 + 1;
     s1.cnt = (int)ncols - n0;
@@ -235,7 +248,7 @@ __device__ __forceinline__ void make_segments(const InterArgs &A, long long col0
     if (s1.cnt > 0) {
         bb = pt1 / A.p2; pp = pt1 - bb * A.p2;
         load_hood<NT>(A, bb, pp, x, j, s1.h);
-        s1.fbase = A.feats + ((size_t)bb * A.p1) * A.na * A.cin;
+        s1.fbase = reinterpret_cast<const float *>(reinterpret_cast<const TF *>(A.feats) + ((size_t)bb * A.p1) * A.na * A.cin);
     } else {
         s1.h = s0.h;
         s1.fbase = s0.fbase;
@@ -336,9 +349,9 @@ __global__ __launch_bounds__(64 * NW) void inter_fwd_kernel(InterArgs A) {
 
 // Data-gradient tail for the columns of one segment: T[n][c] = sum_k w[n][k] dG[c,k], then
 // dF[b, idx[n], a, c] += T[n][c].  dG of the wave's 16 columns sits in Gs[col][c_local*ks + k].
-template <int NT, int KT>
+template <int NT, int KT, typename TG = float>
 __device__ __forceinline__ void scatter_segment(const InterArgs &A, const Seg<NT> &sg, int ct, int x, int j,
-                                                const float *Gs, int gss) {
+                                                const TG *Gs, int gss) {
     if (sg.cnt <= 0) return;
     // transposed weights: S'[k][n] = beta_k + alpha_n + (2/sigma)(R_a kappa_k).g_n  (A = rk4 row incl. beta, B = (g,1))
     float gB[NT], alphaN[NT];
@@ -364,7 +377,7 @@ __device__ __forceinline__ void scatter_segment(const InterArgs &A, const Seg<NT
                 s = mfma4(rk[kt], gB[t], s);  // D[m = k_local = 4j + r][n = x]
                 // B operand of the contraction over k: dG[k = 16kt + 4j + r][c = x]; rows past ks carry w = 0
                 const int jj = 16 * kt + 4 * j < A.ks ? j : 0;
-                const f32x4 dgc = *reinterpret_cast<const f32x4 *>(Gs + jc * gss + x * A.ks + 16 * kt + 4 * jj);
+                const f32x4 dgc = ld4f(Gs + jc * gss + x * A.ks + 16 * kt + 4 * jj);
 #pragma unroll
                 for (int r = 0; r < 4; ++r) tt = mfma4(fmaxf(s[r], 0.0f), dgc[r], tt);
             }
@@ -974,7 +987,7 @@ __global__ __launch_bounds__(64 * NW8) void inter_bwd_data8_kernel(InterArgs A) 
 // these shapes, tools/gemm_probe.py, against 67-84 for the fused kernels above).  A wave owns one 16-column tile; no
 // LDS, no barriers: weight generation + neighbour contraction exactly as in the fused kernels, the D fragment of
 // the contraction (4 consecutive kernel points of one channel) is one 16-byte global store.
-template <int NT, int KT>
+template <int NT, int KT, typename TF>
 __global__ __launch_bounds__(64 * NW) void inter_group_kernel(InterArgs A) {
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -982,7 +995,7 @@ __global__ __launch_bounds__(64 * NW) void inter_group_kernel(InterArgs A) {
     const long long col0 = ((long long)epn_xcd_tile(blockIdx.x, gridDim.x) * NW + wave) * 16;
     if (col0 >= A.ncol) return;
     const int gss = A.cin * A.ks;
-    float *G = A.out + (size_t)col0 * gss;
+    TF *G = reinterpret_cast<TF *>(A.out) + (size_t)col0 * gss;
     // blockIdx.y walks the 16-channel chunks in groups of col_tiles_per_wg (here: chunks per workgroup): with one
     // chunk per launch row, all tiles of a cloud touch the same 64-byte slice of every feature row at about the same
     // time, so the working set per cloud (p1*na*64 B) fits the XCD's L2
@@ -990,18 +1003,19 @@ __global__ __launch_bounds__(64 * NW) void inter_group_kernel(InterArgs A) {
     const int ct1 = min(ct0 + A.col_tiles_per_wg, A.cin >> 4);
     if (A.na >= 16) {
         Seg<NT> s0, s1;
-        make_segments<NT>(A, col0, x, j, s0, s1);
+        make_segments<NT, TF>(A, col0, x, j, s0, s1);
         for (int ct = ct0; ct < ct1; ++ct) {
-            group_segment<NT, KT>(A, s0, ct, x, j, G + 16 * ct * A.ks, gss);
-            group_segment<NT, KT>(A, s1, ct, x, j, G + 16 * ct * A.ks, gss);
+            group_segment<NT, KT, TF>(A, s0, ct, x, j, G + 16 * ct * A.ks, gss);
+            group_segment<NT, KT, TF>(A, s1, ct, x, j, G + 16 * ct * A.ks, gss);
         }
     } else {
-        for (int ct = ct0; ct < ct1; ++ct) group_chunk_generic<NT, KT>(A, col0, ct, x, j, G + 16 * ct * A.ks, gss);
+        for (int ct = ct0; ct < ct1; ++ct)
+            group_chunk_generic<NT, KT, TF>(A, col0, ct, x, j, G + 16 * ct * A.ks, gss);
     }
 }
 
 // Transpose of the grouping: dF[b, idx[n], a, c] += sum_k w[k][n] dG[col][c*ks + k]  (scatter_segment reads dG from HBM).
-template <int NT, int KT>
+template <int NT, int KT, typename TG>   // dG in TG (float / bf16); the scatter target grad_feats is always fp32
 __global__ __launch_bounds__(64 * NW) void inter_ungroup_kernel(InterArgs A) {
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -1009,7 +1023,7 @@ __global__ __launch_bounds__(64 * NW) void inter_ungroup_kernel(InterArgs A) {
     const long long col0 = ((long long)epn_xcd_tile(blockIdx.x, gridDim.x) * NW + wave) * 16;
     if (col0 >= A.ncol) return;
     const int gss = A.cin * A.ks;
-    const float *dG = A.gout + (size_t)col0 * gss;
+    const TG *dG = reinterpret_cast<const TG *>(A.gout) + (size_t)col0 * gss;
     const int ct0 = blockIdx.y * A.col_tiles_per_wg;          // chunk-major launch order, see inter_group_kernel
     const int ct1 = min(ct0 + A.col_tiles_per_wg, A.cin >> 4);
     InterArgs B = A;
@@ -1018,8 +1032,8 @@ __global__ __launch_bounds__(64 * NW) void inter_ungroup_kernel(InterArgs A) {
         Seg<NT> s0, s1;
         make_segments<NT>(B, col0, x, j, s0, s1);
         for (int ct = ct0; ct < ct1; ++ct) {
-            scatter_segment<NT, KT>(A, s0, ct, x, j, dG + 16 * ct * A.ks, gss);
-            scatter_segment<NT, KT>(A, s1, ct, x, j, dG + 16 * ct * A.ks, gss);
+            scatter_segment<NT, KT, TG>(A, s0, ct, x, j, dG + 16 * ct * A.ks, gss);
+            scatter_segment<NT, KT, TG>(A, s1, ct, x, j, dG + 16 * ct * A.ks, gss);
         }
     } else {
         Seg<NT> sg;
@@ -1036,7 +1050,7 @@ __global__ __launch_bounds__(64 * NW) void inter_ungroup_kernel(InterArgs A) {
             }
             sg.fbase = A.out + ((size_t)bb * A.p1) * A.na * A.cin;
             sg.a0 = a; sg.jc0 = jc; sg.cnt = 1;
-            for (int ct = ct0; ct < ct1; ++ct) scatter_segment<NT, KT>(A, sg, ct, x, j, dG + 16 * ct * A.ks, gss);
+            for (int ct = ct0; ct < ct1; ++ct) scatter_segment<NT, KT, TG>(A, sg, ct, x, j, dG + 16 * ct * A.ks, gss);
         }
     }
 }
@@ -1274,26 +1288,36 @@ int launch_inter_bwd_weight_mfma(const epn_inter_desc *d, const float *rk4, cons
 
 static int chunks_per_row() { return 1; }   // 16-channel chunks per launch row of the grouping kernels
 
-int launch_inter_group_mfma(const epn_inter_desc *d, const float *rk4, const float *feats, float *G, hipStream_t st) {
+int launch_inter_group_mfma(const epn_inter_desc *d, const float *rk4, const void *feats, void *G, int bf16,
+                            hipStream_t st) {
     InterArgs A = make_args(d, rk4);
-    A.feats = feats; A.out = G;
+    A.feats = static_cast<const float *>(feats); A.out = static_cast<float *>(G);
     const unsigned grid = (unsigned)((A.ncol + 16 * NW - 1) / (16 * NW));
     A.col_tiles_per_wg = chunks_per_row();
     const unsigned gy = (unsigned)(((d->cin >> 4) + A.col_tiles_per_wg - 1) / A.col_tiles_per_wg);
-#define EPN_GRP(NT_, KT_, dummy) hipLaunchKernelGGL((inter_group_kernel<NT_, KT_>), dim3(grid, gy), dim3(64 * NW), 0, st, A)
+#define EPN_GRP(NT_, KT_, dummy)                                                                                      \
+    do {                                                                                                              \
+        if (bf16) hipLaunchKernelGGL((inter_group_kernel<NT_, KT_, __bf16>), dim3(grid, gy), dim3(64 * NW), 0, st, A); \
+        else hipLaunchKernelGGL((inter_group_kernel<NT_, KT_, float>), dim3(grid, gy), dim3(64 * NW), 0, st, A);      \
+    } while (0)
     EPN_DISPATCH_NT_KT(EPN_GRP, 0);
 #undef EPN_GRP
     EPN_CHECK_LAUNCH();
     return 0;
 }
 
-int launch_inter_ungroup_mfma(const epn_inter_desc *d, const float *rk4, const float *dG, float *dF, hipStream_t st) {
+int launch_inter_ungroup_mfma(const epn_inter_desc *d, const float *rk4, const void *dG, float *dF, int bf16,
+                              hipStream_t st) {
     InterArgs A = make_args(d, rk4);
-    A.gout = dG; A.out = dF;
+    A.gout = static_cast<const float *>(dG); A.out = dF;
     const unsigned grid = (unsigned)((A.ncol + 16 * NW - 1) / (16 * NW));
     A.col_tiles_per_wg = chunks_per_row();
     const unsigned gy = (unsigned)(((d->cin >> 4) + A.col_tiles_per_wg - 1) / A.col_tiles_per_wg);
-#define EPN_UGRP(NT_, KT_, dummy) hipLaunchKernelGGL((inter_ungroup_kernel<NT_, KT_>), dim3(grid, gy), dim3(64 * NW), 0, st, A)
+#define EPN_UGRP(NT_, KT_, dummy)                                                                                       \
+    do {                                                                                                                \
+        if (bf16) hipLaunchKernelGGL((inter_ungroup_kernel<NT_, KT_, __bf16>), dim3(grid, gy), dim3(64 * NW), 0, st, A); \
+        else hipLaunchKernelGGL((inter_ungroup_kernel<NT_, KT_, float>), dim3(grid, gy), dim3(64 * NW), 0, st, A);      \
+    } while (0)
     EPN_DISPATCH_NT_KT(EPN_UGRP, 0);
 #undef EPN_UGRP
     EPN_CHECK_LAUNCH();

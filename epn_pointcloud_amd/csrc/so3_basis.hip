@@ -16,9 +16,10 @@ constexpr int SB_LD = 65;     // LDS row pitch of M (floats)
 constexpr int SB_TPW = 4;     // (point, channel block) tasks per wave: amortises the 16 KB load of M
 
 struct SbArgs {
-    const float *in, *M;
+    const void *in;           // T = float or __bf16 (feature storage); M and the arithmetic are fp32
+    const float *M;
     const int32_t *blk;       // [na][2] = (base row of the irreducible block, d*d) per spectral row
-    float *out;
+    void *out;
     long long pts;
     int na, c, in_spec, out_spec;
 };
@@ -27,6 +28,18 @@ __device__ __forceinline__ f32x4 mfma4(float a, float b, f32x4 c) {
     return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0);
 }
 
+typedef __bf16 sbf16x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ f32x4 sb_ld(const float *p) { return *reinterpret_cast<const f32x4 *>(p); }
+__device__ __forceinline__ f32x4 sb_ld(const __bf16 *p) {
+    const sbf16x4 v = *reinterpret_cast<const sbf16x4 *>(p);
+    return f32x4{(float)v[0], (float)v[1], (float)v[2], (float)v[3]};
+}
+__device__ __forceinline__ void sb_st(float *p, f32x4 v) { *reinterpret_cast<f32x4 *>(p) = v; }
+__device__ __forceinline__ void sb_st(__bf16 *p, f32x4 v) {
+    *reinterpret_cast<sbf16x4 *>(p) = sbf16x4{(__bf16)v[0], (__bf16)v[1], (__bf16)v[2], (__bf16)v[3]};
+}
+
+template <typename T>
 __global__ __launch_bounds__(64 * SB_WAVES) void so3_basis_kernel(SbArgs A) {
     __shared__ float Ms[64 * SB_LD];
     __shared__ int bs[64], d2s[64];
@@ -65,7 +78,7 @@ __global__ __launch_bounds__(64 * SB_WAVES) void so3_basis_kernel(SbArgs A) {
         f32x4 bv[16];
 #pragma unroll
         for (int st = 0; st < 16; ++st)
-            if (st < nst) bv[st] = *reinterpret_cast<const f32x4 *>(A.in + row_addr(A.in_spec, 4 * st + j));
+            if (st < nst) bv[st] = sb_ld(static_cast<const T *>(A.in) + row_addr(A.in_spec, 4 * st + j));
 #pragma unroll
         for (int st = 0; st < 16; ++st) {
             if (st < nst) {
@@ -85,7 +98,7 @@ __global__ __launch_bounds__(64 * SB_WAVES) void so3_basis_kernel(SbArgs A) {
                 const int r = 16 * mt + 4 * j + rr;
                 if (r < A.na) {
                     const f32x4 v = {acc[mt][0][rr], acc[mt][1][rr], acc[mt][2][rr], acc[mt][3][rr]};
-                    *reinterpret_cast<f32x4 *>(A.out + row_addr(A.out_spec, r)) = v;
+                    sb_st(static_cast<T *>(A.out) + row_addr(A.out_spec, r), v);
                 }
             }
     }
@@ -96,8 +109,8 @@ __global__ __launch_bounds__(64 * SB_WAVES) void so3_basis_kernel(SbArgs A) {
 
 using namespace epn;
 
-extern "C" int epn_so3_basis_f32(const float *in, const float *M, const int32_t *blocks, long long pts, int na, int c,
-                                 int in_spectral, int out_spectral, float *out, epn_stream_t stream) {
+static int so3_basis_any(const void *in, const float *M, const int32_t *blocks, long long pts, int na, int c,
+                        int in_spectral, int out_spectral, void *out, int bf16, epn_stream_t stream) {
     if (pts < 0 || na < 4 || na > 64 || (na & 3) || c < 64 || (c & 63)) return EPN_EINVAL;
     if (pts == 0) return 0;
     if (!in || !M || !blocks || !out) return EPN_ENULL;
@@ -106,8 +119,18 @@ extern "C" int epn_so3_basis_f32(const float *in, const float *M, const int32_t 
     A.in_spec = in_spectral; A.out_spec = out_spectral;
     const long long tasks = pts * (c >> 6);
     const long long per_wg = (long long)SB_WAVES * SB_TPW;
-    hipLaunchKernelGGL(so3_basis_kernel, dim3((unsigned)((tasks + per_wg - 1) / per_wg)), dim3(64 * SB_WAVES), 0,
-                       epn_stream(stream), A);
+    const dim3 grid((unsigned)((tasks + per_wg - 1) / per_wg));
+    if (bf16) hipLaunchKernelGGL(so3_basis_kernel<__bf16>, grid, dim3(64 * SB_WAVES), 0, epn_stream(stream), A);
+    else hipLaunchKernelGGL(so3_basis_kernel<float>, grid, dim3(64 * SB_WAVES), 0, epn_stream(stream), A);
     EPN_CHECK_LAUNCH();
     return 0;
+}
+
+extern "C" int epn_so3_basis_f32(const float *in, const float *M, const int32_t *blocks, long long pts, int na, int c,
+                                 int in_spectral, int out_spectral, float *out, epn_stream_t stream) {
+    return so3_basis_any(in, M, blocks, pts, na, c, in_spectral, out_spectral, out, 0, stream);
+}
+extern "C" int epn_so3_basis_bf16(const void *in, const float *M, const int32_t *blocks, long long pts, int na, int c,
+                                  int in_spectral, int out_spectral, void *out, epn_stream_t stream) {
+    return so3_basis_any(in, M, blocks, pts, na, c, in_spectral, out_spectral, out, 1, stream);
 }

@@ -140,6 +140,8 @@ class _SO3ConvModel(nn.Module):
         x = S.preprocess_input(pts, self.na_in)
         for stage in self.backbone:
             x = stage(x)
+        if x.feats.dtype != torch.float32:          # bf16 feature path: the heads run in fp32 (their inputs are small)
+            x = zptk.SphericalPointCloud(x.xyz, ops.cast_feats(x.feats, torch.float32), x.anchors)
         return x
 
     def get_anchor(self):

@@ -50,12 +50,15 @@ def _inter_key(d):
     return (d.b, d.p1, d.p2, d.nn, d.na, d.ks, d.cin, d.cout)
 
 
+FEATURE_DTYPES = (torch.float32, torch.bfloat16)
+
+
 def to_cl(t, name="feats"):
-    """Logical [b,c,p,a] float32 device tensor -> channels-last contiguous (no copy if already so)."""
+    """Logical [b,c,p,a] float32 / bfloat16 device tensor -> channels-last contiguous (no copy if already so)."""
     if not t.is_cuda:
         raise RuntimeError(f"{name} must be a CUDA tensor")
-    if t.dtype != torch.float32:
-        raise TypeError(f"{name} must be float32, got {t.dtype} (bf16 variants: later round)")
+    if t.dtype not in FEATURE_DTYPES:
+        raise TypeError(f"{name} must be float32 or bfloat16, got {t.dtype}")
     if t.dim() != 4:
         raise ValueError(f"{name} must be [b,c,p,a]")
     return t.contiguous(memory_format=torch.channels_last)
@@ -66,8 +69,37 @@ def _cl_ptr(t):
     return ctypes.c_void_p(t.data_ptr())
 
 
-def empty_cl(b, c, p, a, device):
-    return torch.empty((b, c, p, a), dtype=torch.float32, device=device, memory_format=torch.channels_last)
+def empty_cl(b, c, p, a, device, dtype=torch.float32):
+    return torch.empty((b, c, p, a), dtype=dtype, device=device, memory_format=torch.channels_last)
+
+
+def _entry(lib, base, dtype):
+    """C entry point of `base` for a feature dtype: epn_<base>_f32 | epn_<base>_bf16."""
+    return getattr(lib, f"epn_{base}_{'bf16' if dtype == torch.bfloat16 else 'f32'}")
+
+
+class CastFn(torch.autograd.Function):
+    """fp32 <-> bf16 copy on the library's cast kernel (the seams of the bf16 feature path: after the fp32 first layer,
+    before the fp32 PointnetSO3Conv / heads); the gradient is cast back."""
+
+    @staticmethod
+    def forward(ctx, x, dtype):
+        ctx.src = x.dtype
+        if x.dim() == 4:
+            x = to_cl(x)
+            out = torch.empty_like(x, dtype=dtype)      # preserves channels-last strides
+            _lib.check(_lib.get_lib().epn_cast(x.data_ptr(), out.data_ptr(), x.numel(), int(x.dtype == torch.bfloat16),
+                                               int(dtype == torch.bfloat16), _lib.stream_of(x)), "cast")
+            return out
+        return gemm.cast(x.contiguous(), dtype)
+
+    @staticmethod
+    def backward(ctx, g):
+        return CastFn.apply(g, ctx.src), None
+
+
+def cast_feats(x, dtype):
+    return x if x.dtype == dtype else CastFn.apply(x, dtype)
 
 
 class InterGeometry:
@@ -212,10 +244,10 @@ class InterGroupFn(torch.autograd.Function):
         if f.shape[2] != d.p1 or f.shape[3] != d.na or f.shape[0] != d.b:
             raise ValueError(f"shape mismatch: feats {tuple(f.shape)}, geometry b={d.b} p1={d.p1} na={d.na}")
         cols = d.b * d.p2 * d.na
-        G = torch.empty((cols, cin * d.ks), dtype=torch.float32, device=f.device)
+        G = torch.empty((cols, cin * d.ks), dtype=f.dtype, device=f.device)
         ws, wsp, wsn = _group_workspace(lib, d, f.device)
-        _lib.check(lib.epn_inter_group_f32(ctypes.byref(d), _cl_ptr(f), _lib.dev_ptr(G, "grouped"), wsp, wsn,
-                                           _lib.stream_of(f)), "inter_group")
+        _lib.check(_entry(lib, "inter_group", f.dtype)(ctypes.byref(d), _cl_ptr(f), ctypes.c_void_p(G.data_ptr()), wsp,
+                                                       wsn, _lib.stream_of(f)), "inter_group")
         ctx.geo, ctx.cin = geo, cin
         return G
 
@@ -224,11 +256,11 @@ class InterGroupFn(torch.autograd.Function):
         lib = _lib.get_lib()
         d = ctx.geo.desc(ctx.cin, 16)
         dG = dG.contiguous()
-        gf = empty_cl(d.b, ctx.cin, d.p1, d.na, dG.device)
+        gf = empty_cl(d.b, ctx.cin, d.p1, d.na, dG.device)          # the scatter target is fp32 for either dtype
         ws, wsp, wsn = _group_workspace(lib, d, dG.device)
-        _lib.check(lib.epn_inter_ungroup_f32(ctypes.byref(d), _lib.dev_ptr(dG, "grad_grouped"), _cl_ptr(gf), wsp, wsn,
-                                             _lib.stream_of(dG)), "inter_ungroup")
-        return gf, None
+        _lib.check(_entry(lib, "inter_ungroup", dG.dtype)(ctypes.byref(d), ctypes.c_void_p(dG.data_ptr()), _cl_ptr(gf),
+                                                         wsp, wsn, _lib.stream_of(dG)), "inter_ungroup")
+        return cast_feats(gf, dG.dtype), None
 
 
 def inter_group(feats, geo):
@@ -255,13 +287,15 @@ class InterSO3ConvSplitFn(torch.autograd.Function):
             raise ValueError(f"shape mismatch: feats {tuple(f.shape)}, W {tuple(Wc.shape)}, geometry "
                              f"b={d.b} p1={d.p1} na={d.na} ks={d.ks}")
         cols = d.b * d.p2 * d.na
-        G = torch.empty((cols, ck), dtype=torch.float32, device=f.device)
+        G = torch.empty((cols, ck), dtype=f.dtype, device=f.device)
         ws, wsp, wsn = _group_workspace(lib, d, f.device)
         gflops = 9.0 * cols * d.ks * d.nn + 2.0 * cols * cin * d.ks * d.nn
+        grp = _entry(lib, "inter_group", f.dtype)
         _lib.check(_launch("inter_group", _inter_key(d), gflops, f.device,
-                           lambda: lib.epn_inter_group_f32(ctypes.byref(d), _cl_ptr(f), _lib.dev_ptr(G, "grouped"), wsp,
-                                                           wsn, _lib.stream_of(f))), "inter_group")
-        out2d = _launch("inter_gemm", _inter_key(d), 2.0 * cols * cout * ck, f.device, lambda: gemm.gemm_nt(G, Wc))
+                           lambda: grp(ctypes.byref(d), _cl_ptr(f), ctypes.c_void_p(G.data_ptr()), wsp, wsn,
+                                       _lib.stream_of(f))), "inter_group")
+        Wd = gemm.cast(Wc, f.dtype)                                  # fp32 master weights; bf16 copy per call
+        out2d = _launch("inter_gemm", _inter_key(d), 2.0 * cols * cout * ck, f.device, lambda: gemm.gemm_nt(G, Wd))
         ctx.save_for_backward(G, Wc)
         ctx.geo, ctx.cin = geo, cin
         return out2d.view(d.b, d.p2, d.na, cout).permute(0, 3, 1, 2)
@@ -274,7 +308,7 @@ class InterSO3ConvSplitFn(torch.autograd.Function):
         cout, ck = Wc.shape
         d = geo.desc(cin, cout)
         cols = d.b * d.p2 * d.na
-        g = to_cl(grad_out, "grad_out")
+        g = cast_feats(to_cl(grad_out, "grad_out"), G.dtype)
         g2d = g.permute(0, 2, 3, 1).reshape(cols, cout)   # view of the channels-last buffer
         need_f, need_w = ctx.needs_input_grad[0], ctx.needs_input_grad[1]
         gemm_fl = 2.0 * cols * cout * ck
@@ -282,9 +316,11 @@ class InterSO3ConvSplitFn(torch.autograd.Function):
         if need_w:
             gW = _launch("inter_gemm_dw", _inter_key(d), gemm_fl, G.device, lambda: gemm.gemm_tn(g2d, G))
         if need_f:
-            gf = empty_cl(d.b, cin, d.p1, d.na, G.device)
+            gf = empty_cl(d.b, cin, d.p1, d.na, G.device)           # fp32: the scatter target of either dtype
             mode = os.environ.get("EPN_INTER_BWD_DATA", "auto")
-            if mode == "auto":          # widest layers: library dG GEMM + scatter beats the fused kernel (measured)
+            if G.dtype != torch.float32:
+                mode = "split"          # bf16 features: dG GEMM on the bf16 MFMA kernel + scatter
+            elif mode == "auto":        # widest layers: dG GEMM + scatter beats the fused kernel (measured)
                 mode = "split" if cin * cout >= 65536 else "fused"
             if mode == "fused" and lib.epn_inter_is_fused(ctypes.byref(d)) and cin >= 16:
                 # The fused data-gradient kernel (W^T dOut + per-column tail in one pass, no dG tensor) beats
@@ -300,14 +336,15 @@ class InterSO3ConvSplitFn(torch.autograd.Function):
                                                                               wsn, _lib.stream_of(G))),
                            "inter_so3conv_bwd_data")
             else:
-                Wt = gemm.transpose_cast(Wc, Wc.dtype)                       # [ck, cout]: dG = dOut W as an NT GEMM
+                Wt = gemm.transpose_cast(Wc, G.dtype)                        # [ck, cout]: dG = dOut W as an NT GEMM
                 dG = _launch("inter_gemm", _inter_key(d), gemm_fl, G.device, lambda: gemm.gemm_nt(g2d, Wt))
                 ws, wsp, wsn = _group_workspace(lib, d, G.device)
                 gflops = 9.0 * cols * d.ks * d.nn + 2.0 * cols * cin * d.ks * d.nn
+                ungrp = _entry(lib, "inter_ungroup", G.dtype)
                 _lib.check(_launch("inter_ungroup", _inter_key(d), gflops, G.device,
-                                   lambda: lib.epn_inter_ungroup_f32(ctypes.byref(d), _lib.dev_ptr(dG, "grad_grouped"),
-                                                                     _cl_ptr(gf), wsp, wsn, _lib.stream_of(G))),
-                           "inter_ungroup")
+                                   lambda: ungrp(ctypes.byref(d), ctypes.c_void_p(dG.data_ptr()), _cl_ptr(gf), wsp, wsn,
+                                                 _lib.stream_of(G))), "inter_ungroup")
+            gf = cast_feats(gf, G.dtype)
         return gf, gW, None
 
 
@@ -425,11 +462,21 @@ class IntraSO3ConvFn(torch.autograd.Function):
         return gf, gW, None
 
 
+def _intra_group(lib, f, idx32, b, p, na, kn, c):
+    """grouped[col][k*c + ci] = f[b][p][idx[a,k]][ci] (epn_intra_group_*), any feature dtype."""
+    G = torch.empty((b * p * na, kn * c), dtype=f.dtype, device=f.device)
+    _lib.check(_launch("intra_group", (b, p, na, kn, c), 0.0, f.device,
+                       lambda: _entry(lib, "intra_group", f.dtype)(
+                           _cl_ptr(f), _lib.dev_ptr(idx32, "intra_idx", torch.int32), ctypes.c_void_p(G.data_ptr()),
+                           b, p, na, kn, c, _lib.stream_of(f))), "intra_group")
+    return G
+
+
 class IntraSO3ConvSplitFn(torch.autograd.Function):
     """IntraSO3Conv in the reference's two steps (intra_so3conv_grouping, then BasicSO3Conv's matmul): the anchor
-    gather as one streaming HIP kernel writing grouped[col][kn*cin], `out = grouped Wp^T` and `dW = dOut^T grouped` as
-    library fp32 GEMMs; the data gradient stays on the fused kernel (no grouped-gradient tensor).  `grouped` is kept
-    for the backward pass (training-time choice, like InterSO3ConvSplitFn)."""
+    gather as one streaming HIP kernel writing grouped[col][kn*cin], `out = grouped Wp^T` and `dW = dOut^T grouped` on
+    the library's GEMM kernels.  Data gradient: fp32 on the fused kernel (no grouped-gradient tensor); bf16 as the same
+    two steps through the inverse anchor permutation.  `grouped` is kept for the backward pass."""
 
     @staticmethod
     def forward(ctx, feats, W, intra_idx32):
@@ -443,12 +490,8 @@ class IntraSO3ConvSplitFn(torch.autograd.Function):
             raise ValueError(f"shape mismatch: feats {tuple(f.shape)}, W {tuple(Wc.shape)}, "
                              f"intra_idx {tuple(intra_idx32.shape)}")
         cols = b * p * na
-        G = torch.empty((cols, kn * cin), dtype=torch.float32, device=f.device)
-        _lib.check(_launch("intra_group", (b, p, na, kn, cin, cout), 0.0, f.device,
-                           lambda: lib.epn_intra_group_f32(_cl_ptr(f), _lib.dev_ptr(intra_idx32, "intra_idx", torch.int32),
-                                                           _lib.dev_ptr(G, "grouped"), b, p, na, kn, cin,
-                                                           _lib.stream_of(f))), "intra_group")
-        Wp = Wc.view(cout, cin, kn).permute(0, 2, 1).reshape(cout, kn * cin)      # [o][k*cin + c]
+        G = _intra_group(lib, f, intra_idx32, b, p, na, kn, cin)
+        Wp = gemm.cast(Wc.view(cout, cin, kn).permute(0, 2, 1).reshape(cout, kn * cin), f.dtype)     # [o][k*cin + c]
         fl = 2.0 * cols * cout * cin * kn
         out2d = _launch("intra_gemm", (b, p, na, kn, cin, cout), fl, f.device, lambda: gemm.gemm_nt(G, Wp))
         ctx.save_for_backward(G, Wc, intra_idx32)
@@ -462,7 +505,7 @@ class IntraSO3ConvSplitFn(torch.autograd.Function):
         b, cin, p, na = ctx.dims
         cout, kn = Wc.shape[0], iidx.shape[1]
         cols = b * p * na
-        g = to_cl(grad_out, "grad_out")
+        g = cast_feats(to_cl(grad_out, "grad_out"), G.dtype)
         fl = 2.0 * cols * cout * cin * kn
         gf = gW = None
         if ctx.needs_input_grad[1]:
@@ -470,15 +513,25 @@ class IntraSO3ConvSplitFn(torch.autograd.Function):
             gWp = _launch("intra_gemm_dw", (b, p, na, kn, cin, cout), fl, G.device, lambda: gemm.gemm_tn(g2d, G))
             gW = gWp.view(cout, kn, cin).permute(0, 2, 1).reshape(cout, cin * kn)
         if ctx.needs_input_grad[0]:
-            gf = empty_cl(b, cin, p, na, G.device)
             inv = inverse_intra_idx(iidx)
-            ws, wsp, wsn = _intra_ws(lib, na, kn, cin, cout, G.device)
-            _lib.check(_launch("intra_bwd_data", (b, p, na, kn, cin, cout), fl, G.device,
-                               lambda: lib.epn_intra_so3conv_bwd_data_f32(
-                                   _cl_ptr(g), _lib.dev_ptr(iidx, "intra_idx", torch.int32),
-                                   _lib.dev_ptr(inv, "inv_idx", torch.int32), _lib.dev_ptr(Wc, "W"),
-                                   b, p, na, kn, cin, cout, _cl_ptr(gf), wsp, wsn, _lib.stream_of(G))),
-                       "intra_so3conv_bwd_data")
+            if G.dtype == torch.float32 or inv is None:
+                gf = empty_cl(b, cin, p, na, G.device)
+                g32 = cast_feats(g, torch.float32)
+                ws, wsp, wsn = _intra_ws(lib, na, kn, cin, cout, G.device)
+                _lib.check(_launch("intra_bwd_data", (b, p, na, kn, cin, cout), fl, G.device,
+                                   lambda: lib.epn_intra_so3conv_bwd_data_f32(
+                                       _cl_ptr(g32), _lib.dev_ptr(iidx, "intra_idx", torch.int32),
+                                       _lib.dev_ptr(inv, "inv_idx", torch.int32), _lib.dev_ptr(Wc, "W"),
+                                       b, p, na, kn, cin, cout, _cl_ptr(gf), wsp, wsn, _lib.stream_of(G))),
+                           "intra_so3conv_bwd_data")
+                gf = cast_feats(gf, G.dtype)
+            else:
+                # dF[col][ci] = sum_{k,o} dOut[pt, inv[a,k], o] W[o, ci*kn + k]: gather through the inverse permutation,
+                # then an NT GEMM against W re-ordered to [ci][k*cout + o]
+                Gd = _intra_group(lib, g, inv, b, p, na, kn, cout)
+                Wq = gemm.cast(Wc.view(cout, cin, kn).permute(1, 2, 0).reshape(cin, kn * cout), G.dtype)
+                gf2d = _launch("intra_gemm", (b, p, na, kn, cout, cin), fl, G.device, lambda: gemm.gemm_nt(Gd, Wq))
+                gf = gf2d.view(b, p, na, cin).permute(0, 3, 1, 2)
         return gf, gW, None
 
 
@@ -528,8 +581,11 @@ def spectral_basis(intra_idx32):
 
 
 def _basis_call(lib, src, M, basis, pts, c, in_spec, out_spec, dst, kind):
+    if src.dtype != dst.dtype or src.dtype not in FEATURE_DTYPES:
+        raise TypeError(f"so3_basis: {src.dtype} -> {dst.dtype}")
+    fn = _entry(lib, "so3_basis", src.dtype)
     _lib.check(_launch(kind, ("so3_basis", pts, c), 2.0 * pts * basis.na * basis.na * c, src.device,
-                       lambda: lib.epn_so3_basis_f32(ctypes.c_void_p(src.data_ptr()), _lib.dev_ptr(M, "M"),
+                       lambda: fn(ctypes.c_void_p(src.data_ptr()), _lib.dev_ptr(M, "M"),
                                                      _lib.dev_ptr(basis.blocks, "blocks", torch.int32),
                                                      ctypes.c_longlong(pts), basis.na, c, in_spec, out_spec,
                                                      ctypes.c_void_p(dst.data_ptr()), _lib.stream_of(src))),
@@ -545,7 +601,7 @@ class ToSpectralFn(torch.autograd.Function):
         lib = _lib.get_lib()
         f = to_cl(feats)
         b, c, p, na = f.shape
-        y = torch.empty(na * b * p * c, dtype=torch.float32, device=f.device)
+        y = torch.empty(na * b * p * c, dtype=f.dtype, device=f.device)
         _basis_call(lib, f, basis.Ut, basis, b * p, c, 0, 1, y, "so3_basis")
         ctx.basis, ctx.dims = basis, (b, c, p, na)
         return y
@@ -554,7 +610,7 @@ class ToSpectralFn(torch.autograd.Function):
     def backward(ctx, gy):
         lib = _lib.get_lib()
         b, c, p, na = ctx.dims
-        gf = empty_cl(b, c, p, na, gy.device)
+        gf = empty_cl(b, c, p, na, gy.device, gy.dtype)
         _basis_call(lib, gy.contiguous(), ctx.basis.U, ctx.basis, b * p, c, 1, 0, gf, "so3_basis")
         return gf, None
 
@@ -565,7 +621,7 @@ class FromSpectralFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, y, basis, b, p, c):
         lib = _lib.get_lib()
-        out = empty_cl(b, c, p, basis.na, y.device)
+        out = empty_cl(b, c, p, basis.na, y.device, y.dtype)
         _basis_call(lib, y.contiguous(), basis.U, basis, b * p, c, 1, 0, out, "so3_basis")
         ctx.basis, ctx.dims = basis, (b, c, p)
         return out
@@ -575,7 +631,7 @@ class FromSpectralFn(torch.autograd.Function):
         lib = _lib.get_lib()
         b, c, p = ctx.dims
         g = to_cl(gout, "grad_out")
-        gy = torch.empty(ctx.basis.na * b * p * c, dtype=torch.float32, device=g.device)
+        gy = torch.empty(ctx.basis.na * b * p * c, dtype=g.dtype, device=g.device)
         _basis_call(lib, g, ctx.basis.Ut, ctx.basis, b * p, c, 0, 1, gy, "so3_basis")
         return gy, None, None, None, None
 
@@ -664,13 +720,15 @@ class NormActFn(torch.autograd.Function):
         sums = torch.empty((groups, c, 2), dtype=torch.float32, device=xc.device)
         st = _lib.stream_of(xc)
         ws = torch.empty(max(int(lib.epn_norm_workspace_bytes(groups, rows, c)), 16), dtype=torch.uint8, device=xc.device)
-        _lib.check(lib.epn_chan_stats_f32(_cl_ptr(xc), groups, rows, c, _lib.dev_ptr(sums, "sums"),
-                                          ctypes.c_void_p(ws.data_ptr()), ctypes.c_size_t(ws.numel()), st), "chan_stats")
-        y = empty_cl(b, c, p, a, xc.device)
+        dt = xc.dtype
+        _lib.check(_entry(lib, "chan_stats", dt)(_cl_ptr(xc), groups, rows, c, _lib.dev_ptr(sums, "sums"),
+                                                 ctypes.c_void_p(ws.data_ptr()), ctypes.c_size_t(ws.numel()), st),
+                   "chan_stats")
+        y = empty_cl(b, c, p, a, xc.device, dt)
         g = gamma.contiguous() if gamma is not None else None
         bt = beta.contiguous() if beta is not None else None
-        r = to_cl(residual, "residual") if residual is not None else None
-        _lib.check(lib.epn_norm_act_fwd_f32(_cl_ptr(xc), groups, rows, c, _lib.dev_ptr(sums, "sums"),
+        r = cast_feats(to_cl(residual, "residual"), dt) if residual is not None else None
+        _lib.check(_entry(lib, "norm_act_fwd", dt)(_cl_ptr(xc), groups, rows, c, _lib.dev_ptr(sums, "sums"),
                                             _lib.dev_ptr(g, "gamma"), _lib.dev_ptr(bt, "beta"),
                                             _cl_ptr(r) if r is not None else ctypes.c_void_p(0), float(eps),
                                             float(slope), _cl_ptr(y), st), "norm_act_fwd")
@@ -684,14 +742,14 @@ class NormActFn(torch.autograd.Function):
         lib = _lib.get_lib()
         xc, sums, g, bt = ctx.saved_tensors
         groups, rows, c, eps, slope, has_res, has_cb = ctx.cfg
-        dy = to_cl(grad_y, "grad_y")
+        dy = cast_feats(to_cl(grad_y, "grad_y"), xc.dtype)
         st = _lib.stream_of(xc)
         dsums = torch.empty_like(sums)
         dg = torch.empty(c, dtype=torch.float32, device=xc.device) if g is not None else None
         db = torch.empty(c, dtype=torch.float32, device=xc.device) if bt is not None else None
         gp, bp = _lib.dev_ptr(g, "gamma"), _lib.dev_ptr(bt, "beta")
         ws = torch.empty(max(int(lib.epn_norm_workspace_bytes(groups, rows, c)), 16), dtype=torch.uint8, device=xc.device)
-        _lib.check(lib.epn_norm_act_bwd_reduce_f32(_cl_ptr(xc), _cl_ptr(dy), groups, rows, c,
+        _lib.check(_entry(lib, "norm_act_bwd_reduce", xc.dtype)(_cl_ptr(xc), _cl_ptr(dy), groups, rows, c,
                                                    _lib.dev_ptr(sums, "sums"), gp, bp, eps, slope,
                                                    _lib.dev_ptr(dsums, "dsums"), _lib.dev_ptr(dg, "dgamma"),
                                                    _lib.dev_ptr(db, "dbeta"), ctypes.c_void_p(ws.data_ptr()),
@@ -699,7 +757,7 @@ class NormActFn(torch.autograd.Function):
         dx = None
         if ctx.needs_input_grad[0]:
             dx = torch.empty_like(xc)
-            _lib.check(lib.epn_norm_act_bwd_apply_f32(_cl_ptr(xc), _cl_ptr(dy), groups, rows, c,
+            _lib.check(_entry(lib, "norm_act_bwd_apply", xc.dtype)(_cl_ptr(xc), _cl_ptr(dy), groups, rows, c,
                                                       _lib.dev_ptr(sums, "sums"), _lib.dev_ptr(dsums, "dsums"), gp, bp,
                                                       eps, slope, _cl_ptr(dx), st), "norm_act_bwd_apply")
         # conv_bias (a bias the normalisation cancels, see norm_act): exact gradient = 0
@@ -744,13 +802,19 @@ def inter_mode():
     return os.environ.get("EPN_INTER_MODE", "auto")
 
 
-def inter_so3conv(feats, W, geo):
+def inter_so3conv(feats, W, geo, out_dtype=None):
+    """InterSO3Conv's compute.  out_dtype (default: the dtype of feats) lets the fp32 first layer (cin = 1, all-ones
+    occupancy features) hand bf16 features to the rest of a bf16 network."""
     mode = inter_mode()
-    if isinstance(geo, DenseInterWeights):
-        return InterSO3ConvFn.apply(feats, W, geo)
-    if mode == "split" or (mode == "auto" and feats.shape[1] % 16 == 0):
-        return InterSO3ConvSplitFn.apply(feats, W, geo)
-    return InterSO3ConvFn.apply(feats, W, geo)
+    out_dtype = out_dtype or feats.dtype
+    split_ok = feats.shape[1] % 16 == 0 and not isinstance(geo, DenseInterWeights)
+    if feats.dtype == torch.bfloat16 and split_ok:
+        return cast_feats(InterSO3ConvSplitFn.apply(feats, W, geo), out_dtype)
+    if feats.dtype != torch.float32:         # shapes only the fp32 fused / generic kernels take
+        feats = cast_feats(feats, torch.float32)
+    if split_ok and mode in ("split", "auto"):
+        return cast_feats(InterSO3ConvSplitFn.apply(feats, W, geo), out_dtype)
+    return cast_feats(InterSO3ConvFn.apply(feats, W, geo), out_dtype)
 
 
 def intra_mode():
@@ -767,12 +831,16 @@ def intra_so3conv_fused(feats, W, intra_idx32):
 def intra_so3conv(feats, W, intra_idx32):
     mode = intra_mode()
     cin, cout = feats.shape[1], W.shape[0]
+    bf = feats.dtype == torch.bfloat16
     if mode in ("auto", "spectral") and feats.is_cuda and cin % 64 == 0 and cout % 64 == 0 and intra_idx32.shape[1] > 1:
         basis = spectral_basis(intra_idx32)
         if basis is not None:
             return intra_so3conv_spectral(feats, W, intra_idx32, basis)
-    if mode == "split" or (mode in ("auto", "spectral") and cin % 16 == 0 and cout % 16 == 0):
+    if (bf and cin % 8 == 0 and cout % 8 == 0) or mode == "split" or \
+            (mode in ("auto", "spectral") and cin % 16 == 0 and cout % 16 == 0):
         return IntraSO3ConvSplitFn.apply(feats, W, intra_idx32)
+    if bf:                                   # odd widths: fp32 kernels between two casts
+        return cast_feats(IntraSO3ConvFn.apply(cast_feats(feats, torch.float32), W, intra_idx32), torch.bfloat16)
     return IntraSO3ConvFn.apply(feats, W, intra_idx32)
 
 
@@ -785,6 +853,8 @@ class PointnetSO3ConvFn(torch.autograd.Function):
     def forward(ctx, feats, xyz, anchors, weight, bias):
         lib = _lib.get_lib()
         fc = to_cl(feats, "feats")
+        if fc.dtype != torch.float32:
+            raise TypeError("PointnetSO3ConvFn takes fp32 features (pointnet_so3conv casts bf16 ones)")
         b, c, p, a = fc.shape
         co = weight.shape[0]
         if weight.numel() != co * (c + 3):
@@ -847,19 +917,28 @@ def _identity_index(na, device):
 
 
 def conv1x1(x, weight, bias=None):
-    """nn.Conv2d(cin, cout, 1) on a [b,c,p,a] tensor, channels-last in and out with no layout copy.
-    Runs on the intra GEMM kernel with a single, identity anchor neighbour.
-    Shapes the MFMA kernel does not take (cin = 1 of the first block, the few-channel heads) go to torch."""
+    """nn.Conv2d(cin, cout, 1) on a [b,c,p,a] tensor, channels-last in and out with no layout copy: one NT GEMM
+    [cols, cin] x [cout, cin]^T on the zero-copy 2-D view (fp32 master weight, cast per call for bf16 features).
+    fp32 with widths that are multiples of 16 keeps the intra GEMM kernel (single, identity anchor neighbour);
+    cin = 1 (the occupancy feature of the first block) is an outer product; odd shapes go to torch."""
     cout, cin = weight.shape[0], weight.shape[1]
-    if x.is_cuda and cin % 16 == 0 and cout % 16 == 0:
-        y = IntraSO3ConvFn.apply(x, weight.reshape(cout, cin), _identity_index(x.shape[3], x.device))
+    if x.is_cuda and x.dtype == torch.bfloat16 and cin % 8 == 0:
+        xc = to_cl(x)
+        b, c, p, a = xc.shape
+        y2d = gemm.matmul_nt(xc.permute(0, 2, 3, 1).reshape(-1, c), weight.reshape(cout, cin))
+        y = y2d.view(b, p, a, cout).permute(0, 3, 1, 2)
+    elif x.is_cuda and cin % 16 == 0 and cout % 16 == 0:
+        y = IntraSO3ConvFn.apply(cast_feats(x, torch.float32), weight.reshape(cout, cin),
+                                 _identity_index(x.shape[3], x.device))
+        y = cast_feats(y, x.dtype)
     elif x.is_cuda and cin == 1:
         # single input channel (the occupancy feature of the first block): an outer product, written channels-last
-        y = (to_cl(x).permute(0, 2, 3, 1) * weight.reshape(cout)).permute(0, 3, 1, 2)
+        y = (to_cl(x).permute(0, 2, 3, 1).float() * weight.reshape(cout)).permute(0, 3, 1, 2)
     else:
-        y = torch.nn.functional.conv2d(x, weight.reshape(cout, cin, 1, 1))
+        y = torch.nn.functional.conv2d(x.float(), weight.reshape(cout, cin, 1, 1))
     return y if bias is None else y + bias.view(1, -1, 1, 1)
 
 
 def pointnet_so3conv(feats, xyz, anchors, weight, bias):
-    return PointnetSO3ConvFn.apply(feats, xyz, anchors, weight, bias)
+    """bf16 features are converted once (the aggregation tail is < 1 % of a step and runs its fp32 kernels)."""
+    return PointnetSO3ConvFn.apply(cast_feats(feats, torch.float32), xyz, anchors, weight, bias)

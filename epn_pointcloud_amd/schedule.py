@@ -127,8 +127,9 @@ class SeparableBlock(nn.Module):
             feat = self._drop(F.leaky_relu(self.intra_conv.norm(z.feats)))
         if self.stride > 1:
             skip = zptk.functional.batched_index_select(skip, 2, sample_idx.long())
-        skip = F.leaky_relu(self.norm(self.skip_conv(skip)))
-        return inter_idx, inter_w, sample_idx, zptk.SphericalPointCloud(z.xyz, feat + skip, z.anchors)
+        skip = F.leaky_relu(self.norm(self.skip_conv(skip.float())))       # stock modules hold fp32 parameters
+        return inter_idx, inter_w, sample_idx, zptk.SphericalPointCloud(z.xyz, (feat.float() + skip).to(feat.dtype),
+                                                                        z.anchors)
 
 
 class FusedSeparableBlock(SeparableBlock):
@@ -228,6 +229,19 @@ class BasicBlock(nn.Module):
             if blk.stride > 1:
                 inter_idx, inter_w = None, None
         return x
+
+
+def set_feature_dtype(model, dtype):
+    """Feature storage dtype of a network built from the blocks above: torch.float32 (default) or torch.bfloat16
+    (BASELINE configs 3-4: bf16 features, fp32 accumulation).  Parameters, coordinates, indices and the kernel-influence
+    weights stay fp32; every InterSO3Conv emits features in `dtype` (the first layer computes in fp32 and converts),
+    everything downstream follows its input's dtype, heads / PointnetSO3Conv convert back to fp32."""
+    if dtype not in ops.FEATURE_DTYPES:
+        raise TypeError(f"feature dtype must be float32 or bfloat16, got {dtype}")
+    for m in model.modules():
+        if isinstance(m, sptk.InterSO3Conv):
+            m.feat_dtype = dtype
+    return model
 
 
 def stages(layers):

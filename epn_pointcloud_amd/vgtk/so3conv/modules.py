@@ -91,6 +91,7 @@ class InterSO3Conv(nn.Module):
         self.basic_conv = BasicSO3Conv(dim_in, dim_out, self.kernel_size)
         self.register_buffer('anchors', torch.from_numpy(np.ascontiguousarray(anchors)))
         self.register_buffer('kernels', torch.from_numpy(np.ascontiguousarray(kernels)))
+        self.feat_dtype = None     # output feature dtype; None = the input's (set by schedule.set_feature_dtype)
 
     def forward(self, x, inter_idx=None, inter_w=None):
         xyz, feats = x.xyz, x.feats
@@ -119,7 +120,7 @@ class InterSO3Conv(nn.Module):
                 handle = inter_w
             else:
                 handle = ops.DenseInterWeights(inter_idx.int().contiguous(), inter_w, xyz.shape[2])
-        out = ops.inter_so3conv(feats, self.basic_conv.W, handle)
+        out = ops.inter_so3conv(feats, self.basic_conv.W, handle, self.feat_dtype)
         return inter_idx, inter_w, sample_idx, SphericalPointCloud(new_xyz, out, self.anchors)
 
 

@@ -284,6 +284,37 @@ int epn_gemm_tn_bf16(const void *X, long long ldx, const void *Y, long long ldy,
 int epn_transpose_cast(const void *src, void *dst, int rows, int cols, int src_bf16, int dst_bf16, epn_stream_t stream);
 int epn_cast(const void *src, void *dst, size_t n, int src_bf16, int dst_bf16, epn_stream_t stream);
 
+/* ---------------------------------------------------------------------------------------------------------------------
+ * bf16 feature path (BASELINE configs 3-4: "bf16 features / fp32 accumulate"; the reference dispatches float/double only,
+ * grouping_cuda_kernel.cu:477,638, so these follow the same interfaces as their _f32 twins with feature tensors stored
+ * as bfloat16).  Coordinates, indices, kernel-influence weights w, statistics, affine parameters, weight gradients
+ * and every accumulation stay fp32; products inside the GEMMs are bf16 x bf16 -> fp32.
+ *   epn_inter_group_bf16   : feats_cl bf16 [b][p1][na][cin] -> grouped bf16 [b*p2*na][cin*ks]   (cin % 16 == 0)
+ *   epn_inter_ungroup_bf16 : grad_grouped bf16 -> grad_feats_cl **fp32** (atomic scatter target; convert with epn_cast)
+ *   epn_intra_group_bf16   : pure gather of bf16 rows (c % 8 == 0)
+ *   epn_so3_basis_bf16, epn_chan_stats_bf16, epn_norm_act_*_bf16: as the _f32 entry points, x / y / dy / dx / residual
+ *   in bf16.  The first layer (cin = 1) and PointnetSO3Conv run their fp32 kernels on tensors converted by epn_cast. */
+int epn_inter_group_bf16(const epn_inter_desc *d, const void *feats_cl, void *grouped, void *workspace,
+                         size_t workspace_bytes, epn_stream_t stream);
+int epn_inter_ungroup_bf16(const epn_inter_desc *d, const void *grad_grouped, float *grad_feats_cl, void *workspace,
+                           size_t workspace_bytes, epn_stream_t stream);
+int epn_intra_group_bf16(const void *feats_cl, const int32_t *intra_idx, void *grouped, int b, int p, int na, int kn,
+                         int c, epn_stream_t stream);
+int epn_so3_basis_bf16(const void *in, const float *M, const int32_t *blocks, long long pts, int na, int c,
+                       int in_spectral, int out_spectral, void *out, epn_stream_t stream);
+int epn_chan_stats_bf16(const void *x_cl, int groups, long long rows, int c, float *sums, void *workspace,
+                        size_t workspace_bytes, epn_stream_t stream);
+int epn_norm_act_fwd_bf16(const void *x_cl, int groups, long long rows, int c, const float *sums, const float *gamma,
+                          const float *beta, const void *residual_cl, float eps, float slope, void *y_cl,
+                          epn_stream_t stream);
+int epn_norm_act_bwd_reduce_bf16(const void *x_cl, const void *dy_cl, int groups, long long rows, int c,
+                                 const float *sums, const float *gamma, const float *beta, float eps, float slope,
+                                 float *dsums, float *dgamma, float *dbeta, void *workspace, size_t workspace_bytes,
+                                 epn_stream_t stream);
+int epn_norm_act_bwd_apply_bf16(const void *x_cl, const void *dy_cl, int groups, long long rows, int c,
+                                const float *sums, const float *dsums, const float *gamma, const float *beta, float eps,
+                                float slope, void *dx_cl, epn_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -1,0 +1,209 @@
+"""bf16 feature path (BASELINE configs 3-4: bf16 features, fp32 accumulation), through the C ABI.
+
+Tolerance.  A bf16 value carries 8 significant bits: rounding once is a relative error of at most 2^-9 = 1.95e-3.  The
+HIP path rounds (i) the grouped features G, (ii) the weights W, (iii) the layer output; the oracle below is the fp32
+restatement fed the SAME bf16-rounded inputs (features and weights), so what is compared is (i) + (iii) plus the
+re-association inside the GEMMs: an output element is a sum of K = cin*ks products each carrying an independent 2^-9
+relative error, i.e. ~ 2^-9 * |term| * sqrt(K) in absolute terms, bounded here by BF16_TOL = 2e-2 (a few 2^-9 units,
+with the random-walk factor folded in) relative to the largest reference magnitude of the tensor.  Gradients see one
+more rounding (dOut, dG) and use the same bound on the relative L2 error.
+"""
+import numpy as np
+import pytest
+import torch
+
+from conftest import unit_ball_cloud
+from oracle import so3conv_ref as R
+
+pytestmark = pytest.mark.gpu
+T = torch.from_numpy
+BF16_TOL = 2e-2
+
+
+def _mods(vgtk_alias):
+    import vgtk.so3conv as sptk
+    import vgtk.spconv as zptk
+    return sptk, zptk
+
+
+def r16(t):
+    """Round to bf16 and back (what the HIP path stores)."""
+    return t.to(torch.bfloat16).float()
+
+
+def rel_max(got, want):
+    return (got.float().cpu() - want).abs().max().item() / max(want.abs().max().item(), 1e-12)
+
+
+def rel_l2(got, want):
+    return ((got.float().cpu() - want).norm() / want.norm().clamp_min(1e-12)).item()
+
+
+# ------------------------------------------------------------------------------------------------ GEMM kernels
+@pytest.mark.parametrize("dt", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("M,N,K", [(1000, 64, 256), (513, 192, 320), (256, 32, 64), (777, 320, 128), (100, 24, 40),
+                                   (4096, 128, 1536), (1, 64, 64)])
+def test_gemm_nt_vs_fp64(gpu, dt, M, N, K):
+    from epn_pointcloud_amd import gemm
+    torch.manual_seed(M + N + K)
+    A = torch.randn(M, K, device=gpu).to(dt)
+    B = torch.randn(N, K, device=gpu).to(dt)
+    C = gemm.gemm_nt(A, B)
+    ref = A.double() @ B.double().t()
+    tol = 1e-5 if dt == torch.float32 else 1e-2         # fp32: exact-f32 MFMA; bf16: one output rounding (2^-9)
+    assert (C.double() - ref).abs().max().item() <= tol * ref.abs().max().item()
+
+
+@pytest.mark.parametrize("dt", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("R_,N1,N2", [(4096, 64, 512), (2048, 128, 192), (960, 32, 768), (1024, 256, 256), (100, 20, 36),
+                                      (61440, 64, 1536), (32, 8, 8)])
+def test_gemm_tn_vs_fp64(gpu, dt, R_, N1, N2):
+    from epn_pointcloud_amd import gemm
+    torch.manual_seed(R_ + N1 + N2)
+    X = torch.randn(R_, N1, device=gpu).to(dt)
+    Y = torch.randn(R_, N2, device=gpu).to(dt)
+    C = gemm.gemm_tn(X, Y)
+    ref = X.double().t() @ Y.double()
+    assert (C.double() - ref).abs().max().item() <= 2e-5 * ref.abs().max().item() * max(1.0, (R_ / 4096) ** 0.5)
+    # the split over R is summed in a fixed order: bitwise repeatable
+    assert torch.equal(C, gemm.gemm_tn(X, Y))
+
+
+def test_gemm_grouped_and_transpose(gpu):
+    from epn_pointcloud_amd import gemm
+    torch.manual_seed(3)
+    probs = []
+    for d in (1, 3, 3, 4, 5):
+        probs.append((torch.randn(640 * d, 64 * d, device=gpu), torch.randn(64 * d, 64 * d, device=gpu), None))
+    outs = gemm.gemm_nt_grouped(probs)
+    for (A, B, _), C in zip(probs, outs):
+        ref = A.double() @ B.double().t()
+        assert (C.double() - ref).abs().max().item() <= 1e-5 * ref.abs().max().item()
+    W = torch.randn(96, 200, device=gpu)
+    assert torch.equal(gemm.transpose_cast(W, torch.float32), W.t().contiguous())
+    assert torch.equal(gemm.transpose_cast(W, torch.bfloat16), W.t().contiguous().bfloat16())
+    assert torch.equal(gemm.cast(W, torch.bfloat16), W.bfloat16())
+
+
+# ------------------------------------------------------------------------------------------------ convolutions
+@pytest.mark.parametrize("cin,cout,stride,K", [(32, 32, 1, 32), (32, 64, 2, 64), (64, 64, 1, 16), (16, 48, 2, 20)])
+def test_inter_bf16_vs_oracle(gpu, vgtk_alias, cin, cout, stride, K):
+    sptk, zptk = _mods(vgtk_alias)
+    rng = np.random.default_rng(cin + K)
+    torch.manual_seed(cin + K)
+    xyz = T(unit_ball_cloud(rng, 2, 128))
+    conv = sptk.InterSO3Conv(cin, cout, 1, stride, 0.4, 0.08, K, lazy_sample=True)
+    conv.basic_conv.W.data = r16(conv.basic_conv.W.data)
+    feats = r16(torch.randn(2, cin, 128, 60))
+    fo = feats.clone().requires_grad_(True)
+    Wo = conv.basic_conv.W.detach().clone().requires_grad_(True)
+    o_idx, _, o_sidx, _, oy = R.inter_so3conv(xyz, fo, Wo, conv.anchors, conv.kernels, stride, 0.4, 0.08, K, True)
+    gy = r16(torch.randn_like(oy))
+    odW, odF = torch.autograd.grad(oy, [Wo, fo], gy)
+    conv = conv.to(gpu)
+    fg = feats.to(gpu).bfloat16().requires_grad_(True)
+    iidx, _, sidx, y = conv(zptk.SphericalPointCloud(xyz.to(gpu), fg, None))
+    assert y.feats.dtype == torch.bfloat16
+    dW, dF = torch.autograd.grad(y.feats, [conv.basic_conv.W, fg], gy.to(gpu).bfloat16())
+    assert torch.equal(iidx.cpu(), o_idx) and torch.equal(sidx.cpu(), o_sidx)      # index work is fp32: bit-exact
+    assert dW.dtype == torch.float32 and dF.dtype == torch.bfloat16
+    assert rel_max(y.feats.detach(), oy.detach()) < BF16_TOL
+    assert rel_l2(dW, odW) < BF16_TOL
+    assert rel_l2(dF, odF) < BF16_TOL
+
+
+@pytest.mark.parametrize("cin,cout,p", [(64, 64, 48), (128, 64, 16), (32, 32, 40), (32, 64, 24)])
+def test_intra_bf16_vs_oracle(gpu, vgtk_alias, cin, cout, p):
+    """64-multiples take the spectral form (bf16 basis change + bf16 block GEMMs), the 32-channel layers of the
+    rotation / 3DMatch schedules the split form."""
+    sptk, zptk = _mods(vgtk_alias)
+    torch.manual_seed(cin + p)
+    conv = sptk.IntraSO3Conv(cin, cout)
+    conv.basic_conv.W.data = r16(conv.basic_conv.W.data)
+    feats = r16(torch.randn(2, cin, p, 60))
+    fo = feats.clone().requires_grad_(True)
+    Wo = conv.basic_conv.W.detach().clone().requires_grad_(True)
+    oy = R.intra_so3conv(fo, Wo, conv.intra_idx)
+    gy = r16(torch.randn_like(oy))
+    odW, odF = torch.autograd.grad(oy, [Wo, fo], gy)
+    conv = conv.to(gpu)
+    fg = feats.to(gpu).bfloat16().requires_grad_(True)
+    y = conv(zptk.SphericalPointCloud(torch.zeros(2, 3, p, device=gpu), fg, None))
+    assert y.feats.dtype == torch.bfloat16
+    dW, dF = torch.autograd.grad(y.feats, [conv.basic_conv.W, fg], gy.to(gpu).bfloat16())
+    assert rel_max(y.feats.detach(), oy.detach()) < BF16_TOL
+    assert rel_l2(dW, odW) < BF16_TOL
+    assert rel_l2(dF, odF) < BF16_TOL
+
+
+@pytest.mark.parametrize("instance", [False, True])
+def test_norm_act_bf16(gpu, instance):
+    from epn_pointcloud_amd import ops
+    torch.manual_seed(5)
+    x = r16(torch.randn(3, 32, 50, 60) * 2 + 0.5)
+    res = r16(torch.randn(3, 32, 50, 60))
+    norm = (torch.nn.InstanceNorm2d(32, affine=False) if instance else torch.nn.BatchNorm2d(32)).train()
+    xo = x.clone().requires_grad_(True)
+    ro = res.clone().requires_grad_(True)
+    yo = torch.nn.functional.leaky_relu(norm(xo)) + ro
+    gy = r16(torch.randn_like(yo))
+    odx, odr = torch.autograd.grad(yo, [xo, ro], gy)
+    norm2 = (torch.nn.InstanceNorm2d(32, affine=False) if instance else torch.nn.BatchNorm2d(32)).to(gpu).train()
+    xg = x.to(gpu).bfloat16().requires_grad_(True)
+    rg = res.to(gpu).bfloat16().requires_grad_(True)
+    y = ops.norm_act(xg, norm2, residual=rg)
+    assert y.dtype == torch.bfloat16
+    dx, dr = torch.autograd.grad(y, [xg, rg], gy.to(gpu).bfloat16())
+    assert rel_max(y.detach(), yo.detach()) < 1e-2          # statistics and arithmetic are fp32: one output rounding
+    assert rel_l2(dx, odx) < 1e-2 and rel_l2(dr, odr) < 1e-2
+
+
+def test_separable_block_bf16_tracks_fp32(gpu, vgtk_alias):
+    """One FusedSeparableBlock (inter -> norm -> intra -> norm + skip) in bf16 against the same block in fp32."""
+    from epn_pointcloud_amd import schedule as S
+    sptk, zptk = _mods(vgtk_alias)
+    rng = np.random.default_rng(9)
+    torch.manual_seed(9)
+    layer = S.Layer(64, 64, 1, 0.4, 0.08, 16, True, 1)
+    blk = S.FusedSeparableBlock(layer, 60, None).to(gpu).train()
+    xyz = T(unit_ball_cloud(rng, 2, 128)).to(gpu)
+    feats = torch.randn(2, 64, 128, 60, device=gpu)
+    _, _, _, y32 = blk(zptk.SphericalPointCloud(xyz, feats, None))
+    S.set_feature_dtype(blk, torch.bfloat16)
+    _, _, _, y16 = blk(zptk.SphericalPointCloud(xyz, feats.bfloat16(), None))
+    assert y16.feats.dtype == torch.bfloat16
+    assert rel_l2(y16.feats, y32.feats.float().cpu()) < 3e-2
+
+
+# ------------------------------------------------------------------------------------------------ configs 3 and 4
+@pytest.mark.parametrize("model,points,batch", [("reg", 1024, 64), ("inv", 2048, 64)])
+def test_config_full_size_bf16(gpu, model, points, batch):
+    """BASELINE configs 3 (ModelNet40 rotation estimation: 32 pairs = 64 clouds, N=1024) and 4 (3DMatch descriptor:
+    64 patches, N=2048) at their stated size in bf16: forward + backward run, everything finite, and the network output
+    tracks the fp32 network (same weights, same clouds; whose kernels are oracle-checked in test_gpu_conv.py) -- the
+    size-independent property available for a float pipeline.  The index work (FPS, ball query) is fp32 in both."""
+    from epn_pointcloud_amd import models as M, schedule as S
+    torch.manual_seed(11)
+    build = M.build_reg if model == "reg" else M.build_inv
+    net = build(points).to(gpu).train()
+    scale = 0.4 if model == "inv" else 1.0
+    pts = S.synthetic_clouds(batch, points, gpu, seed=77, scale=scale)
+    inp = pts.view(batch // 2, 2, points, 3) if model == "reg" else pts
+
+    def run():
+        for p in net.parameters():
+            p.grad = None
+        out = net(inp)
+        loss = out[0].float().square().mean() + (out[1].float().square().mean() if model == "reg" else 0.0)
+        loss.backward()
+        feats = out[0].detach().float().cpu()
+        g = torch.cat([p.grad.flatten().float().cpu() for p in net.parameters() if p.grad is not None])
+        return loss.item(), feats, g
+
+    l32, f32, g32 = run()
+    S.set_feature_dtype(net, torch.bfloat16)
+    l16, f16, g16 = run()
+    assert np.isfinite(l16) and torch.isfinite(f16).all() and torch.isfinite(g16).all()
+    # 7-8 blocks deep, each rounding its activations to 8 bits: a few percent at the output
+    assert abs(l16 - l32) <= 0.1 * abs(l32) + 1e-6
+    assert rel_l2(f16, f32) < 0.15

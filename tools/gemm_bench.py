@@ -26,11 +26,32 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--dtype", default="f32")
     ap.add_argument("--quick", action="store_true")
+    ap.add_argument("--one", default="", help="profile mode: 'nt:M,N,K' or 'tn:R,N1,N2' -> 3 launches of that problem (own + torch)")
+    ap.add_argument("--cfg", type=int, default=0, help="NT tile override (csrc/gemm.hip launch_nt_typed), 0 = heuristic")
     a = ap.parse_args()
+    if a.cfg:
+        from epn_pointcloud_amd import _lib
+        _lib.check(_lib.get_lib().epn_set_kernel_policy(0x100 | a.cfg), "set_kernel_policy")
     dt = torch.float32 if a.dtype == "f32" else torch.bfloat16
     dev = torch.device("cuda:0")
     torch.manual_seed(0)
     tol = 2e-3 if dt == torch.float32 else 3e-2
+
+    if a.one:
+        kind, dims = a.one.split(":")
+        d0, d1, d2 = (int(v) for v in dims.split(","))
+        if kind == "nt":
+            A = torch.randn(d0, d2, device=dev).to(dt); B = torch.randn(d1, d2, device=dev).to(dt)
+            for _ in range(3):
+                gemm.gemm_nt(A, B)
+                torch.mm(A, B.t())
+        else:
+            X = torch.randn(d0, d1, device=dev).to(dt); Y = torch.randn(d0, d2, device=dev).to(dt)
+            for _ in range(3):
+                gemm.gemm_tn(X, Y)
+                torch.mm(X.t(), Y)
+        torch.cuda.synchronize()
+        return
 
     # ---- small correctness cases vs fp64 (edges: ragged M, N not a tile multiple)
     for (M, N, K) in [(1000, 64, 256), (513, 192, 320), (256, 32, 64), (777, 320, 128), (100, 24, 40)]:
