@@ -1,15 +1,20 @@
 #!/usr/bin/env python3
-"""bench.py -- point-clouds/sec, forward + backward, of the EPN hot path on MI355X.
+"""bench.py -- point-clouds/sec of the EPN hot path on MI355X.
 
-    python bench.py --gpus N --steps K --warmup W
-    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 ... bench.py --gpus N ...
+    python bench.py --gpus N --steps K --warmup W [--model cls|reg|inv] [--dtype f32|bf16] [--forward-only]
 
-Workload (BASELINE.json configs[1]): the ModelNet40 classification network cls_so3net_pn, B=32 clouds per GPU, N=1024
-points, K=32/16 neighbours, A=60 anchors, fp32 -- 7 separable blocks (FPS -> ball query -> gather -> InterSO3Conv ->
-IntraSO3Conv + the block's norm/activation/skip glue) and the ClsOutBlockPointnet head (1x1 conv, PointnetSO3Conv,
-attention over the anchors, 40-way logits), random-init weights, synthetic unit-ball clouds and labels already resident
-in HBM.  One step = forward + cross-entropy + backward (+ gradient all-reduce over RCCL when N > 1) + Adam update.
---backbone-only drops the head (loss = mean square of the last feature map).  Weak scaling: per-GPU batch fixed.  Prints ONE JSON line (rank 0).
+With N > 1 and no launcher environment the script starts its own N ranks (one process per GPU, dp.launch);
+`python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 ... bench.py --gpus N ...` works
+the same way.
+
+Workloads (BASELINE.json `configs`):
+  cls (default, the headline metric = configs[1]): the ModelNet40 classification network cls_so3net_pn, B=32 clouds per
+      GPU, N=1024, K=32/16 neighbours, A=60 anchors, fp32 -- 7 separable blocks (FPS -> ball query -> grouping ->
+      InterSO3Conv -> IntraSO3Conv + the block's norm/activation/skip glue) and the ClsOutBlockPointnet head;
+  reg --dtype bf16 (configs[2]): ModelNet40 rotation estimation, 32 pairs = 64 clouds, N=1024, bf16 features;
+  inv --dtype bf16 (configs[3]): 3DMatch descriptor, 64 patches, N=2048, bf16 features.
+Random-init weights, synthetic unit-ball clouds and labels already resident in HBM.  One step = forward + loss + backward
+(+ gradient all-reduce over RCCL when N > 1) + Adam update.  Weak scaling: per-GPU batch fixed.  Prints ONE JSON line.
 """
 import argparse
 import json
@@ -23,21 +28,24 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
-MFMA_F32_PEAK_TFLOPS = 157.3   # /opt/skills/guides/MI355X_MICROARCH.md, "Peak FP32 (matrix)"
+# /opt/skills/guides/MI355X_MICROARCH.md: "Peak FP32 (matrix)", "Peak BF16/FP16 MFMA" (dense), HBM3E peak
+PEAK_TFLOPS = {"f32": 157.3, "bf16": 2500.0}
+HBM_PEAK_GBS = 8000.0
 
-BLAS_FAMILY = "rocBLAS fp32 GEMM (Cijk_*)"   # the library kernels torch.mm dispatches to (Tensile "Cijk_..." names)
-KERNEL_OF = {  # C-ABI call -> device kernel family it launches on this workload (csrc/*.hip; template variants summed)
+# C-ABI entry point (what the HIP events bracket) -> the device kernel that does its work (csrc/*.hip; template variants
+# summed; the rocprofv3 kernel trace of the same command is committed under profiles/ and lists them by name)
+KERNEL_OF = {
     "inter_fwd": "epn::inter_fwd8_kernel", "inter_bwd_data": "epn::inter_bwd_data8_kernel",
     "inter_bwd_weight": "epn::inter_bwd_weight8_kernel", "intra_fwd": "epn::intra_gemm_kernel",
-    "intra_bwd_data": "epn::intra_gemm_kernel", "intra_bwd_weight": "epn::intra_bwd_weight_pt_kernel",
+    "intra_bwd_data": "epn::intra_gemm_kernel", "intra_bwd_weight": "epn::intra_bwd_weight_v4_kernel",
     "inter_group": "epn::inter_group_kernel", "inter_ungroup": "epn::inter_ungroup_kernel",
     "inter_gemm": "epn::gemm_nt_kernel", "intra_gemm": "epn::gemm_nt_kernel",
-    "inter_gemm_dw": "epn::gemm_tn_f32_kernel", "intra_gemm_dw": "epn::gemm_tn_f32_kernel",
+    "inter_gemm_dw": "epn::gemm_tn_kernel", "intra_gemm_dw": "epn::gemm_tn_kernel",
     "intra_group": "epn::intra_group_kernel", "so3_basis": "epn::so3_basis_kernel",
     "pointnet_fwd": "epn::pointnet_fwd_kernel", "pointnet_bwd_data": "epn::pointnet_bwd_data_kernel",
     "pointnet_bwd_weight": "epn::pointnet_bwd_weight_kernel",
 }
-PMC_FILE = os.path.join(ROOT, "profiles", "r01_pmc_per_kernel.json")   # tools/collect_profiles.sh + pmc_summary.py
+PMC_FILE = os.path.join(ROOT, "profiles", "r02_pmc_per_kernel.json")   # tools/collect_profiles.sh + pmc_summary.py
 
 
 def recorded_traffic(kernel_family):
@@ -49,8 +57,7 @@ def recorded_traffic(kernel_family):
         return None
     tot = n = 0.0
     for name, e in pmc.items():
-        fam = BLAS_FAMILY if name.startswith("Cijk_") else name.split("<")[0]
-        if fam == kernel_family and "hbm_bytes_per_launch" in e:
+        if kernel_family.split("::")[-1].replace("_kernel", "") in name and "hbm_bytes_per_launch" in e:
             tot += e["hbm_bytes_per_launch"] * e["launches"]
             n += e["launches"]
     return round(tot / n) if n else None
@@ -61,24 +68,26 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--batch", type=int, default=32, help="clouds per GPU")
-    ap.add_argument("--points", type=int, default=1024)
+    ap.add_argument("--batch", type=int, default=0, help="clouds per GPU (default: 32 for cls, 64 for reg / inv)")
+    ap.add_argument("--points", type=int, default=0, help="points per cloud (default: 1024; 2048 for inv)")
+    ap.add_argument("--dtype", default="", choices=["", "f32", "bf16"],
+                    help="feature storage / GEMM operand type (default: f32 for cls, bf16 for reg / inv as BASELINE states)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-clouds", type=int, default=2, help="sample size of the CPU baseline")
+    ap.add_argument("--cpu-clouds", type=int, default=4, help="sample size of the CPU baseline (SURVEY 8d: B=4 chunks)")
     ap.add_argument("--cpu-threads", type=int, default=16,
-                    help="torch CPU threads of the baseline (16 measured fastest of {16,48,256} on the 2x EPYC 9575F "
-                         "GPU host: the materialising reference algorithm is memory-bound and slows down with more)")
+                    help="torch CPU threads of the baseline (the GPU box's cgroup grants 16 CPUs; measured fastest of "
+                         "{16,48,256} on the 2x EPYC 9575F host: the materialising reference algorithm slows down with more)")
     ap.add_argument("--forward-only", action="store_true")
     ap.add_argument("--no-graph", action="store_true", help="eager launches instead of replaying a captured HIP graph")
     ap.add_argument("--backbone-only", action="store_true", help="without the output head")
-    ap.add_argument("--model", default="cls", choices=["cls", "reg", "inv"],
-                    help="cls = BASELINE configs[1] (the headline metric); reg / inv = the layer schedules of configs[2] / "
-                         "[3] in fp32 (their bf16 variants are not implemented yet)")
+    ap.add_argument("--model", default="cls", choices=["cls", "reg", "inv"])
     return ap.parse_args()
 
 
 def cpu_baseline(layers, product_sd, n_points, n_clouds, threads=16, head=True):
-    """The oracle's materialising restatement of the same network (kind "port"), fwd+bwd, on the host cores."""
+    """The oracle's materialising restatement of the same network (kind "port"), on the host cores: one warm-up
+    forward of a single cloud, then ONE timed forward + backward of `n_clouds` clouds; the forward share is reported
+    separately (north_star states its >= 10x target on the forward pass)."""
     from epn_pointcloud_amd import schedule as S
     from epn_pointcloud_amd.vgtk.so3conv import functional as L
     from epn_pointcloud_amd.vgtk import functional as fr
@@ -93,102 +102,145 @@ def cpu_baseline(layers, product_sd, n_points, n_clouds, threads=16, head=True):
     ref.train()
     pts = S.synthetic_clouds(n_clouds, n_points, "cpu", seed=2913)
     labels = torch.arange(n_clouds) % 40
+    with torch.no_grad():                                   # warm-up: thread pool, allocator, C index library
+        ref(pts[:1])
     t0 = time.perf_counter()
     if head:
         logits, _ = ref(pts)
-        torch.nn.functional.cross_entropy(logits, labels).backward()
+        loss = torch.nn.functional.cross_entropy(logits, labels)
     else:
         _, feats = ref(pts)
-        feats.square().mean().backward()
-    dt = time.perf_counter() - t0
-    return {"value": n_clouds / dt, "unit": "point-clouds/s", "cores": cores, "kind": "port",
-            "host_cpus": os.cpu_count(),
-            "sample": f"{n_clouds} clouds N={n_points} A=60, fwd+bwd once, oracle/backbone_ref.py (torch CPU "
-                      f"{torch.get_num_threads()} threads + C index kernels), {dt:.1f} s"}
+        loss = feats.square().mean()
+    t1 = time.perf_counter()
+    loss.backward()
+    t2 = time.perf_counter()
+    return {"value": n_clouds / (t2 - t0), "unit": "point-clouds/s", "cores": cores, "kind": "port",
+            "forward_only_value": n_clouds / (t1 - t0), "host_cpus": os.cpu_count(),
+            "sample": f"{n_clouds} clouds N={n_points} A=60 in one batch, warmed (1 cloud fwd), then fwd {t1 - t0:.1f} s + bwd "
+                      f"{t2 - t1:.1f} s once; oracle/backbone_ref.py (torch CPU {torch.get_num_threads()} threads + C index "
+                      f"kernels)"}
+
+
+def index_kernel_line(pts, layers, dev, reps=20):
+    """FPS and ball query of the first layer, timed alone with HIP events (us per cloud and GB/s on
+    the algorithmic bytes: FPS reads a cloud once (12 B/point) and writes m indices; the ball query reads support and
+    query coordinates and writes K indices per query)."""
+    from epn_pointcloud_amd.vgtk import pc as pctk
+    b, n, _ = pts.shape
+    l0 = layers[0]
+    xyz = pts.permute(0, 2, 1).contiguous()
+    m = -(-n // l0.stride)
+
+    def timed(fn):
+        fn()
+        torch.cuda.synchronize(dev)
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(reps):
+            out = fn()
+        e1.record()
+        torch.cuda.synchronize(dev)
+        return e0.elapsed_time(e1) / reps * 1e3, out      # us per launch
+
+    us_fps, (_, new_xyz) = timed(lambda: pctk.furthest_sample(xyz, m, False))
+    us_bq, _ = timed(lambda: pctk.ball_query_index(new_xyz, xyz, l0.radius, l0.nn))
+    fps_bytes = b * (n * 12 + m * 4)
+    bq_bytes = b * (n * 12 + m * 12 + m * l0.nn * 4)
+    return {"fps": {"n": n, "m": m, "us_per_launch": round(us_fps, 1), "us_per_cloud": round(us_fps / b, 2),
+                    "GB/s": round(fps_bytes / us_fps / 1e3, 2), "bound": "latency (m-1 dependent rounds per cloud)"},
+            "ball_query": {"queries": m, "support": n, "K": l0.nn, "us_per_launch": round(us_bq, 1),
+                           "us_per_cloud": round(us_bq / b, 2), "GB/s": round(bq_bytes / us_bq / 1e3, 2)}}
 
 
 def main():
     args = parse()
     from epn_pointcloud_amd import _lib, dp, models as M, ops, schedule as S
-    _lib.get_lib()                                     # fail loudly if the HIP library is missing
-    rank, local_rank, world = dp.init_from_env()
-    assert world == args.gpus or world == 1 and args.gpus == 1, (world, args.gpus)
+    rank, local_rank, world = dp.env_world()
+    if args.gpus > 1 and world == 1 and "EPN_DP_CHILD" not in os.environ:
+        sys.exit(dp.launch(args.gpus))                  # no launcher: start the ranks ourselves
+    assert world == args.gpus, f"WORLD_SIZE={world} but --gpus {args.gpus}"
+    _lib.get_lib()                                      # fail loudly if the HIP library is missing
     assert torch.cuda.is_available(), "bench.py needs an MI355X"
     dev = torch.device("cuda", local_rank)
     torch.cuda.set_device(dev)
 
-    if args.model == "inv" and args.points == 1024:
-        args.points = 2048                                  # 3DMatch patches (generate_eval.py:26,68)
+    dtype_name = args.dtype or ("f32" if args.model == "cls" else "bf16")
+    fdtype = torch.float32 if dtype_name == "f32" else torch.bfloat16
+    args.batch = args.batch or (32 if args.model == "cls" else 64)
+    args.points = args.points or (2048 if args.model == "inv" else 1024)   # 3DMatch patches (generate_eval.py:26,68)
     layers = {"cls": S.cls_so3net_schedule, "reg": S.reg_so3net_schedule,
               "inv": S.inv_so3net_schedule}[args.model](args.points)
-    torch.manual_seed(2913)
+    torch.manual_seed(2913)                                 # same seed on every rank: replicas start identical
     head = not args.backbone_only
     if not head:
-        model = S.HotPathBackbone(layers, norm="BatchNorm2d" if args.model == "cls" else None)
+        model = S.HotPathBackbone(layers, norm="BatchNorm2d" if args.model == "cls" else None, model=args.model)
     elif args.model == "cls":
         model = M.ClsSO3ConvModel(layers, out_mlps=(256,), pooling="attention")
     elif args.model == "reg":
         model = M.RegSO3ConvModel(layers)
     else:
         model = M.InvSO3ConvModel(layers)
-    model = model.to(dev).train()
-    dp.broadcast_parameters(model)
+    model = S.set_feature_dtype(model.to(dev).train(), fdtype)
     params = [p for p in model.parameters() if p.requires_grad]
     opt = torch.optim.Adam(params, lr=1e-3)
     scale = 0.4 if args.model == "inv" else 1.0            # 3DMatch search_radius (options.py:30)
     pts = S.synthetic_clouds(args.batch, args.points, dev, seed=2913 + rank, scale=scale)   # resident in HBM
+    flat_pts = pts
     labels = (torch.arange(args.batch, device=dev) + rank) % 40
     if head and args.model == "reg":                        # pairs of clouds [b/2, 2, n, 3] (reg_so3net.py:31-33)
         pts = pts.view(args.batch // 2, 2, args.points, 3)
 
     def loss_of(out):
         if not head:
-            return out.feats.square().mean()
+            return out.feats.float().square().mean()
         if args.model == "cls":
             return torch.nn.functional.cross_entropy(out[0], labels)
         if args.model == "inv":                             # descriptors are unit vectors: push them apart
             return (out[0] @ out[0].t()).square().mean()
         return out[0].square().mean() + out[1].square().mean()
 
+    # gradients live in one flat buffer cut into per-stage buckets (dp.GradBuckets): zero() instead of zero_grad, the
+    # all-reduce runs on slices of it -- issued from backward hooks (eager) or right after the replayed graph
+    buckets = None if args.forward_only else dp.GradBuckets(dp.stage_buckets(model), world, hooks=False)
+
     def compute():                      # the hot path: forward (+ loss + backward)
         if args.forward_only:
             with torch.no_grad():
                 return loss_of(model(pts))
+        buckets.zero()
         loss = loss_of(model(pts))
         loss.backward()
         return loss
 
-    def eager_step():
-        opt.zero_grad(set_to_none=True)
-        loss = compute()
+    def finish():
         if not args.forward_only:
-            dp.allreduce_gradients(params, world)
+            buckets.finish()
             opt.step()
+
+    def eager_step():
+        loss = compute()
+        finish()
         return loss
 
-    def fence():
-        if world > 1:
-            torch.distributed.barrier()
-        torch.cuda.synchronize()
-
-    # warm-up (also what torch requires before a capture: eager iterations on a side stream)
+    # warm-up (also what torch requires before a capture: eager iterations on a side stream); single-rank so far --
+    # the process group is created AFTER the capture (RCCL's watchdog thread issues HIP calls of its own, which a
+    # capture in progress does not tolerate), replicas are identical by construction (same seed) and re-synchronised
+    # by the broadcast below
     side = torch.cuda.Stream(device=dev)
     side.wait_stream(torch.cuda.current_stream(dev))
     with torch.cuda.stream(side):
-        for _ in range(max(args.warmup, 1) if not args.no_graph else args.warmup):
-            eager_step()
+        for _ in range(max(args.warmup, 1)):
+            compute()
+            if not args.forward_only:
+                opt.step()
     torch.cuda.current_stream(dev).wait_stream(side)
-    fence()
+    torch.cuda.synchronize(dev)
 
-    # The ~1300 launches of one step (kernels of this library, library GEMMs, small torch ops) are captured ONCE into a
-    # HIP graph and replayed: same kernels, same work, no per-launch host latency / inter-kernel bubbles.  Gradient
-    # all-reduce and the Adam update stay outside the graph (identical path for every world size).
+    # The ~1300 launches of one step are captured ONCE into a HIP graph and replayed: same kernels, same work, no
+    # per-launch host latency.  Gradient all-reduce and the Adam update stay outside the graph.
     launch, graph, static_loss = "eager", None, None
-    # single-process runs only: with a process group alive, RCCL's watchdog thread issues HIP calls of its own, which a
-    # capture in progress does not tolerate on every stack -- not worth 1 % to the multi-GPU runs
-    if not args.no_graph and world == 1:
+    if not args.no_graph:
         try:
-            opt.zero_grad(set_to_none=True)      # gradients are (re)materialised inside the graph's memory pool
             graph = torch.cuda.CUDAGraph()
             with torch.cuda.graph(graph, capture_error_mode="thread_local"):
                 static_loss = compute()
@@ -199,17 +251,24 @@ def main():
             if rank == 0:
                 print(f"[bench] HIP graph capture unavailable ({type(e).__name__}: {e}); eager launches", file=sys.stderr)
 
+    dp.init_from_env()                           # RCCL communicator (world > 1), after the capture
+    dp.broadcast_parameters(model)
+    if graph is None and buckets is not None and world > 1:      # eager: per-stage all-reduce from backward hooks
+        buckets = dp.GradBuckets(dp.stage_buckets(model), world, hooks=True)
+
     def step():
         if graph is None:
             return eager_step()
         graph.replay()
-        if not args.forward_only:
-            dp.allreduce_gradients(params, world)
-            opt.step()
+        finish()
         return static_loss
 
-    if graph is not None:
-        step()                                   # one untimed replay
+    def fence():
+        if world > 1:
+            torch.distributed.barrier()
+        torch.cuda.synchronize()
+
+    step()                                       # one untimed step on the final path (RCCL lazy init included)
     fence()
     if graph is None:
         ops.profile_begin()                      # eager: HIP events around every call of the timed region itself
@@ -224,7 +283,6 @@ def main():
         # graph replays have no host-side launch points: for the roofline the same step runs eagerly, timed call by
         # call, right after the timed region (same process, same shapes, same kernels)
         prof_steps = min(args.steps, 3)
-        opt.zero_grad(set_to_none=True)
         eager_step()                             # untimed: refills the eager allocator pool after the capture, so no
         fence()                                  # allocation stall sits between an event and the kernel it brackets
         ops.profile_begin()
@@ -239,53 +297,64 @@ def main():
     assert torch.isfinite(last.float()).all(), "non-finite output in the timed region"
 
     if rank == 0:
-        # ---- roofline of the dominant kernel, from HIP events recorded around its launches in the timed region
+        # ---- roofline of the dominant kernel, from HIP events recorded around its launches
         agg = {}
         for kind, key, flops, e0, e1 in records:
             k = KERNEL_OF.get(kind, kind)
-            if kind.startswith("inter") and key[6] == 1:      # cin = 1 (first layer): dedicated kernels
+            if kind.startswith("inter") and len(key) > 6 and key[6] == 1:      # cin = 1 (first layer): dedicated kernels
                 k = {"inter_fwd": "epn::inter_c1_fwd_kernel", "inter_bwd_weight": "epn::inter_c1_bwd_weight_kernel"}.get(kind, k)
             a = agg.setdefault(k, {"ms": 0.0, "flops": 0.0, "launches": 0})
             a["ms"] += e0.elapsed_time(e1)
             a["flops"] += flops
             a["launches"] += 1
+        peak = PEAK_TFLOPS[dtype_name]
+
         def roof(k):
             d = agg[k]
             ach = d["flops"] / (d["ms"] * 1e-3) / 1e12
-            return {"bound": "mfma", "kernel": k, "achieved": round(ach, 2), "peak": MFMA_F32_PEAK_TFLOPS,
-                    "unit": "TFLOP/s", "frac": round(ach / MFMA_F32_PEAK_TFLOPS, 4),
-                    "traffic": recorded_traffic(k) if args.model == "cls" and args.batch == 32 else None,
+            return {"bound": "mfma", "kernel": k, "achieved": round(ach, 2), "peak": peak, "unit": "TFLOP/s",
+                    "frac": round(ach / peak, 4),
+                    "traffic": recorded_traffic(k) if (args.model == "cls" and args.batch == 32 and dtype_name == "f32") else None,
                     "launches": d["launches"], "avg_launch_ms": round(d["ms"] / d["launches"], 4)}
 
         dom = max(agg, key=lambda k: agg[k]["ms"])
-        own = max((k for k in agg if k.startswith("epn::")), key=lambda k: agg[k]["ms"])
         roofline = roof(dom)
         roofline["traffic_note"] = ("HBM bytes/launch (avg over the family's launches) from the committed rocprofv3 "
-                                    "--pmc passes, profiles/r01_pmc_per_kernel.json")
-        roofline["own_kernel"] = roof(own)      # the dominant kernel of THIS library (the GEMM family is rocBLAS)
+                                    "--pmc passes, profiles/r02_pmc_per_kernel.json")
         roofline["per_kernel_ms_per_step"] = {k: round(v["ms"] / prof_steps, 3) for k, v in sorted(agg.items())}
-        roofline["measured"] = (f"HIP events around every call of {prof_steps} eager step(s) "
-                                + ("run right after the timed graph replays" if graph is not None else "= the timed region"))
+        roofline["per_kernel_tflops"] = {k: round(v["flops"] / (v["ms"] * 1e-3) / 1e12, 1) for k, v in sorted(agg.items())
+                                         if v["flops"] > 0}
+        roofline["measured"] = (f"HIP events on the launch stream around every C-ABI call of {prof_steps} eager step(s) "
+                                + ("run right after the timed graph replays (same process, kernels and shapes; the skip "
+                                   "branch's kernels share the GPU from a second stream)" if graph is not None
+                                   else "= the timed region") + "; names: C-ABI call -> kernel, bench.py KERNEL_OF")
+        if dtype_name == "bf16":
+            roofline["note"] = ("bf16 GEMMs run far below the 2.5 PF MFMA roof by construction: at these widths the step "
+                                "is bound by HBM traffic of the grouped features (see DESIGN.md 3.6)")
+        nn_desc = "/".join(str(k) for k in sorted({l.nn for l in layers}, reverse=True))
         out = {
             "metric": (f"point-clouds/sec {'fwd' if args.forward_only else 'fwd+bwd'}, "
                        + ("ModelNet40" if args.model != "inv" else "3DMatch") + f" N={args.points} A=60"),
             "value": round(args.batch * world * args.steps / dt, 3), "unit": "point-clouds/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(dt / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",
-            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "vs_baseline": None, "dtype": dtype_name, "data": "synthetic",
             "config": {"workload": {"cls": "ModelNet40 classification (cls_so3net_pn: 7 separable SO3 blocks",
                                     "reg": "ModelNet40 relative rotation (reg_so3net: 7 separable SO3 blocks",
                                     "inv": "3DMatch descriptor (inv_so3net_pn: 8 separable SO3 blocks"}[args.model]
                                    + ({"cls": " + ClsOutBlockPointnet head)", "reg": " + RelSO3OutBlockR head)",
                                        "inv": " + InvOutBlockMVD head)"}[args.model] if head else ", backbone only)")
-                                   + f", B={args.batch}/GPU N={args.points} K={'/'.join(str(k) for k in sorted({l.nn for l in layers}, reverse=True))} "
-                                   + f"A=60 fp32, {'fwd' if args.forward_only else 'fwd+bwd+Adam'}",
+                                   + f", B={args.batch}/GPU N={args.points} K={nn_desc} A=60 "
+                                   + ("fp32" if dtype_name == "f32" else "bf16 features / fp32 accumulate")
+                                   + f", {'fwd' if args.forward_only else 'fwd+bwd+Adam'}",
                        "global_batch": args.batch * world, "points": args.points, "anchors": 60, "launch": launch,
                        "hbm_peak_gb": round(torch.cuda.max_memory_allocated(dev) / 2 ** 30, 1),
                        "parallelism": f"dp{world}"},
             "roofline": roofline,
         }
-        if world == 1 and not args.no_cpu_baseline and args.model == "cls":
+        if world == 1:
+            out["index_kernels"] = index_kernel_line(flat_pts, layers, dev)
+        if world == 1 and not args.no_cpu_baseline and args.model == "cls" and not args.forward_only:
             out["cpu_baseline"] = cpu_baseline(layers, model.state_dict(), args.points, args.cpu_clouds,
                                                args.cpu_threads, head)
         print(json.dumps(out), flush=True)

@@ -38,17 +38,21 @@ __device__ __forceinline__ void store_out(__bf16 *p, float v) { *p = (__bf16)v; 
 
 // ------------------------------------------------------------------------------------------------ NT
 // Block tile BM x BN = (WGM*TM*32) x (WGN*TN*32), WGM*WGN waves, each wave TM x TN MFMA tiles of 32x32.
-// K step = 128 bytes of a row (32 floats / 64 bf16).
-template <typename T, typename TO, int WGM, int WGN, int TM, int TN>
+// K step = KS 16-byte slots of a row: KS = 8 (128 bytes: 32 floats / 64 bf16) or, for contraction lengths that are
+// only a multiple of half that (the 32-channel layers in bf16), KS = 4.
+template <typename T, typename TO, int WGM, int WGN, int TM, int TN, int KS = 8>
 __global__ __launch_bounds__(64 * WGM * WGN) void gemm_nt_kernel(GemmNtBatch B) {
     constexpr int NW = WGM * WGN;
     constexpr int BM = WGM * TM * 32, BN = WGN * TN * 32;
-    constexpr int ROWS = BM + BN;                  // LDS rows per stage (A rows, then Bt rows), 128 B each
-    constexpr int NG = ROWS / 8;                   // 8-row groups = wave-level load instructions per stage
-    constexpr int GPW = (NG + NW - 1) / NW;        // groups per wave
+    constexpr int ROWS = BM + BN;                  // LDS rows per stage (A rows, then Bt rows)
+    constexpr int ROWB = KS * 16;                  // bytes per LDS row
+    constexpr int RPG = 64 / KS;                   // rows per wave-level load instruction (1 KiB)
+    constexpr int NG = ROWS / RPG;                 // wave-level load instructions per stage
+    constexpr int GPW = (NG + NW - 1) / NW;        // ... per wave
     constexpr int E16 = ElemOf<T>::PER16;          // elements per 16-byte slot
-    constexpr int BKE = 8 * E16;                   // elements per K step
-    __shared__ __attribute__((aligned(1024))) char smem[2 * ROWS * 128];
+    constexpr int BKE = KS * E16;                  // elements per K step
+    constexpr int NS = KS / 2;                     // fragment steps per K step (two slots each: lane groups j = 0, 1)
+    __shared__ __attribute__((aligned(1024))) char smem[2 * ROWS * ROWB];
 
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -71,8 +75,9 @@ __global__ __launch_bounds__(64 * WGM * WGN) void gemm_nt_kernel(GemmNtBatch B) 
 #pragma unroll
     for (int i = 0; i < GPW; ++i) {
         const int g = wave + i * NW;
-        const int r = 8 * g + (lane >> 3);                     // LDS row
-        const int slot = (lane & 7) ^ ((r >> 1) & 7);          // logical 16-byte slot stored at physical lane%8
+        const int r = RPG * g + lane / KS;                     // LDS row
+        // logical 16-byte slot stored at physical slot lane % KS (conflict-free ds_read_b128 of 32 consecutive rows)
+        const int slot = (lane % KS) ^ (KS == 8 ? (r >> 1) & 7 : (r >> 2) & 3);
         if (r < BM) {
             long long gr = m0 + r;
             gr = gr < P.M ? gr : P.M - 1;
@@ -86,7 +91,7 @@ __global__ __launch_bounds__(64 * WGM * WGN) void gemm_nt_kernel(GemmNtBatch B) 
     auto stage_one = [&](int buf, int i) {
         const int g = wave + i * NW;
         if (NG % NW == 0 || g < NG) {
-            glds16(src[i], smem + buf * (ROWS * 128) + g * 1024);
+            glds16(src[i], smem + buf * (ROWS * ROWB) + g * 1024);
             src[i] += BKE;
         }
     };
@@ -99,13 +104,13 @@ __global__ __launch_bounds__(64 * WGM * WGN) void gemm_nt_kernel(GemmNtBatch B) 
 
     const int wm = wave / WGN, wn = wave % WGN;
     const int li = lane & 31, lj = lane >> 5;
-    const int fsw = (li >> 1) & 7;
+    const int fsw = KS == 8 ? (li >> 1) & 7 : (li >> 2) & 3;
     // byte offsets of this lane's fragment rows inside a stage
     int aoff[TM], boff[TN];
 #pragma unroll
-    for (int i = 0; i < TM; ++i) aoff[i] = ((wm * TM + i) * 32 + li) * 128;
+    for (int i = 0; i < TM; ++i) aoff[i] = ((wm * TM + i) * 32 + li) * ROWB;
 #pragma unroll
-    for (int i = 0; i < TN; ++i) boff[i] = (BM + (wn * TN + i) * 32 + li) * 128;
+    for (int i = 0; i < TN; ++i) boff[i] = (BM + (wn * TN + i) * 32 + li) * ROWB;
 
     f32x16 acc[TM][TN];
 #pragma unroll
@@ -121,11 +126,11 @@ __global__ __launch_bounds__(64 * WGM * WGN) void gemm_nt_kernel(GemmNtBatch B) 
     // one per MFMA group over the step, the partner waves on alternating groups (sched_barrier pins the placement; left
     // alone the compiler hoists all of them in front of the first ds_read).  fp32: +3 % over the burst; bf16 is
     // HBM-bound on these shapes and keeps the burst.
-    constexpr int NGRP = 16;                   // fp32: MFMA groups per K step (4 fragment steps x 4 contraction pairs)
+    constexpr int NGRP = 4 * NS;               // fp32: MFMA groups per K step (NS fragment steps x 4 contraction pairs)
     stage(0);
     for (int kt = 0; kt < nk; ++kt) {
         __syncthreads();                       // stage kt has landed (vmcnt(0) rides on the barrier); buffer (kt+1)&1 is free
-        const char *base = smem + (kt & 1) * (ROWS * 128);
+        const char *base = smem + (kt & 1) * (ROWS * ROWB);
         const bool more = kt + 1 < nk;
         if constexpr (sizeof(T) != 4) {
             if (more) stage((kt + 1) & 1);
@@ -142,8 +147,8 @@ __global__ __launch_bounds__(64 * WGM * WGN) void gemm_nt_kernel(GemmNtBatch B) 
             };
             rd(0, 0);
 #pragma unroll
-            for (int s = 0; s < 4; ++s) {
-                if (s + 1 < 4) rd(s + 1, (s + 1) & 1);
+            for (int s = 0; s < NS; ++s) {
+                if (s + 1 < NS) rd(s + 1, (s + 1) & 1);
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
                     __builtin_amdgcn_sched_barrier(0);
@@ -166,7 +171,7 @@ __global__ __launch_bounds__(64 * WGM * WGN) void gemm_nt_kernel(GemmNtBatch B) 
             }
         } else {
 #pragma unroll
-            for (int s = 0; s < 4; ++s) {
+            for (int s = 0; s < NS; ++s) {
                 const int so = ((2 * s + lj) ^ fsw) * 16;
                 bf16x8 a[TM], b[TN];
 #pragma unroll
@@ -524,7 +529,7 @@ __global__ void gemm_tn_generic_kernel(const T *__restrict__ X, const T *__restr
     C[(long long)n1 * ldc + n2] = s;
 }
 
-template <typename T, typename TO, int WGM, int WGN, int TM, int TN>
+template <typename T, typename TO, int WGM, int WGN, int TM, int TN, int KS = 8>
 int launch_nt_cfg(GemmNtBatch &B, hipStream_t st) {
     constexpr int BM = WGM * TM * 32, BN = WGN * TN * 32;
     unsigned total = 0;
@@ -536,7 +541,7 @@ int launch_nt_cfg(GemmNtBatch &B, hipStream_t st) {
     }
     B.ntiles = total;
     if (total == 0) return 0;
-    hipLaunchKernelGGL((gemm_nt_kernel<T, TO, WGM, WGN, TM, TN>), dim3(total), dim3(64 * WGM * WGN), 0, st, B);
+    hipLaunchKernelGGL((gemm_nt_kernel<T, TO, WGM, WGN, TM, TN, KS>), dim3(total), dim3(64 * WGM * WGN), 0, st, B);
     EPN_CHECK_LAUNCH();
     return 0;
 }
@@ -544,13 +549,14 @@ int launch_nt_cfg(GemmNtBatch &B, hipStream_t st) {
 template <typename T, typename TO>
 int launch_nt_typed(GemmNtBatch &B, hipStream_t st) {
     constexpr int E16 = ElemOf<T>::PER16;
-    bool fast = true;
+    bool fast = true, half_k = false;
     int maxn = 0, minn = 1 << 30;
     for (int i = 0; i < B.nprob; ++i) {
         const GemmNtProb &p = B.p[i];
         if (p.M < 0 || p.N < 1 || p.K < 1) return EPN_EINVAL;
         if (!p.A || !p.Bt || !p.C) return EPN_ENULL;
-        if (p.K % (8 * E16) || p.lda % E16 || p.ldb % E16 || ((uintptr_t)p.A & 15) || ((uintptr_t)p.Bt & 15)) fast = false;
+        if (p.K % (4 * E16) || p.lda % E16 || p.ldb % E16 || ((uintptr_t)p.A & 15) || ((uintptr_t)p.Bt & 15)) fast = false;
+        if (p.K % (8 * E16)) half_k = true;      // K a multiple of 4 slots only: the short-K-step kernels
         maxn = p.N > maxn ? p.N : maxn;
         minn = p.N < minn ? p.N : minn;
     }
@@ -565,6 +571,11 @@ int launch_nt_typed(GemmNtBatch &B, hipStream_t st) {
             EPN_CHECK_LAUNCH();
         }
         return 0;
+    }
+    if (half_k) {
+        if (maxn <= 32) return launch_nt_cfg<T, TO, 8, 1, 2, 1, 4>(B, st);
+        if (maxn <= 64) return launch_nt_cfg<T, TO, 8, 1, 2, 2, 4>(B, st);
+        return launch_nt_cfg<T, TO, 4, 2, 2, 2, 4>(B, st);
     }
     const int pol = kernel_policy();
     if ((pol & ~0xff) == 0x100) {           // tuning override (tools/gemm_bench.py --cfg)

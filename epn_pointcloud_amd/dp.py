@@ -1,19 +1,61 @@
 """Data-parallel glue for the hot path: one process per GPU, batch sharded across ranks, the ONLY collective
 is the gradient all-reduce (RCCL over xGMI; torch backend "nccl").  The reference's nn.DataParallel
 (vgtk/vgtk/app/trainer.py:153-160) is replaced by this.  Clouds are independent, so there is no activation
-or index exchange."""
+or index exchange.
+
+    launch(...)          self-spawn N ranks when no torchrun environment is present (python bench.py --gpus N)
+    init_from_env(...)   torchrun-style env -> process group
+    GradBuckets          gradients live in ONE flat buffer cut into per-stage buckets: no cat, no copy-back; a
+                         bucket's all-reduce is issued from a backward hook as soon as its last gradient is
+                         written, i.e. it overlaps with the rest of the backward pass
+"""
 import os
+import socket
+import subprocess
+import sys
 
 import torch
 import torch.distributed as dist
 
 
-def init_from_env(backend=None):
-    """torchrun-style env (RANK/LOCAL_RANK/WORLD_SIZE/MASTER_ADDR/MASTER_PORT) -> (rank, local_rank, world)."""
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world > 1 and not dist.is_initialized():
+def free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def launch(world, argv=None, env=None):
+    """Run `argv` (default: this very command line) as `world` rank processes on this node, one per GPU, with the
+    torchrun environment (RANK / LOCAL_RANK / WORLD_SIZE / MASTER_ADDR=127.0.0.1 / MASTER_PORT).  Rank 0 inherits
+    stdout; returns the worst exit code.  What `python -m torch.distributed.run --nproc-per-node N` would do, for
+    callers that start the program without a launcher."""
+    argv = list(argv) if argv is not None else [sys.executable] + sys.argv
+    port = free_port()
+    procs = []
+    for r in range(world):
+        e = dict(os.environ if env is None else env)
+        e.update(RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
+                 EPN_DP_CHILD="1")
+        e.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        procs.append(subprocess.Popen(argv, env=e, stdout=None if r == 0 else subprocess.DEVNULL))
+    rc = 0
+    for p in procs:
+        rc = max(rc, abs(p.wait()))
+    return rc
+
+
+def env_world():
+    """(rank, local_rank, world) from the torchrun environment, without touching torch.distributed."""
+    return (int(os.environ.get("RANK", "0")), int(os.environ.get("LOCAL_RANK", "0")),
+            int(os.environ.get("WORLD_SIZE", "1")))
+
+
+def init_from_env(backend=None, force=False):
+    """torchrun-style env (RANK/LOCAL_RANK/WORLD_SIZE/MASTER_ADDR/MASTER_PORT) -> (rank, local_rank, world).
+    The process group is created for world > 1 (or world == 1 with force=True: a single-rank RCCL communicator, used
+    to exercise the nccl branch on one GPU)."""
+    rank, local_rank, world = env_world()
+    if (world > 1 or force) and not dist.is_initialized():
         if backend is None:
             backend = "nccl" if torch.cuda.is_available() else "gloo"
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
@@ -34,10 +76,108 @@ def shard_batch(global_batch, rank, world):
     return start, start + base + (1 if rank < rem else 0)
 
 
+class GradBuckets:
+    """All gradients of `params` as views into one flat fp32 buffer, cut into buckets (given as lists of parameters,
+    e.g. one per backbone stage, in the order backward produces them last-to-first).
+
+    * no concatenation and no copy-back: autograd accumulates straight into the views (`p.grad` is pre-set, so the
+      AccumulateGrad nodes add in place; call zero() at the start of a step);
+    * overlap: with hooks=True a post-accumulate hook counts a bucket's parameters down and issues its asynchronous
+      all-reduce the moment the last one is written -- the deeper stages' backward kernels keep running underneath;
+      finish() waits for all of them and applies the 1/world average.  With hooks=False (a step replayed as one HIP
+      graph has no host-side hook points) finish() issues the all-reduces itself: the whole cls model is 31 MB, ~0.4 ms
+      over xGMI against a >100 ms step.
+    xGMI is point-to-point (7 links x ~153 GB/s per GPU): few large buckets, not NCCL-style 25 MB chunks."""
+
+    def __init__(self, buckets, world, hooks=True):
+        self.world = world
+        self.buckets = [[p for p in b if p.requires_grad] for b in buckets]
+        self.buckets = [b for b in self.buckets if b]
+        params = [p for b in self.buckets for p in b]
+        if not params:
+            raise ValueError("no trainable parameters")
+        dev, total = params[0].device, sum(p.numel() for p in params)
+        self.flat = torch.zeros(total, dtype=torch.float32, device=dev)
+        self.spans, off = [], 0
+        for b in self.buckets:
+            start = off
+            for p in b:
+                p.grad = self.flat[off:off + p.numel()].view_as(p)
+                off += p.numel()
+            self.spans.append((start, off))
+        self._pending = [len(b) for b in self.buckets]
+        self._works = []
+        self._handles = []
+        if hooks and world > 1:
+            for bi, b in enumerate(self.buckets):
+                for p in b:
+                    self._handles.append(p.register_post_accumulate_grad_hook(self._make_hook(bi)))
+        self.hooks = hooks and world > 1
+
+    def _make_hook(self, bi):
+        def hook(_p):
+            self._pending[bi] -= 1
+            if self._pending[bi] == 0:
+                self._issue(bi)
+        return hook
+
+    def _issue(self, bi):
+        a, b = self.spans[bi]
+        self._works.append(dist.all_reduce(self.flat[a:b], op=dist.ReduceOp.SUM, async_op=True))
+
+    def zero(self):
+        self.flat.zero_()
+        self._pending = [len(b) for b in self.buckets]
+
+    def finish(self):
+        """Complete this step's all-reduces (issuing them first when no hooks ran) and average.  Returns the number of
+        collectives of the step."""
+        if self.world <= 1:
+            return 0
+        if not self.hooks:
+            for bi in range(len(self.buckets)):
+                self._issue(bi)
+        else:
+            for bi, n in enumerate(self._pending):      # a bucket whose parameters got no gradient this step
+                if n > 0:
+                    self._issue(bi)
+        n = len(self._works)
+        for w in self._works:
+            w.wait()
+        self._works = []
+        self.flat.div_(self.world)
+        self._pending = [len(b) for b in self.buckets]
+        return n
+
+    def remove_hooks(self):
+        for h in self._handles:
+            h.remove()
+        self._handles, self.hooks = [], False
+
+
+def stage_buckets(model):
+    """Bucket layout for the shipped networks: the head first, then the backbone stages last-to-first -- the order in
+    which backward completes them -- so every bucket's all-reduce starts as early as possible."""
+    buckets, seen = [], set()
+
+    def take(mod):
+        ps = [p for p in mod.parameters() if id(p) not in seen]
+        seen.update(id(p) for p in ps)
+        if ps:
+            buckets.append(ps)
+
+    if hasattr(model, "outblock"):
+        take(model.outblock)
+    if hasattr(model, "backbone"):
+        for stage in reversed(list(model.backbone)):
+            take(stage)
+    take(model)                                   # whatever is left
+    return buckets
+
+
 def allreduce_gradients(params, world, bucket_bytes=64 << 20):
-    """Average gradients across ranks with a few large flat all-reduces.  xGMI is point-to-point
-    (7 links x ~153 GB/s per GPU), so ring all-reduce is per-link bound: prefer few, large buckets (the
-    whole cls model is 31 MB fp32 -> one bucket) over NCCL-style 25 MB-and-smaller chunks."""
+    """Stand-alone form (no GradBuckets): average the existing p.grad tensors across ranks with a few flat
+    all-reduces.  Kept for callers that own their gradient tensors; bench.py uses GradBuckets."""
     if world <= 1:
         return 0
     grads = [p.grad for p in params if p.grad is not None]

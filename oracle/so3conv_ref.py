@@ -109,6 +109,32 @@ def inter_grouping(xyz, feats, stride, n_neighbor, anchors, kernels, radius, sig
     return inter_idx, inter_w, new_xyz, new_feats, sample_idx
 
 
+def inter_pooling_naive(inter_idx, sample_idx, feats, alpha=0.5):
+    """vgtk/vgtk/spconv/functional.py:393-399: alpha * feats[sampled] + (1 - alpha) * mean over the ball."""
+    b, p, nn = inter_idx.shape
+    a = feats.shape[3]
+    new_feats = batched_index_select(feats, 2, sample_idx.long())
+    g = batched_index_select(add_shadow_feature(feats), 2, inter_idx.long().view(b, -1)).view(b, -1, p, nn, a)
+    return alpha * new_feats + (1 - alpha) * g.mean(3)
+
+
+def inter_blurring_naive(inter_idx, feats, alpha=0.5):
+    """vgtk/vgtk/spconv/functional.py:402-407: the same blend without sub-sampling."""
+    b, p, nn = inter_idx.shape
+    a = feats.shape[3]
+    g = batched_index_select(add_shadow_feature(feats), 2, inter_idx.long().view(b, -1)).view(b, -1, p, nn, a)
+    return alpha * feats + (1 - alpha) * g.mean(3)
+
+
+def inter_blurring(xyz, feats, n_neighbor, radius, stride, inter_idx=None, lazy_sample=True):
+    """vgtk/vgtk/so3conv/functional.py:108-116 (inter_so3conv_blurring)."""
+    if inter_idx is None:
+        _, inter_idx, sample_idx, sample_xyz = inter_grouping_ball(xyz, stride, radius, n_neighbor, lazy_sample)
+    if stride == 1:
+        return inter_blurring_naive(inter_idx, feats), xyz
+    return inter_pooling_naive(inter_idx, sample_idx, feats), sample_xyz
+
+
 def basic_conv(W, g):
     """vgtk/vgtk/so3conv/modules.py:48-55: W[Cout, Cin*ks] @ G.view(B, Cin*ks, P*A), no bias."""
     b, _, _, p, a = g.shape

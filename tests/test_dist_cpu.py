@@ -59,6 +59,28 @@ def test_two_rank_gradient_allreduce_matches_single_process(tmp_path):
         assert torch.allclose(g0, p.grad, atol=1e-6)
 
 
+def test_launcher_gradbuckets_two_ranks(tmp_path):
+    """The launcher bench.py uses when started without torchrun (dp.launch: N rank processes with the torchrun
+    environment) + GradBuckets: gradients are views of one flat buffer, each stage's all-reduce is issued from a
+    backward hook, two consecutive steps, results equal to the single-process gradients."""
+    import sys as _sys
+    from epn_pointcloud_amd import dp
+    rc = dp.launch(2, [_sys.executable, os.path.join(ROOT, "tests", "dp_worker.py"), str(tmp_path)])
+    assert rc == 0
+    r0 = torch.load(tmp_path / "r0.pt")
+    r1 = torch.load(tmp_path / "r1.pt")
+    assert r0["collectives"] == 2 and r0["views"]            # one all-reduce per stage bucket, no copies
+    torch.manual_seed(0)
+    model = torch.nn.Sequential(torch.nn.Linear(6, 5), torch.nn.ReLU(), torch.nn.Linear(5, 3))
+    data = torch.arange(7 * 6, dtype=torch.float32).view(7, 6) / 10.0
+    for step in range(2):
+        model.zero_grad()
+        (model(data + step).square().sum() / 7.0).backward()
+        for g0, g1, p in zip(r0["grads"][step], r1["grads"][step], model.parameters()):
+            assert torch.equal(g0, g1)
+            assert torch.allclose(g0, p.grad, atol=1e-6)
+
+
 def test_shard_batch_covers_everything():
     from epn_pointcloud_amd import dp
     for gb in (1, 7, 32, 256):

@@ -42,7 +42,8 @@ def rel_l2(got, want):
 # ------------------------------------------------------------------------------------------------ GEMM kernels
 @pytest.mark.parametrize("dt", [torch.float32, torch.bfloat16])
 @pytest.mark.parametrize("M,N,K", [(1000, 64, 256), (513, 192, 320), (256, 32, 64), (777, 320, 128), (100, 24, 40),
-                                   (4096, 128, 1536), (1, 64, 64)])
+                                   (4096, 128, 1536), (1, 64, 64), (3000, 768, 32), (2000, 32, 32), (900, 64, 96),
+                                   (1500, 200, 16)])
 def test_gemm_nt_vs_fp64(gpu, dt, M, N, K):
     from epn_pointcloud_amd import gemm
     torch.manual_seed(M + N + K)

@@ -140,9 +140,9 @@ def _inter_case(gpu, sptk, zptk, b, n, cin, cout, stride, radius, sigma, K, lazy
 def test_inter_vs_oracle(gpu, vgtk_alias, inter_mode, cin, cout, stride, K, lazy):
     sptk, zptk = _mods(vgtk_alias)
     (y, oy), (dW, odW), (dF, odF) = _inter_case(gpu, sptk, zptk, 2, 128, cin, cout, stride, 0.4, 0.08, K, lazy, 100 + cin)
-    assert (y - oy).abs().max().item() < TOL * max(1.0, oy.abs().max().item())
+    assert (y - oy).abs().max().item() < TOL
     assert _rel(dW, odW) < TOL
-    assert (dF - odF).abs().max().item() < TOL * max(1.0, odF.abs().max().item())
+    assert (dF - odF).abs().max().item() < TOL
 
 
 @pytest.mark.parametrize("cin,cout,p", [(8, 8, 40), (5, 3, 17), (16, 16, 64), (32, 64, 33), (64, 64, 128), (128, 128, 16),
@@ -161,9 +161,9 @@ def test_intra_vs_oracle(gpu, vgtk_alias, intra_mode, cin, cout, p):
     fg = feats.to(gpu).requires_grad_(True)
     y = conv(zptk.SphericalPointCloud(torch.zeros(2, 3, p, device=gpu), fg, None))
     dW, dF = torch.autograd.grad(y.feats, [conv.basic_conv.W, fg], gy.to(gpu))
-    assert (y.feats.detach().cpu() - oy.detach()).abs().max().item() < TOL * max(1.0, oy.abs().max().item())
+    assert (y.feats.detach().cpu() - oy.detach()).abs().max().item() < TOL
     assert _rel(dW.cpu(), odW) < TOL
-    assert (dF.cpu() - odF).abs().max().item() < TOL * max(1.0, odF.abs().max().item())
+    assert (dF.cpu() - odF).abs().max().item() < TOL
 
 
 def test_reuse_of_returned_idx_and_weights(gpu, vgtk_alias):
@@ -232,8 +232,9 @@ def test_generic_and_fused_kernels_agree(gpu, vgtk_alias, inter_mode):
     from epn_pointcloud_amd import _lib
     with _lib.generic_kernels():
         generic = run()
-    for a, b in zip(fused, generic):
-        assert (a - b).abs().max().item() < TOL * max(1.0, b.abs().max().item())
+    for i, (a, b) in enumerate(zip(fused, generic)):
+        # features (first two entries): absolute 1e-3 (north_star); gradients reach |500| here: 1e-3 of their scale
+        assert (a - b).abs().max().item() < (TOL if i < 2 else TOL * max(1.0, b.abs().max().item()))
 
 
 def test_plumbing_config_a12_tetrahedral_subgroup(gpu, vgtk_alias):
@@ -271,8 +272,8 @@ def test_plumbing_config_a12_tetrahedral_subgroup(gpu, vgtk_alias):
         yg = ops.inter_so3conv(fg, W1g, geo)
         zg = ops.intra_so3conv(yg, W2g, cay.to(gpu))
         g_gpu = torch.autograd.grad(zg, [fg, W1g, W2g], gz.to(gpu))
-        assert (zg.detach().cpu() - z.detach()).abs().max().item() < TOL * max(1.0, z.abs().max().item())
-        for a, b in zip(g_gpu, g_ref):
+        assert (zg.detach().cpu() - z.detach()).abs().max().item() < TOL
+        for a, b in zip(g_gpu, g_ref):              # gradients (two of them weight gradients): 1e-3 of their own scale
             assert (a.cpu() - b).abs().max().item() < TOL * max(1.0, b.abs().max().item())
 
 
@@ -284,9 +285,9 @@ def test_inter_large_neighbourhoods_and_odd_widths(gpu, vgtk_alias, inter_mode, 
     sptk, zptk = _mods(vgtk_alias)
     (y, oy), (dW, odW), (dF, odF) = _inter_case(gpu, sptk, zptk, 1, 512, cin, cout, stride, radius, sigma, K, True,
                                                 500 + K)
-    assert (y - oy).abs().max().item() < TOL * max(1.0, oy.abs().max().item())
+    assert (y - oy).abs().max().item() < TOL
     assert _rel(dW, odW) < TOL
-    assert (dF - odF).abs().max().item() < TOL * max(1.0, odF.abs().max().item())
+    assert (dF - odF).abs().max().item() < TOL
 
 
 def test_fused_dispatch_covers_the_modelnet_schedule(gpu):
@@ -428,9 +429,9 @@ def test_group_ungroup_abi_vs_oracle(gpu, vgtk_alias, cin, K, na_sel, stride):
     fg = feats.to(gpu).requires_grad_(True)
     G = ops.inter_group(fg, geo)
     assert tuple(G.shape) == tuple(want.shape)
-    assert (G.detach().cpu() - want.detach()).abs().max().item() < TOL * max(1.0, want.abs().max().item())
+    assert (G.detach().cpu() - want.detach()).abs().max().item() < TOL
     (dF,) = torch.autograd.grad(G, fg, gG.to(gpu))
-    assert (dF.cpu() - o_dF).abs().max().item() < TOL * max(1.0, o_dF.abs().max().item())
+    assert (dF.cpu() - o_dF).abs().max().item() < TOL
 
 
 def test_arbitrary_index_rows_are_not_deduplicated(gpu, vgtk_alias, inter_mode):
@@ -464,9 +465,9 @@ def test_arbitrary_index_rows_are_not_deduplicated(gpu, vgtk_alias, inter_mode):
     fg, Wg = feats.to(gpu).requires_grad_(True), W.to(gpu).requires_grad_(True)
     y = ops.inter_so3conv(fg, Wg, geo)
     dW, dF = torch.autograd.grad(y, [Wg, fg], gy.to(gpu))
-    assert (y.detach().cpu() - y_ref.detach()).abs().max().item() < TOL * max(1.0, y_ref.abs().max().item())
+    assert (y.detach().cpu() - y_ref.detach()).abs().max().item() < TOL
     assert _rel(dW.cpu(), dW_ref) < TOL
-    assert (dF.cpu() - dF_ref).abs().max().item() < TOL * max(1.0, dF_ref.abs().max().item())
+    assert (dF.cpu() - dF_ref).abs().max().item() < TOL
 
 
 def test_split_and_fused_forms_agree_at_full_size(gpu, vgtk_alias):
@@ -493,9 +494,9 @@ def test_split_and_fused_forms_agree_at_full_size(gpu, vgtk_alias):
         outs.append((y.detach(), dW, dF))
         del y, gy
     (y0, dW0, dF0), (y1, dW1, dF1) = outs
-    assert (y0 - y1).abs().max().item() < TOL * max(1.0, y0.abs().max().item())
+    assert (y0 - y1).abs().max().item() < TOL
     assert _rel(dW1, dW0) < TOL
-    assert (dF0 - dF1).abs().max().item() < TOL * max(1.0, dF0.abs().max().item())
+    assert (dF0 - dF1).abs().max().item() < TOL
 
 
 def test_so3_basis_kernel_and_block_layout(gpu, vgtk_alias):
@@ -558,6 +559,6 @@ def test_intra_forms_agree_at_full_size(gpu, vgtk_alias):
         del y, gy
     y0, dW0, dF0 = outs[0]
     for y1, dW1, dF1 in outs[1:]:
-        assert (y0 - y1).abs().max().item() < TOL * max(1.0, y0.abs().max().item())
+        assert (y0 - y1).abs().max().item() < TOL
         assert _rel(dW1, dW0) < TOL
-        assert (dF0 - dF1).abs().max().item() < TOL * max(1.0, dF0.abs().max().item())
+        assert (dF0 - dF1).abs().max().item() < TOL

@@ -1,0 +1,43 @@
+"""RCCL on the one GPU a test box has: the `nccl` branch of dp.init_from_env with a single-rank communicator, an
+all-reduce of the flat gradient buffer through it, and bench.py's own multi-rank launcher path (`--gpus 1` children
+are not spawned; the launcher itself is covered on CPU by tests/test_dist_cpu.py).  Runs in a subprocess so that the
+process group never leaks into the pytest process."""
+import os
+import subprocess
+import sys
+
+import pytest
+
+from conftest import ROOT
+
+pytestmark = pytest.mark.gpu
+
+WORKER = r"""
+import os, sys, torch
+sys.path.insert(0, os.environ["EPN_ROOT"])
+from epn_pointcloud_amd import dp
+import torch.distributed as dist
+rank, local_rank, world = dp.init_from_env(backend="nccl", force=True)
+assert dist.is_initialized() and dist.get_backend() == "nccl" and (rank, world) == (0, 1)
+dev = torch.device("cuda", local_rank)
+lin = torch.nn.Linear(8, 4).to(dev)
+gb = dp.GradBuckets([list(lin.parameters())], world, hooks=False)
+gb.zero()
+lin(torch.ones(3, 8, device=dev)).sum().backward()
+before = gb.flat.clone()
+work = dist.all_reduce(gb.flat, op=dist.ReduceOp.SUM, async_op=True)     # RCCL kernel on the flat gradient bucket
+work.wait()
+torch.cuda.synchronize()
+assert torch.equal(gb.flat, before)                                      # one rank: sum == itself
+dp.broadcast_parameters(lin)
+dist.barrier()
+dist.destroy_process_group()
+print("RCCL_OK")
+"""
+
+
+def test_single_rank_rccl_allreduce(gpu):
+    env = dict(os.environ, RANK="0", LOCAL_RANK="0", WORLD_SIZE="1", MASTER_ADDR="127.0.0.1", MASTER_PORT="29517",
+               EPN_ROOT=ROOT, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    r = subprocess.run([sys.executable, "-c", WORKER], env=env, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0 and "RCCL_OK" in r.stdout, r.stdout + r.stderr

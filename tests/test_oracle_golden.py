@@ -171,3 +171,30 @@ def test_legacy_zpconv_oracle_against_reference_naive_golden():
     nbr = idx[:, :, None, None, :].expand(b, p2, na, ks, nn).contiguous()
     out = R.zp_inter_forward(nbr, w.contiguous(), feats)
     assert torch.allclose(out, T(g["G"]), atol=1e-4)
+
+
+def test_functional_api_rows_vs_reference():
+    """the oracle's restatements against the imported reference (functional_api.npz)."""
+    g = golden("functional_api.npz")
+    xyz, feats = T(g["a11_xyz"]), T(g["a11_feats"])
+    for tag in ("s2", "s1"):
+        stride, lazy, radius, nn = g[f"a7_{tag}_args"]
+        gx, bidx, sidx, sxyz = R.inter_grouping_ball(xyz, int(stride), float(radius), int(nn), bool(lazy))
+        assert torch.equal(bidx.int(), T(g[f"a7_{tag}_ball_idx"])) and torch.equal(sidx.int(), T(g[f"a7_{tag}_sample_idx"]))
+        assert torch.equal(gx, T(g[f"a7_{tag}_grouped_xyz"])) and torch.equal(sxyz, T(g[f"a7_{tag}_sample_xyz"]))
+    anchors, kernels = T(g["a11_anchors"]), T(g["a11_kernels"])
+    idx, w, new_xyz, new_feats, sidx = R.inter_grouping(xyz, feats, 2, 12, anchors, kernels, 0.45, 0.1, None, None, False)
+    assert torch.equal(idx.int(), T(g["a11_inter_idx"])) and torch.equal(sidx.int(), T(g["a11_sample_idx"]))
+    assert (w[:, :, :6] - T(g["a11_inter_w_a6"])).abs().max().item() < 1e-5
+    assert (new_feats - T(g["a11_new_feats"])).abs().max().item() < 1e-4
+    feats2 = T(g["a11r_feats"])
+    i1, w1, _, _, _ = R.inter_grouping(new_xyz, feats2, 1, 12, anchors, kernels, 0.45, 0.1, None, None, True)
+    _, _, rx, rf, rs = R.inter_grouping(new_xyz, feats2, 1, 12, anchors, kernels, 0.45, 0.1, i1, w1, True)
+    assert rs is None and torch.equal(i1.int(), T(g["a11r_inter_idx"]))
+    assert (rf - T(g["a11r_new_feats"])).abs().max().item() < 1e-4
+    assert (R.inter_pooling_naive(idx, sidx, feats) - T(g["a18_pool"])).abs().max().item() < 1e-6
+    assert (R.inter_blurring_naive(i1, feats2) - T(g["a18_blur"])).abs().max().item() < 1e-6
+    f2, x2 = R.inter_blurring(xyz, feats, 10, 0.45, 2, None, False)
+    assert (f2 - T(g["a18_blurring_s2_feats"])).abs().max().item() < 1e-6 and torch.equal(x2, T(g["a18_blurring_s2_xyz"]))
+    f1, x1 = R.inter_blurring(new_xyz, feats2, 10, 0.45, 1, None, True)
+    assert (f1 - T(g["a18_blurring_s1_feats"])).abs().max().item() < 1e-6 and torch.equal(x1, T(g["a18_blurring_s1_xyz"]))

@@ -75,7 +75,7 @@ def main():
         return
 
     nt_shapes = [(983040, 64, 1536), (491520, 128, 1536), (491520, 128, 3072), (245760, 256, 3072), (245760, 256, 6144),
-                 (122880, 256, 6144), (245760, 6144, 256), (983040, 64, 64), (1966080, 32, 768)]
+                 (122880, 256, 6144), (245760, 6144, 256), (983040, 64, 64), (1966080, 32, 768), (1966080, 768, 32), (1966080, 32, 32)]
     for (M, N, K) in nt_shapes:
         A = torch.randn(M, K, device=dev).to(dt)
         B = torch.randn(N, K, device=dev).to(dt)
