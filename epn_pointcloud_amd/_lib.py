@@ -21,7 +21,7 @@ EXPORTS = [
     "epn_intra_so3conv_bwd_data_f32", "epn_intra_so3conv_bwd_weight_f32",
     "epn_norm_workspace_bytes", "epn_chan_stats_f32", "epn_norm_act_fwd_f32", "epn_norm_act_bwd_reduce_f32", "epn_norm_act_bwd_apply_f32",
     "epn_inter_group_workspace_bytes", "epn_inter_group_f32", "epn_inter_ungroup_f32", "epn_intra_group_f32", "epn_so3_basis_f32",
-    "epn_zp_inter_fwd_f32", "epn_zp_inter_bwd_f32", "epn_zp_intra_fwd_f32", "epn_zp_intra_bwd_f32",
+    "epn_anchor_query_f32", "epn_zp_inter_fwd_f32", "epn_zp_inter_bwd_f32", "epn_zp_intra_fwd_f32", "epn_zp_intra_bwd_f32",
     "epn_pointnet_so3conv_fwd_f32", "epn_pointnet_so3conv_bwd_data_f32", "epn_pointnet_so3conv_bwd_weight_f32",
     "epn_gemm_nt_f32", "epn_gemm_nt_bf16", "epn_gemm_tn_workspace_bytes", "epn_gemm_tn_f32", "epn_gemm_tn_bf16",
     "epn_transpose_cast", "epn_cast",
@@ -83,6 +83,7 @@ def get_lib():
     lib.epn_intra_group_f32.argtypes = [_vp, _vp, _vp, _ci, _ci, _ci, _ci, _ci, _vp]
     for _n in ("epn_zp_inter_fwd_f32", "epn_zp_inter_bwd_f32", "epn_zp_intra_fwd_f32", "epn_zp_intra_bwd_f32"):
         getattr(lib, _n).argtypes = [_vp, _vp, _vp, _ci, _ci, _ci, _ci, _ci, _ci, _ci, _vp, _vp]
+    lib.epn_anchor_query_f32.argtypes = [_vp, _vp, _vp, _ci, _ci, _ci, _ci, _ci, _vp, _vp]
     lib.epn_so3_basis_f32.argtypes = [_vp, _vp, _vp, ctypes.c_longlong, _ci, _ci, _ci, _ci, _vp, _vp]
     lib.epn_inter_is_fused.argtypes = [dp]
     lib.epn_inter_is_fused.restype = _ci

@@ -156,3 +156,48 @@ extern "C" int epn_zp_intra_bwd_f32(const int32_t *anchor_neighbors, const float
     EPN_CHECK_LAUNCH();
     return 0;
 }
+
+// ---- vgtk.cuda.grouping.anchor_query (grouping_cuda.cpp:88-108, kernel grouping_cuda_kernel.cu:180-247): for every
+// grouped neighbour offset g = grouped_xyz[b,:,p,n], anchor direction a and 2-D kernel point (kw, kh):
+//     norm = |g| + 1e-6,  theta = acos(g . anchor_a / norm),  w[b,p,a,k,n] = (kw - norm)^2 + ((kh - theta) * norm)^2
+// One thread per (b, p, n): the 3 coordinates are read once, the na*ks results are written with n fastest (the
+// reference's layout), consecutive threads = consecutive n -> coalesced stores.  sample_idx / grouped_indices / nq are
+// part of the reference signature but unused by its kernel, and so here.
+namespace epn {
+namespace {
+__global__ void anchor_query_kernel(const float *__restrict__ gxyz, const float *__restrict__ anchors,
+                                    const float *__restrict__ kp, float *__restrict__ w, int b, int np, int nn, int na,
+                                    int ks) {
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    const long long per_b = (long long)np * nn;
+    if (i >= (long long)b * per_b) return;
+    const int bi = (int)(i / per_b);
+    const long long r = i - (long long)bi * per_b;       // p*nn + n
+    const long long pi = r / nn;
+    const int ni = (int)(r - pi * nn);
+    const float *g = gxyz + (size_t)bi * 3 * per_b;
+    const float x = g[r], y = g[per_b + r], z = g[2 * per_b + r];
+    const float norm = sqrtf(x * x + y * y + z * z) + 1e-6f;
+    float *o = w + (((size_t)bi * np + pi) * na) * ks * nn + ni;
+    for (int a = 0; a < na; ++a) {
+        const float theta = acosf((x * anchors[3 * a] + y * anchors[3 * a + 1] + z * anchors[3 * a + 2]) / norm);
+        for (int k = 0; k < ks; ++k) {
+            const float d0 = kp[2 * k] - norm, d1 = (kp[2 * k + 1] - theta) * norm;
+            o[((size_t)a * ks + k) * nn] = d0 * d0 + d1 * d1;
+        }
+    }
+}
+}  // namespace
+}  // namespace epn
+
+extern "C" int epn_anchor_query_f32(const float *grouped_xyz, const float *anchors, const float *kernel_points, int b,
+                                    int np, int nn, int na, int ks, float *anchor_weights, epn_stream_t stream) {
+    if (b < 0 || np < 0 || nn < 1 || na < 1 || ks < 1) return EPN_EINVAL;
+    const long long total = (long long)b * np * nn;
+    if (total == 0) return 0;
+    if (!grouped_xyz || !anchors || !kernel_points || !anchor_weights) return EPN_ENULL;
+    hipLaunchKernelGGL(epn::anchor_query_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, epn_stream(stream),
+                       grouped_xyz, anchors, kernel_points, anchor_weights, b, np, nn, na, ks);
+    EPN_CHECK_LAUNCH();
+    return 0;
+}

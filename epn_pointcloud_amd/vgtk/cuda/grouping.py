@@ -45,5 +45,17 @@ def initial_anchor_query(centers, xyz, kernel_points, radius, sigma):
 
 
 def anchor_query(sample_idx, grouped_indices, grouped_xyz, anchors, kernel_points, nq):
-    """grouping_cuda.cpp:88-106; legacy ZPConv, every call site in the reference is commented out."""
-    raise NotImplementedError("anchor_query: legacy ZPConv kernel, out of scope (SURVEY.md section 2 row 1)")
+    """(sample_idx i[b,p], grouped_indices i[b,p,nn], grouped_xyz f[b,3,p,nn], anchors f[na,3], kernel_points f[ks,2],
+    int nq) -> [anchor_weights f[b,p,na,ks,nn]]  (grouping_cuda.cpp:88-108; legacy ZPConv).  sample_idx,
+    grouped_indices and nq are checked like the reference does (CHECK_INPUT) and otherwise unused, as in its kernel."""
+    lib = _lib.get_lib()
+    _lib.dev_ptr(sample_idx, "sample_idx", torch.int32)
+    _lib.dev_ptr(grouped_indices, "grouped_indices", torch.int32)
+    g, a, k = (_lib.dev_ptr(grouped_xyz, "grouped_xyz"), _lib.dev_ptr(anchors, "anchors"),
+               _lib.dev_ptr(kernel_points, "kernel_points"))
+    b, _, p, nn = grouped_xyz.shape
+    na, ks = anchors.shape[0], kernel_points.shape[0]
+    w = torch.empty((b, p, na, ks, nn), dtype=torch.float32, device=grouped_xyz.device)
+    _lib.check(lib.epn_anchor_query_f32(g, a, k, b, p, nn, na, ks, _lib.dev_ptr(w, "anchor_weights"),
+                                        _lib.stream_of(grouped_xyz)), "anchor_query")
+    return [w]

@@ -244,6 +244,14 @@ int epn_pointnet_so3conv_bwd_weight_f32(const float *grad_out, const int32_t *ar
  *   intra: anchor_neighbors i32[na_out][ann], anchor_weights f32[na_out][ks][ann], feats f32[b][c][np][na_in]
  *          anchor_feats f32[b][c][ks][np][na_out];  grad_feats f32[b][c][np][na_in]
  * Indices outside [0, nq) / [0, na_in) contribute nothing (the reference reads out of bounds). */
+/* replaces vgtk.cuda.grouping.anchor_query (vgtk/vgtk/cuda/grouping_cuda.cpp:88-108, kernel
+ * grouping_cuda_kernel.cu:180-247; legacy ZPConv, every call site in the reference is commented out):
+ *   grouped_xyz f32[b][3][np][nn] (local coordinates), anchors f32[na][3] (unit directions), kernel_points f32[ks][2]
+ *   anchor_weights f32[b][np][na][ks][nn] = (kw - norm)^2 + ((kh - theta) * norm)^2,
+ *       norm = |g| + 1e-6, theta = acos(g . anchor / norm)      (fully written; the reference pre-fills 1e6)
+ * The reference's sample_idx / grouped_indices / nq arguments are unused by its kernel and not part of this entry. */
+int epn_anchor_query_f32(const float *grouped_xyz, const float *anchors, const float *kernel_points, int b, int np,
+                         int nn, int na, int ks, float *anchor_weights, epn_stream_t stream);
 int epn_zp_inter_fwd_f32(const int32_t *anchor_neighbors, const float *anchor_weights, const float *feats, int b, int c,
                          int np, int nq, int na, int ks, int ann, float *anchor_feats, epn_stream_t stream);
 int epn_zp_inter_bwd_f32(const int32_t *anchor_neighbors, const float *anchor_weights, const float *grad_anchor_feats,

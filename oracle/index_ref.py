@@ -138,3 +138,19 @@ def initial_anchor_query(centers, xyz, kernel_points, radius, sigma):
 
 def opt_n_threads(work_size):
     return _load().epn_oracle_opt_n_threads(int(work_size))
+
+
+def anchor_query(sample_idx, grouped_indices, grouped_xyz, anchors, kernel_points, nq):
+    """vgtk.cuda.grouping.anchor_query restated in numpy float32 (grouping_cuda.cpp:88-108, kernel
+    grouping_cuda_kernel.cu:180-247): w[b,p,a,k,n] = (kw - norm)^2 + ((kh - theta) norm)^2 with
+    norm = |g| + 1e-6, theta = acos(g . anchor_a / norm).  Elementwise float arithmetic (sqrt, acos): the HIP kernel is
+    compared within 1e-5, not bit-exactly.  sample_idx / grouped_indices / nq are unused by the reference kernel."""
+    g = grouped_xyz.detach().cpu().numpy().astype(np.float32)                    # [b,3,p,nn]
+    A = anchors.detach().cpu().numpy().astype(np.float32)                        # [na,3]
+    K = kernel_points.detach().cpu().numpy().astype(np.float32)                  # [ks,2]
+    norm = (np.sqrt((g * g).sum(1)) + np.float32(1e-6)).astype(np.float32)       # [b,p,nn]
+    dot = np.einsum('bcpn,ac->bpan', g, A).astype(np.float32)                    # [b,p,na,nn]
+    theta = np.arccos(np.clip(dot / norm[:, :, None, :], -1.0, 1.0)).astype(np.float32)
+    d0 = K[None, None, None, :, 0, None] - norm[:, :, None, None, :]             # [b,p,1,ks,nn]
+    d1 = (K[None, None, None, :, 1, None] - theta[:, :, :, None, :]) * norm[:, :, None, None, :]
+    return [torch.from_numpy((d0 * d0 + d1 * d1).astype(np.float32))]

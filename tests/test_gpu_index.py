@@ -196,3 +196,30 @@ def test_legacy_zpconv_grouping_functions(gpu, vgtk_alias):
     dgot = zp.intra_zpconv_backward(inbr.to(gpu), iw.to(gpu), gy.to(gpu), na_in)
     assert tuple(dgot.shape) == (b, c, npts, na_in)
     assert (dgot.cpu() - dwant).abs().max().item() < 1e-4
+
+
+def test_anchor_query_vs_oracle(gpu, vgtk_alias):
+    """vgtk.cuda.grouping.anchor_query (legacy ZPConv): HIP kernel vs the numpy restatement of
+    grouping_cuda_kernel.cu:180-247, plus two values worked out by hand."""
+    import vgtk.cuda.grouping as cuda_nn
+    from oracle import index_ref
+    rng = np.random.default_rng(5)
+    b, p, nn, na, ks = 2, 37, 9, 12, 5
+    g = torch.from_numpy(rng.standard_normal((b, 3, p, nn)).astype(np.float32) * 0.3)
+    anc = rng.standard_normal((na, 3)).astype(np.float32)
+    anc = torch.from_numpy(anc / np.linalg.norm(anc, axis=1, keepdims=True))
+    kp = torch.from_numpy(rng.random((ks, 2)).astype(np.float32))
+    sidx = torch.zeros(b, p, dtype=torch.int32)
+    gidx = torch.zeros(b, p, nn, dtype=torch.int32)
+    want = index_ref.anchor_query(sidx, gidx, g, anc, kp, 100)[0]
+    got = cuda_nn.anchor_query(sidx.to(gpu), gidx.to(gpu), g.to(gpu), anc.to(gpu), kp.to(gpu), 100)[0]
+    assert tuple(got.shape) == (b, p, na, ks, nn)
+    assert (got.cpu() - want).abs().max().item() < 1e-5
+    # by hand: g = (0, 0, 2), anchor +z, kernel point (kw, kh) = (1, 0): norm = 2 (+1e-6), theta = 0 -> (1-2)^2 + 0 = 1;
+    #          anchor +x: theta = pi/2 -> 1 + (pi/2 * 2)^2 = 1 + pi^2
+    g1 = torch.tensor([0.0, 0.0, 2.0]).view(1, 3, 1, 1)
+    a1 = torch.tensor([[0.0, 0.0, 1.0], [1.0, 0.0, 0.0]])
+    k1 = torch.tensor([[1.0, 0.0]])
+    z = torch.zeros(1, 1, dtype=torch.int32, device=gpu)
+    w = cuda_nn.anchor_query(z, z.view(1, 1, 1), g1.to(gpu), a1.to(gpu), k1.to(gpu), 1)[0].cpu().flatten()
+    assert abs(w[0].item() - 1.0) < 1e-4 and abs(w[1].item() - (1.0 + np.pi ** 2)) < 1e-4

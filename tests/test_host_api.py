@@ -68,8 +68,9 @@ def test_cpu_tensors_are_rejected_like_check_cuda(vgtk_alias):
         conv(zptk.SphericalPointCloud(x, torch.rand(1, 4, 32, 60), None))
     with pytest.raises(RuntimeError, match="must be a CUDA tensor"):
         cuda_nn.initial_anchor_query(x, torch.rand(8, 3), torch.rand(24, 60, 3), 0.4, 0.08)
-    with pytest.raises(NotImplementedError):
-        cuda_nn.anchor_query(None, None, None, None, None, 0)
+    with pytest.raises(RuntimeError, match="must be a CUDA tensor"):
+        cuda_nn.anchor_query(torch.zeros(1, 4, dtype=torch.int32), torch.zeros(1, 4, 3, dtype=torch.int32),
+                             torch.rand(1, 3, 4, 3), torch.rand(12, 3), torch.rand(5, 2), 32)
 
 
 def test_lazy_sample_index_and_occupancy(vgtk_alias):
