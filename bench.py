@@ -41,6 +41,7 @@ KERNEL_OF = {
     "inter_group": "epn::inter_group_kernel", "inter_ungroup": "epn::inter_ungroup_kernel",
     "inter_gemm": "epn::gemm_nt_kernel", "intra_gemm": "epn::gemm_nt_kernel",
     "inter_gemm_dw": "epn::gemm_tn_kernel", "intra_gemm_dw": "epn::gemm_tn_kernel",
+    "conv1x1_gemm": "epn::gemm_nt_kernel", "conv1x1_gemm_dw": "epn::gemm_tn_kernel",
     "intra_group": "epn::intra_group_kernel", "so3_basis": "epn::so3_basis_kernel",
     "pointnet_fwd": "epn::pointnet_fwd_kernel", "pointnet_bwd_data": "epn::pointnet_bwd_data_kernel",
     "pointnet_bwd_weight": "epn::pointnet_bwd_weight_kernel",

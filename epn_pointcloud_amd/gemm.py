@@ -128,19 +128,24 @@ class MatmulNT(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, A, W):
+        from . import ops
         Wc = W if W.dtype == A.dtype else cast(W, A.dtype)
         ctx.save_for_backward(A, W)
-        return gemm_nt(A, Wc)
+        M, K, N = A.shape[0], A.shape[1], W.shape[0]
+        return ops._launch("conv1x1_gemm", ("nt", M, N, K), 2.0 * M * N * K, A.device, lambda: gemm_nt(A, Wc))
 
     @staticmethod
     def backward(ctx, dC):
         A, W = ctx.saved_tensors
         dC = dC if dC.dtype == A.dtype else dC.to(A.dtype)
+        from . import ops
         dA = dW = None
+        M, K, N = A.shape[0], A.shape[1], W.shape[0]
         if ctx.needs_input_grad[0]:
-            dA = gemm_nt(dC, transpose_cast(W, A.dtype))
+            Wt = transpose_cast(W, A.dtype)
+            dA = ops._launch("conv1x1_gemm", ("nt", M, K, N), 2.0 * M * N * K, A.device, lambda: gemm_nt(dC, Wt))
         if ctx.needs_input_grad[1]:
-            dW = gemm_tn(dC, A)
+            dW = ops._launch("conv1x1_gemm_dw", ("tn", M, N, K), 2.0 * M * N * K, A.device, lambda: gemm_tn(dC, A))
         return dA, dW
 
 

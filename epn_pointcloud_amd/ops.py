@@ -919,11 +919,11 @@ def _identity_index(na, device):
 def conv1x1(x, weight, bias=None):
     """nn.Conv2d(cin, cout, 1) on a [b,c,p,a] tensor, channels-last in and out with no layout copy: one NT GEMM
     [cols, cin] x [cout, cin]^T on the zero-copy 2-D view (fp32 master weight, cast per call for bf16 features).
-    fp32 with widths that are multiples of 16 keeps the intra GEMM kernel (single, identity anchor neighbour);
+    bf16 widths that are only multiples of 16 run the fp32 intra GEMM kernel (single, identity anchor neighbour);
     cin = 1 (the occupancy feature of the first block) is an outer product; odd shapes go to torch."""
     cout, cin = weight.shape[0], weight.shape[1]
-    if x.is_cuda and x.dtype == torch.bfloat16 and cin % 8 == 0:
-        xc = to_cl(x)
+    if x.is_cuda and ((x.dtype == torch.bfloat16 and cin % 32 == 0) or (x.dtype == torch.float32 and cin % 16 == 0)):
+        xc = to_cl(x)                   # K = cin is a whole number of 64-byte half K steps: the MFMA GEMM kernels
         b, c, p, a = xc.shape
         y2d = gemm.matmul_nt(xc.permute(0, 2, 3, 1).reshape(-1, c), weight.reshape(cout, cin))
         y = y2d.view(b, p, a, cout).permute(0, 3, 1, 2)
