@@ -39,6 +39,7 @@ KERNEL_OF = {
     "inter_bwd_weight": "epn::inter_bwd_weight8_kernel", "intra_fwd": "epn::intra_gemm_kernel",
     "intra_bwd_data": "epn::intra_gemm_kernel", "intra_bwd_weight": "epn::intra_bwd_weight_v4_kernel",
     "inter_group": "epn::inter_group_kernel", "inter_ungroup": "epn::inter_ungroup_kernel",
+    "inter_ungroup_det": "epn::inter_ungroup_slots_kernel + inter_reduce_slots_kernel",
     "inter_gemm": "epn::gemm_nt_kernel", "intra_gemm": "epn::gemm_nt_kernel",
     "inter_gemm_dw": "epn::gemm_tn_kernel", "intra_gemm_dw": "epn::gemm_tn_kernel",
     "conv1x1_gemm": "epn::gemm_nt_kernel", "conv1x1_gemm_dw": "epn::gemm_tn_kernel",

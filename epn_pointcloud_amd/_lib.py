@@ -26,6 +26,7 @@ EXPORTS = [
     "epn_gemm_nt_f32", "epn_gemm_nt_bf16", "epn_gemm_tn_workspace_bytes", "epn_gemm_tn_f32", "epn_gemm_tn_bf16",
     "epn_transpose_cast", "epn_cast",
     "epn_inter_group_bf16", "epn_inter_ungroup_bf16", "epn_intra_group_bf16", "epn_so3_basis_bf16",
+    "epn_inter_inverse_list", "epn_inter_ungroup_det_f32", "epn_inter_ungroup_det_bf16",
     "epn_chan_stats_bf16", "epn_norm_act_fwd_bf16", "epn_norm_act_bwd_reduce_bf16", "epn_norm_act_bwd_apply_bf16",
 ]
 
@@ -112,6 +113,10 @@ def get_lib():
     lib.epn_transpose_cast.argtypes = [_vp, _vp, _ci, _ci, _ci, _ci, _vp]
     lib.epn_cast.argtypes = [_vp, _vp, _sz, _ci, _ci, _vp]
     # the bf16 twins share their fp32 counterparts' signatures (void* feature pointers)
+    lib.epn_inter_inverse_list.argtypes = [_vp, _ci, _ci, _ci, _ci, _vp, _vp, _vp]
+    lib.epn_inter_inverse_list.restype = _ci
+    lib.epn_inter_ungroup_det_f32.argtypes = [dp, _vp, _vp, _vp, _vp, _vp, _sz, _vp, _sz, _vp]
+    lib.epn_inter_ungroup_det_bf16.argtypes = lib.epn_inter_ungroup_det_f32.argtypes
     lib.epn_inter_group_bf16.argtypes = lib.epn_inter_group_f32.argtypes
     lib.epn_inter_ungroup_bf16.argtypes = lib.epn_inter_ungroup_f32.argtypes
     lib.epn_intra_group_bf16.argtypes = lib.epn_intra_group_f32.argtypes

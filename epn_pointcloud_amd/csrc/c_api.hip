@@ -14,7 +14,7 @@ static bool force_generic() { return g_policy.load(std::memory_order_relaxed) ==
 namespace epn { int kernel_policy() { return g_policy.load(std::memory_order_relaxed); } }
 
 extern "C" int epn_set_kernel_policy(int policy) {
-    if (policy != 0 && policy != 1 && (policy & ~0xff) != 0x100) return EPN_EINVAL;   // 0x100 | cfg: tools/gemm_bench.py
+    if (policy != 0 && policy != 1 && (policy & ~0xff) != 0x100 && (policy & ~0xff) != 0x200) return EPN_EINVAL;   // 0x100 | cfg: tools/gemm_bench.py
     g_policy.store(policy, std::memory_order_relaxed);
     return 0;
 }
@@ -235,6 +235,45 @@ extern "C" int epn_inter_ungroup_f32(const epn_inter_desc *d, const float *grad_
 extern "C" int epn_inter_ungroup_bf16(const epn_inter_desc *d, const void *grad_grouped, float *grad_feats_cl,
                                       void *workspace, size_t workspace_bytes, epn_stream_t stream) {
     return inter_ungroup_any(d, grad_grouped, grad_feats_cl, workspace, workspace_bytes, 1, stream);
+}
+
+extern "C" int epn_inter_inverse_list(const int32_t *ball_idx, int b, int p1, int p2, int nn, int32_t *offsets,
+                                      int32_t *entries, epn_stream_t stream) {
+    if (b < 0 || p1 < 1 || p2 < 0 || nn < 1) return EPN_EINVAL;
+    if (b == 0) return 0;
+    if (!ball_idx || !offsets || !entries) return EPN_ENULL;
+    return launch_inverse_list(ball_idx, b, p1, p2, nn, offsets, entries, epn_stream(stream));
+}
+
+static int inter_ungroup_det_any(const epn_inter_desc *d, const void *grad_grouped, void *grad_feats_cl,
+                                 const int32_t *offsets, const int32_t *entries, void *slab, size_t slab_bytes,
+                                 void *workspace, size_t workspace_bytes, int bf16, epn_stream_t stream) {
+    hipStream_t st = epn_stream(stream);
+    InterWs ws;
+    float *base = nullptr;
+    int rc = prep_tables(d, workspace, workspace_bytes, ws, base, st);
+    if (rc) return rc;
+    if (!inter_group_mfma_ok(d) || d->na < 16 || (d->na * d->cin) % 4) return EPN_EINVAL;
+    if (!grad_feats_cl) return EPN_ENULL;
+    if (d->b == 0) return 0;
+    if (!grad_grouped || !offsets || !entries || !slab) return EPN_ENULL;
+    const size_t need = (size_t)d->b * d->p2 * d->nn * d->na * d->cin * (bf16 ? 2 : 4);
+    if (slab_bytes < need) return EPN_EWORKSPACE;
+    rc = launch_inter_tables_mfma(d, base + ws.rk_off, base + ws.rk4_off, base + ws.beta_off, st);
+    if (rc) return rc;
+    return launch_inter_ungroup_det_mfma(d, base + ws.rk4_off, grad_grouped, grad_feats_cl, slab, offsets, entries, bf16, st);
+}
+extern "C" int epn_inter_ungroup_det_f32(const epn_inter_desc *d, const float *grad_grouped, float *grad_feats_cl,
+                                         const int32_t *offsets, const int32_t *entries, void *slab, size_t slab_bytes,
+                                         void *workspace, size_t workspace_bytes, epn_stream_t stream) {
+    return inter_ungroup_det_any(d, grad_grouped, grad_feats_cl, offsets, entries, slab, slab_bytes, workspace,
+                                 workspace_bytes, 0, stream);
+}
+extern "C" int epn_inter_ungroup_det_bf16(const epn_inter_desc *d, const void *grad_grouped, void *grad_feats_cl,
+                                          const int32_t *offsets, const int32_t *entries, void *slab, size_t slab_bytes,
+                                          void *workspace, size_t workspace_bytes, epn_stream_t stream) {
+    return inter_ungroup_det_any(d, grad_grouped, grad_feats_cl, offsets, entries, slab, slab_bytes, workspace,
+                                 workspace_bytes, 1, stream);
 }
 
 static int check_intra(int b, int p, int na, int kn, int cin, int cout) {

@@ -664,7 +664,12 @@ int gemm_tn_splits(bool bf16, long long R, int N1, int N2) {
     gemm_tn_tile(bf16, N1, N2, &bn1, &bn2);
     const long long tiles = (long long)((N1 + bn1 - 1) / bn1) * ((N2 + bn2 - 1) / bn2);
     const long long chunks = R / 32;
-    long long s = (1024 + tiles - 1) / tiles;          // ~4 workgroups per CU in total (512 measured 12 % slower)
+    const int pol = kernel_policy();
+    const long long target = (pol & ~0xff) == 0x200 ? 256LL * (pol & 0xff) : 2048;   // 0x200 | v: tuning override
+    // ~8 workgroups per CU in total: measured on the dW shapes of the ModelNet schedule, 512 / 1024 / 2048 / 4096 ->
+    // 91 / 106 / 118 / 120 TFLOP/s (short row ranges spread evenly over the XCDs; the fp32 partial slabs and their
+    // fixed-order reduction are included in those times)
+    long long s = (target + tiles - 1) / tiles;
     const long long smax = chunks / 8 > 1 ? chunks / 8 : 1;   // at least 8 K steps per split
     if (s > smax) s = smax;
     if (s > 512) s = 512;

@@ -349,9 +349,11 @@ __global__ __launch_bounds__(64 * NW) void inter_fwd_kernel(InterArgs A) {
 
 // Data-gradient tail for the columns of one segment: T[n][c] = sum_k w[n][k] dG[c,k], then
 // dF[b, idx[n], a, c] += T[n][c].  dG of the wave's 16 columns sits in Gs[col][c_local*ks + k].
-template <int NT, int KT, typename TG = float>
+// DET: instead of the atomic scatter, the per-slot contributions T[b][p][n][a][c] (element type TG) are stored to the
+// slab `A.out` (deterministic data gradient: inter_reduce_slots_kernel then sums them per destination in a fixed order).
+template <int NT, int KT, typename TG = float, bool DET = false>
 __device__ __forceinline__ void scatter_segment(const InterArgs &A, const Seg<NT> &sg, int ct, int x, int j,
-                                                const TG *Gs, int gss) {
+                                                const TG *Gs, int gss, long long pt = 0) {
     if (sg.cnt <= 0) return;
     // transposed weights: S'[k][n] = beta_k + alpha_n + (2/sigma)(R_a kappa_k).g_n  (A = rk4 row incl. beta, B = (g,1))
     float gB[NT], alphaN[NT];
@@ -382,9 +384,20 @@ __device__ __forceinline__ void scatter_segment(const InterArgs &A, const Seg<NT
                 for (int r = 0; r < 4; ++r) tt = mfma4(fmaxf(s[r], 0.0f), dgc[r], tt);
             }
             // tt: lane (x = c, j), register r -> n = 16t + 4j + r
+            if constexpr (DET) {
+                TG *slab = reinterpret_cast<TG *>(A.out);
 #pragma unroll
-            for (int r = 0; r < 4; ++r)
-                if (sg.h.mul[t][r] != 0.0f) atomicAdd(drow + sg.h.q[t][r], tt[r] * sg.h.mul[t][r]);
+                for (int r = 0; r < 4; ++r) {
+                    const int n = 16 * t + 4 * j + r;
+                    if (n < A.nn)
+                        slab[(((size_t)pt * A.nn + n) * A.na + a) * A.cin + 16 * ct + x] =
+                            (TG)(sg.h.ok[t][r] ? tt[r] : 0.0f);
+                }
+            } else {
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+                    if (sg.h.mul[t][r] != 0.0f) atomicAdd(drow + sg.h.q[t][r], tt[r] * sg.h.mul[t][r]);
+            }
         }
     }
 }
@@ -1055,6 +1068,104 @@ __global__ __launch_bounds__(64 * NW) void inter_ungroup_kernel(InterArgs A) {
     }
 }
 
+// Deterministic transpose of the grouping, step 1: slab[b][p][n][a][c] = sum_k w[k][n] dG[col][c*ks + k] (no atomics).
+template <int NT, int KT, typename TG>
+__global__ __launch_bounds__(64 * NW) void inter_ungroup_slots_kernel(InterArgs A) {
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int x = lane & 15, j = lane >> 4;
+    const long long col0 = ((long long)epn_xcd_tile(blockIdx.x, gridDim.x) * NW + wave) * 16;
+    if (col0 >= A.ncol) return;
+    const int gss = A.cin * A.ks;
+    const TG *dG = reinterpret_cast<const TG *>(A.gout) + (size_t)col0 * gss;
+    const int ct0 = blockIdx.y * A.col_tiles_per_wg;
+    const int ct1 = min(ct0 + A.col_tiles_per_wg, A.cin >> 4);
+    Seg<NT> s0, s1;
+    make_segments<NT, TG>(A, col0, x, j, s0, s1);     // only the neighbourhood fragments are used (fbase is not)
+    const long long pt0 = col0 / A.na;
+    for (int ct = ct0; ct < ct1; ++ct) {
+        scatter_segment<NT, KT, TG, true>(A, s0, ct, x, j, dG + 16 * ct * A.ks, gss, pt0);
+        scatter_segment<NT, KT, TG, true>(A, s1, ct, x, j, dG + 16 * ct * A.ks, gss, pt0 + 1);
+    }
+}
+
+// Inverse neighbour list of one cloud as CSR, entries in increasing (p, n) order (what makes the sums below
+// order-deterministic): off[b][q] .. off[b][q+1] index ent[b][.] = p*nn + n with idx[b][p][n] == q.  One workgroup per
+// cloud; thread q scans the cloud's index rows, staged through LDS in pieces (broadcast reads), twice: count, then fill.
+constexpr int INV_PIECE = 8192;
+__global__ __launch_bounds__(1024) void inverse_list_kernel(const int32_t *__restrict__ idx, int p1, int entries,
+                                                            int32_t *__restrict__ off, int32_t *__restrict__ ent) {
+    __shared__ int32_t piece[INV_PIECE];
+    __shared__ int32_t scan[1024];
+    const int b = blockIdx.x, tid = threadIdx.x;
+    const int32_t *row = idx + (size_t)b * entries;
+    int32_t *o = off + (size_t)b * (p1 + 1);
+    int32_t *e = ent + (size_t)b * entries;
+    // destinations are handled 1024 at a time (p1 <= 1024 for every shipped schedule: one round)
+    int base_total = 0;
+    for (int q0 = 0; q0 < p1; q0 += 1024) {
+        const int q = q0 + tid;
+        int cnt = 0;
+        for (int e0 = 0; e0 < entries; e0 += INV_PIECE) {
+            const int ne = min(INV_PIECE, entries - e0);
+            __syncthreads();
+            for (int i = tid; i < ne; i += 1024) piece[i] = row[e0 + i];
+            __syncthreads();
+            if (q < p1)
+                for (int i = 0; i < ne; ++i) cnt += piece[i] == q;
+        }
+        // exclusive scan of the 1024 counts (Hillis-Steele in LDS)
+        __syncthreads();
+        scan[tid] = cnt;
+        __syncthreads();
+        for (int d = 1; d < 1024; d <<= 1) {
+            const int v = tid >= d ? scan[tid - d] : 0;
+            __syncthreads();
+            scan[tid] += v;
+            __syncthreads();
+        }
+        const int start = base_total + scan[tid] - cnt;
+        if (q < p1) o[q] = start;
+        int w = start;
+        for (int e0 = 0; e0 < entries; e0 += INV_PIECE) {
+            const int ne = min(INV_PIECE, entries - e0);
+            __syncthreads();
+            for (int i = tid; i < ne; i += 1024) piece[i] = row[e0 + i];
+            __syncthreads();
+            if (q < p1)
+                for (int i = 0; i < ne; ++i)
+                    if (piece[i] == q) e[w++] = e0 + i;
+        }
+        base_total += scan[1023];
+        __syncthreads();
+    }
+    if (tid == 0) o[p1] = base_total;
+}
+
+// Step 2: dF[b][q][a][c] = sum over the inverse list of q, in list order, of slab[b][entry][a][c]; fp32 accumulation,
+// output in TO.  One thread per 4 consecutive (a, c) elements of one destination row: fully coalesced slab reads.
+template <typename TG, typename TO>
+__global__ __launch_bounds__(256) void inter_reduce_slots_kernel(const TG *__restrict__ slab, const int32_t *__restrict__ off,
+                                                                 const int32_t *__restrict__ ent, TO *__restrict__ dF,
+                                                                 int b, int p1, int entries, int rowlen) {
+    const int v4 = rowlen >> 2;
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (long long)b * p1 * v4) return;
+    const int c4 = (int)(i % v4);
+    const long long bq = i / v4;
+    const int bb = (int)(bq / p1), q = (int)(bq - (long long)bb * p1);
+    const int32_t *o = off + (size_t)bb * (p1 + 1);
+    const int32_t *e = ent + (size_t)bb * entries;
+    const TG *sl = slab + (size_t)bb * entries * rowlen + 4 * c4;
+    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+    const int e1 = o[q + 1];
+    for (int k = o[q]; k < e1; ++k) {
+        const f32x4 v = ld4f(sl + (size_t)e[k] * rowlen);
+        acc[0] += v[0]; acc[1] += v[1]; acc[2] += v[2]; acc[3] += v[3];
+    }
+    st4f(dF + (size_t)bq * rowlen + 4 * c4, acc);
+}
+
 __global__ void rk4_table_kernel(const float *__restrict__ rk, int na, int ks, float sigma_inv,
                                  float *__restrict__ rk4) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -1302,6 +1413,41 @@ int launch_inter_group_mfma(const epn_inter_desc *d, const float *rk4, const voi
     } while (0)
     EPN_DISPATCH_NT_KT(EPN_GRP, 0);
 #undef EPN_GRP
+    EPN_CHECK_LAUNCH();
+    return 0;
+}
+
+int launch_inverse_list(const int32_t *idx, int b, int p1, int p2, int nn, int32_t *off, int32_t *ent, hipStream_t st) {
+    hipLaunchKernelGGL(inverse_list_kernel, dim3(b), dim3(1024), 0, st, idx, p1, p2 * nn, off, ent);
+    EPN_CHECK_LAUNCH();
+    return 0;
+}
+
+// deterministic data gradient: slab (element type = dG's) <- per-slot contributions, then the ordered reduction
+int launch_inter_ungroup_det_mfma(const epn_inter_desc *d, const float *rk4, const void *dG, void *dF, void *slab,
+                                  const int32_t *off, const int32_t *ent, int bf16, hipStream_t st) {
+    InterArgs A = make_args(d, rk4);
+    A.gout = static_cast<const float *>(dG); A.out = static_cast<float *>(slab);
+    const unsigned grid = (unsigned)((A.ncol + 16 * NW - 1) / (16 * NW));
+    A.col_tiles_per_wg = 1;
+    const unsigned gy = (unsigned)(d->cin >> 4);
+#define EPN_USLOT(NT_, KT_, dummy)                                                                                       \
+    do {                                                                                                                 \
+        if (bf16) hipLaunchKernelGGL((inter_ungroup_slots_kernel<NT_, KT_, __bf16>), dim3(grid, gy), dim3(64 * NW), 0, st, A); \
+        else hipLaunchKernelGGL((inter_ungroup_slots_kernel<NT_, KT_, float>), dim3(grid, gy), dim3(64 * NW), 0, st, A);      \
+    } while (0)
+    EPN_DISPATCH_NT_KT(EPN_USLOT, 0);
+#undef EPN_USLOT
+    EPN_CHECK_LAUNCH();
+    const int rowlen = d->na * d->cin, entries = d->p2 * d->nn;
+    const long long n = (long long)d->b * d->p1 * (rowlen >> 2);
+    const dim3 g2((unsigned)((n + 255) / 256));
+    if (bf16)
+        hipLaunchKernelGGL((inter_reduce_slots_kernel<__bf16, __bf16>), g2, dim3(256), 0, st, static_cast<const __bf16 *>(slab),
+                           off, ent, static_cast<__bf16 *>(dF), d->b, d->p1, entries, rowlen);
+    else
+        hipLaunchKernelGGL((inter_reduce_slots_kernel<float, float>), g2, dim3(256), 0, st, static_cast<const float *>(slab),
+                           off, ent, static_cast<float *>(dF), d->b, d->p1, entries, rowlen);
     EPN_CHECK_LAUNCH();
     return 0;
 }

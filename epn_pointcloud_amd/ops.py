@@ -112,6 +112,7 @@ class InterGeometry:
         self.xyz, self.new_xyz, self.ball_idx = xyz, new_xyz, ball_idx
         self.anchors, self.kernels, self.sigma = anchors.contiguous(), kernels.contiguous(), float(sigma)
         self._dense = None
+        self._inverse = None
 
     @property
     def shape(self):
@@ -135,6 +136,22 @@ class InterGeometry:
         d.b, d.p1, d.p2, d.nn = b, self.xyz.shape[2], p2, nn
         d.na, d.ks, d.cin, d.cout = self.anchors.shape[0], self.kernels.shape[0], int(cin), int(cout)
         return d
+
+    def inverse_list(self):
+        """CSR inverse of the ball query (offsets [b, p1+1], entries [b, p2*nn], entries of a destination in increasing
+        (p, n) order) for the deterministic data gradient; built once per geometry by epn_inter_inverse_list."""
+        if self._inverse is None:
+            lib = _lib.get_lib()
+            b, p2, nn = self.ball_idx.shape
+            p1 = self.xyz.shape[2]
+            off = torch.empty((b, p1 + 1), dtype=torch.int32, device=self.device)
+            ent = torch.empty((b, p2 * nn), dtype=torch.int32, device=self.device)
+            _lib.check(lib.epn_inter_inverse_list(_lib.dev_ptr(self.ball_idx, "inter_idx", torch.int32), b, p1, p2, nn,
+                                                  _lib.dev_ptr(off, "offsets", torch.int32),
+                                                  _lib.dev_ptr(ent, "entries", torch.int32), _lib.stream_of(off)),
+                       "inter_inverse_list")
+            self._inverse = (off, ent)
+        return self._inverse
 
     def dense(self):
         """Materialise w[b,p2,na,ks,nn] with the HIP kernel (API compatibility only)."""
@@ -318,8 +335,8 @@ class InterSO3ConvSplitFn(torch.autograd.Function):
         if need_f:
             gf = empty_cl(d.b, cin, d.p1, d.na, G.device)           # fp32: the scatter target of either dtype
             mode = os.environ.get("EPN_INTER_BWD_DATA", "auto")
-            if G.dtype != torch.float32:
-                mode = "split"          # bf16 features: dG GEMM on the bf16 MFMA kernel + scatter
+            if G.dtype != torch.float32 or deterministic_bwd(G.dtype):
+                mode = "split"          # bf16 features / deterministic mode: dG GEMM + (atomic-free) transpose of the grouping
             elif mode == "auto":        # widest layers: dG GEMM + scatter beats the fused kernel (measured)
                 mode = "split" if cin * cout >= 65536 else "fused"
             if mode == "fused" and lib.epn_inter_is_fused(ctypes.byref(d)) and cin >= 16:
@@ -340,6 +357,20 @@ class InterSO3ConvSplitFn(torch.autograd.Function):
                 dG = _launch("inter_gemm", _inter_key(d), gemm_fl, G.device, lambda: gemm.gemm_nt(g2d, Wt))
                 ws, wsp, wsn = _group_workspace(lib, d, G.device)
                 gflops = 9.0 * cols * d.ks * d.nn + 2.0 * cols * cin * d.ks * d.nn
+                if deterministic_bwd(G.dtype) and isinstance(geo, InterGeometry) and d.na >= 16:
+                    # atomic-free: per-slot slab + ordered reduction over the inverse neighbour list (bitwise repeatable;
+                    # for bf16 also faster than the fp32 atomic scatter + conversion at K >= 32)
+                    off, ent = geo.inverse_list()
+                    gf = empty_cl(d.b, cin, d.p1, d.na, G.device, G.dtype)
+                    slab = torch.empty(d.b * d.p2 * d.nn * d.na * cin, dtype=G.dtype, device=G.device)
+                    det = _entry(lib, "inter_ungroup_det", G.dtype)
+                    _lib.check(_launch("inter_ungroup_det", _inter_key(d), gflops, G.device,
+                                       lambda: det(ctypes.byref(d), ctypes.c_void_p(dG.data_ptr()), _cl_ptr(gf),
+                                                   _lib.dev_ptr(off, "offsets", torch.int32),
+                                                   _lib.dev_ptr(ent, "entries", torch.int32),
+                                                   ctypes.c_void_p(slab.data_ptr()), slab.numel() * slab.element_size(),
+                                                   wsp, wsn, _lib.stream_of(G))), "inter_ungroup_det")
+                    return gf, gW, None
                 ungrp = _entry(lib, "inter_ungroup", G.dtype)
                 _lib.check(_launch("inter_ungroup", _inter_key(d), gflops, G.device,
                                    lambda: ungrp(ctypes.byref(d), ctypes.c_void_p(dG.data_ptr()), _cl_ptr(gf), wsp, wsn,
@@ -793,6 +824,16 @@ def norm_act(x, norm, residual=None, slope=0.01, conv_bias=None):
                 norm.running_mean.lerp_(mean, m)
                 norm.running_var.lerp_(var, m)
     return y
+
+
+def deterministic_bwd(dtype):
+    """Atomic-free, bitwise repeatable InterSO3Conv data gradient?  EPN_DETERMINISTIC = 1 | 0 | auto (default): auto =
+    yes for bf16 features (where it is also the faster form), no for fp32 (the fused kernel with its fp32 atomic scatter
+    is ~5 % of a step faster there)."""
+    v = os.environ.get("EPN_DETERMINISTIC", "auto")
+    if v == "auto":
+        return dtype == torch.bfloat16
+    return v == "1"
 
 
 def inter_mode():

@@ -323,6 +323,25 @@ int epn_norm_act_bwd_apply_bf16(const void *x_cl, const void *dy_cl, int groups,
                                 const float *sums, const float *dsums, const float *gamma, const float *beta, float eps,
                                 float slope, void *dx_cl, epn_stream_t stream);
 
+/* ---------------------------------------------------------------------------------------------------------------------
+ * Deterministic (atomic-free) data gradient of the grouping -- the transpose of epn_inter_group_* without the fp32 atomic
+ * scatter of epn_inter_ungroup_* (reference: torch autograd through gather + einsum, whose index_add is itself
+ * non-deterministic on CUDA; SURVEY a17 asked for an atomic-free form):
+ *   1. epn_inter_inverse_list: ball_idx i32[b][p2][nn] -> CSR per cloud, offsets i32[b][p1+1], entries i32[b][p2*nn]
+ *      (entry = p*nn + n with ball_idx[b][p][n] == q, in increasing order) -- once per geometry;
+ *   2. epn_inter_ungroup_det_*: per-slot contributions slab[b][p][n][a][c] = sum_k w * grad_grouped (plain stores;
+ *      slab has the element type of grad_grouped, b*p2*nn*na*cin elements), then grad_feats_cl[b][q][a][c] = the sum
+ *      over q's list in list order (fp32 accumulation; fully overwritten; f32 -> float, bf16 -> bf16 output).
+ * Bitwise repeatable.  Requires cin % 16 == 0 and na >= 16 (the MFMA grouping kernels). */
+int epn_inter_inverse_list(const int32_t *ball_idx, int b, int p1, int p2, int nn, int32_t *offsets, int32_t *entries,
+                           epn_stream_t stream);
+int epn_inter_ungroup_det_f32(const epn_inter_desc *d, const float *grad_grouped, float *grad_feats_cl,
+                              const int32_t *offsets, const int32_t *entries, void *slab, size_t slab_bytes,
+                              void *workspace, size_t workspace_bytes, epn_stream_t stream);
+int epn_inter_ungroup_det_bf16(const epn_inter_desc *d, const void *grad_grouped, void *grad_feats_cl,
+                               const int32_t *offsets, const int32_t *entries, void *slab, size_t slab_bytes,
+                               void *workspace, size_t workspace_bytes, epn_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -208,3 +208,36 @@ def test_config_full_size_bf16(gpu, model, points, batch):
     # 7-8 blocks deep, each rounding its activations to 8 bits: a few percent at the output
     assert abs(l16 - l32) <= 0.1 * abs(l32) + 1e-6
     assert rel_l2(f16, f32) < 0.15
+
+
+@pytest.mark.parametrize("dt", [torch.float32, torch.bfloat16])
+def test_deterministic_data_gradient(gpu, vgtk_alias, dt, monkeypatch):
+    """EPN_DETERMINISTIC=1 (default for bf16): the InterSO3Conv data gradient without atomics -- per-slot slab + ordered
+    reduction over the inverse neighbour list.  Bitwise repeatable, and equal (to rounding) to the atomic-scatter path
+    and to the oracle."""
+    sptk, zptk = _mods(vgtk_alias)
+    rng = np.random.default_rng(77)
+    torch.manual_seed(77)
+    xyz = T(unit_ball_cloud(rng, 3, 160))
+    conv = sptk.InterSO3Conv(32, 48, 1, 2, 0.4, 0.08, 20, lazy_sample=False)
+    conv.basic_conv.W.data = r16(conv.basic_conv.W.data)
+    feats = r16(torch.randn(3, 32, 160, 60))
+    fo = feats.clone().requires_grad_(True)
+    _, _, _, _, oy = R.inter_so3conv(xyz, fo, conv.basic_conv.W.detach().clone(), conv.anchors, conv.kernels, 2, 0.4, 0.08,
+                                     20, False)
+    gy = r16(torch.randn_like(oy))
+    (odF,) = torch.autograd.grad(oy, [fo], gy)
+    conv = conv.to(gpu)
+
+    def run(det):
+        monkeypatch.setenv("EPN_DETERMINISTIC", det)
+        fg = feats.to(gpu).to(dt).requires_grad_(True)
+        _, _, _, y = conv(zptk.SphericalPointCloud(xyz.to(gpu), fg, None))
+        (dF,) = torch.autograd.grad(y.feats, [fg], gy.to(gpu).to(dt))
+        return dF
+
+    d1, d2, d0 = run("1"), run("1"), run("0")
+    assert torch.equal(d1, d2)                                   # bitwise repeatable
+    tol = 1e-3 if dt == torch.float32 else BF16_TOL * odF.abs().max().item()
+    assert (d1.float().cpu() - odF).abs().max().item() < tol     # vs the oracle
+    assert (d1.float() - d0.float()).abs().max().item() < tol     # vs the atomic scatter

@@ -31,7 +31,7 @@ def main():
     a = ap.parse_args()
     if a.cfg:
         from epn_pointcloud_amd import _lib
-        _lib.check(_lib.get_lib().epn_set_kernel_policy(0x100 | a.cfg), "set_kernel_policy")
+        _lib.check(_lib.get_lib().epn_set_kernel_policy(a.cfg if a.cfg >= 0x100 else 0x100 | a.cfg), "set_kernel_policy")
     dt = torch.float32 if a.dtype == "f32" else torch.bfloat16
     dev = torch.device("cuda:0")
     torch.manual_seed(0)
