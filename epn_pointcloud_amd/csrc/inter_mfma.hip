@@ -1429,8 +1429,11 @@ int launch_inter_ungroup_det_mfma(const epn_inter_desc *d, const float *rk4, con
     InterArgs A = make_args(d, rk4);
     A.gout = static_cast<const float *>(dG); A.out = static_cast<float *>(slab);
     const unsigned grid = (unsigned)((A.ncol + 16 * NW - 1) / (16 * NW));
-    A.col_tiles_per_wg = 1;
-    const unsigned gy = (unsigned)(d->cin >> 4);
+    // every wave walks ALL 16-channel chunks of its 16 columns: the [16 anchors][cin] block of a slot is then written by
+    // one wave within a few hundred cycles and leaves L2 as whole lines (chunk-major launch order, which the gather
+    // kernels use for their reads, writes each 128-byte line in 32/64-byte pieces seconds apart: 2x slower, measured)
+    A.col_tiles_per_wg = d->cin >> 4;
+    const unsigned gy = 1;
 #define EPN_USLOT(NT_, KT_, dummy)                                                                                       \
     do {                                                                                                                 \
         if (bf16) hipLaunchKernelGGL((inter_ungroup_slots_kernel<NT_, KT_, __bf16>), dim3(grid, gy), dim3(64 * NW), 0, st, A); \

@@ -212,7 +212,7 @@ def test_config_full_size_bf16(gpu, model, points, batch):
 
 @pytest.mark.parametrize("dt", [torch.float32, torch.bfloat16])
 def test_deterministic_data_gradient(gpu, vgtk_alias, dt, monkeypatch):
-    """EPN_DETERMINISTIC=1 (default for bf16): the InterSO3Conv data gradient without atomics -- per-slot slab + ordered
+    """EPN_DETERMINISTIC=1: the InterSO3Conv data gradient without atomics -- per-slot slab + ordered
     reduction over the inverse neighbour list.  Bitwise repeatable, and equal (to rounding) to the atomic-scatter path
     and to the oracle."""
     sptk, zptk = _mods(vgtk_alias)
