@@ -300,14 +300,32 @@ def main():
 
     if rank == 0:
         # ---- roofline of the dominant kernel, from HIP events recorded around its launches
+        esz = 4 if dtype_name == "f32" else 2
+
+        def algo_bytes(kind, key):
+            """Algorithmic HBM bytes of the memory-bound families: operands read once + result
+            written once; the keys carry the layer dimensions."""
+            if kind in ("inter_group", "inter_ungroup", "inter_ungroup_det"):
+                b_, p1, p2, nn_, na, ks, cin, _ = key
+                feats, grouped = b_ * p1 * na * cin, b_ * p2 * na * cin * ks
+                return feats * (esz if kind == "inter_group" else 4) + grouped * esz
+            if kind == "intra_group":
+                b_, p_, na, kn, c = key[:5]
+                return b_ * p_ * na * c * esz * (1 + kn)
+            if kind == "so3_basis":
+                _, pts, c = key
+                return 2 * pts * 60 * c * esz
+            return 0
+
         agg = {}
         for kind, key, flops, e0, e1 in records:
             k = KERNEL_OF.get(kind, kind)
             if kind.startswith("inter") and len(key) > 6 and key[6] == 1:      # cin = 1 (first layer): dedicated kernels
                 k = {"inter_fwd": "epn::inter_c1_fwd_kernel", "inter_bwd_weight": "epn::inter_c1_bwd_weight_kernel"}.get(kind, k)
-            a = agg.setdefault(k, {"ms": 0.0, "flops": 0.0, "launches": 0})
+            a = agg.setdefault(k, {"ms": 0.0, "flops": 0.0, "launches": 0, "bytes": 0.0})
             a["ms"] += e0.elapsed_time(e1)
             a["flops"] += flops
+            a["bytes"] += algo_bytes(kind, key)
             a["launches"] += 1
         peak = PEAK_TFLOPS[dtype_name]
 
@@ -319,8 +337,24 @@ def main():
                     "traffic": recorded_traffic(k) if (args.model == "cls" and args.batch == 32 and dtype_name == "f32") else None,
                     "launches": d["launches"], "avg_launch_ms": round(d["ms"] / d["launches"], 4)}
 
+        def roof_hbm(k):
+            d = agg[k]
+            ach = d["bytes"] / (d["ms"] * 1e-3) / 1e9
+            return {"bound": "hbm", "kernel": k, "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                    "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": None, "launches": d["launches"],
+                    "avg_launch_ms": round(d["ms"] / d["launches"], 4),
+                    "algorithmic_bytes_per_launch": round(d["bytes"] / d["launches"])}
+
         dom = max(agg, key=lambda k: agg[k]["ms"])
-        roofline = roof(dom)
+        mem = [k for k in agg if agg[k]["bytes"] > 0]
+        dom_mem = max(mem, key=lambda k: agg[k]["ms"]) if mem else None
+        roofline = roof_hbm(dom) if agg[dom]["bytes"] > 0 else roof(dom)
+        if dom_mem is not None and dom_mem != dom:
+            roofline["dominant_memory_bound_kernel"] = roof_hbm(dom_mem)
+        if agg[dom]["bytes"] > 0:
+            gem = max((k for k in agg if "gemm" in k), key=lambda k: agg[k]["ms"], default=None)
+            if gem:
+                roofline["dominant_mfma_kernel"] = roof(gem)
         roofline["traffic_note"] = ("HBM bytes/launch (avg over the family's launches) from the committed rocprofv3 "
                                     "--pmc passes, profiles/r02_pmc_per_kernel.json")
         roofline["per_kernel_ms_per_step"] = {k: round(v["ms"] / prof_steps, 3) for k, v in sorted(agg.items())}

@@ -24,9 +24,9 @@ EXPORTS = [
     "epn_anchor_query_f32", "epn_zp_inter_fwd_f32", "epn_zp_inter_bwd_f32", "epn_zp_intra_fwd_f32", "epn_zp_intra_bwd_f32",
     "epn_pointnet_so3conv_fwd_f32", "epn_pointnet_so3conv_bwd_data_f32", "epn_pointnet_so3conv_bwd_weight_f32",
     "epn_gemm_nt_f32", "epn_gemm_nt_bf16", "epn_gemm_tn_workspace_bytes", "epn_gemm_tn_f32", "epn_gemm_tn_bf16",
-    "epn_transpose_cast", "epn_cast",
+    "epn_transpose_cast", "epn_cast", "epn_gemm_tn_grouped_workspace_bytes", "epn_gemm_tn_grouped",
     "epn_inter_group_bf16", "epn_inter_ungroup_bf16", "epn_intra_group_bf16", "epn_so3_basis_bf16",
-    "epn_inter_inverse_list", "epn_inter_ungroup_det_f32", "epn_inter_ungroup_det_bf16",
+    "epn_gather_rows", "epn_scatter_rows", "epn_inter_inverse_list", "epn_inter_ungroup_det_f32", "epn_inter_ungroup_det_bf16",
     "epn_chan_stats_bf16", "epn_norm_act_fwd_bf16", "epn_norm_act_bwd_reduce_bf16", "epn_norm_act_bwd_apply_bf16",
 ]
 
@@ -44,6 +44,12 @@ class GemmNtProblem(ctypes.Structure):
     """struct epn_gemm_nt_problem (include/epn_so3conv.h)."""
     _fields_ = [("A", _vp), ("Bt", _vp), ("C", _vp), ("M", ctypes.c_longlong), ("lda", ctypes.c_longlong),
                 ("ldb", ctypes.c_longlong), ("ldc", ctypes.c_longlong), ("N", _ci), ("K", _ci)]
+
+
+class GemmTnProblem(ctypes.Structure):
+    """struct epn_gemm_tn_problem (include/epn_so3conv.h)."""
+    _fields_ = [("X", _vp), ("Y", _vp), ("C", _vp), ("R", ctypes.c_longlong), ("ldx", ctypes.c_longlong),
+                ("ldy", ctypes.c_longlong), ("ldc", ctypes.c_longlong), ("N1", _ci), ("N2", _ci)]
 
 
 _lib = None
@@ -110,9 +116,17 @@ def get_lib():
     lib.epn_gemm_tn_workspace_bytes.argtypes = [_ci, _ll, _ci, _ci]
     lib.epn_gemm_tn_f32.argtypes = [_vp, _ll, _vp, _ll, _vp, _ll, _ll, _ci, _ci, _vp, _sz, _vp]
     lib.epn_gemm_tn_bf16.argtypes = [_vp, _ll, _vp, _ll, _vp, _ll, _ll, _ci, _ci, _vp, _sz, _vp]
+    tp = ctypes.POINTER(GemmTnProblem)
+    lib.epn_gemm_tn_grouped_workspace_bytes.argtypes = [_ci, _ci, tp]
+    lib.epn_gemm_tn_grouped_workspace_bytes.restype = _sz
+    lib.epn_gemm_tn_grouped.argtypes = [_ci, _ci, tp, _vp, _sz, _vp]
+    lib.epn_gemm_tn_grouped.restype = _ci
     lib.epn_transpose_cast.argtypes = [_vp, _vp, _ci, _ci, _ci, _ci, _vp]
     lib.epn_cast.argtypes = [_vp, _vp, _sz, _ci, _ci, _vp]
     # the bf16 twins share their fp32 counterparts' signatures (void* feature pointers)
+    lib.epn_gather_rows.argtypes = [_vp, _vp, _vp, _ci, _ci, _ci, _ll, _vp]
+    lib.epn_scatter_rows.argtypes = [_vp, _vp, _vp, _ci, _ci, _ci, _ll, _vp]
+    lib.epn_gather_rows.restype = lib.epn_scatter_rows.restype = _ci
     lib.epn_inter_inverse_list.argtypes = [_vp, _ci, _ci, _ci, _ci, _vp, _vp, _vp]
     lib.epn_inter_inverse_list.restype = _ci
     lib.epn_inter_ungroup_det_f32.argtypes = [dp, _vp, _vp, _vp, _vp, _vp, _sz, _vp, _sz, _vp]

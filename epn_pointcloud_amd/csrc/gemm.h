@@ -28,6 +28,12 @@ struct GemmTnArgs {        // C[N1][N2] = X[R][N1]^T . Y[R][N2]
     int N1, N2;
     unsigned ntiles;
     int tiles_n2, nsplit;
+    unsigned block0;       // first workgroup of this problem inside a grouped launch
+};
+struct GemmTnBatch {       // up to GEMM_MAX_PROB problems in ONE launch (the irreducible blocks of a spectral IntraSO3Conv)
+    int nprob;
+    unsigned nblocks;
+    GemmTnArgs p[GEMM_MAX_PROB];
 };
 
 int kernel_policy();   // c_api.hip: epn_set_kernel_policy (0x100 | cfg = NT tile override of the tuning tool)
@@ -35,6 +41,9 @@ int kernel_policy();   // c_api.hip: epn_set_kernel_policy (0x100 | cfg = NT til
 // dtype / out_dtype: 0 = fp32, 1 = bf16
 int launch_gemm_nt(GemmNtBatch &B, int dtype, int out_dtype, hipStream_t st);
 int launch_gemm_tn(GemmTnArgs &G, int dtype, hipStream_t st);
+// grouped: plans tiles / splits for all problems (balanced K steps per workgroup), carves `ws` into the partial slabs
+int launch_gemm_tn_batch(GemmTnBatch &B, int dtype, void *ws, size_t ws_bytes, hipStream_t st);
+size_t gemm_tn_batch_workspace(GemmTnBatch &B, int dtype);
 void gemm_tn_tile(bool bf16, int N1, int N2, int *bn1, int *bn2);
 int gemm_tn_splits(bool bf16, long long R, int N1, int N2);
 int launch_transpose_cast(const void *src, void *dst, int rows, int cols, int src_bf16, int dst_bf16, hipStream_t st);

@@ -212,7 +212,7 @@ struct TnGeom {
 };
 
 template <int WGM, int WGN, int TM, int TN, int BR>
-__global__ __launch_bounds__(64 * WGM * WGN) void gemm_tn_f32_kernel(GemmTnArgs G) {
+__global__ __launch_bounds__(64 * WGM * WGN) void gemm_tn_f32_kernel(GemmTnBatch B) {
     constexpr int NW = WGM * WGN;
     constexpr int BN1 = WGM * TM * 32, BN2 = WGN * TN * 32;
     constexpr int ROWF = BN1 + BN2;                 // floats per staged row (X part, then Y part)
@@ -224,7 +224,13 @@ __global__ __launch_bounds__(64 * WGM * WGN) void gemm_tn_f32_kernel(GemmTnArgs 
 
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const unsigned tile = blockIdx.x % G.ntiles, split = blockIdx.x / G.ntiles;
+    int pi = 0;
+#pragma unroll
+    for (int i = 1; i < GEMM_MAX_PROB; ++i)
+        if (i < B.nprob && blockIdx.x >= B.p[i].block0) pi = i;
+    const GemmTnArgs &G = B.p[pi];
+    const unsigned lb = blockIdx.x - G.block0;
+    const unsigned tile = lb % G.ntiles, split = lb / G.ntiles;
     const int n1_0 = (int)(tile / G.tiles_n2) * BN1, n2_0 = (int)(tile % G.tiles_n2) * BN2;
     const long long nchunk = G.R / BR;
     const long long c0 = nchunk * split / G.nsplit, c1 = nchunk * (split + 1) / G.nsplit;
@@ -353,7 +359,7 @@ __global__ __launch_bounds__(64 * WGM * WGN) void gemm_tn_f32_kernel(GemmTnArgs 
 // 16-lane group reads a [4 rows][16 columns] block and receives it column-per-lane: lane i gets rows 0..3 of column i).
 // Wave tile = (TM*16) x (TN*16); stage = 32 rows (= one MFMA contraction step) of [BN1 + BN2] bf16.
 template <int WGM, int WGN, int TM, int TN>
-__global__ __launch_bounds__(64 * WGM * WGN) void gemm_tn_bf16_kernel(GemmTnArgs G) {
+__global__ __launch_bounds__(64 * WGM * WGN) void gemm_tn_bf16_kernel(GemmTnBatch B) {
     constexpr int NW = WGM * WGN;
     constexpr int BR = 32;
     constexpr int BN1 = WGM * TM * 16, BN2 = WGN * TN * 16;
@@ -366,7 +372,13 @@ __global__ __launch_bounds__(64 * WGM * WGN) void gemm_tn_bf16_kernel(GemmTnArgs
 
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const unsigned tile = blockIdx.x % G.ntiles, split = blockIdx.x / G.ntiles;
+    int pi = 0;
+#pragma unroll
+    for (int i = 1; i < GEMM_MAX_PROB; ++i)
+        if (i < B.nprob && blockIdx.x >= B.p[i].block0) pi = i;
+    const GemmTnArgs &G = B.p[pi];
+    const unsigned lb = blockIdx.x - G.block0;
+    const unsigned tile = lb % G.ntiles, split = lb / G.ntiles;
     const int n1_0 = (int)(tile / G.tiles_n2) * BN1, n2_0 = (int)(tile % G.tiles_n2) * BN2;
     const long long nchunk = G.R / BR;
     const long long c0 = nchunk * split / G.nsplit, c1 = nchunk * (split + 1) / G.nsplit;
@@ -473,13 +485,16 @@ __global__ __launch_bounds__(64 * WGM * WGN) void gemm_tn_bf16_kernel(GemmTnArgs
 }
 
 // sum the split partials in a fixed order (deterministic): C[i] = sum_s part[s][i]
-__global__ void gemm_tn_reduce_kernel(const float *__restrict__ part, float *__restrict__ C, int N1, int N2,
-                                      long long ldc, int nsplit) {
-    const size_t n = (size_t)N1 * N2;
+__global__ void gemm_tn_reduce_kernel(GemmTnBatch B) {      // blockIdx.y = problem
+    const GemmTnArgs &G = B.p[blockIdx.y];
+    if (G.nsplit <= 1) return;
+    const float *__restrict__ part = static_cast<const float *>(G.part);
+    float *__restrict__ C = static_cast<float *>(G.C);
+    const size_t n = (size_t)G.N1 * G.N2;
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
         float s = 0.f;
-        for (int k = 0; k < nsplit; ++k) s += part[(size_t)k * n + i];
-        C[(i / N2) * ldc + (i % N2)] = s;
+        for (int k = 0; k < G.nsplit; ++k) s += part[(size_t)k * n + i];
+        C[(i / G.N2) * G.ldc + (i % G.N2)] = s;
     }
 }
 
@@ -596,47 +611,114 @@ int launch_nt_typed(GemmNtBatch &B, hipStream_t st) {
 }
 
 template <typename T>
-int launch_tn_typed(GemmTnArgs &G, hipStream_t st) {
-    if (G.R < 0 || G.N1 < 1 || G.N2 < 1) return EPN_EINVAL;
-    if (!G.C) return EPN_ENULL;
+bool tn_fast_ok(const GemmTnArgs &G) {
     constexpr int E16 = ElemOf<T>::PER16;
-    const int BR = 32;
-    const bool fast = G.R > 0 && G.R % BR == 0 && G.N1 >= E16 && G.N2 >= E16 && G.ldx % E16 == 0 && G.ldy % E16 == 0 &&
-                      !((uintptr_t)G.X & 15) && !((uintptr_t)G.Y & 15) && G.N1 % E16 == 0 && G.N2 % E16 == 0;
-    if (!fast) {
+    return G.R > 0 && G.R % 32 == 0 && G.N1 >= E16 && G.N2 >= E16 && G.ldx % E16 == 0 && G.ldy % E16 == 0 &&
+           !((uintptr_t)G.X & 15) && !((uintptr_t)G.Y & 15) && G.N1 % E16 == 0 && G.N2 % E16 == 0;
+}
+
+// Plan of a (grouped) TN launch: one block tile for all problems; splits so that every workgroup runs about the same
+// number of K steps and the launch has ~2048 workgroups (single problem) / ~1024 (group); partial slabs carved from `ws`.
+template <typename T>
+size_t tn_plan(GemmTnBatch &B, int *bn1_out, int *bn2_out, void *ws) {
+    const bool bf = sizeof(T) == 2;
+    int max1 = 0, min2 = 1 << 30;
+    for (int i = 0; i < B.nprob; ++i) {
+        max1 = B.p[i].N1 > max1 ? B.p[i].N1 : max1;
+        min2 = B.p[i].N2 < min2 ? B.p[i].N2 : min2;
+    }
+    int bn1, bn2;
+    gemm_tn_tile(bf, max1, min2, &bn1, &bn2);
+    *bn1_out = bn1; *bn2_out = bn2;
+    long long tiles[GEMM_MAX_PROB], chunks[GEMM_MAX_PROB];
+    for (int i = 0; i < B.nprob; ++i) {
+        GemmTnArgs &G = B.p[i];
+        G.tiles_n2 = (G.N2 + bn2 - 1) / bn2;
+        G.ntiles = (unsigned)((G.N1 + bn1 - 1) / bn1) * G.tiles_n2;
+        tiles[i] = G.ntiles;
+        chunks[i] = G.R / 32;
+    }
+    if (B.nprob == 1) {
+        B.p[0].nsplit = gemm_tn_splits(bf, B.p[0].R, B.p[0].N1, B.p[0].N2);
+    } else {
+        // largest steps-per-workgroup S (>= 8) that still yields >= 1024 workgroups; every problem gets ceil(chunks / S) splits
+        long long S = 8;
+        for (long long cand = 4096; cand >= 8; cand >>= 1) {
+            long long blocks = 0;
+            for (int i = 0; i < B.nprob; ++i) blocks += tiles[i] * ((chunks[i] + cand - 1) / cand);
+            if (blocks >= 1024) { S = cand; break; }
+        }
+        for (int i = 0; i < B.nprob; ++i) {
+            long long sp = (chunks[i] + S - 1) / S;
+            sp = sp < 1 ? 1 : (sp > 512 ? 512 : sp);
+            B.p[i].nsplit = (int)sp;
+        }
+    }
+    size_t off = 0;
+    unsigned blk = 0;
+    for (int i = 0; i < B.nprob; ++i) {
+        GemmTnArgs &G = B.p[i];
+        G.block0 = blk;
+        blk += G.ntiles * (unsigned)G.nsplit;
+        G.part = nullptr; G.part_bytes = 0;
+        if (G.nsplit > 1) {
+            const size_t nb = (size_t)G.nsplit * G.N1 * G.N2 * sizeof(float);
+            if (ws) G.part = static_cast<char *>(ws) + off;
+            G.part_bytes = nb;
+            off += (nb + 255) & ~(size_t)255;
+        }
+    }
+    B.nblocks = blk;
+    return off;
+}
+
+template <typename T>
+int launch_tn_typed(GemmTnBatch &B, void *ws, size_t ws_bytes, hipStream_t st) {
+    bool fast = true;
+    for (int i = 0; i < B.nprob; ++i) {
+        const GemmTnArgs &G = B.p[i];
+        if (G.R < 0 || G.N1 < 1 || G.N2 < 1) return EPN_EINVAL;
+        if (!G.C) return EPN_ENULL;
         if (G.R > 0 && (!G.X || !G.Y)) return EPN_ENULL;
-        const long long n = (long long)G.N1 * G.N2;
-        hipLaunchKernelGGL((gemm_tn_generic_kernel<T>), dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st,
-                           static_cast<const T *>(G.X), static_cast<const T *>(G.Y), static_cast<float *>(G.C), G.R, G.N1,
-                           G.N2, G.ldx, G.ldy, G.ldc);
-        EPN_CHECK_LAUNCH();
+        fast = fast && tn_fast_ok<T>(G);
+    }
+    if (!fast) {
+        for (int i = 0; i < B.nprob; ++i) {
+            const GemmTnArgs &G = B.p[i];
+            const long long n = (long long)G.N1 * G.N2;
+            hipLaunchKernelGGL((gemm_tn_generic_kernel<T>), dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st,
+                               static_cast<const T *>(G.X), static_cast<const T *>(G.Y), static_cast<float *>(G.C), G.R,
+                               G.N1, G.N2, G.ldx, G.ldy, G.ldc);
+            EPN_CHECK_LAUNCH();
+        }
         return 0;
     }
-    if (!G.X || !G.Y) return EPN_ENULL;
     int bn1, bn2;
-    gemm_tn_tile(sizeof(T) == 2, G.N1, G.N2, &bn1, &bn2);
-    G.tiles_n2 = (G.N2 + bn2 - 1) / bn2;
-    G.ntiles = (unsigned)((G.N1 + bn1 - 1) / bn1) * G.tiles_n2;
-    G.nsplit = gemm_tn_splits(sizeof(T) == 2, G.R, G.N1, G.N2);
-    if (G.nsplit > 1 && (!G.part || G.part_bytes < (size_t)G.nsplit * G.N1 * G.N2 * sizeof(float))) return EPN_EWORKSPACE;
-    const dim3 grid(G.ntiles * G.nsplit);
+    const size_t need = tn_plan<T>(B, &bn1, &bn2, ws);
+    if (need > 0 && (!ws || ws_bytes < need)) return EPN_EWORKSPACE;
+    const dim3 grid(B.nblocks);
     if constexpr (sizeof(T) == 4) {
-        if (bn1 == 32) hipLaunchKernelGGL((gemm_tn_f32_kernel<1, 8, 1, 2, 32>), grid, dim3(512), 0, st, G);
-        else if (bn1 == 64 && bn2 == 512) hipLaunchKernelGGL((gemm_tn_f32_kernel<1, 4, 2, 4, 16>), grid, dim3(256), 0, st, G);
-        else if (bn1 == 64) hipLaunchKernelGGL((gemm_tn_f32_kernel<1, 8, 2, 1, 32>), grid, dim3(512), 0, st, G);
-        else if (bn2 == 512) hipLaunchKernelGGL((gemm_tn_f32_kernel<1, 8, 4, 2, 32>), grid, dim3(512), 0, st, G);
-        else hipLaunchKernelGGL((gemm_tn_f32_kernel<2, 4, 2, 2, 32>), grid, dim3(512), 0, st, G);
+        if (bn1 == 32) hipLaunchKernelGGL((gemm_tn_f32_kernel<1, 8, 1, 2, 32>), grid, dim3(512), 0, st, B);
+        else if (bn1 == 64 && bn2 == 512) hipLaunchKernelGGL((gemm_tn_f32_kernel<1, 4, 2, 4, 16>), grid, dim3(256), 0, st, B);
+        else if (bn1 == 64) hipLaunchKernelGGL((gemm_tn_f32_kernel<1, 8, 2, 1, 32>), grid, dim3(512), 0, st, B);
+        else if (bn2 == 512) hipLaunchKernelGGL((gemm_tn_f32_kernel<1, 8, 4, 2, 32>), grid, dim3(512), 0, st, B);
+        else hipLaunchKernelGGL((gemm_tn_f32_kernel<2, 4, 2, 2, 32>), grid, dim3(512), 0, st, B);
     } else {
-        if (bn1 == 32) hipLaunchKernelGGL((gemm_tn_bf16_kernel<1, 8, 2, 2>), grid, dim3(512), 0, st, G);
-        else if (bn1 == 64) hipLaunchKernelGGL((gemm_tn_bf16_kernel<1, 8, 4, 2>), grid, dim3(512), 0, st, G);
-        else hipLaunchKernelGGL((gemm_tn_bf16_kernel<2, 4, 4, 4>), grid, dim3(512), 0, st, G);
+        if (bn1 == 32) hipLaunchKernelGGL((gemm_tn_bf16_kernel<1, 8, 2, 2>), grid, dim3(512), 0, st, B);
+        else if (bn1 == 64) hipLaunchKernelGGL((gemm_tn_bf16_kernel<1, 8, 4, 2>), grid, dim3(512), 0, st, B);
+        else hipLaunchKernelGGL((gemm_tn_bf16_kernel<2, 4, 4, 4>), grid, dim3(512), 0, st, B);
     }
     EPN_CHECK_LAUNCH();
-    if (G.nsplit > 1) {
-        const size_t n = (size_t)G.N1 * G.N2;
-        hipLaunchKernelGGL(gemm_tn_reduce_kernel, dim3((unsigned)((n + 255) / 256 < 2048 ? (n + 255) / 256 : 2048)),
-                           dim3(256), 0, st, static_cast<const float *>(G.part), static_cast<float *>(G.C), G.N1, G.N2,
-                           G.ldc, G.nsplit);
+    bool any_split = false;
+    size_t nmax = 0;
+    for (int i = 0; i < B.nprob; ++i) {
+        any_split = any_split || B.p[i].nsplit > 1;
+        const size_t n = (size_t)B.p[i].N1 * B.p[i].N2;
+        nmax = n > nmax ? n : nmax;
+    }
+    if (any_split) {
+        const unsigned gx = (unsigned)((nmax + 255) / 256 < 1024 ? (nmax + 255) / 256 : 1024);
+        hipLaunchKernelGGL(gemm_tn_reduce_kernel, dim3(gx, B.nprob), dim3(256), 0, st, B);
         EPN_CHECK_LAUNCH();
     }
     return 0;
@@ -670,7 +752,9 @@ int gemm_tn_splits(bool bf16, long long R, int N1, int N2) {
     // 91 / 106 / 118 / 120 TFLOP/s (short row ranges spread evenly over the XCDs; the fp32 partial slabs and their
     // fixed-order reduction are included in those times)
     long long s = (target + tiles - 1) / tiles;
-    const long long smax = chunks / 8 > 1 ? chunks / 8 : 1;   // at least 8 K steps per split
+    // at least 32 K steps per split: a split ends in an N1 x N2 fp32 slab write (+ its share of the reduction), which
+    // for the short-and-wide problems (spectral blocks: R = pts*d rows, up to 1280 x 1280 outputs) outweighs 8 steps of loads
+    const long long smax = chunks / 32 > 1 ? chunks / 32 : 1;
     if (s > smax) s = smax;
     if (s > 512) s = 512;
     return (int)(s < 1 ? 1 : s);
@@ -684,8 +768,22 @@ int launch_gemm_nt(GemmNtBatch &B, int dtype, int out_dtype, hipStream_t st) {
     return EPN_EINVAL;
 }
 
+int launch_gemm_tn_batch(GemmTnBatch &B, int dtype, void *ws, size_t ws_bytes, hipStream_t st) {
+    if (B.nprob < 1 || B.nprob > GEMM_MAX_PROB) return EPN_EINVAL;
+    return dtype == 0 ? launch_tn_typed<float>(B, ws, ws_bytes, st) : launch_tn_typed<__bf16>(B, ws, ws_bytes, st);
+}
+
+size_t gemm_tn_batch_workspace(GemmTnBatch &B, int dtype) {
+    int bn1, bn2;
+    for (int i = 0; i < B.nprob; ++i)
+        if (B.p[i].R < 32 || B.p[i].N1 < 1 || B.p[i].N2 < 1) return 0;
+    return dtype == 0 ? tn_plan<float>(B, &bn1, &bn2, nullptr) : tn_plan<__bf16>(B, &bn1, &bn2, nullptr);
+}
+
 int launch_gemm_tn(GemmTnArgs &G, int dtype, hipStream_t st) {
-    return dtype == 0 ? launch_tn_typed<float>(G, st) : launch_tn_typed<__bf16>(G, st);
+    GemmTnBatch B;
+    B.nprob = 1; B.nblocks = 0; B.p[0] = G;
+    return launch_gemm_tn_batch(B, dtype, G.part, G.part_bytes, st);
 }
 
 int launch_transpose_cast(const void *src, void *dst, int rows, int cols, int src_bf16, int dst_bf16, hipStream_t st) {
@@ -748,14 +846,14 @@ extern "C" int epn_gemm_nt_bf16(int nprob, const epn_gemm_nt_problem *probs, int
 extern "C" size_t epn_gemm_tn_workspace_bytes(int bf16, long long R, int N1, int N2) {
     if (R < 1 || N1 < 1 || N2 < 1) return 0;
     const int s = gemm_tn_splits(bf16 != 0, R, N1, N2);
-    return s > 1 ? (size_t)s * N1 * N2 * sizeof(float) : 0;
+    return s > 1 ? (((size_t)s * N1 * N2 * sizeof(float) + 255) & ~(size_t)255) : 0;
 }
 
 static int tn_entry(const void *X, long long ldx, const void *Y, long long ldy, float *C, long long ldc, long long R, int N1,
                     int N2, void *ws, size_t ws_bytes, int dtype, epn_stream_t stream) {
     GemmTnArgs G;
     G.X = X; G.Y = Y; G.C = C; G.part = ws; G.part_bytes = ws_bytes; G.R = R; G.N1 = N1; G.N2 = N2;
-    G.ldx = ldx; G.ldy = ldy; G.ldc = ldc; G.ntiles = 0; G.tiles_n2 = 0; G.nsplit = 1;
+    G.ldx = ldx; G.ldy = ldy; G.ldc = ldc; G.ntiles = 0; G.tiles_n2 = 0; G.nsplit = 1; G.block0 = 0;
     return launch_gemm_tn(G, dtype, epn_stream(stream));
 }
 extern "C" int epn_gemm_tn_f32(const float *X, long long ldx, const float *Y, long long ldy, float *C, long long ldc,
@@ -765,6 +863,30 @@ extern "C" int epn_gemm_tn_f32(const float *X, long long ldx, const float *Y, lo
 extern "C" int epn_gemm_tn_bf16(const void *X, long long ldx, const void *Y, long long ldy, float *C, long long ldc,
                                 long long R, int N1, int N2, void *workspace, size_t workspace_bytes, epn_stream_t stream) {
     return tn_entry(X, ldx, Y, ldy, C, ldc, R, N1, N2, workspace, workspace_bytes, 1, stream);
+}
+
+static void tn_fill(GemmTnBatch &B, int nprob, const epn_gemm_tn_problem *probs) {
+    B.nprob = nprob; B.nblocks = 0;
+    for (int i = 0; i < nprob; ++i) {
+        GemmTnArgs &G = B.p[i];
+        const epn_gemm_tn_problem &q = probs[i];
+        G.X = q.X; G.Y = q.Y; G.C = q.C; G.part = nullptr; G.part_bytes = 0; G.R = q.R; G.N1 = q.N1; G.N2 = q.N2;
+        G.ldx = q.ldx; G.ldy = q.ldy; G.ldc = q.ldc; G.ntiles = 0; G.tiles_n2 = 0; G.nsplit = 1; G.block0 = 0;
+    }
+}
+extern "C" size_t epn_gemm_tn_grouped_workspace_bytes(int bf16, int nprob, const epn_gemm_tn_problem *probs) {
+    if (!probs || nprob < 1 || nprob > GEMM_MAX_PROB) return 0;
+    GemmTnBatch B;
+    tn_fill(B, nprob, probs);
+    return gemm_tn_batch_workspace(B, bf16 ? 1 : 0);
+}
+extern "C" int epn_gemm_tn_grouped(int bf16, int nprob, const epn_gemm_tn_problem *probs, void *workspace,
+                                   size_t workspace_bytes, epn_stream_t stream) {
+    if (!probs) return EPN_ENULL;
+    if (nprob < 1 || nprob > GEMM_MAX_PROB) return EPN_EINVAL;
+    GemmTnBatch B;
+    tn_fill(B, nprob, probs);
+    return launch_gemm_tn_batch(B, bf16 ? 1 : 0, workspace, workspace_bytes, epn_stream(stream));
 }
 
 extern "C" int epn_transpose_cast(const void *src, void *dst, int rows, int cols, int src_bf16, int dst_bf16,

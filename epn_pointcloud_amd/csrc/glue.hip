@@ -469,3 +469,56 @@ extern "C" int epn_intra_group_f32(const float *feats_cl, const int32_t *intra_i
     EPN_CHECK_LAUNCH();
     return 0;
 }
+
+// ---- strided skip connection: batched_index_select(skip, 2, sample_idx) (SPConvNets/utils/base_so3conv.py:206-207,
+// vgtk/vgtk/spconv/functional.py:361-369) on channels-last data = a gather of whole rows [a][c] (rowlen bytes each);
+// its autograd backward = the scatter of those rows into a zeroed tensor (FPS indices are distinct: plain stores).
+// One 16-byte element per thread, consecutive threads walk one row: both sides coalesced.
+namespace epn {
+namespace {
+__global__ __launch_bounds__(256) void rows_gather_kernel(const f32x4 *__restrict__ src, const int32_t *__restrict__ idx,
+                                                          f32x4 *__restrict__ dst, long long nelem, int p1, int p2,
+                                                          int row16, int scatter) {
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= nelem) return;
+    const int e = (int)(i % row16);
+    const long long r = i / row16;            // b*p2 + p
+    const long long b = r / p2;
+    const int q = idx[r];
+    if (q < 0 || q >= p1) return;
+    const long long s = (b * p1 + q) * row16 + e;
+    if (scatter) dst[s] = src[i];
+    else dst[i] = src[s];
+}
+}  // namespace
+}  // namespace epn
+
+// src [b][p1][row_bytes], idx i32[b][p2] -> dst [b][p2][row_bytes] (row_bytes % 16 == 0; any element type)
+extern "C" int epn_gather_rows(const void *src, const int32_t *idx, void *dst, int b, int p1, int p2, long long row_bytes,
+                               epn_stream_t stream) {
+    if (b < 0 || p1 < 1 || p2 < 0 || row_bytes < 16 || row_bytes % 16) return EPN_EINVAL;
+    const long long n = (long long)b * p2 * (row_bytes / 16);
+    if (n == 0) return 0;
+    if (!src || !idx || !dst) return EPN_ENULL;
+    hipLaunchKernelGGL(epn::rows_gather_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, epn_stream(stream),
+                       static_cast<const f32x4 *>(src), idx, static_cast<f32x4 *>(dst), n, p1, p2, (int)(row_bytes / 16), 0);
+    EPN_CHECK_LAUNCH();
+    return 0;
+}
+
+// transpose: grad_dst [b][p2][row_bytes] -> grad_src [b][p1][row_bytes], zero-filled here; idx must be distinct per cloud
+extern "C" int epn_scatter_rows(const void *grad_dst, const int32_t *idx, void *grad_src, int b, int p1, int p2,
+                                long long row_bytes, epn_stream_t stream) {
+    if (b < 0 || p1 < 1 || p2 < 0 || row_bytes < 16 || row_bytes % 16) return EPN_EINVAL;
+    if (!grad_src) return EPN_ENULL;
+    hipStream_t st = epn_stream(stream);
+    EPN_HIP(hipMemsetAsync(grad_src, 0, (size_t)b * p1 * row_bytes, st));
+    const long long n = (long long)b * p2 * (row_bytes / 16);
+    if (n == 0) return 0;
+    if (!grad_dst || !idx) return EPN_ENULL;
+    hipLaunchKernelGGL(epn::rows_gather_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st,
+                       static_cast<const f32x4 *>(grad_dst), idx, static_cast<f32x4 *>(grad_src), n, p1, p2,
+                       (int)(row_bytes / 16), 1);
+    EPN_CHECK_LAUNCH();
+    return 0;
+}

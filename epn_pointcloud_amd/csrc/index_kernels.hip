@@ -112,6 +112,94 @@ __global__ __launch_bounds__(1024) void fps_kernel(const float *__restrict__ xyz
     }
 }
 
+// DPP-reduction FPS (n <= 8192): the m - 1 rounds of FPS are a dependent chain, so the round latency is all that matters
+// (32 clouds are 32 workgroups on 256 CUs whatever the geometry).  Every lane keeps PPT points and their running
+// min-distances in registers; the arg-max of a round is one 64-bit max per wave done with DPP moves (xor 1, xor 2,
+// half-row mirror, row mirror, row_bcast15, row_bcast31: register-to-register, a few cycles each, against ~60 for a
+// ds_bpermute shuffle), one LDS slot per wave, ONE barrier, and <= 4 uniform-address LDS reads; the winner's coordinates
+// come back as uniform-address LDS reads too.  4 waves per cloud: a single wave issues ~1 VALU instruction per 5 cycles,
+// so PPT = 16 on one wave (measured: 670 us for m = 512) loses to PPT = 4 on four.  The reference's tie-breaking is the total order stated above fps_key, extended
+// by "inside one virtual thread the smaller index wins" (its strict `>` scan), encoded as key =
+// [fkey(value):32][1023 - bitrev10(k mod block):10][0x3FFFFF - k:22] per POINT, so any assignment of points to lanes
+// reproduces it.  Round 1's multi-wave kernel took 570 us for m = 512; this one ~90 us.
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ void dpp_max_u64(unsigned &hi, unsigned &lo) {
+    const unsigned oh = (unsigned)__builtin_amdgcn_update_dpp((int)hi, (int)hi, CTRL, ROW_MASK, 0xf, false);
+    const unsigned ol = (unsigned)__builtin_amdgcn_update_dpp((int)lo, (int)lo, CTRL, ROW_MASK, 0xf, false);
+    const bool take = oh > hi || (oh == hi && ol > lo);
+    hi = take ? oh : hi;
+    lo = take ? ol : lo;
+}
+
+template <int PPT, int NWAVE>
+__global__ __launch_bounds__(64 * NWAVE) void fps_wave_kernel(const float *__restrict__ xyz, int n, int m, int block,
+                                                              int32_t *__restrict__ idxs) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    unsigned long long *slots = reinterpret_cast<unsigned long long *>(smem);             // [2][NWAVE]
+    float *cloud = reinterpret_cast<float *>(smem + 2 * 8 * sizeof(unsigned long long));  // [3][n]
+    constexpr int T = 64 * NWAVE;
+    const int tid = threadIdx.x;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const float *d = xyz + (size_t)blockIdx.x * 3 * n;
+    int32_t *out = idxs + (size_t)blockIdx.x * m;
+    for (int i = tid; i < 3 * n; i += T) cloud[i] = d[i];
+
+    float px[PPT], py[PPT], pz[PPT], tmp[PPT];
+    unsigned pri[PPT];      // 0 for points that never compete (outside the cloud, or inside the 1e-3 dead zone)
+#pragma unroll
+    for (int i = 0; i < PPT; ++i) {
+        const int k = tid + T * i;
+        const bool in = k < n;
+        px[i] = in ? d[k] : 0.f;
+        py[i] = in ? d[n + k] : 0.f;
+        pz[i] = in ? d[2 * n + k] : 0.f;
+        tmp[i] = 1e10f;
+        const bool live = in && !((double)epn_sq3(px[i], py[i], pz[i]) <= 1e-3);
+        const unsigned t = (unsigned)(k % block);                       // the reference's thread of point k
+        pri[i] = live ? (((1023u - (__brev(t) >> 22)) << 22) | (0x3FFFFFu - (unsigned)k)) : 0u;
+    }
+    if (tid == 0) out[0] = 0;
+    __syncthreads();
+
+    int old = 0;
+    for (int j = 1; j < m; ++j) {
+        const float x1 = cloud[old], y1 = cloud[n + old], z1 = cloud[2 * n + old];
+        unsigned long long best = 0ull;
+#pragma unroll
+        for (int i = 0; i < PPT; ++i) {
+            const float dd = epn_sq3(px[i] - x1, py[i] - y1, pz[i] - z1);
+            const float d2 = fminf(dd, tmp[i]);
+            tmp[i] = d2;
+            // live points: key = [bits(d2) + 1][pri]; the others keep key 0 (pri == 0 marks them; a live point's pri is
+            // never 0 because its low field is 0x3FFFFF - k > 0)
+            const unsigned long long key =
+                pri[i] ? (((unsigned long long)(__float_as_uint(d2) + 1u) << 32) | pri[i]) : 0ull;
+            best = key > best ? key : best;
+        }
+        unsigned bh = (unsigned)(best >> 32), bl = (unsigned)best;
+        dpp_max_u64<0xB1, 0xf>(bh, bl);     // quad_perm [1,0,3,2]: xor 1
+        dpp_max_u64<0x4E, 0xf>(bh, bl);     // quad_perm [2,3,0,1]: xor 2
+        dpp_max_u64<0x141, 0xf>(bh, bl);    // row_half_mirror: 8 lanes
+        dpp_max_u64<0x140, 0xf>(bh, bl);    // row_mirror: 16 lanes
+        dpp_max_u64<0x142, 0xa>(bh, bl);    // row_bcast15 into rows 1, 3
+        dpp_max_u64<0x143, 0xc>(bh, bl);    // row_bcast31 into rows 2, 3: lane 63 holds the wave maximum
+        unsigned long long w = ((unsigned long long)(unsigned)__builtin_amdgcn_readlane((int)bh, 63) << 32) |
+                               (unsigned)__builtin_amdgcn_readlane((int)bl, 63);
+        if (NWAVE > 1) {
+            unsigned long long *slot = slots + (j & 1) * 8;        // two slot sets: one barrier per round suffices
+            if ((tid & 63) == 0) slot[wave] = w;
+            __syncthreads();
+#pragma unroll
+            for (int q = 0; q < NWAVE; ++q) {
+                const unsigned long long o = slot[q];               // uniform address: LDS broadcast
+                w = o > w ? o : w;
+            }
+        }
+        old = (w >> 32) == 0ull ? 0 : (int)(0x3FFFFFu - ((unsigned)w & 0x3FFFFFu));   // no live point: besti stays 0
+        if (tid == 0) out[j] = old;
+    }
+}
+
 // ------------------------------------------------------------------------------------ ball query
 __global__ __launch_bounds__(256) void ball_query_kernel(const float *__restrict__ new_xyz,
                                                          const float *__restrict__ xyz, int n, int m,
@@ -205,6 +293,27 @@ extern "C" int epn_fps_f32(const float *xyz, int b, int n, int m, int32_t *idx, 
     if (b == 0 || m == 0) return 0;
     if (!xyz || !idx) return EPN_ENULL;
     const int block = opt_n_threads(n);
+    hipStream_t st0 = epn_stream(stream);
+    if (n <= 256 * 32) {                       // DPP-reduction kernel: 1-4 waves per cloud, <= 1 barrier per round
+        const size_t sh = 2 * 8 * sizeof(unsigned long long) + (size_t)3 * n * sizeof(float);
+#define EPN_FPSW(P, W)                                                                                               \
+    do {                                                                                                             \
+        EPN_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&fps_wave_kernel<P, W>),                          \
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh));                           \
+        hipLaunchKernelGGL((fps_wave_kernel<P, W>), dim3(b), dim3(64 * W), sh, st0, xyz, n, m, block, idx);          \
+    } while (0)
+        if (n <= 64) EPN_FPSW(1, 1);
+        else if (n <= 128) EPN_FPSW(1, 2);
+        else if (n <= 256) EPN_FPSW(1, 4);
+        else if (n <= 512) EPN_FPSW(2, 4);
+        else if (n <= 1024) EPN_FPSW(4, 4);           // 8 waves x 2 points measured the same (279 vs 271 us for m = 512):
+        else if (n <= 2048) EPN_FPSW(8, 4);           // the fixed per-round chain (DPP max, LDS hop, barrier) dominates
+        else if (n <= 4096) EPN_FPSW(16, 4);
+        else EPN_FPSW(32, 4);
+#undef EPN_FPSW
+        EPN_CHECK_LAUNCH();
+        return 0;
+    }
     const int threads = block < 64 ? 64 : block;
     const int ppt = epn_cdiv(n, block);
     const int in_lds = (size_t)3 * n * sizeof(float) <= 96 * 1024;

@@ -101,6 +101,35 @@ def gemm_tn(X, Y, out=None):
     return out
 
 
+def gemm_tn_grouped(problems):
+    """problems: list of (X [R,N1], Y [R,N2]) of one dtype -> list of fp32 X^T Y, ONE launch (+ one reduction launch)."""
+    lib = _lib.get_lib()
+    arr = (_lib.GemmTnProblem * len(problems))()
+    outs, keep, bf = [], [], None
+    for i, (X, Y) in enumerate(problems):
+        X, Y = _rowmajor(X, "X"), _rowmajor(Y, "Y")
+        if X.shape[0] != Y.shape[0]:
+            raise ValueError(f"gemm_tn: row mismatch {tuple(X.shape)} vs {tuple(Y.shape)}")
+        b = _is_bf16(X)
+        if _is_bf16(Y) != b or (bf is not None and bf != b):
+            raise TypeError("gemm_tn: mixed operand dtypes")
+        bf = b
+        C = torch.empty((X.shape[1], Y.shape[1]), dtype=torch.float32, device=X.device)
+        p = arr[i]
+        p.X, p.Y, p.C = X.data_ptr(), Y.data_ptr(), C.data_ptr()
+        p.R, p.N1, p.N2 = X.shape[0], X.shape[1], Y.shape[1]
+        p.ldx = X.stride(0) if X.shape[0] > 1 else X.shape[1]
+        p.ldy = Y.stride(0) if Y.shape[0] > 1 else Y.shape[1]
+        p.ldc = C.shape[1]
+        outs.append(C)
+        keep += [X, Y]
+    nbytes = int(lib.epn_gemm_tn_grouped_workspace_bytes(bf, len(problems), arr))
+    ws = torch.empty(max(nbytes, 16), dtype=torch.uint8, device=outs[0].device)
+    _lib.check(lib.epn_gemm_tn_grouped(bf, len(problems), arr, ws.data_ptr(), ws.numel(), _lib.stream_of(outs[0])),
+               "gemm_tn_grouped")
+    return outs
+
+
 def transpose_cast(W, dtype):
     """[r,c] -> [c,r] contiguous in `dtype` (fp32 / bf16) with the library's kernel (weights only)."""
     lib = _lib.get_lib()

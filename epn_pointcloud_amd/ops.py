@@ -693,7 +693,7 @@ class _BlockGemmsFn(torch.autograd.Function):
         basis, pts, cin, cout = ctx.cfg
         gz = gz.contiguous()
         gy = torch.empty_like(y) if ctx.needs_input_grad[0] else None
-        gws, probs, fl = [], [], 0.0
+        gws, probs, tprobs, tidx, fl, flw = [None] * len(whats), [], [], [], 0.0, 0.0
         for bi, (d, base, wh) in enumerate(zip(basis.dims, basis.bases, whats)):
             A = y[base * pts * cin:(base + d * d) * pts * cin].view(pts * d, d * cin)
             G = gz[base * pts * cout:(base + d * d) * pts * cout].view(pts * d, d * cout)
@@ -703,10 +703,14 @@ class _BlockGemmsFn(torch.autograd.Function):
                 probs.append((G, gemm.cast(wh, y.dtype), gA))               # dY = dZ What^T: Bt = What [d*cin, d*cout]
                 fl += f1
             if ctx.needs_input_grad[5 + bi]:
-                gws.append(_launch("intra_gemm_dw", ("spectral_dw", pts * d, d * cin, d * cout), f1, y.device,
-                                   lambda: gemm.gemm_tn(A, G)))
-            else:
-                gws.append(None)
+                tprobs.append((A, G))
+                tidx.append(bi)
+                flw += f1
+        if tprobs:      # the five weight-gradient GEMMs, each too small to fill the chip alone: ONE grouped TN launch
+            outs = _launch("intra_gemm_dw", ("spectral_dw", pts, cin, cout), flw, y.device,
+                           lambda: gemm.gemm_tn_grouped(tprobs))
+            for bi, o in zip(tidx, outs):
+                gws[bi] = o
         if probs:
             _launch("intra_gemm", ("spectral_dA", pts, cin, cout), fl, y.device, lambda: gemm.gemm_nt_grouped(probs))
         return (gy, None, None, None, None, *gws)
@@ -953,6 +957,46 @@ def _identity_index(na, device):
     if key not in _IDENT:
         _IDENT[key] = torch.arange(na, dtype=torch.int32, device=device).view(na, 1)
     return _IDENT[key]
+
+
+class GatherRowsFn(torch.autograd.Function):
+    """batched_index_select(feats, 2, sample_idx) of the strided skip connection (SPConvNets/utils/base_so3conv.py:206-207)
+    on channels-last data: whole [a][c] rows move (epn_gather_rows); backward scatters them back into a zeroed tensor
+    (epn_scatter_rows; FPS indices are distinct, so no accumulation is needed)."""
+
+    @staticmethod
+    def forward(ctx, feats, sample_idx):
+        lib = _lib.get_lib()
+        f = to_cl(feats)
+        b, c, p1, a = f.shape
+        idx = sample_idx.int().contiguous()
+        p2 = idx.shape[1]
+        out = empty_cl(b, c, p2, a, f.device, f.dtype)
+        _lib.check(lib.epn_gather_rows(_cl_ptr(f), _lib.dev_ptr(idx, "sample_idx", torch.int32), _cl_ptr(out), b, p1, p2,
+                                       a * c * f.element_size(), _lib.stream_of(f)), "gather_rows")
+        ctx.save_for_backward(idx)
+        ctx.dims = (b, c, p1, a)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        lib = _lib.get_lib()
+        (idx,) = ctx.saved_tensors
+        b, c, p1, a = ctx.dims
+        gc = to_cl(g, "grad")
+        gs = empty_cl(b, c, p1, a, gc.device, gc.dtype)
+        _lib.check(lib.epn_scatter_rows(_cl_ptr(gc), _lib.dev_ptr(idx, "sample_idx", torch.int32), _cl_ptr(gs), b, p1,
+                                        idx.shape[1], a * c * gc.element_size(), _lib.stream_of(gc)), "scatter_rows")
+        return gs, None
+
+
+def gather_rows(feats, sample_idx):
+    """Rows of a [b,c,p,a] tensor selected along p; needs a*c*elem_size % 16 == 0 (else torch.gather)."""
+    if feats.is_cuda and (feats.shape[1] * feats.shape[3] * feats.element_size()) % 16 == 0 and \
+            feats.dtype in FEATURE_DTYPES:
+        return GatherRowsFn.apply(feats, sample_idx)
+    idx = sample_idx.long().view(feats.shape[0], 1, -1, 1).expand(-1, feats.shape[1], -1, feats.shape[3])
+    return torch.gather(feats, 2, idx)
 
 
 def conv1x1(x, weight, bias=None):

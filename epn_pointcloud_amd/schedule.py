@@ -149,10 +149,7 @@ class FusedSeparableBlock(SeparableBlock):
         def skip_branch():
             sk = skip
             if self.stride > 1:                                    # batched_index_select(skip, 2, sample_idx) on rows
-                s_cl = ops.to_cl(sk).permute(0, 2, 3, 1)           # [b,p1,a,c] view of the channels-last image
-                b, p1, a, c = s_cl.shape
-                idx = sample_idx.long().view(b, -1, 1).expand(-1, -1, a * c)
-                sk = torch.gather(s_cl.reshape(b, p1, a * c), 1, idx).view(b, -1, a, c).permute(0, 3, 1, 2)
+                sk = ops.gather_rows(sk, sample_idx)
             sk = ops.conv1x1(sk, self.skip_conv.weight, None)       # the norm cancels the bias: see ops.norm_act
             return ops.norm_act(sk, self.norm, conv_bias=self.skip_conv.bias)
 

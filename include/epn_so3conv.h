@@ -287,6 +287,17 @@ int epn_gemm_tn_f32(const float *X, long long ldx, const float *Y, long long ldy
                     int N1, int N2, void *workspace, size_t workspace_bytes, epn_stream_t stream);
 int epn_gemm_tn_bf16(const void *X, long long ldx, const void *Y, long long ldy, float *C, long long ldc, long long R,
                      int N1, int N2, void *workspace, size_t workspace_bytes, epn_stream_t stream);
+/* Grouped TN: up to 6 problems in ONE launch (the five weight-gradient GEMMs of a spectral IntraSO3Conv layer, each too
+ * small to fill the chip alone); splits are planned so that every workgroup runs about the same number of K steps. */
+typedef struct epn_gemm_tn_problem {
+    const void *X, *Y;
+    float *C;
+    long long R, ldx, ldy, ldc;
+    int N1, N2;
+} epn_gemm_tn_problem;
+size_t epn_gemm_tn_grouped_workspace_bytes(int bf16, int nprob, const epn_gemm_tn_problem *probs);
+int epn_gemm_tn_grouped(int bf16, int nprob, const epn_gemm_tn_problem *probs, void *workspace, size_t workspace_bytes,
+                        epn_stream_t stream);
 /* dst[cols][rows] = src[rows][cols]^T with an optional fp32 <-> bf16 conversion (weights: W^T for the data gradient,
  * bf16 copies of the fp32 master weights); epn_cast converts a flat array. */
 int epn_transpose_cast(const void *src, void *dst, int rows, int cols, int src_bf16, int dst_bf16, epn_stream_t stream);
@@ -341,6 +352,17 @@ int epn_inter_ungroup_det_f32(const epn_inter_desc *d, const float *grad_grouped
 int epn_inter_ungroup_det_bf16(const epn_inter_desc *d, const void *grad_grouped, void *grad_feats_cl,
                                const int32_t *offsets, const int32_t *entries, void *slab, size_t slab_bytes,
                                void *workspace, size_t workspace_bytes, epn_stream_t stream);
+
+/* Strided skip connection of SeparableSO3ConvBlock: replaces zptk.functional.batched_index_select(skip_feature, 2,
+ * sample_idx) (SPConvNets/utils/base_so3conv.py:206-207; vgtk/vgtk/spconv/functional.py:361-369: torch.gather with a
+ * broadcast index) on channels-last data, where it is a gather of whole [a][c] rows, and its autograd backward.
+ *   src [b][p1][row_bytes], idx i32[b][p2] -> dst [b][p2][row_bytes]            (row_bytes % 16 == 0, any element type)
+ *   epn_scatter_rows: grad_src [b][p1][row_bytes] = 0, then row idx[b][p] <- grad_dst[b][p] (indices distinct per cloud,
+ *   as FPS indices are: plain stores, deterministic) */
+int epn_gather_rows(const void *src, const int32_t *idx, void *dst, int b, int p1, int p2, long long row_bytes,
+                    epn_stream_t stream);
+int epn_scatter_rows(const void *grad_dst, const int32_t *idx, void *grad_src, int b, int p1, int p2, long long row_bytes,
+                     epn_stream_t stream);
 
 #ifdef __cplusplus
 }

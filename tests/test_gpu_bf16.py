@@ -86,6 +86,21 @@ def test_gemm_grouped_and_transpose(gpu):
     assert torch.equal(gemm.cast(W, torch.bfloat16), W.bfloat16())
 
 
+@pytest.mark.parametrize("dt", [torch.float32, torch.bfloat16])
+def test_gemm_tn_grouped(gpu, dt):
+    """One launch for the five weight-gradient GEMMs of a spectral IntraSO3Conv layer (R = pts*d rows, d*c x d*c outputs)."""
+    from epn_pointcloud_amd import gemm
+    torch.manual_seed(8)
+    probs = [(torch.randn(2048 * d, 64 * d, device=gpu).to(dt), torch.randn(2048 * d, 32 * d, device=gpu).to(dt))
+             for d in (1, 3, 3, 4, 5)]
+    outs = gemm.gemm_tn_grouped(probs)
+    for (X, Y), C in zip(probs, outs):
+        ref = X.double().t() @ Y.double()
+        assert (C.double() - ref).abs().max().item() <= 3e-5 * ref.abs().max().item()
+    again = gemm.gemm_tn_grouped(probs)
+    assert all(torch.equal(a, b) for a, b in zip(outs, again))         # fixed-order reduction: bitwise repeatable
+
+
 # ------------------------------------------------------------------------------------------------ convolutions
 @pytest.mark.parametrize("cin,cout,stride,K", [(32, 32, 1, 32), (32, 64, 2, 64), (64, 64, 1, 16), (16, 48, 2, 20)])
 def test_inter_bf16_vs_oracle(gpu, vgtk_alias, cin, cout, stride, K):

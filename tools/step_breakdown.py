@@ -29,7 +29,9 @@ for kind, key, fl, e0, e1 in rec:
     ms = e0.elapsed_time(e1)
     k = (kind,) + tuple(key)[:8]
     agg[k][0] += 1; agg[k][1] += ms; fam[kind] += ms
+    agg[k].append(fl) if len(agg[k]) == 2 else None
 print({k: round(v, 2) for k, v in sorted(fam.items(), key=lambda kv: -kv[1])}, "sum", round(sum(fam.values()), 1))
 for k, v in sorted(agg.items(), key=lambda kv: -kv[1][1]):
     if flt in k[0]:
-        print(f"{v[1]:7.3f} ms x{v[0]}  {k}")
+        tf = v[2] * v[0] / (v[1] * 1e-3) / 1e12 if len(v) > 2 and v[1] > 0 else 0.0
+        print(f"{v[1]:7.3f} ms x{v[0]} {tf:6.1f} TF  {k}")
