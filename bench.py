@@ -59,7 +59,8 @@ def recorded_traffic(kernel_family):
         return None
     tot = n = 0.0
     for name, e in pmc.items():
-        if kernel_family.split("::")[-1].replace("_kernel", "") in name and "hbm_bytes_per_launch" in e:
+        if (name == kernel_family or (("<" not in kernel_family) and
+                                      kernel_family.split("::")[-1].replace("_kernel", "") in name)) and "hbm_bytes_per_launch" in e:
             tot += e["hbm_bytes_per_launch"] * e["launches"]
             n += e["launches"]
     return round(tot / n) if n else None
@@ -317,9 +318,39 @@ def main():
                 return 2 * pts * 60 * c * esz
             return 0
 
+        def nt_name(ns, kk):
+            """Template instance launch_nt_typed (csrc/gemm.hip) picks for N in `ns`, contraction length kk -- the names
+            rocprofv3 reports (profiles/r02_kernel_stats.csv)."""
+            t = "float, float" if dtype_name == "f32" else "__bf16, __bf16"
+            e16 = 4 if dtype_name == "f32" else 8
+            if kk % (4 * e16):
+                return "epn::gemm_nt_generic_kernel"
+            ksz = 8 if kk % (8 * e16) == 0 else 4
+            if ksz == 8 and min(ns) >= 256 and dtype_name == "f32":
+                cfg = "4, 2, 2, 4"
+            elif max(ns) <= 32:
+                cfg = "8, 1, 2, 1"
+            elif max(ns) <= 64:
+                cfg = "8, 1, 2, 2"
+            else:
+                cfg = "4, 2, 2, 2"
+            return f"epn::gemm_nt_kernel<{t}, {cfg}, {ksz}>"
+
+        def kernel_of(kind, key):
+            if kind == "inter_gemm":
+                return nt_name([key[7]], key[6] * key[5])
+            if kind == "inter_gemm_dg":
+                return nt_name([key[6] * key[5]], key[7])
+            if kind == "intra_gemm" and key[0] in ("spectral", "spectral_dA"):
+                cio = (key[2], key[3]) if key[0] == "spectral" else (key[3], key[2])
+                return nt_name([d_ * cio[1] for d_ in (1, 3, 3, 4, 5)], cio[0])
+            if kind == "conv1x1_gemm":
+                return nt_name([key[2]], key[3])
+            return KERNEL_OF.get(kind, kind)
+
         agg = {}
         for kind, key, flops, e0, e1 in records:
-            k = KERNEL_OF.get(kind, kind)
+            k = kernel_of(kind, key)
             if kind.startswith("inter") and len(key) > 6 and key[6] == 1:      # cin = 1 (first layer): dedicated kernels
                 k = {"inter_fwd": "epn::inter_c1_fwd_kernel", "inter_bwd_weight": "epn::inter_c1_bwd_weight_kernel"}.get(kind, k)
             a = agg.setdefault(k, {"ms": 0.0, "flops": 0.0, "launches": 0, "bytes": 0.0})

@@ -354,7 +354,7 @@ class InterSO3ConvSplitFn(torch.autograd.Function):
                            "inter_so3conv_bwd_data")
             else:
                 Wt = gemm.transpose_cast(Wc, G.dtype)                        # [ck, cout]: dG = dOut W as an NT GEMM
-                dG = _launch("inter_gemm", _inter_key(d), gemm_fl, G.device, lambda: gemm.gemm_nt(g2d, Wt))
+                dG = _launch("inter_gemm_dg", _inter_key(d), gemm_fl, G.device, lambda: gemm.gemm_nt(g2d, Wt))
                 ws, wsp, wsn = _group_workspace(lib, d, G.device)
                 gflops = 9.0 * cols * d.ks * d.nn + 2.0 * cols * cin * d.ks * d.nn
                 if deterministic_bwd(G.dtype) and isinstance(geo, InterGeometry) and d.na >= 16:
@@ -1008,8 +1008,14 @@ def conv1x1(x, weight, bias=None):
     if x.is_cuda and ((x.dtype == torch.bfloat16 and cin % 32 == 0) or (x.dtype == torch.float32 and cin % 16 == 0)):
         xc = to_cl(x)                   # K = cin is a whole number of 64-byte half K steps: the MFMA GEMM kernels
         b, c, p, a = xc.shape
-        y2d = gemm.matmul_nt(xc.permute(0, 2, 3, 1).reshape(-1, c), weight.reshape(cout, cin))
-        y = y2d.view(b, p, a, cout).permute(0, 3, 1, 2)
+        w2 = weight.reshape(cout, cin)
+        pad = (-cout) % 8               # the weight-gradient (TN) kernels want output widths that are whole 16-byte
+        if pad:                         # groups: zero rows are appended (a 1- or 4-channel head), sliced off again
+            w2 = torch.cat((w2, w2.new_zeros(pad, cin)), 0)
+        y2d = gemm.matmul_nt(xc.permute(0, 2, 3, 1).reshape(-1, c), w2)
+        if pad:
+            y2d = y2d[:, :cout]
+        y = y2d.reshape(b, p, a, cout).permute(0, 3, 1, 2)
     elif x.is_cuda and cin % 16 == 0 and cout % 16 == 0:
         y = IntraSO3ConvFn.apply(cast_feats(x, torch.float32), weight.reshape(cout, cin),
                                  _identity_index(x.shape[3], x.device))
