@@ -151,3 +151,20 @@ def test_full_width_cls_step_matches_oracle_loss(gpu):
     assert abs(loss_g.item() - loss_r.item()) < TOL
     for n, u, v in zip(names, gg, gr):
         assert grad_close(u, v), n
+
+
+def test_cls_model_kanchor20_vs_reference_golden(gpu):
+    """Reduced-anchor configuration: every block is an InterSO3ConvBlock (no intra conv, no skip); outputs and two
+    gradients against the reference's own build of that network."""
+    from epn_pointcloud_amd import models as M
+    from test_models_cpu import tiny_layers
+    g = golden("model_cls_k20_tiny.npz")
+    m = fill_state_dict(M.ClsSO3ConvModel(tiny_layers("cls"), out_mlps=(32,), pooling="attention", kanchor=20)).to(gpu).train()
+    logits, att = m(T(g["pts"]).to(gpu))
+    loss = torch.nn.functional.cross_entropy(logits, T(g["labels"]).to(gpu))
+    assert close(logits, g["logits"]) and close(att, g["attention"])
+    assert abs(loss.item() - float(g["loss"])) < TOL
+    pd = dict(m.named_parameters())
+    grads = torch.autograd.grad(loss, [pd[n] for n in g["grad_names"].tolist()])
+    for i, gr in enumerate(grads):
+        assert grad_close(gr, g[f"grad{i}"])

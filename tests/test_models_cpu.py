@@ -110,3 +110,20 @@ def test_oracle_inv_model_vs_reference_golden():
     desc, attn = filled_oracle("inv")(T(g["pts"]))
     assert (desc.detach() - T(g["descriptor"])).abs().max().item() < TOL
     assert (attn[:, :, ::8].detach() - T(g["attention_sub"])).abs().max().item() < TOL
+
+
+def test_kanchor20_state_dict_layout_matches_reference():
+    """kanchor = 20: the reference builds 'inter_block's (cls_so3net_pn.py:127); the product must build the same tree."""
+    from epn_pointcloud_amd import models as M
+    g = golden("model_cls_k20_tiny.npz")
+    m = M.ClsSO3ConvModel(tiny_layers("cls"), out_mlps=(32,), pooling="attention", kanchor=20)
+    mine = sorted(f"{k}:{'x'.join(str(d) for d in v.shape)}" for k, v in m.state_dict().items())
+    assert mine == sorted(g["layout"].tolist())
+
+
+def test_separable_block_rejects_unsupported_kanchor():
+    from epn_pointcloud_amd import schedule as S
+    with pytest.raises(NotImplementedError):
+        S.SeparableBlock(tiny_layers("cls")[1], kanchor=20)
+    blk = S.SeparableBlock(tiny_layers("cls")[1], kanchor=1)         # use_intra = kanchor > 1 (base_so3conv.py:177)
+    assert not hasattr(blk, "intra_conv")
