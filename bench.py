@@ -164,7 +164,7 @@ def main():
     assert world == args.gpus, f"WORLD_SIZE={world} but --gpus {args.gpus}"
     _lib.get_lib()                                      # fail loudly if the HIP library is missing
     assert torch.cuda.is_available(), "bench.py needs an MI355X"
-    dev = torch.device("cuda", local_rank)
+    dev = dp.local_device(local_rank)
     torch.cuda.set_device(dev)
 
     dtype_name = args.dtype or ("f32" if args.model == "cls" else "bf16")
@@ -318,7 +318,7 @@ def main():
                 return 2 * pts * 60 * c * esz
             return 0
 
-        def nt_name(ns, kk):
+        def nt_name(ns, kk, m_rows=0):
             """Template instance launch_nt_typed (csrc/gemm.hip) picks for N in `ns`, contraction length kk -- the names
             rocprofv3 reports (profiles/r02_kernel_stats.csv)."""
             t = "float, float" if dtype_name == "f32" else "__bf16, __bf16"
@@ -326,7 +326,10 @@ def main():
             if kk % (4 * e16):
                 return "epn::gemm_nt_generic_kernel"
             ksz = 8 if kk % (8 * e16) == 0 else 4
-            if ksz == 8 and min(ns) >= 256 and dtype_name == "f32":
+            if (dtype_name == "f32" and ksz == 8 and len(ns) == 1 and ns[0] in (128, 256)
+                    and (m_rows // 128) * (ns[0] // 128) >= 3840):
+                cfg = "2, 2, 2, 2"
+            elif ksz == 8 and min(ns) >= 256 and dtype_name == "f32":
                 cfg = "4, 2, 2, 4"
             elif max(ns) <= 32:
                 cfg = "8, 1, 2, 1"
@@ -336,16 +339,35 @@ def main():
                 cfg = "4, 2, 2, 2"
             return f"epn::gemm_nt_kernel<{t}, {cfg}, {ksz}>"
 
+        def tn_name(n1, n2):
+            """Template instance gemm_tn_tile / launch_tn_typed (csrc/gemm.hip) pick for an N1 x N2 output."""
+            if dtype_name == "bf16":
+                cfg = "1, 8, 2, 2" if n1 <= 32 else ("1, 8, 4, 2" if n1 <= 64 else "2, 4, 4, 4")
+                return f"epn::gemm_tn_bf16_kernel<{cfg}>"
+            if n1 <= 32:
+                cfg = "1, 8, 1, 2, 32"
+            elif n1 <= 64:
+                cfg = "1, 4, 2, 4, 16" if n2 >= 512 else "1, 8, 2, 1, 32"
+            else:
+                cfg = "1, 8, 4, 2, 32" if n2 >= 512 else "2, 4, 2, 2, 32"
+            return f"epn::gemm_tn_f32_kernel<{cfg}>"
+
         def kernel_of(kind, key):
+            if kind == "inter_gemm_dw":
+                return tn_name(key[7], key[6] * key[5])
+            if kind == "intra_gemm_dw" and key[0] == "spectral_dw":
+                return tn_name(5 * key[2], key[3])           # grouped: max N1, min N2 of the five blocks
+            if kind == "conv1x1_gemm_dw":
+                return tn_name(key[2], key[3])
             if kind == "inter_gemm":
-                return nt_name([key[7]], key[6] * key[5])
+                return nt_name([key[7]], key[6] * key[5], key[0] * key[2] * key[4])
             if kind == "inter_gemm_dg":
                 return nt_name([key[6] * key[5]], key[7])
             if kind == "intra_gemm" and key[0] in ("spectral", "spectral_dA"):
                 cio = (key[2], key[3]) if key[0] == "spectral" else (key[3], key[2])
                 return nt_name([d_ * cio[1] for d_ in (1, 3, 3, 4, 5)], cio[0])
             if kind == "conv1x1_gemm":
-                return nt_name([key[2]], key[3])
+                return nt_name([key[2]], key[3], key[1])
             return KERNEL_OF.get(kind, kind)
 
         agg = {}

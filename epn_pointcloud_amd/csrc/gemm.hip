@@ -604,6 +604,11 @@ int launch_nt_typed(GemmNtBatch &B, hipStream_t st) {
             default: break;
         }
     }
+    if (sizeof(T) == 4 && B.nprob == 1 && maxn >= 128 && maxn <= 256 && maxn % 128 == 0 &&
+        (B.p[0].M / 128) * (maxn / 128) >= 3840)
+        // many-tile problems: 128 x 128 tiles, 4 waves, two workgroups per CU (measured on 491520 x 128 and 245760 x 256:
+        // 130-140 TFLOP/s against 124-136 for the 256-row tiles; below ~3840 tiles the big tiles win)
+        return launch_nt_cfg<T, TO, 2, 2, 2, 2>(B, st);
     if (maxn <= 32) return launch_nt_cfg<T, TO, 8, 1, 2, 1>(B, st);      // 512 x 32
     if (maxn <= 64) return launch_nt_cfg<T, TO, 8, 1, 2, 2>(B, st);      // 512 x 64
     if (minn >= 256 && sizeof(T) == 4) return launch_nt_cfg<T, TO, 4, 2, 2, 4>(B, st);   // 256 x 256 (fewer loads / MFMA)
@@ -698,6 +703,11 @@ int launch_tn_typed(GemmTnBatch &B, void *ws, size_t ws_bytes, hipStream_t st) {
     if (need > 0 && (!ws || ws_bytes < need)) return EPN_EWORKSPACE;
     const dim3 grid(B.nblocks);
     if constexpr (sizeof(T) == 4) {
+        const int pol = kernel_policy();
+        if ((pol & ~0xff) == 0x300 && bn1 == 128) {          // tuning override (tools/gemm_bench.py --cfg 0x30v)
+            if ((pol & 0xff) == 1 && bn2 == 256) { hipLaunchKernelGGL((gemm_tn_f32_kernel<2, 4, 2, 2, 16>), grid, dim3(512), 0, st, B); EPN_CHECK_LAUNCH(); goto launched; }
+            if ((pol & 0xff) == 2 && bn2 == 512) { hipLaunchKernelGGL((gemm_tn_f32_kernel<1, 8, 4, 2, 16>), grid, dim3(512), 0, st, B); EPN_CHECK_LAUNCH(); goto launched; }
+        }
         if (bn1 == 32) hipLaunchKernelGGL((gemm_tn_f32_kernel<1, 8, 1, 2, 32>), grid, dim3(512), 0, st, B);
         else if (bn1 == 64 && bn2 == 512) hipLaunchKernelGGL((gemm_tn_f32_kernel<1, 4, 2, 4, 16>), grid, dim3(256), 0, st, B);
         else if (bn1 == 64) hipLaunchKernelGGL((gemm_tn_f32_kernel<1, 8, 2, 1, 32>), grid, dim3(512), 0, st, B);
@@ -709,6 +719,7 @@ int launch_tn_typed(GemmTnBatch &B, void *ws, size_t ws_bytes, hipStream_t st) {
         else hipLaunchKernelGGL((gemm_tn_bf16_kernel<2, 4, 4, 4>), grid, dim3(512), 0, st, B);
     }
     EPN_CHECK_LAUNCH();
+launched:
     bool any_split = false;
     size_t nmax = 0;
     for (int i = 0; i < B.nprob; ++i) {

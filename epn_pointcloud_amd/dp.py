@@ -57,7 +57,8 @@ def init_from_env(backend=None, force=False):
     rank, local_rank, world = env_world()
     if (world > 1 or force) and not dist.is_initialized():
         if backend is None:
-            backend = "nccl" if torch.cuda.is_available() else "gloo"
+            # EPN_DP_BACKEND=gloo: rehearsal of the multi-rank path on a box with fewer GPUs than ranks (see local_device)
+            backend = os.environ.get("EPN_DP_BACKEND") or ("nccl" if torch.cuda.is_available() else "gloo")
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29500")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")   # dmabuf IPC only on this driver (RCCL needs it)
@@ -67,6 +68,13 @@ def init_from_env(backend=None, force=False):
             kwargs["device_id"] = torch.device("cuda", local_rank)
         dist.init_process_group(backend=backend, rank=rank, world_size=world, **kwargs)
     return rank, local_rank, world
+
+
+def local_device(local_rank):
+    """cuda:<local_rank>; with EPN_DP_SHARE_GPU=1 every rank uses cuda:0 (a rehearsal of the multi-rank control flow --
+    launcher, capture before communicator, broadcast, bucketed all-reduce, max-over-ranks timing -- on a one-GPU box,
+    with EPN_DP_BACKEND=gloo since RCCL refuses two ranks on one device; never a measurement)."""
+    return torch.device("cuda", 0 if os.environ.get("EPN_DP_SHARE_GPU") == "1" else local_rank)
 
 
 def shard_batch(global_batch, rank, world):
