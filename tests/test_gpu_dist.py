@@ -43,7 +43,8 @@ def test_single_rank_rccl_allreduce(gpu):
     assert r.returncode == 0 and "RCCL_OK" in r.stdout, r.stdout + r.stderr
 
 
-def test_bench_two_ranks_rehearsal_on_one_gpu(gpu):
+@pytest.mark.parametrize("extra,launch", [([], "hipgraph"), (["--no-graph"], "eager")])
+def test_bench_two_ranks_rehearsal_on_one_gpu(gpu, extra, launch):
     """`python bench.py --gpus 2` end to end through its own launcher (no torchrun): two rank processes, the HIP graph
     captured before the communicator exists, parameter broadcast, flat-bucket gradient all-reduce, barrier + max-over-ranks
     timing, ONE JSON line from rank 0.  Both ranks share the single GPU of the test box and talk over gloo
@@ -54,9 +55,9 @@ def test_bench_two_ranks_rehearsal_on_one_gpu(gpu):
     for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "EPN_DP_CHILD"):
         env.pop(k, None)
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1",
-                        "--batch", "4", "--no-cpu-baseline"], env=env, capture_output=True, text=True, timeout=900)
+                        "--batch", "4", "--no-cpu-baseline"] + extra, env=env, capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
     line = [l for l in r.stdout.splitlines() if l.startswith("{")][-1]
     out = json.loads(line)
     assert out["n_gpus"] == 2 and out["config"]["global_batch"] == 8 and out["config"]["parallelism"] == "dp2"
-    assert out["value"] > 0 and out["config"]["launch"] == "hipgraph"
+    assert out["value"] > 0 and out["config"]["launch"] == launch     # eager: per-stage all-reduce from backward hooks
