@@ -14,7 +14,7 @@ static bool force_generic() { return g_policy.load(std::memory_order_relaxed) ==
 namespace epn { int kernel_policy() { return g_policy.load(std::memory_order_relaxed); } }
 
 extern "C" int epn_set_kernel_policy(int policy) {
-    if (policy != 0 && policy != 1 && (policy & ~0xff) != 0x100 && (policy & ~0xff) != 0x200 && (policy & ~0xff) != 0x300) return EPN_EINVAL;   // 0x100 | cfg: tools/gemm_bench.py
+    if (policy != 0 && policy != 1 && (policy & ~0xff) != 0x100 && (policy & ~0xff) != 0x200 && (policy & ~0xff) != 0x300 && (policy & ~0xff) != 0x400) return EPN_EINVAL;   // 0x100 | cfg: tools/gemm_bench.py
     g_policy.store(policy, std::memory_order_relaxed);
     return 0;
 }
@@ -214,7 +214,8 @@ static int inter_ungroup_any(const epn_inter_desc *d, const void *grad_grouped, 
     if (inter_group_mfma_ok(d) && !force_generic()) {
         rc = launch_inter_tables_mfma(d, base + ws.rk_off, base + ws.rk4_off, base + ws.beta_off, st);
         if (rc) return rc;
-        return launch_inter_ungroup_mfma(d, base + ws.rk4_off, grad_grouped, grad_feats_cl, bf16, st);
+        return launch_inter_ungroup_mfma(d, base + ws.rk4_off, grad_grouped, grad_feats_cl,
+                                         reinterpret_cast<int32_t *>(base + ws.order_off), bf16, st);
     }
     if (bf16) return EPN_EINVAL;
     return launch_inter_scatter(d, base + ws.rk_off, static_cast<const float *>(grad_grouped), grad_feats_cl, st);

@@ -9,7 +9,7 @@ namespace epn {
 
 // workspace carve-up (float offsets) for one inter descriptor
 struct InterWs {
-    size_t rk_off, rk4_off, beta_off, big_off, total_floats;
+    size_t rk_off, rk4_off, beta_off, order_off, big_off, total_floats;
 };
 static inline size_t rnd64(size_t x) { return (x + 63) & ~(size_t)63; }
 static inline bool inter_mfma_shape_ok(const epn_inter_desc *d) {
@@ -23,7 +23,8 @@ static inline InterWs inter_ws(const epn_inter_desc *d) {
     w.rk_off = 0;
     w.rk4_off = rnd64((size_t)d->na * d->ks * 3);
     w.beta_off = w.rk4_off + rnd64((size_t)d->na * EPN_KS_MAX * 4);
-    w.big_off = w.beta_off + rnd64((size_t)d->na * EPN_KS_MAX);
+    w.order_off = w.beta_off + rnd64((size_t)d->na * EPN_KS_MAX);   // b*p2 int32: spatial order of the output points
+    w.big_off = w.order_off + rnd64((size_t)d->b * d->p2);
     // generic path: materialised grouped features; MFMA path: transposed weight for bwd_data
     const size_t big = inter_uses_mfma(d) ? (size_t)d->cout * d->cin * d->ks
                                           : (size_t)d->b * d->p2 * d->na * d->cin * d->ks;
@@ -70,8 +71,9 @@ static inline bool inter_group_mfma_ok(const epn_inter_desc *d) {
 // bf16 != 0: feats / G (group) and dG (ungroup) are bf16; the scatter target dF is fp32 either way
 int launch_inter_group_mfma(const epn_inter_desc *d, const float *rk4, const void *feats, void *G, int bf16,
                             hipStream_t st);
-int launch_inter_ungroup_mfma(const epn_inter_desc *d, const float *rk4, const void *dG, float *dF, int bf16,
-                              hipStream_t st);
+// order: b*p2 int32 of scratch for the Morton order of the output points (nullptr: per-slot atomic scatter)
+int launch_inter_ungroup_mfma(const epn_inter_desc *d, const float *rk4, const void *dG, float *dF, int32_t *order,
+                              int bf16, hipStream_t st);
 // deterministic (atomic-free) data gradient of the grouping: inverse neighbour list + per-slot slab + ordered reduction
 int launch_inverse_list(const int32_t *idx, int b, int p1, int p2, int nn, int32_t *off, int32_t *ent, hipStream_t st);
 int launch_inter_ungroup_det_mfma(const epn_inter_desc *d, const float *rk4, const void *dG, void *dF, void *slab,

@@ -19,6 +19,7 @@
 #include <cstdlib>
 
 #include "conv_internal.h"
+#include "gemm.h"
 
 
 namespace epn {
@@ -1068,6 +1069,237 @@ __global__ __launch_bounds__(64 * NW) void inter_ungroup_kernel(InterArgs A) {
     }
 }
 
+// Spatial order of the output points of each cloud (Morton code of the centre, 10 bits per axis over the cloud's
+// bounding box): consecutive points in this order have heavily overlapping neighbourhoods, which is what
+// inter_ungroup_shared_kernel exploits.  One workgroup per cloud, rank sort in LDS (p2 <= MORTON_MAX).
+constexpr int MORTON_MAX = 4096;
+__device__ __forceinline__ unsigned spread3(unsigned v) {   // 10 bits -> every third bit
+    v &= 0x3ffu;
+    v = (v | (v << 16)) & 0x030000ffu;
+    v = (v | (v << 8)) & 0x0300f00fu;
+    v = (v | (v << 4)) & 0x030c30c3u;
+    v = (v | (v << 2)) & 0x09249249u;
+    return v;
+}
+__global__ __launch_bounds__(1024) void morton_order_kernel(const float *__restrict__ new_xyz, int p2,
+                                                            int32_t *__restrict__ order) {
+    __shared__ unsigned code[MORTON_MAX];
+    __shared__ float red[6][16];
+    const int b = blockIdx.x, tid = threadIdx.x;
+    const float *c = new_xyz + (size_t)b * 3 * p2;
+    float lo[3] = {3e38f, 3e38f, 3e38f}, hi[3] = {-3e38f, -3e38f, -3e38f};
+    for (int i = tid; i < p2; i += 1024)
+#pragma unroll
+        for (int ax = 0; ax < 3; ++ax) {
+            const float v = c[ax * p2 + i];
+            lo[ax] = fminf(lo[ax], v); hi[ax] = fmaxf(hi[ax], v);
+        }
+#pragma unroll
+    for (int ax = 0; ax < 3; ++ax) {
+#pragma unroll
+        for (int o = 32; o >= 1; o >>= 1) {
+            lo[ax] = fminf(lo[ax], __shfl_xor(lo[ax], o, 64));
+            hi[ax] = fmaxf(hi[ax], __shfl_xor(hi[ax], o, 64));
+        }
+        if ((tid & 63) == 0) { red[ax][tid >> 6] = lo[ax]; red[3 + ax][tid >> 6] = hi[ax]; }
+    }
+    __syncthreads();
+    float scale[3];
+#pragma unroll
+    for (int ax = 0; ax < 3; ++ax) {
+        float l = red[ax][0], h = red[3 + ax][0];
+        for (int w = 1; w < 16; ++w) { l = fminf(l, red[ax][w]); h = fmaxf(h, red[3 + ax][w]); }
+        lo[ax] = l;
+        scale[ax] = h > l ? 1023.0f / (h - l) : 0.0f;
+    }
+    for (int i = tid; i < p2; i += 1024) {
+        unsigned m = 0;
+#pragma unroll
+        for (int ax = 0; ax < 3; ++ax) {
+            const float v = (c[ax * p2 + i] - lo[ax]) * scale[ax];
+            const unsigned q = (unsigned)fminf(fmaxf(v, 0.0f), 1023.0f);   // NaN -> 0
+            m |= spread3(q) << ax;
+        }
+        code[i] = m;
+    }
+    __syncthreads();
+    for (int i = tid; i < p2; i += 1024) {
+        const unsigned mine = code[i];
+        int rank = 0;
+        for (int k = 0; k < p2; ++k) {
+            const unsigned o = code[k];
+            rank += (o < mine) || (o == mine && k < i);
+        }
+        order[(size_t)b * p2 + rank] = i;
+    }
+}
+
+// Transpose of the grouping with the scatter pre-reduced in LDS.  A workgroup takes GP output points that are adjacent
+// in the Morton order (one wave each).  Their GP*K neighbour slots name far fewer DISTINCT input points (ModelNet
+// schedule: 2.9-3.4x fewer for GP = 8), so per anchor the waves store their per-slot contributions T[n][c] to an LDS
+// tile (plain stores), and after one barrier the workgroup sums the slots of each distinct destination (lists built
+// once per workgroup) and issues ONE global atomic per (destination, anchor, channel) instead of one per slot.  The
+// tile is double-buffered over anchors: one barrier per column.  (ds_add_f32 into a shared accumulator was measured at
+// ~1 lane per clock on gfx950 -- 2x slower than the global atomics it replaced; hence stores + a gather-sum.)
+constexpr int USH_TAB = 4096;   // destinations are de-duplicated through a direct-address table: p1 <= USH_TAB
+template <int NT, int KT, typename TG, int GP>
+__global__ __launch_bounds__(64 * GP) void inter_ungroup_shared_kernel(InterArgs A, const int32_t *__restrict__ order) {
+    constexpr int EW = 16 * NT;        // neighbour slots per point (padded)
+    constexpr int E = GP * EW;         // slots of the workgroup (128 or 256)
+    constexpr int SS = 20;             // floats per slot row: 16 channels + 4 (rows 4 apart fall on distinct banks)
+    constexpr int NTH = 64 * GP;
+    constexpr int CH = E / 64;         // 64-slot chunks
+    constexpr int EPT = (E + NTH - 1) / NTH;   // slots per thread in the set-up passes
+    __shared__ int qlist[E];           // destination of each slot, -1 when masked or a cyclic repeat
+    __shared__ int slot_of[E];         // slot -> distinct-destination number
+    __shared__ int uq[E];              // distinct destination -> input point
+    __shared__ int cnt[E];
+    __shared__ int off[E + 1];         // CSR over distinct destinations ...
+    __shared__ int list[E];            // ... of the slots that feed them
+    __shared__ int chunk_cnt[CH];
+    __shared__ __attribute__((aligned(16))) float Tb[2 * E * SS];
+    int *tab = reinterpret_cast<int *>(Tb);   // set-up only: input point -> first slot naming it
+    static_assert(2 * E * SS >= USH_TAB, "direct-address table must fit the tile buffers");
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int x = lane & 15, j = lane >> 4;
+    const int groups = A.p2 / GP;
+    const int blk = epn_xcd_tile(blockIdx.x, gridDim.x);
+    const int bb = blk / groups, grp = blk - bb * groups;
+    const int pp = order[(size_t)bb * A.p2 + grp * GP + wave];
+    const int ct = blockIdx.y;
+    const int gss = A.cin * A.ks;
+
+    Hood<NT> h;
+    load_hood<NT>(A, bb, pp, x, j, h);
+    if (x == 0) {
+        const int32_t *row = A.idx + ((size_t)bb * A.p2 + pp) * A.nn;
+#pragma unroll
+        for (int t = 0; t < NT; ++t)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int n = 16 * t + 4 * j + r;
+                qlist[wave * EW + n] = h.mul[t][r] != 0.0f ? row[n] : -1;
+            }
+    }
+    for (int e = tid; e < E; e += NTH) cnt[e] = 0;
+    __syncthreads();
+    int myq[EPT], myr[EPT];
+#pragma unroll
+    for (int k = 0; k < EPT; ++k) {
+        const int e = tid + k * NTH;
+        myq[k] = e < E ? qlist[e] : -1;
+        if (myq[k] >= 0) tab[myq[k]] = 0x7fffffff;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < EPT; ++k)
+        if (myq[k] >= 0) atomicMin(&tab[myq[k]], tid + k * NTH);
+    __syncthreads();
+    // number the distinct destinations in slot order: ballot per 64-slot chunk, then chunk prefix
+    for (int c = wave; c < CH; c += GP) {
+        const int e = c * 64 + lane;
+        const int q = qlist[e];
+        const bool leader = q >= 0 && tab[q] == e;
+        const unsigned long long m = __ballot(leader);
+        if (leader) slot_of[e] = __popcll(m & ((1ull << lane) - 1ull));
+        if (lane == 0) chunk_cnt[c] = __popcll(m);
+    }
+    __syncthreads();
+    int U = 0;
+#pragma unroll
+    for (int c = 0; c < CH; ++c) U += chunk_cnt[c];
+#pragma unroll
+    for (int k = 0; k < EPT; ++k) {
+        const int e = tid + k * NTH;
+        if (myq[k] >= 0 && tab[myq[k]] == e) {
+            int base = 0;
+            for (int c = 0; c < (e >> 6); ++c) base += chunk_cnt[c];
+            const int sl = base + slot_of[e];
+            slot_of[e] = sl;
+            uq[sl] = myq[k];
+        }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < EPT; ++k) {
+        const int e = tid + k * NTH;
+        myr[k] = 0;
+        if (myq[k] >= 0) {
+            const int sl = slot_of[tab[myq[k]]];
+            slot_of[e] = sl;                    // a leader rewrites its own value
+            myr[k] = atomicAdd(&cnt[sl], 1);
+        }
+    }
+    __syncthreads();
+    if (wave == 0) {                            // exclusive scan of cnt[0..E) by one wave: E/64 consecutive slots per lane
+        int loc[CH], sum = 0;
+#pragma unroll
+        for (int c = 0; c < CH; ++c) { loc[c] = sum; sum += cnt[lane * CH + c]; }
+        int incl = sum;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) {
+            const int v = __shfl_up(incl, o, 64);
+            incl += lane >= o ? v : 0;
+        }
+        const int excl = incl - sum;
+#pragma unroll
+        for (int c = 0; c < CH; ++c) off[lane * CH + c] = excl + loc[c];
+        if (lane == 63) off[E] = incl;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < EPT; ++k)
+        if (myq[k] >= 0) list[off[slot_of[tid + k * NTH]] + myr[k]] = tid + k * NTH;
+    __syncthreads();                            // also: tab (aliasing Tb) is dead from here on
+
+    float gB[NT], alphaN[NT];
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+        alphaN[t] = __shfl(h.gA[t], 48 + x, 64);
+        gB[t] = j == 3 ? 1.0f : h.gA[t];
+    }
+    const TG *dG = reinterpret_cast<const TG *>(A.gout) + ((size_t)bb * A.p2 + pp) * A.na * gss + (size_t)(16 * ct + x) * A.ks;
+    float *dcloud = A.out + ((size_t)bb * A.p1) * A.na * A.cin + 16 * ct;
+    for (int a = 0; a < A.na; ++a) {
+        float *buf = Tb + (a & 1) * E * SS + wave * EW * SS + x;
+        float rk[KT];
+        f32x4 dgc[KT];
+#pragma unroll
+        for (int kt = 0; kt < KT; ++kt) {
+            rk[kt] = A.rk4[((size_t)a * EPN_KS_MAX + 16 * kt + x) * 4 + j];
+            const int jj = 16 * kt + 4 * j < A.ks ? j : 0;
+            dgc[kt] = ld4f(dG + (size_t)a * gss + 16 * kt + 4 * jj);
+        }
+#pragma unroll
+        for (int t = 0; t < NT; ++t) {
+            f32x4 tt = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int kt = 0; kt < KT; ++kt) {
+                f32x4 s = {alphaN[t], alphaN[t], alphaN[t], alphaN[t]};
+                s = mfma4(rk[kt], gB[t], s);
+#pragma unroll
+                for (int r = 0; r < 4; ++r) tt = mfma4(fmaxf(s[r], 0.0f), dgc[kt][r], tt);
+            }
+            // tt: lane (x = c, j), register r -> slot n = 16t + 4j + r
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+                if (h.mul[t][r] != 0.0f) buf[(16 * t + 4 * j + r) * SS] = tt[r] * h.mul[t][r];
+        }
+        __syncthreads();
+        const float *rb = Tb + (a & 1) * E * SS;
+        for (int i = tid; i < U * 16; i += NTH) {
+            const int u = i >> 4, c = i & 15;
+            float sum = 0.0f;
+            const int k1 = off[u + 1];
+            for (int k = off[u]; k < k1; ++k) sum += rb[list[k] * SS + c];
+            atomicAdd(dcloud + ((size_t)uq[u] * A.na + a) * A.cin + c, sum);
+        }
+    }
+}
+
 // Deterministic transpose of the grouping, step 1: slab[b][p][n][a][c] = sum_k w[k][n] dG[col][c*ks + k] (no atomics).
 template <int NT, int KT, typename TG>
 __global__ __launch_bounds__(64 * NW) void inter_ungroup_slots_kernel(InterArgs A) {
@@ -1455,10 +1687,39 @@ int launch_inter_ungroup_det_mfma(const epn_inter_desc *d, const float *rk4, con
     return 0;
 }
 
-int launch_inter_ungroup_mfma(const epn_inter_desc *d, const float *rk4, const void *dG, float *dF, int bf16,
-                              hipStream_t st) {
+int launch_inter_ungroup_mfma(const epn_inter_desc *d, const float *rk4, const void *dG, float *dF, int32_t *order,
+                              int bf16, hipStream_t st) {
     InterArgs A = make_args(d, rk4);
     A.gout = static_cast<const float *>(dG); A.out = dF;
+    // LDS pre-reduced scatter over Morton-adjacent output points (see inter_ungroup_shared_kernel); kernel policy
+    // 0x400 | 1 keeps the per-slot atomic scatter for A/B measurements
+    const int nt = (d->nn + 15) / 16;
+    const int gp = nt <= 2 ? 8 : (nt <= 4 ? 4 : 2);
+    if (order && d->p2 % gp == 0 && d->p2 <= MORTON_MAX && d->p1 <= USH_TAB && kernel_policy() != (0x400 | 1)) {
+        hipLaunchKernelGGL(morton_order_kernel, dim3(d->b), dim3(1024), 0, st, d->new_xyz, d->p2, order);
+        EPN_CHECK_LAUNCH();
+        const dim3 grid((unsigned)(d->b * (d->p2 / gp)), (unsigned)(d->cin >> 4));
+#define EPN_USH(NT_, KT_, GP_)                                                                                            \
+    do {                                                                                                                  \
+        if (bf16) hipLaunchKernelGGL((inter_ungroup_shared_kernel<NT_, KT_, __bf16, GP_>), grid, dim3(64 * GP_), 0, st, A, order); \
+        else hipLaunchKernelGGL((inter_ungroup_shared_kernel<NT_, KT_, float, GP_>), grid, dim3(64 * GP_), 0, st, A, order);      \
+    } while (0)
+        const int kt = (d->ks + 15) / 16;
+        if (kt == 1) {
+            if (nt <= 1) EPN_USH(1, 1, 8);
+            else if (nt <= 2) EPN_USH(2, 1, 8);
+            else if (nt <= 4) EPN_USH(4, 1, 4);
+            else EPN_USH(8, 1, 2);
+        } else {
+            if (nt <= 1) EPN_USH(1, 2, 8);
+            else if (nt <= 2) EPN_USH(2, 2, 8);
+            else if (nt <= 4) EPN_USH(4, 2, 4);
+            else EPN_USH(8, 2, 2);
+        }
+#undef EPN_USH
+        EPN_CHECK_LAUNCH();
+        return 0;
+    }
     const unsigned grid = (unsigned)((A.ncol + 16 * NW - 1) / (16 * NW));
     A.col_tiles_per_wg = chunks_per_row();
     const unsigned gy = (unsigned)(((d->cin >> 4) + A.col_tiles_per_wg - 1) / A.col_tiles_per_wg);

@@ -337,15 +337,16 @@ class InterSO3ConvSplitFn(torch.autograd.Function):
             mode = os.environ.get("EPN_INTER_BWD_DATA", "auto")
             if G.dtype != torch.float32 or deterministic_bwd(G.dtype):
                 mode = "split"          # bf16 features / deterministic mode: dG GEMM + (atomic-free) transpose of the grouping
-            elif mode == "auto":        # widest layers: dG GEMM + scatter beats the fused kernel (measured)
-                mode = "split" if cin * cout >= 65536 else "fused"
+            elif mode == "auto":
+                # dG GEMM + LDS-pre-reduced scatter (epn_inter_ungroup) against the fused kernel, measured per layer of
+                # the ModelNet schedule at B=32: 64->64 4.28 vs 4.13 ms, 64->128 3.41 vs 3.57, 128->128 5.61 vs 5.73,
+                # 128->256 4.77 vs 5.45, 256->256 split only
+                mode = "split" if cin * cout >= 8192 else "fused"
             if mode == "fused" and lib.epn_inter_is_fused(ctypes.byref(d)) and cin >= 16:
-                # The fused data-gradient kernel (W^T dOut + per-column tail in one pass, no dG tensor) beats
-                # dG-GEMM + ungroup (36 vs 39 ms per step).  Both end in the same fp32 atomic scatter -- cols*K*cin =
-                # 1.0e9 atomics for every layer, ~3.3 ms per layer at the L2 atomic units -- and the fused kernel hides
-                # most of it under its MFMA phases.  Also measured and dropped: an atomic-free CSR-gather transpose
-                # (re-reads every 96-byte dG row K times: 3x slower) and running the weight-gradient GEMM on a side
-                # stream underneath the scatter (no overlap materialises: +-1 ms).
+                # The fused data-gradient kernel (W^T dOut + per-column tail in one pass, no dG tensor): its fp32 atomic
+                # scatter -- cols*K*cin = 1.0e9 atomics per layer -- hides under the MFMA phases.  Also measured and
+                # dropped: an atomic-free CSR-gather transpose (re-reads every 96-byte dG row K times: 3x slower) and
+                # running the weight-gradient GEMM on a side stream underneath the scatter (no overlap: +-1 ms).
                 ws, wsp, wsn = _workspace(lib, d, G.device)
                 _lib.check(_launch("inter_bwd_data", _inter_key(d), _inter_flops(d), G.device,
                                    lambda: lib.epn_inter_so3conv_bwd_data_f32(ctypes.byref(d), _cl_ptr(g),

@@ -37,7 +37,9 @@ const char *epn_version(void);
 const char *epn_strerror(int code);
 /* Cross-check switch, the library's only process-wide state (a relaxed atomic; default 0): 0 = every entry point picks
  * its best kernel, 1 = the any-shape generic kernels everywhere (an independent on-device implementation used by the
- * parity tests).  Not for production use; set it before launching from other threads. */
+ * parity tests).  Not for production use; set it before launching from other threads.  Values 0x100|v .. 0x400|v are
+ * A/B switches of the tuning tools (tools/gemm_bench.py, tools/step_breakdown.py): GEMM tile overrides, and 0x401 =
+ * per-slot atomic scatter in epn_inter_ungroup_* instead of the LDS-pre-reduced one. */
 int epn_set_kernel_policy(int policy);
 
 /* ------------------------------------------------------------------ index kernels ---------- */
@@ -182,6 +184,9 @@ int epn_initial_anchor_query_f32(const float *centers, const float *xyz, const f
  *   grouped f32[b*p2*na][cin*ks]   row = column (b, p, a), element c*ks + k  -- the reference's [b, c, ks, p2, na] tensor
  *                                  with the (c, ks) axes last, so  out_cl[col][o] = grouped[col][:] . W[o][:]
  * epn_inter_ungroup_f32 is the transpose: grad_feats_cl[b][idx][a][c] += sum_k w * grad_grouped (zero-fills first).
+ * Its workgroups take 8 output points that are neighbours in space (Morton order of new_xyz, computed into the
+ * workspace), sum the contributions of the slots that name the same input point in LDS and issue one fp32 atomic per
+ * distinct (input point, anchor, channel): ~3x fewer atomics than one per slot.
  * cout / dense_w of the descriptor are ignored (dense_w must be NULL).  Neither inter_w nor the gathered neighbour
  * features are materialised; the fused entry points above additionally avoid `grouped` itself (inference, or when
  * HBM is short: `grouped` is cin*ks*4 bytes per column, 6 GB for a 64-channel layer at B=32). */

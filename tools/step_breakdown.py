@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Per-call breakdown of one training step of the cls network (HIP events around every C-ABI call and library GEMM):
-which layer / shape costs what.  usage: tools/step_breakdown.py [substring filter]"""
+which layer / shape costs what.  usage: [EPN_SB_DTYPE=bf16] [EPN_SB_POLICY=0x401] tools/step_breakdown.py [substring filter]"""
 import collections
 import os
 import sys
@@ -8,11 +8,16 @@ import sys
 import torch
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-from epn_pointcloud_amd import models as M, schedule as S, ops  # noqa: E402
+from epn_pointcloud_amd import models as M, schedule as S, ops, _lib  # noqa: E402
+
+if os.environ.get("EPN_SB_POLICY"):
+    _lib.check(_lib.get_lib().epn_set_kernel_policy(int(os.environ["EPN_SB_POLICY"], 0)), "set_kernel_policy")
 
 flt = sys.argv[1] if len(sys.argv) > 1 else ""
 dev = torch.device("cuda", 0)
 model = M.ClsSO3ConvModel(S.cls_so3net_schedule(1024), out_mlps=(256,), pooling="attention").to(dev).train()
+if os.environ.get("EPN_SB_DTYPE") == "bf16":
+    S.set_feature_dtype(model, torch.bfloat16)
 pts = S.synthetic_clouds(32, 1024, dev)
 labels = torch.arange(32, device=dev) % 40
 
