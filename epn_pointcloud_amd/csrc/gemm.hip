@@ -633,7 +633,7 @@ size_t tn_plan(GemmTnBatch &B, int *bn1_out, int *bn2_out, void *ws) {
         min2 = B.p[i].N2 < min2 ? B.p[i].N2 : min2;
     }
     int bn1, bn2;
-    gemm_tn_tile(bf, max1, min2, &bn1, &bn2);
+    gemm_tn_tile(bf, max1, B.nprob > 1 && min2 < 256 ? 256 : min2, &bn1, &bn2);   // groups: the wide tiles
     *bn1_out = bn1; *bn2_out = bn2;
     long long tiles[GEMM_MAX_PROB], chunks[GEMM_MAX_PROB];
     for (int i = 0; i < B.nprob; ++i) {
@@ -709,6 +709,10 @@ int launch_tn_typed(GemmTnBatch &B, void *ws, size_t ws_bytes, hipStream_t st) {
             if ((pol & 0xff) == 2 && bn2 == 512) { hipLaunchKernelGGL((gemm_tn_f32_kernel<1, 8, 4, 2, 16>), grid, dim3(512), 0, st, B); EPN_CHECK_LAUNCH(); goto launched; }
         }
         if (bn1 == 32) hipLaunchKernelGGL((gemm_tn_f32_kernel<1, 8, 1, 2, 32>), grid, dim3(512), 0, st, B);
+        else if (bn1 == 64 && bn2 == 64) hipLaunchKernelGGL((gemm_tn_f32_kernel<2, 2, 1, 1, 32>), grid, dim3(256), 0, st, B);
+        else if (bn1 == 64 && bn2 == 128) hipLaunchKernelGGL((gemm_tn_f32_kernel<2, 2, 1, 2, 32>), grid, dim3(256), 0, st, B);
+        else if (bn1 == 128 && bn2 == 64) hipLaunchKernelGGL((gemm_tn_f32_kernel<2, 2, 2, 1, 32>), grid, dim3(256), 0, st, B);
+        else if (bn1 == 128 && bn2 == 128) hipLaunchKernelGGL((gemm_tn_f32_kernel<2, 2, 2, 2, 32>), grid, dim3(256), 0, st, B);
         else if (bn1 == 64 && bn2 == 512) hipLaunchKernelGGL((gemm_tn_f32_kernel<1, 4, 2, 4, 16>), grid, dim3(256), 0, st, B);
         else if (bn1 == 64) hipLaunchKernelGGL((gemm_tn_f32_kernel<1, 8, 2, 1, 32>), grid, dim3(512), 0, st, B);
         else if (bn2 == 512) hipLaunchKernelGGL((gemm_tn_f32_kernel<1, 8, 4, 2, 32>), grid, dim3(512), 0, st, B);
@@ -746,9 +750,10 @@ void gemm_tn_tile(bool bf16, int N1, int N2, int *bn1, int *bn2) {
     } else {
         // wide outputs (dW of the inter convolutions: N2 = cin*ks): 512-column tiles, 8 MFMAs per pair of LDS reads;
         // narrow ones (spectral blocks, 1x1 convolutions): 256-column tiles
+        // narrow single problems (dW of the 1x1 convolutions: N2 = cin <= 128): 64- / 128-column tiles, 4 waves
         if (N1 <= 32) { *bn1 = 32; *bn2 = 512; }
-        else if (N1 <= 64) { *bn1 = 64; *bn2 = N2 >= 512 ? 512 : 256; }
-        else { *bn1 = 128; *bn2 = N2 >= 512 ? 512 : 256; }
+        else if (N1 <= 64) { *bn1 = 64; *bn2 = N2 >= 512 ? 512 : (N2 > 128 ? 256 : (N2 > 64 ? 128 : 64)); }
+        else { *bn1 = 128; *bn2 = N2 >= 512 ? 512 : (N2 > 128 ? 256 : (N2 > 64 ? 128 : 64)); }
     }
 }
 

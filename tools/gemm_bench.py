@@ -27,6 +27,7 @@ def main():
     ap.add_argument("--dtype", default="f32")
     ap.add_argument("--quick", action="store_true")
     ap.add_argument("--one", default="", help="profile mode: 'nt:M,N,K' or 'tn:R,N1,N2' -> 3 launches of that problem (own + torch)")
+    ap.add_argument("--set", default="all", help="all | small (the narrow 1x1-convolution shapes only)")
     ap.add_argument("--cfg", type=int, default=0, help="NT tile override (csrc/gemm.hip launch_nt_typed), 0 = heuristic")
     a = ap.parse_args()
     if a.cfg:
@@ -74,7 +75,10 @@ def main():
     if a.quick:
         return
 
-    nt_shapes = [(983040, 64, 1536), (491520, 128, 1536), (491520, 128, 3072), (245760, 256, 3072), (245760, 256, 6144),
+    small = a.set == "small"
+    nt_shapes = [(983040, 64, 64), (491520, 128, 128), (245760, 128, 256), (491520, 64, 128), (245760, 256, 256),
+                 (122880, 256, 256), (245760, 256, 128), (491520, 128, 64)] if small else \
+                [(983040, 64, 1536), (491520, 128, 1536), (491520, 128, 3072), (245760, 256, 3072), (245760, 256, 6144),
                  (122880, 256, 6144), (245760, 6144, 256), (983040, 64, 64), (1966080, 32, 768), (1966080, 768, 32), (1966080, 32, 32)]
     for (M, N, K) in nt_shapes:
         A = torch.randn(M, K, device=dev).to(dt)
@@ -87,7 +91,9 @@ def main():
         fl = 2.0 * M * N * K
         print(f"NT  {M}x{N}x{K}: own {t0:.3f} ms {fl / t0 / 1e9:.1f} TF | torch {t1:.3f} ms {fl / t1 / 1e9:.1f} TF | diff {err:.1e}")
         del A, B, C, ref
-    tn_shapes = [(983040, 64, 1536), (491520, 128, 1536), (491520, 128, 3072), (245760, 256, 3072), (245760, 256, 6144),
+    tn_shapes = [(491520, 128, 128), (245760, 256, 256), (245760, 256, 128), (491520, 128, 64), (983040, 64, 64),
+                 (122880, 256, 256)] if small else \
+                [(983040, 64, 1536), (491520, 128, 1536), (491520, 128, 3072), (245760, 256, 3072), (245760, 256, 6144),
                  (122880, 256, 6144), (983040, 64, 64)]
     for (R, N1, N2) in tn_shapes:
         X = torch.randn(R, N1, device=dev).to(dt)
@@ -100,6 +106,8 @@ def main():
         fl = 2.0 * R * N1 * N2
         print(f"TN  {R}x{N1}x{N2}: own {t0:.3f} ms {fl / t0 / 1e9:.1f} TF | torch {t1:.3f} ms {fl / t1 / 1e9:.1f} TF | diff {err:.1e}")
         del X, Y, C, ref
+    if small:
+        return
     # grouped spectral blocks (cin = cout = c): M = pts*d, K = N = d*c
     for pts, c in [(16384, 64), (8192, 128), (4096, 256)]:
         probs, fl = [], 0.0
