@@ -204,20 +204,27 @@ def main():
 
     # gradients live in one flat buffer cut into per-stage buckets (dp.GradBuckets): zero() instead of zero_grad, the
     # all-reduce runs on slices of it -- issued from backward hooks (eager) or right after the replayed graph
-    buckets = None if args.forward_only else dp.GradBuckets(dp.stage_buckets(model), world, hooks=False)
+    # (world > 1 only: a single rank lets autograd hand its gradient tensors to p.grad directly -- no per-parameter
+    # accumulate kernel, no zero fill)
+    buckets = None if args.forward_only or world == 1 else dp.GradBuckets(dp.stage_buckets(model), world, hooks=False)
 
     def compute():                      # the hot path: forward (+ loss + backward)
         if args.forward_only:
             with torch.no_grad():
                 return loss_of(model(pts))
-        buckets.zero()
+        if buckets is not None:
+            buckets.zero()
+        else:
+            for p in params:
+                p.grad = None
         loss = loss_of(model(pts))
         loss.backward()
         return loss
 
     def finish():
         if not args.forward_only:
-            buckets.finish()
+            if buckets is not None:
+                buckets.finish()
             opt.step()
 
     def eager_step():

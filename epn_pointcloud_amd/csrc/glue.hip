@@ -22,6 +22,7 @@ struct NormArgs {
 };
 
 typedef __bf16 gbf16x4 __attribute__((ext_vector_type(4)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ f32x4 ld4(const float *p) { return *reinterpret_cast<const f32x4 *>(p); }
 __device__ __forceinline__ f32x4 ld4(const __bf16 *p) {
     const gbf16x4 v = *reinterpret_cast<const gbf16x4 *>(p);
@@ -99,8 +100,17 @@ __global__ __launch_bounds__(256) void stats_finish_kernel(const float *__restri
     const int el = threadIdx.x & 15, sl = threadIdx.x >> 4;
     const int g = blockIdx.y, e = blockIdx.x * 16 + el;
     float acc = 0.f;
-    if (e < c2)
-        for (int b = sl; b < nb; b += 16) acc += part[((size_t)g * nb + b) * c2 + e];
+    if (e < c2) {
+        // 8 independent loads in flight per thread (a dependent chain of nb/16 strided loads cost ~30 us per launch)
+        const float *p = part + (size_t)g * nb * c2 + e;
+        float a8[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+        int b = sl;
+        for (; b + 112 < nb; b += 128)
+#pragma unroll
+            for (int u = 0; u < 8; ++u) a8[u] += p[(size_t)(b + 16 * u) * c2];
+        for (; b < nb; b += 16) a8[0] += p[(size_t)b * c2];
+        acc = ((a8[0] + a8[1]) + (a8[2] + a8[3])) + ((a8[4] + a8[5]) + (a8[6] + a8[7]));
+    }
     red[sl][el] = acc;
     __syncthreads();
     if (sl == 0 && e < c2) {
@@ -118,12 +128,23 @@ __global__ __launch_bounds__(256) void bwd_finish_kernel(const float *__restrict
     const int el = threadIdx.x & 15, sl = threadIdx.x >> 4;
     const int g = blockIdx.y, ch = blockIdx.x * 16 + el;
     float sa = 0.f, sb = 0.f;
-    if (ch < c)
-        for (int b = sl; b < nb; b += 16) {
-            const float *p = part + (((size_t)g * nb + b) * c + ch) * 2;
-            sa += p[0];
-            sb += p[1];
+    if (ch < c) {
+        const float *p0 = part + ((size_t)g * nb * c + ch) * 2;
+        f32x2 a4[4] = {{0.f, 0.f}, {0.f, 0.f}, {0.f, 0.f}, {0.f, 0.f}};
+        int b = sl;
+        for (; b + 48 < nb; b += 64)
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const f32x2 v = *reinterpret_cast<const f32x2 *>(p0 + (size_t)(b + 16 * u) * c * 2);
+                a4[u][0] += v[0]; a4[u][1] += v[1];
+            }
+        for (; b < nb; b += 16) {
+            const f32x2 v = *reinterpret_cast<const f32x2 *>(p0 + (size_t)b * c * 2);
+            a4[0][0] += v[0]; a4[0][1] += v[1];
         }
+        sa = (a4[0][0] + a4[1][0]) + (a4[2][0] + a4[3][0]);
+        sb = (a4[0][1] + a4[1][1]) + (a4[2][1] + a4[3][1]);
+    }
     red[sl][0][el] = sa;
     red[sl][1][el] = sb;
     __syncthreads();

@@ -7,9 +7,10 @@ unchanged.
     InvSO3ConvModel   SPConvNets/models/inv_so3net_pn.py:15-41     3DMatch invariant descriptor (InvOutBlockMVD)
 
 The backbones are schedule.BasicBlock stages (fused HIP convolutions + HIP block glue); every head aggregates over
-points with PointnetSO3Conv, which is one fused HIP pass (epn_pointnet_so3conv_*_f32).  What remains on torch are the
-per-anchor tails on [b, c, a]-sized tensors (BatchNorm1d, the attention Conv1d + softmax, the final Linear) and, for
-the pair head, the 60 x 60 anchor-pair MLP.
+points with PointnetSO3Conv, which is one fused HIP pass (epn_pointnet_so3conv_*_f32); the heads' 1x1 convolutions
+and Linear layers (attention logits, class logits, the pair head's 60 x 60 anchor-pair MLP) run on the library's GEMMs
+(ops.conv1x1 / ops.linear).  What remains on torch are elementwise tails on [b, c, a]-sized tensors (BatchNorm1d,
+softmax, relu).
 """
 import torch
 import torch.nn as nn
@@ -57,11 +58,13 @@ class ClsOutBlockPointnet(nn.Module):
         elif self.pooling_method == 'max':
             y = y.max(2)[0]
         elif self.pooling_method.startswith('attention'):
-            out_feat = self.attention_layer(y)                              # [b, 1, a]
+            nb, c, na = y.shape                                             # Conv1d(c, 1, 1) as a GEMM over (b, a) rows
+            att = self.attention_layer
+            out_feat = ops.linear(y.transpose(1, 2).reshape(nb * na, c), att.weight, att.bias).view(nb, 1, na)
             y = (y * F.softmax(out_feat * self.temperature, dim=2)).sum(-1)
         else:
             raise NotImplementedError(f"Pooling mode {self.pooling_method} is not implemented!")
-        return self.fc2(y), out_feat.squeeze()
+        return ops.linear(y, self.fc2.weight, self.fc2.bias), out_feat.squeeze()
 
 
 class InvOutBlockMVD(nn.Module):

@@ -1029,6 +1029,24 @@ def conv1x1(x, weight, bias=None):
     return y if bias is None else y + bias.view(1, -1, 1, 1)
 
 
+def linear(x, weight, bias=None):
+    """nn.Linear / a 1x1 convolution on rows: x [rows, cin] @ weight[cout, cin]^T (+ bias) on the library's NT / TN GEMMs
+    (fp32, cin % 16 == 0; output widths padded to whole 8-channel groups as in conv1x1).  The per-anchor tails of the
+    heads (attention logits, class logits) go through this instead of MIOpen / BLAS."""
+    cout, cin = weight.shape[0], weight.shape[1]
+    w2 = weight.reshape(cout, cin)
+    if x.is_cuda and x.dtype == torch.float32 and cin % 16 == 0:
+        pad = (-cout) % 8
+        if pad:
+            w2 = torch.cat((w2, w2.new_zeros(pad, cin)), 0)
+        y = gemm.matmul_nt(x.contiguous(), w2)
+        if pad:
+            y = y[:, :cout]
+    else:
+        y = torch.nn.functional.linear(x.float(), w2)
+    return y if bias is None else y + bias
+
+
 def pointnet_so3conv(feats, xyz, anchors, weight, bias):
     """bf16 features are converted once (the aggregation tail is < 1 % of a step and runs its fp32 kernels)."""
     return PointnetSO3ConvFn.apply(cast_feats(feats, torch.float32), xyz, anchors, weight, bias)
