@@ -17,6 +17,7 @@
 // Fragment layouts (verified on hardware by tools/mfma_probe.hip): lane l, x = l & 15, j = l >> 4:
 //   A[m = x][k = j],  B[k = j][n = x],  D[m = 4j + r][n = x]  (r = register 0..3).
 #include <cstdlib>
+#include <type_traits>
 
 #include "conv_internal.h"
 #include "gemm.h"
@@ -59,6 +60,24 @@ __device__ __forceinline__ f32x4 ld4f(const __bf16 *p) {
 __device__ __forceinline__ void st4f(float *p, f32x4 v) { *reinterpret_cast<f32x4 *>(p) = v; }
 __device__ __forceinline__ void st4f(__bf16 *p, f32x4 v) {
     *reinterpret_cast<bf16x4_t *>(p) = bf16x4_t{(__bf16)v[0], (__bf16)v[1], (__bf16)v[2], (__bf16)v[3]};
+}
+
+// bf16 feature path: the neighbour contraction runs on the bf16 MFMAs.  The weight MFMA's D fragment (lane (x, j),
+// registers 0..3 = four consecutive contraction indices) is, rounded to bf16 and packed, exactly the A fragment of
+// v_mfma_f32_16x16x16_bf16 (A[m = x][k = 4j + r]); two such fragments side by side feed v_mfma_f32_16x16x32_bf16
+// (k = 8j + e: any bijection works as long as A and B use the same one).  Accumulation stays fp32.
+typedef short s16x4 __attribute__((ext_vector_type(4)));
+typedef __bf16 bf16x8_t __attribute__((ext_vector_type(8)));
+__device__ __forceinline__ bf16x4_t relu_pack4(f32x4 s) {
+    return bf16x4_t{(__bf16)fmaxf(s[0], 0.0f), (__bf16)fmaxf(s[1], 0.0f), (__bf16)fmaxf(s[2], 0.0f), (__bf16)fmaxf(s[3], 0.0f)};
+}
+__device__ __forceinline__ f32x4 mfma_bf16_k16(bf16x4_t a, bf16x4_t b, f32x4 c) {
+    return __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(__builtin_bit_cast(s16x4, a), __builtin_bit_cast(s16x4, b), c, 0, 0, 0);
+}
+__device__ __forceinline__ f32x4 mfma_bf16_k32(bf16x4_t a0, bf16x4_t a1, bf16x4_t b0, bf16x4_t b1, f32x4 c) {
+    const bf16x8_t a = {a0[0], a0[1], a0[2], a0[3], a1[0], a1[1], a1[2], a1[3]};
+    const bf16x8_t b = {b0[0], b0[1], b0[2], b0[3], b1[0], b1[1], b1[2], b1[3]};
+    return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0);
 }
 
 // Per-point neighbourhood fragments, shared by all columns (anchors) of one output point.
@@ -200,10 +219,55 @@ __device__ __forceinline__ void load_f(const InterArgs &A, const Seg<NT> &sg, in
         for (int r = 0; r < 4; ++r) f[t][r] = (float)fb[sg.h.q[t][r]];
 }
 
+// bf16 features: raw 16-bit neighbour values of one column, packed four to a B fragment (masked slots zeroed)
+template <int NT>
+__device__ __forceinline__ void load_f_raw(const InterArgs &A, const Seg<NT> &sg, int a, int coff, bf16x4_t (&f)[NT]) {
+    const __bf16 *fb = reinterpret_cast<const __bf16 *>(sg.fbase) + (size_t)a * A.cin + coff;
+#pragma unroll
+    for (int t = 0; t < NT; ++t)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) f[t][r] = sg.h.ok[t][r] ? fb[sg.h.q[t][r]] : (__bf16)0.0f;
+}
+
+template <int NT, int KT>
+__device__ __forceinline__ void group_segment_bf16(const InterArgs &A, const Seg<NT> &sg, int ct, int x, int j,
+                                                   __bf16 *Gs, int gss) {
+    const int coff = 16 * ct + x;
+    bf16x4_t fcur[NT], fnext[NT];
+    load_f_raw<NT>(A, sg, sg.a0, coff, fcur);
+    for (int i = 0; i < sg.cnt; ++i) {
+        const int a = sg.a0 + i;
+        const int an = i + 1 < sg.cnt ? a + 1 : a;
+        load_f_raw<NT>(A, sg, an, coff, fnext);
+        f32x4 w[KT][NT];
+        make_weights<NT, KT>(A, a, x, j, sg.h, w);     // relu already applied
+#pragma unroll
+        for (int kt = 0; kt < KT; ++kt) {
+            f32x4 g = {0.f, 0.f, 0.f, 0.f};
+            if constexpr (NT % 2 == 0) {
+#pragma unroll
+                for (int t = 0; t < NT; t += 2)
+                    g = mfma_bf16_k32(relu_pack4(w[kt][t]), relu_pack4(w[kt][t + 1]), fcur[t], fcur[t + 1], g);
+            } else {
+#pragma unroll
+                for (int t = 0; t < NT; ++t) g = mfma_bf16_k16(relu_pack4(w[kt][t]), fcur[t], g);
+            }
+            if (16 * kt + 4 * j < A.ks)
+                st4f(Gs + (sg.jc0 + i) * gss + x * A.ks + 16 * kt + 4 * j, g);
+        }
+#pragma unroll
+        for (int t = 0; t < NT; ++t) fcur[t] = fnext[t];
+    }
+}
+
 template <int NT, int KT, typename TF = float>
 __device__ __forceinline__ void group_segment(const InterArgs &A, const Seg<NT> &sg, int ct, int x, int j,
                                               TF *Gs, int gss) {
     if (sg.cnt <= 0) return;
+    if constexpr (sizeof(TF) == 2) {
+        group_segment_bf16<NT, KT>(A, sg, ct, x, j, Gs, gss);
+        return;
+    }
     const int coff = 16 * ct + x;
     float fcur[NT][4], fnext[NT][4];
     load_f<NT, TF>(A, sg, sg.a0, coff, fcur);
@@ -1266,22 +1330,35 @@ __global__ __launch_bounds__(64 * GP) void inter_ungroup_shared_kernel(InterArgs
     for (int a = 0; a < A.na; ++a) {
         float *buf = Tb + (a & 1) * E * SS + wave * EW * SS + x;
         float rk[KT];
-        f32x4 dgc[KT];
+        typename std::conditional<sizeof(TG) == 2, bf16x4_t, f32x4>::type dgc[KT];
 #pragma unroll
         for (int kt = 0; kt < KT; ++kt) {
             rk[kt] = A.rk4[((size_t)a * EPN_KS_MAX + 16 * kt + x) * 4 + j];
             const int jj = 16 * kt + 4 * j < A.ks ? j : 0;
-            dgc[kt] = ld4f(dG + (size_t)a * gss + 16 * kt + 4 * jj);
+            if constexpr (sizeof(TG) == 2) dgc[kt] = *reinterpret_cast<const bf16x4_t *>(dG + (size_t)a * gss + 16 * kt + 4 * jj);
+            else dgc[kt] = ld4f(dG + (size_t)a * gss + 16 * kt + 4 * jj);
         }
 #pragma unroll
         for (int t = 0; t < NT; ++t) {
             f32x4 tt = {0.f, 0.f, 0.f, 0.f};
+            if constexpr (sizeof(TG) == 2) {
+                // bf16 dG: the contraction over the kernel points on the bf16 MFMA (both 16-point tiles in one K = 32)
+                f32x4 sk[KT];
 #pragma unroll
-            for (int kt = 0; kt < KT; ++kt) {
-                f32x4 s = {alphaN[t], alphaN[t], alphaN[t], alphaN[t]};
-                s = mfma4(rk[kt], gB[t], s);
+                for (int kt = 0; kt < KT; ++kt) {
+                    sk[kt] = f32x4{alphaN[t], alphaN[t], alphaN[t], alphaN[t]};
+                    sk[kt] = mfma4(rk[kt], gB[t], sk[kt]);
+                }
+                if constexpr (KT == 2) tt = mfma_bf16_k32(relu_pack4(sk[0]), relu_pack4(sk[1]), dgc[0], dgc[1], tt);
+                else tt = mfma_bf16_k16(relu_pack4(sk[0]), dgc[0], tt);
+            } else {
 #pragma unroll
-                for (int r = 0; r < 4; ++r) tt = mfma4(fmaxf(s[r], 0.0f), dgc[kt][r], tt);
+                for (int kt = 0; kt < KT; ++kt) {
+                    f32x4 s = {alphaN[t], alphaN[t], alphaN[t], alphaN[t]};
+                    s = mfma4(rk[kt], gB[t], s);
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) tt = mfma4(fmaxf(s[r], 0.0f), dgc[kt][r], tt);
+                }
             }
             // tt: lane (x = c, j), register r -> slot n = 16t + 4j + r
 #pragma unroll
