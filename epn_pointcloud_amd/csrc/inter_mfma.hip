@@ -1206,7 +1206,7 @@ __global__ __launch_bounds__(1024) void morton_order_kernel(const float *__restr
 // tile is double-buffered over anchors: one barrier per column.  (ds_add_f32 into a shared accumulator was measured at
 // ~1 lane per clock on gfx950 -- 2x slower than the global atomics it replaced; hence stores + a gather-sum.)
 constexpr int USH_TAB = 4096;   // destinations are de-duplicated through a direct-address table: p1 <= USH_TAB
-template <int NT, int KT, typename TG, int GP>
+template <int NT, int KT, typename TG, int GP, int NB = 2>   // NB tile buffers: 2 = one barrier per column, 1 = two (half the LDS)
 __global__ __launch_bounds__(64 * GP) void inter_ungroup_shared_kernel(InterArgs A, const int32_t *__restrict__ order) {
     constexpr int EW = 16 * NT;        // neighbour slots per point (padded)
     constexpr int E = GP * EW;         // slots of the workgroup (128 or 256)
@@ -1221,9 +1221,9 @@ __global__ __launch_bounds__(64 * GP) void inter_ungroup_shared_kernel(InterArgs
     __shared__ int off[E + 1];         // CSR over distinct destinations ...
     __shared__ int list[E];            // ... of the slots that feed them
     __shared__ int chunk_cnt[CH];
-    __shared__ __attribute__((aligned(16))) float Tb[2 * E * SS];
+    __shared__ __attribute__((aligned(16))) float Tb[NB * E * SS];
     int *tab = reinterpret_cast<int *>(Tb);   // set-up only: input point -> first slot naming it
-    static_assert(2 * E * SS >= USH_TAB, "direct-address table must fit the tile buffers");
+    static_assert(NB * E * SS >= USH_TAB, "direct-address table must fit the tile buffers");
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -1328,7 +1328,7 @@ __global__ __launch_bounds__(64 * GP) void inter_ungroup_shared_kernel(InterArgs
     const TG *dG = reinterpret_cast<const TG *>(A.gout) + ((size_t)bb * A.p2 + pp) * A.na * gss + (size_t)(16 * ct + x) * A.ks;
     float *dcloud = A.out + ((size_t)bb * A.p1) * A.na * A.cin + 16 * ct;
     for (int a = 0; a < A.na; ++a) {
-        float *buf = Tb + (a & 1) * E * SS + wave * EW * SS + x;
+        float *buf = Tb + (a & (NB - 1)) * E * SS + wave * EW * SS + x;
         float rk[KT];
         typename std::conditional<sizeof(TG) == 2, bf16x4_t, f32x4>::type dgc[KT];
 #pragma unroll
@@ -1366,7 +1366,7 @@ __global__ __launch_bounds__(64 * GP) void inter_ungroup_shared_kernel(InterArgs
                 if (h.mul[t][r] != 0.0f) buf[(16 * t + 4 * j + r) * SS] = tt[r] * h.mul[t][r];
         }
         __syncthreads();
-        const float *rb = Tb + (a & 1) * E * SS;
+        const float *rb = Tb + (a & (NB - 1)) * E * SS;
         for (int i = tid; i < U * 16; i += NTH) {
             const int u = i >> 4, c = i & 15;
             float sum = 0.0f;
@@ -1374,6 +1374,7 @@ __global__ __launch_bounds__(64 * GP) void inter_ungroup_shared_kernel(InterArgs
             for (int k = off[u]; k < k1; ++k) sum += rb[list[k] * SS + c];
             atomicAdd(dcloud + ((size_t)uq[u] * A.na + a) * A.cin + c, sum);
         }
+        if constexpr (NB == 1) __syncthreads();
     }
 }
 
@@ -1778,8 +1779,8 @@ int launch_inter_ungroup_mfma(const epn_inter_desc *d, const float *rk4, const v
         const dim3 grid((unsigned)(d->b * (d->p2 / gp)), (unsigned)(d->cin >> 4));
 #define EPN_USH(NT_, KT_, GP_)                                                                                            \
     do {                                                                                                                  \
-        if (bf16) hipLaunchKernelGGL((inter_ungroup_shared_kernel<NT_, KT_, __bf16, GP_>), grid, dim3(64 * GP_), 0, st, A, order); \
-        else hipLaunchKernelGGL((inter_ungroup_shared_kernel<NT_, KT_, float, GP_>), grid, dim3(64 * GP_), 0, st, A, order);      \
+        if (bf16) hipLaunchKernelGGL((inter_ungroup_shared_kernel<NT_, KT_, __bf16, GP_, (GP_ < 8 ? 1 : 2)>), grid, dim3(64 * GP_), 0, st, A, order); \
+        else hipLaunchKernelGGL((inter_ungroup_shared_kernel<NT_, KT_, float, GP_, (GP_ < 8 ? 1 : 2)>), grid, dim3(64 * GP_), 0, st, A, order);      \
     } while (0)
         const int kt = (d->ks + 15) / 16;
         if (kt == 1) {
