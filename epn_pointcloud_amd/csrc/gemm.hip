@@ -484,14 +484,43 @@ __global__ __launch_bounds__(64 * WGM * WGN) void gemm_tn_bf16_kernel(GemmTnBatc
             }
 }
 
-// sum the split partials in a fixed order (deterministic): C[i] = sum_s part[s][i]
-__global__ void gemm_tn_reduce_kernel(GemmTnBatch B) {      // blockIdx.y = problem
+// sum the split partials in a fixed order (deterministic): C[i] = sum_s part[s][i].  Streaming: 16-byte loads, eight
+// splits in flight per thread (a scalar loop over the splits ran at a third of the HBM rate).
+__global__ __launch_bounds__(256) void gemm_tn_reduce_kernel(GemmTnBatch B) {      // blockIdx.y = problem
     const GemmTnArgs &G = B.p[blockIdx.y];
     if (G.nsplit <= 1) return;
     const float *__restrict__ part = static_cast<const float *>(G.part);
     float *__restrict__ C = static_cast<float *>(G.C);
     const size_t n = (size_t)G.N1 * G.N2;
-    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+    const size_t stride = (size_t)gridDim.x * blockDim.x;
+    if ((G.N2 & 3) == 0 && (G.ldc & 3) == 0 && !((uintptr_t)C & 15)) {
+        const size_t n4 = n >> 2;
+        for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += stride) {
+            const f32x4 *p = reinterpret_cast<const f32x4 *>(part) + i;
+            f32x4 a[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) a[u] = f32x4{0.f, 0.f, 0.f, 0.f};
+            int k = 0;
+            for (; k + 8 <= G.nsplit; k += 8)
+#pragma unroll
+                for (int u = 0; u < 8; ++u) {
+                    const f32x4 v = p[(size_t)(k + u) * n4];
+                    a[u][0] += v[0]; a[u][1] += v[1]; a[u][2] += v[2]; a[u][3] += v[3];
+                }
+            for (; k < G.nsplit; ++k) {
+                const f32x4 v = p[(size_t)k * n4];
+                a[0][0] += v[0]; a[0][1] += v[1]; a[0][2] += v[2]; a[0][3] += v[3];
+            }
+            f32x4 r;
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+                r[e] = ((a[0][e] + a[1][e]) + (a[2][e] + a[3][e])) + ((a[4][e] + a[5][e]) + (a[6][e] + a[7][e]));
+            const size_t e0 = i << 2;
+            *reinterpret_cast<f32x4 *>(C + (e0 / G.N2) * G.ldc + (e0 % G.N2)) = r;
+        }
+        return;
+    }
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
         float s = 0.f;
         for (int k = 0; k < G.nsplit; ++k) s += part[(size_t)k * n + i];
         C[(i / G.N2) * G.ldc + (i % G.N2)] = s;
@@ -732,7 +761,8 @@ launched:
         nmax = n > nmax ? n : nmax;
     }
     if (any_split) {
-        const unsigned gx = (unsigned)((nmax + 255) / 256 < 1024 ? (nmax + 255) / 256 : 1024);
+        const size_t nv = (nmax + 3) / 4;               // one thread per four outputs
+        const unsigned gx = (unsigned)((nv + 255) / 256 < 2048 ? (nv + 255) / 256 : 2048);
         hipLaunchKernelGGL(gemm_tn_reduce_kernel, dim3(gx, B.nprob), dim3(256), 0, st, B);
         EPN_CHECK_LAUNCH();
     }

@@ -856,9 +856,27 @@ def inter_so3conv(feats, W, geo, out_dtype=None):
         return cast_feats(InterSO3ConvSplitFn.apply(feats, W, geo), out_dtype)
     if feats.dtype != torch.float32:         # shapes only the fp32 fused / generic kernels take
         feats = cast_feats(feats, torch.float32)
+    if split_ok and mode == "auto" and feats.is_cuda:
+        # the split form keeps grouped[cols, cin*ks] (and its gradient) alive: 6 GB per layer at B=32 on the ModelNet
+        # schedule.  A layer whose grouped tensor would take more than an eighth of the device falls back to the fused
+        # kernels, which never materialise it (small-memory parts, very large batches).
+        d_b, d_p2 = geo.ball_idx.shape[0], geo.ball_idx.shape[1]
+        g_bytes = d_b * d_p2 * geo.anchors.shape[0] * feats.shape[1] * geo.kernels.shape[0] * 4
+        if g_bytes > _device_bytes(feats.device) // 8:
+            split_ok = False
     if split_ok and mode in ("split", "auto"):
         return cast_feats(InterSO3ConvSplitFn.apply(feats, W, geo), out_dtype)
     return cast_feats(InterSO3ConvFn.apply(feats, W, geo), out_dtype)
+
+
+_DEVICE_BYTES = {}
+
+
+def _device_bytes(device):
+    key = torch.device(device).index or 0
+    if key not in _DEVICE_BYTES:
+        _DEVICE_BYTES[key] = torch.cuda.get_device_properties(key).total_memory
+    return _DEVICE_BYTES[key]
 
 
 def intra_mode():
