@@ -27,7 +27,7 @@ def main():
     ap.add_argument("--dtype", default="f32")
     ap.add_argument("--quick", action="store_true")
     ap.add_argument("--one", default="", help="profile mode: 'nt:M,N,K' or 'tn:R,N1,N2' -> 3 launches of that problem (own + torch)")
-    ap.add_argument("--set", default="all", help="all | small (the narrow 1x1-convolution shapes only)")
+    ap.add_argument("--set", default="all", help="all | small (the narrow 1x1-convolution shapes) | dg (short-K data-gradient GEMMs)")
     ap.add_argument("--cfg", type=int, default=0, help="NT tile override (csrc/gemm.hip launch_nt_typed), 0 = heuristic")
     a = ap.parse_args()
     if a.cfg:
@@ -75,8 +75,9 @@ def main():
     if a.quick:
         return
 
-    small = a.set == "small"
-    nt_shapes = [(983040, 64, 64), (491520, 128, 128), (245760, 128, 256), (491520, 64, 128), (245760, 256, 256),
+    small = a.set in ("small", "dg")
+    nt_shapes = [(491520, 1536, 128), (491520, 3072, 128), (245760, 3072, 256), (245760, 6144, 256), (122880, 6144, 256),
+                 (983040, 1536, 64)] if a.set == "dg" else [(983040, 64, 64), (491520, 128, 128), (245760, 128, 256), (491520, 64, 128), (245760, 256, 256),
                  (122880, 256, 256), (245760, 256, 128), (491520, 128, 64)] if small else \
                 [(983040, 64, 1536), (491520, 128, 1536), (491520, 128, 3072), (245760, 256, 3072), (245760, 256, 6144),
                  (122880, 256, 6144), (245760, 6144, 256), (983040, 64, 64), (1966080, 32, 768), (1966080, 768, 32), (1966080, 32, 32)]
@@ -91,7 +92,7 @@ def main():
         fl = 2.0 * M * N * K
         print(f"NT  {M}x{N}x{K}: own {t0:.3f} ms {fl / t0 / 1e9:.1f} TF | torch {t1:.3f} ms {fl / t1 / 1e9:.1f} TF | diff {err:.1e}")
         del A, B, C, ref
-    tn_shapes = [(491520, 128, 128), (245760, 256, 256), (245760, 256, 128), (491520, 128, 64), (983040, 64, 64),
+    tn_shapes = [] if a.set == "dg" else [(491520, 128, 128), (245760, 256, 256), (245760, 256, 128), (491520, 128, 64), (983040, 64, 64),
                  (122880, 256, 256)] if small else \
                 [(983040, 64, 1536), (491520, 128, 1536), (491520, 128, 3072), (245760, 256, 3072), (245760, 256, 6144),
                  (122880, 256, 6144), (983040, 64, 64)]
