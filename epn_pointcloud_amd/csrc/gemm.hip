@@ -132,7 +132,8 @@ __global__ __launch_bounds__(64 * WGM * WGN) void gemm_nt_kernel(GemmNtBatch B) 
         __syncthreads();                       // stage kt has landed (vmcnt(0) rides on the barrier); buffer (kt+1)&1 is free
         const char *base = smem + (kt & 1) * (ROWS * ROWB);
         const bool more = kt + 1 < nk;
-        if constexpr (sizeof(T) != 4) {
+        constexpr bool BURST = sizeof(T) != 4 || BN <= 64;   // HBM-bound shapes: the whole next stage is requested at once
+        if constexpr (BURST) {
             if (more) stage((kt + 1) & 1);
         }
         if constexpr (sizeof(T) == 4) {
@@ -152,7 +153,7 @@ __global__ __launch_bounds__(64 * WGM * WGN) void gemm_nt_kernel(GemmNtBatch B) 
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
                     __builtin_amdgcn_sched_barrier(0);
-                    if (more) {
+                    if (more && !BURST) {
                         const int grp = 4 * s + e;
 #pragma unroll
                         for (int i = 0; i < GPW; ++i) {
@@ -676,6 +677,8 @@ int launch_nt_typed(GemmNtBatch &B, hipStream_t st) {
             case 4: return launch_nt_cfg<T, TO, 2, 4, 2, 2>(B, st);      // 128 x 256, 8 waves
             case 5: return launch_nt_cfg<T, TO, 4, 1, 2, 2>(B, st);      // 256 x 64, 4 waves
             case 6: return launch_nt_cfg<T, TO, 2, 2, 4, 2>(B, st);      // 256 x 128, 4 waves, 128 x 64 per wave
+            case 7: return launch_nt_cfg<T, TO, 8, 1, 2, 2, 4>(B, st);   // 512 x 64, half K steps: 2 workgroups / CU
+            case 8: return launch_nt_cfg<T, TO, 4, 1, 2, 2, 4>(B, st);   // 256 x 64, half K steps, 4 waves
             default: break;
         }
     }
@@ -684,6 +687,12 @@ int launch_nt_typed(GemmNtBatch &B, hipStream_t st) {
         // many-tile problems: 128 x 128 tiles, 4 waves, two workgroups per CU (measured on 491520 x 128 and 245760 x 256:
         // 130-140 TFLOP/s against 124-136 for the 256-row tiles; below ~3840 tiles the big tiles win)
         return launch_nt_cfg<T, TO, 2, 2, 2, 2>(B, st);
+    if (sizeof(T) == 4 && B.nprob > 1) {
+        // grouped spectral blocks (widths d*c, d = 1, 3, 3, 4, 5): narrow tiles waste less of the ragged widths
+        // (c = 64: 256 x 64 tiles 0.40 ms vs 0.45; c = 128 / 256: 128 x 128 tiles 0.65 / 1.22 vs 0.69 / 1.25, measured)
+        if (maxn <= 320 && minn <= 64) return launch_nt_cfg<T, TO, 4, 1, 2, 2>(B, st);
+        return launch_nt_cfg<T, TO, 2, 2, 2, 2>(B, st);
+    }
     if (maxn <= 32) return launch_nt_cfg<T, TO, 8, 1, 2, 1>(B, st);      // 512 x 32
     if (maxn <= 64) return launch_nt_cfg<T, TO, 8, 1, 2, 2>(B, st);      // 512 x 64
     if (minn >= 256 && sizeof(T) == 4) return launch_nt_cfg<T, TO, 4, 2, 2, 4>(B, st);   // 256 x 256 (fewer loads / MFMA)
