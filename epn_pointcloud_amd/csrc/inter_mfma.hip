@@ -45,6 +45,14 @@ struct InterArgs {
     int col_tiles_per_wg;  // bwd_weight only
 };
 
+// max(x, 0) as ONE instruction: the integer maximum of the bit patterns (negative floats are negative integers).
+// fmaxf(x, 0.0f) compiles to two v_max_f32 (IEEE canonicalisation of the operand first); the weight generation does
+// 16-32 of them per column and the grouping kernels are VALU-bound.
+__device__ __forceinline__ float relu_f(float x) {
+    const int b = __builtin_bit_cast(int, x);
+    return __builtin_bit_cast(float, b > 0 ? b : 0);
+}
+
 __device__ __forceinline__ f32x4 mfma4(float a, float b, f32x4 c) {
     return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0);
 }
@@ -69,7 +77,7 @@ __device__ __forceinline__ void st4f(__bf16 *p, f32x4 v) {
 typedef short s16x4 __attribute__((ext_vector_type(4)));
 typedef __bf16 bf16x8_t __attribute__((ext_vector_type(8)));
 __device__ __forceinline__ bf16x4_t relu_pack4(f32x4 s) {
-    return bf16x4_t{(__bf16)fmaxf(s[0], 0.0f), (__bf16)fmaxf(s[1], 0.0f), (__bf16)fmaxf(s[2], 0.0f), (__bf16)fmaxf(s[3], 0.0f)};
+    return bf16x4_t{(__bf16)relu_f(s[0]), (__bf16)relu_f(s[1]), (__bf16)relu_f(s[2]), (__bf16)relu_f(s[3])};
 }
 __device__ __forceinline__ f32x4 mfma_bf16_k16(bf16x4_t a, bf16x4_t b, f32x4 c) {
     return __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(__builtin_bit_cast(s16x4, a), __builtin_bit_cast(s16x4, b), c, 0, 0, 0);
@@ -153,7 +161,7 @@ __device__ __forceinline__ void make_weights(const InterArgs &A, int a, int x, i
             f32x4 s = {beta, beta, beta, beta};
             s = mfma4(h.gA[t], rk, s);
 #pragma unroll
-            for (int r = 0; r < 4; ++r) s[r] = fmaxf(s[r], 0.0f);
+            for (int r = 0; r < 4; ++r) s[r] = relu_f(s[r]);
             w[kt][t] = s;
         }
     }
@@ -219,44 +227,85 @@ __device__ __forceinline__ void load_f(const InterArgs &A, const Seg<NT> &sg, in
         for (int r = 0; r < 4; ++r) f[t][r] = (float)fb[sg.h.q[t][r]];
 }
 
-// bf16 features: raw 16-bit neighbour values of one column, packed four to a B fragment (masked slots zeroed)
+// bf16 features: raw 16-bit neighbour values of one column, two to a dword, four to a B fragment.  Addressing is a
+// wave-uniform row base plus a 32-bit lane offset (neighbour row + channel); masked slots (their offset points at row 0)
+// are zeroed by an AND with a per-point mask, so there is no branch and no 64-bit arithmetic per load.
 template <int NT>
-__device__ __forceinline__ void load_f_raw(const InterArgs &A, const Seg<NT> &sg, int a, int coff, bf16x4_t (&f)[NT]) {
-    const __bf16 *fb = reinterpret_cast<const __bf16 *>(sg.fbase) + (size_t)a * A.cin + coff;
+struct RawHood {
+    unsigned off[NT][4];     // element offset idx*na*cin + x of neighbour 16t + 4j + r
+    unsigned mask[NT][2];    // 0xffff per valid slot, packed like the values
+};
+
+template <int NT>
+__device__ __forceinline__ void make_raw_hood(const Seg<NT> &sg, int x, RawHood<NT> &rh) {
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) rh.off[t][r] = (unsigned)sg.h.q[t][r] + (unsigned)x;
+        rh.mask[t][0] = (sg.h.ok[t][0] ? 0xffffu : 0u) | (sg.h.ok[t][1] ? 0xffff0000u : 0u);
+        rh.mask[t][1] = (sg.h.ok[t][2] ? 0xffffu : 0u) | (sg.h.ok[t][3] ? 0xffff0000u : 0u);
+    }
+}
+
+template <int NT>
+__device__ __forceinline__ void load_f_raw(const unsigned short *__restrict__ rowbase, const RawHood<NT> &rh,
+                                           unsigned (&f)[NT][4]) {
 #pragma unroll
     for (int t = 0; t < NT; ++t)
 #pragma unroll
-        for (int r = 0; r < 4; ++r) f[t][r] = sg.h.ok[t][r] ? fb[sg.h.q[t][r]] : (__bf16)0.0f;
+        for (int r = 0; r < 4; ++r) f[t][r] = rowbase[rh.off[t][r]];
+}
+
+template <int NT>
+__device__ __forceinline__ bf16x4_t pack_f_raw(const RawHood<NT> &rh, const unsigned (&f)[NT][4], int t) {
+    typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+    u32x2 p;
+    p[0] = (f[t][0] | (f[t][1] << 16)) & rh.mask[t][0];
+    p[1] = (f[t][2] | (f[t][3] << 16)) & rh.mask[t][1];
+    return __builtin_bit_cast(bf16x4_t, p);
+}
+
+__device__ __forceinline__ bf16x4_t pack4(f32x4 s) {      // s already clamped at zero
+    return bf16x4_t{(__bf16)s[0], (__bf16)s[1], (__bf16)s[2], (__bf16)s[3]};
 }
 
 template <int NT, int KT>
 __device__ __forceinline__ void group_segment_bf16(const InterArgs &A, const Seg<NT> &sg, int ct, int x, int j,
                                                    __bf16 *Gs, int gss) {
-    const int coff = 16 * ct + x;
-    bf16x4_t fcur[NT], fnext[NT];
-    load_f_raw<NT>(A, sg, sg.a0, coff, fcur);
+    RawHood<NT> rh;
+    make_raw_hood<NT>(sg, x, rh);
+    // wave-uniform: first element of channel chunk ct of anchor a0 in this cloud's feature block
+    const unsigned short *rb = reinterpret_cast<const unsigned short *>(sg.fbase) + (size_t)sg.a0 * A.cin + 16 * ct;
+    unsigned fcur[NT][4], fnext[NT][4];
+    load_f_raw<NT>(rb, rh, fcur);
+    const unsigned lane_st = (unsigned)(x * A.ks + 4 * j);
     for (int i = 0; i < sg.cnt; ++i) {
         const int a = sg.a0 + i;
-        const int an = i + 1 < sg.cnt ? a + 1 : a;
-        load_f_raw<NT>(A, sg, an, coff, fnext);
+        const int inext = i + 1 < sg.cnt ? i + 1 : i;   // last column re-reads its own rows (cache hit, result unused)
+        load_f_raw<NT>(rb + (size_t)inext * A.cin, rh, fnext);
         f32x4 w[KT][NT];
         make_weights<NT, KT>(A, a, x, j, sg.h, w);     // relu already applied
+        bf16x4_t fb4[NT];
+#pragma unroll
+        for (int t = 0; t < NT; ++t) fb4[t] = pack_f_raw<NT>(rh, fcur, t);
+        __bf16 *grow = Gs + (size_t)(sg.jc0 + i) * gss;   // wave-uniform row of G
 #pragma unroll
         for (int kt = 0; kt < KT; ++kt) {
             f32x4 g = {0.f, 0.f, 0.f, 0.f};
             if constexpr (NT % 2 == 0) {
 #pragma unroll
                 for (int t = 0; t < NT; t += 2)
-                    g = mfma_bf16_k32(relu_pack4(w[kt][t]), relu_pack4(w[kt][t + 1]), fcur[t], fcur[t + 1], g);
+                    g = mfma_bf16_k32(pack4(w[kt][t]), pack4(w[kt][t + 1]), fb4[t], fb4[t + 1], g);
             } else {
 #pragma unroll
-                for (int t = 0; t < NT; ++t) g = mfma_bf16_k16(relu_pack4(w[kt][t]), fcur[t], g);
+                for (int t = 0; t < NT; ++t) g = mfma_bf16_k16(pack4(w[kt][t]), fb4[t], g);
             }
-            if (16 * kt + 4 * j < A.ks)
-                st4f(Gs + (sg.jc0 + i) * gss + x * A.ks + 16 * kt + 4 * j, g);
+            if (16 * kt + 4 * j < A.ks) st4f(grow + 16 * kt + lane_st, g);
         }
 #pragma unroll
-        for (int t = 0; t < NT; ++t) fcur[t] = fnext[t];
+        for (int t = 0; t < NT; ++t)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) fcur[t][r] = fnext[t][r];
     }
 }
 
@@ -446,7 +495,7 @@ __device__ __forceinline__ void scatter_segment(const InterArgs &A, const Seg<NT
                 const int jj = 16 * kt + 4 * j < A.ks ? j : 0;
                 const f32x4 dgc = ld4f(Gs + jc * gss + x * A.ks + 16 * kt + 4 * jj);
 #pragma unroll
-                for (int r = 0; r < 4; ++r) tt = mfma4(fmaxf(s[r], 0.0f), dgc[r], tt);
+                for (int r = 0; r < 4; ++r) tt = mfma4(relu_f(s[r]), dgc[r], tt);
             }
             // tt: lane (x = c, j), register r -> n = 16t + 4j + r
             if constexpr (DET) {
@@ -727,7 +776,7 @@ __device__ __forceinline__ void group16(const InterArgs &A, const Seg<NT> &s0, c
                 f32x4 sw = {bt, bt, bt, bt};
                 sw = mfma4(first ? s0.h.gA[t] : s1.h.gA[t], rkv, sw);
 #pragma unroll
-                for (int r = 0; r < 4; ++r) g[kt] = mfma4(fmaxf(sw[r], 0.0f), f[jc][t][r], g[kt]);
+                for (int r = 0; r < 4; ++r) g[kt] = mfma4(relu_f(sw[r]), f[jc][t][r], g[kt]);
             }
         }
         *reinterpret_cast<f32x4 *>(Gs + jc * GS0 + x * 16 + 4 * j) = g[0];   // k = 4j + r of channel x
@@ -1357,7 +1406,7 @@ __global__ __launch_bounds__(64 * GP) void inter_ungroup_shared_kernel(InterArgs
                     f32x4 s = {alphaN[t], alphaN[t], alphaN[t], alphaN[t]};
                     s = mfma4(rk[kt], gB[t], s);
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) tt = mfma4(fmaxf(s[r], 0.0f), dgc[kt][r], tt);
+                    for (int r = 0; r < 4; ++r) tt = mfma4(relu_f(s[r]), dgc[kt][r], tt);
                 }
             }
             // tt: lane (x = c, j), register r -> slot n = 16t + 4j + r
