@@ -1,14 +1,14 @@
 #!/bin/bash
 # Per-replay kernel time of bench.py's HIP graph: two rocprofv3 kernel traces that differ only in --steps; the
 # difference of the per-kernel totals divided by the extra steps is what ONE replayed step spends in each kernel
-# (warm-up, capture, eager roofline passes cancel).  usage (on the GPU box): tools/replay_profile.sh <tag> [bench args]
+# (warm-up, capture and the 3 eager roofline passes of either run cancel).  usage (on the GPU box): tools/replay_profile.sh <tag> [bench args]
 set -e
 R=$(cd "$(dirname "$0")/.." && pwd)
 TAG=${1:-replay}; shift || true
 OUT=$R/gpurun_out/$TAG
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
-for K in 2 12; do
+for K in 3 13; do
   rocprofv3 --kernel-trace --stats -d $OUT/s$K -o s -- python $R/bench.py --steps $K --warmup 2 --no-cpu-baseline "$@" > $OUT/s$K.log 2>&1
   python $R/tools/rocprof_summary.py $(find $OUT/s$K -name "*.db" | head -1) $OUT/k$K.csv > /dev/null
   rm -rf $OUT/s$K
@@ -17,7 +17,7 @@ python - <<PY
 import csv
 def load(p):
     return {r["Name"]: (int(r["Calls"]), float(r["TotalDurationUs"])) for r in csv.DictReader(open(p))}
-a, b = load("$OUT/k2.csv"), load("$OUT/k12.csv")
+a, b = load("$OUT/k3.csv"), load("$OUT/k13.csv")
 rows = []
 for n, (c, t) in b.items():
     c0, t0 = a.get(n, (0, 0.0))
@@ -29,6 +29,9 @@ with open("$OUT/per_replay.csv", "w") as f:
     f.write("Name,CallsPerStep,UsPerStep,Percent\n")
     for n, c, t in rows:
         f.write('"%s",%.1f,%.1f,%.2f\n' % (n, c, t, 100 * t / tot))
+import os
+for f in ("k3.csv", "k13.csv"):
+    os.remove(os.path.join("$OUT", f))
 print("kernel time per replayed step: %.2f ms over %d kernels, %.0f launches" % (tot / 1e3, len(rows), sum(r[1] for r in rows)))
 PY
-grep -h '"metric"' $OUT/s12.log | tail -1 | cut -c1-220
+grep -h '"metric"' $OUT/s13.log | tail -1 | cut -c1-220
