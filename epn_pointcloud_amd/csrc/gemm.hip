@@ -852,7 +852,9 @@ int gemm_tn_splits(bool bf16, long long R, int N1, int N2) {
     // ~8 workgroups per CU in total: measured on the dW shapes of the ModelNet schedule, 512 / 1024 / 2048 / 4096 ->
     // 91 / 106 / 118 / 120 TFLOP/s (short row ranges spread evenly over the XCDs; the fp32 partial slabs and their
     // fixed-order reduction are included in those times)
-    long long s = (target + tiles - 1) / tiles;
+    // rounded DOWN: the wide tiles take a whole CU's LDS, so 2048 workgroups are exactly 8 rounds of the 256 CUs and one
+    // workgroup more is a ninth round that runs 16 workgroups wide (24 tiles x 86 splits = 2064: measured 118 -> 129 TFLOP/s)
+    long long s = target / tiles;
     // at least 32 K steps per split: a split ends in an N1 x N2 fp32 slab write (+ its share of the reduction), which
     // for the short-and-wide problems (spectral blocks: R = pts*d rows, up to 1280 x 1280 outputs) outweighs 8 steps of loads
     const long long smax = chunks / 32 > 1 ? chunks / 32 : 1;
