@@ -677,8 +677,6 @@ int launch_nt_typed(GemmNtBatch &B, hipStream_t st) {
             case 4: return launch_nt_cfg<T, TO, 2, 4, 2, 2>(B, st);      // 128 x 256, 8 waves
             case 5: return launch_nt_cfg<T, TO, 4, 1, 2, 2>(B, st);      // 256 x 64, 4 waves
             case 6: return launch_nt_cfg<T, TO, 2, 2, 4, 2>(B, st);      // 256 x 128, 4 waves, 128 x 64 per wave
-            case 7: return launch_nt_cfg<T, TO, 8, 1, 2, 2, 4>(B, st);   // 512 x 64, half K steps: 2 workgroups / CU
-            case 8: return launch_nt_cfg<T, TO, 4, 1, 2, 2, 4>(B, st);   // 256 x 64, half K steps, 4 waves
             default: break;
         }
     }
