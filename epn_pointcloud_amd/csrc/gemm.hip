@@ -728,12 +728,15 @@ size_t tn_plan(GemmTnBatch &B, int *bn1_out, int *bn2_out, void *ws) {
     if (B.nprob == 1) {
         B.p[0].nsplit = gemm_tn_splits(bf, B.p[0].R, B.p[0].N1, B.p[0].N2);
     } else {
-        // largest steps-per-workgroup S (>= 8) that still yields >= 1024 workgroups; every problem gets ceil(chunks / S) splits
+        // smallest steps-per-workgroup S (>= 8) whose launch fits `target` workgroups (whole rounds of the 256 CUs: these
+        // tiles take a CU's LDS each); every problem gets ceil(chunks / S) splits
+        const long long target = 256;   // one round: fewer, longer workgroups = fewer partial slabs (256/512/1024/2048: 6.2/6.7/7.4/7.9 ms per step)
         long long S = 8;
-        for (long long cand = 4096; cand >= 8; cand >>= 1) {
+        for (long long cand = 8; cand <= 8192; ++cand) {
             long long blocks = 0;
             for (int i = 0; i < B.nprob; ++i) blocks += tiles[i] * ((chunks[i] + cand - 1) / cand);
-            if (blocks >= 1024) { S = cand; break; }
+            S = cand;
+            if (blocks <= target) break;
         }
         for (int i = 0; i < B.nprob; ++i) {
             long long sp = (chunks[i] + S - 1) / S;
@@ -846,10 +849,10 @@ int gemm_tn_splits(bool bf16, long long R, int N1, int N2) {
     const long long tiles = (long long)((N1 + bn1 - 1) / bn1) * ((N2 + bn2 - 1) / bn2);
     const long long chunks = R / 32;
     const int pol = kernel_policy();
-    const long long target = (pol & ~0xff) == 0x200 ? 256LL * (pol & 0xff) : 2048;   // 0x200 | v: tuning override
-    // ~8 workgroups per CU in total: measured on the dW shapes of the ModelNet schedule, 512 / 1024 / 2048 / 4096 ->
-    // 91 / 106 / 118 / 120 TFLOP/s (short row ranges spread evenly over the XCDs; the fp32 partial slabs and their
-    // fixed-order reduction are included in those times)
+    const long long target = (pol & ~0xff) == 0x200 ? 256LL * (pol & 0xff) : 512;    // 0x200 | v: tuning override
+    // two rounds of the 256 CUs.  With the split count rounded down (below) 512 / 1024 / 1536 / 2048 workgroups run the dW
+    // shapes of the ModelNet schedule within 1.5 % of each other (18.7 / 18.8 / 18.9 / 19.0 ms summed, fp32 partial slabs and
+    // their fixed-order reduction included); fewer workgroups = fewer partial slabs
     // rounded DOWN: the wide tiles take a whole CU's LDS, so 2048 workgroups are exactly 8 rounds of the 256 CUs and one
     // workgroup more is a ninth round that runs 16 workgroups wide (24 tiles x 86 splits = 2064: measured 118 -> 129 TFLOP/s)
     long long s = target / tiles;
