@@ -38,7 +38,7 @@ KERNEL_OF = {
     "inter_fwd": "epn::inter_fwd8_kernel", "inter_bwd_data": "epn::inter_bwd_data8_kernel",
     "inter_bwd_weight": "epn::inter_bwd_weight8_kernel", "intra_fwd": "epn::intra_gemm_kernel",
     "intra_bwd_data": "epn::intra_gemm_kernel", "intra_bwd_weight": "epn::intra_bwd_weight_v4_kernel",
-    "inter_group": "epn::inter_group_kernel", "inter_ungroup": "epn::inter_ungroup_kernel",
+    "inter_group": "epn::inter_group_kernel", "inter_ungroup": "epn::inter_ungroup_shared_kernel",
     "inter_ungroup_det": "epn::inter_ungroup_slots_kernel + inter_reduce_slots_kernel",
     "inter_gemm": "epn::gemm_nt_kernel", "intra_gemm": "epn::gemm_nt_kernel",
     "inter_gemm_dw": "epn::gemm_tn_kernel", "intra_gemm_dw": "epn::gemm_tn_kernel",
@@ -333,37 +333,44 @@ def main():
             if kk % (4 * e16):
                 return "epn::gemm_nt_generic_kernel"
             ksz = 8 if kk % (8 * e16) == 0 else 4
-            if (dtype_name == "f32" and ksz == 8 and len(ns) == 1 and ns[0] in (128, 256)
+            if ksz == 4:
+                cfg = "8, 1, 2, 1" if max(ns) <= 32 else ("8, 1, 2, 2" if max(ns) <= 64 else "4, 2, 2, 2")
+            elif dtype_name == "f32" and len(ns) > 1:          # grouped spectral blocks
+                cfg = "4, 1, 2, 2" if (max(ns) <= 320 and min(ns) <= 64) else "2, 2, 2, 2"
+            elif (dtype_name == "f32" and len(ns) == 1 and ns[0] in (128, 256)
                     and (m_rows // 128) * (ns[0] // 128) >= 3840):
                 cfg = "2, 2, 2, 2"
-            elif ksz == 8 and min(ns) >= 256 and dtype_name == "f32":
-                cfg = "4, 2, 2, 4"
             elif max(ns) <= 32:
                 cfg = "8, 1, 2, 1"
             elif max(ns) <= 64:
                 cfg = "8, 1, 2, 2"
+            elif min(ns) >= 256 and dtype_name == "f32":
+                cfg = "4, 2, 2, 4"
             else:
                 cfg = "4, 2, 2, 2"
             return f"epn::gemm_nt_kernel<{t}, {cfg}, {ksz}>"
 
-        def tn_name(n1, n2):
+        def tn_name(n1, n2, grouped=False):
             """Template instance gemm_tn_tile / launch_tn_typed (csrc/gemm.hip) pick for an N1 x N2 output."""
             if dtype_name == "bf16":
                 cfg = "1, 8, 2, 2" if n1 <= 32 else ("1, 8, 4, 2" if n1 <= 64 else "2, 4, 4, 4")
                 return f"epn::gemm_tn_bf16_kernel<{cfg}>"
+            if grouped and n2 < 256:
+                n2 = 256
+            w2 = 512 if n2 >= 512 else (256 if n2 > 128 else (128 if n2 > 64 else 64))
             if n1 <= 32:
                 cfg = "1, 8, 1, 2, 32"
             elif n1 <= 64:
-                cfg = "1, 4, 2, 4, 16" if n2 >= 512 else "1, 8, 2, 1, 32"
+                cfg = {512: "1, 4, 2, 4, 16", 256: "1, 8, 2, 1, 32", 128: "2, 2, 1, 2, 32", 64: "2, 2, 1, 1, 32"}[w2]
             else:
-                cfg = "1, 8, 4, 2, 32" if n2 >= 512 else "2, 4, 2, 2, 32"
+                cfg = {512: "1, 8, 4, 2, 32", 256: "2, 4, 2, 2, 32", 128: "2, 2, 2, 2, 32", 64: "2, 2, 2, 1, 32"}[w2]
             return f"epn::gemm_tn_f32_kernel<{cfg}>"
 
         def kernel_of(kind, key):
             if kind == "inter_gemm_dw":
                 return tn_name(key[7], key[6] * key[5])
             if kind == "intra_gemm_dw" and key[0] == "spectral_dw":
-                return tn_name(5 * key[2], key[3])           # grouped: max N1, min N2 of the five blocks
+                return tn_name(5 * key[2], key[3], grouped=True)   # grouped: max N1, min N2 of the five blocks
             if kind == "conv1x1_gemm_dw":
                 return tn_name(key[2], key[3])
             if kind == "inter_gemm":

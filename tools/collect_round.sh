@@ -1,0 +1,32 @@
+#!/bin/bash
+# Everything the round's profiles/ directory is built from, in ONE gpurun call (same box for all numbers):
+#   rocprofv3 kernel stats + PMC passes of the cls bench (collect_profiles.sh), the same for the bf16 rotation network,
+#   per-replay kernel times (replay_profile.sh), and the bench lines of every configuration.
+# usage (GPU box): tools/collect_round.sh <tag>      -> gpurun_out/<tag>/...
+R=$(cd "$(dirname "$0")/.." && pwd)
+TAG=${1:-r02}
+OUT=$R/gpurun_out/$TAG
+mkdir -p $OUT
+cd $R
+bash tools/collect_profiles.sh $TAG > $OUT/collect.log 2>&1
+EPN_BENCH_ARGS="--model reg --dtype bf16" bash tools/collect_profiles.sh ${TAG}_reg > $OUT/collect_reg.log 2>&1
+for f in kernel_stats.csv pmc_per_kernel.json bench_under_rocprof.json; do cp gpurun_out/${TAG}_reg/$f $OUT/reg_bf16_$f; done
+bash tools/replay_profile.sh ${TAG}_replay > $OUT/replay.log 2>&1
+cp gpurun_out/${TAG}_replay/per_replay.csv $OUT/per_replay_cls.csv
+python bench.py > $OUT/bench_cls.json 2> $OUT/bench_cls.err
+python bench.py --model reg --dtype bf16 --no-cpu-baseline > $OUT/bench_reg.json 2>/dev/null
+python bench.py --model inv --dtype bf16 --no-cpu-baseline > $OUT/bench_inv.json 2>/dev/null
+python bench.py --forward-only --no-cpu-baseline > $OUT/bench_cls_fwd.json 2>/dev/null
+python bench.py --model reg --dtype f32 --no-cpu-baseline > $OUT/bench_reg_f32.json 2>/dev/null
+python bench.py --dtype bf16 --no-cpu-baseline > $OUT/bench_cls_bf16.json 2>/dev/null
+python tools/gemm_bench.py > $OUT/gemm_bench_f32.txt 2>&1
+python tools/gemm_bench.py --dtype bf16 > $OUT/gemm_bench_bf16.txt 2>&1
+python tools/hbm_probe.py > $OUT/hbm_probe.txt 2>&1
+rm -rf gpurun_out/${TAG}_reg gpurun_out/${TAG}_replay $OUT/pmc_*.log $OUT/stats.log
+for f in $OUT/bench_*.json; do python - <<PY
+import json
+d = json.loads(open("$f").read().strip().splitlines()[-1])
+r = d.get("roofline", {})
+print("$(basename $f)", d["value"], d["ms_per_step"], d["dtype"], "|", r.get("kernel", "")[:60], r.get("bound"), r.get("achieved"), r.get("frac"))
+PY
+done
