@@ -180,7 +180,9 @@ int launch_inter_c1_bwd_weight(const epn_inter_desc *d, const float *rk, const f
     C1Args A = make_c1(d, rk);
     A.feats = feats; A.gout = dOut; A.out = dW;
     const long long groups = (A.ncol + 255) / 256;
-    long long wgs = groups < 2048 ? groups : 2048;
+    // two rounds of workgroups: each ends in cout*ks atomics onto the same 1536 addresses (2048 workgroups: 1.48 ms,
+    // of which ~0.9 ms contention; 512: see DESIGN 5)
+    long long wgs = groups < 512 ? groups : 512;
     A.groups_per_wg = (int)((groups + wgs - 1) / wgs);
     const unsigned grid = (unsigned)((groups + A.groups_per_wg - 1) / A.groups_per_wg);
     hipLaunchKernelGGL(inter_c1_bwd_weight_kernel, dim3(grid), dim3(256), 0, st, A);
