@@ -26,7 +26,7 @@ EXPORTS = [
     "epn_gemm_nt_f32", "epn_gemm_nt_bf16", "epn_gemm_tn_workspace_bytes", "epn_gemm_tn_f32", "epn_gemm_tn_bf16",
     "epn_transpose_cast", "epn_cast", "epn_gemm_tn_grouped_workspace_bytes", "epn_gemm_tn_grouped",
     "epn_inter_group_bf16", "epn_inter_ungroup_bf16", "epn_intra_group_bf16", "epn_so3_basis_bf16",
-    "epn_gather_rows", "epn_scatter_rows", "epn_inter_inverse_list", "epn_inter_ungroup_det_f32", "epn_inter_ungroup_det_bf16",
+    "epn_gather_rows", "epn_scatter_rows", "epn_conv1x1_c1_f32", "epn_conv1x1_c1_bwd_weight_f32", "epn_inter_inverse_list", "epn_inter_ungroup_det_f32", "epn_inter_ungroup_det_bf16",
     "epn_chan_stats_bf16", "epn_norm_act_fwd_bf16", "epn_norm_act_bwd_reduce_bf16", "epn_norm_act_bwd_apply_bf16",
 ]
 
@@ -126,6 +126,8 @@ def get_lib():
     # the bf16 twins share their fp32 counterparts' signatures (void* feature pointers)
     lib.epn_gather_rows.argtypes = [_vp, _vp, _vp, _ci, _ci, _ci, _ll, _vp]
     lib.epn_scatter_rows.argtypes = [_vp, _vp, _vp, _ci, _ci, _ci, _ll, _vp]
+    lib.epn_conv1x1_c1_f32.argtypes = [_vp, _vp, _vp, _ll, _ci, _vp]
+    lib.epn_conv1x1_c1_bwd_weight_f32.argtypes = [_vp, _vp, _vp, _ll, _ci, _vp]
     lib.epn_gather_rows.restype = lib.epn_scatter_rows.restype = _ci
     lib.epn_inter_inverse_list.argtypes = [_vp, _ci, _ci, _ci, _ci, _vp, _vp, _vp]
     lib.epn_inter_inverse_list.restype = _ci

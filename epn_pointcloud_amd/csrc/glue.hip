@@ -543,3 +543,73 @@ extern "C" int epn_scatter_rows(const void *grad_dst, const int32_t *idx, void *
     EPN_CHECK_LAUNCH();
     return 0;
 }
+
+// ---- 1x1 convolution of a single input channel (the occupancy feature of the first block): an outer product
+//      y[row][c] = x[row] * w[c], and its weight gradient dw[c] = sum_row x[row] * dy[row][c]
+namespace epn {
+namespace {
+__global__ __launch_bounds__(256) void c1_outer_kernel(const float *__restrict__ x, const f32x4 *__restrict__ w,
+                                                       f32x4 *__restrict__ y, long long n4, int c4) {
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n4) return;
+    const float xv = x[i / c4];
+    const f32x4 wv = w[i % c4];
+    y[i] = f32x4{xv * wv[0], xv * wv[1], xv * wv[2], xv * wv[3]};
+}
+
+// block = (c/4 channel lanes) x (256 / (c/4) row lanes); per-channel partial sums, LDS tree, one atomic per channel and block
+__global__ __launch_bounds__(256) void c1_outer_bwd_kernel(const float *__restrict__ x, const f32x4 *__restrict__ dy,
+                                                           float *__restrict__ dw, long long rows, int c4,
+                                                           long long rows_per_block) {
+    __shared__ float red[256][4];
+    const int cl = threadIdx.x % c4, rl = threadIdx.x / c4, rstep = 256 / c4;
+    const long long r0 = (long long)blockIdx.x * rows_per_block;
+    long long r1 = r0 + rows_per_block;
+    r1 = r1 < rows ? r1 : rows;
+    f32x4 s = {0.f, 0.f, 0.f, 0.f};
+    if (rl < rstep)
+        for (long long r = r0 + rl; r < r1; r += rstep) {
+            const float xv = x[r];
+            const f32x4 d = dy[r * c4 + cl];
+            s[0] += xv * d[0]; s[1] += xv * d[1]; s[2] += xv * d[2]; s[3] += xv * d[3];
+        }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) red[threadIdx.x][i] = s[i];
+    __syncthreads();
+    if (rl == 0) {
+        for (int t = 1; t < rstep; ++t)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) s[i] += red[t * c4 + cl][i];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) atomicAdd(dw + 4 * cl + i, s[i]);
+    }
+}
+}  // namespace
+}  // namespace epn
+
+extern "C" int epn_conv1x1_c1_f32(const float *x, const float *w, float *y, long long rows, int cout, epn_stream_t stream) {
+    if (rows < 0 || cout < 4 || cout % 4 || cout > 1024) return EPN_EINVAL;
+    if (rows == 0) return 0;
+    if (!x || !w || !y) return EPN_ENULL;
+    const long long n4 = rows * (cout / 4);
+    hipLaunchKernelGGL(epn::c1_outer_kernel, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, epn_stream(stream), x,
+                       reinterpret_cast<const f32x4 *>(w), reinterpret_cast<f32x4 *>(y), n4, cout / 4);
+    EPN_CHECK_LAUNCH();
+    return 0;
+}
+
+extern "C" int epn_conv1x1_c1_bwd_weight_f32(const float *x, const float *grad_y, float *grad_w, long long rows, int cout,
+                                              epn_stream_t stream) {
+    if (rows < 0 || cout < 4 || cout % 4 || cout > 1024 || 256 % (cout / 4)) return EPN_EINVAL;
+    if (!grad_w) return EPN_ENULL;
+    hipStream_t st = epn_stream(stream);
+    EPN_HIP(hipMemsetAsync(grad_w, 0, sizeof(float) * cout, st));
+    if (rows == 0) return 0;
+    if (!x || !grad_y) return EPN_ENULL;
+    const long long blocks = rows < 1024 * 64 ? (rows + 63) / 64 : 1024;
+    const long long rpb = (rows + blocks - 1) / blocks;
+    hipLaunchKernelGGL(epn::c1_outer_bwd_kernel, dim3((unsigned)((rows + rpb - 1) / rpb)), dim3(256), 0, st, x,
+                       reinterpret_cast<const f32x4 *>(grad_y), grad_w, rows, cout / 4, rpb);
+    EPN_CHECK_LAUNCH();
+    return 0;
+}

@@ -1018,6 +1018,35 @@ def gather_rows(feats, sample_idx):
     return torch.gather(feats, 2, idx)
 
 
+class Conv1x1C1Fn(torch.autograd.Function):
+    """nn.Conv2d(1, cout, 1) on channels-last rows: y[row][c] = x[row] * w[c] (epn_conv1x1_c1_f32); the weight gradient is
+    one streaming reduction (epn_conv1x1_c1_bwd_weight_f32).  x is the occupancy feature of the first block (an input)."""
+
+    @staticmethod
+    def forward(ctx, x_rows, w):
+        lib = _lib.get_lib()
+        x_rows, w = x_rows.contiguous(), w.contiguous()
+        y = torch.empty((x_rows.numel(), w.numel()), dtype=torch.float32, device=x_rows.device)
+        _lib.check(lib.epn_conv1x1_c1_f32(x_rows.data_ptr(), w.data_ptr(), y.data_ptr(), x_rows.numel(), w.numel(),
+                                          _lib.stream_of(x_rows)), "conv1x1_c1")
+        ctx.save_for_backward(x_rows, w)
+        return y
+
+    @staticmethod
+    def backward(ctx, gy):
+        x_rows, w = ctx.saved_tensors
+        lib = _lib.get_lib()
+        gy = gy.contiguous()
+        gx = gw = None
+        if ctx.needs_input_grad[1]:
+            gw = torch.empty_like(w)
+            _lib.check(lib.epn_conv1x1_c1_bwd_weight_f32(x_rows.data_ptr(), gy.data_ptr(), gw.data_ptr(), x_rows.numel(),
+                                                         w.numel(), _lib.stream_of(gy)), "conv1x1_c1_bwd_weight")
+        if ctx.needs_input_grad[0]:
+            gx = gy @ w
+        return gx, gw
+
+
 def conv1x1(x, weight, bias=None):
     """nn.Conv2d(cin, cout, 1) on a [b,c,p,a] tensor, channels-last in and out with no layout copy: one NT GEMM
     [cols, cin] x [cout, cin]^T on the zero-copy 2-D view (fp32 master weight, cast per call for bf16 features).
@@ -1039,8 +1068,12 @@ def conv1x1(x, weight, bias=None):
         y = IntraSO3ConvFn.apply(cast_feats(x, torch.float32), weight.reshape(cout, cin),
                                  _identity_index(x.shape[3], x.device))
         y = cast_feats(y, x.dtype)
-    elif x.is_cuda and cin == 1:
+    elif x.is_cuda and cin == 1 and cout % 4 == 0 and 256 % (cout // 4) == 0 and cout <= 1024:
         # single input channel (the occupancy feature of the first block): an outer product, written channels-last
+        b, _, p, a = x.shape
+        y2d = Conv1x1C1Fn.apply(to_cl(x).float().reshape(-1), weight.reshape(cout).float())
+        y = y2d.reshape(b, p, a, cout).permute(0, 3, 1, 2)
+    elif x.is_cuda and cin == 1:
         y = (to_cl(x).permute(0, 2, 3, 1).float() * weight.reshape(cout)).permute(0, 3, 1, 2)
     else:
         y = torch.nn.functional.conv2d(x.float(), weight.reshape(cout, cin, 1, 1))

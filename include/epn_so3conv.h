@@ -369,6 +369,14 @@ int epn_gather_rows(const void *src, const int32_t *idx, void *dst, int b, int p
 int epn_scatter_rows(const void *grad_dst, const int32_t *idx, void *grad_src, int b, int p1, int p2, long long row_bytes,
                      epn_stream_t stream);
 
+/* 1x1 convolution of a SINGLE input channel (the skip branch of every model's first block, whose input is the
+ * occupancy feature: nn.Conv2d(1, cout, 1), SPConvNets/utils/base_so3conv.py:186): y[row][c] = x[row] * w[c], rows =
+ * b*p*a of the channels-last tensor, cout % 4 == 0; and its weight gradient grad_w[c] = sum_row x[row] * grad_y[row][c]
+ * (zero-fills grad_w first; 256 % (cout/4) == 0). */
+int epn_conv1x1_c1_f32(const float *x, const float *w, float *y, long long rows, int cout, epn_stream_t stream);
+int epn_conv1x1_c1_bwd_weight_f32(const float *x, const float *grad_y, float *grad_w, long long rows, int cout,
+                                  epn_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -564,3 +564,23 @@ def test_intra_forms_agree_at_full_size(gpu, vgtk_alias):
         assert (y0 - y1).abs().max().item() < TOL
         assert _rel(dW1, dW0) < TOL
         assert (dF0 - dF1).abs().max().item() < TOL
+
+
+@pytest.mark.parametrize("cout", [16, 64, 32, 20])
+def test_conv1x1_single_input_channel(gpu, cout):
+    """ops.conv1x1 with cin = 1 (skip branch of every first block, nn.Conv2d(1, cout, 1): base_so3conv.py:186): the
+    outer-product kernel and its streaming weight gradient against torch's conv2d (cout = 20 takes the torch fallback)."""
+    from epn_pointcloud_amd import ops
+    torch.manual_seed(cout)
+    x = torch.randn(3, 1, 37, 60, device=gpu)
+    w = torch.randn(cout, 1, 1, 1, device=gpu, requires_grad=True)
+    bias = torch.randn(cout, device=gpu)
+    y = ops.conv1x1(x, w, bias)
+    ref = torch.nn.functional.conv2d(x, w.detach().clone().requires_grad_(True), bias)
+    assert tuple(y.shape) == tuple(ref.shape)
+    assert (y - ref).abs().max().item() < 1e-5
+    gy = torch.randn_like(ref)
+    (gw,) = torch.autograd.grad(y, w, gy)
+    w2 = w.detach().clone().requires_grad_(True)
+    (gw_ref,) = torch.autograd.grad(torch.nn.functional.conv2d(x, w2, bias), w2, gy)
+    assert _rel(gw.flatten().cpu(), gw_ref.flatten().cpu()) < 1e-5
