@@ -12,7 +12,8 @@ struct GemmNtProb {        // C[M][N] = A[M][K] . Bt[N][K]^T
     long long M, lda, ldb, ldc;
     int N, K;
     int tiles_n;           // filled by the launcher
-    unsigned tile0;        // first tile id of this problem inside the grouped launch
+    unsigned tile0;        // first workgroup of this problem inside the grouped launch (a multiple of 8)
+    unsigned ntile;        // its tiles; workgroups tile0 + ntile .. next tile0 are padding
 };
 struct GemmNtBatch {
     int nprob;
