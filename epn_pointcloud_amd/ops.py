@@ -339,9 +339,10 @@ class InterSO3ConvSplitFn(torch.autograd.Function):
                 mode = "split"          # bf16 features / deterministic mode: dG GEMM + (atomic-free) transpose of the grouping
             elif mode == "auto":
                 # dG GEMM + LDS-pre-reduced scatter (epn_inter_ungroup) against the fused kernel, measured per layer of
-                # the ModelNet schedule at B=32: 64->64 4.28 vs 4.13 ms, 64->128 3.41 vs 3.57, 128->128 5.61 vs 5.73,
-                # 128->256 4.77 vs 5.45, 256->256 split only
-                mode = "split" if cin * cout >= 8192 else "fused"
+                # the ModelNet schedule at B=32: 64->64 3.65 vs 4.05 ms, 64->128 3.4 vs 3.6, 128->128 5.6 vs 5.7,
+                # 128->256 4.8 vs 5.5; rotation / 3DMatch networks in fp32 (K = 32..64): the whole step 4 % faster.
+                # The fused kernel stays the memory-lean choice (EPN_INTER_BWD_DATA=fused: no [cols, cin*ks] gradient).
+                mode = "split"
             if mode == "fused" and lib.epn_inter_is_fused(ctypes.byref(d)) and cin >= 16:
                 # The fused data-gradient kernel (W^T dOut + per-column tail in one pass, no dG tensor): its fp32 atomic
                 # scatter -- cols*K*cin = 1.0e9 atomics per layer -- hides under the MFMA phases.  Also measured and
