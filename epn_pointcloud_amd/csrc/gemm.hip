@@ -799,11 +799,6 @@ int launch_tn_typed(GemmTnBatch &B, void *ws, size_t ws_bytes, hipStream_t st) {
     if (need > 0 && (!ws || ws_bytes < need)) return EPN_EWORKSPACE;
     const dim3 grid(B.nblocks);
     if constexpr (sizeof(T) == 4) {
-        const int pol = kernel_policy();
-        if ((pol & ~0xff) == 0x300 && bn1 == 128) {          // tuning override (tools/gemm_bench.py --cfg 0x30v)
-            if ((pol & 0xff) == 1 && bn2 == 256) { hipLaunchKernelGGL((gemm_tn_f32_kernel<2, 4, 2, 2, 16>), grid, dim3(512), 0, st, B); EPN_CHECK_LAUNCH(); goto launched; }
-            if ((pol & 0xff) == 2 && bn2 == 512) { hipLaunchKernelGGL((gemm_tn_f32_kernel<1, 8, 4, 2, 16>), grid, dim3(512), 0, st, B); EPN_CHECK_LAUNCH(); goto launched; }
-        }
         if (bn1 == 32) hipLaunchKernelGGL((gemm_tn_f32_kernel<1, 8, 1, 2, 32>), grid, dim3(512), 0, st, B);
         else if (bn1 == 64 && bn2 == 64) hipLaunchKernelGGL((gemm_tn_f32_kernel<2, 2, 1, 1, 32>), grid, dim3(256), 0, st, B);
         else if (bn1 == 64 && bn2 == 128) hipLaunchKernelGGL((gemm_tn_f32_kernel<2, 2, 1, 2, 32>), grid, dim3(256), 0, st, B);
@@ -819,7 +814,6 @@ int launch_tn_typed(GemmTnBatch &B, void *ws, size_t ws_bytes, hipStream_t st) {
         else hipLaunchKernelGGL((gemm_tn_bf16_kernel<2, 4, 4, 4>), grid, dim3(512), 0, st, B);
     }
     EPN_CHECK_LAUNCH();
-launched:
     bool any_split = false;
     size_t nmax = 0;
     for (int i = 0; i < B.nprob; ++i) {
