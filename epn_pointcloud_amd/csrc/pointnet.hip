@@ -263,6 +263,7 @@ __global__ __launch_bounds__(256) void pointnet_bwd_weight_kernel(PnArgs A) {
     for (int e0 = 0; e0 < ce; e0 += 256) {
         const int e = e0 + threadIdx.x;
         float acc = 0.f, accb = 0.f;
+#pragma unroll 8                       // independent gathers: eight in flight per thread (was a dependent-latency chain)
         for (long long q = q0; q < q1; ++q) {
             const int bb = (int)(q / A.a), ai = (int)(q % A.a);
             const float g = A.gout[q * A.co + o];
