@@ -262,23 +262,46 @@ __global__ __launch_bounds__(256) void pointnet_bwd_weight_kernel(PnArgs A) {
     q1 = q1 < nba ? q1 : nba;
     for (int e0 = 0; e0 < ce; e0 += 256) {
         const int e = e0 + threadIdx.x;
+        if (e >= ce) continue;                         // (the last pass has 3 live threads: the coordinate channels)
         float acc = 0.f, accb = 0.f;
-#pragma unroll 8                       // independent gathers: eight in flight per thread (was a dependent-latency chain)
-        for (long long q = q0; q < q1; ++q) {
-            const int bb = (int)(q / A.a), ai = (int)(q % A.a);
-            const float g = A.gout[q * A.co + o];
-            const int ps = A.arg_in[q * A.co + o];
+        auto term = [&](long long q, float g, int ps, float f) {
             accb += g;
             if (e < A.c) {
-                acc += g * A.feats[(((size_t)bb * A.p + ps) * A.a + ai) * A.c + e];
-            } else if (e < ce) {
+                acc += g * f;
+            } else {
+                const int bb = (int)(q / A.a), ai = (int)(q % A.a);
                 const float ctr[3] = {A.centre_in[bb * 3], A.centre_in[bb * 3 + 1], A.centre_in[bb * 3 + 2]};
                 float x3[3];
                 ext_xyz(A, bb, ai, ps, ctr, x3);
                 acc += g * x3[e - A.c];
             }
+        };
+        // eight (gradient, arg-max, gathered feature) triples in flight per thread: the loop was a chain of dependent
+        // load latencies (arg-max -> feature row), ~120 of them per thread
+        long long q = q0;
+        for (; q + 8 <= q1; q += 8) {
+            float g[8], f[8];
+            int ps[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                g[u] = A.gout[(q + u) * A.co + o];
+                ps[u] = A.arg_in[(q + u) * A.co + o];
+            }
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const int bb = (int)((q + u) / A.a), ai = (int)((q + u) % A.a);
+                f[u] = e < A.c ? A.feats[(((size_t)bb * A.p + ps[u]) * A.a + ai) * A.c + e] : 0.0f;
+            }
+#pragma unroll
+            for (int u = 0; u < 8; ++u) term(q + u, g[u], ps[u], f[u]);
         }
-        if (e < ce) atomicAdd(A.dW + (size_t)o * ce + e, acc);
+        for (; q < q1; ++q) {
+            const int bb = (int)(q / A.a), ai = (int)(q % A.a);
+            const float g = A.gout[q * A.co + o];
+            const int ps = A.arg_in[q * A.co + o];
+            term(q, g, ps, e < A.c ? A.feats[(((size_t)bb * A.p + ps) * A.a + ai) * A.c + e] : 0.0f);
+        }
+        atomicAdd(A.dW + (size_t)o * ce + e, acc);
         if (e == 0 && A.dbias) atomicAdd(A.dbias + o, accb);
     }
 }
