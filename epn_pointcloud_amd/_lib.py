@@ -26,7 +26,8 @@ EXPORTS = [
     "epn_gemm_nt_f32", "epn_gemm_nt_bf16", "epn_gemm_tn_workspace_bytes", "epn_gemm_tn_f32", "epn_gemm_tn_bf16",
     "epn_transpose_cast", "epn_cast", "epn_gemm_tn_grouped_workspace_bytes", "epn_gemm_tn_grouped",
     "epn_inter_group_bf16", "epn_inter_ungroup_bf16", "epn_intra_group_bf16", "epn_so3_basis_bf16",
-    "epn_gather_rows", "epn_scatter_rows", "epn_conv1x1_c1_f32", "epn_conv1x1_c1_bwd_weight_f32", "epn_inter_inverse_list", "epn_inter_ungroup_det_f32", "epn_inter_ungroup_det_bf16",
+    "epn_gather_rows", "epn_scatter_rows", "epn_conv1x1_c1_f32", "epn_conv1x1_c1_bwd_weight_f32",
+    "epn_ball_query_f64", "epn_fps_f64", "epn_gather_fwd_f64", "epn_gather_bwd_f64", "epn_inter_inverse_list", "epn_inter_ungroup_det_f32", "epn_inter_ungroup_det_bf16",
     "epn_chan_stats_bf16", "epn_norm_act_fwd_bf16", "epn_norm_act_bwd_reduce_bf16", "epn_norm_act_bwd_apply_bf16",
 ]
 
@@ -76,6 +77,10 @@ def get_lib():
     lib.epn_initial_anchor_query_f32.argtypes = [_vp, _vp, _vp, _ci, _ci, _ci, _ci, _ci, _cf, _cf, _vp, _vp, _vp]
     lib.epn_gather_fwd_f32.argtypes = [_vp, _vp, _ci, _ci, _ci, _ci, _vp, _vp]
     lib.epn_gather_bwd_f32.argtypes = [_vp, _vp, _ci, _ci, _ci, _ci, _vp, _vp]
+    lib.epn_ball_query_f64.argtypes = [_vp, _vp, _ci, _ci, _ci, ctypes.c_double, _ci, _vp, _vp]
+    lib.epn_fps_f64.argtypes = [_vp, _ci, _ci, _ci, _vp, _vp, _vp]
+    lib.epn_gather_fwd_f64.argtypes = lib.epn_gather_fwd_f32.argtypes
+    lib.epn_gather_bwd_f64.argtypes = lib.epn_gather_bwd_f32.argtypes
     dp = ctypes.POINTER(InterDesc)
     lib.epn_inter_workspace_bytes.argtypes = [dp]
     lib.epn_inter_workspace_bytes.restype = _sz
@@ -181,6 +186,13 @@ def same_device(*tensors):
     devs = {t.device for t in tensors if t is not None}
     if len(devs) > 1:
         raise RuntimeError(f"tensors of one call are on different devices: {sorted(str(d) for d in devs)}")
+
+
+def float_dtype(t, name):
+    """float32 or float64: the dtypes the reference's index / gather extensions dispatch on."""
+    if t.dtype not in (torch.float32, torch.float64):
+        raise TypeError(f"{name} must be float32 or float64, got {t.dtype}")
+    return t.dtype
 
 
 def dev_ptr(t, name, dtype=torch.float32):

@@ -201,9 +201,19 @@ __global__ __launch_bounds__(64 * NWAVE) void fps_wave_kernel(const float *__res
 }
 
 // ------------------------------------------------------------------------------------ ball query
-__global__ __launch_bounds__(256) void ball_query_kernel(const float *__restrict__ new_xyz,
-                                                         const float *__restrict__ xyz, int n, int m,
-                                                         float radius, int nsample,
+// canonical squared norm in T (epn_sq3 for float; the same fma chain in double for the fp64 dispatch)
+__device__ __forceinline__ float sq3_t(float a, float b, float c) { return epn_sq3(a, b, c); }
+__device__ __forceinline__ double sq3_t(double a, double b, double c) {
+    double t = __dmul_rn(a, a);
+    t = __fma_rn(b, b, t);
+    t = __fma_rn(c, c, t);
+    return t;
+}
+
+template <typename T>   // float, or double (the reference dispatches on both: grouping_cuda_kernel.cu:477)
+__global__ __launch_bounds__(256) void ball_query_kernel(const T *__restrict__ new_xyz,
+                                                         const T *__restrict__ xyz, int n, int m,
+                                                         T radius, int nsample,
                                                          int32_t *__restrict__ idx) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -212,10 +222,10 @@ __global__ __launch_bounds__(256) void ball_query_kernel(const float *__restrict
     const int j = blockIdx.x * (blockDim.x >> 6) + wave;
     if (j >= m) return;  // whole wave exits together; no block-level barrier below
 
-    const float *q = new_xyz + (size_t)bi * 3 * m;
-    const float *s = xyz + (size_t)bi * 3 * n;
-    const float qx = q[j], qy = q[m + j], qz = q[2 * m + j];
-    const float radius2 = __fmul_rn(radius, radius);
+    const T *q = new_xyz + (size_t)bi * 3 * m;
+    const T *s = xyz + (size_t)bi * 3 * n;
+    const T qx = q[j], qy = q[m + j], qz = q[2 * m + j];
+    const T radius2 = radius * radius;      // one rounded multiply in T (no contraction possible)
 
     for (int t = lane; t < nsample; t += 64) row[t] = 0;  // reference zero-initialises idx
 
@@ -224,7 +234,7 @@ __global__ __launch_bounds__(256) void ball_query_kernel(const float *__restrict
         const int k = base + lane;
         bool hit = false;
         if (k < n) {
-            const float d2 = epn_sq3(qx - s[k], qy - s[n + k], qz - s[2 * n + k]);
+            const T d2 = sq3_t(qx - s[k], qy - s[n + k], qz - s[2 * n + k]);
             hit = d2 < radius2;
         }
         const unsigned long long mask = __ballot(hit);
@@ -245,9 +255,10 @@ __global__ __launch_bounds__(256) void ball_query_kernel(const float *__restrict
 }
 
 // ------------------------------------------------------------------------------------ gather
-__global__ __launch_bounds__(256) void gather_fwd_kernel(const float *__restrict__ points,
+template <typename T>
+__global__ __launch_bounds__(256) void gather_fwd_kernel(const T *__restrict__ points,
                                                          const int32_t *__restrict__ idx, int c, int n,
-                                                         int m, float *__restrict__ out) {
+                                                         int m, T *__restrict__ out) {
     const int bi = blockIdx.z, ci = blockIdx.y;
     const int j = blockIdx.x * blockDim.x + threadIdx.x;
     if (j >= m) return;
@@ -255,14 +266,62 @@ __global__ __launch_bounds__(256) void gather_fwd_kernel(const float *__restrict
     out[((size_t)bi * c + ci) * m + j] = points[((size_t)bi * c + ci) * n + a];
 }
 
-__global__ __launch_bounds__(256) void gather_bwd_kernel(const float *__restrict__ grad_out,
+template <typename T>
+__global__ __launch_bounds__(256) void gather_bwd_kernel(const T *__restrict__ grad_out,
                                                          const int32_t *__restrict__ idx, int c, int n,
-                                                         int m, float *__restrict__ grad_points) {
+                                                         int m, T *__restrict__ grad_points) {
     const int bi = blockIdx.z, ci = blockIdx.y;
     const int j = blockIdx.x * blockDim.x + threadIdx.x;
     if (j >= m) return;
     const int a = idx[(size_t)bi * m + j];
     atomicAdd(grad_points + ((size_t)bi * c + ci) * n + a, grad_out[((size_t)bi * c + ci) * m + j]);
+}
+
+// fp64 FPS (furthest_point_sampling_cuda_kernel<scalar_t = double>, grouping_cuda_kernel.cu:351-466): not a hot path
+// (every shipped model samples fp32 coordinates), so this is the reference's own structure -- `block` virtual threads
+// scanning k = tid, tid + block, ..., a shared-memory tree with its __update tie rule (keep the first on ties) -- with
+// the running minima in global memory (temp) exactly like the reference.
+__global__ __launch_bounds__(1024) void fps_f64_kernel(const double *__restrict__ xyz, int n, int m, int block,
+                                                       double *__restrict__ temp, int32_t *__restrict__ idxs) {
+    __shared__ double dists[1024];
+    __shared__ int dists_i[1024];
+    const int tid = threadIdx.x;
+    const double *d = xyz + (size_t)blockIdx.x * 3 * n;
+    double *tmp = temp + (size_t)blockIdx.x * n;
+    int32_t *out = idxs + (size_t)blockIdx.x * m;
+    for (int k = tid; k < n; k += block) tmp[k] = 1e10;
+    if (tid == 0) out[0] = 0;
+    __syncthreads();
+    int old = 0;
+    for (int j = 1; j < m; ++j) {
+        int besti = 0;
+        double best = -1.0;
+        const double x1 = d[old], y1 = d[n + old], z1 = d[2 * n + old];
+        for (int k = tid; k < n; k += block) {
+            const double x2 = d[k], y2 = d[n + k], z2 = d[2 * n + k];
+            if (sq3_t(x2, y2, z2) <= 1e-3) continue;
+            const double dd = sq3_t(x2 - x1, y2 - y1, z2 - z1);
+            const double d2 = dd < tmp[k] ? dd : tmp[k];
+            tmp[k] = d2;
+            besti = d2 > best ? k : besti;
+            best = d2 > best ? d2 : best;
+        }
+        dists[tid] = best;
+        dists_i[tid] = besti;
+        __syncthreads();
+        for (int off = block / 2; off >= 1; off >>= 1) {
+            if (tid < off) {
+                const double v1 = dists[tid], v2 = dists[tid + off];
+                const int i1 = dists_i[tid], i2 = dists_i[tid + off];
+                dists[tid] = v1 > v2 ? v1 : v2;
+                dists_i[tid] = v2 > v1 ? i2 : i1;
+            }
+            __syncthreads();
+        }
+        old = dists_i[0];
+        if (tid == 0) out[j] = old;
+        __syncthreads();
+    }
 }
 
 int opt_n_threads(int work_size) {  // grouping_cuda_kernel.cu:29-33, same double-precision formula
@@ -282,7 +341,7 @@ extern "C" int epn_ball_query_f32(const float *new_xyz, const float *xyz, int b,
     if (b > 65535) return EPN_EINVAL;
     const int waves = 4;
     dim3 grid(epn_cdiv(m, waves), b);
-    hipLaunchKernelGGL(ball_query_kernel, grid, dim3(64 * waves), waves * nsample * sizeof(int32_t),
+    hipLaunchKernelGGL(ball_query_kernel<float>, grid, dim3(64 * waves), waves * nsample * sizeof(int32_t),
                        epn_stream(stream), new_xyz, xyz, n, m, radius, nsample, idx);
     EPN_CHECK_LAUNCH();
     return 0;
@@ -343,7 +402,7 @@ extern "C" int epn_gather_fwd_f32(const float *points, const int32_t *idx, int b
     if (!points || !idx || !out) return EPN_ENULL;
     if (c > 65535 || b > 65535) return EPN_EINVAL;
     dim3 grid(epn_cdiv(m, 256), c, b);
-    hipLaunchKernelGGL(gather_fwd_kernel, grid, dim3(256), 0, epn_stream(stream), points, idx, c, n, m, out);
+    hipLaunchKernelGGL(gather_fwd_kernel<float>, grid, dim3(256), 0, epn_stream(stream), points, idx, c, n, m, out);
     EPN_CHECK_LAUNCH();
     return 0;
 }
@@ -358,7 +417,7 @@ extern "C" int epn_gather_bwd_f32(const float *grad_out, const int32_t *idx, int
     if (!grad_out || !idx) return EPN_ENULL;
     if (c > 65535 || b > 65535) return EPN_EINVAL;
     dim3 grid(epn_cdiv(m, 256), c, b);
-    hipLaunchKernelGGL(gather_bwd_kernel, grid, dim3(256), 0, epn_stream(stream), grad_out, idx, c, n, m,
+    hipLaunchKernelGGL(gather_bwd_kernel<float>, grid, dim3(256), 0, epn_stream(stream), grad_out, idx, c, n, m,
                        grad_points);
     EPN_CHECK_LAUNCH();
     return 0;
@@ -458,6 +517,59 @@ extern "C" int epn_initial_anchor_query_f32(const float *centers, const float *x
     if (!centers || !kernel_points || !anchor_weights || !anchor_ctn || (m > 0 && !xyz)) return EPN_ENULL;
     hipLaunchKernelGGL(initial_anchor_query_kernel, dim3((unsigned)nc, (unsigned)b), dim3(AQ_T), 0, epn_stream(stream),
                        centers, xyz, kernel_points, nc, m, na, ks, radius, sigma, anchor_weights, anchor_ctn);
+    EPN_CHECK_LAUNCH();
+    return 0;
+}
+
+// ---- fp64 dispatch of the index / gather extensions (AT_DISPATCH_FLOATING_TYPES in the reference: double callers)
+extern "C" int epn_ball_query_f64(const double *new_xyz, const double *xyz, int b, int n, int m, double radius,
+                                  int nsample, int32_t *idx, epn_stream_t stream) {
+    if (b < 0 || n < 1 || m < 0 || nsample < 1 || nsample > 4096) return EPN_EINVAL;
+    if (b == 0 || m == 0) return 0;
+    if (!new_xyz || !xyz || !idx) return EPN_ENULL;
+    if (b > 65535) return EPN_EINVAL;
+    const int waves = 4;
+    dim3 grid(epn_cdiv(m, waves), b);
+    hipLaunchKernelGGL(ball_query_kernel<double>, grid, dim3(64 * waves), waves * nsample * sizeof(int32_t),
+                       epn_stream(stream), new_xyz, xyz, n, m, radius, nsample, idx);
+    EPN_CHECK_LAUNCH();
+    return 0;
+}
+
+extern "C" int epn_fps_f64(const double *xyz, int b, int n, int m, double *temp, int32_t *idx, epn_stream_t stream) {
+    if (b < 0 || n < 1 || m < 0) return EPN_EINVAL;
+    if (b == 0 || m == 0) return 0;
+    if (!xyz || !temp || !idx) return EPN_ENULL;
+    const int block = opt_n_threads(n);
+    hipLaunchKernelGGL(fps_f64_kernel, dim3(b), dim3(block), 0, epn_stream(stream), xyz, n, m, block, temp, idx);
+    EPN_CHECK_LAUNCH();
+    return 0;
+}
+
+extern "C" int epn_gather_fwd_f64(const double *points, const int32_t *idx, int b, int c, int n, int m, double *out,
+                                  epn_stream_t stream) {
+    if (b < 0 || c < 0 || n < 1 || m < 0) return EPN_EINVAL;
+    if (b == 0 || c == 0 || m == 0) return 0;
+    if (!points || !idx || !out) return EPN_ENULL;
+    if (c > 65535 || b > 65535) return EPN_EINVAL;
+    dim3 grid(epn_cdiv(m, 256), c, b);
+    hipLaunchKernelGGL(gather_fwd_kernel<double>, grid, dim3(256), 0, epn_stream(stream), points, idx, c, n, m, out);
+    EPN_CHECK_LAUNCH();
+    return 0;
+}
+
+extern "C" int epn_gather_bwd_f64(const double *grad_out, const int32_t *idx, int b, int c, int n, int m,
+                                  double *grad_points, epn_stream_t stream) {
+    if (b < 0 || c < 0 || n < 1 || m < 0) return EPN_EINVAL;
+    if (b == 0 || c == 0) return 0;
+    if (!grad_points) return EPN_ENULL;
+    EPN_HIP(hipMemsetAsync(grad_points, 0, sizeof(double) * (size_t)b * c * n, epn_stream(stream)));
+    if (m == 0) return 0;
+    if (!grad_out || !idx) return EPN_ENULL;
+    if (c > 65535 || b > 65535) return EPN_EINVAL;
+    dim3 grid(epn_cdiv(m, 256), c, b);
+    hipLaunchKernelGGL(gather_bwd_kernel<double>, grid, dim3(256), 0, epn_stream(stream), grad_out, idx, c, n, m,
+                       grad_points);
     EPN_CHECK_LAUNCH();
     return 0;
 }

@@ -5,24 +5,34 @@ from ... import _lib
 
 
 def ball_query(new_xyz, xyz, radius, nsample):
-    """(new_xyz f[b,3,m], xyz f[b,3,n], float radius, int nsample) -> int32 [b,m,nsample]
-    (grouping_cuda.cpp:71-86)."""
+    """(new_xyz f[b,3,m], xyz f[b,3,n], float radius, int nsample) -> int32 [b,m,nsample]; float32 or float64 coordinates
+    (grouping_cuda.cpp:71-86; AT_DISPATCH_FLOATING_TYPES, grouping_cuda_kernel.cu:477)."""
     lib = _lib.get_lib()
-    q, s = _lib.dev_ptr(new_xyz, "new_xyz"), _lib.dev_ptr(xyz, "xyz")
+    dt = _lib.float_dtype(xyz, "xyz")
+    q, s = _lib.dev_ptr(new_xyz, "new_xyz", dt), _lib.dev_ptr(xyz, "xyz", dt)
     b, _, m = new_xyz.shape
     n = xyz.shape[2]
     idx = torch.empty((b, m, int(nsample)), dtype=torch.int32, device=xyz.device)
-    _lib.check(lib.epn_ball_query_f32(q, s, b, n, m, float(radius), int(nsample),
-                                      _lib.dev_ptr(idx, "idx", torch.int32), _lib.stream_of(xyz)), "ball_query")
+    fn = lib.epn_ball_query_f64 if dt == torch.float64 else lib.epn_ball_query_f32
+    _lib.check(fn(q, s, b, n, m, float(radius), int(nsample), _lib.dev_ptr(idx, "idx", torch.int32), _lib.stream_of(xyz)),
+               "ball_query")
     return idx
 
 
 def furthest_point_sampling(source_xyz, m):
-    """(xyz f[b,3,n], int m) -> int32 [b,m]  (grouping_cuda.cpp:160-174)."""
+    """(xyz f[b,3,n], int m) -> int32 [b,m]; float32 or float64 coordinates (grouping_cuda.cpp:160-174; the fp64
+    instantiation keeps its running minima in a temp tensor like the reference, :167-168)."""
     lib = _lib.get_lib()
-    p = _lib.dev_ptr(source_xyz, "source_xyz")
+    dt = _lib.float_dtype(source_xyz, "source_xyz")
+    p = _lib.dev_ptr(source_xyz, "source_xyz", dt)
     b, _, n = source_xyz.shape
     idx = torch.empty((b, int(m)), dtype=torch.int32, device=source_xyz.device)
+    if dt == torch.float64:
+        temp = torch.empty((b, n), dtype=torch.float64, device=source_xyz.device)
+        _lib.check(lib.epn_fps_f64(p, b, n, int(m), _lib.dev_ptr(temp, "temp", dt),
+                                   _lib.dev_ptr(idx, "sampled_idx", torch.int32), _lib.stream_of(source_xyz)),
+                   "furthest_point_sampling")
+        return idx
     _lib.check(lib.epn_fps_f32(p, b, n, int(m), _lib.dev_ptr(idx, "sampled_idx", torch.int32),
                                _lib.stream_of(source_xyz)), "furthest_point_sampling")
     return idx

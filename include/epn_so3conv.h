@@ -63,6 +63,19 @@ int epn_gather_fwd_f32(const float *points, const int32_t *idx, int b, int c, in
 int epn_gather_bwd_f32(const float *grad_out, const int32_t *idx, int b, int c, int n, int m,
                        float *grad_points, epn_stream_t stream);
 
+/* fp64 dispatch of the same four extensions: the reference instantiates them for float AND double
+ * (AT_DISPATCH_FLOATING_TYPES: grouping_cuda_kernel.cu:477 ball query, :638-726 FPS; gathering_cuda_kernel.cu:117,151).
+ * Same semantics with double coordinates / features; indices stay int32.  epn_fps_f64 takes the reference's `temp`
+ * buffer (f64[b,n], grouping_cuda.cpp:167-168; initialised to 1e10 here) because it keeps the running minima there, as the
+ * reference kernel does -- fp64 sampling is a compatibility path, not a tuned one. */
+int epn_ball_query_f64(const double *new_xyz, const double *xyz, int b, int n, int m, double radius, int nsample,
+                       int32_t *idx, epn_stream_t stream);
+int epn_fps_f64(const double *xyz, int b, int n, int m, double *temp, int32_t *idx, epn_stream_t stream);
+int epn_gather_fwd_f64(const double *points, const int32_t *idx, int b, int c, int n, int m, double *out,
+                       epn_stream_t stream);
+int epn_gather_bwd_f64(const double *grad_out, const int32_t *idx, int b, int c, int n, int m, double *grad_points,
+                       epn_stream_t stream);
+
 /* ------------------------------------------------------------------ InterSO3Conv ------------ */
 
 /* Geometry + shapes of one inter convolution (vgtk/vgtk/so3conv/functional.py:118-178).

@@ -186,3 +186,100 @@ void epn_oracle_initial_anchor_query_f32(const float *centers, const float *xyz,
         }
     }
 }
+
+/* ------------------------------------------------------------------------------------------------------------------
+ * fp64 variants: the reference dispatches these kernels on float AND double (AT_DISPATCH_FLOATING_TYPES,
+ * grouping_cuda_kernel.cu:477,638-726, gathering_cuda_kernel.cu:117,151).  Same algorithms with scalar_t = double;
+ * the radius / temp / 1e-3 threshold arithmetic follows the templates (radius2 = radius*radius in scalar_t, the
+ * magnitude test compares a double with the double literal).  Canonical squared distance as above, in double.
+ */
+static inline double sq3d(double a, double b, double c) {
+    double t = a * a;
+    t = fma(b, b, t);
+    t = fma(c, c, t);
+    return t;
+}
+
+void epn_oracle_ball_query_f64(const double *new_xyz, const double *xyz, int b, int n, int m, double radius,
+                               int nsample, int32_t *idx) {
+    const double radius2 = radius * radius;
+    memset(idx, 0, sizeof(int32_t) * (size_t)b * m * nsample);
+    for (int bi = 0; bi < b; ++bi) {
+        const double *q = new_xyz + (size_t)bi * 3 * m;
+        const double *s = xyz + (size_t)bi * 3 * n;
+        int32_t *o = idx + (size_t)bi * m * nsample;
+        for (int j = 0; j < m; ++j) {
+            const double qx = q[j], qy = q[m + j], qz = q[2 * m + j];
+            int cnt = 0;
+            for (int k = 0; k < n && cnt < nsample; ++k) {
+                const double d2 = sq3d(qx - s[k], qy - s[n + k], qz - s[2 * n + k]);
+                if (d2 < radius2) {
+                    o[j * nsample + cnt] = k;
+                    ++cnt;
+                }
+            }
+            if (cnt < nsample - 1)
+                for (int k = 0; k + cnt < nsample; ++k) o[j * nsample + k + cnt] = o[j * nsample + k];
+        }
+    }
+}
+
+void epn_oracle_fps_f64(const double *dataset, int b, int n, int m, double *temp, int32_t *idxs) {
+    if (m <= 0) return;
+    const int block = epn_oracle_opt_n_threads(n);
+    double *dists = (double *)malloc(sizeof(double) * block);
+    int *dists_i = (int *)malloc(sizeof(int) * block);
+    for (int bi = 0; bi < b; ++bi) {
+        const double *d = dataset + (size_t)bi * 3 * n;
+        double *tmp = temp + (size_t)bi * n;
+        int32_t *out = idxs + (size_t)bi * m;
+        int old = 0;
+        out[0] = 0;
+        for (int j = 1; j < m; ++j) {
+            const double x1 = d[old], y1 = d[n + old], z1 = d[2 * n + old];
+            for (int tid = 0; tid < block; ++tid) {
+                int besti = 0;
+                double best = -1.0;
+                for (int k = tid; k < n; k += block) {
+                    const double x2 = d[k], y2 = d[n + k], z2 = d[2 * n + k];
+                    if (sq3d(x2, y2, z2) <= 1e-3) continue;
+                    const double dd = sq3d(x2 - x1, y2 - y1, z2 - z1);
+                    const double d2 = dd < tmp[k] ? dd : tmp[k];
+                    tmp[k] = d2;
+                    besti = d2 > best ? k : besti;
+                    best = d2 > best ? d2 : best;
+                }
+                dists[tid] = best;
+                dists_i[tid] = besti;
+            }
+            for (int off = block / 2; off >= 1; off >>= 1)
+                for (int tid = 0; tid < off; ++tid) {
+                    const double v1 = dists[tid], v2 = dists[tid + off];
+                    const int i1 = dists_i[tid], i2 = dists_i[tid + off];
+                    dists[tid] = v1 > v2 ? v1 : v2;
+                    dists_i[tid] = v2 > v1 ? i2 : i1;
+                }
+            old = dists_i[0];
+            out[j] = old;
+        }
+    }
+    free(dists);
+    free(dists_i);
+}
+
+void epn_oracle_gather_fwd_f64(const double *points, const int32_t *idx, int b, int c, int n, int m, double *out) {
+    for (int bi = 0; bi < b; ++bi)
+        for (int ci = 0; ci < c; ++ci)
+            for (int j = 0; j < m; ++j)
+                out[((size_t)bi * c + ci) * m + j] = points[((size_t)bi * c + ci) * n + idx[(size_t)bi * m + j]];
+}
+
+void epn_oracle_gather_bwd_f64(const double *grad_out, const int32_t *idx, int b, int c, int n, int m,
+                               double *grad_points) {
+    memset(grad_points, 0, sizeof(double) * (size_t)b * c * n);
+    for (int bi = 0; bi < b; ++bi)
+        for (int ci = 0; ci < c; ++ci)
+            for (int j = 0; j < m; ++j)
+                grad_points[((size_t)bi * c + ci) * n + idx[(size_t)bi * m + j]] +=
+                    grad_out[((size_t)bi * c + ci) * m + j];
+}

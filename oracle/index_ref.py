@@ -53,6 +53,11 @@ def _load():
         lib.epn_oracle_gather_bwd_f32.argtypes = [f32p, i32p, ci, ci, ci, ci, f32p]
         lib.epn_oracle_initial_anchor_query_f32.argtypes = [f32p, f32p, f32p, ci, ci, ci, ci, ci, ctypes.c_float,
                                                             ctypes.c_float, f32p, f32p]
+        f64p = ctypes.POINTER(ctypes.c_double)
+        lib.epn_oracle_ball_query_f64.argtypes = [f64p, f64p, ci, ci, ci, ctypes.c_double, ci, i32p]
+        lib.epn_oracle_fps_f64.argtypes = [f64p, ci, ci, ci, f64p, i32p]
+        lib.epn_oracle_gather_fwd_f64.argtypes = [f64p, i32p, ci, ci, ci, ci, f64p]
+        lib.epn_oracle_gather_bwd_f64.argtypes = [f64p, i32p, ci, ci, ci, ci, f64p]
         lib.epn_oracle_opt_n_threads.argtypes = [ci]
         lib.epn_oracle_opt_n_threads.restype = ci
         _lib = lib
@@ -62,6 +67,16 @@ def _load():
 def _f32(t):
     a = np.ascontiguousarray(t.detach().cpu().numpy(), dtype=np.float32)
     return a, a.ctypes.data_as(ctypes.POINTER(ctypes.c_float))
+
+
+def _f64(t):
+    a = np.ascontiguousarray(t.detach().cpu().numpy(), dtype=np.float64)
+    return a, a.ctypes.data_as(ctypes.POINTER(ctypes.c_double))
+
+
+def _is64(t):
+    """The reference dispatches the index / gather kernels on float and double (AT_DISPATCH_FLOATING_TYPES)."""
+    return t.dtype == torch.float64
 
 
 def _i32(t):
@@ -74,9 +89,15 @@ def ball_query(new_xyz, xyz, radius, nsample):
     lib = _load()
     b, _, m = new_xyz.shape
     n = xyz.shape[2]
+    out = np.zeros((b, m, nsample), dtype=np.int32)
+    if _is64(xyz):
+        qa, qp = _f64(new_xyz)
+        sa, sp = _f64(xyz)
+        lib.epn_oracle_ball_query_f64(qp, sp, b, n, m, float(radius), int(nsample),
+                                      out.ctypes.data_as(ctypes.POINTER(ctypes.c_int32)))
+        return torch.from_numpy(out)
     qa, qp = _f32(new_xyz)
     sa, sp = _f32(xyz)
-    out = np.zeros((b, m, nsample), dtype=np.int32)
     lib.epn_oracle_ball_query_f32(qp, sp, b, n, m, float(radius), int(nsample),
                                   out.ctypes.data_as(ctypes.POINTER(ctypes.c_int32)))
     return torch.from_numpy(out)
@@ -86,9 +107,15 @@ def furthest_point_sampling(xyz, m):
     """(xyz f[b,3,n], m) -> int32 [b,m]; temp = 1e10 as grouping_cuda.cpp:167-168."""
     lib = _load()
     b, _, n = xyz.shape
+    out = np.zeros((b, m), dtype=np.int32)
+    if _is64(xyz):
+        xa, xp = _f64(xyz)
+        temp = np.full((b, n), 1e10, dtype=np.float64)
+        lib.epn_oracle_fps_f64(xp, b, n, int(m), temp.ctypes.data_as(ctypes.POINTER(ctypes.c_double)),
+                               out.ctypes.data_as(ctypes.POINTER(ctypes.c_int32)))
+        return torch.from_numpy(out)
     xa, xp = _f32(xyz)
     temp = np.full((b, n), 1e10, dtype=np.float32)
-    out = np.zeros((b, m), dtype=np.int32)
     lib.epn_oracle_fps_f32(xp, b, n, int(m), temp.ctypes.data_as(ctypes.POINTER(ctypes.c_float)),
                            out.ctypes.data_as(ctypes.POINTER(ctypes.c_int32)))
     return torch.from_numpy(out)
@@ -99,8 +126,13 @@ def gather_points_forward(points, idx):
     lib = _load()
     b, c, n = points.shape
     m = idx.shape[1]
-    pa, pp = _f32(points)
     ia, ip = _i32(idx)
+    if _is64(points):
+        pa, pp = _f64(points)
+        out = np.zeros((b, c, m), dtype=np.float64)
+        lib.epn_oracle_gather_fwd_f64(pp, ip, b, c, n, m, out.ctypes.data_as(ctypes.POINTER(ctypes.c_double)))
+        return torch.from_numpy(out)
+    pa, pp = _f32(points)
     out = np.zeros((b, c, m), dtype=np.float32)
     lib.epn_oracle_gather_fwd_f32(pp, ip, b, c, n, m, out.ctypes.data_as(ctypes.POINTER(ctypes.c_float)))
     return torch.from_numpy(out)
@@ -110,8 +142,14 @@ def gather_points_backward(grad_out, idx, npoint):
     """(grad_out f[b,c,m], idx int32[b,m], npoint) -> f[b,c,npoint]."""
     lib = _load()
     b, c, m = grad_out.shape
-    ga, gp = _f32(grad_out)
     ia, ip = _i32(idx)
+    if _is64(grad_out):
+        ga, gp = _f64(grad_out)
+        out = np.zeros((b, c, npoint), dtype=np.float64)
+        lib.epn_oracle_gather_bwd_f64(gp, ip, b, c, int(npoint), m,
+                                      out.ctypes.data_as(ctypes.POINTER(ctypes.c_double)))
+        return torch.from_numpy(out)
+    ga, gp = _f32(grad_out)
     out = np.zeros((b, c, npoint), dtype=np.float32)
     lib.epn_oracle_gather_bwd_f32(gp, ip, b, c, int(npoint), m,
                                   out.ctypes.data_as(ctypes.POINTER(ctypes.c_float)))

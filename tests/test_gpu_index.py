@@ -223,3 +223,44 @@ def test_anchor_query_vs_oracle(gpu, vgtk_alias):
     z = torch.zeros(1, 1, dtype=torch.int32, device=gpu)
     w = cuda_nn.anchor_query(z, z.view(1, 1, 1), g1.to(gpu), a1.to(gpu), k1.to(gpu), 1)[0].cpu().flatten()
     assert abs(w[0].item() - 1.0) < 1e-4 and abs(w[1].item() - (1.0 + np.pi ** 2)) < 1e-4
+
+
+@pytest.mark.parametrize("b,n,m", [(1, 1, 1), (2, 3, 2), (3, 63, 17), (2, 100, 33), (4, 513, 200), (1, 5000, 64)])
+def test_fps_f64_vs_oracle(ext, b, n, m):
+    """fp64 dispatch of FPS (furthest_point_sampling_cuda_kernel<double>, grouping_cuda_kernel.cu:638-726): bit-exact
+    indices against the double oracle, including clouds where float and double sampling differ."""
+    cuda_nn, _, dev = ext
+    rng = np.random.default_rng(n * 17 + m)
+    x = T(rng.standard_normal((b, 3, n))) * 0.5                       # float64
+    got = cuda_nn.furthest_point_sampling(x.to(dev), m).cpu()
+    assert got.dtype == torch.int32
+    assert torch.equal(got, index_ref.furthest_point_sampling(x, m))
+
+
+@pytest.mark.parametrize("b,n,m,r,k", [(2, 200, 50, 0.4, 16), (1, 1000, 64, 0.2, 32), (3, 77, 77, 0.9, 8), (1, 130, 5, 1e-6, 4)])
+def test_ball_query_f64_vs_oracle(ext, b, n, m, r, k):
+    cuda_nn, _, dev = ext
+    rng = np.random.default_rng(n + m)
+    s = T(rng.standard_normal((b, 3, n))) * 0.5
+    q = s[:, :, :m].contiguous()
+    got = cuda_nn.ball_query(q.to(dev), s.to(dev), r, k).cpu()
+    assert torch.equal(got, index_ref.ball_query(q, s, r, k))
+
+
+def test_gather_f64_and_dtype_errors(ext):
+    """gather_points fwd / bwd in double (gathering_cuda_kernel.cu:117,151) and the dtype contract of the wrappers."""
+    cuda_nn, gather, dev = ext
+    rng = np.random.default_rng(5)
+    p = T(rng.standard_normal((2, 7, 90)))
+    idx = T(rng.integers(0, 90, size=(2, 40)).astype(np.int32))
+    out = gather.gather_points_forward(p.to(dev), idx.to(dev))
+    assert out.dtype == torch.float64
+    assert torch.equal(out.cpu(), index_ref.gather_points_forward(p, idx))
+    g = T(rng.standard_normal((2, 7, 40)))
+    gb = gather.gather_points_backward(g.to(dev), idx.to(dev), 90)
+    assert gb.dtype == torch.float64
+    assert (gb.cpu() - index_ref.gather_points_backward(g, idx, 90)).abs().max().item() < 1e-12
+    with pytest.raises(TypeError):
+        cuda_nn.furthest_point_sampling(p.half().to(dev), 4)
+    with pytest.raises(TypeError):
+        cuda_nn.ball_query(p[:, :3, :4].float().contiguous().to(dev), p[:, :3].contiguous().to(dev), 0.1, 4)   # mixed dtypes
