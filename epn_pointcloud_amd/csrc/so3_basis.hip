@@ -22,7 +22,38 @@ struct SbArgs {
     void *out;
     long long pts;
     int na, c, in_spec, out_spec;
+    // optional: leaky_relu(norm(.)) applied to the input rows as they are loaded ("norm on load": the block glue's first
+    // normalisation folded into the basis change) -- nsums[g][c] = (sum x, sum x^2) as epn_chan_stats writes
+    const float *nsums, *ngamma, *nbeta;
+    float neps, nslope, ninv_rows;
+    int ngroups;
+    long long npts_per_group;
 };
+
+// per-lane normalisation of its 4 channels: n = (v - mean) * rstd * gamma + beta, leaky (the formula of glue.hip's
+// norm_act_fwd_kernel, so folded and unfolded paths agree to the last bit)
+struct SbNorm {
+    float mean[4], rstd[4], ga[4], be[4];
+    float slope;
+};
+__device__ __forceinline__ void sb_norm_load(const SbArgs &A, long long pt, int ch, SbNorm &N) {
+    const int g = A.ngroups == 1 ? 0 : (int)(pt / A.npts_per_group);
+    const float *s = A.nsums + ((size_t)g * A.c + ch) * 2;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const float m = s[2 * i] * A.ninv_rows;
+        const float var = fmaxf(s[2 * i + 1] * A.ninv_rows - m * m, 0.0f);
+        N.mean[i] = m;
+        N.rstd[i] = rsqrtf(var + A.neps);
+        N.ga[i] = A.ngamma ? A.ngamma[ch + i] : 1.0f;
+        N.be[i] = A.nbeta ? A.nbeta[ch + i] : 0.0f;
+    }
+    N.slope = A.nslope;
+}
+__device__ __forceinline__ float sb_norm1(const SbNorm &N, int i, float v) {
+    const float n = (v - N.mean[i]) * N.rstd[i] * N.ga[i] + N.be[i];
+    return n > 0.0f ? n : n * N.slope;
+}
 
 __device__ __forceinline__ f32x4 mfma4(float a, float b, f32x4 c) {
     return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0);
@@ -79,6 +110,20 @@ __global__ __launch_bounds__(64 * SB_WAVES) void so3_basis_kernel(SbArgs A) {
 #pragma unroll
         for (int st = 0; st < 16; ++st)
             if (st < nst) bv[st] = sb_ld(static_cast<const T *>(A.in) + row_addr(A.in_spec, 4 * st + j));
+        if (A.nsums) {
+            SbNorm N;
+            sb_norm_load(A, pt, choff, N);
+#pragma unroll
+            for (int st = 0; st < 16; ++st)
+                if (st < nst) {
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) {
+                        float n = sb_norm1(N, i, bv[st][i]);
+                        if constexpr (sizeof(T) == 2) n = (float)(__bf16)n;    // what the unfolded path stores and re-reads
+                        bv[st][i] = n;
+                    }
+                }
+        }
 #pragma unroll
         for (int st = 0; st < 16; ++st) {
             if (st < nst) {
@@ -155,6 +200,23 @@ __global__ __launch_bounds__(64 * SB_WAVES) void so3_basis_bf16_kernel(SbArgs A)
                 const int r = 32 * ks + 8 * j + e;
                 raw[ks][e] = r < A.na ? *reinterpret_cast<const sbu32x2 *>(in + row_addr(A.in_spec, r)) : sbu32x2{0u, 0u};
             }
+        if (A.nsums) {
+            SbNorm N;
+            sb_norm_load(A, pt, choff, N);
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    if (32 * ks + 8 * j + e < A.na) {
+                        const sbu32x2 w = raw[ks][e];
+                        const float v0 = __builtin_bit_cast(float, w[0] << 16), v1 = __builtin_bit_cast(float, w[0] & 0xffff0000u);
+                        const float v2 = __builtin_bit_cast(float, w[1] << 16), v3 = __builtin_bit_cast(float, w[1] & 0xffff0000u);
+                        const sbf16x4 o = {(__bf16)sb_norm1(N, 0, v0), (__bf16)sb_norm1(N, 1, v1), (__bf16)sb_norm1(N, 2, v2),
+                                           (__bf16)sb_norm1(N, 3, v3)};
+                        raw[ks][e] = __builtin_bit_cast(sbu32x2, o);
+                    }
+                }
+        }
         f32x4 acc[4][4];
 #pragma unroll
         for (int mt = 0; mt < 4; ++mt)
@@ -203,14 +265,32 @@ __global__ __launch_bounds__(64 * SB_WAVES) void so3_basis_bf16_kernel(SbArgs A)
 
 using namespace epn;
 
+struct SbNormHost {
+    const float *sums, *gamma, *beta;
+    int groups;
+    long long pts_per_group;
+    float eps, slope;
+};
+
 static int so3_basis_any(const void *in, const float *M, const int32_t *blocks, long long pts, int na, int c,
-                        int in_spectral, int out_spectral, void *out, int bf16, epn_stream_t stream) {
+                        int in_spectral, int out_spectral, void *out, int bf16, epn_stream_t stream,
+                        const SbNormHost *nh = nullptr) {
     if (pts < 0 || na < 4 || na > 64 || (na & 3) || c < 64 || (c & 63)) return EPN_EINVAL;
     if (pts == 0) return 0;
     if (!in || !M || !blocks || !out) return EPN_ENULL;
     SbArgs A;
     A.in = in; A.M = M; A.blk = blocks; A.out = out; A.pts = pts; A.na = na; A.c = c;
     A.in_spec = in_spectral; A.out_spec = out_spectral;
+    A.nsums = nullptr; A.ngamma = A.nbeta = nullptr; A.neps = 0.f; A.nslope = 0.f; A.ninv_rows = 0.f; A.ngroups = 1;
+    A.npts_per_group = pts;
+    if (nh) {
+        if (!nh->sums) return EPN_ENULL;
+        if (in_spectral || nh->groups < 1 || nh->pts_per_group < 1 || (nh->groups > 1 && nh->groups * nh->pts_per_group != pts))
+            return EPN_EINVAL;
+        A.nsums = nh->sums; A.ngamma = nh->gamma; A.nbeta = nh->beta; A.neps = nh->eps; A.nslope = nh->slope;
+        A.ngroups = nh->groups; A.npts_per_group = nh->groups > 1 ? nh->pts_per_group : pts;
+        A.ninv_rows = 1.0f / ((float)A.npts_per_group * (float)na);
+    }
     const long long tasks = pts * (c >> 6);
     const long long per_wg = (long long)SB_WAVES * SB_TPW;
     const dim3 grid((unsigned)((tasks + per_wg - 1) / per_wg));
@@ -227,4 +307,19 @@ extern "C" int epn_so3_basis_f32(const float *in, const float *M, const int32_t 
 extern "C" int epn_so3_basis_bf16(const void *in, const float *M, const int32_t *blocks, long long pts, int na, int c,
                                   int in_spectral, int out_spectral, void *out, epn_stream_t stream) {
     return so3_basis_any(in, M, blocks, pts, na, c, in_spectral, out_spectral, out, 1, stream);
+}
+
+// leaky_relu(norm(in)) applied on load, then the change of basis (in plain layout only): sums[g][c] = (sum x, sum x^2)
+// over the (points of group g) x anchors rows, groups = 1 (BatchNorm2d) or the number of clouds (InstanceNorm2d)
+extern "C" int epn_so3_basis_norm_f32(const float *in, const float *M, const int32_t *blocks, long long pts, int na, int c,
+                                      int out_spectral, float *out, const float *sums, int groups, long long pts_per_group,
+                                      const float *gamma, const float *beta, float eps, float slope, epn_stream_t stream) {
+    const SbNormHost nh = {sums, gamma, beta, groups, pts_per_group, eps, slope};
+    return so3_basis_any(in, M, blocks, pts, na, c, 0, out_spectral, out, 0, stream, &nh);
+}
+extern "C" int epn_so3_basis_norm_bf16(const void *in, const float *M, const int32_t *blocks, long long pts, int na, int c,
+                                       int out_spectral, void *out, const float *sums, int groups, long long pts_per_group,
+                                       const float *gamma, const float *beta, float eps, float slope, epn_stream_t stream) {
+    const SbNormHost nh = {sums, gamma, beta, groups, pts_per_group, eps, slope};
+    return so3_basis_any(in, M, blocks, pts, na, c, 0, out_spectral, out, 1, stream, &nh);
 }

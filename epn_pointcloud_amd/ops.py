@@ -718,7 +718,7 @@ class _BlockGemmsFn(torch.autograd.Function):
         return (gy, None, None, None, None, *gws)
 
 
-def intra_so3conv_spectral(feats, W, intra_idx32, basis):
+def intra_so3conv_spectral(feats, W, intra_idx32, basis, pre_norm=None, pre_slope=0.01):
     """IntraSO3Conv.forward (vgtk/vgtk/so3conv/modules.py:197-200) in the block-diagonal anchor basis: same result up to
     fp32 rounding, 244 instead of 720 multiply-adds per (point, cin, cout), no [cols, 12*cin] grouped tensor; gradients
     by autograd through the same pieces (GEMMs and transforms on this library's HIP kernels)."""
@@ -728,7 +728,15 @@ def intra_so3conv_spectral(feats, W, intra_idx32, basis):
     if W.shape[1] != cin * kn or intra_idx32.shape[0] != na:
         raise ValueError(f"shape mismatch: feats {tuple(f.shape)}, W {tuple(W.shape)}, intra_idx {tuple(intra_idx32.shape)}")
     pts = b * p
-    y = ToSpectralFn.apply(f, basis)
+    if pre_norm is not None:
+        # the block's preceding norm + leaky_relu, folded into the transform's loads (training-mode statistics)
+        import torch.nn as nn
+        inst = isinstance(pre_norm, nn.InstanceNorm2d)
+        y, sums = NormToSpectralFn.apply(f, getattr(pre_norm, "weight", None), getattr(pre_norm, "bias", None), None,
+                                         inst, pre_norm.eps, pre_slope, basis)
+        _update_running_stats(pre_norm, sums, b * p * na)
+    else:
+        y = ToSpectralFn.apply(f, basis)
     # What^rho[(j, c), (i, o)] = sum_k W[o, c, k] rho(g_k)[i, j]: one small GEMM for all blocks, then a re-layout each
     wh_all = gemm.matmul_nt(W.reshape(cout * cin, kn), basis.rho_all_t)     # [cout*cin, na]
     whats = [wh_all[:, base:base + d * d].reshape(cout, cin, d, d).permute(3, 1, 2, 0).reshape(d * cin, d * cout)
@@ -754,13 +762,9 @@ class NormActFn(torch.autograd.Function):
         xc = to_cl(x, "x")
         b, c, p, a = xc.shape
         groups, rows = (b, p * a) if instance else (1, b * p * a)
-        sums = torch.empty((groups, c, 2), dtype=torch.float32, device=xc.device)
         st = _lib.stream_of(xc)
-        ws = torch.empty(max(int(lib.epn_norm_workspace_bytes(groups, rows, c)), 16), dtype=torch.uint8, device=xc.device)
         dt = xc.dtype
-        _lib.check(_entry(lib, "chan_stats", dt)(_cl_ptr(xc), groups, rows, c, _lib.dev_ptr(sums, "sums"),
-                                                 ctypes.c_void_p(ws.data_ptr()), ctypes.c_size_t(ws.numel()), st),
-                   "chan_stats")
+        sums = _chan_stats(xc, groups, rows, c)
         y = empty_cl(b, c, p, a, xc.device, dt)
         g = gamma.contiguous() if gamma is not None else None
         bt = beta.contiguous() if beta is not None else None
@@ -776,30 +780,108 @@ class NormActFn(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, grad_y, _grad_sums):
-        lib = _lib.get_lib()
         xc, sums, g, bt = ctx.saved_tensors
         groups, rows, c, eps, slope, has_res, has_cb = ctx.cfg
         dy = cast_feats(to_cl(grad_y, "grad_y"), xc.dtype)
-        st = _lib.stream_of(xc)
-        dsums = torch.empty_like(sums)
-        dg = torch.empty(c, dtype=torch.float32, device=xc.device) if g is not None else None
-        db = torch.empty(c, dtype=torch.float32, device=xc.device) if bt is not None else None
-        gp, bp = _lib.dev_ptr(g, "gamma"), _lib.dev_ptr(bt, "beta")
-        ws = torch.empty(max(int(lib.epn_norm_workspace_bytes(groups, rows, c)), 16), dtype=torch.uint8, device=xc.device)
-        _lib.check(_entry(lib, "norm_act_bwd_reduce", xc.dtype)(_cl_ptr(xc), _cl_ptr(dy), groups, rows, c,
-                                                   _lib.dev_ptr(sums, "sums"), gp, bp, eps, slope,
-                                                   _lib.dev_ptr(dsums, "dsums"), _lib.dev_ptr(dg, "dgamma"),
-                                                   _lib.dev_ptr(db, "dbeta"), ctypes.c_void_p(ws.data_ptr()),
-                                                   ctypes.c_size_t(ws.numel()), st), "norm_act_bwd_reduce")
-        dx = None
-        if ctx.needs_input_grad[0]:
-            dx = torch.empty_like(xc)
-            _lib.check(_entry(lib, "norm_act_bwd_apply", xc.dtype)(_cl_ptr(xc), _cl_ptr(dy), groups, rows, c,
-                                                      _lib.dev_ptr(sums, "sums"), _lib.dev_ptr(dsums, "dsums"), gp, bp,
-                                                      eps, slope, _cl_ptr(dx), st), "norm_act_bwd_apply")
+        dx, dg, db = _norm_act_backward(xc, dy, sums, g, bt, groups, rows, c, eps, slope, ctx.needs_input_grad[0])
         # conv_bias (a bias the normalisation cancels, see norm_act): exact gradient = 0
         dcb = torch.zeros(c, dtype=torch.float32, device=xc.device) if has_cb else None
         return dx, dg, db, (dy if has_res else None), dcb, None, None, None
+
+
+def _chan_stats(xc, groups, rows, c):
+    """sums[g][c] = (sum x, sum x^2) of a channels-last tensor (epn_chan_stats_*: block partials + finishing kernel)."""
+    lib = _lib.get_lib()
+    sums = torch.empty((groups, c, 2), dtype=torch.float32, device=xc.device)
+    ws = torch.empty(max(int(lib.epn_norm_workspace_bytes(groups, rows, c)), 16), dtype=torch.uint8, device=xc.device)
+    _lib.check(_entry(lib, "chan_stats", xc.dtype)(_cl_ptr(xc), groups, rows, c, _lib.dev_ptr(sums, "sums"),
+                                                   ctypes.c_void_p(ws.data_ptr()), ctypes.c_size_t(ws.numel()),
+                                                   _lib.stream_of(xc)), "chan_stats")
+    return sums
+
+
+def _norm_act_backward(xc, dy, sums, g, bt, groups, rows, c, eps, slope, need_dx):
+    """Backward of y = leaky(norm(x)): (dx, dgamma, dbeta) from x, dy and the forward statistics (two streaming passes)."""
+    lib = _lib.get_lib()
+    st = _lib.stream_of(xc)
+    dsums = torch.empty_like(sums)
+    dg = torch.empty(c, dtype=torch.float32, device=xc.device) if g is not None else None
+    db = torch.empty(c, dtype=torch.float32, device=xc.device) if bt is not None else None
+    gp, bp = _lib.dev_ptr(g, "gamma"), _lib.dev_ptr(bt, "beta")
+    ws = torch.empty(max(int(lib.epn_norm_workspace_bytes(groups, rows, c)), 16), dtype=torch.uint8, device=xc.device)
+    _lib.check(_entry(lib, "norm_act_bwd_reduce", xc.dtype)(_cl_ptr(xc), _cl_ptr(dy), groups, rows, c,
+                                               _lib.dev_ptr(sums, "sums"), gp, bp, eps, slope,
+                                               _lib.dev_ptr(dsums, "dsums"), _lib.dev_ptr(dg, "dgamma"),
+                                               _lib.dev_ptr(db, "dbeta"), ctypes.c_void_p(ws.data_ptr()),
+                                               ctypes.c_size_t(ws.numel()), st), "norm_act_bwd_reduce")
+    dx = None
+    if need_dx:
+        dx = torch.empty_like(xc)
+        _lib.check(_entry(lib, "norm_act_bwd_apply", xc.dtype)(_cl_ptr(xc), _cl_ptr(dy), groups, rows, c,
+                                                  _lib.dev_ptr(sums, "sums"), _lib.dev_ptr(dsums, "dsums"), gp, bp,
+                                                  eps, slope, _cl_ptr(dx), st), "norm_act_bwd_apply")
+    return dx, dg, db
+
+
+class NormToSpectralFn(torch.autograd.Function):
+    """ToSpectral(leaky_relu(norm(x))) with the normalisation applied as the basis-change kernel loads its rows
+    (epn_so3_basis_norm_*): the normalised tensor is never written or re-read (SURVEY 8f.1 "norm on load").  Backward:
+    inverse transform of the spectral gradient, then the two norm passes of NormActFn.  Returns (y_spectral, sums)."""
+
+    @staticmethod
+    def forward(ctx, x, gamma, beta, conv_bias, instance, eps, slope, basis):
+        lib = _lib.get_lib()
+        xc = to_cl(x, "x")
+        b, c, p, na = xc.shape
+        groups, rows = (b, p * na) if instance else (1, b * p * na)
+        sums = _chan_stats(xc, groups, rows, c)
+        g = gamma.contiguous() if gamma is not None else None
+        bt = beta.contiguous() if beta is not None else None
+        y = torch.empty(na * b * p * c, dtype=xc.dtype, device=xc.device)
+        fn = _entry(lib, "so3_basis_norm", xc.dtype)
+        _lib.check(_launch("so3_basis", ("so3_basis", b * p, c), 2.0 * b * p * na * na * c, xc.device,
+                           lambda: fn(_cl_ptr(xc), _lib.dev_ptr(basis.Ut, "M"), _lib.dev_ptr(basis.blocks, "blocks", torch.int32),
+                                      ctypes.c_longlong(b * p), na, c, 1, ctypes.c_void_p(y.data_ptr()),
+                                      _lib.dev_ptr(sums, "sums"), groups, ctypes.c_longlong(p),
+                                      _lib.dev_ptr(g, "gamma"), _lib.dev_ptr(bt, "beta"), float(eps), float(slope),
+                                      _lib.stream_of(xc))), "so3_basis_norm")
+        ctx.save_for_backward(xc, sums, g, bt)
+        ctx.basis = basis
+        ctx.cfg = (groups, rows, c, float(eps), float(slope), conv_bias is not None, (b, c, p, na))
+        ctx.mark_non_differentiable(sums)
+        return y, sums
+
+    @staticmethod
+    def backward(ctx, gy, _grad_sums):
+        lib = _lib.get_lib()
+        xc, sums, g, bt = ctx.saved_tensors
+        groups, rows, c, eps, slope, has_cb, (b, _, p, na) = ctx.cfg
+        gf = empty_cl(b, c, p, na, gy.device, xc.dtype)
+        _basis_call(lib, cast_feats(gy.contiguous(), xc.dtype), ctx.basis.U, ctx.basis, b * p, c, 1, 0, gf, "so3_basis")
+        dx, dg, db = _norm_act_backward(xc, gf, sums, g, bt, groups, rows, c, eps, slope, ctx.needs_input_grad[0])
+        dcb = torch.zeros(c, dtype=torch.float32, device=xc.device) if has_cb else None
+        return dx, dg, db, dcb, None, None, None, None
+
+
+def _update_running_stats(norm, sums, n, conv_bias=None):
+    """BatchNorm's running statistics from (sum x, sum x^2), exactly as the torch module updates them in training mode."""
+    import torch.nn as nn
+    if isinstance(norm, nn.InstanceNorm2d) or not norm.track_running_stats or norm.running_mean is None:
+        return
+    with torch.no_grad():
+        mean = sums[0, :, 0] / n
+        var = (sums[0, :, 1] / n - mean * mean).clamp_min_(0) * (n / max(n - 1, 1))   # unbiased, as BatchNorm stores
+        if conv_bias is not None:
+            mean = mean + conv_bias
+        norm.num_batches_tracked += 1
+        # momentum=None: cumulative moving average, as torch.nn.modules.batchnorm._BatchNorm.forward
+        if norm.momentum is not None:
+            norm.running_mean.mul_(1 - norm.momentum).add_(mean, alpha=norm.momentum)
+            norm.running_var.mul_(1 - norm.momentum).add_(var, alpha=norm.momentum)
+        else:                                                  # device-side weight: no host sync (graph capture)
+            m = norm.num_batches_tracked.to(mean.dtype).reciprocal()
+            norm.running_mean.lerp_(mean, m)
+            norm.running_var.lerp_(var, m)
 
 
 def norm_act(x, norm, residual=None, slope=0.01, conv_bias=None):
@@ -813,22 +895,7 @@ def norm_act(x, norm, residual=None, slope=0.01, conv_bias=None):
     gamma = getattr(norm, "weight", None)
     beta = getattr(norm, "bias", None)
     y, sums = NormActFn.apply(x, gamma, beta, residual, conv_bias, instance, norm.eps, slope)
-    if not instance and norm.track_running_stats and norm.running_mean is not None:
-        with torch.no_grad():
-            n = x.shape[0] * x.shape[2] * x.shape[3]
-            mean = sums[0, :, 0] / n
-            var = (sums[0, :, 1] / n - mean * mean).clamp_min_(0) * (n / max(n - 1, 1))   # unbiased, as BatchNorm stores
-            if conv_bias is not None:
-                mean = mean + conv_bias
-            norm.num_batches_tracked += 1
-            # momentum=None: cumulative moving average, as torch.nn.modules.batchnorm._BatchNorm.forward
-            if norm.momentum is not None:
-                norm.running_mean.mul_(1 - norm.momentum).add_(mean, alpha=norm.momentum)
-                norm.running_var.mul_(1 - norm.momentum).add_(var, alpha=norm.momentum)
-            else:                                                  # device-side weight: no host sync (graph capture)
-                m = norm.num_batches_tracked.to(mean.dtype).reciprocal()
-                norm.running_mean.lerp_(mean, m)
-                norm.running_var.lerp_(var, m)
+    _update_running_stats(norm, sums, x.shape[0] * x.shape[2] * x.shape[3], conv_bias)
     return y
 
 
@@ -891,14 +958,25 @@ def intra_so3conv_fused(feats, W, intra_idx32):
     return IntraSO3ConvFn.apply(feats, W, intra_idx32)
 
 
-def intra_so3conv(feats, W, intra_idx32):
+def intra_takes_spectral(cin, cout, intra_idx32, is_cuda=True):
+    """Will intra_so3conv run the block-diagonal form for these widths / this table?  (Then a preceding norm + leaky_relu
+    can be folded into its basis change: intra_so3conv(..., pre_norm=).)"""
+    return (intra_mode() in ("auto", "spectral") and is_cuda and cin % 64 == 0 and cout % 64 == 0
+            and intra_idx32.shape[1] > 1 and spectral_basis(intra_idx32) is not None)
+
+
+def intra_so3conv(feats, W, intra_idx32, pre_norm=None):
+    """pre_norm: an nn.BatchNorm2d / nn.InstanceNorm2d(affine=False) whose leaky_relu(norm(feats)) is the actual input
+    (training mode); only with intra_takes_spectral(...) -- other forms get the normalised tensor from ops.norm_act."""
     mode = intra_mode()
     cin, cout = feats.shape[1], W.shape[0]
     bf = feats.dtype == torch.bfloat16
     if mode in ("auto", "spectral") and feats.is_cuda and cin % 64 == 0 and cout % 64 == 0 and intra_idx32.shape[1] > 1:
         basis = spectral_basis(intra_idx32)
         if basis is not None:
-            return intra_so3conv_spectral(feats, W, intra_idx32, basis)
+            return intra_so3conv_spectral(feats, W, intra_idx32, basis, pre_norm=pre_norm)
+    if pre_norm is not None:
+        feats = norm_act(feats, pre_norm)
     if (bf and cin % 8 == 0 and cout % 8 == 0) or mode == "split" or \
             (mode in ("auto", "spectral") and cin % 16 == 0 and cout % 16 == 0):
         return IntraSO3ConvSplitFn.apply(feats, W, intra_idx32)

@@ -162,8 +162,13 @@ class FusedSeparableBlock(SeparableBlock):
             side.wait_stream(main)
             with torch.cuda.stream(side):
                 s = skip_branch()
-        feat = ops.norm_act(y.feats, self.inter_conv.norm)
-        z = self.intra_conv.conv(zptk.SphericalPointCloud(y.xyz, feat, y.anchors))
+        if os.environ.get("EPN_NORM_ON_LOAD", "1") == "1" and self.intra_conv.conv.takes_spectral_form(y.feats.is_cuda):
+            # norm + leaky_relu of the inter convolution applied as the intra convolution's basis change loads its
+            # rows: the normalised tensor is never written
+            z = self.intra_conv.conv(zptk.SphericalPointCloud(y.xyz, y.feats, y.anchors), pre_norm=self.inter_conv.norm)
+        else:
+            feat = ops.norm_act(y.feats, self.inter_conv.norm)
+            z = self.intra_conv.conv(zptk.SphericalPointCloud(y.xyz, feat, y.anchors))
         if side is None:
             s = skip_branch()
         else:

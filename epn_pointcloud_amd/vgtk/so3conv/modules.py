@@ -148,9 +148,14 @@ class IntraSO3Conv(nn.Module):
             self._idx32_cache, self._idx32_key = src.int().contiguous(), key
         return self._idx32_cache
 
-    def forward(self, x):
-        feats = ops.intra_so3conv(x.feats, self.basic_conv.W, self._idx32())
+    def forward(self, x, pre_norm=None):
+        """pre_norm (extension, used by schedule.FusedSeparableBlock): the norm module whose leaky_relu(norm(x.feats)) is the
+        input -- folded into the convolution's basis change when it takes the block-diagonal form."""
+        feats = ops.intra_so3conv(x.feats, self.basic_conv.W, self._idx32(), pre_norm=pre_norm)
         return SphericalPointCloud(x.xyz, feats, self.anchors)
+
+    def takes_spectral_form(self, is_cuda=True):
+        return ops.intra_takes_spectral(self.dim_in, self.dim_out, self._idx32(), is_cuda)
 
 
 class PointnetSO3Conv(nn.Module):

@@ -339,6 +339,17 @@ int epn_intra_group_bf16(const void *feats_cl, const int32_t *intra_idx, void *g
                          int c, epn_stream_t stream);
 int epn_so3_basis_bf16(const void *in, const float *M, const int32_t *blocks, long long pts, int na, int c,
                        int in_spectral, int out_spectral, void *out, epn_stream_t stream);
+
+/* Block glue folded into the basis change ("norm on load", SPConvNets/utils/base_so3conv.py:196-204: InterSO3ConvBlock's
+ * norm + leaky_relu feeding IntraSO3Conv): out = basis_change(leaky_relu(norm(in))) with `in` in the plain channels-last
+ * layout and sums[g][c] = (sum x, sum x^2) from epn_chan_stats_* (groups = 1: BatchNorm2d, or the number of clouds with
+ * pts_per_group points each: InstanceNorm2d; gamma / beta may be NULL).  The normalised tensor is never written. */
+int epn_so3_basis_norm_f32(const float *in, const float *M, const int32_t *blocks, long long pts, int na, int c,
+                           int out_spectral, float *out, const float *sums, int groups, long long pts_per_group,
+                           const float *gamma, const float *beta, float eps, float slope, epn_stream_t stream);
+int epn_so3_basis_norm_bf16(const void *in, const float *M, const int32_t *blocks, long long pts, int na, int c,
+                            int out_spectral, void *out, const float *sums, int groups, long long pts_per_group,
+                            const float *gamma, const float *beta, float eps, float slope, epn_stream_t stream);
 int epn_chan_stats_bf16(const void *x_cl, int groups, long long rows, int c, float *sums, void *workspace,
                         size_t workspace_bytes, epn_stream_t stream);
 int epn_norm_act_fwd_bf16(const void *x_cl, int groups, long long rows, int c, const float *sums, const float *gamma,

@@ -584,3 +584,43 @@ def test_conv1x1_single_input_channel(gpu, cout):
     w2 = w.detach().clone().requires_grad_(True)
     (gw_ref,) = torch.autograd.grad(torch.nn.functional.conv2d(x, w2, bias), w2, gy)
     assert _rel(gw.flatten().cpu(), gw_ref.flatten().cpu()) < 1e-5
+
+
+@pytest.mark.parametrize("instance", [False, True])
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_norm_folded_into_basis_change(gpu, vgtk_alias, instance, dtype):
+    """intra_so3conv(x, pre_norm=norm) -- the block's first norm + leaky_relu applied as the basis change loads its rows
+    (epn_so3_basis_norm_*) -- against intra_so3conv(norm_act(x, norm)): outputs, all gradients and BatchNorm's running
+    statistics (SPConvNets/utils/base_so3conv.py:196-204)."""
+    import copy
+    import torch.nn as nn
+    from epn_pointcloud_amd import ops
+    from epn_pointcloud_amd.vgtk.so3conv import functional as L
+    torch.manual_seed(3)
+    b, c, co, p = 3, 64, 128, 10
+    idx = torch.from_numpy(L.get_intra_idx()).int().to(gpu)
+    x = (torch.randn(b, c, p, 60, device=gpu) * 2 + 0.5).to(dtype)
+    W = (torch.randn(co, c * 12, device=gpu) / (c * 12) ** 0.5)
+    norm = nn.InstanceNorm2d(c, affine=False).to(gpu) if instance else nn.BatchNorm2d(c).to(gpu)
+    if not instance:
+        with torch.no_grad():
+            norm.weight.uniform_(0.5, 1.5); norm.bias.uniform_(-0.3, 0.3)
+    n1, n2 = norm, copy.deepcopy(norm)
+    assert ops.intra_takes_spectral(c, co, idx)
+    xa, Wa = x.clone().requires_grad_(True), W.clone().requires_grad_(True)
+    xb, Wb = x.clone().requires_grad_(True), W.clone().requires_grad_(True)
+    ya = ops.intra_so3conv(xa, Wa, idx, pre_norm=n1)
+    yb = ops.intra_so3conv(ops.norm_act(xb, n2), Wb, idx)
+    tol = 1e-5 if dtype == torch.float32 else 2e-2
+    scale = yb.float().abs().max().item()
+    assert (ya.float() - yb.float()).abs().max().item() <= tol * max(scale, 1.0)
+    gy = torch.randn_like(yb)
+    pa = [xa, Wa] + ([n1.weight, n1.bias] if not instance else [])
+    pb = [xb, Wb] + ([n2.weight, n2.bias] if not instance else [])
+    ga, gb = torch.autograd.grad(ya, pa, gy), torch.autograd.grad(yb, pb, gy)
+    for u, v in zip(ga, gb):
+        assert (u.float() - v.float()).abs().max().item() <= tol * max(v.float().abs().max().item(), 1.0)
+    if not instance:
+        assert torch.allclose(n1.running_mean, n2.running_mean, atol=1e-6)
+        assert torch.allclose(n1.running_var, n2.running_var, atol=1e-5)
+        assert int(n1.num_batches_tracked) == int(n2.num_batches_tracked) == 1
