@@ -84,6 +84,8 @@ def parse():
     ap.add_argument("--no-graph", action="store_true", help="eager launches instead of replaying a captured HIP graph")
     ap.add_argument("--backbone-only", action="store_true", help="without the output head")
     ap.add_argument("--model", default="cls", choices=["cls", "reg", "inv"])
+    ap.add_argument("--policy", default="", help="A/B switch of the tuning tools: epn_set_kernel_policy value (e.g. 0x401), see "
+                                                 "include/epn_so3conv.h; default = the library's own choices")
     return ap.parse_args()
 
 
@@ -166,6 +168,9 @@ def main():
     assert torch.cuda.is_available(), "bench.py needs an MI355X"
     dev = dp.local_device(local_rank)
     torch.cuda.set_device(dev)
+    if args.policy:
+        from epn_pointcloud_amd import _lib
+        _lib.check(_lib.get_lib().epn_set_kernel_policy(int(args.policy, 0)), "set_kernel_policy")
 
     dtype_name = args.dtype or ("f32" if args.model == "cls" else "bf16")
     fdtype = torch.float32 if dtype_name == "f32" else torch.bfloat16

@@ -1828,7 +1828,11 @@ int launch_inter_ungroup_mfma(const epn_inter_desc *d, const float *rk4, const v
     // LDS pre-reduced scatter over Morton-adjacent output points (see inter_ungroup_shared_kernel); kernel policy
     // 0x400 | 1 keeps the per-slot atomic scatter for A/B measurements
     const int nt = (d->nn + 15) / 16;
-    const int gp = nt <= 2 ? 8 : (nt <= 4 ? 4 : 2);
+    // output points per workgroup (= waves): more points share more destinations (16: 4-5x fewer distinct destinations
+    // than slots, 8: 3x) but cost LDS and a wider barrier.  Measured per layer (ModelNet / rotation / 3DMatch schedules):
+    // K = 16: 8 points, two tile buffers (16: +7 %); K = 32: 16 points, one buffer (-5 % fp32, -12 % bf16);
+    // K = 64: 8 points, one buffer; K = 128: 2.  K = 32 / 64 fall back to half the group when p2 does not divide.
+    const int gp = nt <= 1 ? 8 : (nt <= 2 ? (d->p2 % 16 == 0 ? 16 : 8) : (nt <= 4 ? (d->p2 % 8 == 0 ? 8 : 4) : 2));
     if (order && d->p2 % gp == 0 && d->p2 <= MORTON_MAX && d->p1 <= USH_TAB && kernel_policy() != (0x400 | 1)) {
         hipLaunchKernelGGL(morton_order_kernel, dim3(d->b), dim3(1024), 0, st, d->new_xyz, d->p2, order);
         EPN_CHECK_LAUNCH();
@@ -1836,19 +1840,19 @@ int launch_inter_ungroup_mfma(const epn_inter_desc *d, const float *rk4, const v
         const dim3 grid((unsigned)(d->b * (d->p2 / gp)), (unsigned)(((d->cin >> 4) + A.col_tiles_per_wg - 1) / A.col_tiles_per_wg));
 #define EPN_USH(NT_, KT_, GP_)                                                                                            \
     do {                                                                                                                  \
-        if (bf16) hipLaunchKernelGGL((inter_ungroup_shared_kernel<NT_, KT_, __bf16, GP_, (GP_ < 8 ? 1 : 2)>), grid, dim3(64 * GP_), 0, st, A, order); \
-        else hipLaunchKernelGGL((inter_ungroup_shared_kernel<NT_, KT_, float, GP_, (GP_ < 8 ? 1 : 2)>), grid, dim3(64 * GP_), 0, st, A, order);      \
+        if (bf16) hipLaunchKernelGGL((inter_ungroup_shared_kernel<NT_, KT_, __bf16, GP_, ((NT_ == 1 && GP_ == 8) ? 2 : 1)>), grid, dim3(64 * GP_), 0, st, A, order); \
+        else hipLaunchKernelGGL((inter_ungroup_shared_kernel<NT_, KT_, float, GP_, ((NT_ == 1 && GP_ == 8) ? 2 : 1)>), grid, dim3(64 * GP_), 0, st, A, order);      \
     } while (0)
         const int kt = (d->ks + 15) / 16;
         if (kt == 1) {
             if (nt <= 1) EPN_USH(1, 1, 8);
-            else if (nt <= 2) EPN_USH(2, 1, 8);
-            else if (nt <= 4) EPN_USH(4, 1, 4);
+            else if (nt <= 2) { if (gp == 16) EPN_USH(2, 1, 16); else EPN_USH(2, 1, 8); }
+            else if (nt <= 4) { if (gp == 8) EPN_USH(4, 1, 8); else EPN_USH(4, 1, 4); }
             else EPN_USH(8, 1, 2);
         } else {
             if (nt <= 1) EPN_USH(1, 2, 8);
-            else if (nt <= 2) EPN_USH(2, 2, 8);
-            else if (nt <= 4) EPN_USH(4, 2, 4);
+            else if (nt <= 2) { if (gp == 16) EPN_USH(2, 2, 16); else EPN_USH(2, 2, 8); }
+            else if (nt <= 4) { if (gp == 8) EPN_USH(4, 2, 8); else EPN_USH(4, 2, 4); }
             else EPN_USH(8, 2, 2);
         }
 #undef EPN_USH

@@ -197,7 +197,7 @@ int epn_initial_anchor_query_f32(const float *centers, const float *xyz, const f
  *   grouped f32[b*p2*na][cin*ks]   row = column (b, p, a), element c*ks + k  -- the reference's [b, c, ks, p2, na] tensor
  *                                  with the (c, ks) axes last, so  out_cl[col][o] = grouped[col][:] . W[o][:]
  * epn_inter_ungroup_f32 is the transpose: grad_feats_cl[b][idx][a][c] += sum_k w * grad_grouped (zero-fills first).
- * Its workgroups take 8 output points that are neighbours in space (Morton order of new_xyz, computed into the
+ * Its workgroups take 8-16 output points that are neighbours in space (Morton order of new_xyz, computed into the
  * workspace), sum the contributions of the slots that name the same input point in LDS and issue one fp32 atomic per
  * distinct (input point, anchor, channel): ~3x fewer atomics than one per slot.
  * cout / dense_w of the descriptor are ignored (dense_w must be NULL).  Neither inter_w nor the gathered neighbour

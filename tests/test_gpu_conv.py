@@ -400,21 +400,24 @@ def test_fused_block_matches_stock_block(gpu, vgtk_alias):
                 assert torch.allclose(u, v, atol=1e-4), n
 
 
-@pytest.mark.parametrize("cin,K,na_sel,stride", [(16, 16, None, 1), (32, 32, None, 2), (48, 100, None, 2), (5, 9, None, 1),
-                                                 (16, 16, 12, 1), (16, 32, None, 1), (32, 64, None, 2), (16, 24, 7, 1)])
-def test_group_ungroup_abi_vs_oracle(gpu, vgtk_alias, cin, K, na_sel, stride):
+@pytest.mark.parametrize("cin,K,na_sel,stride,n", [(16, 16, None, 1, 200), (32, 32, None, 2, 200), (48, 100, None, 2, 200),
+                                                   (5, 9, None, 1, 200), (16, 16, 12, 1, 200), (16, 32, None, 1, 200),
+                                                   (32, 64, None, 2, 200), (16, 24, 7, 1, 200), (16, 32, None, 1, 208),
+                                                   (16, 64, None, 1, 104)])
+def test_group_ungroup_abi_vs_oracle(gpu, vgtk_alias, cin, K, na_sel, stride, n):
     """epn_inter_group_f32 / epn_inter_ungroup_f32 (the grouping-only ABI of the split convolution) against the
     oracle's inter_grouping and its autograd transpose: MFMA kernels for cin % 16 == 0 (K up to 128, also fewer than 16
     anchors), generic kernels otherwise.  The transpose runs the LDS-pre-reduced scatter over Morton-ordered point groups
-    (8 / 4 / 2 points per workgroup for K <= 32 / 64 / 128) when p2 divides, the per-slot atomic scatter otherwise
-    (K=32, stride 2: p2 = 100)."""
+    (8 / 16 / 8 / 2 points per workgroup for K <= 16 / 32 / 64 / 128, half of that for K = 32 / 64 when p2 does not
+    divide: n = 208 and 104 exercise the full groups) when p2 divides, the per-slot atomic scatter otherwise (K=32,
+    stride 2: p2 = 100)."""
     from epn_pointcloud_amd import ops
     from epn_pointcloud_amd.vgtk import pc as pctk
     from epn_pointcloud_amd.vgtk.so3conv import functional as L
     from epn_pointcloud_amd.vgtk import functional as fr
     rng = np.random.default_rng(cin + K)
     torch.manual_seed(cin + K)
-    b, n, radius, sigma = 2, 200, 0.45, 0.09
+    b, radius, sigma = 2, 0.45, 0.09
     xyz = T(unit_ball_cloud(rng, b, n))
     anchors = T(L.get_anchors(60))
     if na_sel:
