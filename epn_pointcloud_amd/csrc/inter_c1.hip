@@ -2,7 +2,7 @@
 // occupancy feature of get_occupancy_features (vgtk/vgtk/so3conv/functional.py:25-44).  With one channel the layer
 // is not matrix work (24 grouped values and a [cout x 24] weight per column): it is bound by the weight generation
 // on the VALU and by the output write.  One lane owns one column (b, p, a):
-//   G[k]   = sum_n F[idx[n], a] * relu(1 - |g_n - R_a kappa_k|^2 / sigma)        (functional.py:190-200, as written)
+//   G[k]   = sum_n F[idx[n], a] * relu(1 - |g_n - R_a kappa_k|^2 / sigma)        (functional.py:190-200, expanded)
 //   out[o] = sum_k W[o][k] * G[k]                                                  (modules.py:52)
 // The weight gradient reduces dOut (x) G over all columns with MFMAs (M = kernel point, N = output channel,
 // contraction = columns), the grouped values passing through LDS once.
@@ -30,11 +30,18 @@ __device__ __forceinline__ void group_column(const C1Args &A, long long col, flo
     const int a = (int)(col % A.na);
     const long long pt = col / A.na;
     const int bb = (int)(pt / A.p2), pp = (int)(pt - (long long)bb * A.p2);
-    float rx[EPN_KS_MAX], ry[EPN_KS_MAX], rz[EPN_KS_MAX];
+    // expanded form of relu(1 - |g_n - R_a kappa_k|^2 / sigma) (the one the MFMA kernels use, inter_mfma.hip):
+    //   alpha_n + beta_k + (2/sigma) g_n . (R_a kappa_k),  alpha_n = 1 - |g_n|^2/sigma,  beta_k = -|kappa_k|^2/sigma
+    // 5 VALU operations per (neighbour, kernel point) instead of 9; differs from the literal form by fp32 rounding
+    // (<= 5e-7 on w)
+    float rx[EPN_KS_MAX], ry[EPN_KS_MAX], rz[EPN_KS_MAX], beta[EPN_KS_MAX];
+    const float two_si = 2.0f * A.sigma_inv;
 #pragma unroll
     for (int k = 0; k < EPN_KS_MAX; ++k) {
         const float *e = A.rk + ((size_t)a * A.ks + (k < A.ks ? k : 0)) * 3;
-        rx[k] = e[0]; ry[k] = e[1]; rz[k] = e[2];
+        const float x = e[0], y = e[1], z = e[2];
+        beta[k] = -(x * x + y * y + z * z) * A.sigma_inv;
+        rx[k] = two_si * x; ry[k] = two_si * y; rz[k] = two_si * z;
         g[k] = 0.f;
     }
     const int32_t *row = A.idx + ((size_t)bb * A.p2 + pp) * A.nn;
@@ -46,13 +53,14 @@ __device__ __forceinline__ void group_column(const C1Args &A, long long col, flo
         const int q = row[n];
         if (q < 0 || q >= A.p1) continue;   // shadow index: zero feature row (spconv/functional.py:91-95)
         const float gx = s[q] - cx, gy = s[A.p1 + q] - cy, gz = s[2 * A.p1 + q] - cz;
+        const float alpha = 1.0f - (gx * gx + gy * gy + gz * gz) * A.sigma_inv;
         const float fv = f[(size_t)q * A.na];
 #pragma unroll
         for (int k = 0; k < EPN_KS_MAX; ++k) {
             if (k < A.ks) {
-                const float dx = gx - rx[k], dy = gy - ry[k], dz = gz - rz[k];
-                const float w = fmaxf(1.0f - (dx * dx + dy * dy + dz * dz) * A.sigma_inv, 0.0f);
-                g[k] += fv * w;
+                const float sv = (alpha + beta[k]) + gx * rx[k] + gy * ry[k] + gz * rz[k];
+                const int sb = __builtin_bit_cast(int, sv);
+                g[k] += fv * __builtin_bit_cast(float, sb > 0 ? sb : 0);
             }
         }
     }
