@@ -40,7 +40,7 @@ __device__ __forceinline__ void store_out(__bf16 *p, float v) { *p = (__bf16)v; 
 // Block tile BM x BN = (WGM*TM*32) x (WGN*TN*32), WGM*WGN waves, each wave TM x TN MFMA tiles of 32x32.
 // K step = KS 16-byte slots of a row: KS = 8 (128 bytes: 32 floats / 64 bf16) or, for contraction lengths that are
 // only a multiple of half that (the 32-channel layers in bf16), KS = 4.
-template <typename T, typename TO, int WGM, int WGN, int TM, int TN, int KS = 8>
+template <typename T, typename TO, int WGM, int WGN, int TM, int TN, int KS = 8, int NSTG = 2>
 __global__ __launch_bounds__(64 * WGM * WGN) void gemm_nt_kernel(GemmNtBatch B) {
     constexpr int NW = WGM * WGN;
     constexpr int BM = WGM * TM * 32, BN = WGN * TN * 32;
@@ -52,7 +52,7 @@ __global__ __launch_bounds__(64 * WGM * WGN) void gemm_nt_kernel(GemmNtBatch B) 
     constexpr int E16 = ElemOf<T>::PER16;          // elements per 16-byte slot
     constexpr int BKE = KS * E16;                  // elements per K step
     constexpr int NS = KS / 2;                     // fragment steps per K step (two slots each: lane groups j = 0, 1)
-    __shared__ __attribute__((aligned(1024))) char smem[2 * ROWS * ROWB];
+    __shared__ __attribute__((aligned(1024))) char smem[NSTG * ROWS * ROWB];
 
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -131,14 +131,31 @@ __global__ __launch_bounds__(64 * WGM * WGN) void gemm_nt_kernel(GemmNtBatch B) 
     // alone the compiler hoists all of them in front of the first ds_read).  fp32: +3 % over the burst; bf16 is
     // HBM-bound on these shapes and keeps the burst.
     constexpr int NGRP = 4 * NS;               // fp32: MFMA groups per K step (NS fragment steps x 4 contraction pairs)
+    constexpr bool BURST = sizeof(T) != 4 || BN <= 64;   // HBM-bound shapes: the whole next stage is requested at once
+    static_assert(NSTG == 2 || (NSTG == 3 && BURST && NG % NW == 0), "the 3-stage ring is for the burst (HBM-bound) configurations");
     stage(0);
+    if constexpr (NSTG == 3) {
+        if (nk > 1) stage(1);
+    }
     for (int kt = 0; kt < nk; ++kt) {
-        __syncthreads();                       // stage kt has landed (vmcnt(0) rides on the barrier); buffer (kt+1)&1 is free
-        const char *base = smem + (kt & 1) * (ROWS * ROWB);
         const bool more = kt + 1 < nk;
-        constexpr bool BURST = sizeof(T) != 4 || BN <= 64;   // HBM-bound shapes: the whole next stage is requested at once
+        if constexpr (NSTG == 3) {
+            // Two stages in flight (HBM-bound operands: one stage of bytes per CU does not cover the loaded latency):
+            // stage kt must have landed, stage kt+1 (this wave's GPW youngest loads) may still be on its way.
+            if (more) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(GPW) : "memory");
+            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+            asm volatile("" ::: "memory");
+        } else {
+            __syncthreads();                   // stage kt has landed (vmcnt(0) rides on the barrier); buffer (kt+1)&1 is free
+        }
+        const char *base = smem + (kt % NSTG) * (ROWS * ROWB);
         if constexpr (BURST) {
-            if (more) stage((kt + 1) & 1);
+            if constexpr (NSTG == 3) {
+                if (kt + 2 < nk) stage((kt + 2) % 3);      // buffer of step kt-1: every wave is past it (barrier above)
+            } else {
+                if (more) stage((kt + 1) & 1);
+            }
         }
         if constexpr (sizeof(T) == 4) {
             // fragments of step s+1 are read while the MFMAs of step s issue (two register sets, static indices)
@@ -624,7 +641,7 @@ __global__ void gemm_tn_generic_kernel(const T *__restrict__ X, const T *__restr
     C[(long long)n1 * ldc + n2] = s;
 }
 
-template <typename T, typename TO, int WGM, int WGN, int TM, int TN, int KS = 8>
+template <typename T, typename TO, int WGM, int WGN, int TM, int TN, int KS = 8, int NSTG = 2>
 int launch_nt_cfg(GemmNtBatch &B, hipStream_t st) {
     constexpr int BM = WGM * TM * 32, BN = WGN * TN * 32;
     // longest contraction first: the tiles are dispatched in table order, and a tile's run time is ~K, so the short
@@ -643,7 +660,7 @@ int launch_nt_cfg(GemmNtBatch &B, hipStream_t st) {
     }
     B.ntiles = total;
     if (total == 0) return 0;
-    hipLaunchKernelGGL((gemm_nt_kernel<T, TO, WGM, WGN, TM, TN, KS>), dim3(total), dim3(64 * WGM * WGN), 0, st, B);
+    hipLaunchKernelGGL((gemm_nt_kernel<T, TO, WGM, WGN, TM, TN, KS, NSTG>), dim3(total), dim3(64 * WGM * WGN), 0, st, B);
     EPN_CHECK_LAUNCH();
     return 0;
 }
@@ -705,7 +722,11 @@ int launch_nt_typed(GemmNtBatch &B, hipStream_t st) {
     if (maxn <= 32) return launch_nt_cfg<T, TO, 8, 1, 2, 1>(B, st);      // 512 x 32
     if (maxn <= 64) return launch_nt_cfg<T, TO, 8, 1, 2, 2>(B, st);      // 512 x 64
     if (minn >= 256 && sizeof(T) == 4) return launch_nt_cfg<T, TO, 4, 2, 2, 4>(B, st);   // 256 x 256 (fewer loads / MFMA)
-    return launch_nt_cfg<T, TO, 4, 2, 2, 2>(B, st);                      // 256 x 128
+    // 256 x 128.  bf16 is HBM-bound on these shapes (it streams G or dG): a THREE-stage LDS ring keeps two stages of loads
+    // in flight (144 KB of LDS; the wait before the barrier is vmcnt(loads of one stage), not 0): 10-16 % faster on the
+    // schedule's shapes (245760 x 256 x 6144: 1.07 -> 0.93 ms).  Narrow tiles and fp32 (MFMA-bound) measured no gain.
+    if constexpr (sizeof(T) == 2) return launch_nt_cfg<T, TO, 4, 2, 2, 2, 8, 3>(B, st);
+    else return launch_nt_cfg<T, TO, 4, 2, 2, 2>(B, st);
 }
 
 template <typename T>
