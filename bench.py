@@ -353,7 +353,8 @@ def main():
                 cfg = "4, 2, 2, 4"
             else:
                 cfg = "4, 2, 2, 2"
-            return f"epn::gemm_nt_kernel<{t}, {cfg}, {ksz}>"
+            nstg = 3 if (dtype_name == "bf16" and cfg == "4, 2, 2, 2" and ksz == 8) else 2    # LDS ring depth
+            return f"epn::gemm_nt_kernel<{t}, {cfg}, {ksz}, {nstg}>"
 
         def tn_name(n1, n2, grouped=False):
             """Template instance gemm_tn_tile / launch_tn_typed (csrc/gemm.hip) pick for an N1 x N2 output."""
