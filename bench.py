@@ -359,7 +359,7 @@ def main():
         def tn_name(n1, n2, grouped=False):
             """Template instance gemm_tn_tile / launch_tn_typed (csrc/gemm.hip) pick for an N1 x N2 output."""
             if dtype_name == "bf16":
-                cfg = "1, 8, 2, 2" if n1 <= 32 else ("1, 8, 4, 2" if n1 <= 64 else "2, 4, 4, 4")
+                cfg = "1, 4, 2, 4" if n1 <= 32 else ("1, 4, 4, 4" if n1 <= 64 else "2, 2, 4, 8")
                 return f"epn::gemm_tn_bf16_kernel<{cfg}>"
             if grouped and n2 < 256:
                 n2 = 256

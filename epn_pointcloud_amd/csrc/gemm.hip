@@ -830,9 +830,12 @@ int launch_tn_typed(GemmTnBatch &B, void *ws, size_t ws_bytes, hipStream_t st) {
         else if (bn2 == 512) hipLaunchKernelGGL((gemm_tn_f32_kernel<1, 8, 4, 2, 32>), grid, dim3(512), 0, st, B);
         else hipLaunchKernelGGL((gemm_tn_f32_kernel<2, 4, 2, 2, 32>), grid, dim3(512), 0, st, B);
     } else {
-        if (bn1 == 32) hipLaunchKernelGGL((gemm_tn_bf16_kernel<1, 8, 2, 2>), grid, dim3(512), 0, st, B);
-        else if (bn1 == 64) hipLaunchKernelGGL((gemm_tn_bf16_kernel<1, 8, 4, 2>), grid, dim3(512), 0, st, B);
-        else hipLaunchKernelGGL((gemm_tn_bf16_kernel<2, 4, 4, 4>), grid, dim3(512), 0, st, B);
+        if (bn1 == 32) hipLaunchKernelGGL((gemm_tn_bf16_kernel<1, 4, 2, 4>), grid, dim3(256), 0, st, B);        // 4 waves: fewer,
+        else if (bn1 == 64) hipLaunchKernelGGL((gemm_tn_bf16_kernel<1, 4, 4, 4>), grid, dim3(256), 0, st, B);   // larger wave tiles
+        // 128 x 256 tile on FOUR waves (64 x 128 per wave: 32 MFMAs per 12 transposed LDS reads).  The 8-wave form (16 MFMAs
+        // per 16 reads) was LDS-bandwidth bound -- 3 workgroups x 64 KB of fragment reads per 1024 cycles > 128 B/clk:
+        // 245760 x 256 x 6144: 1.63 -> 1.23 ms (630 TFLOP/s)
+        else hipLaunchKernelGGL((gemm_tn_bf16_kernel<2, 2, 4, 8>), grid, dim3(256), 0, st, B);
     }
     EPN_CHECK_LAUNCH();
     bool any_split = false;
