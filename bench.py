@@ -349,7 +349,7 @@ def main():
                 cfg = "8, 1, 2, 1"
             elif max(ns) <= 64:
                 cfg = "8, 1, 2, 2"
-            elif min(ns) >= 256 and dtype_name == "f32":
+            elif min(ns) >= 256:
                 cfg = "4, 2, 2, 4"
             else:
                 cfg = "4, 2, 2, 2"
