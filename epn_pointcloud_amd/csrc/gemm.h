@@ -14,6 +14,7 @@ struct GemmNtProb {        // C[M][N] = A[M][K] . Bt[N][K]^T
     int tiles_n;           // filled by the launcher
     unsigned tile0;        // first workgroup of this problem inside the grouped launch (a multiple of 8)
     unsigned ntile;        // its tiles; workgroups tile0 + ntile .. next tile0 are padding
+    const void *Bp;        // split GEMM (gemm_x3.hip): the three bf16 planes [3][N][K] of Bt, filled by its launcher
 };
 struct GemmNtBatch {
     int nprob;
@@ -41,6 +42,11 @@ int kernel_policy();   // c_api.hip: epn_set_kernel_policy (0x100 | cfg = NT til
 
 // dtype / out_dtype: 0 = fp32, 1 = bf16
 int launch_gemm_nt(GemmNtBatch &B, int dtype, int out_dtype, hipStream_t st);
+// fp32 operands on the bf16 matrix pipe at fp32 accuracy (gemm_x3.hip); falls back to launch_gemm_nt when a problem does
+// not qualify (K % 32, alignment) or the workspace is missing
+bool gemm_nt_x3_ok(const GemmNtBatch &B);
+size_t gemm_nt_x3_workspace(const GemmNtBatch &B);
+int launch_gemm_nt_x3(GemmNtBatch &B, void *ws, size_t ws_bytes, hipStream_t st);
 int launch_gemm_tn(GemmTnArgs &G, int dtype, hipStream_t st);
 // grouped: plans tiles / splits for all problems (balanced K steps per workgroup), carves `ws` into the partial slabs
 int launch_gemm_tn_batch(GemmTnBatch &B, int dtype, void *ws, size_t ws_bytes, hipStream_t st);

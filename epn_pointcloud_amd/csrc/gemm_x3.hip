@@ -1,0 +1,337 @@
+// fp32 weight contractions on the bf16 matrix pipe, at fp32 accuracy ("split" GEMMs).
+//
+// v_mfma_f32_32x32x2_f32 runs at 64 FLOP/clk/SIMD, v_mfma_f32_32x32x16_bf16 at 1024.  An fp32 value splits WITHOUT LOSS
+// into three bf16 pieces x = h + m + l: h = rne_bf16(x), m = rne_bf16(x - h), l = x - h - m (both remainders are exact
+// in fp32, and the last one has at most 8 significant bits, i.e. it IS a bf16).  A product a*b is then nine piece
+// products, each exact in the fp32 accumulator of the MFMA; the six of relative weight >= 2^-16
+//     hh + (hm + mh) + (mm + hl + lh)
+// are kept, the three dropped ones (ml, lm, ll) are together below 2^-24 |a||b| -- less than the ONE rounding an fp32
+// FMA commits per product.  Six bf16 MFMAs of 32 cycles replace eight fp32 MFMAs of 64 cycles for the same 32x32x16
+// block: 2.7x the matrix rate, with the error of an fp32 GEMM (tools/x3_probe.py: rms error vs fp64 0.85x that of the
+// native fp32 kernel on the schedule's shapes).  This is NOT a bf16 GEMM: no input bit is discarded.
+//
+//   NT  C[M][N] = A[M][K] . Bt[N][K]^T   A = activations (fp32 in HBM, split in registers after the LDS read),
+//                                        Bt = weights (small): split ONCE per call into three bf16 planes
+//                                        [3][N][K] (workspace), which the kernel stages like bf16 operands.
+//
+// Staging, swizzles and the epilogue follow gemm_nt_kernel (gemm.hip); the K step is 32 values (128-byte fp32 rows of
+// A, three 64-byte bf16 rows per weight row).
+#include "conv_internal.h"
+#include "gemm.h"
+
+namespace epn {
+namespace {
+
+typedef __attribute__((address_space(3))) void lds_void;
+typedef __attribute__((address_space(1))) const void glb_void;
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ void glds16(const void *g, char *lds_wave_base) {
+    __builtin_amdgcn_global_load_lds((glb_void *)g, (lds_void *)lds_wave_base, 16, 0, 0);
+}
+__device__ __forceinline__ unsigned pack_rne(float a, float b) {   // v_cvt_pk_bf16_f32
+    const f32x2 v = {a, b};
+    return __builtin_bit_cast(unsigned, __builtin_convertvector(v, bf16x2));
+}
+__device__ __forceinline__ float lo_f(unsigned p) { return __builtin_bit_cast(float, p << 16); }
+__device__ __forceinline__ float hi_f(unsigned p) { return __builtin_bit_cast(float, p & 0xffff0000u); }
+
+// eight fp32 values -> three bf16x8 fragments (4.5 VALU instructions per value)
+__device__ __forceinline__ void split3(const f32x4 u, const f32x4 v, bf16x8 &h, bf16x8 &m, bf16x8 &l) {
+    const float x[8] = {u[0], u[1], u[2], u[3], v[0], v[1], v[2], v[3]};
+    u32x4 H, M, L;
+#pragma unroll
+    for (int p = 0; p < 4; ++p) {
+        const unsigned hp = pack_rne(x[2 * p], x[2 * p + 1]);
+        const float r0 = x[2 * p] - lo_f(hp), r1 = x[2 * p + 1] - hi_f(hp);
+        const unsigned mp = pack_rne(r0, r1);
+        H[p] = hp; M[p] = mp; L[p] = pack_rne(r0 - lo_f(mp), r1 - hi_f(mp));
+    }
+    h = __builtin_bit_cast(bf16x8, H); m = __builtin_bit_cast(bf16x8, M); l = __builtin_bit_cast(bf16x8, L);
+}
+
+// weights -> planes[3][N][K] (bf16), two values per thread
+__global__ void split_planes_kernel(const float *__restrict__ W, long long ldw, int N, int K, unsigned *__restrict__ planes) {
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;   // pair index
+    const int k2 = K >> 1;
+    if (i >= (long long)N * k2) return;
+    const int n = (int)(i / k2), k = 2 * (int)(i % k2);
+    const float x0 = W[n * ldw + k], x1 = W[n * ldw + k + 1];
+    const unsigned hp = pack_rne(x0, x1);
+    const float r0 = x0 - lo_f(hp), r1 = x1 - hi_f(hp);
+    const unsigned mp = pack_rne(r0, r1);
+    const size_t plane = (size_t)N * k2;
+    planes[i] = hp;
+    planes[plane + i] = mp;
+    planes[2 * plane + i] = pack_rne(r0 - lo_f(mp), r1 - hi_f(mp));
+}
+
+template <int WGM, int WGN, int TM, int TN, int NSTG>
+__global__ __launch_bounds__(64 * WGM * WGN) void gemm_nt_x3_kernel(GemmNtBatch B) {
+    constexpr int NW = WGM * WGN;
+    constexpr int BM = WGM * TM * 32, BN = WGN * TN * 32;
+    constexpr int A_BYTES = BM * 128;              // fp32 rows of the activation tile, 32 values per K step
+    constexpr int P_BYTES = BN * 64;               // one bf16 plane of the weight tile
+    constexpr int STAGE = A_BYTES + 3 * P_BYTES;
+    constexpr int NGA = BM / 8, NGB = 3 * BN / 16;  // 1 KiB wave-level load instructions per stage (8 / 16 rows each)
+    constexpr int NG = NGA + NGB;
+    constexpr int GPW = (NG + NW - 1) / NW;
+    constexpr int INFLIGHT = NG % NW == 0 ? GPW : GPW - 1;   // loads of the youngest stage a wave may leave pending
+    static_assert(NSTG * STAGE <= 160 * 1024, "LDS");
+    __shared__ __attribute__((aligned(1024))) char smem[NSTG * STAGE];
+
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    int pi = 0;
+#pragma unroll
+    for (int i = 1; i < GEMM_MAX_PROB; ++i)
+        if (i < B.nprob && blockIdx.x >= B.p[i].tile0) pi = i;
+    const GemmNtProb &P = B.p[pi];
+    if (blockIdx.x - P.tile0 >= P.ntile) return;
+    const unsigned t = epn_xcd_tile(blockIdx.x - P.tile0, P.ntile);
+    const long long m0 = (long long)(t / P.tiles_n) * BM;
+    const int n0 = (int)(t % P.tiles_n) * BN;
+    const int nk = P.K / 32;
+
+    const char *src[GPW];
+    int adv[GPW];
+#pragma unroll
+    for (int i = 0; i < GPW; ++i) {
+        const int g = wave + i * NW;
+        if (g < NGA) {
+            const int r = 8 * g + lane / 8;
+            const int slot = (lane % 8) ^ ((r >> 1) & 7);
+            long long gr = m0 + r;
+            gr = gr < P.M ? gr : P.M - 1;
+            src[i] = reinterpret_cast<const char *>(static_cast<const float *>(P.A) + gr * P.lda + slot * 4);
+            adv[i] = 128;
+        } else {
+            const int rb = 16 * (g - NGA) + lane / 4;          // plane * BN + weight row of the tile
+            const int plane = rb / BN, n = rb % BN;
+            const int slot = (lane % 4) ^ ((rb >> 2) & 3);
+            int gn = n0 + n;
+            gn = gn < P.N ? gn : P.N - 1;
+            src[i] = reinterpret_cast<const char *>(static_cast<const __bf16 *>(P.Bp) + ((size_t)plane * P.N + gn) * P.K + slot * 8);
+            adv[i] = 64;
+        }
+    }
+    auto stage = [&](int buf) {
+#pragma unroll
+        for (int i = 0; i < GPW; ++i) {
+            const int g = wave + i * NW;
+            if (NG % NW == 0 || g < NG) {
+                glds16(src[i], smem + buf * STAGE + g * 1024);
+                src[i] += adv[i];
+            }
+        }
+    };
+
+    const int wm = wave / WGN, wn = wave % WGN;
+    const int li = lane & 31, lj = lane >> 5;
+    const int fswA = (li >> 1) & 7, fswB = (li >> 2) & 3;
+    int aoff[TM], boff[TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i) aoff[i] = ((wm * TM + i) * 32 + li) * 128;
+#pragma unroll
+    for (int i = 0; i < TN; ++i) boff[i] = A_BYTES + ((wn * TN + i) * 32 + li) * 64;
+
+    f32x16 acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    stage(0);
+    if constexpr (NSTG == 3) {
+        if (nk > 1) stage(1);
+    }
+    for (int kt = 0; kt < nk; ++kt) {
+        const bool more = kt + 1 < nk;
+        if constexpr (NSTG == 3) {
+            if (more) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(INFLIGHT) : "memory");
+            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+            asm volatile("" ::: "memory");
+            if (kt + 2 < nk) stage((kt + 2) % 3);
+        } else {
+            __syncthreads();
+            if (more) stage((kt + 1) & 1);
+        }
+        const char *base = smem + (kt % NSTG) * STAGE;
+#pragma unroll
+        for (int s = 0; s < 2; ++s) {           // 16 contraction values per fragment step: lane group lj holds 8 of them
+            const int sa0 = ((4 * s + 2 * lj) ^ fswA) * 16, sa1 = ((4 * s + 2 * lj + 1) ^ fswA) * 16;
+            const int sb = ((2 * s + lj) ^ fswB) * 16;
+            bf16x8 ah[TM], am[TM], al[TM], bh[TN], bm[TN], bl[TN];
+#pragma unroll
+            for (int j = 0; j < TN; ++j) {
+                bh[j] = *reinterpret_cast<const bf16x8 *>(base + boff[j] + sb);
+                bm[j] = *reinterpret_cast<const bf16x8 *>(base + boff[j] + P_BYTES + sb);
+                bl[j] = *reinterpret_cast<const bf16x8 *>(base + boff[j] + 2 * P_BYTES + sb);
+            }
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+                split3(*reinterpret_cast<const f32x4 *>(base + aoff[i] + sa0),
+                       *reinterpret_cast<const f32x4 *>(base + aoff[i] + sa1), ah[i], am[i], al[i]);
+#define EPN_X3_TERM(PA, PB)                                                                                 \
+    _Pragma("unroll") for (int i = 0; i < TM; ++i) _Pragma("unroll") for (int j = 0; j < TN; ++j)         \
+        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(PA[i], PB[j], acc[i][j], 0, 0, 0)
+            EPN_X3_TERM(ah, bl);                // small terms first
+            EPN_X3_TERM(al, bh);
+            EPN_X3_TERM(am, bm);
+            EPN_X3_TERM(ah, bm);
+            EPN_X3_TERM(am, bh);
+            EPN_X3_TERM(ah, bh);
+#undef EPN_X3_TERM
+        }
+    }
+
+    // ---- epilogue: D[row = (r&3) + 8 (r>>2) + 4 lj][col = li]   (as gemm_nt_kernel)
+    float *__restrict__ C = static_cast<float *>(P.C);
+    if (m0 + BM <= P.M && n0 + BN <= P.N && (long long)BM * P.ldc < (1LL << 30)) {
+        float *__restrict__ cw = C + (size_t)(m0 + wm * TM * 32) * P.ldc + (n0 + wn * TN * 32);
+        const unsigned ldc = (unsigned)P.ldc;
+        const unsigned lane_off = 4u * lj * ldc + li;
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const unsigned o = lane_off + (unsigned)(i * 32 + (r & 3) + 8 * (r >> 2)) * ldc;
+#pragma unroll
+                for (int j = 0; j < TN; ++j) cw[o + j * 32] = acc[i][j][r];
+            }
+        return;
+    }
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+            const int n = n0 + (wn * TN + j) * 32 + li;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const long long m = m0 + (wm * TM + i) * 32 + (r & 3) + 8 * (r >> 2) + 4 * lj;
+                if (m < P.M && n < P.N) C[m * P.ldc + n] = acc[i][j][r];
+            }
+        }
+}
+
+template <int WGM, int WGN, int TM, int TN, int NSTG>
+int launch_x3_cfg(GemmNtBatch &B, hipStream_t st) {
+    constexpr int BM = WGM * TM * 32, BN = WGN * TN * 32;
+    for (int i = 1; i < B.nprob; ++i)           // longest contraction first (see launch_nt_cfg)
+        for (int k = i; k > 0 && B.p[k].K > B.p[k - 1].K; --k) {
+            const GemmNtProb tmp = B.p[k]; B.p[k] = B.p[k - 1]; B.p[k - 1] = tmp;
+        }
+    unsigned total = 0;
+    for (int i = 0; i < B.nprob; ++i) {
+        GemmNtProb &p = B.p[i];
+        p.tiles_n = (p.N + BN - 1) / BN;
+        p.tile0 = total;
+        p.ntile = (unsigned)((p.M + BM - 1) / BM) * p.tiles_n;
+        total += i + 1 < B.nprob ? (p.ntile + 7u) & ~7u : p.ntile;
+    }
+    B.ntiles = total;
+    if (total == 0) return 0;
+    hipLaunchKernelGGL((gemm_nt_x3_kernel<WGM, WGN, TM, TN, NSTG>), dim3(total), dim3(64 * WGM * WGN), 0, st, B);
+    EPN_CHECK_LAUNCH();
+    return 0;
+}
+
+inline size_t planes_bytes(const GemmNtProb &p) { return ((size_t)6 * p.N * p.K + 255) & ~(size_t)255; }
+
+}  // namespace
+
+bool gemm_nt_x3_ok(const GemmNtBatch &B) {
+    for (int i = 0; i < B.nprob; ++i) {
+        const GemmNtProb &p = B.p[i];
+        if (p.M < 1 || p.N < 1 || p.K < 32 || p.K % 32 || p.lda % 4 || ((uintptr_t)p.A & 15) || !p.A || !p.Bt || !p.C) return false;
+    }
+    return B.nprob >= 1 && B.nprob <= GEMM_MAX_PROB;
+}
+
+size_t gemm_nt_x3_workspace(const GemmNtBatch &B) {
+    size_t n = 0;
+    for (int i = 0; i < B.nprob; ++i) n += planes_bytes(B.p[i]);
+    return n;
+}
+
+int launch_gemm_nt_x3(GemmNtBatch &B, void *ws, size_t ws_bytes, hipStream_t st) {
+    if (!gemm_nt_x3_ok(B) || !ws || ws_bytes < gemm_nt_x3_workspace(B)) return launch_gemm_nt(B, 0, 0, st);
+    char *w = static_cast<char *>(ws);
+    int maxn = 0, minn = 1 << 30;
+    for (int i = 0; i < B.nprob; ++i) {
+        GemmNtProb &p = B.p[i];
+        const long long pairs = (long long)p.N * (p.K / 2);
+        hipLaunchKernelGGL(split_planes_kernel, dim3((unsigned)((pairs + 255) / 256)), dim3(256), 0, st,
+                           static_cast<const float *>(p.Bt), p.ldb, p.N, p.K, reinterpret_cast<unsigned *>(w));
+        EPN_CHECK_LAUNCH();
+        p.Bp = w;
+        w += planes_bytes(p);
+        maxn = p.N > maxn ? p.N : maxn;
+        minn = p.N < minn ? p.N : minn;
+    }
+    const int pol = kernel_policy();
+    if ((pol & ~0xff) == 0x100) {               // tuning override (tools/x3_probe.py)
+        switch (pol & 0xff) {
+            case 0x21: return launch_x3_cfg<4, 2, 2, 2, 2>(B, st);     // 256 x 128, 8 waves
+            case 0x22: return launch_x3_cfg<4, 2, 2, 4, 2>(B, st);     // 256 x 256, 8 waves (all of the LDS)
+            case 0x23: return launch_x3_cfg<2, 2, 2, 2, 2>(B, st);     // 128 x 128, 4 waves
+            case 0x24: return launch_x3_cfg<2, 2, 2, 2, 3>(B, st);
+            case 0x25: return launch_x3_cfg<4, 1, 2, 2, 3>(B, st);     // 256 x 64, 4 waves
+            case 0x26: return launch_x3_cfg<4, 1, 2, 2, 2>(B, st);
+            case 0x27: return launch_x3_cfg<2, 2, 4, 2, 2>(B, st);     // 256 x 128, 4 waves (128 x 64 per wave)
+            case 0x28: return launch_x3_cfg<2, 4, 2, 2, 2>(B, st);     // 128 x 256, 8 waves
+            case 0x29: return launch_x3_cfg<2, 2, 2, 4, 2>(B, st);     // 128 x 256, 4 waves
+            case 0x2a: return launch_x3_cfg<8, 1, 2, 1, 2>(B, st);     // 512 x 32
+            default: break;
+        }
+    }
+    if (B.nprob > 1) {                          // grouped spectral blocks: ragged widths, narrow tiles (see launch_nt_typed)
+        if (maxn <= 320 && minn <= 64) return launch_x3_cfg<4, 1, 2, 2, 3>(B, st);
+        return launch_x3_cfg<2, 2, 2, 2, 2>(B, st);
+    }
+    if (maxn <= 32) return launch_x3_cfg<8, 1, 2, 1, 2>(B, st);
+    if (maxn <= 64) return launch_x3_cfg<4, 1, 2, 2, 3>(B, st);
+    if (maxn <= 128 || maxn % 256 > 128 || (maxn % 256 && maxn < 512)) return launch_x3_cfg<4, 2, 2, 2, 2>(B, st);
+    return launch_x3_cfg<4, 2, 2, 4, 2>(B, st);
+}
+
+}  // namespace epn
+
+using namespace epn;
+
+extern "C" size_t epn_gemm_nt_split_workspace_bytes(int nprob, const epn_gemm_nt_problem *probs) {
+    if (!probs || nprob < 1) return 0;
+    size_t n = 0;
+    for (int i = 0; i < nprob; ++i) n += (((size_t)6 * probs[i].N * probs[i].K + 255) & ~(size_t)255);
+    return n;
+}
+
+extern "C" int epn_gemm_nt_split_f32(int nprob, const epn_gemm_nt_problem *probs, void *workspace, size_t workspace_bytes,
+                                     epn_stream_t stream) {
+    if (!probs) return EPN_ENULL;
+    if (nprob < 1) return EPN_EINVAL;
+    hipStream_t st = epn_stream(stream);
+    char *w = static_cast<char *>(workspace);
+    size_t left = workspace ? workspace_bytes : 0;
+    for (int i0 = 0; i0 < nprob; i0 += GEMM_MAX_PROB) {
+        GemmNtBatch B;
+        B.nprob = nprob - i0 < GEMM_MAX_PROB ? nprob - i0 : GEMM_MAX_PROB;
+        for (int i = 0; i < B.nprob; ++i) {
+            const epn_gemm_nt_problem &q = probs[i0 + i];
+            GemmNtProb &p = B.p[i];
+            p.A = q.A; p.Bt = q.Bt; p.C = q.C; p.M = q.M; p.N = q.N; p.K = q.K; p.lda = q.lda; p.ldb = q.ldb; p.ldc = q.ldc;
+            p.tiles_n = 0; p.tile0 = 0; p.ntile = 0; p.Bp = nullptr;
+        }
+        const size_t need = gemm_nt_x3_workspace(B);
+        int rc = launch_gemm_nt_x3(B, need <= left ? w : nullptr, need <= left ? need : 0, st);
+        if (rc) return rc;
+        if (need <= left) { w += need; left -= need; }
+    }
+    return 0;
+}

@@ -6,10 +6,23 @@ own MFMA GEMM kernels (csrc/gemm.hip) -- no torch.mm / BLAS on the path.
     matmul_nt(A, W)             -> autograd Function over the two (dA = dC @ W as NT on W^T, dW = dC^T A as TN)
 """
 import ctypes
+import os
 
 import torch
 
 from . import _lib
+
+
+# fp32 contractions: "split" = on the bf16 matrix pipe with lossless three-way operand splitting (fp32 accuracy,
+# csrc/gemm_x3.hip), "native" = v_mfma_f32_32x32x2_f32
+FP32_MODE = os.environ.get("EPN_GEMM_FP32", "native")
+
+
+def set_fp32_mode(mode):
+    global FP32_MODE
+    if mode not in ("split", "native"):
+        raise ValueError("fp32 GEMM mode is 'split' or 'native'")
+    FP32_MODE = mode
 
 
 def _is_bf16(t):
@@ -67,6 +80,10 @@ def gemm_nt_grouped(problems, out_dtype=None):
     if bf:
         out_f32 = 1 if outs[0].dtype == torch.float32 else 0
         _lib.check(lib.epn_gemm_nt_bf16(len(problems), arr, out_f32, st), "gemm_nt_bf16")
+    elif FP32_MODE == "split":
+        nbytes = int(lib.epn_gemm_nt_split_workspace_bytes(len(problems), arr))
+        ws = torch.empty(max(nbytes, 256), dtype=torch.uint8, device=outs[0].device)
+        _lib.check(lib.epn_gemm_nt_split_f32(len(problems), arr, ws.data_ptr(), ws.numel(), st), "gemm_nt_split_f32")
     else:
         _lib.check(lib.epn_gemm_nt_f32(len(problems), arr, st), "gemm_nt_f32")
     return outs

@@ -300,6 +300,15 @@ typedef struct epn_gemm_nt_problem {
 } epn_gemm_nt_problem;
 int epn_gemm_nt_f32(int nprob, const epn_gemm_nt_problem *probs, epn_stream_t stream);
 int epn_gemm_nt_bf16(int nprob, const epn_gemm_nt_problem *probs, int out_f32, epn_stream_t stream);
+/* Split form of the fp32 NT contraction: the same fp32 operands and fp32 result, computed on the bf16 matrix pipe.
+ * Every fp32 value is split WITHOUT LOSS into three bf16 pieces (round-to-nearest remainders); the six piece products
+ * of weight >= 2^-16 are accumulated in fp32, the three dropped ones are below 2^-24 |a||b| (less than the rounding
+ * of one fp32 FMA): fp32 accuracy at 2.7x the matrix rate of v_mfma_f32_32x32x2_f32.  Bt (the weights) is split once
+ * per call into `workspace` (epn_gemm_nt_split_workspace_bytes); problems that do not qualify (K % 32, row alignment)
+ * or a missing workspace run on epn_gemm_nt_f32's kernels. */
+size_t epn_gemm_nt_split_workspace_bytes(int nprob, const epn_gemm_nt_problem *probs);
+int epn_gemm_nt_split_f32(int nprob, const epn_gemm_nt_problem *probs, void *workspace, size_t workspace_bytes,
+                          epn_stream_t stream);
 size_t epn_gemm_tn_workspace_bytes(int bf16, long long R, int N1, int N2);
 int epn_gemm_tn_f32(const float *X, long long ldx, const float *Y, long long ldy, float *C, long long ldc, long long R,
                     int N1, int N2, void *workspace, size_t workspace_bytes, epn_stream_t stream);

@@ -1,0 +1,37 @@
+"""Probe of the split-bf16 (fp32-accurate) NT contraction against the native fp32 MFMA kernel: time + error vs fp64."""
+import os
+import sys
+
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from epn_pointcloud_amd import gemm, _lib  # noqa: E402
+from gemm_bench import timeit  # noqa: E402
+
+
+def main():
+    dev = torch.device("cuda:0")
+    torch.manual_seed(0)
+    shapes = [(983040, 64, 1536), (491520, 128, 1536), (245760, 256, 3072), (245760, 256, 6144), (245760, 6144, 256), (245760, 320, 320)]
+    cfgs = [int(c, 0) for c in (sys.argv[1].split(",") if len(sys.argv) > 1 else ["0", "0x1", "0x121", "0x122", "0x123", "0x124", "0x125", "0x127", "0x128", "0x129"])]
+    for (M, N, K) in shapes:
+        A = torch.randn(M, K, device=dev) * torch.exp(torch.randn(M, 1, device=dev))
+        B = torch.randn(N, K, device=dev)
+        ref = A[:2048].double() @ B.double().t()
+        C = torch.empty(M, N, device=dev)
+        for cfg in cfgs:
+            gemm.set_fp32_mode("native" if cfg == 0 else "split")
+            _lib.check(_lib.get_lib().epn_set_kernel_policy(cfg if cfg > 1 else 0), "policy")
+            C.zero_()
+            gemm.gemm_nt(A, B, out=C)
+            err = ((C[:2048].double() - ref).abs().max() / ref.abs().max()).item()
+            rms = ((C[:2048].double() - ref).pow(2).mean().sqrt() / ref.pow(2).mean().sqrt()).item()
+            tail = (C[-2048:].double() - A[-2048:].double() @ B.double().t()).abs().max().item()
+            t = timeit(lambda: gemm.gemm_nt(A, B, out=C))
+            print(f"NT {M}x{N}x{K} cfg {cfg:#x}: {t:.3f} ms {2.0 * M * N * K / t / 1e9:.1f} TF  max {err:.2e} rms {rms:.2e} tail {tail:.1e}", flush=True)
+        _lib.get_lib().epn_set_kernel_policy(0)
+        del A, B, C, ref
+
+
+if __name__ == "__main__":
+    main()
