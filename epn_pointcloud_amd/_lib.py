@@ -23,7 +23,7 @@ EXPORTS = [
     "epn_inter_group_workspace_bytes", "epn_inter_group_f32", "epn_inter_ungroup_f32", "epn_intra_group_f32", "epn_so3_basis_f32",
     "epn_anchor_query_f32", "epn_zp_inter_fwd_f32", "epn_zp_inter_bwd_f32", "epn_zp_intra_fwd_f32", "epn_zp_intra_bwd_f32",
     "epn_pointnet_so3conv_fwd_f32", "epn_pointnet_so3conv_bwd_data_f32", "epn_pointnet_so3conv_bwd_weight_f32",
-    "epn_gemm_nt_f32", "epn_gemm_nt_bf16", "epn_gemm_nt_split_workspace_bytes", "epn_gemm_nt_split_f32", "epn_gemm_tn_workspace_bytes", "epn_gemm_tn_f32", "epn_gemm_tn_bf16",
+    "epn_gemm_nt_f32", "epn_gemm_nt_bf16", "epn_gemm_nt_split_workspace_bytes", "epn_gemm_nt_split_f32", "epn_gemm_tn_workspace_bytes", "epn_gemm_tn_f32", "epn_gemm_tn_split_f32", "epn_gemm_tn_bf16",
     "epn_transpose_cast", "epn_cast", "epn_gemm_tn_grouped_workspace_bytes", "epn_gemm_tn_grouped",
     "epn_inter_group_bf16", "epn_inter_ungroup_bf16", "epn_intra_group_bf16", "epn_so3_basis_bf16",
     "epn_gather_rows", "epn_scatter_rows", "epn_conv1x1_c1_f32", "epn_conv1x1_c1_bwd_weight_f32",
@@ -127,6 +127,7 @@ def get_lib():
     lib.epn_gemm_tn_workspace_bytes.argtypes = [_ci, _ll, _ci, _ci]
     lib.epn_gemm_tn_f32.argtypes = [_vp, _ll, _vp, _ll, _vp, _ll, _ll, _ci, _ci, _vp, _sz, _vp]
     lib.epn_gemm_tn_bf16.argtypes = [_vp, _ll, _vp, _ll, _vp, _ll, _ll, _ci, _ci, _vp, _sz, _vp]
+    lib.epn_gemm_tn_split_f32.argtypes = [_vp, _ll, _vp, _ll, _vp, _ll, _ll, _ci, _ci, _vp, _sz, _vp]
     tp = ctypes.POINTER(GemmTnProblem)
     lib.epn_gemm_tn_grouped_workspace_bytes.argtypes = [_ci, _ci, tp]
     lib.epn_gemm_tn_grouped_workspace_bytes.restype = _sz

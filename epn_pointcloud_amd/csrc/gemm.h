@@ -51,8 +51,8 @@ int launch_gemm_tn(GemmTnArgs &G, int dtype, hipStream_t st);
 // grouped: plans tiles / splits for all problems (balanced K steps per workgroup), carves `ws` into the partial slabs
 int launch_gemm_tn_batch(GemmTnBatch &B, int dtype, void *ws, size_t ws_bytes, hipStream_t st);
 size_t gemm_tn_batch_workspace(GemmTnBatch &B, int dtype);
-void gemm_tn_tile(bool bf16, int N1, int N2, int *bn1, int *bn2);
-int gemm_tn_splits(bool bf16, long long R, int N1, int N2);
+void gemm_tn_tile(int dtype, int N1, int N2, int *bn1, int *bn2);   // dtype: 0 fp32, 1 bf16, 2 fp32 operands, split form
+int gemm_tn_splits(int dtype, long long R, int N1, int N2);
 int launch_transpose_cast(const void *src, void *dst, int rows, int cols, int src_bf16, int dst_bf16, hipStream_t st);
 int launch_cast(const void *src, void *dst, size_t n, int src_bf16, int dst_bf16, hipStream_t st);
 

@@ -250,7 +250,29 @@ struct TnGeom {
     long long r0, r1;     // row range of this split
 };
 
-template <int WGM, int WGN, int TM, int TN, int BR>
+// Split form (X3, see gemm_x3.hip): fp32 operands split without loss into three bf16 pieces in registers, six
+// v_mfma_f32_32x32x16_bf16 per 32x32x16 block instead of eight v_mfma_f32_32x32x2_f32 -- fp32 accuracy at 2.7x the rate.
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ unsigned pack_rne(float a, float b) {   // v_cvt_pk_bf16_f32
+    const f32x2 v = {a, b};
+    return __builtin_bit_cast(unsigned, __builtin_convertvector(v, bf16x2));
+}
+__device__ __forceinline__ void split3(const float (&x)[8], bf16x8 &h, bf16x8 &m, bf16x8 &l) {
+    u32x4 H, M, L;
+#pragma unroll
+    for (int p = 0; p < 4; ++p) {
+        const unsigned hp = pack_rne(x[2 * p], x[2 * p + 1]);
+        const float r0 = x[2 * p] - __builtin_bit_cast(float, hp << 16);
+        const float r1 = x[2 * p + 1] - __builtin_bit_cast(float, hp & 0xffff0000u);
+        const unsigned mp = pack_rne(r0, r1);
+        H[p] = hp; M[p] = mp;
+        L[p] = pack_rne(r0 - __builtin_bit_cast(float, mp << 16), r1 - __builtin_bit_cast(float, mp & 0xffff0000u));
+    }
+    h = __builtin_bit_cast(bf16x8, H); m = __builtin_bit_cast(bf16x8, M); l = __builtin_bit_cast(bf16x8, L);
+}
+
+template <int WGM, int WGN, int TM, int TN, int BR, bool X3 = false>
 __global__ __launch_bounds__(64 * WGM * WGN) void gemm_tn_f32_kernel(GemmTnBatch B) {
     constexpr int NW = WGM * WGN;
     constexpr int BN1 = WGM * TM * 32, BN2 = WGN * TN * 32;
@@ -328,6 +350,51 @@ __global__ __launch_bounds__(64 * WGM * WGN) void gemm_tn_f32_kernel(GemmTnBatch
         __syncthreads();
         const char *base = smem + (kt & 1) * STAGE_B;
         const bool more = kt + 1 < nk;
+        if constexpr (X3) {
+            if (more) stage((kt + 1) & 1);
+#pragma unroll
+            for (int s = 0; s < BR / 16; ++s) {     // 16 rows per fragment step: lane group lj holds rows 8 lj .. 8 lj + 7
+                float xa[TM][8], yb[TN][8];
+#pragma unroll
+                for (int k = 0; k < 8; ++k) {
+                    const char *row = base + (16 * s + 8 * lj + k) * (ROWF * 4);
+                    if constexpr (TM == 4) {
+                        const f32x4 v = *reinterpret_cast<const f32x4 *>(row + xo);
+                        xa[0][k] = v[0]; xa[1][k] = v[1]; xa[2][k] = v[2]; xa[3][k] = v[3];
+                    } else if constexpr (TM == 2) {
+                        const f32x2 v = *reinterpret_cast<const f32x2 *>(row + xo);
+                        xa[0][k] = v[0]; xa[1][k] = v[1];
+                    } else {
+                        xa[0][k] = *reinterpret_cast<const float *>(row + xo);
+                    }
+                    if constexpr (TN == 4) {
+                        const f32x4 v = *reinterpret_cast<const f32x4 *>(row + yo);
+                        yb[0][k] = v[0]; yb[1][k] = v[1]; yb[2][k] = v[2]; yb[3][k] = v[3];
+                    } else if constexpr (TN == 2) {
+                        const f32x2 v = *reinterpret_cast<const f32x2 *>(row + yo);
+                        yb[0][k] = v[0]; yb[1][k] = v[1];
+                    } else {
+                        yb[0][k] = *reinterpret_cast<const float *>(row + yo);
+                    }
+                }
+                bf16x8 ah[TM], am[TM], al[TM], bh[TN], bm[TN], bl[TN];
+#pragma unroll
+                for (int i = 0; i < TM; ++i) split3(xa[i], ah[i], am[i], al[i]);
+#pragma unroll
+                for (int j = 0; j < TN; ++j) split3(yb[j], bh[j], bm[j], bl[j]);
+#define EPN_X3_TERM(PA, PB)                                                                                 \
+    _Pragma("unroll") for (int i = 0; i < TM; ++i) _Pragma("unroll") for (int j = 0; j < TN; ++j)         \
+        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(PA[i], PB[j], acc[i][j], 0, 0, 0)
+                EPN_X3_TERM(ah, bl);                // small terms first
+                EPN_X3_TERM(al, bh);
+                EPN_X3_TERM(am, bm);
+                EPN_X3_TERM(ah, bm);
+                EPN_X3_TERM(am, bh);
+                EPN_X3_TERM(ah, bh);
+#undef EPN_X3_TERM
+            }
+            continue;
+        }
         // fragments of k-pair s+1 are read while the MFMAs of pair s issue (two register sets, static indices)
         float a[2][TM], b[2][TN];
         auto rd = [&](int s, int set) {
@@ -731,6 +798,8 @@ int launch_nt_typed(GemmNtBatch &B, hipStream_t st) {
     else return launch_nt_cfg<T, TO, 4, 2, 2, 2>(B, st);
 }
 
+constexpr int tn_waves(int wgm, int wgn, int, int, int) { return wgm * wgn; }
+
 template <typename T>
 bool tn_fast_ok(const GemmTnArgs &G) {
     constexpr int E16 = ElemOf<T>::PER16;
@@ -741,8 +810,8 @@ bool tn_fast_ok(const GemmTnArgs &G) {
 // Plan of a (grouped) TN launch: one block tile for all problems; splits so that every workgroup runs about the same
 // number of K steps and the launch has ~2048 workgroups (single problem) / ~1024 (group); partial slabs carved from `ws`.
 template <typename T>
-size_t tn_plan(GemmTnBatch &B, int *bn1_out, int *bn2_out, void *ws) {
-    const bool bf = sizeof(T) == 2;
+size_t tn_plan(GemmTnBatch &B, int *bn1_out, int *bn2_out, void *ws, bool x3 = false) {
+    const int bf = sizeof(T) == 2 ? 1 : (x3 ? 2 : 0);
     int max1 = 0, min2 = 1 << 30;
     for (int i = 0; i < B.nprob; ++i) {
         max1 = B.p[i].N1 > max1 ? B.p[i].N1 : max1;
@@ -797,7 +866,7 @@ size_t tn_plan(GemmTnBatch &B, int *bn1_out, int *bn2_out, void *ws) {
 }
 
 template <typename T>
-int launch_tn_typed(GemmTnBatch &B, void *ws, size_t ws_bytes, hipStream_t st) {
+int launch_tn_typed(GemmTnBatch &B, void *ws, size_t ws_bytes, hipStream_t st, bool x3 = false) {
     bool fast = true;
     for (int i = 0; i < B.nprob; ++i) {
         const GemmTnArgs &G = B.p[i];
@@ -818,19 +887,25 @@ int launch_tn_typed(GemmTnBatch &B, void *ws, size_t ws_bytes, hipStream_t st) {
         return 0;
     }
     int bn1, bn2;
-    const size_t need = tn_plan<T>(B, &bn1, &bn2, ws);
+    const size_t need = tn_plan<T>(B, &bn1, &bn2, ws, x3);
     if (need > 0 && (!ws || ws_bytes < need)) return EPN_EWORKSPACE;
     const dim3 grid(B.nblocks);
     if constexpr (sizeof(T) == 4) {
-        if (bn1 == 32) hipLaunchKernelGGL((gemm_tn_f32_kernel<1, 8, 1, 2, 32>), grid, dim3(512), 0, st, B);
-        else if (bn1 == 64 && bn2 == 64) hipLaunchKernelGGL((gemm_tn_f32_kernel<2, 2, 1, 1, 32>), grid, dim3(256), 0, st, B);
-        else if (bn1 == 64 && bn2 == 128) hipLaunchKernelGGL((gemm_tn_f32_kernel<2, 2, 1, 2, 32>), grid, dim3(256), 0, st, B);
-        else if (bn1 == 128 && bn2 == 64) hipLaunchKernelGGL((gemm_tn_f32_kernel<2, 2, 2, 1, 32>), grid, dim3(256), 0, st, B);
-        else if (bn1 == 128 && bn2 == 128) hipLaunchKernelGGL((gemm_tn_f32_kernel<2, 2, 2, 2, 32>), grid, dim3(256), 0, st, B);
-        else if (bn1 == 64 && bn2 == 512) hipLaunchKernelGGL((gemm_tn_f32_kernel<1, 4, 2, 4, 16>), grid, dim3(256), 0, st, B);
-        else if (bn1 == 64) hipLaunchKernelGGL((gemm_tn_f32_kernel<1, 8, 2, 1, 32>), grid, dim3(512), 0, st, B);
-        else if (bn2 == 512) hipLaunchKernelGGL((gemm_tn_f32_kernel<1, 8, 4, 2, 32>), grid, dim3(512), 0, st, B);
-        else hipLaunchKernelGGL((gemm_tn_f32_kernel<2, 4, 2, 2, 32>), grid, dim3(512), 0, st, B);
+#define EPN_TN(...)                                                                                                  \
+    do {                                                                                                             \
+        if (x3) hipLaunchKernelGGL((gemm_tn_f32_kernel<__VA_ARGS__, true>), grid, dim3(64 * tn_waves(__VA_ARGS__)), 0, st, B);  \
+        else hipLaunchKernelGGL((gemm_tn_f32_kernel<__VA_ARGS__, false>), grid, dim3(64 * tn_waves(__VA_ARGS__)), 0, st, B);    \
+    } while (0)
+        if (bn1 == 32) EPN_TN(1, 8, 1, 2, 32);
+        else if (bn1 == 64 && bn2 == 64) EPN_TN(2, 2, 1, 1, 32);
+        else if (bn1 == 64 && bn2 == 128) EPN_TN(2, 2, 1, 2, 32);
+        else if (bn1 == 128 && bn2 == 64) EPN_TN(2, 2, 2, 1, 32);
+        else if (bn1 == 128 && bn2 == 128) EPN_TN(2, 2, 2, 2, 32);
+        else if (bn1 == 64 && bn2 == 512) EPN_TN(1, 4, 2, 4, 16);
+        else if (bn1 == 64) EPN_TN(1, 8, 2, 1, 32);
+        else if (bn2 == 512) EPN_TN(1, 8, 4, 2, 32);
+        else EPN_TN(2, 4, 2, 2, 32);
+#undef EPN_TN
     } else {
         if (bn1 == 32) hipLaunchKernelGGL((gemm_tn_bf16_kernel<1, 4, 2, 4>), grid, dim3(256), 0, st, B);        // 4 waves: fewer,
         else if (bn1 == 64) hipLaunchKernelGGL((gemm_tn_bf16_kernel<1, 4, 4, 4>), grid, dim3(256), 0, st, B);   // larger wave tiles
@@ -859,8 +934,8 @@ int launch_tn_typed(GemmTnBatch &B, void *ws, size_t ws_bytes, hipStream_t st) {
 }  // namespace
 
 // block tile of the TN kernels for an output of N1 x N2 (shared with the workspace query)
-void gemm_tn_tile(bool bf16, int N1, int N2, int *bn1, int *bn2) {
-    if (bf16) {
+void gemm_tn_tile(int dtype, int N1, int N2, int *bn1, int *bn2) {   // dtype: 0 fp32, 1 bf16, 2 fp32 split form
+    if (dtype == 1) {
         if (N1 <= 32) { *bn1 = 32; *bn2 = 256; }
         else if (N1 <= 64) { *bn1 = 64; *bn2 = 256; }
         else { *bn1 = 128; *bn2 = 256; }
@@ -868,15 +943,18 @@ void gemm_tn_tile(bool bf16, int N1, int N2, int *bn1, int *bn2) {
         // wide outputs (dW of the inter convolutions: N2 = cin*ks): 512-column tiles, 8 MFMAs per pair of LDS reads;
         // narrow ones (spectral blocks, 1x1 convolutions): 256-column tiles
         // narrow single problems (dW of the 1x1 convolutions: N2 = cin <= 128): 64- / 128-column tiles, 4 waves
+        // split form: both operands are split on the VALU (36 instructions per fragment): the 128 x 256 tile on eight
+        // waves (64 x 64 per wave, no spills) runs the wide weight gradients at 150 TFLOP/s, the 128 x 512 one at 137
+        if (dtype == 2 && N1 > 64 && N2 >= 512) { *bn1 = 128; *bn2 = 256; return; }
         if (N1 <= 32) { *bn1 = 32; *bn2 = 512; }
         else if (N1 <= 64) { *bn1 = 64; *bn2 = N2 >= 512 ? 512 : (N2 > 128 ? 256 : (N2 > 64 ? 128 : 64)); }
         else { *bn1 = 128; *bn2 = N2 >= 512 ? 512 : (N2 > 128 ? 256 : (N2 > 64 ? 128 : 64)); }
     }
 }
 
-int gemm_tn_splits(bool bf16, long long R, int N1, int N2) {
+int gemm_tn_splits(int dtype, long long R, int N1, int N2) {
     int bn1, bn2;
-    gemm_tn_tile(bf16, N1, N2, &bn1, &bn2);
+    gemm_tn_tile(dtype, N1, N2, &bn1, &bn2);
     const long long tiles = (long long)((N1 + bn1 - 1) / bn1) * ((N2 + bn2 - 1) / bn2);
     const long long chunks = R / 32;
     const int pol = kernel_policy();
@@ -905,6 +983,7 @@ int launch_gemm_nt(GemmNtBatch &B, int dtype, int out_dtype, hipStream_t st) {
 
 int launch_gemm_tn_batch(GemmTnBatch &B, int dtype, void *ws, size_t ws_bytes, hipStream_t st) {
     if (B.nprob < 1 || B.nprob > GEMM_MAX_PROB) return EPN_EINVAL;
+    if (dtype == 2) return launch_tn_typed<float>(B, ws, ws_bytes, st, true);    // fp32 operands, split form
     return dtype == 0 ? launch_tn_typed<float>(B, ws, ws_bytes, st) : launch_tn_typed<__bf16>(B, ws, ws_bytes, st);
 }
 
@@ -912,7 +991,7 @@ size_t gemm_tn_batch_workspace(GemmTnBatch &B, int dtype) {
     int bn1, bn2;
     for (int i = 0; i < B.nprob; ++i)
         if (B.p[i].R < 32 || B.p[i].N1 < 1 || B.p[i].N2 < 1) return 0;
-    return dtype == 0 ? tn_plan<float>(B, &bn1, &bn2, nullptr) : tn_plan<__bf16>(B, &bn1, &bn2, nullptr);
+    return dtype != 1 ? tn_plan<float>(B, &bn1, &bn2, nullptr, dtype == 2) : tn_plan<__bf16>(B, &bn1, &bn2, nullptr);
 }
 
 int launch_gemm_tn(GemmTnArgs &G, int dtype, hipStream_t st) {
@@ -980,7 +1059,7 @@ extern "C" int epn_gemm_nt_bf16(int nprob, const epn_gemm_nt_problem *probs, int
 
 extern "C" size_t epn_gemm_tn_workspace_bytes(int bf16, long long R, int N1, int N2) {
     if (R < 1 || N1 < 1 || N2 < 1) return 0;
-    const int s = gemm_tn_splits(bf16 != 0, R, N1, N2);
+    const int s = gemm_tn_splits(bf16, R, N1, N2);
     return s > 1 ? (((size_t)s * N1 * N2 * sizeof(float) + 255) & ~(size_t)255) : 0;
 }
 
@@ -994,6 +1073,10 @@ static int tn_entry(const void *X, long long ldx, const void *Y, long long ldy, 
 extern "C" int epn_gemm_tn_f32(const float *X, long long ldx, const float *Y, long long ldy, float *C, long long ldc,
                                long long R, int N1, int N2, void *workspace, size_t workspace_bytes, epn_stream_t stream) {
     return tn_entry(X, ldx, Y, ldy, C, ldc, R, N1, N2, workspace, workspace_bytes, 0, stream);
+}
+extern "C" int epn_gemm_tn_split_f32(const float *X, long long ldx, const float *Y, long long ldy, float *C, long long ldc,
+                                     long long R, int N1, int N2, void *workspace, size_t workspace_bytes, epn_stream_t stream) {
+    return tn_entry(X, ldx, Y, ldy, C, ldc, R, N1, N2, workspace, workspace_bytes, 2, stream);
 }
 extern "C" int epn_gemm_tn_bf16(const void *X, long long ldx, const void *Y, long long ldy, float *C, long long ldc,
                                 long long R, int N1, int N2, void *workspace, size_t workspace_bytes, epn_stream_t stream) {
@@ -1013,7 +1096,7 @@ extern "C" size_t epn_gemm_tn_grouped_workspace_bytes(int bf16, int nprob, const
     if (!probs || nprob < 1 || nprob > GEMM_MAX_PROB) return 0;
     GemmTnBatch B;
     tn_fill(B, nprob, probs);
-    return gemm_tn_batch_workspace(B, bf16 ? 1 : 0);
+    return gemm_tn_batch_workspace(B, bf16);
 }
 extern "C" int epn_gemm_tn_grouped(int bf16, int nprob, const epn_gemm_tn_problem *probs, void *workspace,
                                    size_t workspace_bytes, epn_stream_t stream) {
@@ -1021,7 +1104,7 @@ extern "C" int epn_gemm_tn_grouped(int bf16, int nprob, const epn_gemm_tn_proble
     if (nprob < 1 || nprob > GEMM_MAX_PROB) return EPN_EINVAL;
     GemmTnBatch B;
     tn_fill(B, nprob, probs);
-    return launch_gemm_tn_batch(B, bf16 ? 1 : 0, workspace, workspace_bytes, epn_stream(stream));
+    return launch_gemm_tn_batch(B, bf16 == 2 ? 2 : (bf16 ? 1 : 0), workspace, workspace_bytes, epn_stream(stream));
 }
 
 extern "C" int epn_transpose_cast(const void *src, void *dst, int rows, int cols, int src_bf16, int dst_bf16,

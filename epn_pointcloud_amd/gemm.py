@@ -107,9 +107,10 @@ def gemm_tn(X, Y, out=None):
         out = torch.empty((N1, N2), dtype=torch.float32, device=X.device)
     elif out.dtype != torch.float32 or out.stride(1) != 1 or tuple(out.shape) != (N1, N2):
         raise ValueError("gemm_tn: output must be row-major fp32 [N1,N2]")
-    nbytes = int(lib.epn_gemm_tn_workspace_bytes(bf, R, N1, N2))
+    split = not bf and FP32_MODE == "split"
+    nbytes = int(lib.epn_gemm_tn_workspace_bytes(2 if split else bf, R, N1, N2))
     ws = torch.empty(max(nbytes, 16), dtype=torch.uint8, device=X.device)
-    fn = lib.epn_gemm_tn_bf16 if bf else lib.epn_gemm_tn_f32
+    fn = lib.epn_gemm_tn_bf16 if bf else (lib.epn_gemm_tn_split_f32 if split else lib.epn_gemm_tn_f32)
     ldx = X.stride(0) if R > 1 else N1
     ldy = Y.stride(0) if R > 1 else N2
     ldc = out.stride(0) if N1 > 1 else N2
@@ -140,9 +141,10 @@ def gemm_tn_grouped(problems):
         p.ldc = C.shape[1]
         outs.append(C)
         keep += [X, Y]
-    nbytes = int(lib.epn_gemm_tn_grouped_workspace_bytes(bf, len(problems), arr))
+    mode = 2 if (not bf and FP32_MODE == "split") else bf
+    nbytes = int(lib.epn_gemm_tn_grouped_workspace_bytes(mode, len(problems), arr))
     ws = torch.empty(max(nbytes, 16), dtype=torch.uint8, device=outs[0].device)
-    _lib.check(lib.epn_gemm_tn_grouped(bf, len(problems), arr, ws.data_ptr(), ws.numel(), _lib.stream_of(outs[0])),
+    _lib.check(lib.epn_gemm_tn_grouped(mode, len(problems), arr, ws.data_ptr(), ws.numel(), _lib.stream_of(outs[0])),
                "gemm_tn_grouped")
     return outs
 

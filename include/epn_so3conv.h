@@ -314,7 +314,10 @@ int epn_gemm_tn_f32(const float *X, long long ldx, const float *Y, long long ldy
                     int N1, int N2, void *workspace, size_t workspace_bytes, epn_stream_t stream);
 int epn_gemm_tn_bf16(const void *X, long long ldx, const void *Y, long long ldy, float *C, long long ldc, long long R,
                      int N1, int N2, void *workspace, size_t workspace_bytes, epn_stream_t stream);
-/* Grouped TN: up to 6 problems in ONE launch (the five weight-gradient GEMMs of a spectral IntraSO3Conv layer, each too
+/* split form of epn_gemm_tn_f32 (see epn_gemm_nt_split_f32): both operands are split in registers; same workspace */
+int epn_gemm_tn_split_f32(const float *X, long long ldx, const float *Y, long long ldy, float *C, long long ldc,
+                          long long R, int N1, int N2, void *workspace, size_t workspace_bytes, epn_stream_t stream);
+/* Grouped TN (`bf16`: 0 = fp32, 1 = bf16 operands, 2 = fp32 operands in the split form): up to 6 problems in ONE launch (the five weight-gradient GEMMs of a spectral IntraSO3Conv layer, each too
  * small to fill the chip alone); splits are planned so that every workgroup runs about the same number of K steps. */
 typedef struct epn_gemm_tn_problem {
     const void *X, *Y;

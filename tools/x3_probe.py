@@ -14,7 +14,7 @@ def main():
     torch.manual_seed(0)
     shapes = [(983040, 64, 1536), (491520, 128, 1536), (245760, 256, 3072), (245760, 256, 6144), (245760, 6144, 256), (245760, 320, 320)]
     cfgs = [int(c, 0) for c in (sys.argv[1].split(",") if len(sys.argv) > 1 else ["0", "0x1", "0x121", "0x122", "0x123", "0x124", "0x125", "0x127", "0x128", "0x129"])]
-    for (M, N, K) in shapes:
+    for (M, N, K) in (shapes if "nt" in os.environ.get("X3_PROBE", "nt,tn") else []):
         A = torch.randn(M, K, device=dev) * torch.exp(torch.randn(M, 1, device=dev))
         B = torch.randn(N, K, device=dev)
         ref = A[:2048].double() @ B.double().t()
@@ -31,6 +31,20 @@ def main():
             print(f"NT {M}x{N}x{K} cfg {cfg:#x}: {t:.3f} ms {2.0 * M * N * K / t / 1e9:.1f} TF  max {err:.2e} rms {rms:.2e} tail {tail:.1e}", flush=True)
         _lib.get_lib().epn_set_kernel_policy(0)
         del A, B, C, ref
+    for (R, N1, N2) in [(983040, 64, 1536), (491520, 128, 1536), (245760, 256, 3072), (245760, 256, 6144), (491520, 128, 128), (245760, 256, 256)]:
+        X = torch.randn(R, N1, device=dev) * torch.exp(torch.randn(1, N1, device=dev))
+        Y = torch.randn(R, N2, device=dev)
+        ref = X[:, :32].double().t() @ Y[:, :256].double()
+        for mode in ("native", "split"):
+            gemm.set_fp32_mode(mode)
+            C = gemm.gemm_tn(X, Y)
+            d = C[:32, :256].double() - ref
+            err = (d.abs().max() / ref.abs().max()).item()
+            rms = (d.pow(2).mean().sqrt() / ref.pow(2).mean().sqrt()).item()
+            t = timeit(lambda: gemm.gemm_tn(X, Y, out=C))
+            print(f"TN {R}x{N1}x{N2} {mode}: {t:.3f} ms {2.0 * R * N1 * N2 / t / 1e9:.1f} TF  max {err:.2e} rms {rms:.2e}", flush=True)
+        del X, Y, C, ref
+    gemm.set_fp32_mode("native")
 
 
 if __name__ == "__main__":
