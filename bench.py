@@ -173,6 +173,8 @@ def main():
         _lib.check(_lib.get_lib().epn_set_kernel_policy(int(args.policy, 0)), "set_kernel_policy")
 
     dtype_name = args.dtype or ("f32" if args.model == "cls" else "bf16")
+    from epn_pointcloud_amd import gemm as _gemm
+    split_gemm = dtype_name == "f32" and _gemm.FP32_MODE == "split"
     fdtype = torch.float32 if dtype_name == "f32" else torch.bfloat16
     args.batch = args.batch or (32 if args.model == "cls" else 64)
     args.points = args.points or (2048 if args.model == "inv" else 1024)   # 3DMatch patches (generate_eval.py:26,68)
@@ -338,6 +340,19 @@ def main():
             if kk % (4 * e16):
                 return "epn::gemm_nt_generic_kernel"
             ksz = 8 if kk % (8 * e16) == 0 else 4
+            if dtype_name == "f32" and split_gemm and ksz == 8:        # launch_gemm_nt_x3 (csrc/gemm_x3.hip)
+                mx = max(ns)
+                if len(ns) > 1:
+                    cfg = "4, 1, 2, 2, 3" if (mx <= 320 and min(ns) <= 64) else "2, 2, 2, 2, 2"
+                elif mx <= 32:
+                    cfg = "8, 1, 2, 1, 2"
+                elif mx <= 64:
+                    cfg = "4, 1, 2, 2, 3"
+                elif mx <= 128 or mx % 256 > 128 or (mx % 256 and mx < 512):
+                    cfg = "4, 2, 2, 2, 2"
+                else:
+                    cfg = "4, 2, 2, 4, 2"
+                return f"epn::gemm_nt_x3_kernel<{cfg}>"
             if ksz == 4:
                 cfg = "8, 1, 2, 1" if max(ns) <= 32 else ("8, 1, 2, 2" if max(ns) <= 64 else "4, 2, 2, 2")
             elif dtype_name == "f32" and len(ns) > 1:          # grouped spectral blocks
@@ -364,13 +379,16 @@ def main():
             if grouped and n2 < 256:
                 n2 = 256
             w2 = 512 if n2 >= 512 else (256 if n2 > 128 else (128 if n2 > 64 else 64))
+            x3 = "true" if split_gemm else "false"
+            if split_gemm and n1 > 64 and n2 >= 512:
+                return "epn::gemm_tn_f32_kernel<2, 4, 2, 2, 32, true>"
             if n1 <= 32:
                 cfg = "1, 8, 1, 2, 32"
             elif n1 <= 64:
                 cfg = {512: "1, 4, 2, 4, 16", 256: "1, 8, 2, 1, 32", 128: "2, 2, 1, 2, 32", 64: "2, 2, 1, 1, 32"}[w2]
             else:
                 cfg = {512: "1, 8, 4, 2, 32", 256: "2, 4, 2, 2, 32", 128: "2, 2, 2, 2, 32", 64: "2, 2, 2, 1, 32"}[w2]
-            return f"epn::gemm_tn_f32_kernel<{cfg}>"
+            return f"epn::gemm_tn_f32_kernel<{cfg}, {x3}>"
 
         def kernel_of(kind, key):
             if kind == "inter_gemm_dw":
@@ -405,6 +423,18 @@ def main():
         def roof(k):
             d = agg[k]
             ach = d["flops"] / (d["ms"] * 1e-3) / 1e12
+            if "_x3_" in k or k.endswith("true>"):
+                # split form: every fp32 multiply-add is six bf16 MFMA multiply-adds (fp32 accumulate); the roof is the
+                # bf16 matrix pipe and `achieved` the flops it EXECUTES; the fp32-equivalent rate is reported beside it
+                return {"bound": "mfma", "kernel": k, "achieved": round(6 * ach, 1), "peak": PEAK_TFLOPS["bf16"],
+                        "unit": "TFLOP/s", "frac": round(6 * ach / PEAK_TFLOPS["bf16"], 4),
+                        "algorithmic_fp32_tflops": round(ach, 2),
+                        "vs_fp32_mfma_peak": round(ach / PEAK_TFLOPS["f32"], 3),
+                        "note": ("fp32 operands split losslessly into 3 bf16 pieces, 6 piece products per multiply on "
+                                 "v_mfma_f32_32x32x16_bf16, fp32 accumulate (csrc/gemm_x3.hip): fp32 accuracy; achieved = "
+                                 "executed bf16 flops = 6 x algorithmic"),
+                        "traffic": recorded_traffic(k) if (args.model == "cls" and args.batch == 32 and dtype_name == "f32") else None,
+                        "launches": d["launches"], "avg_launch_ms": round(d["ms"] / d["launches"], 4)}
             return {"bound": "mfma", "kernel": k, "achieved": round(ach, 2), "peak": peak, "unit": "TFLOP/s",
                     "frac": round(ach / peak, 4),
                     "traffic": recorded_traffic(k) if (args.model == "cls" and args.batch == 32 and dtype_name == "f32") else None,
@@ -454,10 +484,12 @@ def main():
                                    + ({"cls": " + ClsOutBlockPointnet head)", "reg": " + RelSO3OutBlockR head)",
                                        "inv": " + InvOutBlockMVD head)"}[args.model] if head else ", backbone only)")
                                    + f", B={args.batch}/GPU N={args.points} K={nn_desc} A=60 "
-                                   + ("fp32" if dtype_name == "f32" else "bf16 features / fp32 accumulate")
+                                   + (("fp32 (weight contractions: lossless 3 x bf16 split on the bf16 MFMAs, fp32 accumulate)"
+                                       if split_gemm else "fp32") if dtype_name == "f32" else "bf16 features / fp32 accumulate")
                                    + f", {'fwd' if args.forward_only else 'fwd+bwd+Adam'}",
                        "global_batch": args.batch * world, "points": args.points, "anchors": 60, "launch": launch,
                        "hbm_peak_gb": round(torch.cuda.max_memory_allocated(dev) / 2 ** 30, 1),
+                       "fp32_gemm": ("split" if split_gemm else "native") if dtype_name == "f32" else None,
                        "parallelism": f"dp{world}"},
             "roofline": roofline,
         }

@@ -288,6 +288,9 @@ int launch_gemm_nt_x3(GemmNtBatch &B, void *ws, size_t ws_bytes, hipStream_t st)
             case 0x28: return launch_x3_cfg<2, 4, 2, 2, 2>(B, st);     // 128 x 256, 8 waves
             case 0x29: return launch_x3_cfg<2, 2, 2, 4, 2>(B, st);     // 128 x 256, 4 waves
             case 0x2a: return launch_x3_cfg<8, 1, 2, 1, 2>(B, st);     // 512 x 32
+            case 0x2b: return launch_x3_cfg<4, 4, 2, 2, 2>(B, st);     // 256 x 256, 16 waves
+            case 0x2c: return launch_x3_cfg<4, 4, 2, 1, 2>(B, st);     // 256 x 128, 16 waves
+            case 0x2d: return launch_x3_cfg<8, 2, 1, 4, 2>(B, st);     // 256 x 256, 16 waves, 32 x 128 per wave
             default: break;
         }
     }

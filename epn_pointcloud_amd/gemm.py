@@ -15,7 +15,7 @@ from . import _lib
 
 # fp32 contractions: "split" = on the bf16 matrix pipe with lossless three-way operand splitting (fp32 accuracy,
 # csrc/gemm_x3.hip), "native" = v_mfma_f32_32x32x2_f32
-FP32_MODE = os.environ.get("EPN_GEMM_FP32", "native")
+FP32_MODE = os.environ.get("EPN_GEMM_FP32", "split")
 
 
 def set_fp32_mode(mode):
