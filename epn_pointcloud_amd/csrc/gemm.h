@@ -31,6 +31,7 @@ struct GemmTnArgs {        // C[N1][N2] = X[R][N1]^T . Y[R][N2]
     unsigned ntiles;
     int tiles_n2, nsplit;
     unsigned block0;       // first workgroup of this problem inside a grouped launch
+    const void *Xp;        // split form: the three bf16 planes [3][R/8][N1][8] of X (workspace), set by the plan
 };
 struct GemmTnBatch {       // up to GEMM_MAX_PROB problems in ONE launch (the irreducible blocks of a spectral IntraSO3Conv)
     int nprob;

@@ -272,6 +272,8 @@ __device__ __forceinline__ void split3(const float (&x)[8], bf16x8 &h, bf16x8 &m
     h = __builtin_bit_cast(bf16x8, H); m = __builtin_bit_cast(bf16x8, M); l = __builtin_bit_cast(bf16x8, L);
 }
 
+// X3: both operands split in registers (the narrow / grouped problems, where a separate splitting pass over X would cost
+// as much as the GEMM); the wide weight gradients run on gemm_tn_x3_kernel below.
 template <int WGM, int WGN, int TM, int TN, int BR, bool X3 = false>
 __global__ __launch_bounds__(64 * WGM * WGN) void gemm_tn_f32_kernel(GemmTnBatch B) {
     constexpr int NW = WGM * WGN;
@@ -466,6 +468,179 @@ __global__ __launch_bounds__(64 * WGM * WGN) void gemm_tn_f32_kernel(GemmTnBatch
         for (int r = 0; r < 16; ++r) {
             const int ri = (r & 3) + 8 * (r >> 2) + 4 * lj;
             const int n1 = n1_0 + wm * TM * 32 + TM * ri + i;
+            const int n2 = n2_0 + wn * TN * 32 + TN * li;
+            if (n1 < G.N1) {
+#pragma unroll
+                for (int j = 0; j < TN; ++j)
+                    if (n2 + j < G.N2) C[(long long)n1 * ldc + n2 + j] = acc[i][j][r];
+            }
+        }
+}
+
+// ------------------------------------------------------------------------------------------------ TN (fp32, split form)
+// Split form with the NARROW operand X (the output gradient: N1 = cout columns, a few % of the bytes of Y) split ahead of
+// the GEMM by split_octets_kernel into three bf16 planes laid out [plane][R/8][N1][8]: the eight contraction values a
+// lane needs for one output row are one 16-byte chunk, so an X fragment is ONE ds_read_b128 per plane and costs no VALU
+// work; only Y (the grouped features, streamed once) is split in registers -- 36 VALU instructions per Y fragment,
+// 1.5 per MFMA for a 128 x 64 wave tile instead of 4.5-6 when both operands are split in the kernel (the VALU/issue
+// slots beside a 32-cycle MFMA are what bounded that form at 150 TFLOP/s).  MFMA tile i of a wave covers output rows
+// base + 32 i + (MFMA row) here (contiguous chunks: conflict-free b128 reads), columns as in gemm_tn_f32_kernel.
+__global__ void split_octets_kernel(const float *__restrict__ X, long long ldx, long long R, int N1, u32x4 *__restrict__ planes) {
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    const long long n = (R >> 3) * N1;
+    if (i >= n) return;
+    const long long o = i / N1;
+    const int c = (int)(i - o * N1);
+    float x[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) x[k] = X[(8 * o + k) * ldx + c];
+    bf16x8 h, m, l;
+    split3(x, h, m, l);
+    planes[i] = __builtin_bit_cast(u32x4, h);
+    planes[n + i] = __builtin_bit_cast(u32x4, m);
+    planes[2 * n + i] = __builtin_bit_cast(u32x4, l);
+}
+
+template <int WGM, int WGN, int TM, int TN, int BR>
+__global__ __launch_bounds__(64 * WGM * WGN) void gemm_tn_x3_kernel(GemmTnBatch B) {
+    constexpr int NW = WGM * WGN;
+    constexpr int BN1 = WGM * TM * 32, BN2 = WGN * TN * 32;
+    constexpr int OCT = BR / 8;                     // row octets per stage
+    constexpr int XB = 3 * OCT * BN1 * 16;          // X planes of a stage: [plane][octet][n1] 16-byte chunks
+    constexpr int YB = BR * BN2 * 4;                // Y rows (fp32)
+    constexpr int STAGE_B = XB + YB;
+    constexpr int NIX = XB / 1024, NI = STAGE_B / 1024;
+    constexpr int IPW = (NI + NW - 1) / NW;
+    static_assert(XB % 1024 == 0 && YB % 1024 == 0 && 2 * STAGE_B <= 160 * 1024, "stage");
+    __shared__ __attribute__((aligned(1024))) char smem[2 * STAGE_B];
+
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    int pi = 0;
+#pragma unroll
+    for (int i = 1; i < GEMM_MAX_PROB; ++i)
+        if (i < B.nprob && blockIdx.x >= B.p[i].block0) pi = i;
+    const GemmTnArgs &G = B.p[pi];
+    const unsigned lb = blockIdx.x - G.block0;
+    const unsigned tile = lb % G.ntiles, split = lb / G.ntiles;
+    const int n1_0 = (int)(tile / G.tiles_n2) * BN1, n2_0 = (int)(tile % G.tiles_n2) * BN2;
+    const long long nchunk = G.R / BR;
+    const long long c0 = nchunk * split / G.nsplit, c1 = nchunk * (split + 1) / G.nsplit;
+    const int nk = (int)(c1 - c0);
+
+    const char *src[IPW];
+    long long sstep[IPW];
+#pragma unroll
+    for (int i = 0; i < IPW; ++i) {
+        const int q = wave + i * NW;
+        if (q < NIX) {
+            const int ci = 64 * q + lane;            // chunk of the [plane][octet][n1] image
+            const int c = ci % BN1, po = ci / BN1;
+            const int oct = po % OCT, pl = po / OCT;
+            int n = n1_0 + c;
+            n = n < G.N1 ? n : G.N1 - 1;
+            src[i] = static_cast<const char *>(G.Xp) + (((size_t)pl * (G.R >> 3) + (c0 * OCT + oct)) * G.N1 + n) * 16;
+            sstep[i] = (long long)OCT * G.N1 * 16;
+        } else {
+            const int fo = 256 * (q - NIX) + 4 * lane;
+            const int r = fo / BN2, c = fo % BN2;
+            int n = n2_0 + c;
+            n = n < G.N2 - 4 ? n : G.N2 - 4;
+            src[i] = reinterpret_cast<const char *>(static_cast<const float *>(G.Y) + (c0 * BR + r) * G.ldy + n);
+            sstep[i] = (long long)BR * G.ldy * 4;
+        }
+    }
+    auto stage = [&](int buf) {
+#pragma unroll
+        for (int i = 0; i < IPW; ++i) {
+            const int q = wave + i * NW;
+            if (NI % NW == 0 || q < NI) {
+                glds16(src[i], smem + buf * STAGE_B + q * 1024);
+                src[i] += sstep[i];
+            }
+        }
+    };
+
+    const int wm = wave / WGN, wn = wave % WGN;
+    const int li = lane & 31, lj = lane >> 5;
+    const int xo = (wm * TM * 32 + li) * 16;                      // chunk of MFMA tile 0 inside an [octet] row of a plane
+    const int yo = XB + (wn * TN * 32 + TN * li) * 4;
+
+    f32x16 acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    if (nk > 0) stage(0);
+    for (int kt = 0; kt < nk; ++kt) {
+        __syncthreads();
+        const char *base = smem + (kt & 1) * STAGE_B;
+        if (kt + 1 < nk) stage((kt + 1) & 1);
+#pragma unroll
+        for (int s = 0; s < BR / 16; ++s) {         // 16 rows per fragment step: lane group lj holds octet 2 s + lj
+            bf16x8 ah[TM], am[TM], al[TM], bh[TN], bm[TN], bl[TN];
+            float yb[TN][8];
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {
+                const char *row = base + (16 * s + 8 * lj + k) * (BN2 * 4);
+                if constexpr (TN == 4) {
+                    const f32x4 v = *reinterpret_cast<const f32x4 *>(row + yo);
+                    yb[0][k] = v[0]; yb[1][k] = v[1]; yb[2][k] = v[2]; yb[3][k] = v[3];
+                } else if constexpr (TN == 2) {
+                    const f32x2 v = *reinterpret_cast<const f32x2 *>(row + yo);
+                    yb[0][k] = v[0]; yb[1][k] = v[1];
+                } else {
+                    yb[0][k] = *reinterpret_cast<const float *>(row + yo);
+                }
+            }
+#pragma unroll
+            for (int i = 0; i < TM; ++i) {
+                const char *xp = base + (2 * s + lj) * (BN1 * 16) + xo + i * 512;
+                ah[i] = *reinterpret_cast<const bf16x8 *>(xp);
+                am[i] = *reinterpret_cast<const bf16x8 *>(xp + OCT * BN1 * 16);
+                al[i] = *reinterpret_cast<const bf16x8 *>(xp + 2 * OCT * BN1 * 16);
+            }
+#pragma unroll
+            for (int j = 0; j < TN; ++j) split3(yb[j], bh[j], bm[j], bl[j]);
+#define EPN_X3_TERM(PA, PB)                                                                                 \
+    _Pragma("unroll") for (int i = 0; i < TM; ++i) _Pragma("unroll") for (int j = 0; j < TN; ++j)         \
+        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(PA[i], PB[j], acc[i][j], 0, 0, 0)
+            EPN_X3_TERM(ah, bl);                    // small terms first
+            EPN_X3_TERM(al, bh);
+            EPN_X3_TERM(am, bm);
+            EPN_X3_TERM(ah, bm);
+            EPN_X3_TERM(am, bh);
+            EPN_X3_TERM(ah, bh);
+#undef EPN_X3_TERM
+        }
+    }
+
+    // ---- epilogue: MFMA row ri of tile i = output row base1 + 32 i + ri; column li of tile j = base2 + TN*li + j
+    float *__restrict__ C = G.nsplit > 1 ? static_cast<float *>(G.part) + (size_t)split * G.N1 * G.N2
+                                         : static_cast<float *>(G.C);
+    const long long ldc = G.nsplit > 1 ? G.N2 : G.ldc;
+    if (n1_0 + BN1 <= G.N1 && n2_0 + BN2 <= G.N2 && (long long)BN1 * ldc < (1LL << 30)) {
+        float *__restrict__ cw = C + (size_t)(n1_0 + wm * TM * 32) * ldc + (n2_0 + wn * TN * 32);
+        const unsigned ld = (unsigned)ldc;
+        const unsigned lane_off = (unsigned)(4 * lj) * ld + TN * li;
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const unsigned o = lane_off + (unsigned)(32 * i + (r & 3) + 8 * (r >> 2)) * ld;
+#pragma unroll
+                for (int j = 0; j < TN; ++j) cw[o + j] = acc[i][j][r];
+            }
+        return;
+    }
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int n1 = n1_0 + wm * TM * 32 + 32 * i + (r & 3) + 8 * (r >> 2) + 4 * lj;
             const int n2 = n2_0 + wn * TN * 32 + TN * li;
             if (n1 < G.N1) {
 #pragma unroll
@@ -799,6 +974,8 @@ int launch_nt_typed(GemmNtBatch &B, hipStream_t st) {
 }
 
 constexpr int tn_waves(int wgm, int wgn, int, int, int) { return wgm * wgn; }
+// split form: single wide weight gradients take the pre-split planes kernel, narrow / grouped ones split in the kernel
+inline bool tn_planes_form(int nprob, int N2) { return nprob == 1 && N2 >= 512; }
 
 template <typename T>
 bool tn_fast_ok(const GemmTnArgs &G) {
@@ -818,7 +995,7 @@ size_t tn_plan(GemmTnBatch &B, int *bn1_out, int *bn2_out, void *ws, bool x3 = f
         min2 = B.p[i].N2 < min2 ? B.p[i].N2 : min2;
     }
     int bn1, bn2;
-    gemm_tn_tile(bf, max1, B.nprob > 1 && min2 < 256 ? 256 : min2, &bn1, &bn2);   // groups: the wide tiles
+    gemm_tn_tile(B.nprob > 1 && bf == 2 ? 0 : bf, max1, B.nprob > 1 && min2 < 256 ? 256 : min2, &bn1, &bn2);   // groups: the wide tiles
     *bn1_out = bn1; *bn2_out = bn2;
     long long tiles[GEMM_MAX_PROB], chunks[GEMM_MAX_PROB];
     for (int i = 0; i < B.nprob; ++i) {
@@ -862,6 +1039,13 @@ size_t tn_plan(GemmTnBatch &B, int *bn1_out, int *bn2_out, void *ws, bool x3 = f
         }
     }
     B.nblocks = blk;
+    for (int i = 0; i < B.nprob; ++i) B.p[i].Xp = nullptr;
+    if (x3 && tn_planes_form(B.nprob, B.p[0].N2)) {     // bf16 planes of the narrow operand: 6 bytes per value
+        GemmTnArgs &G = B.p[0];
+        // (a null workspace = size query: a non-null marker keeps the two passes on the same path)
+        G.Xp = ws ? static_cast<char *>(ws) + off : reinterpret_cast<const void *>(1);
+        off += ((size_t)6 * G.R * G.N1 + 255) & ~(size_t)255;
+    }
     return off;
 }
 
@@ -896,7 +1080,19 @@ int launch_tn_typed(GemmTnBatch &B, void *ws, size_t ws_bytes, hipStream_t st, b
         if (x3) hipLaunchKernelGGL((gemm_tn_f32_kernel<__VA_ARGS__, true>), grid, dim3(64 * tn_waves(__VA_ARGS__)), 0, st, B);  \
         else hipLaunchKernelGGL((gemm_tn_f32_kernel<__VA_ARGS__, false>), grid, dim3(64 * tn_waves(__VA_ARGS__)), 0, st, B);    \
     } while (0)
-        if (bn1 == 32) EPN_TN(1, 8, 1, 2, 32);
+#define EPN_TX(...) hipLaunchKernelGGL((gemm_tn_x3_kernel<__VA_ARGS__>), grid, dim3(64 * tn_waves(__VA_ARGS__)), 0, st, B)
+        if (x3 && B.p[0].Xp) {
+            const GemmTnArgs &G = B.p[0];               // the narrow operand's bf16 planes (workspace, after the slabs)
+            const long long n = (G.R >> 3) * G.N1;
+            hipLaunchKernelGGL(split_octets_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st,
+                               static_cast<const float *>(G.X), G.ldx, G.R, G.N1, static_cast<u32x4 *>(const_cast<void *>(G.Xp)));
+            EPN_CHECK_LAUNCH();
+            if (bn1 == 32) EPN_TX(1, 8, 1, 2, 32);
+            else if (bn1 == 64) EPN_TX(1, 8, 2, 2, 16);
+            else if (bn1 == 256) EPN_TX(2, 4, 4, 2, 16);
+            else EPN_TX(1, 8, 4, 2, 16);
+        }
+        else if (bn1 == 32) EPN_TN(1, 8, 1, 2, 32);
         else if (bn1 == 64 && bn2 == 64) EPN_TN(2, 2, 1, 1, 32);
         else if (bn1 == 64 && bn2 == 128) EPN_TN(2, 2, 1, 2, 32);
         else if (bn1 == 128 && bn2 == 64) EPN_TN(2, 2, 2, 1, 32);
@@ -906,6 +1102,7 @@ int launch_tn_typed(GemmTnBatch &B, void *ws, size_t ws_bytes, hipStream_t st, b
         else if (bn2 == 512) EPN_TN(1, 8, 4, 2, 32);
         else EPN_TN(2, 4, 2, 2, 32);
 #undef EPN_TN
+#undef EPN_TX
     } else {
         if (bn1 == 32) hipLaunchKernelGGL((gemm_tn_bf16_kernel<1, 4, 2, 4>), grid, dim3(256), 0, st, B);        // 4 waves: fewer,
         else if (bn1 == 64) hipLaunchKernelGGL((gemm_tn_bf16_kernel<1, 4, 4, 4>), grid, dim3(256), 0, st, B);   // larger wave tiles
@@ -943,9 +1140,13 @@ void gemm_tn_tile(int dtype, int N1, int N2, int *bn1, int *bn2) {   // dtype: 0
         // wide outputs (dW of the inter convolutions: N2 = cin*ks): 512-column tiles, 8 MFMAs per pair of LDS reads;
         // narrow ones (spectral blocks, 1x1 convolutions): 256-column tiles
         // narrow single problems (dW of the 1x1 convolutions: N2 = cin <= 128): 64- / 128-column tiles, 4 waves
-        // split form: both operands are split on the VALU (36 instructions per fragment): the 128 x 256 tile on eight
-        // waves (64 x 64 per wave, no spills) runs the wide weight gradients at 150 TFLOP/s, the 128 x 512 one at 137
-        if (dtype == 2 && N1 > 64 && N2 >= 512) { *bn1 = 128; *bn2 = 256; return; }
+        if (dtype == 2 && N2 >= 512) {   // split form, wide outputs (gemm_tn_x3_kernel): X planes + Y rows, two stages in LDS
+            if (N1 <= 32) { *bn1 = 32; *bn2 = 512; }
+            else if (N1 <= 64) { *bn1 = 64; *bn2 = 512; }
+            else if (N1 >= 256) { *bn1 = 256; *bn2 = 256; }     // X covered by one tile row: Y is streamed once
+            else { *bn1 = 128; *bn2 = 512; }
+            return;
+        }
         if (N1 <= 32) { *bn1 = 32; *bn2 = 512; }
         else if (N1 <= 64) { *bn1 = 64; *bn2 = N2 >= 512 ? 512 : (N2 > 128 ? 256 : (N2 > 64 ? 128 : 64)); }
         else { *bn1 = 128; *bn2 = N2 >= 512 ? 512 : (N2 > 128 ? 256 : (N2 > 64 ? 128 : 64)); }
@@ -1060,14 +1261,15 @@ extern "C" int epn_gemm_nt_bf16(int nprob, const epn_gemm_nt_problem *probs, int
 extern "C" size_t epn_gemm_tn_workspace_bytes(int bf16, long long R, int N1, int N2) {
     if (R < 1 || N1 < 1 || N2 < 1) return 0;
     const int s = gemm_tn_splits(bf16, R, N1, N2);
-    return s > 1 ? (((size_t)s * N1 * N2 * sizeof(float) + 255) & ~(size_t)255) : 0;
+    const size_t planes = bf16 == 2 && N2 >= 512 ? (((size_t)6 * R * N1 + 255) & ~(size_t)255) : 0;   // X's bf16 planes
+    return (s > 1 ? (((size_t)s * N1 * N2 * sizeof(float) + 255) & ~(size_t)255) : 0) + planes;
 }
 
 static int tn_entry(const void *X, long long ldx, const void *Y, long long ldy, float *C, long long ldc, long long R, int N1,
                     int N2, void *ws, size_t ws_bytes, int dtype, epn_stream_t stream) {
     GemmTnArgs G;
     G.X = X; G.Y = Y; G.C = C; G.part = ws; G.part_bytes = ws_bytes; G.R = R; G.N1 = N1; G.N2 = N2;
-    G.ldx = ldx; G.ldy = ldy; G.ldc = ldc; G.ntiles = 0; G.tiles_n2 = 0; G.nsplit = 1; G.block0 = 0;
+    G.ldx = ldx; G.ldy = ldy; G.ldc = ldc; G.ntiles = 0; G.tiles_n2 = 0; G.nsplit = 1; G.block0 = 0; G.Xp = nullptr;
     return launch_gemm_tn(G, dtype, epn_stream(stream));
 }
 extern "C" int epn_gemm_tn_f32(const float *X, long long ldx, const float *Y, long long ldy, float *C, long long ldc,
@@ -1089,7 +1291,7 @@ static void tn_fill(GemmTnBatch &B, int nprob, const epn_gemm_tn_problem *probs)
         GemmTnArgs &G = B.p[i];
         const epn_gemm_tn_problem &q = probs[i];
         G.X = q.X; G.Y = q.Y; G.C = q.C; G.part = nullptr; G.part_bytes = 0; G.R = q.R; G.N1 = q.N1; G.N2 = q.N2;
-        G.ldx = q.ldx; G.ldy = q.ldy; G.ldc = q.ldc; G.ntiles = 0; G.tiles_n2 = 0; G.nsplit = 1; G.block0 = 0;
+        G.ldx = q.ldx; G.ldy = q.ldy; G.ldc = q.ldc; G.ntiles = 0; G.tiles_n2 = 0; G.nsplit = 1; G.block0 = 0; G.Xp = nullptr;
     }
 }
 extern "C" size_t epn_gemm_tn_grouped_workspace_bytes(int bf16, int nprob, const epn_gemm_tn_problem *probs) {

@@ -35,8 +35,9 @@ def main():
         X = torch.randn(R, N1, device=dev) * torch.exp(torch.randn(1, N1, device=dev))
         Y = torch.randn(R, N2, device=dev)
         ref = X[:, :32].double().t() @ Y[:, :256].double()
-        for mode in ("native", "split"):
-            gemm.set_fp32_mode(mode)
+        for mode in ("native", "split", "split:0x301", "split:0x302", "split:0x303"):
+            gemm.set_fp32_mode(mode.split(":")[0])
+            _lib.check(_lib.get_lib().epn_set_kernel_policy(int(mode.split(":")[1], 0) if ":" in mode else 0), "policy")
             C = gemm.gemm_tn(X, Y)
             d = C[:32, :256].double() - ref
             err = (d.abs().max() / ref.abs().max()).item()
@@ -44,6 +45,7 @@ def main():
             t = timeit(lambda: gemm.gemm_tn(X, Y, out=C))
             print(f"TN {R}x{N1}x{N2} {mode}: {t:.3f} ms {2.0 * R * N1 * N2 / t / 1e9:.1f} TF  max {err:.2e} rms {rms:.2e}", flush=True)
         del X, Y, C, ref
+    _lib.get_lib().epn_set_kernel_policy(0)
     gemm.set_fp32_mode("native")
 
 
