@@ -380,8 +380,10 @@ def main():
                 n2 = 256
             w2 = 512 if n2 >= 512 else (256 if n2 > 128 else (128 if n2 > 64 else 64))
             x3 = "true" if split_gemm else "false"
-            if split_gemm and n1 > 64 and n2 >= 512:
-                return "epn::gemm_tn_f32_kernel<2, 4, 2, 2, 32, true>"
+            if split_gemm and not grouped and n2 >= 512:       # wide single problems: pre-split planes kernel
+                cfg = "1, 8, 1, 2, 32" if n1 <= 32 else ("1, 8, 2, 2, 16" if n1 <= 64 else
+                                                           ("2, 4, 4, 2, 16" if n1 >= 256 else "1, 8, 4, 2, 16"))
+                return f"epn::gemm_tn_x3_kernel<{cfg}>"
             if n1 <= 32:
                 cfg = "1, 8, 1, 2, 32"
             elif n1 <= 64:
@@ -423,7 +425,7 @@ def main():
         def roof(k):
             d = agg[k]
             ach = d["flops"] / (d["ms"] * 1e-3) / 1e12
-            if "_x3_" in k or k.endswith("true>"):
+            if "_x3_" in k or k.endswith("true>"):         # gemm_nt_x3 / gemm_tn_x3 / gemm_tn_f32<..., true>
                 # split form: every fp32 multiply-add is six bf16 MFMA multiply-adds (fp32 accumulate); the roof is the
                 # bf16 matrix pipe and `achieved` the flops it EXECUTES; the fp32-equivalent rate is reported beside it
                 return {"bound": "mfma", "kernel": k, "achieved": round(6 * ach, 1), "peak": PEAK_TFLOPS["bf16"],

@@ -14,7 +14,7 @@ static bool force_generic() { return g_policy.load(std::memory_order_relaxed) ==
 namespace epn { int kernel_policy() { return g_policy.load(std::memory_order_relaxed); } }
 
 extern "C" int epn_set_kernel_policy(int policy) {
-    if (policy != 0 && policy != 1 && (policy & ~0xff) != 0x100 && (policy & ~0xff) != 0x200 && (policy & ~0xff) != 0x300 && (policy & ~0xff) != 0x400) return EPN_EINVAL;   // 0x100 | cfg: tools/gemm_bench.py
+    if (policy != 0 && policy != 1 && (policy & ~0xff) != 0x100 && (policy & ~0xff) != 0x200 && (policy & ~0xff) != 0x400) return EPN_EINVAL;   // 0x100 | cfg: tools/gemm_bench.py
     g_policy.store(policy, std::memory_order_relaxed);
     return 0;
 }
