@@ -408,6 +408,9 @@ def main():
                 return nt_name([d_ * cio[1] for d_ in (1, 3, 3, 4, 5)], cio[0])
             if kind == "conv1x1_gemm":
                 return nt_name([key[2]], key[3], key[1])
+            if kind == "so3_basis":
+                return ("epn::so3_basis_x3_kernel" if split_gemm else
+                        ("epn::so3_basis_bf16_kernel" if dtype_name == "bf16" else "epn::so3_basis_kernel"))
             return KERNEL_OF.get(kind, kind)
 
         agg = {}

@@ -27,7 +27,7 @@ EXPORTS = [
     "epn_transpose_cast", "epn_cast", "epn_gemm_tn_grouped_workspace_bytes", "epn_gemm_tn_grouped",
     "epn_inter_group_bf16", "epn_inter_ungroup_bf16", "epn_intra_group_bf16", "epn_so3_basis_bf16",
     "epn_gather_rows", "epn_scatter_rows", "epn_conv1x1_c1_f32", "epn_conv1x1_c1_bwd_weight_f32",
-    "epn_ball_query_f64", "epn_fps_f64", "epn_gather_fwd_f64", "epn_gather_bwd_f64", "epn_so3_basis_norm_f32", "epn_so3_basis_norm_bf16", "epn_inter_inverse_list", "epn_inter_ungroup_det_f32", "epn_inter_ungroup_det_bf16",
+    "epn_ball_query_f64", "epn_fps_f64", "epn_gather_fwd_f64", "epn_gather_bwd_f64", "epn_so3_basis_norm_f32", "epn_so3_basis_norm_bf16", "epn_so3_basis_split_f32", "epn_so3_basis_norm_split_f32", "epn_inter_inverse_list", "epn_inter_ungroup_det_f32", "epn_inter_ungroup_det_bf16",
     "epn_chan_stats_bf16", "epn_norm_act_fwd_bf16", "epn_norm_act_bwd_reduce_bf16", "epn_norm_act_bwd_apply_bf16",
 ]
 
@@ -100,6 +100,8 @@ def get_lib():
     lib.epn_so3_basis_norm_f32.argtypes = [_vp, _vp, _vp, ctypes.c_longlong, _ci, _ci, _ci, _vp, _vp, _ci, ctypes.c_longlong,
                                            _vp, _vp, _cf, _cf, _vp]
     lib.epn_so3_basis_norm_bf16.argtypes = lib.epn_so3_basis_norm_f32.argtypes
+    lib.epn_so3_basis_norm_split_f32.argtypes = lib.epn_so3_basis_norm_f32.argtypes
+    lib.epn_so3_basis_split_f32.argtypes = lib.epn_so3_basis_f32.argtypes
     lib.epn_inter_is_fused.argtypes = [dp]
     lib.epn_inter_is_fused.restype = _ci
     lib.epn_intra_is_fused.argtypes = [_ci, _ci, _ci, _ci]

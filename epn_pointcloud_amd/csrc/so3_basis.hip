@@ -260,6 +260,132 @@ __global__ __launch_bounds__(64 * SB_WAVES) void so3_basis_bf16_kernel(SbArgs A)
     }
 }
 
+// fp32 feature storage, split form (see gemm_x3.hip): M in three bf16 planes in LDS, the input rows split without loss
+// into three bf16 pieces in registers, six v_mfma_f32_16x16x32_bf16 per (M tile, channel tile, 32 rows) -- 192 MFMAs of
+// 16 cycles per task instead of 240 fp32 ones of 32: the transform leaves the matrix pipe as the bound of this
+// HBM-streaming kernel.  fp32 in, fp32 out, fp32 accuracy (the dropped piece products are < 2^-24 of |M||x|).
+typedef unsigned sbu32x4s __attribute__((ext_vector_type(4)));
+typedef __bf16 sbf16x2 __attribute__((ext_vector_type(2)));
+typedef float sbf32x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ unsigned sb_pack(float a, float b) {   // v_cvt_pk_bf16_f32
+    const sbf32x2 v = {a, b};
+    return __builtin_bit_cast(unsigned, __builtin_convertvector(v, sbf16x2));
+}
+__device__ __forceinline__ void sb_split3(const float (&x)[8], sbf16x8 &h, sbf16x8 &m, sbf16x8 &l) {
+    sbu32x4s H, M, L;
+#pragma unroll
+    for (int p = 0; p < 4; ++p) {
+        const unsigned hp = sb_pack(x[2 * p], x[2 * p + 1]);
+        const float r0 = x[2 * p] - __builtin_bit_cast(float, hp << 16);
+        const float r1 = x[2 * p + 1] - __builtin_bit_cast(float, hp & 0xffff0000u);
+        const unsigned mp = sb_pack(r0, r1);
+        H[p] = hp; M[p] = mp;
+        L[p] = sb_pack(r0 - __builtin_bit_cast(float, mp << 16), r1 - __builtin_bit_cast(float, mp & 0xffff0000u));
+    }
+    h = __builtin_bit_cast(sbf16x8, H); m = __builtin_bit_cast(sbf16x8, M); l = __builtin_bit_cast(sbf16x8, L);
+}
+
+__global__ __launch_bounds__(64 * SB_WAVES) __attribute__((amdgpu_waves_per_eu(2, 2))) void so3_basis_x3_kernel(SbArgs A) {
+    __shared__ __attribute__((aligned(16))) __bf16 Mp[3][64 * SBH_LD];
+    __shared__ int bs[64], d2s[64];
+    for (int i = threadIdx.x; i < 64 * 64; i += blockDim.x) {
+        const int r = i >> 6, q = i & 63;
+        const float v = (r < A.na && q < A.na) ? A.M[r * A.na + q] : 0.0f;
+        const __bf16 hi = (__bf16)v;
+        const float r1 = v - (float)hi;
+        const __bf16 mid = (__bf16)r1;
+        Mp[0][r * SBH_LD + q] = hi;
+        Mp[1][r * SBH_LD + q] = mid;
+        Mp[2][r * SBH_LD + q] = (__bf16)(r1 - (float)mid);
+    }
+    if (threadIdx.x < 64) {
+        const int f = threadIdx.x < A.na ? threadIdx.x : 0;
+        bs[threadIdx.x] = A.blk[2 * f];
+        d2s[threadIdx.x] = A.blk[2 * f + 1];
+    }
+    __syncthreads();
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int x = lane & 15, j = lane >> 4;
+    const int ncb = A.c >> 6;
+    const float *in = static_cast<const float *>(A.in);
+    float *out = static_cast<float *>(A.out);
+    for (int it = 0; it < SB_TPW; ++it) {
+        const long long task = ((long long)blockIdx.x * SB_WAVES + wave) * SB_TPW + it;
+        if (task >= A.pts * ncb) return;
+        const long long pt = task / ncb;
+        const int cb = (int)(task - pt * ncb);
+        const int choff = 64 * cb + 4 * x;
+        auto row_addr = [&](int spec, int r) -> size_t {
+            if (spec) return ((size_t)bs[r] * A.pts + (size_t)pt * d2s[r] + (r - bs[r])) * A.c + choff;
+            return ((size_t)pt * A.na + r) * A.c + choff;
+        };
+        f32x4 raw[2][8];          // row 32 ks + 8 j + e, channels 4x .. 4x+3
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                const int r = 32 * ks + 8 * j + e;
+                raw[ks][e] = r < A.na ? sb_ld(in + row_addr(A.in_spec, r)) : f32x4{0.f, 0.f, 0.f, 0.f};
+            }
+        if (A.nsums) {
+            SbNorm N;
+            sb_norm_load(A, pt, choff, N);
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+                for (int e = 0; e < 8; ++e)
+                    if (32 * ks + 8 * j + e < A.na) {
+#pragma unroll
+                        for (int i = 0; i < 4; ++i) raw[ks][e][i] = sb_norm1(N, i, raw[ks][e][i]);
+                    }
+        }
+        f32x4 acc[4][4];
+#pragma unroll
+        for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+            for (int nt = 0; nt < 4; ++nt) acc[mt][nt] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            sbf16x8 bh[4], bm[4], bl[4];
+#pragma unroll
+            for (int nt = 0; nt < 4; ++nt) {
+                const float v[8] = {raw[ks][0][nt], raw[ks][1][nt], raw[ks][2][nt], raw[ks][3][nt],
+                                    raw[ks][4][nt], raw[ks][5][nt], raw[ks][6][nt], raw[ks][7][nt]};
+                sb_split3(v, bh[nt], bm[nt], bl[nt]);
+            }
+#pragma unroll
+            for (int mt = 0; mt < 4; ++mt) {
+                const int ao = (16 * mt + x) * SBH_LD + 32 * ks + 8 * j;
+                const sbf16x8 ah = *reinterpret_cast<const sbf16x8 *>(&Mp[0][ao]);
+                const sbf16x8 am = *reinterpret_cast<const sbf16x8 *>(&Mp[1][ao]);
+                const sbf16x8 al = *reinterpret_cast<const sbf16x8 *>(&Mp[2][ao]);
+#define EPN_SB_TERM(PA, PB)                                                                                  \
+    _Pragma("unroll") for (int nt = 0; nt < 4; ++nt)                                                        \
+        acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(PA, PB[nt], acc[mt][nt], 0, 0, 0)
+                EPN_SB_TERM(ah, bl);
+                EPN_SB_TERM(al, bh);
+                EPN_SB_TERM(am, bm);
+                EPN_SB_TERM(ah, bm);
+                EPN_SB_TERM(am, bh);
+                EPN_SB_TERM(ah, bh);
+#undef EPN_SB_TERM
+            }
+        }
+        // acc[mt][nt][rr]: output row 16 mt + 4 j + rr, channel 4 x + nt
+#pragma unroll
+        for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+            for (int rr = 0; rr < 4; ++rr) {
+                const int r = 16 * mt + 4 * j + rr;
+                if (r < A.na) {
+                    const f32x4 v = {acc[mt][0][rr], acc[mt][1][rr], acc[mt][2][rr], acc[mt][3][rr]};
+                    sb_st(out + row_addr(A.out_spec, r), v);
+                }
+            }
+    }
+}
+
 }  // namespace
 }  // namespace epn
 
@@ -294,7 +420,8 @@ static int so3_basis_any(const void *in, const float *M, const int32_t *blocks, 
     const long long tasks = pts * (c >> 6);
     const long long per_wg = (long long)SB_WAVES * SB_TPW;
     const dim3 grid((unsigned)((tasks + per_wg - 1) / per_wg));
-    if (bf16) hipLaunchKernelGGL(so3_basis_bf16_kernel, grid, dim3(64 * SB_WAVES), 0, epn_stream(stream), A);
+    if (bf16 == 1) hipLaunchKernelGGL(so3_basis_bf16_kernel, grid, dim3(64 * SB_WAVES), 0, epn_stream(stream), A);
+    else if (bf16 == 2) hipLaunchKernelGGL(so3_basis_x3_kernel, grid, dim3(64 * SB_WAVES), 0, epn_stream(stream), A);   // fp32, split form
     else hipLaunchKernelGGL(so3_basis_kernel<float>, grid, dim3(64 * SB_WAVES), 0, epn_stream(stream), A);
     EPN_CHECK_LAUNCH();
     return 0;
@@ -303,6 +430,10 @@ static int so3_basis_any(const void *in, const float *M, const int32_t *blocks, 
 extern "C" int epn_so3_basis_f32(const float *in, const float *M, const int32_t *blocks, long long pts, int na, int c,
                                  int in_spectral, int out_spectral, float *out, epn_stream_t stream) {
     return so3_basis_any(in, M, blocks, pts, na, c, in_spectral, out_spectral, out, 0, stream);
+}
+extern "C" int epn_so3_basis_split_f32(const float *in, const float *M, const int32_t *blocks, long long pts, int na, int c,
+                                       int in_spectral, int out_spectral, float *out, epn_stream_t stream) {
+    return so3_basis_any(in, M, blocks, pts, na, c, in_spectral, out_spectral, out, 2, stream);
 }
 extern "C" int epn_so3_basis_bf16(const void *in, const float *M, const int32_t *blocks, long long pts, int na, int c,
                                   int in_spectral, int out_spectral, void *out, epn_stream_t stream) {
@@ -316,6 +447,13 @@ extern "C" int epn_so3_basis_norm_f32(const float *in, const float *M, const int
                                       const float *gamma, const float *beta, float eps, float slope, epn_stream_t stream) {
     const SbNormHost nh = {sums, gamma, beta, groups, pts_per_group, eps, slope};
     return so3_basis_any(in, M, blocks, pts, na, c, 0, out_spectral, out, 0, stream, &nh);
+}
+extern "C" int epn_so3_basis_norm_split_f32(const float *in, const float *M, const int32_t *blocks, long long pts, int na,
+                                            int c, int out_spectral, float *out, const float *sums, int groups,
+                                            long long pts_per_group, const float *gamma, const float *beta, float eps,
+                                            float slope, epn_stream_t stream) {
+    const SbNormHost nh = {sums, gamma, beta, groups, pts_per_group, eps, slope};
+    return so3_basis_any(in, M, blocks, pts, na, c, 0, out_spectral, out, 2, stream, &nh);
 }
 extern "C" int epn_so3_basis_norm_bf16(const void *in, const float *M, const int32_t *blocks, long long pts, int na, int c,
                                        int out_spectral, void *out, const float *sums, int groups, long long pts_per_group,

@@ -74,7 +74,10 @@ def empty_cl(b, c, p, a, device, dtype=torch.float32):
 
 
 def _entry(lib, base, dtype):
-    """C entry point of `base` for a feature dtype: epn_<base>_f32 | epn_<base>_bf16."""
+    """C entry point of `base` for a feature dtype: epn_<base>_f32 | epn_<base>_bf16; the fp32 change of basis has a
+    split form (bf16 matrix pipe, fp32 accuracy) that follows the GEMMs' switch (gemm.FP32_MODE)."""
+    if dtype != torch.bfloat16 and base in ("so3_basis", "so3_basis_norm") and gemm.FP32_MODE == "split":
+        return getattr(lib, f"epn_{base}_split_f32")
     return getattr(lib, f"epn_{base}_{'bf16' if dtype == torch.bfloat16 else 'f32'}")
 
 

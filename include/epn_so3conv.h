@@ -362,6 +362,13 @@ int epn_so3_basis_norm_f32(const float *in, const float *M, const int32_t *block
 int epn_so3_basis_norm_bf16(const void *in, const float *M, const int32_t *blocks, long long pts, int na, int c,
                             int out_spectral, void *out, const float *sums, int groups, long long pts_per_group,
                             const float *gamma, const float *beta, float eps, float slope, epn_stream_t stream);
+/* fp32 in / fp32 out on the bf16 matrix pipe (split form, see epn_gemm_nt_split_f32): M and the input rows are split
+ * without loss into three bf16 pieces, six piece products per multiply, fp32 accumulation */
+int epn_so3_basis_split_f32(const float *in, const float *M, const int32_t *blocks, long long pts, int na, int c,
+                            int in_spectral, int out_spectral, float *out, epn_stream_t stream);
+int epn_so3_basis_norm_split_f32(const float *in, const float *M, const int32_t *blocks, long long pts, int na, int c,
+                                 int out_spectral, float *out, const float *sums, int groups, long long pts_per_group,
+                                 const float *gamma, const float *beta, float eps, float slope, epn_stream_t stream);
 int epn_chan_stats_bf16(const void *x_cl, int groups, long long rows, int c, float *sums, void *workspace,
                         size_t workspace_bytes, epn_stream_t stream);
 int epn_norm_act_fwd_bf16(const void *x_cl, int groups, long long rows, int c, const float *sums, const float *gamma,
