@@ -262,7 +262,11 @@ static int inter_ungroup_det_any(const epn_inter_desc *d, const void *grad_group
     if (slab_bytes < need) return EPN_EWORKSPACE;
     rc = launch_inter_tables_mfma(d, base + ws.rk_off, base + ws.rk4_off, base + ws.beta_off, st);
     if (rc) return rc;
-    return launch_inter_ungroup_det_mfma(d, base + ws.rk4_off, grad_grouped, grad_feats_cl, slab, offsets, entries, bf16, st);
+    // room behind the slab for one byte per (point, neighbour slot): the pre-reduced form (a third of the slab traffic)
+    const size_t flags = (size_t)d->b * d->p2 * d->nn;
+    unsigned char *canon = slab_bytes >= ((need + 255) & ~(size_t)255) + flags ? static_cast<unsigned char *>(slab) + ((need + 255) & ~(size_t)255) : nullptr;
+    return launch_inter_ungroup_det_mfma(d, base + ws.rk4_off, grad_grouped, grad_feats_cl, slab, offsets, entries, bf16, st,
+                                         reinterpret_cast<int32_t *>(base + ws.order_off), canon);
 }
 extern "C" int epn_inter_ungroup_det_f32(const epn_inter_desc *d, const float *grad_grouped, float *grad_feats_cl,
                                          const int32_t *offsets, const int32_t *entries, void *slab, size_t slab_bytes,

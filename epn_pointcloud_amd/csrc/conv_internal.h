@@ -77,7 +77,8 @@ int launch_inter_ungroup_mfma(const epn_inter_desc *d, const float *rk4, const v
 // deterministic (atomic-free) data gradient of the grouping: inverse neighbour list + per-slot slab + ordered reduction
 int launch_inverse_list(const int32_t *idx, int b, int p1, int p2, int nn, int32_t *off, int32_t *ent, hipStream_t st);
 int launch_inter_ungroup_det_mfma(const epn_inter_desc *d, const float *rk4, const void *dG, void *dF, void *slab,
-                                  const int32_t *off, const int32_t *ent, int bf16, hipStream_t st);
+                                  const int32_t *off, const int32_t *ent, int bf16, hipStream_t st,
+                                  int32_t *order = nullptr, unsigned char *canon = nullptr);
 bool intra_uses_mfma(int na, int kn, int cin, int cout);
 size_t intra_workspace_floats(int kn, int cin, int cout);
 int launch_intra_fwd_mfma(const float *feats, const int32_t *iidx, const float *W, int b, int p, int na, int kn,

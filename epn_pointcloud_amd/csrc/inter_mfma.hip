@@ -1255,8 +1255,13 @@ __global__ __launch_bounds__(1024) void morton_order_kernel(const float *__restr
 // tile is double-buffered over anchors: one barrier per column.  (ds_add_f32 into a shared accumulator was measured at
 // ~1 lane per clock on gfx950 -- 2x slower than the global atomics it replaced; hence stores + a gather-sum.)
 constexpr int USH_TAB = 4096;   // destinations are de-duplicated through a direct-address table: p1 <= USH_TAB
-template <int NT, int KT, typename TG, int GP, int NB = 2>   // NB tile buffers: 2 = one barrier per column, 1 = two (half the LDS)
-__global__ __launch_bounds__(64 * GP) void inter_ungroup_shared_kernel(InterArgs A, const int32_t *__restrict__ order) {
+// DET: atomic-free, bitwise repeatable.  The slots of a destination are summed in ascending slot order and the sum is
+// STORED to the slab row of the destination's first slot (slab[b][p][n][a][c], as inter_ungroup_slots_kernel's, but
+// only ~1/3 of its rows are written); `canon` marks those rows for inter_reduce_slots_kernel, which adds them per
+// destination in the fixed order of the inverse neighbour list.
+template <int NT, int KT, typename TG, int GP, int NB = 2, bool DET = false>   // NB tile buffers: 2 = one barrier per column, 1 = two (half the LDS)
+__global__ __launch_bounds__(64 * GP) void inter_ungroup_shared_kernel(InterArgs A, const int32_t *__restrict__ order,
+                                                                       unsigned char *__restrict__ canon = nullptr) {
     constexpr int EW = 16 * NT;        // neighbour slots per point (padded)
     constexpr int E = GP * EW;         // slots of the workgroup (128 or 256)
     constexpr int SS = 20;             // floats per slot row: 16 channels + 4 (rows 4 apart fall on distinct banks)
@@ -1368,6 +1373,32 @@ __global__ __launch_bounds__(64 * GP) void inter_ungroup_shared_kernel(InterArgs
     for (int k = 0; k < EPT; ++k)
         if (myq[k] >= 0) list[off[slot_of[tid + k * NTH]] + myr[k]] = tid + k * NTH;
     __syncthreads();                            // also: tab (aliasing Tb) is dead from here on
+    if constexpr (DET) {
+        __shared__ int wpp[GP];
+        if (lane == 0) wpp[wave] = pp;
+        for (int u = tid; u < U; u += NTH) {    // ascending slot order per destination: a fixed summation order
+            const int k0 = off[u], k1 = off[u + 1];
+            for (int k = k0 + 1; k < k1; ++k) {
+                const int v = list[k];
+                int m = k - 1;
+                while (m >= k0 && list[m] > v) { list[m + 1] = list[m]; --m; }
+                list[m + 1] = v;
+            }
+        }
+        __syncthreads();
+        // cnt[] (dead) <- slab row of each distinct destination = (point, neighbour slot) of its first slot
+        for (int u = tid; u < U; u += NTH) {
+            const int e0 = list[off[u]];
+            cnt[u] = ((bb * A.p2 + wpp[e0 / EW]) * A.nn + (e0 % EW));
+        }
+        if (blockIdx.y == 0)
+            for (int e = tid; e < E; e += NTH) {
+                const int n = e % EW;
+                if (n < A.nn)
+                    canon[((size_t)bb * A.p2 + wpp[e / EW]) * A.nn + n] = (qlist[e] >= 0 && list[off[slot_of[e]]] == e) ? 1 : 0;
+            }
+        __syncthreads();
+    }
 
     float gB[NT], alphaN[NT];
 #pragma unroll
@@ -1424,7 +1455,12 @@ __global__ __launch_bounds__(64 * GP) void inter_ungroup_shared_kernel(InterArgs
             float sum = 0.0f;
             const int k1 = off[u + 1];
             for (int k = off[u]; k < k1; ++k) sum += rb[list[k] * SS + c];
-            atomicAdd(dcloud + ((size_t)uq[u] * A.na + a) * A.cin + c, sum);
+            if constexpr (DET) {
+                TG *srow = reinterpret_cast<TG *>(A.out) + ((size_t)cnt[u] * A.na + a) * A.cin + 16 * ct + c;
+                if constexpr (sizeof(TG) == 2) *srow = (__bf16)sum; else *srow = sum;
+            } else {
+                atomicAdd(dcloud + ((size_t)uq[u] * A.na + a) * A.cin + c, sum);
+            }
         }
         if constexpr (NB == 1) __syncthreads();
     }
@@ -1505,12 +1541,79 @@ __global__ __launch_bounds__(1024) void inverse_list_kernel(const int32_t *__res
     if (tid == 0) o[p1] = base_total;
 }
 
+// The same list for clouds whose entries fit the LDS (p2*nn <= 32768, p1 <= 4096: every ModelNet / rotation layer): count
+// per destination with LDS atomics, scan, fill in arrival order, then sort every destination's short segment -- the
+// result is the same increasing (p, n) order whatever the arrival order was.  ~40 us instead of ~500 (the scanning
+// kernel above compares every destination with every entry).
+constexpr int INV_LDS_ENT = 32768, INV_LDS_P1 = 4096;
+__global__ __launch_bounds__(1024) void inverse_list_lds_kernel(const int32_t *__restrict__ idx, int p1, int entries,
+                                                                int32_t *__restrict__ off, int32_t *__restrict__ ent) {
+    __shared__ int32_t lst[INV_LDS_ENT];
+    __shared__ int cur[INV_LDS_P1];
+    __shared__ int wsum[16];
+    const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int32_t *row = idx + (size_t)b * entries;
+    int32_t *o = off + (size_t)b * (p1 + 1);
+    int32_t *e = ent + (size_t)b * entries;
+    for (int q = tid; q < p1; q += 1024) cur[q] = 0;
+    __syncthreads();
+    for (int i = tid; i < entries; i += 1024) {
+        const int q = row[i];
+        if (q >= 0 && q < p1) atomicAdd(&cur[q], 1);
+    }
+    __syncthreads();
+    // exclusive scan: four consecutive destinations per thread
+    int c[4], sum = 0;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const int q = 4 * tid + k;
+        c[k] = q < p1 ? cur[q] : 0;
+        sum += c[k];
+    }
+    int incl = sum;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        const int v = __shfl_up(incl, d, 64);
+        incl += lane >= d ? v : 0;
+    }
+    if (lane == 63) wsum[wave] = incl;
+    __syncthreads();
+    int start = incl - sum;
+    for (int w = 0; w < wave; ++w) start += wsum[w];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const int q = 4 * tid + k;
+        if (q < p1) { o[q] = start; cur[q] = start; }
+        start += c[k];
+    }
+    if (tid == 1023) o[p1] = start;
+    __syncthreads();
+    for (int i = tid; i < entries; i += 1024) {
+        const int q = row[i];
+        if (q >= 0 && q < p1) lst[atomicAdd(&cur[q], 1)] = i;
+    }
+    __syncthreads();                            // cur[q] = end of segment q = start of segment q + 1
+    for (int q = tid; q < p1; q += 1024) {
+        const int k0 = q ? cur[q - 1] : 0, k1 = cur[q];
+        for (int k = k0 + 1; k < k1; ++k) {
+            const int v = lst[k];
+            int m = k - 1;
+            while (m >= k0 && lst[m] > v) { lst[m + 1] = lst[m]; --m; }
+            lst[m + 1] = v;
+        }
+    }
+    __syncthreads();
+    const int total = cur[p1 - 1];
+    for (int i = tid; i < total; i += 1024) e[i] = lst[i];
+}
+
 // Step 2: dF[b][q][a][c] = sum over the inverse list of q, in list order, of slab[b][entry][a][c]; fp32 accumulation,
 // output in TO.  One thread per 4 consecutive (a, c) elements of one destination row: fully coalesced slab reads.
 template <typename TG, typename TO>
 __global__ __launch_bounds__(256) void inter_reduce_slots_kernel(const TG *__restrict__ slab, const int32_t *__restrict__ off,
                                                                  const int32_t *__restrict__ ent, TO *__restrict__ dF,
-                                                                 int b, int p1, int entries, int rowlen) {
+                                                                 int b, int p1, int entries, int rowlen,
+                                                                 const unsigned char *__restrict__ canon = nullptr) {
     const int v4 = rowlen >> 2;
     const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= (long long)b * p1 * v4) return;
@@ -1522,7 +1625,9 @@ __global__ __launch_bounds__(256) void inter_reduce_slots_kernel(const TG *__res
     const TG *sl = slab + (size_t)bb * entries * rowlen + 4 * c4;
     f32x4 acc = {0.f, 0.f, 0.f, 0.f};
     const int e1 = o[q + 1];
+    const unsigned char *cf = canon ? canon + (size_t)bb * entries : nullptr;
     for (int k = o[q]; k < e1; ++k) {
+        if (cf && !cf[e[k]]) continue;          // pre-reduced slab: only the marked rows were written
         const f32x4 v = ld4f(sl + (size_t)e[k] * rowlen);
         acc[0] += v[0]; acc[1] += v[1]; acc[2] += v[2]; acc[3] += v[3];
     }
@@ -1784,16 +1889,67 @@ int launch_inter_group_mfma(const epn_inter_desc *d, const float *rk4, const voi
 }
 
 int launch_inverse_list(const int32_t *idx, int b, int p1, int p2, int nn, int32_t *off, int32_t *ent, hipStream_t st) {
-    hipLaunchKernelGGL(inverse_list_kernel, dim3(b), dim3(1024), 0, st, idx, p1, p2 * nn, off, ent);
+    if ((long long)p2 * nn <= INV_LDS_ENT && p1 <= INV_LDS_P1)
+        hipLaunchKernelGGL(inverse_list_lds_kernel, dim3(b), dim3(1024), 0, st, idx, p1, p2 * nn, off, ent);
+    else
+        hipLaunchKernelGGL(inverse_list_kernel, dim3(b), dim3(1024), 0, st, idx, p1, p2 * nn, off, ent);
     EPN_CHECK_LAUNCH();
     return 0;
 }
 
 // deterministic data gradient: slab (element type = dG's) <- per-slot contributions, then the ordered reduction
+// output points per workgroup of the LDS-reduced scatter (see launch_inter_ungroup_mfma)
+static int ungroup_group_points(const epn_inter_desc *d, int nt) {
+    return nt <= 1 ? 8 : (nt <= 2 ? (d->p2 % 16 == 0 ? 16 : 8) : (nt <= 4 ? (d->p2 % 8 == 0 ? 8 : 4) : 2));
+}
+
 int launch_inter_ungroup_det_mfma(const epn_inter_desc *d, const float *rk4, const void *dG, void *dF, void *slab,
-                                  const int32_t *off, const int32_t *ent, int bf16, hipStream_t st) {
+                                  const int32_t *off, const int32_t *ent, int bf16, hipStream_t st, int32_t *order,
+                                  unsigned char *canon) {
     InterArgs A = make_args(d, rk4);
     A.gout = static_cast<const float *>(dG); A.out = static_cast<float *>(slab);
+    const int rowlen = d->na * d->cin, entries = d->p2 * d->nn;
+    const long long nred = (long long)d->b * d->p1 * (rowlen >> 2);
+    const dim3 g2((unsigned)((nred + 255) / 256));
+    {
+        // pre-reduced form: the LDS-reduced scatter (inter_ungroup_shared_kernel, DET) stores one row per (workgroup,
+        // distinct destination) -- about a third of the per-slot slab -- and the ordered reduction skips the rest
+        const int nt = (d->nn + 15) / 16;
+        const int gp = ungroup_group_points(d, nt);
+        if (order && canon && d->p2 % gp == 0 && d->p2 <= MORTON_MAX && d->p1 <= USH_TAB) {
+            hipLaunchKernelGGL(morton_order_kernel, dim3(d->b), dim3(1024), 0, st, d->new_xyz, d->p2, order);
+            EPN_CHECK_LAUNCH();
+            A.col_tiles_per_wg = 1;
+            const dim3 grid((unsigned)(d->b * (d->p2 / gp)), (unsigned)(d->cin >> 4));
+#define EPN_USHD(NT_, KT_, GP_)                                                                                           \
+    do {                                                                                                                  \
+        if (bf16) hipLaunchKernelGGL((inter_ungroup_shared_kernel<NT_, KT_, __bf16, GP_, ((NT_ == 1 && GP_ == 8) ? 2 : 1), true>), grid, dim3(64 * GP_), 0, st, A, order, canon); \
+        else hipLaunchKernelGGL((inter_ungroup_shared_kernel<NT_, KT_, float, GP_, ((NT_ == 1 && GP_ == 8) ? 2 : 1), true>), grid, dim3(64 * GP_), 0, st, A, order, canon);      \
+    } while (0)
+            const int kt = (d->ks + 15) / 16;
+            if (kt == 1) {
+                if (nt <= 1) EPN_USHD(1, 1, 8);
+                else if (nt <= 2) { if (gp == 16) EPN_USHD(2, 1, 16); else EPN_USHD(2, 1, 8); }
+                else if (nt <= 4) { if (gp == 8) EPN_USHD(4, 1, 8); else EPN_USHD(4, 1, 4); }
+                else EPN_USHD(8, 1, 2);
+            } else {
+                if (nt <= 1) EPN_USHD(1, 2, 8);
+                else if (nt <= 2) { if (gp == 16) EPN_USHD(2, 2, 16); else EPN_USHD(2, 2, 8); }
+                else if (nt <= 4) { if (gp == 8) EPN_USHD(4, 2, 8); else EPN_USHD(4, 2, 4); }
+                else EPN_USHD(8, 2, 2);
+            }
+#undef EPN_USHD
+            EPN_CHECK_LAUNCH();
+            if (bf16)
+                hipLaunchKernelGGL((inter_reduce_slots_kernel<__bf16, __bf16>), g2, dim3(256), 0, st, static_cast<const __bf16 *>(slab),
+                                   off, ent, static_cast<__bf16 *>(dF), d->b, d->p1, entries, rowlen, canon);
+            else
+                hipLaunchKernelGGL((inter_reduce_slots_kernel<float, float>), g2, dim3(256), 0, st, static_cast<const float *>(slab),
+                                   off, ent, static_cast<float *>(dF), d->b, d->p1, entries, rowlen, canon);
+            EPN_CHECK_LAUNCH();
+            return 0;
+        }
+    }
     const unsigned grid = (unsigned)((A.ncol + 16 * NW - 1) / (16 * NW));
     // every wave walks ALL 16-channel chunks of its 16 columns: the [16 anchors][cin] block of a slot is then written by
     // one wave within a few hundred cycles and leaves L2 as whole lines (chunk-major launch order, which the gather
@@ -1808,9 +1964,6 @@ int launch_inter_ungroup_det_mfma(const epn_inter_desc *d, const float *rk4, con
     EPN_DISPATCH_NT_KT(EPN_USLOT, 0);
 #undef EPN_USLOT
     EPN_CHECK_LAUNCH();
-    const int rowlen = d->na * d->cin, entries = d->p2 * d->nn;
-    const long long n = (long long)d->b * d->p1 * (rowlen >> 2);
-    const dim3 g2((unsigned)((n + 255) / 256));
     if (bf16)
         hipLaunchKernelGGL((inter_reduce_slots_kernel<__bf16, __bf16>), g2, dim3(256), 0, st, static_cast<const __bf16 *>(slab),
                            off, ent, static_cast<__bf16 *>(dF), d->b, d->p1, entries, rowlen);
@@ -1832,7 +1985,7 @@ int launch_inter_ungroup_mfma(const epn_inter_desc *d, const float *rk4, const v
     // than slots, 8: 3x) but cost LDS and a wider barrier.  Measured per layer (ModelNet / rotation / 3DMatch schedules):
     // K = 16: 8 points, two tile buffers (16: +7 %); K = 32: 16 points, one buffer (-5 % fp32, -12 % bf16);
     // K = 64: 8 points, one buffer; K = 128: 2.  K = 32 / 64 fall back to half the group when p2 does not divide.
-    const int gp = nt <= 1 ? 8 : (nt <= 2 ? (d->p2 % 16 == 0 ? 16 : 8) : (nt <= 4 ? (d->p2 % 8 == 0 ? 8 : 4) : 2));
+    const int gp = ungroup_group_points(d, nt);
     if (order && d->p2 % gp == 0 && d->p2 <= MORTON_MAX && d->p1 <= USH_TAB && kernel_policy() != (0x400 | 1)) {
         hipLaunchKernelGGL(morton_order_kernel, dim3(d->b), dim3(1024), 0, st, d->new_xyz, d->p2, order);
         EPN_CHECK_LAUNCH();

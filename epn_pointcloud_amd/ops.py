@@ -367,7 +367,9 @@ class InterSO3ConvSplitFn(torch.autograd.Function):
                     # for bf16 also faster than the fp32 atomic scatter + conversion at K >= 32)
                     off, ent = geo.inverse_list()
                     gf = empty_cl(d.b, cin, d.p1, d.na, G.device, G.dtype)
-                    slab = torch.empty(d.b * d.p2 * d.nn * d.na * cin, dtype=G.dtype, device=G.device)
+                    # + one byte per (point, neighbour slot) behind the slab: marks of the pre-reduced form
+                    extra = (d.b * d.p2 * d.nn + 512 + G.element_size() - 1) // G.element_size()
+                    slab = torch.empty(d.b * d.p2 * d.nn * d.na * cin + extra, dtype=G.dtype, device=G.device)
                     det = _entry(lib, "inter_ungroup_det", G.dtype)
                     _lib.check(_launch("inter_ungroup_det", _inter_key(d), gflops, G.device,
                                        lambda: det(ctypes.byref(d), ctypes.c_void_p(dG.data_ptr()), _cl_ptr(gf),

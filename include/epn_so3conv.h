@@ -391,6 +391,10 @@ int epn_norm_act_bwd_apply_bf16(const void *x_cl, const void *dy_cl, int groups,
  *   2. epn_inter_ungroup_det_*: per-slot contributions slab[b][p][n][a][c] = sum_k w * grad_grouped (plain stores;
  *      slab has the element type of grad_grouped, b*p2*nn*na*cin elements), then grad_feats_cl[b][q][a][c] = the sum
  *      over q's list in list order (fp32 accumulation; fully overwritten; f32 -> float, bf16 -> bf16 output).
+ *      When slab_bytes leaves room for b*p2*nn more bytes behind the (256-byte rounded) slab and the output points
+ *      divide into the scatter's workgroups, the contributions are pre-reduced: a workgroup of 8-16 spatially adjacent
+ *      output points sums the slots of each distinct destination in LDS (ascending slot order) and stores ONE slab row
+ *      per destination, marked in those bytes; step 2 adds only the marked rows (a third of the slab traffic).
  * Bitwise repeatable.  Requires cin % 16 == 0 and na >= 16 (the MFMA grouping kernels). */
 int epn_inter_inverse_list(const int32_t *ball_idx, int b, int p1, int p2, int nn, int32_t *offsets, int32_t *entries,
                            epn_stream_t stream);

@@ -296,21 +296,48 @@ def test_config_full_size_bf16(gpu, model, points, batch):
     assert rel_l2(f16, f32) < 0.15
 
 
+@pytest.mark.parametrize("b,p1,p2,nn", [(3, 300, 150, 20), (2, 1024, 1024, 32), (2, 4096, 40, 16), (2, 700, 1100, 32)])
+def test_inverse_neighbour_list(gpu, b, p1, p2, nn):
+    """epn_inter_inverse_list (C ABI): CSR inverse of an index tensor, entries of a destination in increasing (p, n)
+    order, out-of-range (shadow) indices dropped.  Clouds whose p2*nn entries fit the LDS take the counting-sort kernel,
+    larger ones (last case: 35200 entries) the scanning kernel; both against a numpy construction."""
+    from epn_pointcloud_amd import _lib
+    rng = np.random.default_rng(p1 + p2)
+    idx = rng.integers(0, p1 + 3, size=(b, p2, nn)).astype(np.int32)          # p1 .. p1+2: shadow indices
+    idx[0, 0, :] = 5                                                            # one destination named by a whole row
+    t = torch.from_numpy(idx).to(gpu)
+    off = torch.empty((b, p1 + 1), dtype=torch.int32, device=gpu)
+    ent = torch.full((b, p2 * nn), -1, dtype=torch.int32, device=gpu)
+    _lib.check(_lib.get_lib().epn_inter_inverse_list(t.data_ptr(), b, p1, p2, nn, off.data_ptr(), ent.data_ptr(),
+                                                      _lib.stream_of(t)), "inverse_list")
+    off, ent = off.cpu().numpy(), ent.cpu().numpy()
+    for bb in range(b):
+        flat = idx[bb].reshape(-1)
+        valid = np.nonzero(flat < p1)[0]
+        order = valid[np.argsort(flat[valid], kind="stable")]                  # by destination, then by entry index
+        counts = np.bincount(flat[valid], minlength=p1)
+        assert np.array_equal(off[bb], np.concatenate([[0], np.cumsum(counts)]))
+        assert np.array_equal(ent[bb, :len(order)], order)
+
+
 @pytest.mark.parametrize("dt", [torch.float32, torch.bfloat16])
-def test_deterministic_data_gradient(gpu, vgtk_alias, dt, monkeypatch):
-    """EPN_DETERMINISTIC=1: the InterSO3Conv data gradient without atomics -- per-slot slab + ordered
-    reduction over the inverse neighbour list.  Bitwise repeatable, and equal (to rounding) to the atomic-scatter path
-    and to the oracle."""
+@pytest.mark.parametrize("K,n", [(20, 160), (16, 128), (40, 128), (20, 150)])
+def test_deterministic_data_gradient(gpu, vgtk_alias, dt, K, n, monkeypatch):
+    """EPN_DETERMINISTIC=1: the InterSO3Conv data gradient without atomics.  Where the output points divide into the
+    scatter's workgroups (n = 160 / 128: 16 / 8 / 8 points for K = 20 / 16 / 40) the LDS-pre-reduced scatter STORES one
+    row per (workgroup, distinct destination), summed in ascending slot order, and the ordered reduction over the inverse
+    neighbour list adds the marked rows; otherwise (n = 150: 75 output points) the per-slot slab.  Bitwise repeatable, and
+    equal (to rounding) to the atomic-scatter path and to the oracle."""
     sptk, zptk = _mods(vgtk_alias)
-    rng = np.random.default_rng(77)
+    rng = np.random.default_rng(77 + K + n)
     torch.manual_seed(77)
-    xyz = T(unit_ball_cloud(rng, 3, 160))
-    conv = sptk.InterSO3Conv(32, 48, 1, 2, 0.4, 0.08, 20, lazy_sample=False)
+    xyz = T(unit_ball_cloud(rng, 3, n))
+    conv = sptk.InterSO3Conv(32, 48, 1, 2, 0.4, 0.08, K, lazy_sample=False)
     conv.basic_conv.W.data = r16(conv.basic_conv.W.data)
-    feats = r16(torch.randn(3, 32, 160, 60))
+    feats = r16(torch.randn(3, 32, n, 60))
     fo = feats.clone().requires_grad_(True)
     _, _, _, _, oy = R.inter_so3conv(xyz, fo, conv.basic_conv.W.detach().clone(), conv.anchors, conv.kernels, 2, 0.4, 0.08,
-                                     20, False)
+                                     K, False)
     gy = r16(torch.randn_like(oy))
     (odF,) = torch.autograd.grad(oy, [fo], gy)
     conv = conv.to(gpu)
