@@ -19,7 +19,7 @@ EXPORTS = [
     "epn_inter_so3conv_bwd_data_f32", "epn_inter_so3conv_bwd_weight_f32", "epn_inter_weights_f32",
     "epn_intra_workspace_bytes", "epn_intra_is_fused", "epn_intra_so3conv_fwd_f32",
     "epn_intra_so3conv_bwd_data_f32", "epn_intra_so3conv_bwd_weight_f32",
-    "epn_norm_workspace_bytes", "epn_chan_stats_f32", "epn_norm_act_fwd_f32", "epn_norm_act_bwd_reduce_f32", "epn_norm_act_bwd_apply_f32",
+    "epn_norm_workspace_bytes", "epn_bn_running_update_f32", "epn_chan_stats_f32", "epn_norm_act_fwd_f32", "epn_norm_act_bwd_reduce_f32", "epn_norm_act_bwd_apply_f32",
     "epn_inter_group_workspace_bytes", "epn_inter_group_f32", "epn_inter_ungroup_f32", "epn_intra_group_f32", "epn_so3_basis_f32",
     "epn_anchor_query_f32", "epn_zp_inter_fwd_f32", "epn_zp_inter_bwd_f32", "epn_zp_intra_fwd_f32", "epn_zp_intra_bwd_f32",
     "epn_pointnet_so3conv_fwd_f32", "epn_pointnet_so3conv_bwd_data_f32", "epn_pointnet_so3conv_bwd_weight_f32",
@@ -116,6 +116,7 @@ def get_lib():
     lib.epn_norm_workspace_bytes.argtypes = [_ci, _ll, _ci]
     lib.epn_norm_workspace_bytes.restype = _sz
     lib.epn_chan_stats_f32.argtypes = [_vp, _ci, _ll, _ci, _vp, _vp, _sz, _vp]
+    lib.epn_bn_running_update_f32.argtypes = [_vp, ctypes.c_double, _vp, _vp, _vp, _vp, _cf, _ci, _vp]
     lib.epn_norm_act_fwd_f32.argtypes = [_vp, _ci, _ll, _ci, _vp, _vp, _vp, _vp, _cf, _cf, _vp, _vp]
     lib.epn_norm_act_bwd_reduce_f32.argtypes = [_vp, _vp, _ci, _ll, _ci, _vp, _vp, _vp, _cf, _cf, _vp, _vp, _vp, _vp,
                                                 _sz, _vp]

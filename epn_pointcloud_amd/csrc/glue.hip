@@ -297,6 +297,26 @@ NormArgs make_norm(long long rows, int c, float eps, float slope, dim3 &grid, in
     return A;
 }
 
+// BatchNorm's running statistics from (sum x, sum x^2) in ONE launch -- what torch.nn.BatchNorm2d does in training mode
+// with ~10 elementwise kernels on c-sized vectors (22 norms per step: ~200 launches of 5 us each).
+__global__ void bn_running_update_kernel(const float *__restrict__ sums, float n, const float *__restrict__ bias,
+                                         float *__restrict__ rmean, float *__restrict__ rvar,
+                                         long long *__restrict__ batches, float momentum, int c) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    // every thread reads the counter before thread 0 of block 0 bumps it (one block: c <= 1024, launcher)
+    const long long nb = *batches + 1;
+    __syncthreads();
+    if (i == 0) *batches = nb;
+    if (i >= c) return;
+    float mean = sums[2 * i] / n;
+    const float varb = fmaxf(sums[2 * i + 1] / n - mean * mean, 0.0f);
+    const float var = varb * (n / fmaxf(n - 1.0f, 1.0f));           // unbiased, as BatchNorm stores it
+    if (bias) mean += bias[i];
+    const float m = momentum >= 0.0f ? momentum : 1.0f / (float)nb;  // momentum = None: cumulative moving average
+    rmean[i] = fmaf(mean - rmean[i], m, rmean[i]);
+    rvar[i] = fmaf(var - rvar[i], m, rvar[i]);
+}
+
 }  // namespace
 }  // namespace epn
 
@@ -392,6 +412,17 @@ static int norm_act_bwd_apply_any(const void *x_cl, const void *dy_cl, int group
     A.x = x_cl; A.dy = dy_cl; A.sums = sums; A.dsums = dsums; A.gamma = gamma; A.beta = beta; A.y = dx_cl;
     if (bf16) hipLaunchKernelGGL(norm_act_bwd_apply_kernel<__bf16>, grid, dim3(GT), 0, epn_stream(stream), A);
     else hipLaunchKernelGGL(norm_act_bwd_apply_kernel<float>, grid, dim3(GT), 0, epn_stream(stream), A);
+    EPN_CHECK_LAUNCH();
+    return 0;
+}
+
+extern "C" int epn_bn_running_update_f32(const float *sums, double count, const float *conv_bias, float *running_mean,
+                                        float *running_var, long long *num_batches_tracked, float momentum, int c,
+                                        epn_stream_t stream) {
+    if (c < 1 || c > 1024 || count < 1.0) return EPN_EINVAL;
+    if (!sums || !running_mean || !running_var || !num_batches_tracked) return EPN_ENULL;
+    hipLaunchKernelGGL(bn_running_update_kernel, dim3(1), dim3(1024), 0, epn_stream(stream), sums, (float)count, conv_bias,
+                       running_mean, running_var, num_batches_tracked, momentum, c);
     EPN_CHECK_LAUNCH();
     return 0;
 }

@@ -873,6 +873,18 @@ def _update_running_stats(norm, sums, n, conv_bias=None):
     import torch.nn as nn
     if isinstance(norm, nn.InstanceNorm2d) or not norm.track_running_stats or norm.running_mean is None:
         return
+    c = norm.running_mean.numel()
+    rm, rv, nb = norm.running_mean, norm.running_var, norm.num_batches_tracked
+    if (sums.is_cuda and c <= 1024 and rm.dtype == torch.float32 and rm.is_contiguous() and rv.is_contiguous()
+            and nb.dtype == torch.int64 and sums.dtype == torch.float32 and sums.is_contiguous()):
+        # one launch instead of ~10 elementwise torch kernels on c-sized vectors
+        with torch.no_grad():
+            bias = conv_bias.detach().float().contiguous() if conv_bias is not None else None
+            _lib.check(_lib.get_lib().epn_bn_running_update_f32(
+                sums.data_ptr(), float(n), bias.data_ptr() if bias is not None else None, rm.data_ptr(), rv.data_ptr(),
+                nb.data_ptr(), float(norm.momentum) if norm.momentum is not None else -1.0, c, _lib.stream_of(sums)),
+                "bn_running_update")
+        return
     with torch.no_grad():
         mean = sums[0, :, 0] / n
         var = (sums[0, :, 1] / n - mean * mean).clamp_min_(0) * (n / max(n - 1, 1))   # unbiased, as BatchNorm stores

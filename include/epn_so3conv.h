@@ -164,6 +164,13 @@ int epn_intra_so3conv_bwd_weight_f32(const float *feats_cl, const float *grad_ou
  * epn_norm_act_bwd_reduce_f32 (also writes dgamma / dbeta when given), then
  *   dx = rstd * (dn - mean(dn) - xhat * mean(dn * xhat))                               epn_norm_act_bwd_apply_f32 */
 size_t epn_norm_workspace_bytes(int groups, long long rows, int c);   /* scratch of the two reduction entry points */
+/* BatchNorm2d's running statistics (training mode) from sums[c][2] of `count` values per channel, in one launch:
+ * mean (+ conv_bias, the bias of the producing convolution when it was not added to x), unbiased variance,
+ * num_batches_tracked += 1, running = running + momentum * (batch - running); momentum < 0 = None (cumulative average,
+ * 1 / num_batches_tracked).  Reference: torch.nn.BatchNorm2d inside SeparableSO3ConvBlock (base_so3conv.py:168-212). */
+int epn_bn_running_update_f32(const float *sums, double count, const float *conv_bias, float *running_mean,
+                              float *running_var, long long *num_batches_tracked, float momentum, int c,
+                              epn_stream_t stream);
 int epn_chan_stats_f32(const float *x_cl, int groups, long long rows, int c, float *sums, void *workspace,
                        size_t workspace_bytes, epn_stream_t stream);
 int epn_norm_act_fwd_f32(const float *x_cl, int groups, long long rows, int c, const float *sums,

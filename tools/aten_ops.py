@@ -1,0 +1,30 @@
+#!/usr/bin/env python3
+"""Which torch (aten) kernels one training step of the cls network still launches, by op and input shape:
+`python tools/aten_ops.py` (torch.profiler, one eager step)."""
+import os
+import sys
+
+import torch
+from torch.profiler import profile, ProfilerActivity
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from epn_pointcloud_amd import models as M, schedule as S  # noqa: E402
+
+dev = torch.device("cuda", 0)
+model = M.ClsSO3ConvModel(S.cls_so3net_schedule(1024), out_mlps=(256,), pooling="attention").to(dev).train()
+pts = S.synthetic_clouds(32, 1024, dev)
+labels = torch.arange(32, device=dev) % 40
+
+
+def step():
+    torch.nn.functional.cross_entropy(model(pts)[0], labels).backward()
+
+
+step(); step(); torch.cuda.synchronize()
+with profile(activities=[ProfilerActivity.CPU, ProfilerActivity.CUDA], record_shapes=True) as prof:
+    step()
+    torch.cuda.synchronize()
+rows = [e for e in prof.key_averages(group_by_input_shape=True) if e.key.startswith("aten::") and e.device_time_total > 0]
+rows.sort(key=lambda e: -e.count)
+for e in rows[:45]:
+    print(f"{e.count:4d} x {e.device_time_total / max(e.count, 1):7.1f} us  {e.key:28s} {str(e.input_shapes)[:110]}")
