@@ -296,7 +296,7 @@ int epn_zp_intra_bwd_f32(const int32_t *anchor_neighbors, const float *anchor_we
  *                                           problems per call (one grouped launch per 6).
  *   TN: C[N1][N2] = X[R][N1]^T . Y[R][N2]  (weight gradients: contraction over the R = b*p*a columns; split over R into
  *                                           fp32 partials in `workspace`, summed in a fixed order: deterministic).
- * fp32: v_mfma_f32_32x32x2_f32, exact f32.  bf16: bf16 operands, fp32 accumulation; NT writes bf16 (or fp32 when
+ * fp32: v_mfma_f32_32x32x2_f32, exact f32 (the split entry points below: the bf16 pipe at fp32 accuracy).  bf16: bf16 operands, fp32 accumulation; NT writes bf16 (or fp32 when
  * out_f32 != 0), TN always writes fp32.  Fast path: K % 32 == 0 (fp32) / 64 (bf16), 16-byte aligned rows; anything
  * else runs on a generic kernel.  C is fully overwritten. */
 typedef struct epn_gemm_nt_problem {
