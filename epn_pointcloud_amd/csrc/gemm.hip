@@ -975,7 +975,8 @@ int launch_nt_typed(GemmNtBatch &B, hipStream_t st) {
 
 constexpr int tn_waves(int wgm, int wgn, int, int, int) { return wgm * wgn; }
 // split form: single wide weight gradients take the pre-split planes kernel, narrow / grouped ones split in the kernel
-inline bool tn_planes_form(int nprob, int N2) { return nprob == 1 && N2 >= 512; }
+// (N2 = the narrowest output; groups of c = 128 blocks measured slower with the extra pass over X: 1.43 vs 1.34 ms)
+inline bool tn_planes_form(int nprob, int N2) { return N2 >= (nprob == 1 ? 512 : 256); }
 
 template <typename T>
 bool tn_fast_ok(const GemmTnArgs &G) {
@@ -996,6 +997,11 @@ size_t tn_plan(GemmTnBatch &B, int *bn1_out, int *bn2_out, void *ws, bool x3 = f
     }
     int bn1, bn2;
     gemm_tn_tile(B.nprob > 1 && bf == 2 ? 0 : bf, max1, B.nprob > 1 && min2 < 256 ? 256 : min2, &bn1, &bn2);   // groups: the wide tiles
+    if (B.nprob > 1 && bf == 2 && min2 >= 256) {       // wide spectral groups (c >= 256), split form: 256 x 256 tiles
+        int min1 = 1 << 30;                             // halve the re-reads of X and Y (every tile row / column streams
+        for (int i = 0; i < B.nprob; ++i) min1 = B.p[i].N1 < min1 ? B.p[i].N1 : min1;   // the other operand again)
+        if (min1 >= 256) { bn1 = 256; bn2 = 256; }
+    }
     *bn1_out = bn1; *bn2_out = bn2;
     long long tiles[GEMM_MAX_PROB], chunks[GEMM_MAX_PROB];
     for (int i = 0; i < B.nprob; ++i) {
@@ -1040,12 +1046,15 @@ size_t tn_plan(GemmTnBatch &B, int *bn1_out, int *bn2_out, void *ws, bool x3 = f
     }
     B.nblocks = blk;
     for (int i = 0; i < B.nprob; ++i) B.p[i].Xp = nullptr;
-    if (x3 && tn_planes_form(B.nprob, B.p[0].N2)) {     // bf16 planes of the narrow operand: 6 bytes per value
-        GemmTnArgs &G = B.p[0];
-        // (a null workspace = size query: a non-null marker keeps the two passes on the same path)
-        G.Xp = ws ? static_cast<char *>(ws) + off : reinterpret_cast<const void *>(1);
-        off += ((size_t)6 * G.R * G.N1 + 255) & ~(size_t)255;
-    }
+    const bool x3_tile = (bn1 == 32 && bn2 == 512) || (bn1 == 64 && bn2 == 512) || (bn1 == 256 && bn2 == 256) ||
+                         (bn1 == 128 && (bn2 == 256 || bn2 == 512));      // instances of gemm_tn_x3_kernel
+    if (x3 && x3_tile && tn_planes_form(B.nprob, min2))  // bf16 planes of X: 6 bytes per value
+        for (int i = 0; i < B.nprob; ++i) {
+            GemmTnArgs &G = B.p[i];
+            // (a null workspace = size query: a non-null marker keeps the two passes on the same path)
+            G.Xp = ws ? static_cast<char *>(ws) + off : reinterpret_cast<const void *>(1);
+            off += ((size_t)6 * G.R * G.N1 + 255) & ~(size_t)255;
+        }
     return off;
 }
 
@@ -1082,14 +1091,17 @@ int launch_tn_typed(GemmTnBatch &B, void *ws, size_t ws_bytes, hipStream_t st, b
     } while (0)
 #define EPN_TX(...) hipLaunchKernelGGL((gemm_tn_x3_kernel<__VA_ARGS__>), grid, dim3(64 * tn_waves(__VA_ARGS__)), 0, st, B)
         if (x3 && B.p[0].Xp) {
-            const GemmTnArgs &G = B.p[0];               // the narrow operand's bf16 planes (workspace, after the slabs)
-            const long long n = (G.R >> 3) * G.N1;
-            hipLaunchKernelGGL(split_octets_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st,
-                               static_cast<const float *>(G.X), G.ldx, G.R, G.N1, static_cast<u32x4 *>(const_cast<void *>(G.Xp)));
-            EPN_CHECK_LAUNCH();
-            if (bn1 == 32) EPN_TX(1, 8, 1, 2, 32);
+            for (int i = 0; i < B.nprob; ++i) {         // X's bf16 planes (workspace, after the slabs)
+                const GemmTnArgs &G = B.p[i];
+                const long long n = (G.R >> 3) * G.N1;
+                hipLaunchKernelGGL(split_octets_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st,
+                                   static_cast<const float *>(G.X), G.ldx, G.R, G.N1, static_cast<u32x4 *>(const_cast<void *>(G.Xp)));
+                EPN_CHECK_LAUNCH();
+            }
+            if (bn1 == 32) EPN_TX(1, 8, 1, 2, 32);           // (bn1, bn2) is one of tn_plan's x3_tile pairs
             else if (bn1 == 64) EPN_TX(1, 8, 2, 2, 16);
             else if (bn1 == 256) EPN_TX(2, 4, 4, 2, 16);
+            else if (bn2 == 256) EPN_TX(2, 4, 2, 2, 32);     // grouped spectral weight gradients (c >= 128)
             else EPN_TX(1, 8, 4, 2, 16);
         }
         else if (bn1 == 32) EPN_TN(1, 8, 1, 2, 32);

@@ -107,14 +107,15 @@ def test_gemm_tn_grouped(gpu, fp32_mode, dt):
     if dt != torch.float32 and fp32_mode == "native":
         pytest.skip("mode only concerns fp32 operands")
     torch.manual_seed(8)
-    probs = [(torch.randn(2048 * d, 64 * d, device=gpu).to(dt), torch.randn(2048 * d, 32 * d, device=gpu).to(dt))
-             for d in (1, 3, 3, 4, 5)]
-    outs = gemm.gemm_tn_grouped(probs)
-    for (X, Y), C in zip(probs, outs):
-        ref = X.double().t() @ Y.double()
-        assert (C.double() - ref).abs().max().item() <= 3e-5 * ref.abs().max().item()
-    again = gemm.gemm_tn_grouped(probs)
-    assert all(torch.equal(a, b) for a, b in zip(outs, again))         # fixed-order reduction: bitwise repeatable
+    for w1, w2 in ((64, 32), (256, 256)):       # (256, 256): every output >= 256 wide -- the split form pre-splits X
+        probs = [(torch.randn(2048 * d, w1 * d, device=gpu).to(dt), torch.randn(2048 * d, w2 * d, device=gpu).to(dt))
+                 for d in (1, 3, 3, 4, 5)]
+        outs = gemm.gemm_tn_grouped(probs)
+        for (X, Y), C in zip(probs, outs):
+            ref = X.double().t() @ Y.double()
+            assert (C.double() - ref).abs().max().item() <= 3e-5 * ref.abs().max().item()
+        again = gemm.gemm_tn_grouped(probs)
+        assert all(torch.equal(a, b) for a, b in zip(outs, again))     # fixed-order reduction: bitwise repeatable
 
 
 @pytest.mark.parametrize("M,N,K", [(8192, 128, 1536), (4096, 256, 6144), (2048, 64, 32768), (4096, 768, 256)])
