@@ -343,7 +343,8 @@ def main():
             if dtype_name == "f32" and split_gemm and ksz == 8:        # launch_gemm_nt_x3 (csrc/gemm_x3.hip)
                 mx = max(ns)
                 if len(ns) > 1:
-                    cfg = "4, 1, 2, 2, 3" if (mx <= 320 and min(ns) <= 64) else "2, 2, 2, 2, 2"
+                    cfg = ("4, 1, 2, 2, 3" if (mx <= 320 and min(ns) <= 64) else
+                           ("4, 2, 2, 4, 2" if min(ns) >= 256 else "2, 2, 2, 2, 2"))
                 elif mx <= 32:
                     cfg = "8, 1, 2, 1, 2"
                 elif mx <= 64:
@@ -380,6 +381,8 @@ def main():
                 n2 = 256
             w2 = 512 if n2 >= 512 else (256 if n2 > 128 else (128 if n2 > 64 else 64))
             x3 = "true" if split_gemm else "false"
+            if split_gemm and grouped and n2 >= 256 and n1 >= 1280:  # wide spectral groups (n1 = 5 c): planes kernel, 256 x 256 tiles
+                return "epn::gemm_tn_x3_kernel<2, 4, 4, 2, 16>"
             if split_gemm and not grouped and n2 >= 512:       # wide single problems: pre-split planes kernel
                 cfg = "1, 8, 1, 2, 32" if n1 <= 32 else ("1, 8, 2, 2, 16" if n1 <= 64 else
                                                            ("2, 4, 4, 2, 16" if n1 >= 256 else "1, 8, 4, 2, 16"))
