@@ -44,7 +44,7 @@ KERNEL_OF = {
     "inter_gemm_dw": "epn::gemm_tn_kernel", "intra_gemm_dw": "epn::gemm_tn_kernel",
     "conv1x1_gemm": "epn::gemm_nt_kernel", "conv1x1_gemm_dw": "epn::gemm_tn_kernel",
     "intra_group": "epn::intra_group_kernel", "so3_basis": "epn::so3_basis_kernel",
-    "pointnet_fwd": "epn::pointnet_fwd_kernel", "pointnet_bwd_data": "epn::pointnet_bwd_data_kernel",
+    "pointnet_fwd": "epn::pointnet_fwd_mfma_kernel", "pointnet_bwd_data": "epn::pointnet_bwd_data_kernel",
     "pointnet_bwd_weight": "epn::pointnet_bwd_weight_kernel",
 }
 PMC_FILE = os.path.join(ROOT, "profiles", "r02_pmc_per_kernel.json")   # tools/collect_profiles.sh + pmc_summary.py
