@@ -173,6 +173,41 @@ def test_split_gemm_ragged_and_fallback(gpu):
         gemm.set_fp32_mode(old)
 
 
+def test_split_gemm_c_abi_workspace_contract(gpu):
+    """epn_gemm_nt_split_f32 without a workspace (or with one that is too small) runs the native fp32 kernels -- same
+    result to rounding; epn_gemm_tn_split_f32 needs its workspace (partial slabs + the planes of X) and says so."""
+    import ctypes
+    from epn_pointcloud_amd import _lib, gemm
+    lib = _lib.get_lib()
+    torch.manual_seed(9)
+    A, B = torch.randn(700, 96, device=gpu), torch.randn(72, 96, device=gpu)
+    ref = A.double() @ B.double().t()
+    arr = (_lib.GemmNtProblem * 1)()
+    for ws_bytes in (None, 16, "exact"):
+        C = torch.zeros(700, 72, device=gpu)
+        arr[0] = gemm._problem(A, B, C)
+        need = int(lib.epn_gemm_nt_split_workspace_bytes(1, arr))
+        assert need >= 6 * 72 * 96
+        n = need if ws_bytes == "exact" else (ws_bytes or 0)
+        ws = torch.empty(max(n, 1), dtype=torch.uint8, device=gpu)
+        rc = lib.epn_gemm_nt_split_f32(1, arr, ws.data_ptr() if ws_bytes else None, n, _lib.stream_of(A))
+        assert rc == 0
+        assert (C.double() - ref).abs().max().item() <= 1e-5 * ref.abs().max().item()
+    X, Y = torch.randn(4096, 64, device=gpu), torch.randn(4096, 768, device=gpu)
+    Cw = torch.empty(64, 768, device=gpu)
+    need = int(lib.epn_gemm_tn_workspace_bytes(2, 4096, 64, 768))
+    assert need >= 6 * 4096 * 64                                     # at least the bf16 planes of X
+    small = torch.empty(256, dtype=torch.uint8, device=gpu)
+    rc = lib.epn_gemm_tn_split_f32(X.data_ptr(), 64, Y.data_ptr(), 768, Cw.data_ptr(), 768, 4096, 64, 768, small.data_ptr(),
+                                   small.numel(), _lib.stream_of(X))
+    assert rc != 0 and b"workspace" in lib.epn_strerror(rc).lower()
+    ws = torch.empty(need, dtype=torch.uint8, device=gpu)
+    _lib.check(lib.epn_gemm_tn_split_f32(X.data_ptr(), 64, Y.data_ptr(), 768, Cw.data_ptr(), 768, 4096, 64, 768, ws.data_ptr(),
+                                         need, _lib.stream_of(X)), "gemm_tn_split")
+    ref = X.double().t() @ Y.double()
+    assert (Cw.double() - ref).abs().max().item() <= 2e-5 * ref.abs().max().item()
+
+
 # ------------------------------------------------------------------------------------------------ convolutions
 @pytest.mark.parametrize("cin,cout,stride,K", [(32, 32, 1, 32), (32, 64, 2, 64), (64, 64, 1, 16), (16, 48, 2, 20)])
 def test_inter_bf16_vs_oracle(gpu, vgtk_alias, cin, cout, stride, K):
