@@ -316,12 +316,16 @@ int epn_gemm_nt_bf16(int nprob, const epn_gemm_nt_problem *probs, int out_f32, e
 size_t epn_gemm_nt_split_workspace_bytes(int nprob, const epn_gemm_nt_problem *probs);
 int epn_gemm_nt_split_f32(int nprob, const epn_gemm_nt_problem *probs, void *workspace, size_t workspace_bytes,
                           epn_stream_t stream);
+/* `bf16`: 0 = fp32 operands (epn_gemm_tn_f32), 1 = bf16 (epn_gemm_tn_bf16), 2 = fp32 operands in the split form
+ * (epn_gemm_tn_split_f32: the partial slabs plus, for N2 >= 512, the three bf16 planes of X = 6 bytes per value) */
 size_t epn_gemm_tn_workspace_bytes(int bf16, long long R, int N1, int N2);
 int epn_gemm_tn_f32(const float *X, long long ldx, const float *Y, long long ldy, float *C, long long ldc, long long R,
                     int N1, int N2, void *workspace, size_t workspace_bytes, epn_stream_t stream);
 int epn_gemm_tn_bf16(const void *X, long long ldx, const void *Y, long long ldy, float *C, long long ldc, long long R,
                      int N1, int N2, void *workspace, size_t workspace_bytes, epn_stream_t stream);
-/* split form of epn_gemm_tn_f32 (see epn_gemm_nt_split_f32): both operands are split in registers; same workspace */
+/* split form of epn_gemm_tn_f32 (see epn_gemm_nt_split_f32).  Wide outputs (N2 >= 512): X, the narrow operand, is split
+ * ahead of the GEMM into bf16 planes laid out [plane][R/8][N1][8] in the workspace, Y in registers; narrow ones: both
+ * operands in registers.  Workspace size: epn_gemm_tn_workspace_bytes(2, ...); too small -> EPN_EWORKSPACE. */
 int epn_gemm_tn_split_f32(const float *X, long long ldx, const float *Y, long long ldy, float *C, long long ldc,
                           long long R, int N1, int N2, void *workspace, size_t workspace_bytes, epn_stream_t stream);
 /* Grouped TN (`bf16`: 0 = fp32, 1 = bf16 operands, 2 = fp32 operands in the split form): up to 6 problems in ONE launch (the five weight-gradient GEMMs of a spectral IntraSO3Conv layer, each too
