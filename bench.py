@@ -76,6 +76,8 @@ def parse():
     ap.add_argument("--dtype", default="", choices=["", "f32", "bf16"],
                     help="feature storage / GEMM operand type (default: f32 for cls, bf16 for reg / inv as BASELINE states)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-native-line", action="store_true",
+                    help="skip the second measurement with the exact-f32 MFMA GEMMs (fp32, single rank, split form only)")
     ap.add_argument("--cpu-clouds", type=int, default=4, help="sample size of the CPU baseline (SURVEY 8d: B=4 chunks)")
     ap.add_argument("--cpu-threads", type=int, default=16,
                     help="torch CPU threads of the baseline (the GPU box's cgroup grants 16 CPUs; measured fastest of "
@@ -501,6 +503,42 @@ def main():
                        "parallelism": f"dp{world}"},
             "roofline": roofline,
         }
+        if world == 1 and split_gemm and not args.no_native_line:
+            # the same step with the weight contractions / basis change on the fp32 matrix instruction
+            # (v_mfma_f32_32x32x2_f32, EPN_GEMM_FP32=native), measured right here: same box, same process, same inputs
+            try:
+                _gemm.set_fp32_mode("native")
+                compute()                                   # eager once (allocations), then its own graph
+                if not args.forward_only:
+                    opt.step()
+                torch.cuda.synchronize()
+                g2 = None
+                if graph is not None:
+                    g2 = torch.cuda.CUDAGraph()
+                    with torch.cuda.graph(g2, capture_error_mode="thread_local"):
+                        compute()
+
+                def native_step():
+                    if g2 is None:
+                        compute()
+                    else:
+                        g2.replay()
+                    finish()
+                native_step()
+                torch.cuda.synchronize()
+                tn0 = time.perf_counter()
+                for _ in range(args.steps):
+                    native_step()
+                torch.cuda.synchronize()
+                dtn = time.perf_counter() - tn0
+                out["native_fp32_mfma"] = {"value": round(args.batch * args.steps / dtn, 3), "unit": "point-clouds/s",
+                                           "ms_per_step": round(dtn / args.steps * 1e3, 3), "steps": args.steps,
+                                           "note": "same step, fp32 contractions on v_mfma_f32_32x32x2_f32 instead of the "
+                                                   "lossless bf16 split (DESIGN.md 3.2b); value / this = speed-up of the split form"}
+            except Exception as e:                          # a report, never a requirement
+                out["native_fp32_mfma"] = {"error": f"{type(e).__name__}: {e}"}
+            finally:
+                _gemm.set_fp32_mode("split")
         if world == 1:
             out["index_kernels"] = index_kernel_line(flat_pts, layers, dev)
         if world == 1 and not args.no_cpu_baseline and args.model == "cls" and not args.forward_only:

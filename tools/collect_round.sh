@@ -19,7 +19,7 @@ python bench.py --model inv --dtype bf16 --no-cpu-baseline > $OUT/bench_inv.json
 python bench.py --forward-only --no-cpu-baseline > $OUT/bench_cls_fwd.json 2>/dev/null
 python bench.py --model reg --dtype f32 --no-cpu-baseline > $OUT/bench_reg_f32.json 2>/dev/null
 python bench.py --dtype bf16 --no-cpu-baseline > $OUT/bench_cls_bf16.json 2>/dev/null
-EPN_GEMM_FP32=native python bench.py --no-cpu-baseline > $OUT/bench_cls_native_fp32_mfma.json 2>/dev/null
+EPN_GEMM_FP32=native python bench.py --no-cpu-baseline --no-native-line > $OUT/bench_cls_native_fp32_mfma.json 2>/dev/null
 (cd tools && python x3_probe.py 2>&1 | grep -v amdgpu.ids > $OUT/x3_probe.txt; python x3_err.py 2>&1 | grep -v amdgpu.ids > $OUT/x3_err.txt)
 python tools/gemm_bench.py > $OUT/gemm_bench_f32.txt 2>&1
 python tools/gemm_bench.py --dtype bf16 > $OUT/gemm_bench_bf16.txt 2>&1
