@@ -118,16 +118,22 @@ __global__ __launch_bounds__(64 * WGM * WGN) void gemm_nt_x3_kernel(GemmNtBatch 
             adv[i] = 64;
         }
     }
-    auto stage = [&](int buf) {
-#pragma unroll
-        for (int i = 0; i < GPW; ++i) {
-            const int g = wave + i * NW;
-            if (NG % NW == 0 || g < NG) {
-                glds16(src[i], smem + buf * STAGE + g * 1024);
-                src[i] += adv[i];
-            }
+    auto stage_one = [&](int buf, int i) {
+        const int g = wave + i * NW;
+        if (NG % NW == 0 || g < NG) {
+            glds16(src[i], smem + buf * STAGE + g * 1024);
+            src[i] += adv[i];
         }
     };
+    auto stage = [&](int buf) {
+#pragma unroll
+        for (int i = 0; i < GPW; ++i) stage_one(buf, i);
+    };
+    // two-stage ring: the next stage's loads are spread over the twelve MFMA groups of the K step (a direct-to-LDS load
+    // costs its wave ~100 cycles of issue; as one burst after the barrier both waves of a SIMD stall together)
+    // (the 256 x 256 tile: +3 %; the smaller tiles measured 1-2 % slower spread than as a burst)
+    constexpr bool SPREAD = NSTG == 2 && GPW <= 12 && TM * TN >= 8;
+    const int wpar = NW >= 8 ? __builtin_amdgcn_readfirstlane((wave >> 2) & 1) : 0;
 
     const int wm = wave / WGN, wn = wave % WGN;
     const int li = lane & 31, lj = lane >> 5;
@@ -160,7 +166,7 @@ __global__ __launch_bounds__(64 * WGM * WGN) void gemm_nt_x3_kernel(GemmNtBatch 
             if (kt + 2 < nk) stage((kt + 2) % 3);
         } else {
             __syncthreads();
-            if (more) stage((kt + 1) & 1);
+            if (more && !SPREAD) stage((kt + 1) & 1);
         }
         const char *base = smem + (kt % NSTG) * STAGE;
 #pragma unroll
@@ -181,12 +187,26 @@ __global__ __launch_bounds__(64 * WGM * WGN) void gemm_nt_x3_kernel(GemmNtBatch 
 #define EPN_X3_TERM(PA, PB)                                                                                 \
     _Pragma("unroll") for (int i = 0; i < TM; ++i) _Pragma("unroll") for (int j = 0; j < TN; ++j)         \
         acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(PA[i], PB[j], acc[i][j], 0, 0, 0)
-            EPN_X3_TERM(ah, bl);                // small terms first
-            EPN_X3_TERM(al, bh);
-            EPN_X3_TERM(am, bm);
-            EPN_X3_TERM(ah, bm);
-            EPN_X3_TERM(am, bh);
-            EPN_X3_TERM(ah, bh);
+#define EPN_X3_LOAD(T_)                                                                                    \
+    if constexpr (SPREAD) {                                                                                 \
+        __builtin_amdgcn_sched_barrier(0);                                                                  \
+        if (more) {                                                                                         \
+            _Pragma("unroll") for (int i = 0; i < GPW; ++i) {                                               \
+                const int g0 = (i * 11) / (GPW > 1 ? GPW - 1 : 1);      /* slot of load i, 0 .. 11 */        \
+                const int g1 = g0 < 11 ? g0 + 1 : 11;                   /* partner wave: one slot later */   \
+                if ((g0 == 6 * s + (T_) && wpar == 0) || (g1 == 6 * s + (T_) && wpar != 0))                 \
+                    stage_one((kt + 1) & 1, i);                                                             \
+            }                                                                                               \
+        }                                                                                                   \
+        __builtin_amdgcn_sched_barrier(0);                                                                  \
+    }
+            EPN_X3_LOAD(0) EPN_X3_TERM(ah, bl);                // small terms first
+            EPN_X3_LOAD(1) EPN_X3_TERM(al, bh);
+            EPN_X3_LOAD(2) EPN_X3_TERM(am, bm);
+            EPN_X3_LOAD(3) EPN_X3_TERM(ah, bm);
+            EPN_X3_LOAD(4) EPN_X3_TERM(am, bh);
+            EPN_X3_LOAD(5) EPN_X3_TERM(ah, bh);
+#undef EPN_X3_LOAD
 #undef EPN_X3_TERM
         }
     }
@@ -288,9 +308,6 @@ int launch_gemm_nt_x3(GemmNtBatch &B, void *ws, size_t ws_bytes, hipStream_t st)
             case 0x28: return launch_x3_cfg<2, 4, 2, 2, 2>(B, st);     // 128 x 256, 8 waves
             case 0x29: return launch_x3_cfg<2, 2, 2, 4, 2>(B, st);     // 128 x 256, 4 waves
             case 0x2a: return launch_x3_cfg<8, 1, 2, 1, 2>(B, st);     // 512 x 32
-            case 0x2b: return launch_x3_cfg<4, 4, 2, 2, 2>(B, st);     // 256 x 256, 16 waves
-            case 0x2c: return launch_x3_cfg<4, 4, 2, 1, 2>(B, st);     // 256 x 128, 16 waves
-            case 0x2d: return launch_x3_cfg<8, 2, 1, 4, 2>(B, st);     // 256 x 256, 16 waves, 32 x 128 per wave
             default: break;
         }
     }
