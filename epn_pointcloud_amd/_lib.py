@@ -29,6 +29,7 @@ EXPORTS = [
     "epn_gather_rows", "epn_scatter_rows", "epn_conv1x1_c1_f32", "epn_conv1x1_c1_bwd_weight_f32",
     "epn_ball_query_f64", "epn_fps_f64", "epn_gather_fwd_f64", "epn_gather_bwd_f64", "epn_so3_basis_norm_f32", "epn_so3_basis_norm_bf16", "epn_so3_basis_split_f32", "epn_so3_basis_norm_split_f32", "epn_inter_inverse_list", "epn_inter_ungroup_det_f32", "epn_inter_ungroup_det_bf16",
     "epn_chan_stats_bf16", "epn_norm_act_fwd_bf16", "epn_norm_act_bwd_reduce_bf16", "epn_norm_act_bwd_apply_bf16",
+    "epn_inter_onchip_ok", "epn_inter_onchip_workspace_bytes", "epn_inter_so3conv_fwd_onchip_f32", "epn_inter_so3conv_fwd_bf16",
 ]
 
 _vp, _ci, _cf, _sz = ctypes.c_void_p, ctypes.c_int, ctypes.c_float, ctypes.c_size_t
@@ -88,6 +89,12 @@ def get_lib():
     lib.epn_inter_so3conv_bwd_data_f32.argtypes = [dp, _vp, _vp, _vp, _vp, _sz, _vp]
     lib.epn_inter_so3conv_bwd_weight_f32.argtypes = [dp, _vp, _vp, _vp, _vp, _sz, _vp]
     lib.epn_inter_weights_f32.argtypes = [dp, _vp, _vp]
+    lib.epn_inter_onchip_ok.argtypes = [dp, _ci]
+    lib.epn_inter_onchip_ok.restype = _ci
+    lib.epn_inter_onchip_workspace_bytes.argtypes = [dp, _ci]
+    lib.epn_inter_onchip_workspace_bytes.restype = _sz
+    lib.epn_inter_so3conv_fwd_onchip_f32.argtypes = [dp, _vp, _vp, _vp, _vp, _sz, _vp]
+    lib.epn_inter_so3conv_fwd_bf16.argtypes = [dp, _vp, _vp, _vp, _vp, _sz, _vp]
     lib.epn_inter_group_workspace_bytes.argtypes = [dp]
     lib.epn_inter_group_workspace_bytes.restype = _sz
     lib.epn_inter_group_f32.argtypes = [dp, _vp, _vp, _vp, _sz, _vp]

@@ -182,6 +182,45 @@ static int prep_tables(const epn_inter_desc *d, void *workspace, size_t bytes, I
     return launch_rk_table(d, base + ws.rk_off, st);
 }
 
+// ---- on-chip form: grouping fused into the weight contraction as its A-tile producer (inter_fx.hip)
+extern "C" int epn_inter_onchip_ok(const epn_inter_desc *d, int bf16) {
+    return d && !check_desc(d) && inter_fx_ok(d, bf16) && !force_generic() ? 1 : 0;
+}
+
+extern "C" size_t epn_inter_onchip_workspace_bytes(const epn_inter_desc *d, int bf16) {
+    if (!d) return 0;
+    InterWs w = inter_ws(d);
+    return w.big_off * sizeof(float) + inter_fx_planes_bytes(d, bf16);   // tables + the permuted bf16 planes of W
+}
+
+static int inter_onchip_fwd(const epn_inter_desc *d, const void *feats_cl, const float *W, void *out_cl, void *workspace,
+                            size_t workspace_bytes, int bf16, epn_stream_t stream) {
+    hipStream_t st = epn_stream(stream);
+    int rc = check_desc(d);
+    if (rc) return rc;
+    if (!inter_fx_ok(d, bf16)) return EPN_EINVAL;
+    if (workspace_bytes < epn_inter_onchip_workspace_bytes(d, bf16)) return EPN_EWORKSPACE;
+    InterWs ws;
+    float *base = nullptr;
+    rc = prep_tables(d, workspace, workspace_bytes, ws, base, st);
+    if (rc) return rc;
+    if (d->b == 0 || d->p2 == 0) return 0;
+    if (!feats_cl || !W || !out_cl) return EPN_ENULL;
+    rc = launch_inter_tables_mfma(d, base + ws.rk_off, base + ws.rk4_off, base + ws.beta_off, st);
+    if (rc) return rc;
+    return launch_inter_fx_fwd(d, base + ws.rk4_off, feats_cl, W, out_cl, base + ws.big_off, bf16, st);
+}
+
+extern "C" int epn_inter_so3conv_fwd_onchip_f32(const epn_inter_desc *d, const float *feats_cl, const float *W,
+                                                float *out_cl, void *workspace, size_t workspace_bytes,
+                                                epn_stream_t stream) {
+    return inter_onchip_fwd(d, feats_cl, W, out_cl, workspace, workspace_bytes, 0, stream);
+}
+extern "C" int epn_inter_so3conv_fwd_bf16(const epn_inter_desc *d, const void *feats_cl, const float *W, void *out_cl,
+                                          void *workspace, size_t workspace_bytes, epn_stream_t stream) {
+    return inter_onchip_fwd(d, feats_cl, W, out_cl, workspace, workspace_bytes, 1, stream);
+}
+
 static int inter_group_any(const epn_inter_desc *d, const void *feats_cl, void *grouped, void *workspace,
                            size_t workspace_bytes, int bf16, epn_stream_t stream) {
     hipStream_t st = epn_stream(stream);

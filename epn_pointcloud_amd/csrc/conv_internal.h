@@ -79,6 +79,12 @@ int launch_inverse_list(const int32_t *idx, int b, int p1, int p2, int nn, int32
 int launch_inter_ungroup_det_mfma(const epn_inter_desc *d, const float *rk4, const void *dG, void *dF, void *slab,
                                   const int32_t *off, const int32_t *ent, int bf16, hipStream_t st,
                                   int32_t *order = nullptr, unsigned char *canon = nullptr);
+// inter_fx.hip: InterSO3Conv with the grouped features kept on chip (grouping = A-tile producer of the weight contraction);
+// fp32 features: lossless 3 x bf16 split on the bf16 MFMAs; bf16 features: bf16 MFMAs.  planes: inter_fx_planes_bytes bytes
+bool inter_fx_ok(const epn_inter_desc *d, int bf16);
+size_t inter_fx_planes_bytes(const epn_inter_desc *d, int bf16);
+int launch_inter_fx_fwd(const epn_inter_desc *d, const float *rk4, const void *feats, const float *W, void *out,
+                        void *planes, int bf16, hipStream_t st);
 bool intra_uses_mfma(int na, int kn, int cin, int cout);
 size_t intra_workspace_floats(int kn, int cin, int cout);
 int launch_intra_fwd_mfma(const float *feats, const int32_t *iidx, const float *W, int b, int p, int na, int kn,

@@ -386,6 +386,71 @@ class InterSO3ConvSplitFn(torch.autograd.Function):
         return gf, gW, None
 
 
+def _onchip_workspace(lib, d, bf16, device):
+    nbytes = lib.epn_inter_onchip_workspace_bytes(ctypes.byref(d), int(bf16))
+    ws = torch.empty(max(int(nbytes), 16), dtype=torch.uint8, device=device)
+    return ws, ctypes.c_void_p(ws.data_ptr()), ctypes.c_size_t(ws.numel())
+
+
+def inter_onchip_ok(feats, W, geo):
+    """Does the on-chip form (csrc/inter_fx.hip: grouping = A-tile producer of the weight contraction) take this layer?"""
+    if isinstance(geo, DenseInterWeights) or not feats.is_cuda or feats.dtype not in FEATURE_DTYPES:
+        return False
+    if feats.dtype == torch.float32 and gemm.FP32_MODE != "split":
+        return False                      # the on-chip fp32 form IS the split (3 x bf16) contraction
+    d = geo.desc(feats.shape[1], W.shape[0])
+    return bool(_lib.get_lib().epn_inter_onchip_ok(ctypes.byref(d), int(feats.dtype == torch.bfloat16)))
+
+
+def inter_onchip_fwd(f, Wc, geo):
+    """out_cl [b, cout, p2, na] (channels-last) of InterSO3Conv with no [cols, cin*ks] tensor (epn_inter_so3conv_fwd_onchip_f32 /
+    epn_inter_so3conv_fwd_bf16)."""
+    lib = _lib.get_lib()
+    cout, ck = Wc.shape
+    cin = f.shape[1]
+    d = geo.desc(cin, cout)
+    if ck != cin * d.ks or f.shape[2] != d.p1 or f.shape[3] != d.na or f.shape[0] != d.b:
+        raise ValueError(f"shape mismatch: feats {tuple(f.shape)}, W {tuple(Wc.shape)}, geometry "
+                         f"b={d.b} p1={d.p1} na={d.na} ks={d.ks}")
+    bf = f.dtype == torch.bfloat16
+    out = empty_cl(d.b, cout, d.p2, d.na, f.device, f.dtype)
+    ws, wsp, wsn = _onchip_workspace(lib, d, bf, f.device)
+    fn = lib.epn_inter_so3conv_fwd_bf16 if bf else lib.epn_inter_so3conv_fwd_onchip_f32
+    _lib.check(_launch("inter_fwd_onchip", _inter_key(d), _inter_flops(d), f.device,
+                       lambda: fn(ctypes.byref(d), _cl_ptr(f), _lib.dev_ptr(Wc, "W"), _cl_ptr(out), wsp, wsn,
+                                  _lib.stream_of(f))), "inter_so3conv_fwd_onchip")
+    return out
+
+
+class InterSO3ConvOnChipFn(torch.autograd.Function):
+    """InterSO3Conv with the grouped features kept on chip (csrc/inter_fx.hip): forward saves only its inputs."""
+
+    @staticmethod
+    def forward(ctx, feats, W, geo):
+        f = to_cl(feats)
+        Wc = W.contiguous()
+        out = inter_onchip_fwd(f, Wc, geo)
+        ctx.save_for_backward(f, Wc)
+        ctx.geo = geo
+        return out
+
+    @staticmethod
+    def backward(ctx, grad_out):
+        f, Wc = ctx.saved_tensors
+        geo = ctx.geo
+        need_f, need_w = ctx.needs_input_grad[0], ctx.needs_input_grad[1]
+        # interim: transposes through the split form (grouped features recomputed, not saved)
+        with torch.enable_grad():
+            fd = f.detach().requires_grad_(need_f)
+            Wd = Wc.detach().requires_grad_(need_w)
+            y = InterSO3ConvSplitFn.apply(fd, Wd, geo)
+        ins = [t for t, n in ((fd, need_f), (Wd, need_w)) if n]
+        grads = list(torch.autograd.grad(y, ins, grad_out))
+        gf = grads.pop(0) if need_f else None
+        gW = grads.pop(0) if need_w else None
+        return gf, gW, None
+
+
 _SIDE = {}
 
 
@@ -937,6 +1002,8 @@ def inter_so3conv(feats, W, geo, out_dtype=None):
     mode = inter_mode()
     out_dtype = out_dtype or feats.dtype
     split_ok = feats.shape[1] % 16 == 0 and not isinstance(geo, DenseInterWeights)
+    if mode == "onchip" and split_ok and inter_onchip_ok(feats, W, geo):
+        return cast_feats(InterSO3ConvOnChipFn.apply(feats, W, geo), out_dtype)
     if feats.dtype == torch.bfloat16 and split_ok:
         return cast_feats(InterSO3ConvSplitFn.apply(feats, W, geo), out_dtype)
     if feats.dtype != torch.float32:         # shapes only the fp32 fused / generic kernels take

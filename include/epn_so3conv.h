@@ -196,6 +196,22 @@ int epn_initial_anchor_query_f32(const float *centers, const float *xyz, const f
                                  int m, int na, int ks, float radius, float sigma, float *anchor_weights,
                                  float *anchor_ctn, epn_stream_t stream);
 
+/* InterSO3Conv with the grouped features kept ON CHIP (north_star: "the [B,N,K,A,C] tile staged through LDS"): the same
+ * result as epn_inter_so3conv_fwd_f32 -- vgtk/vgtk/so3conv/modules.py:157-174 = inter_so3conv_grouping
+ * (vgtk/vgtk/spconv/functional.py:372-390) -> BasicSO3Conv (modules.py:48-55) -- with the neighbour contraction as the
+ * A-tile producer of the weight contraction; no [cols, cin*ks] tensor is written.
+ *   _onchip_f32: fp32 features / output; the weight contraction runs on the bf16 matrix pipe with both operands split
+ *                losslessly into three bf16 pieces (as epn_gemm_nt_split_f32: fp32 accuracy; non-finite inputs give NaN).
+ *   _bf16:       bf16 features / output ("bf16 features, fp32 accumulate"), W fp32 master weights (rounded per call).
+ * Shapes served: epn_inter_onchip_ok(d, bf16) != 0 (cin % 16 == 0, cout % 32 == 0, cout <= 256, ks in {16, 24},
+ * nn <= 64, 32 < na <= 64, no dense_w); EPN_EINVAL otherwise.  Workspace: epn_inter_onchip_workspace_bytes. */
+int epn_inter_onchip_ok(const epn_inter_desc *d, int bf16);
+size_t epn_inter_onchip_workspace_bytes(const epn_inter_desc *d, int bf16);
+int epn_inter_so3conv_fwd_onchip_f32(const epn_inter_desc *d, const float *feats_cl, const float *W, float *out_cl,
+                                     void *workspace, size_t workspace_bytes, epn_stream_t stream);
+int epn_inter_so3conv_fwd_bf16(const epn_inter_desc *d, const void *feats_cl, const float *W, void *out_cl,
+                               void *workspace, size_t workspace_bytes, epn_stream_t stream);
+
 /* ---------------------------------------------------------------------------------------------------------------------
  * Grouping only ("split" convolution): the grouped features as a tensor, the weight contraction left to the caller's
  * BLAS.  replaces vgtk/vgtk/so3conv/functional.py:118-140 (inter_so3conv_grouping: ball grouping + anchor weights +
