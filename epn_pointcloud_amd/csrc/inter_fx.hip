@@ -104,13 +104,21 @@ __global__ void fx_prep_w_kernel(const float *__restrict__ W, int cout, int cin,
     }
 }
 
-template <typename TF, int NT, int PT, int WGM, int WGN, int TN>
+// One production item = one column (anchor) of this wave for one kernel-point block kt of one 16-channel chunk: its
+// gathers / table reads are ISSUED one stage before its MFMAs run (the stage barrier's vmcnt(0) lands them), and its D
+// fragment waits in registers until the phase that consumes it starts.  Per chunk (ks = 24):
+//   fp32 features:  A (4 stages: kernel points 0..15, D registers {0,1})   produces kt = 1 of this chunk, columns 0 .. CPW/2
+//                   B (4 stages: D registers {2,3})                        produces kt = 1, columns CPW/2 .. CPW
+//                   C (4 stages: kernel points 16..23)                     produces kt = 0 of the NEXT chunk
+//   bf16 features:  A (8 stages: kernel points 0..15)                      produces kt = 1 of this chunk
+//                   C (4 stages)                                           produces kt = 0 of the next chunk
+template <typename TF, int NT, int PT, int WGM, int WGN, int TN, int KS>
 __global__ __launch_bounds__(512) void inter_fx_fwd_kernel(FxArgs F) {
     constexpr bool X3 = std::is_same<TF, float>::value;
     constexpr int NP = X3 ? 3 : 1;
     constexpr bool HALF = X3;
     constexpr int NWV = 8;
-    static_assert(WGM * WGN == NWV, "eight waves");
+    static_assert(WGM * WGN * KS == NWV, "eight waves");
     constexpr int BM = 64 * PT, TM = BM / (32 * WGM), BN = WGN * TN * 32, CPW = BM / NWV;
     static_assert(TM >= 1 && TM * 32 * WGM == BM, "row tiles");
     constexpr int PITCH = HALF ? 256 : 512;
@@ -118,7 +126,9 @@ __global__ __launch_bounds__(512) void inter_fx_fwd_kernel(FxArgs F) {
     constexpr int P_BYTES = BN * 64, W_STAGE = NP * P_BYTES;
     constexpr int NGB = NP * BN / 16;                 // 1 KiB wave-level load instructions per W stage
     constexpr int GPW = (NGB + NWV - 1) / NWV;
+    constexpr int NACC = (X3 && TM * TN == 1) ? 2 : 1;   // a lone tile: two accumulators break the six-MFMA dependency chain
     static_assert(A_BYTES + 2 * W_STAGE <= 160 * 1024, "LDS");
+    static_assert(KS == 1 || BM * BN * 4 <= A_BYTES, "K-split reduction buffer");
     __shared__ __attribute__((aligned(1024))) char smem[A_BYTES + 2 * W_STAGE];
     char *const atile = smem;
     char *const wring = smem + A_BYTES;
@@ -139,11 +149,126 @@ __global__ __launch_bounds__(512) void inter_fx_fwd_kernel(FxArgs F) {
     Hood<NT> h;
     load_hood<NT>(A, bb, pp, x, j, h);
     const TF *fslab = reinterpret_cast<const TF *>(A.feats) + ((size_t)bb * A.p1) * A.na * A.cin;
-    RawHood<NT> rh;
-    if constexpr (!X3) {
-        Seg<NT> sg; sg.h = h;
-        make_raw_hood<NT>(sg, x, rh);
+    unsigned okmask[NT][2];                              // bf16: 0xffff per valid neighbour slot, packed like the values
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+        okmask[t][0] = (h.ok[t][0] ? 0xffffu : 0u) | (h.ok[t][1] ? 0xffff0000u : 0u);
+        okmask[t][1] = (h.ok[t][2] ? 0xffffu : 0u) | (h.ok[t][3] ? 0xffff0000u : 0u);
     }
+    // Gathers and table reads use buffer loads: descriptor = this cloud's feature slab / the (R_a kappa_k) table
+    // (wave-uniform), voffset = neighbour row + this lane's channel (column-independent), soffset = anchor * cin + chunk
+    // (wave-uniform): nothing per column is left for the compiler to precompute and keep alive across the unrolled columns.
+    const __amdgpu_buffer_rsrc_t rF = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<TF *>(fslab), 0, (unsigned)A.p1 * A.na * A.cin * (unsigned)sizeof(TF), 0x00020000);
+    const __amdgpu_buffer_rsrc_t rT = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<float *>(A.rk4), 0, (unsigned)A.na * EPN_KS_MAX * 16u, 0x00020000);
+    int vq[NT][4];
+#pragma unroll
+    for (int t = 0; t < NT; ++t)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) vq[t][r] = (h.q[t][r] + x) * (int)sizeof(TF);
+    const int vt_rk = (x * 4 + (j < 3 ? j : 3)) * 4, vt_beta = (x * 4 + 3) * 4;
+
+    struct Pend {                                        // loads of one production item in flight
+        float f[NT][4];
+        float e, beta;
+    };
+    auto issue = [&](Pend &P, int a, int ct, int kt) {
+        const int soff = (a * A.cin + 16 * ct) * (int)sizeof(TF);
+#pragma unroll
+        for (int t = 0; t < NT; ++t)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                if constexpr (X3) P.f[t][r] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rF, vq[t][r], soff, 0));
+                else P.f[t][r] = __uint_as_float((unsigned)(unsigned short)__builtin_amdgcn_raw_buffer_load_b16(rF, vq[t][r], soff, 0));
+            }
+        const int toff = (a * EPN_KS_MAX + 16 * kt) * 16;
+        P.e = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rT, vt_rk, toff, 0));
+        P.beta = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rT, vt_beta, toff, 0));
+    };
+    // weights by S-MFMA (make_weights of inter_device.h, one kernel-point block) + neighbour contraction -> D fragment:
+    // lane (x, j), register r -> kernel point 16kt + 4j + r, channel x
+    auto compute = [&](const Pend &P) -> f32x4 {
+        const float rk = j == 3 ? 1.0f : P.e;
+        f32x4 w[NT];
+#pragma unroll
+        for (int t = 0; t < NT; ++t) {
+            f32x4 sv = {P.beta, P.beta, P.beta, P.beta};
+            sv = mfma4(h.gA[t], rk, sv);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) sv[r] = relu_f(sv[r]);
+            w[t] = sv;
+        }
+        f32x4 g = {0.f, 0.f, 0.f, 0.f};
+        if constexpr (X3) {
+#pragma unroll
+            for (int t = 0; t < NT; ++t)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) g = mfma4(w[t][r], h.ok[t][r] ? P.f[t][r] : 0.0f, g);
+        } else {
+            bf16x4_t fb4[NT];
+#pragma unroll
+            for (int t = 0; t < NT; ++t) {
+                u32x2 pk;
+                pk[0] = (__float_as_uint(P.f[t][0]) | (__float_as_uint(P.f[t][1]) << 16)) & okmask[t][0];
+                pk[1] = (__float_as_uint(P.f[t][2]) | (__float_as_uint(P.f[t][3]) << 16)) & okmask[t][1];
+                fb4[t] = __builtin_bit_cast(bf16x4_t, pk);
+            }
+            if constexpr (NT % 2 == 0) {
+#pragma unroll
+                for (int t = 0; t < NT; t += 2) g = mfma_bf16_k32(pack4(w[t]), pack4(w[t + 1]), fb4[t], fb4[t + 1], g);
+            } else {
+#pragma unroll
+                for (int t = 0; t < NT; ++t) g = mfma_bf16_k16(pack4(w[t]), fb4[t], g);
+            }
+        }
+        return g;
+    };
+    // D fragments waiting for their phase: fp32 features keep fp32 (split at the deposit), bf16 features keep packed pairs
+    constexpr int GR = X3 ? 4 : 2;
+    float gk0[CPW][GR], gk1[CPW][GR];
+    auto keep = [&](float (&dst)[GR], const f32x4 g) {
+        if constexpr (X3) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) dst[r] = g[r];
+        } else {
+            dst[0] = __uint_as_float(pack_rne(g[0], g[1]));
+            dst[1] = __uint_as_float(pack_rne(g[2], g[3]));
+        }
+    };
+#pragma unroll
+    for (int q = 0; q < CPW; ++q)
+#pragma unroll
+        for (int r = 0; r < GR; ++r) gk0[q][r] = gk1[q][r] = 0.f;
+
+    // deposits (rows of padding anchors carry zeros)
+    auto deposit_pair = [&](int q, float v0, float v1) {   // HALF: two D registers -> positions 2 (16j + x) + {0, 1}
+        unsigned hh, mm, ll;
+        split_pair(v0, v1, hh, mm, ll);
+        const int row = prow0 + q;
+        char *arow = atile + row * PITCH;
+        const int off = (((4 * j + (x >> 2)) ^ (row & 15)) << 4) + (x & 3) * 4;
+        *reinterpret_cast<unsigned *>(arow + off) = hh;
+        *reinterpret_cast<unsigned *>(arow + A_PLANE + off) = mm;
+        *reinterpret_cast<unsigned *>(arow + 2 * A_PLANE + off) = ll;
+    };
+    auto deposit_quad = [&](int q, const float (&g)[GR], bool lanes) {   // four D registers -> positions 4 (16j + x) + r
+        const int row = prow0 + q;
+        char *arow = atile + row * PITCH;
+        const int off = (((8 * j + (x >> 1)) ^ (row & 15)) << 4) + (x & 1) * 8;
+        if constexpr (X3) {
+            unsigned h0, m0, l0, h1, m1, l1;
+            split_pair(g[0], g[1], h0, m0, l0);
+            split_pair(g[X3 ? 2 : 0], g[X3 ? 3 : 1], h1, m1, l1);
+            if (lanes) {
+                *reinterpret_cast<u32x2 *>(arow + off) = u32x2{h0, h1};
+                *reinterpret_cast<u32x2 *>(arow + A_PLANE + off) = u32x2{m0, m1};
+                *reinterpret_cast<u32x2 *>(arow + 2 * A_PLANE + off) = u32x2{l0, l1};
+            }
+        } else {
+            if (lanes) *reinterpret_cast<u32x2 *>(arow + off) = u32x2{__float_as_uint(g[0]), __float_as_uint(g[1])};
+        }
+    };
 
     // ---- W ring: source pointers of this wave's load instructions (as gemm_nt_x3_kernel, planes only)
     const char *wsrc[GPW];
@@ -168,7 +293,9 @@ __global__ __launch_bounds__(512) void inter_fx_fwd_kernel(FxArgs F) {
     };
 
     // ---- consumer set-up
-    const int wm = wave / WGN, wn = wave % WGN;
+    const int kh = wave / (WGM * WGN);                   // K split: this wave's 16-position half of every stage
+    const int wmn = wave % (WGM * WGN);
+    const int wm = wmn / WGN, wn = wmn % WGN;
     const int li = lane & 31, lj = lane >> 5;
     const int fswB = (li >> 2) & 3;
     int aoff[TM], boff[TN];
@@ -178,29 +305,63 @@ __global__ __launch_bounds__(512) void inter_fx_fwd_kernel(FxArgs F) {
     for (int i = 0; i < TN; ++i) boff[i] = ((wn * TN + i) * 32 + li) * 64;
     const int fswA = li & 15;                            // row & 15 (tile rows of a fragment are 32-aligned + li)
 
-    f32x16 acc[TM][TN];
+    f32x16 acc[NACC][TM][TN];
 #pragma unroll
-    for (int i = 0; i < TM; ++i)
+    for (int c = 0; c < NACC; ++c)
 #pragma unroll
-        for (int jn = 0; jn < TN; ++jn)
+        for (int i = 0; i < TM; ++i)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) acc[i][jn][r] = 0.f;
+            for (int jn = 0; jn < TN; ++jn)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[c][i][jn][r] = 0.f;
 
     const int nstage = F.KP / 32;
+    const int nchunk = A.cin >> 4;
     int gs = 0;                                          // W stage counter
     wstage(0);
 
-    // nst K32 stages over A-tile slots [2 * 2 * s, ...)
-    auto run_stages = [&](int nst) {
-        for (int s = 0; s < nst; ++s) {
-            // explicit: hipcc's own count lets a direct-to-LDS load issued before the producer phase ride on the partial
-            // vmcnt(N) waits of the gathers issued after it -- measured on gfx950: the ring slot is then read before it landed
+    constexpr int CSMAX = CPW / 4 > 0 ? CPW / 4 : 1;
+    Pend pend[CSMAX];
+
+    // One phase = NST stages over the A tile as deposited.  Stage s runs the MFMAs of the CS production items whose loads
+    // are pending (kernel-point block KT of chunk ct_job, columns Q0 + s CS ..) and issues the loads of the following
+    // items: the next stage's, or (last stage) the first CSN columns of the next phase's job (KTN of chunk ct_next).
+    auto phase = [&](auto nst_c, auto kt_c, auto q0_c, auto cs_c, auto ktn_c, auto q0n_c, auto csn_c, int ct_job, int ct_next,
+                     float (&gdst)[CPW][GR]) {
+        constexpr int NST = decltype(nst_c)::value, KT = decltype(kt_c)::value, Q0 = decltype(q0_c)::value;
+        constexpr int CS = decltype(cs_c)::value, KTN = decltype(ktn_c)::value, CSN = decltype(csn_c)::value;
+        constexpr int Q0N = decltype(q0n_c)::value;
+        int ab = a_base;
+        asm volatile("" : "+s"(ab));                     // opaque: per-column scalars are not hoisted out of the chunk loop
+#pragma unroll
+        for (int s = 0; s < NST; ++s) {
+            // explicit: hipcc's own count lets a direct-to-LDS load issued before other loads ride on their partial
+            // vmcnt(N) waits -- measured on gfx950: the ring slot is then read before it landed
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             __syncthreads();                             // deposits visible, W stage gs landed, ring slot (gs+1)&1 free
             if (gs + 1 < nstage) wstage((gs + 1) & 1);
+            // ---- production: this stage's items
+            if (ct_job < nchunk) {
+#pragma unroll
+                for (int c = 0; c < CS; ++c) {
+                    const int q = Q0 + s * CS + c;
+                    if (ab + q < A.na) keep(gdst[q], compute(pend[c]));
+                }
+            }
+            if (s + 1 < NST) {
+                if (ct_job < nchunk) {
+#pragma unroll
+                    for (int c = 0; c < CS; ++c) issue(pend[c], ab + Q0 + (s + 1) * CS + c, ct_job, KT);
+                }
+            } else if (ct_next < nchunk) {
+#pragma unroll
+                for (int c = 0; c < CSN; ++c) issue(pend[c], ab + Q0N + c, ct_next, KTN);
+            }
+            // ---- weight contraction over this stage's 32 positions
             const char *wb = wring + (gs & 1) * W_STAGE;
 #pragma unroll
             for (int sub = 0; sub < 2; ++sub) {
+                if (KS == 2 && sub != kh) continue;
                 const int slotA = 2 * (2 * s + sub) + lj;
                 const int sa = (slotA ^ fswA) * 16;
                 const int sb = ((2 * sub + lj) ^ fswB) * 16;
@@ -215,165 +376,94 @@ __global__ __launch_bounds__(512) void inter_fx_fwd_kernel(FxArgs F) {
 #pragma unroll
                     for (int p = 0; p < NP; ++p)
                         bfr[jn][p] = *reinterpret_cast<const bf16x8 *>(wb + p * P_BYTES + boff[jn] + sb);
-#define EPN_FX_TERM(PA, PB)                                                                                   \
+#define EPN_FX_TERM(C_, PA, PB)                                                                              \
     _Pragma("unroll") for (int i = 0; i < TM; ++i) _Pragma("unroll") for (int jn = 0; jn < TN; ++jn)         \
-        acc[i][jn] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i][PA], bfr[jn][PB], acc[i][jn], 0, 0, 0)
+        acc[C_][i][jn] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i][PA], bfr[jn][PB], acc[C_][i][jn], 0, 0, 0)
                 if constexpr (X3) {
-                    EPN_FX_TERM(0, 2); EPN_FX_TERM(2, 0); EPN_FX_TERM(1, 1);      // small terms first
-                    EPN_FX_TERM(0, 1); EPN_FX_TERM(1, 0); EPN_FX_TERM(0, 0);
+                    EPN_FX_TERM(0, 0, 2); EPN_FX_TERM(NACC - 1, 2, 0); EPN_FX_TERM(0, 1, 1);      // small terms first
+                    EPN_FX_TERM(NACC - 1, 0, 1); EPN_FX_TERM(0, 1, 0); EPN_FX_TERM(NACC - 1, 0, 0);
                 } else {
-                    EPN_FX_TERM(0, 0);
+                    EPN_FX_TERM(0, 0, 0);
                 }
 #undef EPN_FX_TERM
             }
             ++gs;
         }
     };
+    using I0 = std::integral_constant<int, 0>;
+    using I1 = std::integral_constant<int, 1>;
+    using I4 = std::integral_constant<int, 4>;
+    using I8 = std::integral_constant<int, 8>;
+    using IH = std::integral_constant<int, CPW / 2>;
+    using IC8 = std::integral_constant<int, (CPW / 8 > 0 ? CPW / 8 : 1)>;
+    using IC4 = std::integral_constant<int, CPW / 4>;
+    static_assert(CPW >= 8, "eight columns per wave at least");
 
-    // Gathers and table reads use buffer loads: descriptor = this cloud's feature slab / the (R_a kappa_k) table
-    // (wave-uniform), voffset = neighbour row + this lane's channel (column-independent), soffset = anchor * cin + chunk
-    // (wave-uniform): nothing per column is left for the compiler to precompute and keep alive across the unrolled columns.
-    const __amdgpu_buffer_rsrc_t rF = __builtin_amdgcn_make_buffer_rsrc(
-        const_cast<TF *>(fslab), 0, (unsigned)A.p1 * A.na * A.cin * (unsigned)sizeof(TF), 0x00020000);
-    const __amdgpu_buffer_rsrc_t rT = __builtin_amdgcn_make_buffer_rsrc(
-        const_cast<float *>(A.rk4), 0, (unsigned)A.na * EPN_KS_MAX * 16u, 0x00020000);
-    int vq[NT][4];
+    // ---- prologue: kernel points 0..15 of chunk 0, not overlapped; then the first loads of the pipeline
+    {
+        int ab = a_base;
+        asm volatile("" : "+s"(ab));
 #pragma unroll
-    for (int t = 0; t < NT; ++t)
+        for (int q0 = 0; q0 < CPW; q0 += CSMAX) {
 #pragma unroll
-        for (int r = 0; r < 4; ++r) vq[t][r] = (h.q[t][r] + x) * (int)sizeof(TF);
-    const int vt_rk = (x * 4 + (j < 3 ? j : 3)) * 4, vt_beta = (x * 4 + 3) * 4;
-    auto gather = [&](int a, int ct, float (&f)[NT][4]) {
-        const int soff = (a * A.cin + 16 * ct) * (int)sizeof(TF);
+            for (int c = 0; c < CSMAX; ++c) issue(pend[c], ab + q0 + c, 0, 0);
 #pragma unroll
-        for (int t = 0; t < NT; ++t)
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                if constexpr (X3) f[t][r] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rF, vq[t][r], soff, 0));
-                else f[t][r] = __uint_as_float((unsigned)(unsigned short)__builtin_amdgcn_raw_buffer_load_b16(rF, vq[t][r], soff, 0));
-            }
-    };
-    // kernel-influence weights of one column for ONE kernel-point block kt (make_weights of inter_device.h, one block):
-    // lane (x, j), register r -> k = 16kt + x, n = 16t + 4j + r
-    auto weights = [&](int a, int kt, f32x4 (&w)[NT]) {
-        const int soff = (a * EPN_KS_MAX + 16 * kt) * 16;
-        const float e = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rT, vt_rk, soff, 0));
-        const float beta = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rT, vt_beta, soff, 0));
-        const float rk = j == 3 ? 1.0f : e;
-#pragma unroll
-        for (int t = 0; t < NT; ++t) {
-            f32x4 sv = {beta, beta, beta, beta};
-            sv = mfma4(h.gA[t], rk, sv);
-#pragma unroll
-            for (int r = 0; r < 4; ++r) sv[r] = relu_f(sv[r]);
-            w[t] = sv;
+            for (int c = 0; c < CSMAX; ++c)
+                if (ab + q0 + c < A.na) keep(gk0[q0 + c], compute(pend[c]));
         }
-    };
-
-    float gst[CPW][2];                                   // HALF: D registers {2,3} of the first kernel-point block
 #pragma unroll
-    for (int q = 0; q < CPW; ++q) gst[q][0] = gst[q][1] = 0.f;
-    const int nchunk = A.cin >> 4;
-    // ---- produce kernel-point block KT of this wave's columns for chunk ct, deposit
-    auto produce = [&](auto kt_c, int ct) {
-            constexpr int kt = decltype(kt_c)::value;
-            int ab = a_base;
-            asm volatile("" : "+s"(ab));                 // opaque: per-column scalars are not hoisted out of the chunk loop
-            float fcur[NT][4], fnext[NT][4];
-            gather(ab, ct, fcur);
-#pragma unroll
-            for (int q = 0; q < CPW; ++q) {
-                const int a = ab + q;
-                if (a < A.na) {
-                    gather(q + 1 < CPW ? a + 1 : a, ct, fnext);   // anchors >= na: the descriptor clamps (zeros), unused
-                    f32x4 w[NT];
-                    weights(a, kt, w);
-                    f32x4 g = {0.f, 0.f, 0.f, 0.f};
-                    if constexpr (X3) {
-#pragma unroll
-                        for (int t = 0; t < NT; ++t)
-#pragma unroll
-                            for (int r = 0; r < 4; ++r) g = mfma4(w[t][r], h.ok[t][r] ? fcur[t][r] : 0.0f, g);
-                    } else {
-                        bf16x4_t fb4[NT];
-#pragma unroll
-                        for (int t = 0; t < NT; ++t) {
-                            u32x2 pk;
-                            pk[0] = (__float_as_uint(fcur[t][0]) | (__float_as_uint(fcur[t][1]) << 16)) & rh.mask[t][0];
-                            pk[1] = (__float_as_uint(fcur[t][2]) | (__float_as_uint(fcur[t][3]) << 16)) & rh.mask[t][1];
-                            fb4[t] = __builtin_bit_cast(bf16x4_t, pk);
-                        }
-                        if constexpr (NT % 2 == 0) {
-#pragma unroll
-                            for (int t = 0; t < NT; t += 2) g = mfma_bf16_k32(pack4(w[t]), pack4(w[t + 1]), fb4[t], fb4[t + 1], g);
-                        } else {
-#pragma unroll
-                            for (int t = 0; t < NT; ++t) g = mfma_bf16_k16(pack4(w[t]), fb4[t], g);
-                        }
-                    }
-                    const int row = prow0 + q;
-                    char *arow = atile + row * PITCH;
-                    const int sw = row & 15;
-                    if constexpr (X3) {
-                        if (kt == 0) {
-                            unsigned hh, mm, ll;
-                            split_pair(g[0], g[1], hh, mm, ll);
-                            const int off = (((4 * j + (x >> 2)) ^ sw) << 4) + (x & 3) * 4;
-                            *reinterpret_cast<unsigned *>(arow + off) = hh;
-                            *reinterpret_cast<unsigned *>(arow + A_PLANE + off) = mm;
-                            *reinterpret_cast<unsigned *>(arow + 2 * A_PLANE + off) = ll;
-                            gst[q][0] = g[2]; gst[q][1] = g[3];
-                        } else if (16 + 4 * j < A.ks) {
-                            unsigned h0, m0, l0, h1, m1, l1;
-                            split_pair(g[0], g[1], h0, m0, l0);
-                            split_pair(g[2], g[3], h1, m1, l1);
-                            const u32x2 hh = {h0, h1}, mm = {m0, m1}, ll = {l0, l1};
-                            const int off = (((8 * j + (x >> 1)) ^ sw) << 4) + (x & 1) * 8;
-                            *reinterpret_cast<u32x2 *>(arow + off) = hh;
-                            *reinterpret_cast<u32x2 *>(arow + A_PLANE + off) = mm;
-                            *reinterpret_cast<u32x2 *>(arow + 2 * A_PLANE + off) = ll;
-                        }
-                    } else {
-                        if (kt == 0 || 16 + 4 * j < A.ks) {
-                            u32x2 v;
-                            v[0] = pack_rne(g[0], g[1]); v[1] = pack_rne(g[2], g[3]);
-                            const int off = (((8 * j + (x >> 1)) ^ sw) << 4) + (x & 1) * 8;
-                            *reinterpret_cast<u32x2 *>(arow + off) = v;
-                        }
-                    }
-#pragma unroll
-                    for (int t = 0; t < NT; ++t)
-#pragma unroll
-                        for (int r = 0; r < 4; ++r) fcur[t][r] = fnext[t][r];
-                }
-                __builtin_amdgcn_sched_barrier(0);       // keep the unrolled columns apart (register pressure)
-            }
-    };
+        for (int c = 0; c < IC8::value; ++c) issue(pend[c], ab + c, 0, 1);
+    }
 
     for (int ct = 0; ct < nchunk; ++ct) {
         __syncthreads();                                 // every wave is done reading the A tile
-        produce(std::integral_constant<int, 0>{}, ct);
-        run_stages(HALF ? 4 : 8);
         if constexpr (HALF) {
+#pragma unroll
+            for (int q = 0; q < CPW; ++q) deposit_pair(q, gk0[q][0], gk0[q][1]);
+            phase(I4{}, I1{}, I0{}, IC8{}, I1{}, IH{}, IC8{}, ct, ct, gk1);      // A: produces kt 1, columns 0 .. CPW/2
             __syncthreads();
 #pragma unroll
-            for (int q = 0; q < CPW; ++q) {              // rows of padding anchors carry zeros
-                unsigned hh, mm, ll;
-                split_pair(gst[q][0], gst[q][1], hh, mm, ll);
-                const int row = prow0 + q;
-                char *arow = atile + row * PITCH;
-                const int off = (((4 * j + (x >> 2)) ^ (row & 15)) << 4) + (x & 3) * 4;
-                *reinterpret_cast<unsigned *>(arow + off) = hh;
-                *reinterpret_cast<unsigned *>(arow + A_PLANE + off) = mm;
-                *reinterpret_cast<unsigned *>(arow + 2 * A_PLANE + off) = ll;
-            }
-            run_stages(4);
+            for (int q = 0; q < CPW; ++q) deposit_pair(q, gk0[q][GR - 2], gk0[q][GR - 1]);
+            phase(I4{}, I1{}, IH{}, IC8{}, I0{}, I0{}, IC4{}, ct, ct + 1, gk1);  // B: kt 1, columns CPW/2 .. CPW
+        } else {
+#pragma unroll
+            for (int q = 0; q < CPW; ++q) deposit_quad(q, gk0[q], true);
+            phase(I8{}, I1{}, I0{}, IC8{}, I0{}, I0{}, IC4{}, ct, ct + 1, gk1);  // A: 8 stages, produces kt 1
         }
-        if (F.kq1) {
-            __syncthreads();
-            produce(std::integral_constant<int, 1>{}, ct);
-            run_stages(F.kq1 / 32);
+        __syncthreads();
+#pragma unroll
+        for (int q = 0; q < CPW; ++q) deposit_quad(q, gk1[q], 16 + 4 * j < A.ks);
+        phase(I4{}, I0{}, I0{}, IC4{}, I1{}, I0{}, IC8{}, ct + 1, ct + 1, gk0);  // C: produces kt 0 of the next chunk
+    }
+
+    // ---- K split: the second half's partial sums go through LDS (the A tile is free now)
+    if constexpr (NACC == 2) {
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int jn = 0; jn < TN; ++jn)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[0][i][jn][r] += acc[1][i][jn][r];
+    }
+    if constexpr (KS == 2) {
+        __syncthreads();
+        float *red = reinterpret_cast<float *>(atile) + (size_t)wmn * (TM * TN * 16 * 64);
+        if (kh == 1) {
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int jn = 0; jn < TN; ++jn)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) red[((i * TN + jn) * 16 + r) * 64 + lane] = acc[0][i][jn][r];
         }
+        __syncthreads();
+        if (kh == 1) return;
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int jn = 0; jn < TN; ++jn)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[0][i][jn][r] += red[((i * TN + jn) * 16 + r) * 64 + lane];
     }
 
     // ---- epilogue: D[row = (r&3) + 8 (r>>2) + 4 lj][n = li]; tile row -> (point, anchor)
@@ -389,8 +479,8 @@ __global__ __launch_bounds__(512) void inter_fx_fwd_kernel(FxArgs F) {
                 for (int jn = 0; jn < TN; ++jn) {
                     const int n = (wn * TN + jn) * 32 + li;
                     if (n < A.cout) {
-                        if constexpr (X3) static_cast<float *>(F.out)[o0 + n] = acc[i][jn][r];
-                        else static_cast<__bf16 *>(F.out)[o0 + n] = (__bf16)acc[i][jn][r];
+                        if constexpr (X3) static_cast<float *>(F.out)[o0 + n] = acc[0][i][jn][r];
+                        else static_cast<__bf16 *>(F.out)[o0 + n] = (__bf16)acc[0][i][jn][r];
                     }
                 }
             }
@@ -406,7 +496,7 @@ static inline int fx_kp(const epn_inter_desc *d) { return (d->cin / 16) * (256 +
 bool inter_fx_ok(const epn_inter_desc *d, int bf16) {
     (void)bf16;
     return inter_mfma_available() && !d->dense_w && d->cin % 16 == 0 && d->cin >= 16 && d->cout % 32 == 0 &&
-           d->cout >= 32 && d->cout <= 256 && (d->ks == 16 || d->ks == 24) && d->nn <= 64 && d->na > 32 &&
+           d->cout >= 32 && d->cout <= 256 && d->ks == 24 && d->nn <= 64 && d->na > 32 &&
            d->na <= 64 && (long long)d->p1 * d->na * d->cin < (1LL << 31);
 }
 
@@ -417,23 +507,22 @@ size_t inter_fx_planes_bytes(const epn_inter_desc *d, int bf16) {
 template <typename TF, int NT>
 static int launch_fx_fwd_nt(const FxArgs &F, const epn_inter_desc *d, hipStream_t st) {
     constexpr bool X3 = std::is_same<TF, float>::value;
-#define EPN_FX_GO(PT_, WGM_, WGN_, TN_)                                                                              \
+#define EPN_FX_GO(PT_, WGM_, WGN_, TN_, KS_)                                                                         \
     do {                                                                                                             \
         const unsigned grid = (unsigned)((F.npts + (PT_) - 1) / (PT_));                                              \
-        hipLaunchKernelGGL((inter_fx_fwd_kernel<TF, NT, PT_, WGM_, WGN_, TN_>), dim3(grid), dim3(512), 0, st, F);     \
+        hipLaunchKernelGGL((inter_fx_fwd_kernel<TF, NT, PT_, WGM_, WGN_, TN_, KS_>), dim3(grid), dim3(512), 0, st, F); \
         EPN_CHECK_LAUNCH();                                                                                          \
         return 0;                                                                                                    \
     } while (0)
-    if constexpr (X3) {
-        if (d->cout > 128) EPN_FX_GO(1, 2, 4, 2);      // 64 x 256: A tile 48 KB + W ring 96 KB
-        if (d->cout > 64) EPN_FX_GO(2, 4, 2, 2);       // 128 x 128: 96 + 48
-        if (d->cout > 32) EPN_FX_GO(2, 4, 2, 1);       // 128 x 64
-        EPN_FX_GO(2, 4, 2, 1);
+    if constexpr (X3) {                                // one output point per workgroup: 64 tile rows
+        if (d->cout > 128) EPN_FX_GO(1, 2, 4, 2, 1);   // 64 x 256: A tile 48 KB + W ring 96 KB
+        if (d->cout > 64) EPN_FX_GO(1, 2, 4, 1, 1);    // 64 x 128
+        EPN_FX_GO(1, 2, 2, 1, 2);                      // 64 x 64, the stage's two 16-position halves on two wave groups
     } else {
-        if (d->cout > 128) EPN_FX_GO(2, 4, 2, 4);      // 128 x 256: A tile 64 KB + W ring 32 KB
-        if (d->cout > 64) EPN_FX_GO(2, 4, 2, 2);
-        if (d->cout > 32) EPN_FX_GO(2, 4, 2, 1);
-        EPN_FX_GO(2, 4, 2, 1);
+        if (d->cout > 128) EPN_FX_GO(2, 4, 2, 4, 1);   // 128 x 256: A tile 64 KB + W ring 32 KB
+        if (d->cout > 64) EPN_FX_GO(2, 4, 2, 2, 1);
+        if (d->cout > 32) EPN_FX_GO(2, 4, 2, 1, 1);
+        EPN_FX_GO(2, 4, 1, 1, 2);
     }
 #undef EPN_FX_GO
 }

@@ -62,6 +62,14 @@ def main():
                 print(f"L{li} {l.cin:3d}->{l.cout:3d} K={l.nn:3d} p1={p1:4d} p2={p2:4d}: max|onchip-split| {err:.2e} (max|y| {ref:.2f})  "
                       f"split {ts:.3f} ms  onchip {to:.3f} ms  ({fl / to / 1e9:.0f} TFLOP/s gemm-equivalent)", flush=True)
             else:
+                extra = ""
+                if os.environ.get("FX_ABL"):
+                    from epn_pointcloud_amd import _lib
+                    for pol, nm in ((0x401, "no-gather"), (0x402, "no-table"), (0x403, "no-loads"), (0x407, "no-prod"), (0x408, "no-gemm"), (0x40f, "nothing")):
+                        _lib.get_lib().epn_set_kernel_policy(pol)
+                        extra += f" {nm} {timeit(lambda: ops.inter_onchip_fwd(f, W.contiguous(), geo)):.3f}"
+                    _lib.get_lib().epn_set_kernel_policy(0)
+                print(extra, end="")
                 print(f"L{li}: not served by the on-chip form")
         if l.stride > 1:
             _, xyz = pctk.furthest_sample(xyz, p2, l.lazy)
