@@ -32,22 +32,7 @@ if ROOT not in sys.path:
 PEAK_TFLOPS = {"f32": 157.3, "bf16": 2500.0}
 HBM_PEAK_GBS = 8000.0
 
-# C-ABI entry point (what the HIP events bracket) -> the device kernel that does its work (csrc/*.hip; template variants
-# summed; the rocprofv3 kernel trace of the same command is committed under profiles/ and lists them by name)
-KERNEL_OF = {
-    "inter_fwd": "epn::inter_fwd8_kernel", "inter_bwd_data": "epn::inter_bwd_data8_kernel",
-    "inter_bwd_weight": "epn::inter_bwd_weight8_kernel", "intra_fwd": "epn::intra_gemm_kernel",
-    "intra_bwd_data": "epn::intra_gemm_kernel", "intra_bwd_weight": "epn::intra_bwd_weight_v4_kernel",
-    "inter_group": "epn::inter_group_kernel", "inter_ungroup": "epn::inter_ungroup_shared_kernel",
-    "inter_ungroup_det": "epn::inter_ungroup_slots_kernel + inter_reduce_slots_kernel",
-    "inter_gemm": "epn::gemm_nt_kernel", "intra_gemm": "epn::gemm_nt_kernel",
-    "inter_gemm_dw": "epn::gemm_tn_kernel", "intra_gemm_dw": "epn::gemm_tn_kernel",
-    "conv1x1_gemm": "epn::gemm_nt_kernel", "conv1x1_gemm_dw": "epn::gemm_tn_kernel",
-    "intra_group": "epn::intra_group_kernel", "so3_basis": "epn::so3_basis_kernel",
-    "pointnet_fwd": "epn::pointnet_fwd_mfma_kernel", "pointnet_bwd_data": "epn::pointnet_bwd_data_kernel",
-    "pointnet_bwd_weight": "epn::pointnet_bwd_weight_kernel",
-}
-PMC_FILE = os.path.join(ROOT, "profiles", "r02_pmc_per_kernel.json")   # tools/collect_profiles.sh + pmc_summary.py
+PMC_FILE = os.path.join(ROOT, "profiles", "r03_pmc_per_kernel.json")   # tools/collect_profiles.sh + pmc_summary.py
 
 
 def recorded_traffic(kernel_family):
@@ -59,11 +44,28 @@ def recorded_traffic(kernel_family):
         return None
     tot = n = 0.0
     for name, e in pmc.items():
-        if (name == kernel_family or (("<" not in kernel_family) and
-                                      kernel_family.split("::")[-1].replace("_kernel", "") in name)) and "hbm_bytes_per_launch" in e:
+        if norm_kernel_name(name) == kernel_family and "hbm_bytes_per_launch" in e:
             tot += e["hbm_bytes_per_launch"] * e["launches"]
             n += e["launches"]
     return round(tot / n) if n else None
+
+
+def norm_kernel_name(name):
+    """rocprofv3's demangled kernel name -> the form epn_last_kernel() reports: no 'void ' prefix, no '(anonymous
+    namespace)::', no argument list."""
+    name = name.strip().strip('"')
+    if name.startswith("void "):
+        name = name[5:]
+    name = name.replace("(anonymous namespace)::", "")
+    depth = 0
+    for i, ch in enumerate(name):            # cut the argument list: the first '(' outside template brackets
+        if ch == "<":
+            depth += 1
+        elif ch == ">":
+            depth -= 1
+        elif ch == "(" and depth == 0:
+            return name[:i]
+    return name
 
 
 def parse():
@@ -86,6 +88,9 @@ def parse():
     ap.add_argument("--no-graph", action="store_true", help="eager launches instead of replaying a captured HIP graph")
     ap.add_argument("--backbone-only", action="store_true", help="without the output head")
     ap.add_argument("--model", default="cls", choices=["cls", "reg", "inv"])
+    ap.add_argument("--no-extra-configs", action="store_true",
+                    help="skip the other single-GPU configs (cls forward only, reg bf16, inv bf16) that the default run "
+                         "embeds under \"configs\"")
     ap.add_argument("--policy", default="", help="A/B switch of the tuning tools: epn_set_kernel_policy value (e.g. 0x401), see "
                                                  "include/epn_so3conv.h; default = the library's own choices")
     return ap.parse_args()
@@ -159,55 +164,137 @@ def index_kernel_line(pts, layers, dev, reps=20):
                            "us_per_cloud": round(us_bq / b, 2), "GB/s": round(bq_bytes / us_bq / 1e3, 2)}}
 
 
-def main():
-    args = parse()
-    from epn_pointcloud_amd import _lib, dp, models as M, ops, schedule as S
-    rank, local_rank, world = dp.env_world()
-    if args.gpus > 1 and world == 1 and "EPN_DP_CHILD" not in os.environ:
-        sys.exit(dp.launch(args.gpus))                  # no launcher: start the ranks ourselves
-    assert world == args.gpus, f"WORLD_SIZE={world} but --gpus {args.gpus}"
-    _lib.get_lib()                                      # fail loudly if the HIP library is missing
-    assert torch.cuda.is_available(), "bench.py needs an MI355X"
-    dev = dp.local_device(local_rank)
-    torch.cuda.set_device(dev)
-    if args.policy:
-        from epn_pointcloud_amd import _lib
-        _lib.check(_lib.get_lib().epn_set_kernel_policy(int(args.policy, 0)), "set_kernel_policy")
+WORKLOADS = {"cls": "ModelNet40 classification (cls_so3net_pn: 7 separable SO3 blocks",
+             "reg": "ModelNet40 relative rotation (reg_so3net: 7 separable SO3 blocks",
+             "inv": "3DMatch descriptor (inv_so3net_pn: 8 separable SO3 blocks"}
+HEADS = {"cls": " + ClsOutBlockPointnet head)", "reg": " + RelSO3OutBlockR head)", "inv": " + InvOutBlockMVD head)"}
 
-    dtype_name = args.dtype or ("f32" if args.model == "cls" else "bf16")
+
+def roofline_of(records, prof_steps, dtype_name, split_gemm, with_traffic, graph_mode):
+    """Roofline object of one measured workload from the per-call HIP-event records (ops.profile_end()): every record
+    carries the device kernel the library itself reported for that call (epn_last_kernel), so the names below are the
+    names rocprofv3 prints (profiles/r03_kernel_stats.csv, normalised by norm_kernel_name)."""
+    esz = 4 if dtype_name == "f32" else 2
+
+    def algo_bytes(kind, key):
+        """Algorithmic HBM bytes of the memory-bound families: operands read once + result
+        written once; the keys carry the layer dimensions."""
+        if kind in ("inter_group", "inter_ungroup", "inter_ungroup_det"):
+            b_, p1, p2, nn_, na, ks, cin, _ = key
+            feats, grouped = b_ * p1 * na * cin, b_ * p2 * na * cin * ks
+            return feats * (esz if kind == "inter_group" else 4) + grouped * esz
+        if kind == "intra_group":
+            b_, p_, na, kn, c = key[:5]
+            return b_ * p_ * na * c * esz * (1 + kn)
+        if kind == "so3_basis":
+            _, pts, c = key
+            return 2 * pts * 60 * c * esz
+        return 0
+
+    agg = {}
+    for kind, key, flops, e0, e1, kname in records:
+        k = kname or f"(host) {kind}"
+        a = agg.setdefault(k, {"ms": 0.0, "flops": 0.0, "launches": 0, "bytes": 0.0})
+        a["ms"] += e0.elapsed_time(e1)
+        a["flops"] += flops
+        a["bytes"] += algo_bytes(kind, key)
+        a["launches"] += 1
+    peak = PEAK_TFLOPS[dtype_name]
+
+    def roof(k):
+        d = agg[k]
+        ach = d["flops"] / (d["ms"] * 1e-3) / 1e12
+        traffic = recorded_traffic(k) if with_traffic else None
+        if "_x3_" in k or k.endswith("true>") or (k.startswith("epn::inter_fx") and "<float" in k):
+            # split form: every fp32 multiply-add is six bf16 MFMA multiply-adds (fp32 accumulate); the roof is the
+            # bf16 matrix pipe and `achieved` the flops it EXECUTES; the fp32-equivalent rate is reported beside it
+            return {"bound": "mfma", "kernel": k, "achieved": round(6 * ach, 1), "peak": PEAK_TFLOPS["bf16"],
+                    "unit": "TFLOP/s", "frac": round(6 * ach / PEAK_TFLOPS["bf16"], 4),
+                    "algorithmic_fp32_tflops": round(ach, 2),
+                    "vs_fp32_mfma_peak": round(ach / PEAK_TFLOPS["f32"], 3),
+                    "note": ("fp32 operands split losslessly into 3 bf16 pieces, 6 piece products per multiply on "
+                             "v_mfma_f32_32x32x16_bf16, fp32 accumulate (csrc/gemm_x3.hip): fp32 accuracy; achieved = "
+                             "executed bf16 flops = 6 x algorithmic"),
+                    "traffic": traffic, "launches": d["launches"], "avg_launch_ms": round(d["ms"] / d["launches"], 4)}
+        return {"bound": "mfma", "kernel": k, "achieved": round(ach, 2), "peak": peak, "unit": "TFLOP/s",
+                "frac": round(ach / peak, 4), "traffic": traffic,
+                "launches": d["launches"], "avg_launch_ms": round(d["ms"] / d["launches"], 4)}
+
+    def roof_hbm(k):
+        d = agg[k]
+        ach = d["bytes"] / (d["ms"] * 1e-3) / 1e9
+        return {"bound": "hbm", "kernel": k, "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": recorded_traffic(k) if with_traffic else None,
+                "launches": d["launches"], "avg_launch_ms": round(d["ms"] / d["launches"], 4),
+                "algorithmic_bytes_per_launch": round(d["bytes"] / d["launches"])}
+
+    priced = [k for k in agg if agg[k]["flops"] > 0 or agg[k]["bytes"] > 0]
+    dom = max(priced or agg, key=lambda k: agg[k]["ms"])
+    mem = [k for k in agg if agg[k]["bytes"] > 0]
+    dom_mem = max(mem, key=lambda k: agg[k]["ms"]) if mem else None
+    roofline = roof_hbm(dom) if agg[dom]["bytes"] > 0 else roof(dom)
+    if dom_mem is not None and dom_mem != dom:
+        roofline["dominant_memory_bound_kernel"] = roof_hbm(dom_mem)
+    if agg[dom]["bytes"] > 0:
+        gem = max((k for k in agg if "gemm" in k), key=lambda k: agg[k]["ms"], default=None)
+        if gem:
+            roofline["dominant_mfma_kernel"] = roof(gem)
+    roofline["traffic_note"] = ("HBM bytes/launch (avg over the kernel's launches) from the committed rocprofv3 "
+                                "--pmc passes, " + os.path.relpath(PMC_FILE, ROOT))
+    roofline["per_kernel_ms_per_step"] = {k: round(v["ms"] / prof_steps, 3) for k, v in sorted(agg.items())}
+    roofline["per_kernel_ms_sum"] = round(sum(v["ms"] for v in agg.values()) / prof_steps, 3)
+    roofline["per_kernel_tflops"] = {k: round(v["flops"] / (v["ms"] * 1e-3) / 1e12, 1) for k, v in sorted(agg.items())
+                                     if v["flops"] > 0}
+    roofline["measured"] = (f"HIP events on the launch stream around EVERY C-ABI call of {prof_steps} eager step(s) "
+                            + ("run right after the timed graph replays (same process, kernels and shapes; the skip "
+                               "branch's kernels share the GPU from a second stream, so the sum can exceed the step)"
+                               if graph_mode else "= the timed region")
+                            + "; kernel names: the library's own report per call (epn_last_kernel), i.e. rocprofv3's names")
+    if dtype_name == "bf16":
+        roofline["note"] = ("bf16 GEMMs run far below the 2.5 PF MFMA roof by construction: at these widths the step "
+                            "is bound by HBM traffic of the grouped features (see DESIGN.md 3.6)")
+    return roofline
+
+
+def measure(cfg, rank, local_rank, world, dev, first=True):
+    """One workload (cfg: model, dtype, forward_only, steps, warmup, batch, points, no_graph, backbone_only): builds the
+    network, warms up, captures the step into a HIP graph, times exactly cfg.steps steps between barrier + synchronize
+    fences (max over ranks), then profiles a few eager steps call by call.  Returns (json_dict, handles) on every rank."""
+    from epn_pointcloud_amd import dp, models as M, ops, schedule as S
     from epn_pointcloud_amd import gemm as _gemm
+    dtype_name = cfg.dtype or ("f32" if cfg.model == "cls" else "bf16")
     split_gemm = dtype_name == "f32" and _gemm.FP32_MODE == "split"
     fdtype = torch.float32 if dtype_name == "f32" else torch.bfloat16
-    args.batch = args.batch or (32 if args.model == "cls" else 64)
-    args.points = args.points or (2048 if args.model == "inv" else 1024)   # 3DMatch patches (generate_eval.py:26,68)
+    batch = cfg.batch or (32 if cfg.model == "cls" else 64)
+    points = cfg.points or (2048 if cfg.model == "inv" else 1024)   # 3DMatch patches (generate_eval.py:26,68)
     layers = {"cls": S.cls_so3net_schedule, "reg": S.reg_so3net_schedule,
-              "inv": S.inv_so3net_schedule}[args.model](args.points)
+              "inv": S.inv_so3net_schedule}[cfg.model](points)
     torch.manual_seed(2913)                                 # same seed on every rank: replicas start identical
-    head = not args.backbone_only
+    head = not cfg.backbone_only
     if not head:
-        model = S.HotPathBackbone(layers, norm="BatchNorm2d" if args.model == "cls" else None, model=args.model)
-    elif args.model == "cls":
+        model = S.HotPathBackbone(layers, norm="BatchNorm2d" if cfg.model == "cls" else None, model=cfg.model)
+    elif cfg.model == "cls":
         model = M.ClsSO3ConvModel(layers, out_mlps=(256,), pooling="attention")
-    elif args.model == "reg":
+    elif cfg.model == "reg":
         model = M.RegSO3ConvModel(layers)
     else:
         model = M.InvSO3ConvModel(layers)
     model = S.set_feature_dtype(model.to(dev).train(), fdtype)
     params = [p for p in model.parameters() if p.requires_grad]
     opt = torch.optim.Adam(params, lr=1e-3)
-    scale = 0.4 if args.model == "inv" else 1.0            # 3DMatch search_radius (options.py:30)
-    pts = S.synthetic_clouds(args.batch, args.points, dev, seed=2913 + rank, scale=scale)   # resident in HBM
+    scale = 0.4 if cfg.model == "inv" else 1.0             # 3DMatch search_radius (options.py:30)
+    pts = S.synthetic_clouds(batch, points, dev, seed=2913 + rank, scale=scale)   # resident in HBM
     flat_pts = pts
-    labels = (torch.arange(args.batch, device=dev) + rank) % 40
-    if head and args.model == "reg":                        # pairs of clouds [b/2, 2, n, 3] (reg_so3net.py:31-33)
-        pts = pts.view(args.batch // 2, 2, args.points, 3)
+    labels = (torch.arange(batch, device=dev) + rank) % 40
+    if head and cfg.model == "reg":                         # pairs of clouds [b/2, 2, n, 3] (reg_so3net.py:31-33)
+        pts = pts.view(batch // 2, 2, points, 3)
 
     def loss_of(out):
         if not head:
             return out.feats.float().square().mean()
-        if args.model == "cls":
+        if cfg.model == "cls":
             return torch.nn.functional.cross_entropy(out[0], labels)
-        if args.model == "inv":                             # descriptors are unit vectors: push them apart
+        if cfg.model == "inv":                              # descriptors are unit vectors: push them apart
             return (out[0] @ out[0].t()).square().mean()
         return out[0].square().mean() + out[1].square().mean()
 
@@ -215,10 +302,10 @@ def main():
     # all-reduce runs on slices of it -- issued from backward hooks (eager) or right after the replayed graph
     # (world > 1 only: a single rank lets autograd hand its gradient tensors to p.grad directly -- no per-parameter
     # accumulate kernel, no zero fill)
-    buckets = None if args.forward_only or world == 1 else dp.GradBuckets(dp.stage_buckets(model), world, hooks=False)
+    buckets = None if cfg.forward_only or world == 1 else dp.GradBuckets(dp.stage_buckets(model), world, hooks=False)
 
     def compute():                      # the hot path: forward (+ loss + backward)
-        if args.forward_only:
+        if cfg.forward_only:
             with torch.no_grad():
                 return loss_of(model(pts))
         if buckets is not None:
@@ -231,7 +318,7 @@ def main():
         return loss
 
     def finish():
-        if not args.forward_only:
+        if not cfg.forward_only:
             if buckets is not None:
                 buckets.finish()
             opt.step()
@@ -245,12 +332,13 @@ def main():
     # the process group is created AFTER the capture (RCCL's watchdog thread issues HIP calls of its own, which a
     # capture in progress does not tolerate), replicas are identical by construction (same seed) and re-synchronised
     # by the broadcast below
+    torch.cuda.reset_peak_memory_stats(dev)
     side = torch.cuda.Stream(device=dev)
     side.wait_stream(torch.cuda.current_stream(dev))
     with torch.cuda.stream(side):
-        for _ in range(max(args.warmup, 1)):
+        for _ in range(max(cfg.warmup, 1)):
             compute()
-            if not args.forward_only:
+            if not cfg.forward_only:
                 opt.step()
     torch.cuda.current_stream(dev).wait_stream(side)
     torch.cuda.synchronize(dev)
@@ -258,7 +346,7 @@ def main():
     # The ~1300 launches of one step are captured ONCE into a HIP graph and replayed: same kernels, same work, no
     # per-launch host latency.  Gradient all-reduce and the Adam update stay outside the graph.
     launch, graph, static_loss = "eager", None, None
-    if not args.no_graph:
+    if not cfg.no_graph:
         try:
             graph = torch.cuda.CUDAGraph()
             with torch.cuda.graph(graph, capture_error_mode="thread_local"):
@@ -270,7 +358,8 @@ def main():
             if rank == 0:
                 print(f"[bench] HIP graph capture unavailable ({type(e).__name__}: {e}); eager launches", file=sys.stderr)
 
-    dp.init_from_env()                           # RCCL communicator (world > 1), after the capture
+    if first:
+        dp.init_from_env()                       # RCCL communicator (world > 1), after the capture
     dp.broadcast_parameters(model)
     if graph is None and buckets is not None and world > 1:      # eager: per-stage all-reduce from backward hooks
         buckets = dp.GradBuckets(dp.stage_buckets(model), world, hooks=True)
@@ -292,16 +381,16 @@ def main():
     if graph is None:
         ops.profile_begin()                      # eager: HIP events around every call of the timed region itself
     t0 = time.perf_counter()
-    for _ in range(args.steps):
+    for _ in range(cfg.steps):
         last = step()
     fence()
     dt = time.perf_counter() - t0
     if graph is None:
-        records, prof_steps = ops.profile_end(), args.steps
+        records, prof_steps = ops.profile_end(), cfg.steps
     else:
         # graph replays have no host-side launch points: for the roofline the same step runs eagerly, timed call by
         # call, right after the timed region (same process, same shapes, same kernels)
-        prof_steps = min(args.steps, 3)
+        prof_steps = min(cfg.steps, 3)
         eager_step()                             # untimed: refills the eager allocator pool after the capture, so no
         fence()                                  # allocation stall sits between an event and the kernel it brackets
         ops.profile_begin()
@@ -315,202 +404,60 @@ def main():
         dt = float(t.item())
     assert torch.isfinite(last.float()).all(), "non-finite output in the timed region"
 
+    nn_desc = "/".join(str(k) for k in sorted({l.nn for l in layers}, reverse=True))
+    out = {
+        "metric": (f"point-clouds/sec {'fwd' if cfg.forward_only else 'fwd+bwd'}, "
+                   + ("ModelNet40" if cfg.model != "inv" else "3DMatch") + f" N={points} A=60"),
+        "value": round(batch * world * cfg.steps / dt, 3), "unit": "point-clouds/s",
+        "n_gpus": world, "steps": cfg.steps, "warmup": cfg.warmup,
+        "ms_per_step": round(dt / cfg.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",
+        "vs_baseline": None, "dtype": dtype_name, "data": "synthetic",
+        "config": {"workload": WORKLOADS[cfg.model] + (HEADS[cfg.model] if head else ", backbone only)")
+                               + f", B={batch}/GPU N={points} K={nn_desc} A=60 "
+                               + (("fp32 (weight contractions: lossless 3 x bf16 split on the bf16 MFMAs, fp32 accumulate)"
+                                   if split_gemm else "fp32") if dtype_name == "f32" else "bf16 features / fp32 accumulate")
+                               + f", {'fwd' if cfg.forward_only else 'fwd+bwd+Adam'}",
+                   "global_batch": batch * world, "points": points, "anchors": 60, "launch": launch,
+                   "hbm_peak_gb": round(torch.cuda.max_memory_allocated(dev) / 2 ** 30, 1),
+                   "fp32_gemm": ("split" if split_gemm else "native") if dtype_name == "f32" else None,
+                   "inter_mode": os.environ.get("EPN_INTER_MODE", "auto"),
+                   "parallelism": f"dp{world}"},
+    }
     if rank == 0:
-        # ---- roofline of the dominant kernel, from HIP events recorded around its launches
-        esz = 4 if dtype_name == "f32" else 2
+        out["roofline"] = roofline_of(records, prof_steps, dtype_name, split_gemm,
+                                      cfg.model == "cls" and batch == 32 and dtype_name == "f32" and not cfg.forward_only,
+                                      graph is not None)
+    handles = dict(model=model, layers=layers, flat_pts=flat_pts, compute=compute, finish=finish, opt=opt, graph=graph,
+                   head=head, points=points, batch=batch, split_gemm=split_gemm)
+    return out, handles
 
-        def algo_bytes(kind, key):
-            """Algorithmic HBM bytes of the memory-bound families: operands read once + result
-            written once; the keys carry the layer dimensions."""
-            if kind in ("inter_group", "inter_ungroup", "inter_ungroup_det"):
-                b_, p1, p2, nn_, na, ks, cin, _ = key
-                feats, grouped = b_ * p1 * na * cin, b_ * p2 * na * cin * ks
-                return feats * (esz if kind == "inter_group" else 4) + grouped * esz
-            if kind == "intra_group":
-                b_, p_, na, kn, c = key[:5]
-                return b_ * p_ * na * c * esz * (1 + kn)
-            if kind == "so3_basis":
-                _, pts, c = key
-                return 2 * pts * 60 * c * esz
-            return 0
 
-        def nt_name(ns, kk, m_rows=0):
-            """Template instance launch_nt_typed (csrc/gemm.hip) picks for N in `ns`, contraction length kk -- the names
-            rocprofv3 reports (profiles/r02_kernel_stats.csv)."""
-            t = "float, float" if dtype_name == "f32" else "__bf16, __bf16"
-            e16 = 4 if dtype_name == "f32" else 8
-            if kk % (4 * e16):
-                return "epn::gemm_nt_generic_kernel"
-            ksz = 8 if kk % (8 * e16) == 0 else 4
-            if dtype_name == "f32" and split_gemm and ksz == 8:        # launch_gemm_nt_x3 (csrc/gemm_x3.hip)
-                mx = max(ns)
-                if len(ns) > 1:
-                    cfg = ("4, 1, 2, 2, 3" if (mx <= 320 and min(ns) <= 64) else
-                           ("4, 2, 2, 4, 2" if min(ns) >= 256 else "2, 2, 2, 2, 2"))
-                elif mx <= 32:
-                    cfg = "8, 1, 2, 1, 2"
-                elif mx <= 64:
-                    cfg = "4, 1, 2, 2, 3"
-                elif mx <= 128 or mx % 256 > 128 or (mx % 256 and mx < 512):
-                    cfg = "4, 2, 2, 2, 2"
-                else:
-                    cfg = "4, 2, 2, 4, 2"
-                return f"epn::gemm_nt_x3_kernel<{cfg}>"
-            if ksz == 4:
-                cfg = "8, 1, 2, 1" if max(ns) <= 32 else ("8, 1, 2, 2" if max(ns) <= 64 else "4, 2, 2, 2")
-            elif dtype_name == "f32" and len(ns) > 1:          # grouped spectral blocks
-                cfg = "4, 1, 2, 2" if (max(ns) <= 320 and min(ns) <= 64) else "2, 2, 2, 2"
-            elif (dtype_name == "f32" and len(ns) == 1 and ns[0] in (128, 256)
-                    and (m_rows // 128) * (ns[0] // 128) >= 3840):
-                cfg = "2, 2, 2, 2"
-            elif max(ns) <= 32:
-                cfg = "8, 1, 2, 1"
-            elif max(ns) <= 64:
-                cfg = "8, 1, 2, 2"
-            elif min(ns) >= 256:
-                cfg = "4, 2, 2, 4"
-            else:
-                cfg = "4, 2, 2, 2"
-            nstg = 3 if (dtype_name == "bf16" and cfg == "4, 2, 2, 2" and ksz == 8) else 2    # LDS ring depth
-            return f"epn::gemm_nt_kernel<{t}, {cfg}, {ksz}, {nstg}>"
+def main():
+    args = parse()
+    from epn_pointcloud_amd import _lib, dp
+    rank, local_rank, world = dp.env_world()
+    if args.gpus > 1 and world == 1 and "EPN_DP_CHILD" not in os.environ:
+        sys.exit(dp.launch(args.gpus))                  # no launcher: start the ranks ourselves
+    assert world == args.gpus, f"WORLD_SIZE={world} but --gpus {args.gpus}"
+    _lib.get_lib()                                      # fail loudly if the HIP library is missing
+    assert torch.cuda.is_available(), "bench.py needs an MI355X"
+    dev = dp.local_device(local_rank)
+    torch.cuda.set_device(dev)
+    if args.policy:      # needs a -DEPN_TUNING library (python -m epn_pointcloud_amd.build --tuning; EPN_LIB=...)
+        _lib.check(_lib.get_lib().epn_set_kernel_policy(int(args.policy, 0)), "set_kernel_policy")
 
-        def tn_name(n1, n2, grouped=False):
-            """Template instance gemm_tn_tile / launch_tn_typed (csrc/gemm.hip) pick for an N1 x N2 output."""
-            if dtype_name == "bf16":
-                cfg = "1, 4, 2, 4" if n1 <= 32 else ("1, 4, 4, 4" if n1 <= 64 else "2, 2, 4, 8")
-                return f"epn::gemm_tn_bf16_kernel<{cfg}>"
-            if grouped and n2 < 256:
-                n2 = 256
-            w2 = 512 if n2 >= 512 else (256 if n2 > 128 else (128 if n2 > 64 else 64))
-            x3 = "true" if split_gemm else "false"
-            if split_gemm and grouped and n2 >= 256 and n1 >= 1280:  # wide spectral groups (n1 = 5 c): planes kernel, 256 x 256 tiles
-                return "epn::gemm_tn_x3_kernel<2, 4, 4, 2, 16>"
-            if split_gemm and not grouped and n2 >= 512:       # wide single problems: pre-split planes kernel
-                cfg = "1, 8, 1, 2, 32" if n1 <= 32 else ("1, 8, 2, 2, 16" if n1 <= 64 else
-                                                           ("2, 4, 4, 2, 16" if n1 >= 256 else "1, 8, 4, 2, 16"))
-                return f"epn::gemm_tn_x3_kernel<{cfg}>"
-            if n1 <= 32:
-                cfg = "1, 8, 1, 2, 32"
-            elif n1 <= 64:
-                cfg = {512: "1, 4, 2, 4, 16", 256: "1, 8, 2, 1, 32", 128: "2, 2, 1, 2, 32", 64: "2, 2, 1, 1, 32"}[w2]
-            else:
-                cfg = {512: "1, 8, 4, 2, 32", 256: "2, 4, 2, 2, 32", 128: "2, 2, 2, 2, 32", 64: "2, 2, 2, 1, 32"}[w2]
-            return f"epn::gemm_tn_f32_kernel<{cfg}, {x3}>"
-
-        def kernel_of(kind, key):
-            if kind == "inter_gemm_dw":
-                return tn_name(key[7], key[6] * key[5])
-            if kind == "intra_gemm_dw" and key[0] == "spectral_dw":
-                return tn_name(5 * key[2], key[3], grouped=True)   # grouped: max N1, min N2 of the five blocks
-            if kind == "conv1x1_gemm_dw":
-                return tn_name(key[2], key[3])
-            if kind == "inter_gemm":
-                return nt_name([key[7]], key[6] * key[5], key[0] * key[2] * key[4])
-            if kind == "inter_gemm_dg":
-                return nt_name([key[6] * key[5]], key[7])
-            if kind == "intra_gemm" and key[0] in ("spectral", "spectral_dA"):
-                cio = (key[2], key[3]) if key[0] == "spectral" else (key[3], key[2])
-                return nt_name([d_ * cio[1] for d_ in (1, 3, 3, 4, 5)], cio[0])
-            if kind == "conv1x1_gemm":
-                return nt_name([key[2]], key[3], key[1])
-            if kind == "so3_basis":
-                return ("epn::so3_basis_x3_kernel" if split_gemm else
-                        ("epn::so3_basis_bf16_kernel" if dtype_name == "bf16" else "epn::so3_basis_kernel"))
-            return KERNEL_OF.get(kind, kind)
-
-        agg = {}
-        for kind, key, flops, e0, e1 in records:
-            k = kernel_of(kind, key)
-            if kind.startswith("inter") and len(key) > 6 and key[6] == 1:      # cin = 1 (first layer): dedicated kernels
-                k = {"inter_fwd": "epn::inter_c1_fwd_kernel", "inter_bwd_weight": "epn::inter_c1_bwd_weight_kernel"}.get(kind, k)
-            a = agg.setdefault(k, {"ms": 0.0, "flops": 0.0, "launches": 0, "bytes": 0.0})
-            a["ms"] += e0.elapsed_time(e1)
-            a["flops"] += flops
-            a["bytes"] += algo_bytes(kind, key)
-            a["launches"] += 1
-        peak = PEAK_TFLOPS[dtype_name]
-
-        def roof(k):
-            d = agg[k]
-            ach = d["flops"] / (d["ms"] * 1e-3) / 1e12
-            if "_x3_" in k or k.endswith("true>"):         # gemm_nt_x3 / gemm_tn_x3 / gemm_tn_f32<..., true>
-                # split form: every fp32 multiply-add is six bf16 MFMA multiply-adds (fp32 accumulate); the roof is the
-                # bf16 matrix pipe and `achieved` the flops it EXECUTES; the fp32-equivalent rate is reported beside it
-                return {"bound": "mfma", "kernel": k, "achieved": round(6 * ach, 1), "peak": PEAK_TFLOPS["bf16"],
-                        "unit": "TFLOP/s", "frac": round(6 * ach / PEAK_TFLOPS["bf16"], 4),
-                        "algorithmic_fp32_tflops": round(ach, 2),
-                        "vs_fp32_mfma_peak": round(ach / PEAK_TFLOPS["f32"], 3),
-                        "note": ("fp32 operands split losslessly into 3 bf16 pieces, 6 piece products per multiply on "
-                                 "v_mfma_f32_32x32x16_bf16, fp32 accumulate (csrc/gemm_x3.hip): fp32 accuracy; achieved = "
-                                 "executed bf16 flops = 6 x algorithmic"),
-                        "traffic": recorded_traffic(k) if (args.model == "cls" and args.batch == 32 and dtype_name == "f32") else None,
-                        "launches": d["launches"], "avg_launch_ms": round(d["ms"] / d["launches"], 4)}
-            return {"bound": "mfma", "kernel": k, "achieved": round(ach, 2), "peak": peak, "unit": "TFLOP/s",
-                    "frac": round(ach / peak, 4),
-                    "traffic": recorded_traffic(k) if (args.model == "cls" and args.batch == 32 and dtype_name == "f32") else None,
-                    "launches": d["launches"], "avg_launch_ms": round(d["ms"] / d["launches"], 4)}
-
-        def roof_hbm(k):
-            d = agg[k]
-            ach = d["bytes"] / (d["ms"] * 1e-3) / 1e9
-            return {"bound": "hbm", "kernel": k, "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                    "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": None, "launches": d["launches"],
-                    "avg_launch_ms": round(d["ms"] / d["launches"], 4),
-                    "algorithmic_bytes_per_launch": round(d["bytes"] / d["launches"])}
-
-        dom = max(agg, key=lambda k: agg[k]["ms"])
-        mem = [k for k in agg if agg[k]["bytes"] > 0]
-        dom_mem = max(mem, key=lambda k: agg[k]["ms"]) if mem else None
-        roofline = roof_hbm(dom) if agg[dom]["bytes"] > 0 else roof(dom)
-        if dom_mem is not None and dom_mem != dom:
-            roofline["dominant_memory_bound_kernel"] = roof_hbm(dom_mem)
-        if agg[dom]["bytes"] > 0:
-            gem = max((k for k in agg if "gemm" in k), key=lambda k: agg[k]["ms"], default=None)
-            if gem:
-                roofline["dominant_mfma_kernel"] = roof(gem)
-        roofline["traffic_note"] = ("HBM bytes/launch (avg over the family's launches) from the committed rocprofv3 "
-                                    "--pmc passes, profiles/r02_pmc_per_kernel.json")
-        roofline["per_kernel_ms_per_step"] = {k: round(v["ms"] / prof_steps, 3) for k, v in sorted(agg.items())}
-        roofline["per_kernel_tflops"] = {k: round(v["flops"] / (v["ms"] * 1e-3) / 1e12, 1) for k, v in sorted(agg.items())
-                                         if v["flops"] > 0}
-        roofline["measured"] = (f"HIP events on the launch stream around every C-ABI call of {prof_steps} eager step(s) "
-                                + ("run right after the timed graph replays (same process, kernels and shapes; the skip "
-                                   "branch's kernels share the GPU from a second stream)" if graph is not None
-                                   else "= the timed region") + "; names: C-ABI call -> kernel, bench.py KERNEL_OF")
-        if dtype_name == "bf16":
-            roofline["note"] = ("bf16 GEMMs run far below the 2.5 PF MFMA roof by construction: at these widths the step "
-                                "is bound by HBM traffic of the grouped features (see DESIGN.md 3.6)")
-        nn_desc = "/".join(str(k) for k in sorted({l.nn for l in layers}, reverse=True))
-        out = {
-            "metric": (f"point-clouds/sec {'fwd' if args.forward_only else 'fwd+bwd'}, "
-                       + ("ModelNet40" if args.model != "inv" else "3DMatch") + f" N={args.points} A=60"),
-            "value": round(args.batch * world * args.steps / dt, 3), "unit": "point-clouds/s",
-            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": round(dt / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",
-            "vs_baseline": None, "dtype": dtype_name, "data": "synthetic",
-            "config": {"workload": {"cls": "ModelNet40 classification (cls_so3net_pn: 7 separable SO3 blocks",
-                                    "reg": "ModelNet40 relative rotation (reg_so3net: 7 separable SO3 blocks",
-                                    "inv": "3DMatch descriptor (inv_so3net_pn: 8 separable SO3 blocks"}[args.model]
-                                   + ({"cls": " + ClsOutBlockPointnet head)", "reg": " + RelSO3OutBlockR head)",
-                                       "inv": " + InvOutBlockMVD head)"}[args.model] if head else ", backbone only)")
-                                   + f", B={args.batch}/GPU N={args.points} K={nn_desc} A=60 "
-                                   + (("fp32 (weight contractions: lossless 3 x bf16 split on the bf16 MFMAs, fp32 accumulate)"
-                                       if split_gemm else "fp32") if dtype_name == "f32" else "bf16 features / fp32 accumulate")
-                                   + f", {'fwd' if args.forward_only else 'fwd+bwd+Adam'}",
-                       "global_batch": args.batch * world, "points": args.points, "anchors": 60, "launch": launch,
-                       "hbm_peak_gb": round(torch.cuda.max_memory_allocated(dev) / 2 ** 30, 1),
-                       "fp32_gemm": ("split" if split_gemm else "native") if dtype_name == "f32" else None,
-                       "parallelism": f"dp{world}"},
-            "roofline": roofline,
-        }
-        if world == 1 and split_gemm and not args.no_native_line:
+    out, H = measure(args, rank, local_rank, world, dev)
+    if rank == 0:
+        from epn_pointcloud_amd import gemm as _gemm
+        if world == 1 and H["split_gemm"] and not args.no_native_line:
             # the same step with the weight contractions / basis change on the fp32 matrix instruction
             # (v_mfma_f32_32x32x2_f32, EPN_GEMM_FP32=native), measured right here: same box, same process, same inputs
+            compute, finish, graph = H["compute"], H["finish"], H["graph"]
             try:
                 _gemm.set_fp32_mode("native")
                 compute()                                   # eager once (allocations), then its own graph
                 if not args.forward_only:
-                    opt.step()
+                    H["opt"].step()
                 torch.cuda.synchronize()
                 g2 = None
                 if graph is not None:
@@ -531,19 +478,49 @@ def main():
                     native_step()
                 torch.cuda.synchronize()
                 dtn = time.perf_counter() - tn0
-                out["native_fp32_mfma"] = {"value": round(args.batch * args.steps / dtn, 3), "unit": "point-clouds/s",
+                out["native_fp32_mfma"] = {"value": round(H["batch"] * args.steps / dtn, 3), "unit": "point-clouds/s",
                                            "ms_per_step": round(dtn / args.steps * 1e3, 3), "steps": args.steps,
                                            "note": "same step, fp32 contractions on v_mfma_f32_32x32x2_f32 instead of the "
                                                    "lossless bf16 split (DESIGN.md 3.2b); value / this = speed-up of the split form"}
+                del g2
             except Exception as e:                          # a report, never a requirement
                 out["native_fp32_mfma"] = {"error": f"{type(e).__name__}: {e}"}
             finally:
                 _gemm.set_fp32_mode("split")
         if world == 1:
-            out["index_kernels"] = index_kernel_line(flat_pts, layers, dev)
+            out["index_kernels"] = index_kernel_line(H["flat_pts"], H["layers"], dev)
+        cpu = None
         if world == 1 and not args.no_cpu_baseline and args.model == "cls" and not args.forward_only:
-            out["cpu_baseline"] = cpu_baseline(layers, model.state_dict(), args.points, args.cpu_clouds,
-                                               args.cpu_threads, head)
+            cpu = (H["layers"], {k: v.detach().cpu() for k, v in H["model"].state_dict().items()}, H["points"], H["head"])
+    default_run = (args.model == "cls" and not args.dtype and not args.forward_only and not args.backbone_only
+                   and not args.batch and not args.points)
+    H.clear()
+    if world == 1 and default_run and not args.no_extra_configs:
+        # The other single-GPU BASELINE configs, in the SAME run so that they carry the driver's clock: configs[1] forward
+        # only (north_star states its >= 10x CPU target on the forward pass), configs[2] (rotation estimation, bf16) and
+        # configs[3] (3DMatch descriptor, bf16): 10 graph replays each, own roofline objects.
+        import copy
+        import gc
+        extras = {}
+        for name, model, fwd in (("cls_fwd", "cls", True), ("reg_bf16", "reg", False), ("inv_bf16", "inv", False)):
+            gc.collect()
+            torch.cuda.empty_cache()
+            c = copy.copy(args)
+            c.model, c.forward_only, c.dtype, c.batch, c.points = model, fwd, "", 0, 0
+            c.steps, c.warmup = min(args.steps, 10), min(args.warmup, 2)
+            try:
+                o, h = measure(c, rank, local_rank, world, dev, first=False)
+                h.clear()
+                extras[name] = {k: o[k] for k in ("metric", "value", "unit", "ms_per_step", "steps", "dtype", "config", "roofline")}
+            except Exception as e:                          # a report, never a requirement
+                extras[name] = {"error": f"{type(e).__name__}: {e}"}
+        out["configs"] = extras
+    if rank == 0:
+        if cpu is not None:
+            out["cpu_baseline"] = cpu_baseline(cpu[0], cpu[1], cpu[2], args.cpu_clouds, args.cpu_threads, cpu[3])
+            if "configs" in out and "cls_fwd" in out["configs"] and "value" in out["configs"]["cls_fwd"]:
+                out["configs"]["cls_fwd"]["vs_cpu_forward"] = round(
+                    out["configs"]["cls_fwd"]["value"] / out["cpu_baseline"]["forward_only_value"], 1)
         print(json.dumps(out), flush=True)
     if world > 1:
         torch.distributed.destroy_process_group()

@@ -29,7 +29,7 @@ EXPORTS = [
     "epn_gather_rows", "epn_scatter_rows", "epn_conv1x1_c1_f32", "epn_conv1x1_c1_bwd_weight_f32",
     "epn_ball_query_f64", "epn_fps_f64", "epn_gather_fwd_f64", "epn_gather_bwd_f64", "epn_so3_basis_norm_f32", "epn_so3_basis_norm_bf16", "epn_so3_basis_split_f32", "epn_so3_basis_norm_split_f32", "epn_inter_inverse_list", "epn_inter_ungroup_det_f32", "epn_inter_ungroup_det_bf16",
     "epn_chan_stats_bf16", "epn_norm_act_fwd_bf16", "epn_norm_act_bwd_reduce_bf16", "epn_norm_act_bwd_apply_bf16",
-    "epn_inter_onchip_ok", "epn_inter_onchip_workspace_bytes", "epn_inter_so3conv_fwd_onchip_f32", "epn_inter_so3conv_fwd_bf16",
+    "epn_last_kernel", "epn_inter_onchip_ok", "epn_inter_onchip_workspace_bytes", "epn_inter_so3conv_fwd_onchip_f32", "epn_inter_so3conv_fwd_bf16",
 ]
 
 _vp, _ci, _cf, _sz = ctypes.c_void_p, ctypes.c_int, ctypes.c_float, ctypes.c_size_t
@@ -70,6 +70,7 @@ def get_lib():
     lib = ctypes.CDLL(LIB_PATH)
     lib.epn_version.restype = ctypes.c_char_p
     lib.epn_strerror.restype = ctypes.c_char_p
+    lib.epn_last_kernel.restype = ctypes.c_char_p
     lib.epn_strerror.argtypes = [_ci]
     lib.epn_set_kernel_policy.argtypes = [_ci]
     lib.epn_set_kernel_policy.restype = _ci
@@ -168,8 +169,47 @@ def get_lib():
         if name.endswith("_f32") or name.endswith("_bf16") or name in ("epn_transpose_cast", "epn_cast"):
             getattr(lib, name).restype = _ci
     lib.epn_gemm_tn_workspace_bytes.restype = _sz
-    _lib = lib
-    return lib
+    _lib = _LibProxy(lib)
+    return _lib
+
+
+# Host-only entry points (no stream argument, nothing launched): handed out unwrapped.
+_HOST_ONLY = {"epn_version", "epn_strerror", "epn_set_kernel_policy", "epn_last_kernel", "epn_inter_is_fused",
+              "epn_intra_is_fused", "epn_inter_onchip_ok"}
+CALL_HOOK = None      # ops.profile_begin(): callable(name, fn, args) -> rc, brackets every launching call with HIP events
+
+
+class _StreamArg(ctypes.c_void_p):
+    """epn_stream_t argument that remembers the device to switch back to after the call (stream_of)."""
+    restore = None
+
+
+class _LibProxy:
+    """The CDLL with every launching entry point wrapped: (i) the current device, if stream_of() had to switch it to the
+    tensors' device for the launch, is restored afterwards -- a scoped guard like ATen's, not a permanent set_device;
+    (ii) an optional hook (CALL_HOOK) sees every call, so a benchmark can time ALL of them, not only the ones a
+    caller chose to bracket."""
+
+    def __init__(self, lib):
+        object.__setattr__(self, "_cdll", lib)
+
+    def __getattr__(self, name):
+        fn = getattr(self._cdll, name)
+        if name in _HOST_ONLY or name.endswith("_workspace_bytes"):
+            object.__setattr__(self, name, fn)
+            return fn
+
+        def call(*args):
+            hook = CALL_HOOK
+            try:
+                return fn(*args) if hook is None else hook(name, fn, args)
+            finally:
+                prev = getattr(args[-1], "restore", None) if args else None
+                if prev is not None:
+                    torch.cuda.set_device(prev)
+        call.__name__ = name
+        object.__setattr__(self, name, call)
+        return call
 
 
 class generic_kernels:
@@ -189,13 +229,16 @@ def check(rc, what):
 
 
 def stream_of(t):
-    """Current torch stream of t's device.  The HIP runtime launches on ITS current device, so that is switched to t's
-    device first when it differs (the reference's extensions get the same from ATen's device guard): a tensor on cuda:1
-    while cuda:0 is current must not launch on cuda:0.  The switch persists, like torch.cuda.set_device."""
+    """Current torch stream of t's device, as the epn_stream_t argument of the call being made.  The HIP runtime launches
+    on ITS current device, so that is switched to t's device first when it differs (a tensor on cuda:1 while cuda:0 is
+    current must not launch on cuda:0); the returned argument carries the device to switch back to, and the library
+    proxy restores it when the call returns -- the scoped guard the reference's extensions get from ATen."""
     dev = t.device
+    arg = _StreamArg(torch.cuda.current_stream(dev).cuda_stream)
     if dev.index is not None and torch.cuda.current_device() != dev.index:
+        arg.restore = torch.cuda.current_device()
         torch.cuda.set_device(dev)
-    return ctypes.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
+    return arg
 
 
 def same_device(*tensors):

@@ -26,29 +26,37 @@ def _deps_mtime():
     return max(os.path.getmtime(h) for h in hdrs)
 
 
+TUNING = os.environ.get("EPN_TUNING", "0") == "1"      # tools/ builds: keep the A/B kernel policies (epn_set_kernel_policy 0x100..0x4ff)
+
+
 def _compile(src, force):
-    obj = os.path.join(OBJ, os.path.basename(src)[:-4] + ".o")
+    obj = os.path.join(OBJ, os.path.basename(src)[:-4] + (".tuning.o" if TUNING else ".o"))
     if (not force and os.path.exists(obj) and os.path.getmtime(obj) >= os.path.getmtime(src)
             and os.path.getmtime(obj) >= _deps_mtime()):
         return obj, False
-    subprocess.check_call([HIPCC] + FLAGS + ["-c", src, "-o", obj])
+    subprocess.check_call([HIPCC] + FLAGS + (["-DEPN_TUNING"] if TUNING else []) + ["-c", src, "-o", obj])
     return obj, True
 
 
-def build(force=False, verbose=False):
-    """Compile (if stale) and link the shared library; returns its path."""
+def build(force=False, verbose=False, tuning=None):
+    """Compile (if stale) and link the shared library; returns its path.  tuning=True (or EPN_TUNING=1 / --tuning) builds
+    libepn_so3conv_tuning.so with -DEPN_TUNING for the tools/ A/B scripts (load it with EPN_LIB=...)."""
+    global TUNING, LIB
+    if tuning is not None:
+        TUNING = bool(tuning)
+    lib_path = os.path.join(PKG, "libepn_so3conv_tuning.so") if TUNING else LIB
     os.makedirs(OBJ, exist_ok=True)
     srcs = _sources()
     with concurrent.futures.ThreadPoolExecutor(max_workers=min(8, len(srcs))) as ex:
         results = list(ex.map(lambda s: _compile(s, force), srcs))
     objs = [o for o, _ in results]
-    stale = not os.path.exists(LIB) or any(os.path.getmtime(o) > os.path.getmtime(LIB) for o in objs)
+    stale = not os.path.exists(lib_path) or any(os.path.getmtime(o) > os.path.getmtime(lib_path) for o in objs)
     if force or stale or any(c for _, c in results):
-        subprocess.check_call([HIPCC, "--offload-arch=" + ARCH, "-shared", "-fPIC", "-o", LIB] + objs)
+        subprocess.check_call([HIPCC, "--offload-arch=" + ARCH, "-shared", "-fPIC", "-o", lib_path] + objs)
         if verbose:
-            print("linked", LIB)
-    return LIB
+            print("linked", lib_path)
+    return lib_path
 
 
 if __name__ == "__main__":
-    print(build(force="--force" in os.sys.argv, verbose=True))
+    print(build(force="--force" in os.sys.argv, verbose=True, tuning="--tuning" in os.sys.argv or None))

@@ -2,7 +2,9 @@
 // Dispatch: fused MFMA kernels when cin and cout are multiples of 16, generic kernels otherwise
 // (epn_set_kernel_policy(1) forces the generic path; used by the cross-check tests).
 #include <atomic>
+#include <cstdlib>
 #include <cstring>
+#include <cxxabi.h>
 
 #include "conv_internal.h"
 
@@ -11,10 +13,62 @@ using namespace epn;
 static std::atomic<int> g_policy{0};   // the library's only process-wide state: 0 = best kernel, 1 = generic kernels
 static bool force_generic() { return g_policy.load(std::memory_order_relaxed) == 1; }
 
-namespace epn { int kernel_policy() { return g_policy.load(std::memory_order_relaxed); } }
+namespace epn {
+#ifdef EPN_TUNING
+int kernel_policy() { return g_policy.load(std::memory_order_relaxed); }
+#else
+int kernel_policy() { return 0; }    // tile / scatter overrides exist only in -DEPN_TUNING builds
+#endif
+}
+
+// ---- which kernel did the last call launch?  (thread-local; read and cleared by epn_last_kernel)
+namespace {
+thread_local const void *t_stub = nullptr;
+thread_local bool t_stub_aux = true;
+}  // namespace
+namespace epn {
+void note_kernel(const void *host_stub, bool aux) {
+    if (aux && t_stub) return;                    // a helper never replaces what is already recorded
+    t_stub = host_stub;                           // the last main kernel of a call wins
+    t_stub_aux = aux;
+}
+}  // namespace epn
+
+extern "C" const char *epn_last_kernel(void) {
+    static thread_local char out[320];
+    out[0] = 0;
+    const void *stub = t_stub;
+    t_stub = nullptr;
+    t_stub_aux = true;
+    if (!stub) return out;
+    const char *mangled = hipKernelNameRefByPtr(stub, nullptr);
+    if (!mangled) return out;
+    int status = 0;
+    char *dem = abi::__cxa_demangle(mangled, nullptr, nullptr, &status);
+    const char *b = (status == 0 && dem) ? dem : mangled;
+    if (!std::strncmp(b, "void ", 5)) b += 5;
+    // drop "(anonymous namespace)::" and the argument list (the first '(' outside template brackets)
+    static const char anon[] = "(anonymous namespace)::";
+    size_t o = 0;
+    int depth = 0;
+    for (size_t i = 0; b[i] && o + 1 < sizeof(out);) {
+        if (!std::strncmp(b + i, anon, sizeof(anon) - 1)) { i += sizeof(anon) - 1; continue; }
+        if (b[i] == '<') ++depth;
+        else if (b[i] == '>') --depth;
+        else if (b[i] == '(' && depth == 0) break;
+        out[o++] = b[i++];
+    }
+    out[o] = 0;
+    std::free(dem);
+    return out;
+}
 
 extern "C" int epn_set_kernel_policy(int policy) {
-    if (policy != 0 && policy != 1 && (policy & ~0xff) != 0x100 && (policy & ~0xff) != 0x200 && (policy & ~0xff) != 0x400) return EPN_EINVAL;   // 0x100 | cfg: tools/gemm_bench.py
+#ifdef EPN_TUNING   // tools/ builds (python -m epn_pointcloud_amd.build --tuning): 0x100 | cfg .. 0x400 | cfg = A/B switches
+    if (policy != 0 && policy != 1 && (policy & ~0xff) != 0x100 && (policy & ~0xff) != 0x200 && (policy & ~0xff) != 0x400) return EPN_EINVAL;
+#else
+    if (policy != 0 && policy != 1) return EPN_EINVAL;
+#endif
     g_policy.store(policy, std::memory_order_relaxed);
     return 0;
 }

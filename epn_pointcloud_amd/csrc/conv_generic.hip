@@ -246,7 +246,7 @@ static Geo make_geo(const epn_inter_desc *d) {
 
 int launch_rk_table(const epn_inter_desc *d, float *rk, hipStream_t st) {
     const int n = d->na * d->ks * 3;
-    hipLaunchKernelGGL(rk_table_kernel, dim3(epn_cdiv(n, 256)), dim3(256), 0, st, d->anchors, d->kernels, d->na,
+    EPN_LAUNCH_AUX(rk_table_kernel, dim3(epn_cdiv(n, 256)), dim3(256), 0, st, d->anchors, d->kernels, d->na,
                        d->ks, rk);
     EPN_CHECK_LAUNCH();
     return 0;
@@ -255,7 +255,7 @@ int launch_rk_table(const epn_inter_desc *d, float *rk, hipStream_t st) {
 int launch_inter_weights(const epn_inter_desc *d, float *w, hipStream_t st) {
     const size_t total = (size_t)d->b * d->p2 * d->na * d->ks * d->nn;
     const int blocks = (int)((total + 255) / 256 < 65536 ? (total + 255) / 256 : 65536);
-    hipLaunchKernelGGL(inter_weights_kernel, dim3(blocks), dim3(256), 0, st, make_geo(d), d->anchors, d->kernels, d->sigma,
+    EPN_LAUNCH(inter_weights_kernel, dim3(blocks), dim3(256), 0, st, make_geo(d), d->anchors, d->kernels, d->sigma,
                        d->b, d->na, d->ks, w);
     EPN_CHECK_LAUNCH();
     return 0;
@@ -263,7 +263,7 @@ int launch_inter_weights(const epn_inter_desc *d, float *w, hipStream_t st) {
 
 int launch_inter_group(const epn_inter_desc *d, const float *rk, const float *feats, float *G, hipStream_t st) {
     const size_t total = (size_t)d->b * d->p2 * d->na * d->cin;
-    hipLaunchKernelGGL(inter_group_kernel<EPN_KS_MAX>, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st,
+    EPN_LAUNCH(inter_group_kernel<EPN_KS_MAX>, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st,
                        make_geo(d), rk, d->dense_w, d->sigma, feats, d->b, d->na, d->ks, d->cin, G);
     EPN_CHECK_LAUNCH();
     return 0;
@@ -271,7 +271,7 @@ int launch_inter_group(const epn_inter_desc *d, const float *rk, const float *fe
 
 int launch_inter_scatter(const epn_inter_desc *d, const float *rk, const float *dG, float *dF, hipStream_t st) {
     const size_t total = (size_t)d->b * d->p2 * d->na * d->cin;
-    hipLaunchKernelGGL(inter_scatter_kernel<EPN_KS_MAX>, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st,
+    EPN_LAUNCH(inter_scatter_kernel<EPN_KS_MAX>, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st,
                        make_geo(d), rk, d->dense_w, d->sigma, dG, d->b, d->na, d->ks, d->cin, dF);
     EPN_CHECK_LAUNCH();
     return 0;
@@ -279,7 +279,7 @@ int launch_inter_scatter(const epn_inter_desc *d, const float *rk, const float *
 
 int launch_rowgemm_nt(const float *X, const float *W, size_t ncol, int ck, int cout, float *out, hipStream_t st) {
     const size_t total = ncol * cout;
-    hipLaunchKernelGGL(rowgemm_nt_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, X, W, ncol, ck,
+    EPN_LAUNCH(rowgemm_nt_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, X, W, ncol, ck,
                        cout, out);
     EPN_CHECK_LAUNCH();
     return 0;
@@ -287,7 +287,7 @@ int launch_rowgemm_nt(const float *X, const float *W, size_t ncol, int ck, int c
 
 int launch_rowgemm_nn(const float *dOut, const float *W, size_t ncol, int ck, int cout, float *dX, hipStream_t st) {
     const size_t total = ncol * ck;
-    hipLaunchKernelGGL(rowgemm_nn_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, dOut, W, ncol, ck,
+    EPN_LAUNCH(rowgemm_nn_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, dOut, W, ncol, ck,
                        cout, dX);
     EPN_CHECK_LAUNCH();
     return 0;
@@ -297,7 +297,7 @@ int launch_colreduce_dw(const float *dOut, const float *X, size_t ncol, int ck, 
                         hipStream_t st) {
     const size_t chunk = 512;
     dim3 grid(epn_cdiv((long long)cout * ck, 256), (unsigned)((ncol + chunk - 1) / chunk));
-    hipLaunchKernelGGL(colreduce_dw_kernel, grid, dim3(256), 0, st, dOut, X, ncol, chunk, ck, cout, dW);
+    EPN_LAUNCH(colreduce_dw_kernel, grid, dim3(256), 0, st, dOut, X, ncol, chunk, ck, cout, dW);
     EPN_CHECK_LAUNCH();
     return 0;
 }
@@ -305,7 +305,7 @@ int launch_colreduce_dw(const float *dOut, const float *X, size_t ncol, int ck, 
 int launch_intra_fwd_generic(const float *feats, const int32_t *iidx, const float *W, size_t npts, int na, int kn,
                              int cin, int cout, float *out, hipStream_t st) {
     const size_t total = npts * na * cout;
-    hipLaunchKernelGGL(intra_fwd_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, feats, iidx, W, npts,
+    EPN_LAUNCH(intra_fwd_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, feats, iidx, W, npts,
                        na, kn, cin, cout, out);
     EPN_CHECK_LAUNCH();
     return 0;
@@ -314,7 +314,7 @@ int launch_intra_fwd_generic(const float *feats, const int32_t *iidx, const floa
 int launch_intra_bwd_data_generic(const float *dOut, const int32_t *iidx, const float *W, size_t npts, int na, int kn,
                                   int cin, int cout, float *dF, hipStream_t st) {
     const size_t total = npts * na * cin;
-    hipLaunchKernelGGL(intra_bwd_data_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, dOut, iidx, W,
+    EPN_LAUNCH(intra_bwd_data_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, dOut, iidx, W,
                        npts, na, kn, cin, cout, dF);
     EPN_CHECK_LAUNCH();
     return 0;
@@ -324,7 +324,7 @@ int launch_intra_bwd_weight_generic(const float *feats, const float *dOut, const
                                     int kn, int cin, int cout, float *dW, hipStream_t st) {
     const size_t ncol = npts * na, chunk = 480;
     dim3 grid(epn_cdiv((long long)cout * cin * kn, 256), (unsigned)((ncol + chunk - 1) / chunk));
-    hipLaunchKernelGGL(intra_bwd_weight_kernel, grid, dim3(256), 0, st, feats, dOut, iidx, ncol, chunk, na, kn, cin,
+    EPN_LAUNCH(intra_bwd_weight_kernel, grid, dim3(256), 0, st, feats, dOut, iidx, ncol, chunk, na, kn, cin,
                        cout, dW);
     EPN_CHECK_LAUNCH();
     return 0;

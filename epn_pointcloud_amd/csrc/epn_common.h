@@ -21,6 +21,24 @@
 
 static inline hipStream_t epn_stream(epn_stream_t s) { return (hipStream_t)s; }
 
+// Every launch site records the host stub of the kernel it launches; epn_last_kernel() turns it into the exact template
+// instance name (what a profiler will call the kernel), so that a benchmark never has to re-derive the launchers' tile
+// choices.  AUX launches (table set-up, operand re-packing, partial-sum reductions) only record themselves when the
+// call has launched nothing else.  Cost per launch: two thread-local stores.
+namespace epn {
+void note_kernel(const void *host_stub, bool aux);   // c_api.hip; thread-local, diagnostic only
+}  // namespace epn
+#define EPN_LAUNCH(kern, ...)                                                       \
+    do {                                                                            \
+        ::epn::note_kernel(reinterpret_cast<const void *>(&kern), false);           \
+        hipLaunchKernelGGL(kern, __VA_ARGS__);                                      \
+    } while (0)
+#define EPN_LAUNCH_AUX(kern, ...)                                                   \
+    do {                                                                            \
+        ::epn::note_kernel(reinterpret_cast<const void *>(&kern), true);            \
+        hipLaunchKernelGGL(kern, __VA_ARGS__);                                      \
+    } while (0)
+
 static inline int epn_cdiv(long long a, long long b) { return (int)((a + b - 1) / b); }
 
 // Canonical squared norm shared bit-for-bit with oracle/epn_oracle.c:

@@ -902,7 +902,7 @@ int launch_nt_cfg(GemmNtBatch &B, hipStream_t st) {
     }
     B.ntiles = total;
     if (total == 0) return 0;
-    hipLaunchKernelGGL((gemm_nt_kernel<T, TO, WGM, WGN, TM, TN, KS, NSTG>), dim3(total), dim3(64 * WGM * WGN), 0, st, B);
+    EPN_LAUNCH((gemm_nt_kernel<T, TO, WGM, WGN, TM, TN, KS, NSTG>), dim3(total), dim3(64 * WGM * WGN), 0, st, B);
     EPN_CHECK_LAUNCH();
     return 0;
 }
@@ -926,7 +926,7 @@ int launch_nt_typed(GemmNtBatch &B, hipStream_t st) {
             const GemmNtProb &p = B.p[i];
             if (p.M == 0) continue;
             const long long n = p.M * p.N;
-            hipLaunchKernelGGL((gemm_nt_generic_kernel<T, TO>), dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st,
+            EPN_LAUNCH((gemm_nt_generic_kernel<T, TO>), dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st,
                                static_cast<const T *>(p.A), static_cast<const T *>(p.Bt), static_cast<TO *>(p.C), p.M,
                                p.N, p.K, p.lda, p.ldb, p.ldc);
             EPN_CHECK_LAUNCH();
@@ -1072,7 +1072,7 @@ int launch_tn_typed(GemmTnBatch &B, void *ws, size_t ws_bytes, hipStream_t st, b
         for (int i = 0; i < B.nprob; ++i) {
             const GemmTnArgs &G = B.p[i];
             const long long n = (long long)G.N1 * G.N2;
-            hipLaunchKernelGGL((gemm_tn_generic_kernel<T>), dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st,
+            EPN_LAUNCH((gemm_tn_generic_kernel<T>), dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st,
                                static_cast<const T *>(G.X), static_cast<const T *>(G.Y), static_cast<float *>(G.C), G.R,
                                G.N1, G.N2, G.ldx, G.ldy, G.ldc);
             EPN_CHECK_LAUNCH();
@@ -1086,15 +1086,15 @@ int launch_tn_typed(GemmTnBatch &B, void *ws, size_t ws_bytes, hipStream_t st, b
     if constexpr (sizeof(T) == 4) {
 #define EPN_TN(...)                                                                                                  \
     do {                                                                                                             \
-        if (x3) hipLaunchKernelGGL((gemm_tn_f32_kernel<__VA_ARGS__, true>), grid, dim3(64 * tn_waves(__VA_ARGS__)), 0, st, B);  \
-        else hipLaunchKernelGGL((gemm_tn_f32_kernel<__VA_ARGS__, false>), grid, dim3(64 * tn_waves(__VA_ARGS__)), 0, st, B);    \
+        if (x3) EPN_LAUNCH((gemm_tn_f32_kernel<__VA_ARGS__, true>), grid, dim3(64 * tn_waves(__VA_ARGS__)), 0, st, B);  \
+        else EPN_LAUNCH((gemm_tn_f32_kernel<__VA_ARGS__, false>), grid, dim3(64 * tn_waves(__VA_ARGS__)), 0, st, B);    \
     } while (0)
-#define EPN_TX(...) hipLaunchKernelGGL((gemm_tn_x3_kernel<__VA_ARGS__>), grid, dim3(64 * tn_waves(__VA_ARGS__)), 0, st, B)
+#define EPN_TX(...) EPN_LAUNCH((gemm_tn_x3_kernel<__VA_ARGS__>), grid, dim3(64 * tn_waves(__VA_ARGS__)), 0, st, B)
         if (x3 && B.p[0].Xp) {
             for (int i = 0; i < B.nprob; ++i) {         // X's bf16 planes (workspace, after the slabs)
                 const GemmTnArgs &G = B.p[i];
                 const long long n = (G.R >> 3) * G.N1;
-                hipLaunchKernelGGL(split_octets_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st,
+                EPN_LAUNCH_AUX(split_octets_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st,
                                    static_cast<const float *>(G.X), G.ldx, G.R, G.N1, static_cast<u32x4 *>(const_cast<void *>(G.Xp)));
                 EPN_CHECK_LAUNCH();
             }
@@ -1116,12 +1116,12 @@ int launch_tn_typed(GemmTnBatch &B, void *ws, size_t ws_bytes, hipStream_t st, b
 #undef EPN_TN
 #undef EPN_TX
     } else {
-        if (bn1 == 32) hipLaunchKernelGGL((gemm_tn_bf16_kernel<1, 4, 2, 4>), grid, dim3(256), 0, st, B);        // 4 waves: fewer,
-        else if (bn1 == 64) hipLaunchKernelGGL((gemm_tn_bf16_kernel<1, 4, 4, 4>), grid, dim3(256), 0, st, B);   // larger wave tiles
+        if (bn1 == 32) EPN_LAUNCH((gemm_tn_bf16_kernel<1, 4, 2, 4>), grid, dim3(256), 0, st, B);        // 4 waves: fewer,
+        else if (bn1 == 64) EPN_LAUNCH((gemm_tn_bf16_kernel<1, 4, 4, 4>), grid, dim3(256), 0, st, B);   // larger wave tiles
         // 128 x 256 tile on FOUR waves (64 x 128 per wave: 32 MFMAs per 12 transposed LDS reads).  The 8-wave form (16 MFMAs
         // per 16 reads) was LDS-bandwidth bound -- 3 workgroups x 64 KB of fragment reads per 1024 cycles > 128 B/clk:
         // 245760 x 256 x 6144: 1.63 -> 1.23 ms (630 TFLOP/s)
-        else hipLaunchKernelGGL((gemm_tn_bf16_kernel<2, 2, 4, 8>), grid, dim3(256), 0, st, B);
+        else EPN_LAUNCH((gemm_tn_bf16_kernel<2, 2, 4, 8>), grid, dim3(256), 0, st, B);
     }
     EPN_CHECK_LAUNCH();
     bool any_split = false;
@@ -1134,7 +1134,7 @@ int launch_tn_typed(GemmTnBatch &B, void *ws, size_t ws_bytes, hipStream_t st, b
     if (any_split) {
         const size_t nv = (nmax + 3) / 4;               // one thread per four outputs
         const unsigned gx = (unsigned)((nv + 255) / 256 < 2048 ? (nv + 255) / 256 : 2048);
-        hipLaunchKernelGGL(gemm_tn_reduce_kernel, dim3(gx, B.nprob), dim3(256), 0, st, B);
+        EPN_LAUNCH_AUX(gemm_tn_reduce_kernel, dim3(gx, B.nprob), dim3(256), 0, st, B);
         EPN_CHECK_LAUNCH();
     }
     return 0;
@@ -1218,13 +1218,13 @@ int launch_transpose_cast(const void *src, void *dst, int rows, int cols, int sr
     if (!src || !dst) return EPN_ENULL;
     const dim3 grid((cols + 31) / 32, (rows + 31) / 32), blk(32, 8);
     if (!src_bf16 && !dst_bf16)
-        hipLaunchKernelGGL((transpose_cast_kernel<float, float>), grid, blk, 0, st, (const float *)src, (float *)dst, rows, cols);
+        EPN_LAUNCH((transpose_cast_kernel<float, float>), grid, blk, 0, st, (const float *)src, (float *)dst, rows, cols);
     else if (!src_bf16 && dst_bf16)
-        hipLaunchKernelGGL((transpose_cast_kernel<float, __bf16>), grid, blk, 0, st, (const float *)src, (__bf16 *)dst, rows, cols);
+        EPN_LAUNCH((transpose_cast_kernel<float, __bf16>), grid, blk, 0, st, (const float *)src, (__bf16 *)dst, rows, cols);
     else if (src_bf16 && !dst_bf16)
-        hipLaunchKernelGGL((transpose_cast_kernel<__bf16, float>), grid, blk, 0, st, (const __bf16 *)src, (float *)dst, rows, cols);
+        EPN_LAUNCH((transpose_cast_kernel<__bf16, float>), grid, blk, 0, st, (const __bf16 *)src, (float *)dst, rows, cols);
     else
-        hipLaunchKernelGGL((transpose_cast_kernel<__bf16, __bf16>), grid, blk, 0, st, (const __bf16 *)src, (__bf16 *)dst, rows, cols);
+        EPN_LAUNCH((transpose_cast_kernel<__bf16, __bf16>), grid, blk, 0, st, (const __bf16 *)src, (__bf16 *)dst, rows, cols);
     EPN_CHECK_LAUNCH();
     return 0;
 }
@@ -1233,8 +1233,8 @@ int launch_cast(const void *src, void *dst, size_t n, int src_bf16, int dst_bf16
     if (n == 0) return 0;
     if (!src || !dst) return EPN_ENULL;
     const dim3 grid((unsigned)((n + 255) / 256 < 4096 ? (n + 255) / 256 : 4096)), blk(256);
-    if (!src_bf16 && dst_bf16) hipLaunchKernelGGL((cast_kernel<float, __bf16>), grid, blk, 0, st, (const float *)src, (__bf16 *)dst, n);
-    else if (src_bf16 && !dst_bf16) hipLaunchKernelGGL((cast_kernel<__bf16, float>), grid, blk, 0, st, (const __bf16 *)src, (float *)dst, n);
+    if (!src_bf16 && dst_bf16) EPN_LAUNCH((cast_kernel<float, __bf16>), grid, blk, 0, st, (const float *)src, (__bf16 *)dst, n);
+    else if (src_bf16 && !dst_bf16) EPN_LAUNCH((cast_kernel<__bf16, float>), grid, blk, 0, st, (const __bf16 *)src, (float *)dst, n);
     else return EPN_EINVAL;
     EPN_CHECK_LAUNCH();
     return 0;

@@ -257,7 +257,7 @@ int launch_x3_cfg(GemmNtBatch &B, hipStream_t st) {
     }
     B.ntiles = total;
     if (total == 0) return 0;
-    hipLaunchKernelGGL((gemm_nt_x3_kernel<WGM, WGN, TM, TN, NSTG>), dim3(total), dim3(64 * WGM * WGN), 0, st, B);
+    EPN_LAUNCH((gemm_nt_x3_kernel<WGM, WGN, TM, TN, NSTG>), dim3(total), dim3(64 * WGM * WGN), 0, st, B);
     EPN_CHECK_LAUNCH();
     return 0;
 }
@@ -287,7 +287,7 @@ int launch_gemm_nt_x3(GemmNtBatch &B, void *ws, size_t ws_bytes, hipStream_t st)
     for (int i = 0; i < B.nprob; ++i) {
         GemmNtProb &p = B.p[i];
         const long long pairs = (long long)p.N * (p.K / 2);
-        hipLaunchKernelGGL(split_planes_kernel, dim3((unsigned)((pairs + 255) / 256)), dim3(256), 0, st,
+        EPN_LAUNCH_AUX(split_planes_kernel, dim3((unsigned)((pairs + 255) / 256)), dim3(256), 0, st,
                            static_cast<const float *>(p.Bt), p.ldb, p.N, p.K, reinterpret_cast<unsigned *>(w));
         EPN_CHECK_LAUNCH();
         p.Bp = w;

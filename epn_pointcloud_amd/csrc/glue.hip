@@ -344,10 +344,10 @@ static int chan_stats_any(const void *x_cl, int groups, long long rows, int c, f
     dim3 grid;
     NormArgs A = make_norm(rows, c, 0.f, 0.f, grid, groups);
     A.x = x_cl; A.out_sums = static_cast<float *>(workspace);
-    if (bf16) hipLaunchKernelGGL(chan_stats_kernel<__bf16>, grid, dim3(GT), 0, st, A);
-    else hipLaunchKernelGGL(chan_stats_kernel<float>, grid, dim3(GT), 0, st, A);
+    if (bf16) EPN_LAUNCH(chan_stats_kernel<__bf16>, grid, dim3(GT), 0, st, A);
+    else EPN_LAUNCH(chan_stats_kernel<float>, grid, dim3(GT), 0, st, A);
     EPN_CHECK_LAUNCH();
-    hipLaunchKernelGGL(stats_finish_kernel, dim3(epn_cdiv(2 * c, 16), groups), dim3(256), 0, st, A.out_sums, (int)grid.x,
+    EPN_LAUNCH_AUX(stats_finish_kernel, dim3(epn_cdiv(2 * c, 16), groups), dim3(256), 0, st, A.out_sums, (int)grid.x,
                        c * 2, sums);
     EPN_CHECK_LAUNCH();
     return 0;
@@ -363,8 +363,8 @@ static int norm_act_fwd_any(const void *x_cl, int groups, long long rows, int c,
     dim3 grid;
     NormArgs A = make_norm(rows, c, eps, slope, grid, groups);
     A.x = x_cl; A.sums = sums; A.gamma = gamma; A.beta = beta; A.res = residual_cl; A.y = y_cl;
-    if (bf16) hipLaunchKernelGGL(norm_act_fwd_kernel<__bf16>, grid, dim3(GT), 0, epn_stream(stream), A);
-    else hipLaunchKernelGGL(norm_act_fwd_kernel<float>, grid, dim3(GT), 0, epn_stream(stream), A);
+    if (bf16) EPN_LAUNCH(norm_act_fwd_kernel<__bf16>, grid, dim3(GT), 0, epn_stream(stream), A);
+    else EPN_LAUNCH(norm_act_fwd_kernel<float>, grid, dim3(GT), 0, epn_stream(stream), A);
     EPN_CHECK_LAUNCH();
     return 0;
 }
@@ -389,12 +389,12 @@ static int norm_act_bwd_reduce_any(const void *x_cl, const void *dy_cl, int grou
     NormArgs A = make_norm(rows, c, eps, slope, grid, groups);
     A.x = x_cl; A.dy = dy_cl; A.sums = sums; A.gamma = gamma; A.beta = beta;
     A.out_sums = static_cast<float *>(workspace);
-    if (bf16) hipLaunchKernelGGL(norm_act_bwd_reduce_kernel<__bf16>, grid, dim3(GT), 0, st, A);
-    else hipLaunchKernelGGL(norm_act_bwd_reduce_kernel<float>, grid, dim3(GT), 0, st, A);
+    if (bf16) EPN_LAUNCH(norm_act_bwd_reduce_kernel<__bf16>, grid, dim3(GT), 0, st, A);
+    else EPN_LAUNCH(norm_act_bwd_reduce_kernel<float>, grid, dim3(GT), 0, st, A);
     EPN_CHECK_LAUNCH();
     if (dgamma) EPN_HIP(hipMemsetAsync(dgamma, 0, sizeof(float) * c, st));
     if (dbeta) EPN_HIP(hipMemsetAsync(dbeta, 0, sizeof(float) * c, st));
-    hipLaunchKernelGGL(bwd_finish_kernel, dim3(epn_cdiv(c, 16), groups), dim3(256), 0, st, A.out_sums, (int)grid.x, c, gamma,
+    EPN_LAUNCH_AUX(bwd_finish_kernel, dim3(epn_cdiv(c, 16), groups), dim3(256), 0, st, A.out_sums, (int)grid.x, c, gamma,
                        dsums, dgamma, dbeta);
     EPN_CHECK_LAUNCH();
     return 0;
@@ -410,8 +410,8 @@ static int norm_act_bwd_apply_any(const void *x_cl, const void *dy_cl, int group
     dim3 grid;
     NormArgs A = make_norm(rows, c, eps, slope, grid, groups);
     A.x = x_cl; A.dy = dy_cl; A.sums = sums; A.dsums = dsums; A.gamma = gamma; A.beta = beta; A.y = dx_cl;
-    if (bf16) hipLaunchKernelGGL(norm_act_bwd_apply_kernel<__bf16>, grid, dim3(GT), 0, epn_stream(stream), A);
-    else hipLaunchKernelGGL(norm_act_bwd_apply_kernel<float>, grid, dim3(GT), 0, epn_stream(stream), A);
+    if (bf16) EPN_LAUNCH(norm_act_bwd_apply_kernel<__bf16>, grid, dim3(GT), 0, epn_stream(stream), A);
+    else EPN_LAUNCH(norm_act_bwd_apply_kernel<float>, grid, dim3(GT), 0, epn_stream(stream), A);
     EPN_CHECK_LAUNCH();
     return 0;
 }
@@ -421,7 +421,7 @@ extern "C" int epn_bn_running_update_f32(const float *sums, double count, const 
                                         epn_stream_t stream) {
     if (c < 1 || c > 1024 || count < 1.0) return EPN_EINVAL;
     if (!sums || !running_mean || !running_var || !num_batches_tracked) return EPN_ENULL;
-    hipLaunchKernelGGL(bn_running_update_kernel, dim3(1), dim3(1024), 0, epn_stream(stream), sums, (float)count, conv_bias,
+    EPN_LAUNCH(bn_running_update_kernel, dim3(1), dim3(1024), 0, epn_stream(stream), sums, (float)count, conv_bias,
                        running_mean, running_var, num_batches_tracked, momentum, c);
     EPN_CHECK_LAUNCH();
     return 0;
@@ -510,12 +510,12 @@ extern "C" int epn_intra_group_f32(const float *feats_cl, const int32_t *intra_i
     const long long cols = (long long)b * p * na;
     if (c % 4 == 0) {
         const long long n = cols * kn * (c / 4);
-        hipLaunchKernelGGL((intra_group_kernel<f32x4>), dim3((unsigned)((n + 255) / 256)), dim3(256), 0,
+        EPN_LAUNCH((intra_group_kernel<f32x4>), dim3((unsigned)((n + 255) / 256)), dim3(256), 0,
                            epn_stream(stream), reinterpret_cast<const f32x4 *>(feats_cl), intra_idx,
                            reinterpret_cast<f32x4 *>(grouped), n, na, kn, c / 4);
     } else {
         const long long n = cols * kn * c;
-        hipLaunchKernelGGL((intra_group_kernel<float>), dim3((unsigned)((n + 255) / 256)), dim3(256), 0,
+        EPN_LAUNCH((intra_group_kernel<float>), dim3((unsigned)((n + 255) / 256)), dim3(256), 0,
                            epn_stream(stream), feats_cl, intra_idx, grouped, n, na, kn, c);
     }
     EPN_CHECK_LAUNCH();
@@ -552,7 +552,7 @@ extern "C" int epn_gather_rows(const void *src, const int32_t *idx, void *dst, i
     const long long n = (long long)b * p2 * (row_bytes / 16);
     if (n == 0) return 0;
     if (!src || !idx || !dst) return EPN_ENULL;
-    hipLaunchKernelGGL(epn::rows_gather_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, epn_stream(stream),
+    EPN_LAUNCH(epn::rows_gather_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, epn_stream(stream),
                        static_cast<const f32x4 *>(src), idx, static_cast<f32x4 *>(dst), n, p1, p2, (int)(row_bytes / 16), 0);
     EPN_CHECK_LAUNCH();
     return 0;
@@ -568,7 +568,7 @@ extern "C" int epn_scatter_rows(const void *grad_dst, const int32_t *idx, void *
     const long long n = (long long)b * p2 * (row_bytes / 16);
     if (n == 0) return 0;
     if (!grad_dst || !idx) return EPN_ENULL;
-    hipLaunchKernelGGL(epn::rows_gather_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st,
+    EPN_LAUNCH(epn::rows_gather_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st,
                        static_cast<const f32x4 *>(grad_dst), idx, static_cast<f32x4 *>(grad_src), n, p1, p2,
                        (int)(row_bytes / 16), 1);
     EPN_CHECK_LAUNCH();
@@ -623,7 +623,7 @@ extern "C" int epn_conv1x1_c1_f32(const float *x, const float *w, float *y, long
     if (rows == 0) return 0;
     if (!x || !w || !y) return EPN_ENULL;
     const long long n4 = rows * (cout / 4);
-    hipLaunchKernelGGL(epn::c1_outer_kernel, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, epn_stream(stream), x,
+    EPN_LAUNCH(epn::c1_outer_kernel, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, epn_stream(stream), x,
                        reinterpret_cast<const f32x4 *>(w), reinterpret_cast<f32x4 *>(y), n4, cout / 4);
     EPN_CHECK_LAUNCH();
     return 0;
@@ -639,7 +639,7 @@ extern "C" int epn_conv1x1_c1_bwd_weight_f32(const float *x, const float *grad_y
     if (!x || !grad_y) return EPN_ENULL;
     const long long blocks = rows < 1024 * 64 ? (rows + 63) / 64 : 1024;
     const long long rpb = (rows + blocks - 1) / blocks;
-    hipLaunchKernelGGL(epn::c1_outer_bwd_kernel, dim3((unsigned)((rows + rpb - 1) / rpb)), dim3(256), 0, st, x,
+    EPN_LAUNCH(epn::c1_outer_bwd_kernel, dim3((unsigned)((rows + rpb - 1) / rpb)), dim3(256), 0, st, x,
                        reinterpret_cast<const f32x4 *>(grad_y), grad_w, rows, cout / 4, rpb);
     EPN_CHECK_LAUNCH();
     return 0;

@@ -341,7 +341,7 @@ extern "C" int epn_ball_query_f32(const float *new_xyz, const float *xyz, int b,
     if (b > 65535) return EPN_EINVAL;
     const int waves = 4;
     dim3 grid(epn_cdiv(m, waves), b);
-    hipLaunchKernelGGL(ball_query_kernel<float>, grid, dim3(64 * waves), waves * nsample * sizeof(int32_t),
+    EPN_LAUNCH(ball_query_kernel<float>, grid, dim3(64 * waves), waves * nsample * sizeof(int32_t),
                        epn_stream(stream), new_xyz, xyz, n, m, radius, nsample, idx);
     EPN_CHECK_LAUNCH();
     return 0;
@@ -359,7 +359,7 @@ extern "C" int epn_fps_f32(const float *xyz, int b, int n, int m, int32_t *idx, 
     do {                                                                                                             \
         EPN_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&fps_wave_kernel<P, W>),                          \
                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh));                           \
-        hipLaunchKernelGGL((fps_wave_kernel<P, W>), dim3(b), dim3(64 * W), sh, st0, xyz, n, m, block, idx);          \
+        EPN_LAUNCH((fps_wave_kernel<P, W>), dim3(b), dim3(64 * W), sh, st0, xyz, n, m, block, idx);          \
     } while (0)
         if (n <= 64) EPN_FPSW(1, 1);
         else if (n <= 128) EPN_FPSW(1, 2);
@@ -382,7 +382,7 @@ extern "C" int epn_fps_f32(const float *xyz, int b, int n, int m, int32_t *idx, 
     do {                                                                                            \
         EPN_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&fps_kernel<P>),                 \
                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem));      \
-        hipLaunchKernelGGL(fps_kernel<P>, dim3(b), dim3(threads), shmem, st, xyz, n, m, block, in_lds, idx); \
+        EPN_LAUNCH(fps_kernel<P>, dim3(b), dim3(threads), shmem, st, xyz, n, m, block, in_lds, idx); \
     } while (0)
     if (ppt <= 1) EPN_FPS(1);
     else if (ppt <= 2) EPN_FPS(2);
@@ -402,7 +402,7 @@ extern "C" int epn_gather_fwd_f32(const float *points, const int32_t *idx, int b
     if (!points || !idx || !out) return EPN_ENULL;
     if (c > 65535 || b > 65535) return EPN_EINVAL;
     dim3 grid(epn_cdiv(m, 256), c, b);
-    hipLaunchKernelGGL(gather_fwd_kernel<float>, grid, dim3(256), 0, epn_stream(stream), points, idx, c, n, m, out);
+    EPN_LAUNCH(gather_fwd_kernel<float>, grid, dim3(256), 0, epn_stream(stream), points, idx, c, n, m, out);
     EPN_CHECK_LAUNCH();
     return 0;
 }
@@ -417,7 +417,7 @@ extern "C" int epn_gather_bwd_f32(const float *grad_out, const int32_t *idx, int
     if (!grad_out || !idx) return EPN_ENULL;
     if (c > 65535 || b > 65535) return EPN_EINVAL;
     dim3 grid(epn_cdiv(m, 256), c, b);
-    hipLaunchKernelGGL(gather_bwd_kernel<float>, grid, dim3(256), 0, epn_stream(stream), grad_out, idx, c, n, m,
+    EPN_LAUNCH(gather_bwd_kernel<float>, grid, dim3(256), 0, epn_stream(stream), grad_out, idx, c, n, m,
                        grad_points);
     EPN_CHECK_LAUNCH();
     return 0;
@@ -515,7 +515,7 @@ extern "C" int epn_initial_anchor_query_f32(const float *centers, const float *x
     if ((long long)ks * na > (long long)AQ_T * AQ_OUT) return EPN_EINVAL;
     if (b == 0 || nc == 0) return 0;
     if (!centers || !kernel_points || !anchor_weights || !anchor_ctn || (m > 0 && !xyz)) return EPN_ENULL;
-    hipLaunchKernelGGL(initial_anchor_query_kernel, dim3((unsigned)nc, (unsigned)b), dim3(AQ_T), 0, epn_stream(stream),
+    EPN_LAUNCH(initial_anchor_query_kernel, dim3((unsigned)nc, (unsigned)b), dim3(AQ_T), 0, epn_stream(stream),
                        centers, xyz, kernel_points, nc, m, na, ks, radius, sigma, anchor_weights, anchor_ctn);
     EPN_CHECK_LAUNCH();
     return 0;
@@ -530,7 +530,7 @@ extern "C" int epn_ball_query_f64(const double *new_xyz, const double *xyz, int 
     if (b > 65535) return EPN_EINVAL;
     const int waves = 4;
     dim3 grid(epn_cdiv(m, waves), b);
-    hipLaunchKernelGGL(ball_query_kernel<double>, grid, dim3(64 * waves), waves * nsample * sizeof(int32_t),
+    EPN_LAUNCH(ball_query_kernel<double>, grid, dim3(64 * waves), waves * nsample * sizeof(int32_t),
                        epn_stream(stream), new_xyz, xyz, n, m, radius, nsample, idx);
     EPN_CHECK_LAUNCH();
     return 0;
@@ -541,7 +541,7 @@ extern "C" int epn_fps_f64(const double *xyz, int b, int n, int m, double *temp,
     if (b == 0 || m == 0) return 0;
     if (!xyz || !temp || !idx) return EPN_ENULL;
     const int block = opt_n_threads(n);
-    hipLaunchKernelGGL(fps_f64_kernel, dim3(b), dim3(block), 0, epn_stream(stream), xyz, n, m, block, temp, idx);
+    EPN_LAUNCH(fps_f64_kernel, dim3(b), dim3(block), 0, epn_stream(stream), xyz, n, m, block, temp, idx);
     EPN_CHECK_LAUNCH();
     return 0;
 }
@@ -553,7 +553,7 @@ extern "C" int epn_gather_fwd_f64(const double *points, const int32_t *idx, int 
     if (!points || !idx || !out) return EPN_ENULL;
     if (c > 65535 || b > 65535) return EPN_EINVAL;
     dim3 grid(epn_cdiv(m, 256), c, b);
-    hipLaunchKernelGGL(gather_fwd_kernel<double>, grid, dim3(256), 0, epn_stream(stream), points, idx, c, n, m, out);
+    EPN_LAUNCH(gather_fwd_kernel<double>, grid, dim3(256), 0, epn_stream(stream), points, idx, c, n, m, out);
     EPN_CHECK_LAUNCH();
     return 0;
 }
@@ -568,7 +568,7 @@ extern "C" int epn_gather_bwd_f64(const double *grad_out, const int32_t *idx, in
     if (!grad_out || !idx) return EPN_ENULL;
     if (c > 65535 || b > 65535) return EPN_EINVAL;
     dim3 grid(epn_cdiv(m, 256), c, b);
-    hipLaunchKernelGGL(gather_bwd_kernel<double>, grid, dim3(256), 0, epn_stream(stream), grad_out, idx, c, n, m,
+    EPN_LAUNCH(gather_bwd_kernel<double>, grid, dim3(256), 0, epn_stream(stream), grad_out, idx, c, n, m,
                        grad_points);
     EPN_CHECK_LAUNCH();
     return 0;

@@ -178,7 +178,7 @@ int launch_inter_c1_fwd(const epn_inter_desc *d, const float *rk, const float *f
     C1Args A = make_c1(d, rk);
     A.feats = feats; A.W = W; A.out = out;
     const unsigned grid = (unsigned)((A.ncol + 255) / 256);
-    hipLaunchKernelGGL(inter_c1_fwd_kernel, dim3(grid), dim3(256), (size_t)d->cout * d->ks * sizeof(float), st, A);
+    EPN_LAUNCH(inter_c1_fwd_kernel, dim3(grid), dim3(256), (size_t)d->cout * d->ks * sizeof(float), st, A);
     EPN_CHECK_LAUNCH();
     return 0;
 }
@@ -193,7 +193,7 @@ int launch_inter_c1_bwd_weight(const epn_inter_desc *d, const float *rk, const f
     long long wgs = groups < 512 ? groups : 512;
     A.groups_per_wg = (int)((groups + wgs - 1) / wgs);
     const unsigned grid = (unsigned)((groups + A.groups_per_wg - 1) / A.groups_per_wg);
-    hipLaunchKernelGGL(inter_c1_bwd_weight_kernel, dim3(grid), dim3(256), 0, st, A);
+    EPN_LAUNCH(inter_c1_bwd_weight_kernel, dim3(grid), dim3(256), 0, st, A);
     EPN_CHECK_LAUNCH();
     return 0;
 }

@@ -510,7 +510,7 @@ static int launch_fx_fwd_nt(const FxArgs &F, const epn_inter_desc *d, hipStream_
 #define EPN_FX_GO(PT_, WGM_, WGN_, TN_, KS_)                                                                         \
     do {                                                                                                             \
         const unsigned grid = (unsigned)((F.npts + (PT_) - 1) / (PT_));                                              \
-        hipLaunchKernelGGL((inter_fx_fwd_kernel<TF, NT, PT_, WGM_, WGN_, TN_, KS_>), dim3(grid), dim3(512), 0, st, F); \
+        EPN_LAUNCH((inter_fx_fwd_kernel<TF, NT, PT_, WGM_, WGN_, TN_, KS_>), dim3(grid), dim3(512), 0, st, F); \
         EPN_CHECK_LAUNCH();                                                                                          \
         return 0;                                                                                                    \
     } while (0)
@@ -540,7 +540,7 @@ int launch_inter_fx_fwd(const epn_inter_desc *d, const float *rk4, const void *f
     F.I.col_tiles_per_wg = 1;
     F.Wp = planes; F.out = out; F.KP = fx_kp(d); F.kq1 = fx_kq1(d); F.npts = d->b * d->p2;
     const long long pairs = (long long)d->cout * (F.KP / 2);
-    hipLaunchKernelGGL(fx_prep_w_kernel, dim3((unsigned)((pairs + 255) / 256)), dim3(256), 0, st, W, d->cout, d->cin, d->ks,
+    EPN_LAUNCH_AUX(fx_prep_w_kernel, dim3((unsigned)((pairs + 255) / 256)), dim3(256), 0, st, W, d->cout, d->cin, d->ks,
                        F.kq1, F.KP, bf16 ? 1 : 3, static_cast<unsigned *>(planes));
     EPN_CHECK_LAUNCH();
     const int nt = (d->nn + 15) / 16;

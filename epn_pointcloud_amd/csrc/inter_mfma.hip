@@ -1361,7 +1361,7 @@ int set_lds(K kern, size_t bytes) {
 int launch_inter_tables_mfma(const epn_inter_desc *d, const float *rk, float *rk4, float *beta, hipStream_t st) {
     (void)beta;
     const int n = d->na * EPN_KS_MAX;
-    hipLaunchKernelGGL(rk4_table_kernel, dim3(epn_cdiv(n, 256)), dim3(256), 0, st, rk, d->na, d->ks, 1.0f / d->sigma,
+    EPN_LAUNCH_AUX(rk4_table_kernel, dim3(epn_cdiv(n, 256)), dim3(256), 0, st, rk, d->na, d->ks, 1.0f / d->sigma,
                        rk4);
     EPN_CHECK_LAUNCH();
     return 0;
@@ -1392,7 +1392,7 @@ int launch_inter_fwd_mfma(const epn_inter_desc *d, const float *rk4, const float
     do {                                                                                                \
         int rc_ = set_lds(inter_fwd8_kernel<NT_, MT_>, lds);                                            \
         if (rc_) return rc_;                                                                            \
-        hipLaunchKernelGGL((inter_fwd8_kernel<NT_, MT_>), dim3(grid), dim3(64 * NW8), lds, st, A);      \
+        EPN_LAUNCH((inter_fwd8_kernel<NT_, MT_>), dim3(grid), dim3(64 * NW8), lds, st, A);      \
     } while (0)
         const int mt = d->cout / 16;
         if (d->nn <= 16) {
@@ -1420,7 +1420,7 @@ int launch_inter_fwd_mfma(const epn_inter_desc *d, const float *rk4, const float
     do {                                                                                              \
         int rc_ = set_lds(inter_fwd_kernel<NT_, KT_>, lds);                                           \
         if (rc_) return rc_;                                                                          \
-        hipLaunchKernelGGL((inter_fwd_kernel<NT_, KT_>), dim3(grid), dim3(64 * NW), lds, st, A);      \
+        EPN_LAUNCH((inter_fwd_kernel<NT_, KT_>), dim3(grid), dim3(64 * NW), lds, st, A);      \
     } while (0)
     EPN_DISPATCH_NT_KT(EPN_FWD, 0);
 #undef EPN_FWD
@@ -1433,7 +1433,7 @@ int launch_inter_bwd_data_mfma(const epn_inter_desc *d, const float *rk4, const 
     // WT: scratch [cin*ks][cout] (the caller passes the workspace slot in the `beta` position)
     float *wt = const_cast<float *>(WT);
     const size_t nW = (size_t)d->cout * d->cin * d->ks;
-    hipLaunchKernelGGL(transpose_kernel, dim3((unsigned)((nW + 255) / 256)), dim3(256), 0, st, W, d->cout,
+    EPN_LAUNCH_AUX(transpose_kernel, dim3((unsigned)((nW + 255) / 256)), dim3(256), 0, st, W, d->cout,
                        d->cin * d->ks, wt);
     EPN_CHECK_LAUNCH();
     InterArgs A = make_args(d, rk4);
@@ -1446,7 +1446,7 @@ int launch_inter_bwd_data_mfma(const epn_inter_desc *d, const float *rk4, const 
     do {                                                                                                       \
         int rc_ = set_lds(inter_bwd_data8_kernel<NT_, KT_, MH_>, lds8);                                        \
         if (rc_) return rc_;                                                                                   \
-        hipLaunchKernelGGL((inter_bwd_data8_kernel<NT_, KT_, MH_>), dim3(grid8), dim3(64 * NW8), lds8, st, A); \
+        EPN_LAUNCH((inter_bwd_data8_kernel<NT_, KT_, MH_>), dim3(grid8), dim3(64 * NW8), lds8, st, A); \
     } while (0)
             if (d->nn <= 16) {
                 if (d->ks == 16) EPN_BD8(1, 1, 8); else if (d->ks == 24) EPN_BD8(1, 2, 12); else EPN_BD8(1, 2, 16);
@@ -1464,7 +1464,7 @@ int launch_inter_bwd_data_mfma(const epn_inter_desc *d, const float *rk4, const 
     do {                                                                                              \
         int rc_ = set_lds(inter_bwd_data_kernel<NT_, KT_>, lds);                                      \
         if (rc_) return rc_;                                                                          \
-        hipLaunchKernelGGL((inter_bwd_data_kernel<NT_, KT_>), dim3(grid), dim3(64 * NW), lds, st, A); \
+        EPN_LAUNCH((inter_bwd_data_kernel<NT_, KT_>), dim3(grid), dim3(64 * NW), lds, st, A); \
     } while (0)
     EPN_DISPATCH_NT_KT(EPN_BD, 0);
 #undef EPN_BD
@@ -1492,7 +1492,7 @@ int launch_inter_bwd_weight_mfma(const epn_inter_desc *d, const float *rk4, cons
     do {                                                                                                         \
         int rc_ = set_lds(inter_bwd_weight8_kernel<NT_, MO_>, lds8);                                             \
         if (rc_) return rc_;                                                                                     \
-        hipLaunchKernelGGL((inter_bwd_weight8_kernel<NT_, MO_>), dim3(gx8, chunks8, oblocks8), dim3(64 * NW8),   \
+        EPN_LAUNCH((inter_bwd_weight8_kernel<NT_, MO_>), dim3(gx8, chunks8, oblocks8), dim3(64 * NW8),   \
                            lds8, st, A);                                                                         \
     } while (0)
         if (d->nn <= 16) {
@@ -1517,7 +1517,7 @@ int launch_inter_bwd_weight_mfma(const epn_inter_desc *d, const float *rk4, cons
     do {                                                                                                 \
         int rc_ = set_lds(inter_bwd_weight_kernel<NT_, KT_>, lds);                                       \
         if (rc_) return rc_;                                                                             \
-        hipLaunchKernelGGL((inter_bwd_weight_kernel<NT_, KT_>), dim3(gx, chunks, oblocks), dim3(64 * NW), \
+        EPN_LAUNCH((inter_bwd_weight_kernel<NT_, KT_>), dim3(gx, chunks, oblocks), dim3(64 * NW), \
                            lds, st, A);                                                                  \
     } while (0)
     EPN_DISPATCH_NT_KT(EPN_BW, 0);
@@ -1540,8 +1540,8 @@ int launch_inter_group_mfma(const epn_inter_desc *d, const float *rk4, const voi
     const unsigned gy = (unsigned)(((d->cin >> 4) + A.col_tiles_per_wg - 1) / A.col_tiles_per_wg);
 #define EPN_GRP(NT_, KT_, dummy)                                                                                      \
     do {                                                                                                              \
-        if (bf16) hipLaunchKernelGGL((inter_group_kernel<NT_, KT_, __bf16>), dim3(grid, gy), dim3(64 * NW), 0, st, A); \
-        else hipLaunchKernelGGL((inter_group_kernel<NT_, KT_, float>), dim3(grid, gy), dim3(64 * NW), 0, st, A);      \
+        if (bf16) EPN_LAUNCH((inter_group_kernel<NT_, KT_, __bf16>), dim3(grid, gy), dim3(64 * NW), 0, st, A); \
+        else EPN_LAUNCH((inter_group_kernel<NT_, KT_, float>), dim3(grid, gy), dim3(64 * NW), 0, st, A);      \
     } while (0)
     EPN_DISPATCH_NT_KT(EPN_GRP, 0);
 #undef EPN_GRP
@@ -1551,9 +1551,9 @@ int launch_inter_group_mfma(const epn_inter_desc *d, const float *rk4, const voi
 
 int launch_inverse_list(const int32_t *idx, int b, int p1, int p2, int nn, int32_t *off, int32_t *ent, hipStream_t st) {
     if ((long long)p2 * nn <= INV_LDS_ENT && p1 <= INV_LDS_P1)
-        hipLaunchKernelGGL(inverse_list_lds_kernel, dim3(b), dim3(1024), 0, st, idx, p1, p2 * nn, off, ent);
+        EPN_LAUNCH(inverse_list_lds_kernel, dim3(b), dim3(1024), 0, st, idx, p1, p2 * nn, off, ent);
     else
-        hipLaunchKernelGGL(inverse_list_kernel, dim3(b), dim3(1024), 0, st, idx, p1, p2 * nn, off, ent);
+        EPN_LAUNCH(inverse_list_kernel, dim3(b), dim3(1024), 0, st, idx, p1, p2 * nn, off, ent);
     EPN_CHECK_LAUNCH();
     return 0;
 }
@@ -1578,14 +1578,14 @@ int launch_inter_ungroup_det_mfma(const epn_inter_desc *d, const float *rk4, con
         const int nt = (d->nn + 15) / 16;
         const int gp = ungroup_group_points(d, nt);
         if (order && canon && d->p2 % gp == 0 && d->p2 <= MORTON_MAX && d->p1 <= USH_TAB) {
-            hipLaunchKernelGGL(morton_order_kernel, dim3(d->b), dim3(1024), 0, st, d->new_xyz, d->p2, order);
+            EPN_LAUNCH_AUX(morton_order_kernel, dim3(d->b), dim3(1024), 0, st, d->new_xyz, d->p2, order);
             EPN_CHECK_LAUNCH();
             A.col_tiles_per_wg = 1;
             const dim3 grid((unsigned)(d->b * (d->p2 / gp)), (unsigned)(d->cin >> 4));
 #define EPN_USHD(NT_, KT_, GP_)                                                                                           \
     do {                                                                                                                  \
-        if (bf16) hipLaunchKernelGGL((inter_ungroup_shared_kernel<NT_, KT_, __bf16, GP_, ((NT_ == 1 && GP_ == 8) ? 2 : 1), true>), grid, dim3(64 * GP_), 0, st, A, order, canon); \
-        else hipLaunchKernelGGL((inter_ungroup_shared_kernel<NT_, KT_, float, GP_, ((NT_ == 1 && GP_ == 8) ? 2 : 1), true>), grid, dim3(64 * GP_), 0, st, A, order, canon);      \
+        if (bf16) EPN_LAUNCH((inter_ungroup_shared_kernel<NT_, KT_, __bf16, GP_, ((NT_ == 1 && GP_ == 8) ? 2 : 1), true>), grid, dim3(64 * GP_), 0, st, A, order, canon); \
+        else EPN_LAUNCH((inter_ungroup_shared_kernel<NT_, KT_, float, GP_, ((NT_ == 1 && GP_ == 8) ? 2 : 1), true>), grid, dim3(64 * GP_), 0, st, A, order, canon);      \
     } while (0)
             const int kt = (d->ks + 15) / 16;
             if (kt == 1) {
@@ -1602,10 +1602,10 @@ int launch_inter_ungroup_det_mfma(const epn_inter_desc *d, const float *rk4, con
 #undef EPN_USHD
             EPN_CHECK_LAUNCH();
             if (bf16)
-                hipLaunchKernelGGL((inter_reduce_slots_kernel<__bf16, __bf16>), g2, dim3(256), 0, st, static_cast<const __bf16 *>(slab),
+                EPN_LAUNCH_AUX((inter_reduce_slots_kernel<__bf16, __bf16>), g2, dim3(256), 0, st, static_cast<const __bf16 *>(slab),
                                    off, ent, static_cast<__bf16 *>(dF), d->b, d->p1, entries, rowlen, canon);
             else
-                hipLaunchKernelGGL((inter_reduce_slots_kernel<float, float>), g2, dim3(256), 0, st, static_cast<const float *>(slab),
+                EPN_LAUNCH_AUX((inter_reduce_slots_kernel<float, float>), g2, dim3(256), 0, st, static_cast<const float *>(slab),
                                    off, ent, static_cast<float *>(dF), d->b, d->p1, entries, rowlen, canon);
             EPN_CHECK_LAUNCH();
             return 0;
@@ -1619,17 +1619,17 @@ int launch_inter_ungroup_det_mfma(const epn_inter_desc *d, const float *rk4, con
     const unsigned gy = 1;
 #define EPN_USLOT(NT_, KT_, dummy)                                                                                       \
     do {                                                                                                                 \
-        if (bf16) hipLaunchKernelGGL((inter_ungroup_slots_kernel<NT_, KT_, __bf16>), dim3(grid, gy), dim3(64 * NW), 0, st, A); \
-        else hipLaunchKernelGGL((inter_ungroup_slots_kernel<NT_, KT_, float>), dim3(grid, gy), dim3(64 * NW), 0, st, A);      \
+        if (bf16) EPN_LAUNCH((inter_ungroup_slots_kernel<NT_, KT_, __bf16>), dim3(grid, gy), dim3(64 * NW), 0, st, A); \
+        else EPN_LAUNCH((inter_ungroup_slots_kernel<NT_, KT_, float>), dim3(grid, gy), dim3(64 * NW), 0, st, A);      \
     } while (0)
     EPN_DISPATCH_NT_KT(EPN_USLOT, 0);
 #undef EPN_USLOT
     EPN_CHECK_LAUNCH();
     if (bf16)
-        hipLaunchKernelGGL((inter_reduce_slots_kernel<__bf16, __bf16>), g2, dim3(256), 0, st, static_cast<const __bf16 *>(slab),
+        EPN_LAUNCH_AUX((inter_reduce_slots_kernel<__bf16, __bf16>), g2, dim3(256), 0, st, static_cast<const __bf16 *>(slab),
                            off, ent, static_cast<__bf16 *>(dF), d->b, d->p1, entries, rowlen);
     else
-        hipLaunchKernelGGL((inter_reduce_slots_kernel<float, float>), g2, dim3(256), 0, st, static_cast<const float *>(slab),
+        EPN_LAUNCH_AUX((inter_reduce_slots_kernel<float, float>), g2, dim3(256), 0, st, static_cast<const float *>(slab),
                            off, ent, static_cast<float *>(dF), d->b, d->p1, entries, rowlen);
     EPN_CHECK_LAUNCH();
     return 0;
@@ -1648,14 +1648,14 @@ int launch_inter_ungroup_mfma(const epn_inter_desc *d, const float *rk4, const v
     // K = 64: 8 points, one buffer; K = 128: 2.  K = 32 / 64 fall back to half the group when p2 does not divide.
     const int gp = ungroup_group_points(d, nt);
     if (order && d->p2 % gp == 0 && d->p2 <= MORTON_MAX && d->p1 <= USH_TAB && kernel_policy() != (0x400 | 1)) {
-        hipLaunchKernelGGL(morton_order_kernel, dim3(d->b), dim3(1024), 0, st, d->new_xyz, d->p2, order);
+        EPN_LAUNCH_AUX(morton_order_kernel, dim3(d->b), dim3(1024), 0, st, d->new_xyz, d->p2, order);
         EPN_CHECK_LAUNCH();
         A.col_tiles_per_wg = 1;     // chunks per workgroup (2 / 4 measured: no gain, the slot set-up is ~5 % of a workgroup)
         const dim3 grid((unsigned)(d->b * (d->p2 / gp)), (unsigned)(((d->cin >> 4) + A.col_tiles_per_wg - 1) / A.col_tiles_per_wg));
 #define EPN_USH(NT_, KT_, GP_)                                                                                            \
     do {                                                                                                                  \
-        if (bf16) hipLaunchKernelGGL((inter_ungroup_shared_kernel<NT_, KT_, __bf16, GP_, ((NT_ == 1 && GP_ == 8) ? 2 : 1)>), grid, dim3(64 * GP_), 0, st, A, order); \
-        else hipLaunchKernelGGL((inter_ungroup_shared_kernel<NT_, KT_, float, GP_, ((NT_ == 1 && GP_ == 8) ? 2 : 1)>), grid, dim3(64 * GP_), 0, st, A, order);      \
+        if (bf16) EPN_LAUNCH((inter_ungroup_shared_kernel<NT_, KT_, __bf16, GP_, ((NT_ == 1 && GP_ == 8) ? 2 : 1)>), grid, dim3(64 * GP_), 0, st, A, order); \
+        else EPN_LAUNCH((inter_ungroup_shared_kernel<NT_, KT_, float, GP_, ((NT_ == 1 && GP_ == 8) ? 2 : 1)>), grid, dim3(64 * GP_), 0, st, A, order);      \
     } while (0)
         const int kt = (d->ks + 15) / 16;
         if (kt == 1) {
@@ -1678,8 +1678,8 @@ int launch_inter_ungroup_mfma(const epn_inter_desc *d, const float *rk4, const v
     const unsigned gy = (unsigned)(((d->cin >> 4) + A.col_tiles_per_wg - 1) / A.col_tiles_per_wg);
 #define EPN_UGRP(NT_, KT_, dummy)                                                                                       \
     do {                                                                                                                \
-        if (bf16) hipLaunchKernelGGL((inter_ungroup_kernel<NT_, KT_, __bf16>), dim3(grid, gy), dim3(64 * NW), 0, st, A); \
-        else hipLaunchKernelGGL((inter_ungroup_kernel<NT_, KT_, float>), dim3(grid, gy), dim3(64 * NW), 0, st, A);      \
+        if (bf16) EPN_LAUNCH((inter_ungroup_kernel<NT_, KT_, __bf16>), dim3(grid, gy), dim3(64 * NW), 0, st, A); \
+        else EPN_LAUNCH((inter_ungroup_kernel<NT_, KT_, float>), dim3(grid, gy), dim3(64 * NW), 0, st, A);      \
     } while (0)
     EPN_DISPATCH_NT_KT(EPN_UGRP, 0);
 #undef EPN_UGRP

@@ -339,7 +339,7 @@ int run_gemm(const float *X, const int32_t *idx, const float *Wp, long long ncol
     A.wk = pick_wk(kn * ci, co);
     const size_t lds = (size_t)co * (A.wk + 4) * sizeof(float);
     const unsigned grid = (unsigned)((ncol + 16 * NW - 1) / (16 * NW));
-    hipLaunchKernelGGL(intra_gemm_kernel, dim3(grid), dim3(64 * NW), lds, st, A);
+    EPN_LAUNCH(intra_gemm_kernel, dim3(grid), dim3(64 * NW), lds, st, A);
     EPN_CHECK_LAUNCH();
     return 0;
 }
@@ -356,7 +356,7 @@ size_t intra_workspace_floats(int kn, int cin, int cout) { return rnd64((size_t)
 int launch_intra_fwd_mfma(const float *feats, const int32_t *iidx, const float *W, int b, int p, int na, int kn,
                           int cin, int cout, float *out, float *ws, hipStream_t st) {
     const size_t n = (size_t)cout * cin * kn;
-    hipLaunchKernelGGL(pack_w_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, W, cout, cin, kn, 0, ws);
+    EPN_LAUNCH_AUX(pack_w_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, W, cout, cin, kn, 0, ws);
     EPN_CHECK_LAUNCH();
     return run_gemm(feats, iidx, ws, (long long)b * p * na, na, kn, cin, cout, out, st);
 }
@@ -364,7 +364,7 @@ int launch_intra_fwd_mfma(const float *feats, const int32_t *iidx, const float *
 int launch_intra_bwd_data_mfma(const float *dOut, const int32_t *inv_idx, const float *W, int b, int p, int na,
                                int kn, int cin, int cout, float *dF, float *ws, hipStream_t st) {
     const size_t n = (size_t)cout * cin * kn;
-    hipLaunchKernelGGL(pack_w_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, W, cout, cin, kn, 1, ws);
+    EPN_LAUNCH_AUX(pack_w_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, W, cout, cin, kn, 1, ws);
     EPN_CHECK_LAUNCH();
     return run_gemm(dOut, inv_idx, ws, (long long)b * p * na, na, kn, cout, cin, dF, st);
 }
@@ -397,11 +397,11 @@ int launch_intra_bwd_weight_mfma(const float *feats, const float *dOut, const in
         const int threads = 64 * kn < 512 ? 512 : (64 * kn > 768 ? 768 : 64 * kn);   // staging assumes >= 512 threads
         EPN_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&intra_bwd_weight_pt_kernel),
                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        hipLaunchKernelGGL(intra_bwd_weight_pt_kernel, dim3(gxp, blocks), dim3(threads), lds, st, A, npts, per);
+        EPN_LAUNCH(intra_bwd_weight_pt_kernel, dim3(gxp, blocks), dim3(threads), lds, st, A, npts, per);
     } else if (cout % 64 == 0 && cin % 64 == 0)
-        hipLaunchKernelGGL(intra_bwd_weight_v4_kernel, dim3(gx, kblocks, tblocks), dim3(64 * NW), 0, st, A);
+        EPN_LAUNCH(intra_bwd_weight_v4_kernel, dim3(gx, kblocks, tblocks), dim3(64 * NW), 0, st, A);
     else
-        hipLaunchKernelGGL(intra_bwd_weight_kernel, dim3(gx, kblocks, tblocks), dim3(64 * NW), 0, st, A);
+        EPN_LAUNCH(intra_bwd_weight_kernel, dim3(gx, kblocks, tblocks), dim3(64 * NW), 0, st, A);
     EPN_CHECK_LAUNCH();
     return 0;
 }

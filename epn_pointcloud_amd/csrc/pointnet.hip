@@ -335,10 +335,10 @@ extern "C" int epn_pointnet_so3conv_fwd_f32(const float *feats_cl, const float *
     A.feats = feats_cl; A.xyz = xyz; A.anchors = anchors; A.W = W; A.bias = bias; A.out = out; A.arg = argmax;
     A.centre = centre;
     if (c % 16 == 0)
-        hipLaunchKernelGGL(pointnet_fwd_mfma_kernel, dim3((unsigned)(b * a), (unsigned)epn_cdiv(co, 128)), dim3(256), 0,
+        EPN_LAUNCH(pointnet_fwd_mfma_kernel, dim3((unsigned)(b * a), (unsigned)epn_cdiv(co, 128)), dim3(256), 0,
                            epn_stream(stream), A);
     else
-        hipLaunchKernelGGL(pointnet_fwd_kernel, dim3((unsigned)(b * a), (unsigned)epn_cdiv(co, PN_T)), dim3(PN_T), 0,
+        EPN_LAUNCH(pointnet_fwd_kernel, dim3((unsigned)(b * a), (unsigned)epn_cdiv(co, PN_T)), dim3(PN_T), 0,
                            epn_stream(stream), A);
     EPN_CHECK_LAUNCH();
     return 0;
@@ -353,7 +353,7 @@ extern "C" int epn_pointnet_so3conv_bwd_data_f32(const float *grad_out, const in
     if (!grad_out || !argmax || !W || !grad_feats_cl) return EPN_ENULL;
     PnArgs A = make_pn(b, p, a, c, co);
     A.gout = grad_out; A.arg_in = argmax; A.W = W; A.dfeats = grad_feats_cl;
-    hipLaunchKernelGGL(pointnet_bwd_data_kernel, dim3((unsigned)(b * a), (unsigned)epn_cdiv(c, PN_T)), dim3(PN_T), 0,
+    EPN_LAUNCH(pointnet_bwd_data_kernel, dim3((unsigned)(b * a), (unsigned)epn_cdiv(c, PN_T)), dim3(PN_T), 0,
                        epn_stream(stream), A);
     EPN_CHECK_LAUNCH();
     return 0;
@@ -376,7 +376,7 @@ extern "C" int epn_pointnet_so3conv_bwd_weight_f32(const float *grad_out, const 
     A.dW = grad_W; A.dbias = grad_bias;
     const long long nba = (long long)b * a;
     A.slices = (int)(nba < 16 ? nba : 16);
-    hipLaunchKernelGGL(pointnet_bwd_weight_kernel, dim3((unsigned)co, (unsigned)A.slices), dim3(256), 0, st, A);
+    EPN_LAUNCH(pointnet_bwd_weight_kernel, dim3((unsigned)co, (unsigned)A.slices), dim3(256), 0, st, A);
     EPN_CHECK_LAUNCH();
     return 0;
 }

@@ -420,9 +420,9 @@ static int so3_basis_any(const void *in, const float *M, const int32_t *blocks, 
     const long long tasks = pts * (c >> 6);
     const long long per_wg = (long long)SB_WAVES * SB_TPW;
     const dim3 grid((unsigned)((tasks + per_wg - 1) / per_wg));
-    if (bf16 == 1) hipLaunchKernelGGL(so3_basis_bf16_kernel, grid, dim3(64 * SB_WAVES), 0, epn_stream(stream), A);
-    else if (bf16 == 2) hipLaunchKernelGGL(so3_basis_x3_kernel, grid, dim3(64 * SB_WAVES), 0, epn_stream(stream), A);   // fp32, split form
-    else hipLaunchKernelGGL(so3_basis_kernel<float>, grid, dim3(64 * SB_WAVES), 0, epn_stream(stream), A);
+    if (bf16 == 1) EPN_LAUNCH(so3_basis_bf16_kernel, grid, dim3(64 * SB_WAVES), 0, epn_stream(stream), A);
+    else if (bf16 == 2) EPN_LAUNCH(so3_basis_x3_kernel, grid, dim3(64 * SB_WAVES), 0, epn_stream(stream), A);   // fp32, split form
+    else EPN_LAUNCH(so3_basis_kernel<float>, grid, dim3(64 * SB_WAVES), 0, epn_stream(stream), A);
     EPN_CHECK_LAUNCH();
     return 0;
 }

@@ -105,7 +105,7 @@ extern "C" int epn_zp_inter_fwd_f32(const int32_t *anchor_neighbors, const float
     const long long total = (long long)b * c * ks * np * na;
     if (total == 0) return 0;
     if (!anchor_neighbors || !anchor_weights || !feats || !anchor_feats) return EPN_ENULL;
-    hipLaunchKernelGGL(zp_inter_fwd_kernel, dim3(blocks_of(total)), dim3(256), 0, epn_stream(stream), anchor_neighbors,
+    EPN_LAUNCH(zp_inter_fwd_kernel, dim3(blocks_of(total)), dim3(256), 0, epn_stream(stream), anchor_neighbors,
                        anchor_weights, feats, anchor_feats, b, c, np, nq, na, ks, ann);
     EPN_CHECK_LAUNCH();
     return 0;
@@ -121,7 +121,7 @@ extern "C" int epn_zp_inter_bwd_f32(const int32_t *anchor_neighbors, const float
     const long long total = (long long)b * c * ks * np * na;
     if (total == 0) return 0;
     if (!anchor_neighbors || !anchor_weights || !grad_anchor_feats) return EPN_ENULL;
-    hipLaunchKernelGGL(zp_inter_bwd_kernel, dim3(blocks_of(total)), dim3(256), 0, epn_stream(stream), anchor_neighbors,
+    EPN_LAUNCH(zp_inter_bwd_kernel, dim3(blocks_of(total)), dim3(256), 0, epn_stream(stream), anchor_neighbors,
                        anchor_weights, grad_anchor_feats, grad_feats, b, c, np, nq, na, ks, ann);
     EPN_CHECK_LAUNCH();
     return 0;
@@ -135,7 +135,7 @@ extern "C" int epn_zp_intra_fwd_f32(const int32_t *anchor_neighbors, const float
     const long long total = (long long)b * c * ks * np * na_out;
     if (total == 0) return 0;
     if (!anchor_neighbors || !anchor_weights || !feats || !anchor_feats) return EPN_ENULL;
-    hipLaunchKernelGGL(zp_intra_fwd_kernel, dim3(blocks_of(total)), dim3(256), 0, epn_stream(stream), anchor_neighbors,
+    EPN_LAUNCH(zp_intra_fwd_kernel, dim3(blocks_of(total)), dim3(256), 0, epn_stream(stream), anchor_neighbors,
                        anchor_weights, feats, anchor_feats, b, c, np, na_in, na_out, ks, ann);
     EPN_CHECK_LAUNCH();
     return 0;
@@ -151,7 +151,7 @@ extern "C" int epn_zp_intra_bwd_f32(const int32_t *anchor_neighbors, const float
     const long long total = (long long)b * c * ks * np * na_out;
     if (total == 0) return 0;
     if (!anchor_neighbors || !anchor_weights || !grad_anchor_feats) return EPN_ENULL;
-    hipLaunchKernelGGL(zp_intra_bwd_kernel, dim3(blocks_of(total)), dim3(256), 0, epn_stream(stream), anchor_neighbors,
+    EPN_LAUNCH(zp_intra_bwd_kernel, dim3(blocks_of(total)), dim3(256), 0, epn_stream(stream), anchor_neighbors,
                        anchor_weights, grad_anchor_feats, grad_feats, b, c, np, na_in, na_out, ks, ann);
     EPN_CHECK_LAUNCH();
     return 0;
@@ -196,7 +196,7 @@ extern "C" int epn_anchor_query_f32(const float *grouped_xyz, const float *ancho
     const long long total = (long long)b * np * nn;
     if (total == 0) return 0;
     if (!grouped_xyz || !anchors || !kernel_points || !anchor_weights) return EPN_ENULL;
-    hipLaunchKernelGGL(epn::anchor_query_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, epn_stream(stream),
+    EPN_LAUNCH(epn::anchor_query_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, epn_stream(stream),
                        grouped_xyz, anchors, kernel_points, anchor_weights, b, np, nn, na, ks);
     EPN_CHECK_LAUNCH();
     return 0;

@@ -13,31 +13,61 @@ from . import _lib, gemm
 
 
 # ---- optional per-launch timing (bench.py's roofline leg): HIP events on the launch stream ------------
+# Every launching C-ABI call is bracketed (the library proxy's CALL_HOOK); calls made inside _launch(...) are timed as ONE
+# record carrying the caller's algorithmic flops.  The device kernel of a record is what the library itself reports
+# (epn_last_kernel: the exact template instance the launcher picked), never a guess made here.
 _PROFILE = None
+_DEPTH = 0
+
+
+def _last_kernel():
+    return _lib.get_lib().epn_last_kernel().decode()
+
+
+def _hook(name, fn, args):
+    if _PROFILE is None or _DEPTH > 0:
+        return fn(*args)
+    st = torch.cuda.current_stream()            # stream_of() made the tensors' device current
+    e0 = torch.cuda.Event(enable_timing=True)
+    e1 = torch.cuda.Event(enable_timing=True)
+    e0.record(st)
+    rc = fn(*args)
+    e1.record(st)
+    _PROFILE.append((name[4:], (), 0.0, e0, e1, _last_kernel()))
+    return rc
 
 
 def profile_begin():
     global _PROFILE
     _PROFILE = []
+    _lib.get_lib().epn_last_kernel()            # clear
+    _lib.CALL_HOOK = _hook
 
 
 def profile_end():
-    """-> list of (kind, shape_key, algorithmic_flops, start_event, end_event)"""
+    """-> list of (kind, shape_key, algorithmic_flops, start_event, end_event, device_kernel_name)"""
     global _PROFILE
     rec, _PROFILE = _PROFILE, None
+    _lib.CALL_HOOK = None
     return rec
 
 
 def _launch(kind, key, flops, device, fn):
-    if _PROFILE is None:
+    global _DEPTH
+    if _PROFILE is None or _DEPTH > 0:
         return fn()
     e0 = torch.cuda.Event(enable_timing=True)
     e1 = torch.cuda.Event(enable_timing=True)
     st = torch.cuda.current_stream(device)   # the stream the C ABI launches on (stream_of)
+    _lib.get_lib().epn_last_kernel()         # clear
     e0.record(st)
-    rc = fn()
+    _DEPTH += 1
+    try:
+        rc = fn()
+    finally:
+        _DEPTH -= 1
     e1.record(st)
-    _PROFILE.append((kind, key, flops, e0, e1))
+    _PROFILE.append((kind, key, flops, e0, e1, _last_kernel()))
     return rc
 
 

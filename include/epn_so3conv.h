@@ -3,7 +3,8 @@
  *
  * Drop-in boundary for the EPN SE(3) separable point-convolution hot path.  Every entry point is
  * `extern "C"`, takes plain DEVICE pointers + sizes + a HIP stream (passed as void*), launches
- * asynchronously on that stream, owns no memory and keeps no global state other than epn_set_kernel_policy (thread-safe).  Return
+ * asynchronously on that stream, owns no memory and keeps no global state other than epn_set_kernel_policy (thread-safe) and the thread-local diagnostic
+ * string behind epn_last_kernel.  Return
  * value: 0 on success, otherwise a hipError_t code (launch errors) or a negative EPN_E* code
  * (argument errors).  `epn_strerror` turns either into text.
  *
@@ -35,11 +36,18 @@ typedef void *epn_stream_t; /* hipStream_t; NULL = the null stream */
 
 const char *epn_version(void);
 const char *epn_strerror(int code);
+/* Diagnostic: the device kernel (exact template instance, "(anonymous namespace)::" removed, e.g.
+ * "epn::gemm_nt_x3_kernel<4, 2, 2, 4, 2>") that the calling thread's most recent library call launched as its main
+ * kernel -- what rocprofv3 will call it -- so a benchmark can attribute time without re-deriving the launchers' tile
+ * choices.  Thread-local, cleared by the read; "" when nothing was launched since the last read.  The returned
+ * pointer is valid until the thread's next call of this function. */
+const char *epn_last_kernel(void);
+
 /* Cross-check switch, the library's only process-wide state (a relaxed atomic; default 0): 0 = every entry point picks
  * its best kernel, 1 = the any-shape generic kernels everywhere (an independent on-device implementation used by the
- * parity tests).  Not for production use; set it before launching from other threads.  Values 0x100|v .. 0x400|v are
- * A/B switches of the tuning tools (tools/gemm_bench.py, tools/step_breakdown.py): GEMM tile overrides, and 0x401 =
- * per-slot atomic scatter in epn_inter_ungroup_* instead of the LDS-pre-reduced one. */
+ * parity tests).  Not for production use; set it before launching from other threads.  Any other value: EPN_EINVAL.
+ * (Libraries built with -DEPN_TUNING -- `python -m epn_pointcloud_amd.build --tuning`, used by tools/ only -- also accept
+ * 0x100|v .. 0x400|v, the A/B switches of the tuning tools: GEMM tile overrides, 0x401 = per-slot atomic scatter.) */
 int epn_set_kernel_policy(int policy);
 
 /* ------------------------------------------------------------------ index kernels ---------- */

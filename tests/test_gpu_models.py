@@ -168,3 +168,31 @@ def test_cls_model_kanchor20_vs_reference_golden(gpu):
     grads = torch.autograd.grad(loss, [pd[n] for n in g["grad_names"].tolist()])
     for i, gr in enumerate(grads):
         assert grad_close(gr, g[f"grad{i}"])
+
+
+def test_bench_line_kernel_names_are_profiler_names(gpu):
+    """bench.py's per-kernel table is keyed by what the LIBRARY reports for each call (epn_last_kernel) -- the exact
+    template instances -- so every name must be a kernel name of the committed rocprofv3 trace of the same command
+    (profiles/r03_kernel_stats.csv), compared after bench.norm_kernel_name (no 'void ', no '(anonymous namespace)::',
+    no argument list).  Also: the table covers glue / index / cast kernels, not only the convolutions."""
+    import csv
+    import json
+    import os
+    import subprocess
+    import sys
+    from conftest import ROOT
+    sys.path.insert(0, ROOT)
+    import bench
+    stats = os.path.join(ROOT, "profiles", "r03_kernel_stats.csv")
+    if not os.path.exists(stats):
+        pytest.skip("profiles/r03_kernel_stats.csv not collected yet")
+    known = {bench.norm_kernel_name(r["Name"]) for r in csv.DictReader(open(stats))}
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "2", "--warmup", "1", "--no-cpu-baseline",
+                          "--no-native-line", "--no-extra-configs"], capture_output=True, text=True, timeout=900)
+    assert out.returncode == 0, out.stderr[-2000:]
+    line = json.loads(out.stdout.strip().splitlines()[-1])
+    names = set(line["roofline"]["per_kernel_ms_per_step"])
+    assert line["roofline"]["kernel"] in known
+    missing = sorted(n for n in names if n not in known)
+    assert not missing, missing
+    assert any("norm_act" in n for n in names) and any("fps" in n for n in names)      # glue and index kernels are bracketed

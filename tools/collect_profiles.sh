@@ -8,7 +8,7 @@ TAG=${1:-r01}
 OUT=$R/gpurun_out/$TAG
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
-BENCH="python $R/bench.py --steps 3 --warmup 2 --no-cpu-baseline --no-native-line ${EPN_BENCH_ARGS:-}"
+BENCH="python $R/bench.py --steps 3 --warmup 2 --no-cpu-baseline --no-native-line --no-extra-configs ${EPN_BENCH_ARGS:-}"
 rocprofv3 --kernel-trace --stats -d $OUT/stats -o s -- $BENCH > $OUT/stats.log 2>&1
 for C in FETCH_SIZE WRITE_SIZE "SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_INSTS_VALU_MFMA_MOPS_F32" \
          "SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE"; do

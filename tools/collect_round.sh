@@ -4,7 +4,7 @@
 #   per-replay kernel times (replay_profile.sh), and the bench lines of every configuration.
 # usage (GPU box): tools/collect_round.sh <tag>      -> gpurun_out/<tag>/...
 R=$(cd "$(dirname "$0")/.." && pwd)
-TAG=${1:-r02}
+TAG=${1:-r03}
 OUT=$R/gpurun_out/$TAG
 mkdir -p $OUT
 cd $R
@@ -14,9 +14,9 @@ for f in kernel_stats.csv pmc_per_kernel.json bench_under_rocprof.json; do cp gp
 bash tools/replay_profile.sh ${TAG}_replay > $OUT/replay.log 2>&1
 cp gpurun_out/${TAG}_replay/per_replay.csv $OUT/per_replay_cls.csv
 python bench.py > $OUT/bench_cls.json 2> $OUT/bench_cls.err
-python bench.py --model reg --dtype bf16 --no-cpu-baseline > $OUT/bench_reg.json 2>/dev/null
-python bench.py --model inv --dtype bf16 --no-cpu-baseline > $OUT/bench_inv.json 2>/dev/null
-python bench.py --forward-only --no-cpu-baseline > $OUT/bench_cls_fwd.json 2>/dev/null
+python bench.py --model reg --dtype bf16 --no-cpu-baseline --steps 20 > $OUT/bench_reg.json 2>/dev/null
+python bench.py --model inv --dtype bf16 --no-cpu-baseline --steps 20 > $OUT/bench_inv.json 2>/dev/null
+python bench.py --forward-only --no-cpu-baseline --steps 20 > $OUT/bench_cls_fwd.json 2>/dev/null
 python bench.py --model reg --dtype f32 --no-cpu-baseline > $OUT/bench_reg_f32.json 2>/dev/null
 python bench.py --dtype bf16 --no-cpu-baseline > $OUT/bench_cls_bf16.json 2>/dev/null
 EPN_GEMM_FP32=native python bench.py --no-cpu-baseline --no-native-line > $OUT/bench_cls_native_fp32_mfma.json 2>/dev/null

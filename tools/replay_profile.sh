@@ -9,7 +9,7 @@ OUT=$R/gpurun_out/$TAG
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
 for K in 3 13; do
-  rocprofv3 --kernel-trace --stats -d $OUT/s$K -o s -- python $R/bench.py --steps $K --warmup 2 --no-cpu-baseline --no-native-line "$@" > $OUT/s$K.log 2>&1
+  rocprofv3 --kernel-trace --stats -d $OUT/s$K -o s -- python $R/bench.py --steps $K --warmup 2 --no-cpu-baseline --no-native-line --no-extra-configs "$@" > $OUT/s$K.log 2>&1
   python $R/tools/rocprof_summary.py $(find $OUT/s$K -name "*.db" | head -1) $OUT/k$K.csv > /dev/null
   rm -rf $OUT/s$K
 done
