@@ -29,7 +29,7 @@ EXPORTS = [
     "epn_gather_rows", "epn_scatter_rows", "epn_conv1x1_c1_f32", "epn_conv1x1_c1_bwd_weight_f32",
     "epn_ball_query_f64", "epn_fps_f64", "epn_gather_fwd_f64", "epn_gather_bwd_f64", "epn_so3_basis_norm_f32", "epn_so3_basis_norm_bf16", "epn_so3_basis_split_f32", "epn_so3_basis_norm_split_f32", "epn_inter_inverse_list", "epn_inter_ungroup_det_f32", "epn_inter_ungroup_det_bf16",
     "epn_chan_stats_bf16", "epn_norm_act_fwd_bf16", "epn_norm_act_bwd_reduce_bf16", "epn_norm_act_bwd_apply_bf16",
-    "epn_last_kernel", "epn_inter_onchip_ok", "epn_inter_onchip_workspace_bytes", "epn_inter_so3conv_fwd_onchip_f32", "epn_inter_so3conv_fwd_bf16",
+    "epn_last_kernel", "epn_scatter_rows_add", "epn_inter_onchip_ok", "epn_inter_onchip_workspace_bytes", "epn_inter_so3conv_fwd_onchip_f32", "epn_inter_so3conv_fwd_bf16",
 ]
 
 _vp, _ci, _cf, _sz = ctypes.c_void_p, ctypes.c_int, ctypes.c_float, ctypes.c_size_t
@@ -149,6 +149,8 @@ def get_lib():
     # the bf16 twins share their fp32 counterparts' signatures (void* feature pointers)
     lib.epn_gather_rows.argtypes = [_vp, _vp, _vp, _ci, _ci, _ci, _ll, _vp]
     lib.epn_scatter_rows.argtypes = [_vp, _vp, _vp, _ci, _ci, _ci, _ll, _vp]
+    lib.epn_scatter_rows_add.argtypes = [_vp, _vp, _vp, _ci, _ci, _ci, _ll, _ci, _vp]
+    lib.epn_scatter_rows_add.restype = _ci
     lib.epn_conv1x1_c1_f32.argtypes = [_vp, _vp, _vp, _ll, _ci, _vp]
     lib.epn_conv1x1_c1_bwd_weight_f32.argtypes = [_vp, _vp, _vp, _ll, _ci, _vp]
     lib.epn_gather_rows.restype = lib.epn_scatter_rows.restype = _ci

@@ -281,7 +281,8 @@ size_t gemm_nt_x3_workspace(const GemmNtBatch &B) {
 }
 
 int launch_gemm_nt_x3(GemmNtBatch &B, void *ws, size_t ws_bytes, hipStream_t st) {
-    if (!gemm_nt_x3_ok(B) || !ws || ws_bytes < gemm_nt_x3_workspace(B)) return launch_gemm_nt(B, 0, 0, st);
+    if (!gemm_nt_x3_ok(B) || !ws || ((uintptr_t)ws & 15) || ws_bytes < gemm_nt_x3_workspace(B))
+        return launch_gemm_nt(B, 0, 0, st);      // the planes are read with 16-byte direct-to-LDS loads
     char *w = static_cast<char *>(ws);
     int maxn = 0, minn = 1 << 30;
     for (int i = 0; i < B.nprob; ++i) {

@@ -539,8 +539,33 @@ __global__ __launch_bounds__(256) void rows_gather_kernel(const f32x4 *__restric
     const int q = idx[r];
     if (q < 0 || q >= p1) return;
     const long long s = (b * p1 + q) * row16 + e;
-    if (scatter) dst[s] = src[i];
-    else dst[i] = src[s];
+    if (scatter == 0) {
+        dst[i] = src[s];
+    } else if (scatter == 1) {
+        dst[s] = src[i];
+    } else if (scatter == 2) {                // accumulate fp32: repeated indices (padded / degenerate clouds) add up
+        const f32x4 v = src[i];
+        float *d = reinterpret_cast<float *>(dst + s);
+#pragma unroll
+        for (int k = 0; k < 4; ++k) atomicAdd(d + k, v[k]);
+    } else {                                  // accumulate bf16 pairs: compare-and-swap per dword (contention is the rare case)
+        const f32x4 v = src[i];
+        unsigned *d = reinterpret_cast<unsigned *>(dst + s);
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const unsigned add = __builtin_bit_cast(unsigned, v[k]);
+            if (add == 0u) continue;
+            unsigned old = __hip_atomic_load(d + k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT), upd;
+            do {
+                const float lo = __builtin_bit_cast(float, old << 16) + __builtin_bit_cast(float, add << 16);
+                const float hi = __builtin_bit_cast(float, old & 0xffff0000u) + __builtin_bit_cast(float, add & 0xffff0000u);
+                typedef __bf16 bf2 __attribute__((ext_vector_type(2)));
+                typedef float f2 __attribute__((ext_vector_type(2)));
+                upd = __builtin_bit_cast(unsigned, __builtin_convertvector(f2{lo, hi}, bf2));
+            } while (!__hip_atomic_compare_exchange_strong(d + k, &old, upd, __ATOMIC_RELAXED, __ATOMIC_RELAXED,
+                                                           __HIP_MEMORY_SCOPE_AGENT));
+        }
+    }
 }
 }  // namespace
 }  // namespace epn
@@ -571,6 +596,25 @@ extern "C" int epn_scatter_rows(const void *grad_dst, const int32_t *idx, void *
     EPN_LAUNCH(epn::rows_gather_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st,
                        static_cast<const f32x4 *>(grad_dst), idx, static_cast<f32x4 *>(grad_src), n, p1, p2,
                        (int)(row_bytes / 16), 1);
+    EPN_CHECK_LAUNCH();
+    return 0;
+}
+
+// the same transpose, ACCUMULATING: an index that occurs several times (FPS repeats index 0 when a cloud has fewer live
+// points than samples: padded clouds, points inside its 1e-3 dead zone) receives the sum of its rows, as the backward of
+// torch.gather / the reference's batched_index_select does.  Elements are fp32 (bf16 = 0) or bf16 (bf16 = 1).
+extern "C" int epn_scatter_rows_add(const void *grad_dst, const int32_t *idx, void *grad_src, int b, int p1, int p2,
+                                    long long row_bytes, int bf16, epn_stream_t stream) {
+    if (b < 0 || p1 < 1 || p2 < 0 || row_bytes < 16 || row_bytes % 16) return EPN_EINVAL;
+    if (!grad_src) return EPN_ENULL;
+    hipStream_t st = epn_stream(stream);
+    EPN_HIP(hipMemsetAsync(grad_src, 0, (size_t)b * p1 * row_bytes, st));
+    const long long n = (long long)b * p2 * (row_bytes / 16);
+    if (n == 0) return 0;
+    if (!grad_dst || !idx) return EPN_ENULL;
+    EPN_LAUNCH(epn::rows_gather_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st,
+               static_cast<const f32x4 *>(grad_dst), idx, static_cast<f32x4 *>(grad_src), n, p1, p2,
+               (int)(row_bytes / 16), bf16 ? 3 : 2);
     EPN_CHECK_LAUNCH();
     return 0;
 }

@@ -24,12 +24,17 @@ def free_port():
         return s.getsockname()[1]
 
 
-def launch(world, argv=None, env=None):
+def launch(world, argv=None, env=None, timeout=None):
     """Run `argv` (default: this very command line) as `world` rank processes on this node, one per GPU, with the
     torchrun environment (RANK / LOCAL_RANK / WORLD_SIZE / MASTER_ADDR=127.0.0.1 / MASTER_PORT).  Rank 0 inherits
-    stdout; returns the worst exit code.  What `python -m torch.distributed.run --nproc-per-node N` would do, for
-    callers that start the program without a launcher."""
+    stdout.  The children are POLLED: the first one that exits non-zero (or the watchdog: `timeout` seconds, default
+    EPN_DP_TIMEOUT or 1500) gets the others terminated -- a dead rank must not leave its peers blocked inside a collective
+    until some outer limit kills the job -- and its exit code is returned (124 for the watchdog); 0 when all ranks succeed.
+    What `python -m torch.distributed.run --nproc-per-node N` would do, for callers that start the program without a
+    launcher."""
+    import time
     argv = list(argv) if argv is not None else [sys.executable] + sys.argv
+    timeout = float(os.environ.get("EPN_DP_TIMEOUT", "1500")) if timeout is None else float(timeout)
     port = free_port()
     procs = []
     for r in range(world):
@@ -38,10 +43,35 @@ def launch(world, argv=None, env=None):
                  EPN_DP_CHILD="1")
         e.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         procs.append(subprocess.Popen(argv, env=e, stdout=None if r == 0 else subprocess.DEVNULL))
-    rc = 0
-    for p in procs:
-        rc = max(rc, abs(p.wait()))
-    return rc
+
+    def stop_all():
+        for p in procs:
+            if p.poll() is None:
+                p.terminate()
+        t_end = time.monotonic() + 10.0
+        for p in procs:
+            try:
+                p.wait(timeout=max(0.1, t_end - time.monotonic()))
+            except subprocess.TimeoutExpired:
+                p.kill()                               # exactly the processes started above, never a pattern
+                p.wait()
+
+    deadline = time.monotonic() + timeout
+    while True:
+        codes = [p.poll() for p in procs]
+        bad = [(r, c) for r, c in enumerate(codes) if c not in (None, 0)]
+        if bad:
+            r, c = bad[0]
+            print(f"[dp.launch] rank {r} exited with code {c}; stopping the other ranks", file=sys.stderr)
+            stop_all()
+            return abs(c) or 1
+        if all(c == 0 for c in codes):
+            return 0
+        if time.monotonic() > deadline:
+            print(f"[dp.launch] watchdog: ranks still running after {timeout:.0f} s; stopping them", file=sys.stderr)
+            stop_all()
+            return 124
+        time.sleep(0.05)
 
 
 def env_world():
@@ -131,6 +161,14 @@ class GradBuckets:
 
     def _issue(self, bi):
         a, b = self.spans[bi]
+        if self.flat.is_cuda:
+            # ProcessGroupNCCL orders the collective after the stream that is current HERE only; a block's skip branch
+            # runs (and accumulates its gradients) on the library's side stream (schedule.FusedSeparableBlock,
+            # EPN_SKIP_STREAM), so gradients of this very bucket may still be in flight there
+            from . import ops
+            side = ops.side_stream_if_any(self.flat.device)
+            if side is not None:
+                torch.cuda.current_stream(self.flat.device).wait_stream(side)
         self._works.append(dist.all_reduce(self.flat[a:b], op=dist.ReduceOp.SUM, async_op=True))
 
     def zero(self):

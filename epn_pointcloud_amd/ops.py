@@ -321,9 +321,10 @@ class InterSO3ConvSplitFn(torch.autograd.Function):
     """The same convolution as InterSO3ConvFn in the reference's own two steps -- inter_so3conv_grouping, then
     BasicSO3Conv's matmul (vgtk/vgtk/so3conv/modules.py:38-52,157-174) -- with the grouping as ONE HIP kernel that
     writes only the grouped features G[col][cin*ks] (no inter_w, no gathered neighbours) and the three weight
-    contractions (out = G W^T, dW = dOut^T G, dG = dOut W) as plain fp32 GEMMs on the BLAS library, which runs these
-    shapes at 110-150 TFLOP/s (tools/gemm_probe.py).  G (cin*ks*4 bytes per column) is kept for the backward pass:
-    the training-time choice on a 288 GB part; InterSO3ConvFn is the memory-lean fused form."""
+    contractions (out = G W^T, dW = dOut^T G, dG = dOut W) on this library's own MFMA GEMM kernels (csrc/gemm.hip,
+    csrc/gemm_x3.hip: fp32 operands in the lossless 3 x bf16 split form by default, 160-200 fp32-equivalent TFLOP/s on the
+    schedule's shapes; no BLAS library is involved).  G (cin*ks*4 bytes per column) is kept for the backward pass: the
+    training-time choice on a 288 GB part; InterSO3ConvFn / InterSO3ConvOnChipFn are the forms that never write it."""
 
     @staticmethod
     def forward(ctx, feats, W, geo):
@@ -489,6 +490,11 @@ def _side_stream(device):
     if key not in _SIDE:
         _SIDE[key] = torch.cuda.Stream(device=device)
     return _SIDE[key]
+
+
+def side_stream_if_any(device):
+    """The second stream of `device` if one was ever created (dp.GradBuckets orders its collectives after it)."""
+    return _SIDE.get(str(torch.device(device)))
 
 
 class _TensorCache:
@@ -1173,8 +1179,9 @@ def _identity_index(na, device):
 
 class GatherRowsFn(torch.autograd.Function):
     """batched_index_select(feats, 2, sample_idx) of the strided skip connection (SPConvNets/utils/base_so3conv.py:206-207)
-    on channels-last data: whole [a][c] rows move (epn_gather_rows); backward scatters them back into a zeroed tensor
-    (epn_scatter_rows; FPS indices are distinct, so no accumulation is needed)."""
+    on channels-last data: whole [a][c] rows move (epn_gather_rows); backward adds them back into a zeroed tensor
+    (epn_scatter_rows_add: FPS indices are distinct for ordinary clouds, but repeat index 0 when a cloud has fewer live
+    points than samples -- those rows must receive the SUM, as torch.gather's backward gives)."""
 
     @staticmethod
     def forward(ctx, feats, sample_idx):
@@ -1197,8 +1204,9 @@ class GatherRowsFn(torch.autograd.Function):
         b, c, p1, a = ctx.dims
         gc = to_cl(g, "grad")
         gs = empty_cl(b, c, p1, a, gc.device, gc.dtype)
-        _lib.check(lib.epn_scatter_rows(_cl_ptr(gc), _lib.dev_ptr(idx, "sample_idx", torch.int32), _cl_ptr(gs), b, p1,
-                                        idx.shape[1], a * c * gc.element_size(), _lib.stream_of(gc)), "scatter_rows")
+        _lib.check(lib.epn_scatter_rows_add(_cl_ptr(gc), _lib.dev_ptr(idx, "sample_idx", torch.int32), _cl_ptr(gs), b, p1,
+                                            idx.shape[1], a * c * gc.element_size(), int(gc.dtype == torch.bfloat16),
+                                            _lib.stream_of(gc)), "scatter_rows_add")
         return gs, None
 
 

@@ -10,7 +10,7 @@ import torch.nn as nn
 from ..spconv import SphericalPointCloud
 from .. import pc as pctk
 from . import functional as L
-from ... import ops
+from ... import gemm, ops
 
 __all__ = ["BasicSO3Conv", "KernelPropagation", "InterSO3Conv", "IntraSO3Conv", "PointnetSO3Conv",
            "KERNEL_CONDENSE_RATIO"]
@@ -36,8 +36,16 @@ class BasicSO3Conv(nn.Module):
             self.register_parameter('W', nn.Parameter(W.view(self.dim_out, self.dim_in * self.kernel_size)))
 
     def forward(self, x):
+        """x [b, dim_in, ks, p, a] -> [b, dim_out, p, a] (modules.py:48-55).  Device tensors run on the library's own
+        GEMM (gemm.matmul_nt: rows = (b, p, a) columns, fp32 contractions in the default split form); host tensors
+        -- module construction tests only -- on torch."""
         bs, npt, na = x.shape[0], x.shape[3], x.shape[4]
-        x = x.reshape(bs, self.dim_in * self.kernel_size, npt * na)
+        ck = self.dim_in * self.kernel_size
+        if x.is_cuda and x.dtype in ops.FEATURE_DTYPES:
+            rows = x.reshape(bs, ck, npt * na).permute(0, 2, 1).reshape(bs * npt * na, ck)
+            y = gemm.matmul_nt(rows, self.W)
+            return y.view(bs, npt, na, self.dim_out).permute(0, 3, 1, 2)
+        x = x.reshape(bs, ck, npt * na)
         return torch.matmul(self.W, x).view(bs, self.dim_out, npt, na)
 
 

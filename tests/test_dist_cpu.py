@@ -90,3 +90,23 @@ def test_shard_batch_covers_everything():
             assert all(spans[i][1] == spans[i + 1][0] for i in range(world - 1))
             sizes = [b - a for a, b in spans]
             assert max(sizes) - min(sizes) <= 1
+
+
+def test_launcher_stops_the_other_ranks_when_one_dies(tmp_path):
+    """dp.launch polls its children: rank 1 exits with code 3 while rank 0 would block for a minute (as a rank stuck in a
+    collective would); the launcher terminates rank 0 and returns 3 within seconds.  The watchdog path: every rank hangs,
+    timeout=2 -> 124."""
+    import sys as _sys
+    import time
+    from epn_pointcloud_amd import dp
+    prog = ("import os, sys, time\n"
+            "r = int(os.environ['RANK'])\n"
+            "open(os.path.join(sys.argv[1], f'started{r}'), 'w').close()\n"
+            "sys.exit(3) if r == 1 and sys.argv[2] == 'die' else time.sleep(60)\n")
+    t0 = time.monotonic()
+    rc = dp.launch(2, [_sys.executable, "-c", prog, str(tmp_path), "die"])
+    assert rc == 3 and time.monotonic() - t0 < 30
+    assert (tmp_path / "started0").exists() and (tmp_path / "started1").exists()
+    t0 = time.monotonic()
+    rc = dp.launch(2, [_sys.executable, "-c", prog, str(tmp_path), "hang"], timeout=2)
+    assert rc == 124 and time.monotonic() - t0 < 30

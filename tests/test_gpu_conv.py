@@ -92,7 +92,7 @@ def test_functional_compat_golden(gpu, vgtk_alias):
 @pytest.fixture(params=["fused", "split"])
 def inter_mode(request):
     """Both forms of InterSO3Conv: the fused kernels (memory-lean) and the split form (HIP grouping kernel writing the
-    grouped features + BLAS GEMMs), selected through EPN_INTER_MODE."""
+    grouped features + this library's own MFMA GEMM kernels), selected through EPN_INTER_MODE."""
     old = os.environ.get("EPN_INTER_MODE")
     os.environ["EPN_INTER_MODE"] = request.param
     yield request.param

@@ -85,3 +85,17 @@ def test_lazy_sample_index_and_occupancy(vgtk_alias):
     assert tuple(f.shape) == (2, 1, 16, 60) and (f == 1).all()
     f = sptk.get_occupancy_features(torch.rand(2, 16, 3), 60, use_center=True)
     assert (f[:, :, 0] == 0).all() and (f[:, :, 1:] == 1).all()
+
+
+def test_learning_rate_scheduler_mirror():
+    """vgtk.LearningRateScheduler (vgtk/vgtk/utils.py:33-68, used by vgtk/vgtk/app/trainer.py:167): same constructor,
+    step() returns the rate, param groups updated every decay_step calls."""
+    import torch
+    from epn_pointcloud_amd import vgtk
+    p = torch.nn.Parameter(torch.zeros(1))
+    opt = torch.optim.SGD([p], lr=0.1)
+    sch = vgtk.LearningRateScheduler(opt, 0.1, "exp_decay", 2, decay_rate=0.5)
+    rates = [sch.step() for _ in range(5)]
+    assert rates == [0.1, 0.05, 0.05, 0.025, 0.025] and opt.param_groups[0]["lr"] == 0.025
+    const = vgtk.LearningRateScheduler(opt, 0.3, "constant", 1, decay_rate=0.9)
+    assert const.step() == 0.3 and opt.param_groups[0]["lr"] == 0.3
