@@ -802,6 +802,95 @@ __global__ __launch_bounds__(64 * NW) void inter_group_kernel(InterArgs A) {
     }
 }
 
+// Wide-gather form of the grouping (na >= 16, cin % (16 CG) == 0).  In inter_group_kernel a lane owns ONE channel of a
+// 16-channel chunk: every gather instruction moves 4 (fp32) or 2 (bf16) bytes per lane -- 64-byte segments, one address
+// per lane through the texture addresser, K of them per column and chunk -- and the kernel-influence weights (S-MFMAs,
+// table reads, relu, packing) are regenerated for every chunk.  Here a lane owns CG CONSECUTIVE channels of a group of
+// 16 CG channels (CG = 4: 64 channels): one dwordx4 (fp32) / dwordx2 (bf16) load per neighbour row and lane -- 256 / 128
+// contiguous bytes per 16 lanes -- serves CG chunks, and the weights of a column are generated once for all of them.
+// "Chunk" e of the group is the channel set {16 CG g + CG x + e}: only the lane -> channel map changes, the layout of G
+// does not (a D fragment is still four consecutive kernel points of one channel = one 16 / 8-byte store).
+template <int NT, int KT, typename TF, int CG>
+__global__ __launch_bounds__(64 * NW) void inter_group_wide_kernel(InterArgs A) {
+    constexpr bool BF = sizeof(TF) == 2;
+    typedef unsigned uvec __attribute__((ext_vector_type(BF ? CG / 2 : CG)));   // one lane's CG channels of one row
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int x = lane & 15, j = lane >> 4;
+    const long long col0 = ((long long)epn_xcd_tile(blockIdx.x, gridDim.x) * NW + wave) * 16;
+    if (col0 >= A.ncol) return;
+    const int gss = A.cin * A.ks;
+    TF *G = reinterpret_cast<TF *>(A.out) + (size_t)col0 * gss;
+    const int coff = (int)blockIdx.y * 16 * CG + CG * x;       // first of this lane's channels
+    Seg<NT> seg[2];
+    make_segments<NT, TF>(A, col0, x, j, seg[0], seg[1]);
+    for (int si = 0; si < 2; ++si) {
+        const Seg<NT> &sg = seg[si];
+        if (sg.cnt <= 0) continue;
+        uvec fcur[NT][4], fnext[NT][4];
+        auto gather = [&](int a, uvec (&f)[NT][4]) {
+            const TF *fb = reinterpret_cast<const TF *>(sg.fbase) + (size_t)a * A.cin + coff;
+#pragma unroll
+            for (int t = 0; t < NT; ++t)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) f[t][r] = *reinterpret_cast<const uvec *>(fb + sg.h.q[t][r]);
+        };
+        gather(sg.a0, fcur);
+        for (int i = 0; i < sg.cnt; ++i) {
+            const int a = sg.a0 + i;
+            gather(i + 1 < sg.cnt ? a + 1 : a, fnext);          // last column re-reads its own rows (cache hit, unused)
+            f32x4 w[KT][NT];
+            make_weights<NT, KT>(A, a, x, j, sg.h, w);           // once per column, for all CG chunks
+            TF *grow = G + (size_t)(sg.jc0 + i) * gss + (size_t)coff * A.ks + 4 * j;
+#pragma unroll
+            for (int e = 0; e < CG; ++e) {
+                if constexpr (BF) {
+                    bf16x4_t fb4[NT];
+#pragma unroll
+                    for (int t = 0; t < NT; ++t) {
+                        unsigned v[4];
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) {
+                            const unsigned d = fcur[t][r][e >> 1];
+                            v[r] = sg.h.ok[t][r] ? ((e & 1) ? d >> 16 : d & 0xffffu) : 0u;
+                        }
+                        typedef unsigned u32x2_t __attribute__((ext_vector_type(2)));
+                        fb4[t] = __builtin_bit_cast(bf16x4_t, u32x2_t{v[0] | (v[1] << 16), v[2] | (v[3] << 16)});
+                    }
+#pragma unroll
+                    for (int kt = 0; kt < KT; ++kt) {
+                        f32x4 g = {0.f, 0.f, 0.f, 0.f};
+                        if constexpr (NT % 2 == 0) {
+#pragma unroll
+                            for (int t = 0; t < NT; t += 2)
+                                g = mfma_bf16_k32(pack4(w[kt][t]), pack4(w[kt][t + 1]), fb4[t], fb4[t + 1], g);
+                        } else {
+#pragma unroll
+                            for (int t = 0; t < NT; ++t) g = mfma_bf16_k16(pack4(w[kt][t]), fb4[t], g);
+                        }
+                        if (16 * kt + 4 * j < A.ks) st4f(grow + e * A.ks + 16 * kt, g);
+                    }
+                } else {
+#pragma unroll
+                    for (int kt = 0; kt < KT; ++kt) {
+                        f32x4 g = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                        for (int t = 0; t < NT; ++t)
+#pragma unroll
+                            for (int r = 0; r < 4; ++r)
+                                g = mfma4(w[kt][t][r], sg.h.ok[t][r] ? __uint_as_float(fcur[t][r][e]) : 0.0f, g);
+                        if (16 * kt + 4 * j < A.ks) st4f(grow + e * A.ks + 16 * kt, g);
+                    }
+                }
+            }
+#pragma unroll
+            for (int t = 0; t < NT; ++t)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) fcur[t][r] = fnext[t][r];
+        }
+    }
+}
+
 // Transpose of the grouping: dF[b, idx[n], a, c] += sum_k w[k][n] dG[col][c*ks + k]  (scatter_segment reads dG from HBM).
 template <int NT, int KT, typename TG>   // dG in TG (float / bf16); the scatter target grad_feats is always fp32
 __global__ __launch_bounds__(64 * NW) void inter_ungroup_kernel(InterArgs A) {
@@ -1536,6 +1625,24 @@ int launch_inter_group_mfma(const epn_inter_desc *d, const float *rk4, const voi
     InterArgs A = make_args(d, rk4);
     A.feats = static_cast<const float *>(feats); A.out = static_cast<float *>(G);
     const unsigned grid = (unsigned)((A.ncol + 16 * NW - 1) / (16 * NW));
+    // wide-gather form (a lane owns 4 or 2 consecutive channels).  Measured per layer, B=32/64 schedules: bf16 0.85-0.89 vs
+    // 1.35 ms (K = 64), 1.18 vs 1.49 ms (K = 32) -- the bf16 kernel is bound by its gather instructions; fp32 1.18-1.28 vs
+    // 1.32 ms at K = 32 but 2.05-2.44 vs 1.97 ms at K = 16, where the stores of G bound the kernel either way
+    if (d->na >= 16 && d->cin % 32 == 0 && d->nn <= 64 && (bf16 || d->nn > 16)) {
+        const int cg = d->cin % 64 == 0 ? 4 : 2;
+        const unsigned gyw = (unsigned)(d->cin / (16 * cg));
+#define EPN_GRPW(NT_, KT_, dummy)                                                                                              \
+    do {                                                                                                                       \
+        if (bf16 && cg == 4) EPN_LAUNCH((inter_group_wide_kernel<NT_, KT_, __bf16, 4>), dim3(grid, gyw), dim3(64 * NW), 0, st, A); \
+        else if (bf16) EPN_LAUNCH((inter_group_wide_kernel<NT_, KT_, __bf16, 2>), dim3(grid, gyw), dim3(64 * NW), 0, st, A);    \
+        else if (cg == 4) EPN_LAUNCH((inter_group_wide_kernel<NT_, KT_, float, 4>), dim3(grid, gyw), dim3(64 * NW), 0, st, A);  \
+        else EPN_LAUNCH((inter_group_wide_kernel<NT_, KT_, float, 2>), dim3(grid, gyw), dim3(64 * NW), 0, st, A);               \
+    } while (0)
+        EPN_DISPATCH_NT_KT(EPN_GRPW, 0);
+#undef EPN_GRPW
+        EPN_CHECK_LAUNCH();
+        return 0;
+    }
     A.col_tiles_per_wg = chunks_per_row(bf16);
     const unsigned gy = (unsigned)(((d->cin >> 4) + A.col_tiles_per_wg - 1) / A.col_tiles_per_wg);
 #define EPN_GRP(NT_, KT_, dummy)                                                                                      \
