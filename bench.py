@@ -243,17 +243,39 @@ def roofline_of(records, prof_steps, dtype_name, split_gemm, with_traffic, graph
                                 "--pmc passes, " + os.path.relpath(PMC_FILE, ROOT))
     roofline["per_kernel_ms_per_step"] = {k: round(v["ms"] / prof_steps, 3) for k, v in sorted(agg.items())}
     roofline["per_kernel_ms_sum"] = round(sum(v["ms"] for v in agg.values()) / prof_steps, 3)
+    roofline["per_kernel_launches_per_step"] = {k: round(v["launches"] / prof_steps, 1) for k, v in sorted(agg.items())}
     roofline["per_kernel_tflops"] = {k: round(v["flops"] / (v["ms"] * 1e-3) / 1e12, 1) for k, v in sorted(agg.items())
                                      if v["flops"] > 0}
     roofline["measured"] = (f"HIP events on the launch stream around EVERY C-ABI call of {prof_steps} eager step(s) "
-                            + ("run right after the timed graph replays (same process, kernels and shapes; the skip "
-                               "branch's kernels share the GPU from a second stream, so the sum can exceed the step)"
+                            + ("run right after the timed graph replays (same process, kernels and shapes; each step enqueued "
+                               "behind a spinning kernel so that the brackets hold device time only; the skip branch's kernels "
+                               "share the GPU from a second stream, so the sum can exceed the step)"
                                if graph_mode else "= the timed region")
                             + "; kernel names: the library's own report per call (epn_last_kernel), i.e. rocprofv3's names")
     if dtype_name == "bf16":
         roofline["note"] = ("bf16 GEMMs run far below the 2.5 PF MFMA roof by construction: at these widths the step "
                             "is bound by HBM traffic of the grouped features (see DESIGN.md 3.6)")
     return roofline
+
+
+_SLEEP_CYCLES_PER_MS = None
+
+
+def hold_gpu(ms, dev):
+    """Keep the current stream busy for about `ms` milliseconds (torch's spin kernel, calibrated once): enqueued in front
+    of an eager step that is timed call by call, it lets the host run ahead, so that the HIP events around a call bracket
+    device time only -- without it a host-bound stretch (hundreds of small launches) shows up inside the brackets."""
+    global _SLEEP_CYCLES_PER_MS
+    if _SLEEP_CYCLES_PER_MS is None:
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        torch.cuda._sleep(100000)
+        torch.cuda.synchronize(dev)
+        e0.record()
+        torch.cuda._sleep(2000000)
+        e1.record()
+        torch.cuda.synchronize(dev)
+        _SLEEP_CYCLES_PER_MS = 2000000 / max(e0.elapsed_time(e1), 1e-3)
+    torch.cuda._sleep(int(ms * _SLEEP_CYCLES_PER_MS))
 
 
 def measure(cfg, rank, local_rank, world, dev, first=True):
@@ -391,12 +413,18 @@ def measure(cfg, rank, local_rank, world, dev, first=True):
         # graph replays have no host-side launch points: for the roofline the same step runs eagerly, timed call by
         # call, right after the timed region (same process, same shapes, same kernels)
         prof_steps = min(cfg.steps, 3)
+        t_h = time.perf_counter()
         eager_step()                             # untimed: refills the eager allocator pool after the capture, so no
-        fence()                                  # allocation stall sits between an event and the kernel it brackets
-        ops.profile_begin()
-        for _ in range(prof_steps):
-            eager_step()
+        host_ms0 = (time.perf_counter() - t_h) * 1e3     # allocation stall sits between an event and the kernel it brackets
         fence()
+        host_ms = host_ms0
+        for _ in range(prof_steps):
+            t_h = time.perf_counter()
+            hold_gpu(50.0 + 2.0 * host_ms, dev)              # the host enqueues the whole step behind a spinning kernel
+            ops.profile_begin() if _ == 0 else None
+            eager_step()
+            host_ms = max(host_ms, (time.perf_counter() - t_h) * 1e3)
+            fence()
         records = ops.profile_end()
     if world > 1:
         t = torch.tensor([dt], dtype=torch.float64, device=dev)

@@ -539,32 +539,85 @@ __global__ __launch_bounds__(256) void rows_gather_kernel(const f32x4 *__restric
     const int q = idx[r];
     if (q < 0 || q >= p1) return;
     const long long s = (b * p1 + q) * row16 + e;
-    if (scatter == 0) {
-        dst[i] = src[s];
-    } else if (scatter == 1) {
-        dst[s] = src[i];
-    } else if (scatter == 2) {                // accumulate fp32: repeated indices (padded / degenerate clouds) add up
-        const f32x4 v = src[i];
-        float *d = reinterpret_cast<float *>(dst + s);
+    if (scatter) dst[s] = src[i];
+    else dst[i] = src[s];
+}
+
+// Transpose of the row gather that tolerates REPEATED indices, without atomics: one workgroup per gathered row r.  It scans
+// the cloud's index list (p2 int32, staged in LDS) for other occurrences of q = idx[r].  A unique q -- every row of an
+// ordinary cloud -- is a plain 16-byte store stream.  Of a repeated q (FPS pads degenerate clouds with index 0) only the
+// FIRST occurrence writes: the sum of all its rows, accumulated in fp32 in ascending row order (deterministic; one
+// rounding for bf16).  The target is zero-filled by the caller.
+constexpr int ROWS_P2_MAX = 8192;
+template <bool BF>
+__global__ __launch_bounds__(256) void rows_scatter_add_kernel(const f32x4 *__restrict__ src, const int32_t *__restrict__ idx,
+                                                               f32x4 *__restrict__ dst, int p1, int p2, int row16) {
+    __shared__ int s_row[ROWS_P2_MAX];
+    __shared__ int s_before, s_after;
+    const long long r = blockIdx.x;           // b*p2 + p
+    const long long b = r / p2;
+    const int q = idx[r];
+    if (q < 0 || q >= p1) return;
+    if (threadIdx.x == 0) s_before = s_after = 0;
+    const int32_t *row = idx + b * p2;
+    const int self = (int)(r - b * p2);
+    for (int k = threadIdx.x; k < p2; k += 256) s_row[k] = row[k];
+    __syncthreads();
+    bool before = false, after = false;
+    for (int k = threadIdx.x; k < p2; k += 256) {
+        const bool same = s_row[k] == q;
+        before = before || (same && k < self);
+        after = after || (same && k > self);
+    }
+    if (before) s_before = 1;
+    if (after) s_after = 1;
+    __syncthreads();
+    if (s_before) return;                     // a later occurrence: the first one sums for all
+    const f32x4 *sp = src + r * row16;
+    f32x4 *dp = dst + (b * p1 + q) * row16;
+    if (!s_after) {
+        for (int e = threadIdx.x; e < row16; e += 256) dp[e] = sp[e];
+        return;
+    }
+    for (int e = threadIdx.x; e < row16; e += 256) {
+        f32x4 v = sp[e];
+        if constexpr (!BF) {
+            for (int k = self + 1; k < p2; ++k)
+                if (s_row[k] == q) {
+                    const f32x4 u = src[(b * p2 + k) * row16 + e];
+                    v[0] += u[0]; v[1] += u[1]; v[2] += u[2]; v[3] += u[3];
+                }
+        } else {
+            float acc[8];
 #pragma unroll
-        for (int k = 0; k < 4; ++k) atomicAdd(d + k, v[k]);
-    } else {                                  // accumulate bf16 pairs: compare-and-swap per dword (contention is the rare case)
-        const f32x4 v = src[i];
-        unsigned *d = reinterpret_cast<unsigned *>(dst + s);
+            for (int i = 0; i < 4; ++i) {
+                const float vi = v[i];
+                const unsigned w = __float_as_uint(vi);
+                acc[2 * i] = __uint_as_float(w << 16);
+                acc[2 * i + 1] = __uint_as_float(w & 0xffff0000u);
+            }
+            for (int k = self + 1; k < p2; ++k)
+                if (s_row[k] == q) {
+                    const f32x4 u = src[(b * p2 + k) * row16 + e];
 #pragma unroll
-        for (int k = 0; k < 4; ++k) {
-            const unsigned add = __builtin_bit_cast(unsigned, v[k]);
-            if (add == 0u) continue;
-            unsigned old = __hip_atomic_load(d + k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT), upd;
-            do {
-                const float lo = __builtin_bit_cast(float, old << 16) + __builtin_bit_cast(float, add << 16);
-                const float hi = __builtin_bit_cast(float, old & 0xffff0000u) + __builtin_bit_cast(float, add & 0xffff0000u);
-                typedef __bf16 bf2 __attribute__((ext_vector_type(2)));
-                typedef float f2 __attribute__((ext_vector_type(2)));
-                upd = __builtin_bit_cast(unsigned, __builtin_convertvector(f2{lo, hi}, bf2));
-            } while (!__hip_atomic_compare_exchange_strong(d + k, &old, upd, __ATOMIC_RELAXED, __ATOMIC_RELAXED,
-                                                           __HIP_MEMORY_SCOPE_AGENT));
+                    for (int i = 0; i < 4; ++i) {
+                        const float ui = u[i];
+                        const unsigned w = __float_as_uint(ui);
+                        acc[2 * i] += __uint_as_float(w << 16);
+                        acc[2 * i + 1] += __uint_as_float(w & 0xffff0000u);
+                    }
+                }
+            typedef __bf16 bf2 __attribute__((ext_vector_type(2)));
+            typedef float f2 __attribute__((ext_vector_type(2)));
+            float o[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const bf2 pk = __builtin_convertvector(f2{acc[2 * i], acc[2 * i + 1]}, bf2);
+                o[i] = __uint_as_float(__builtin_bit_cast(unsigned, pk));
+            }
+            v = f32x4{o[0], o[1], o[2], o[3]};
         }
+        dp[e] = v;
     }
 }
 }  // namespace
@@ -600,21 +653,23 @@ extern "C" int epn_scatter_rows(const void *grad_dst, const int32_t *idx, void *
     return 0;
 }
 
-// the same transpose, ACCUMULATING: an index that occurs several times (FPS repeats index 0 when a cloud has fewer live
+// the same transpose, ACCUMULATING (no atomics, deterministic; p2 <= 8192): an index that occurs several times (FPS repeats index 0 when a cloud has fewer live
 // points than samples: padded clouds, points inside its 1e-3 dead zone) receives the sum of its rows, as the backward of
 // torch.gather / the reference's batched_index_select does.  Elements are fp32 (bf16 = 0) or bf16 (bf16 = 1).
 extern "C" int epn_scatter_rows_add(const void *grad_dst, const int32_t *idx, void *grad_src, int b, int p1, int p2,
                                     long long row_bytes, int bf16, epn_stream_t stream) {
-    if (b < 0 || p1 < 1 || p2 < 0 || row_bytes < 16 || row_bytes % 16) return EPN_EINVAL;
+    if (b < 0 || p1 < 1 || p2 < 0 || p2 > epn::ROWS_P2_MAX || row_bytes < 16 || row_bytes % 16) return EPN_EINVAL;
     if (!grad_src) return EPN_ENULL;
     hipStream_t st = epn_stream(stream);
     EPN_HIP(hipMemsetAsync(grad_src, 0, (size_t)b * p1 * row_bytes, st));
     const long long n = (long long)b * p2 * (row_bytes / 16);
     if (n == 0) return 0;
     if (!grad_dst || !idx) return EPN_ENULL;
-    EPN_LAUNCH(epn::rows_gather_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st,
-               static_cast<const f32x4 *>(grad_dst), idx, static_cast<f32x4 *>(grad_src), n, p1, p2,
-               (int)(row_bytes / 16), bf16 ? 3 : 2);
+    const unsigned rows = (unsigned)((long long)b * p2);
+    if (bf16) EPN_LAUNCH(epn::rows_scatter_add_kernel<true>, dim3(rows), dim3(256), 0, st, static_cast<const f32x4 *>(grad_dst),
+                         idx, static_cast<f32x4 *>(grad_src), p1, p2, (int)(row_bytes / 16));
+    else EPN_LAUNCH(epn::rows_scatter_add_kernel<false>, dim3(rows), dim3(256), 0, st, static_cast<const f32x4 *>(grad_dst),
+                    idx, static_cast<f32x4 *>(grad_src), p1, p2, (int)(row_bytes / 16));
     EPN_CHECK_LAUNCH();
     return 0;
 }

@@ -1213,7 +1213,7 @@ class GatherRowsFn(torch.autograd.Function):
 def gather_rows(feats, sample_idx):
     """Rows of a [b,c,p,a] tensor selected along p; needs a*c*elem_size % 16 == 0 (else torch.gather)."""
     if feats.is_cuda and (feats.shape[1] * feats.shape[3] * feats.element_size()) % 16 == 0 and \
-            feats.dtype in FEATURE_DTYPES:
+            feats.dtype in FEATURE_DTYPES and sample_idx.shape[1] <= 8192:
         return GatherRowsFn.apply(feats, sample_idx)
     idx = sample_idx.long().view(feats.shape[0], 1, -1, 1).expand(-1, feats.shape[1], -1, feats.shape[3])
     return torch.gather(feats, 2, idx)

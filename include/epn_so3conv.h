@@ -450,7 +450,8 @@ int epn_gather_rows(const void *src, const int32_t *idx, void *dst, int b, int p
                     epn_stream_t stream);
 int epn_scatter_rows(const void *grad_dst, const int32_t *idx, void *grad_src, int b, int p1, int p2, long long row_bytes,
                      epn_stream_t stream);
-/* epn_scatter_rows that ACCUMULATES (atomic adds): repeated indices -- FPS repeats index 0 for clouds with fewer live
+/* epn_scatter_rows that ACCUMULATES (atomic-free and deterministic: the first occurrence of an index sums all of its
+ * rows in fp32, ascending row order; p2 <= 8192): repeated indices -- FPS repeats index 0 for clouds with fewer live
  * points than samples -- receive the sum of their rows, like the backward of torch.gather / batched_index_select
  * (vgtk/vgtk/spconv/functional.py:28-40).  Elements fp32 (bf16 = 0) or bf16 (bf16 = 1). */
 int epn_scatter_rows_add(const void *grad_dst, const int32_t *idx, void *grad_src, int b, int p1, int p2,

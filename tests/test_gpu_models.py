@@ -196,3 +196,20 @@ def test_bench_line_kernel_names_are_profiler_names(gpu):
     missing = sorted(n for n in names if n not in known)
     assert not missing, missing
     assert any("norm_act" in n for n in names) and any("fps" in n for n in names)      # glue and index kernels are bracketed
+
+
+@pytest.mark.parametrize("dt", [torch.float32, torch.bfloat16])
+def test_gather_rows_backward_accumulates_repeated_indices(gpu, dt):
+    """ops.gather_rows (strided skip connection): the gradient of a source row that was sampled several times -- FPS repeats
+    index 0 for clouds with fewer live points than samples -- is the SUM of its rows' gradients, as torch.gather gives."""
+    from epn_pointcloud_amd import ops
+    torch.manual_seed(5)
+    feats = torch.randn(2, 16, 40, 60, device=gpu).to(dt).requires_grad_(True)
+    idx = torch.stack([torch.arange(20), torch.cat([torch.arange(12), torch.zeros(8, dtype=torch.long)])]).int().to(gpu)
+    g = torch.randn(2, 16, 20, 60, device=gpu).to(dt)
+    (got,) = torch.autograd.grad(ops.gather_rows(feats, idx), [feats], g)
+    ref_in = feats.detach().float().requires_grad_(True)
+    ii = idx.long().view(2, 1, 20, 1).expand(-1, 16, -1, 60)
+    (want,) = torch.autograd.grad(torch.gather(ref_in, 2, ii), [ref_in], g.float())
+    tol = 1e-6 if dt == torch.float32 else 4e-2
+    assert (got.float() - want).abs().max().item() <= tol * max(1.0, want.abs().max().item())
