@@ -31,7 +31,10 @@ def main():
     ap.add_argument("--cfg", type=int, default=0, help="NT tile override (csrc/gemm.hip launch_nt_typed), 0 = heuristic")
     a = ap.parse_args()
     if a.cfg:
+        from _tuning import use_tuning_lib
+        lib_path = use_tuning_lib()           # tile overrides: the -DEPN_TUNING library (before the library is loaded)
         from epn_pointcloud_amd import _lib
+        _lib.LIB_PATH = lib_path
         _lib.check(_lib.get_lib().epn_set_kernel_policy(a.cfg if a.cfg >= 0x100 else 0x100 | a.cfg), "set_kernel_policy")
     dt = torch.float32 if a.dtype == "f32" else torch.bfloat16
     dev = torch.device("cuda:0")

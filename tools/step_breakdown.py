@@ -8,6 +8,9 @@ import sys
 import torch
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+if os.environ.get("EPN_SB_POLICY"):
+    from _tuning import use_tuning_lib
+    use_tuning_lib()                          # A/B policies: the -DEPN_TUNING library
 from epn_pointcloud_amd import models as M, schedule as S, ops, _lib  # noqa: E402
 
 if os.environ.get("EPN_SB_POLICY"):
@@ -30,7 +33,7 @@ step(); step(); torch.cuda.synchronize()
 ops.profile_begin(); step(); torch.cuda.synchronize()
 rec = ops.profile_end()
 agg, fam = collections.defaultdict(lambda: [0, 0.0]), collections.defaultdict(float)
-for kind, key, fl, e0, e1 in rec:
+for kind, key, fl, e0, e1, _kernel in rec:
     ms = e0.elapsed_time(e1)
     k = (kind,) + tuple(key)[:8]
     agg[k][0] += 1; agg[k][1] += ms; fam[kind] += ms

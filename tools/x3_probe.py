@@ -7,6 +7,9 @@ import sys
 import torch
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+if len(sys.argv) > 1:                     # tile overrides: the -DEPN_TUNING library
+    from _tuning import use_tuning_lib
+    use_tuning_lib()
 from epn_pointcloud_amd import gemm, _lib  # noqa: E402
 from gemm_bench import timeit  # noqa: E402
 
