@@ -1012,13 +1012,14 @@ constexpr int USH_TAB = 4096;   // destinations are de-duplicated through a dire
 // CW: 16-channel chunks handled per anchor step.  The kernel-influence weights of an (output point, anchor) pair do not
 // depend on the channel: with CW > 1 they are generated ONCE per anchor (S-MFMAs, table reads, relu, packing) for CW
 // chunks, and one barrier pair covers CW chunks' worth of contributions (the LDS tile row is 16 CW channels wide).
-template <int NT, int KT, typename TG, int GP, int NB = 2, bool DET = false, int CW = 1>   // NB tile buffers: 2 = one barrier per column, 1 = two (half the LDS)
+// CS: chunk groups handled one after the other per anchor step with the SAME weights (the tile stays 16 CW wide).
+template <int NT, int KT, typename TG, int GP, int NB = 2, bool DET = false, int CW = 1, int CS = 1>   // NB tile buffers: 2 = one barrier per column, 1 = two (half the LDS)
 __global__ __launch_bounds__(64 * GP) void inter_ungroup_shared_kernel(InterArgs A, const int32_t *__restrict__ order,
                                                                        unsigned char *__restrict__ canon = nullptr) {
     constexpr int EW = 16 * NT;        // neighbour slots per point (padded)
     constexpr int E = GP * EW;         // slots of the workgroup (128 or 256)
     constexpr int SS = 16 * CW + 4;    // floats per slot row: 16 CW channels + 4 (rows 4 apart fall on distinct banks)
-    static_assert(CW == 1 || !DET, "the deterministic form handles one chunk per step");
+    static_assert((CW == 1 && CS == 1) || !DET, "the deterministic form handles one chunk per step");
     constexpr int NTH = 64 * GP;
     constexpr int CH = E / 64;         // 64-slot chunks
     constexpr int EPT = (E + NTH - 1) / NTH;   // slots per thread in the set-up passes
@@ -1160,78 +1161,79 @@ __global__ __launch_bounds__(64 * GP) void inter_ungroup_shared_kernel(InterArgs
         alphaN[t] = __shfl(h.gA[t], 48 + x, 64);
         gB[t] = j == 3 ? 1.0f : h.gA[t];
     }
-    for (int ct = ct0; ct < ct1; ct += CW) {
+    for (int ct = ct0; ct < ct1; ct += CW * CS) {
     const TG *dG = reinterpret_cast<const TG *>(A.gout) + ((size_t)bb * A.p2 + pp) * A.na * gss + (size_t)(16 * ct + x) * A.ks;
     float *dcloud = A.out + ((size_t)bb * A.p1) * A.na * A.cin + 16 * ct;
     for (int a = 0; a < A.na; ++a) {
-        const int ph = ((ct - ct0) / CW) * A.na + a;                   // tile buffers alternate across chunk groups too
-        float *buf = Tb + (ph & (NB - 1)) * E * SS + wave * EW * SS + x;
         float rk[KT];
 #pragma unroll
         for (int kt = 0; kt < KT; ++kt) rk[kt] = A.rk4[((size_t)a * EPN_KS_MAX + 16 * kt + x) * 4 + j];
-        typename std::conditional<sizeof(TG) == 2, bf16x4_t, f32x4>::type dgc[CW][KT];
+        // weights of this anchor: generated once, used by every chunk of the group
+        typename std::conditional<sizeof(TG) == 2, bf16x4_t, f32x4>::type wgt[NT][KT];
 #pragma unroll
-        for (int cw = 0; cw < CW; ++cw)
-#pragma unroll
-            for (int kt = 0; kt < KT; ++kt) {
-                const int jj = 16 * kt + 4 * j < A.ks ? j : 0;
-                const TG *src = dG + (size_t)a * gss + (size_t)(16 * cw) * A.ks + 16 * kt + 4 * jj;
-                if constexpr (sizeof(TG) == 2) dgc[cw][kt] = *reinterpret_cast<const bf16x4_t *>(src);
-                else dgc[cw][kt] = ld4f(src);
-            }
-#pragma unroll
-        for (int t = 0; t < NT; ++t) {
-            // weights of this anchor for neighbour tile t: generated once, used by every chunk of the group
-            f32x4 sk[KT];
+        for (int t = 0; t < NT; ++t)
 #pragma unroll
             for (int kt = 0; kt < KT; ++kt) {
-                sk[kt] = f32x4{alphaN[t], alphaN[t], alphaN[t], alphaN[t]};
-                sk[kt] = mfma4(rk[kt], gB[t], sk[kt]);
-            }
-            bf16x4_t wp[KT];
-            if constexpr (sizeof(TG) == 2) {
-#pragma unroll
-                for (int kt = 0; kt < KT; ++kt) wp[kt] = relu_pack4(sk[kt]);
-            } else {
-#pragma unroll
-                for (int kt = 0; kt < KT; ++kt)
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) sk[kt][r] = relu_f(sk[kt][r]);
-            }
-#pragma unroll
-            for (int cw = 0; cw < CW; ++cw) {
-                f32x4 tt = {0.f, 0.f, 0.f, 0.f};
+                f32x4 sk = {alphaN[t], alphaN[t], alphaN[t], alphaN[t]};
+                sk = mfma4(rk[kt], gB[t], sk);
                 if constexpr (sizeof(TG) == 2) {
-                    // bf16 dG: the contraction over the kernel points on the bf16 MFMA (both 16-point tiles in one K = 32)
-                    if constexpr (KT == 2) tt = mfma_bf16_k32(wp[0], wp[1], dgc[cw][0], dgc[cw][1], tt);
-                    else tt = mfma_bf16_k16(wp[0], dgc[cw][0], tt);
+                    wgt[t][kt] = relu_pack4(sk);
                 } else {
 #pragma unroll
-                    for (int kt = 0; kt < KT; ++kt)
-#pragma unroll
-                        for (int r = 0; r < 4; ++r) tt = mfma4(sk[kt][r], dgc[cw][kt][r], tt);
+                    for (int r = 0; r < 4; ++r) sk[r] = relu_f(sk[r]);
+                    wgt[t][kt] = sk;
                 }
-                // tt: lane (x = c, j), register r -> slot n = 16t + 4j + r
+            }
 #pragma unroll
-                for (int r = 0; r < 4; ++r)
-                    if (h.mul[t][r] != 0.0f) buf[(16 * t + 4 * j + r) * SS + 16 * cw] = tt[r] * h.mul[t][r];
+        for (int cs = 0; cs < CS; ++cs) {
+            const int ph = (((ct - ct0) / (CW * CS)) * A.na + a) * CS + cs;     // tile buffers alternate across steps
+            float *buf = Tb + (ph & (NB - 1)) * E * SS + wave * EW * SS + x;
+            typename std::conditional<sizeof(TG) == 2, bf16x4_t, f32x4>::type dgc[CW][KT];
+#pragma unroll
+            for (int cw = 0; cw < CW; ++cw)
+#pragma unroll
+                for (int kt = 0; kt < KT; ++kt) {
+                    const int jj = 16 * kt + 4 * j < A.ks ? j : 0;
+                    const TG *src = dG + (size_t)a * gss + (size_t)(16 * (cs * CW + cw)) * A.ks + 16 * kt + 4 * jj;
+                    if constexpr (sizeof(TG) == 2) dgc[cw][kt] = *reinterpret_cast<const bf16x4_t *>(src);
+                    else dgc[cw][kt] = ld4f(src);
+                }
+#pragma unroll
+            for (int t = 0; t < NT; ++t)
+#pragma unroll
+                for (int cw = 0; cw < CW; ++cw) {
+                    f32x4 tt = {0.f, 0.f, 0.f, 0.f};
+                    if constexpr (sizeof(TG) == 2) {
+                        // bf16 dG: the contraction over the kernel points on the bf16 MFMA (both 16-point tiles in one K = 32)
+                        if constexpr (KT == 2) tt = mfma_bf16_k32(wgt[t][0], wgt[t][1], dgc[cw][0], dgc[cw][1], tt);
+                        else tt = mfma_bf16_k16(wgt[t][0], dgc[cw][0], tt);
+                    } else {
+#pragma unroll
+                        for (int kt = 0; kt < KT; ++kt)
+#pragma unroll
+                            for (int r = 0; r < 4; ++r) tt = mfma4(wgt[t][kt][r], dgc[cw][kt][r], tt);
+                    }
+                    // tt: lane (x = c, j), register r -> slot n = 16t + 4j + r
+#pragma unroll
+                    for (int r = 0; r < 4; ++r)
+                        if (h.mul[t][r] != 0.0f) buf[(16 * t + 4 * j + r) * SS + 16 * cw] = tt[r] * h.mul[t][r];
+                }
+            __syncthreads();
+            const float *rb = Tb + (ph & (NB - 1)) * E * SS;
+            for (int i = tid; i < U * 16 * CW; i += NTH) {
+                const int u = i / (16 * CW), c = i % (16 * CW);
+                float sum = 0.0f;
+                const int k1 = off[u + 1];
+                for (int k = off[u]; k < k1; ++k) sum += rb[list[k] * SS + c];
+                if constexpr (DET) {
+                    TG *srow = reinterpret_cast<TG *>(A.out) + ((size_t)cnt[u] * A.na + a) * A.cin + 16 * ct + c;
+                    if constexpr (sizeof(TG) == 2) *srow = (__bf16)sum; else *srow = sum;
+                } else {
+                    atomicAdd(dcloud + ((size_t)uq[u] * A.na + a) * A.cin + 16 * cs * CW + c, sum);
+                }
             }
+            if constexpr (NB == 1) __syncthreads();
         }
-        __syncthreads();
-        const float *rb = Tb + (ph & (NB - 1)) * E * SS;
-        for (int i = tid; i < U * 16 * CW; i += NTH) {
-            const int u = i / (16 * CW), c = i % (16 * CW);
-            float sum = 0.0f;
-            const int k1 = off[u + 1];
-            for (int k = off[u]; k < k1; ++k) sum += rb[list[k] * SS + c];
-            if constexpr (DET) {
-                TG *srow = reinterpret_cast<TG *>(A.out) + ((size_t)cnt[u] * A.na + a) * A.cin + 16 * ct + c;
-                if constexpr (sizeof(TG) == 2) *srow = (__bf16)sum; else *srow = sum;
-            } else {
-                atomicAdd(dcloud + ((size_t)uq[u] * A.na + a) * A.cin + c, sum);
-            }
-        }
-        if constexpr (NB == 1) __syncthreads();
     }
     }
 }
@@ -1776,32 +1778,33 @@ int launch_inter_ungroup_mfma(const epn_inter_desc *d, const float *rk4, const v
     if (order && d->p2 % gp == 0 && d->p2 <= MORTON_MAX && d->p1 <= USH_TAB && kernel_policy() != (0x400 | 1)) {
         EPN_LAUNCH_AUX(morton_order_kernel, dim3(d->b), dim3(1024), 0, st, d->new_xyz, d->p2, order);
         EPN_CHECK_LAUNCH();
-        // chunks per anchor step (template CW): the weights of an anchor are generated once for CW chunks and one barrier
-        // pair covers them; bounded by the LDS tile (E x (16 CW + 4) floats x buffers)
-        // Measured per layer (ms, CW = 1 -> 4): fp32 K = 16 1.93 -> 1.77, K = 32 1.36 -> 1.26; bf16 K = 32 1.60 -> 1.39.  K = 64
-        // (8 waves per workgroup: the 150 KB tile leaves one workgroup per CU) 1.5 -> 1.9-2.6 and cin = 32 (CW = 2)
-        // 1.70 -> 1.78: those keep one chunk per step.
-        const int cw = (d->cin % 64 == 0 && nt <= 2) ? 4 : 1;
-        A.col_tiles_per_wg = cw;
-        const dim3 grid((unsigned)(d->b * (d->p2 / gp)), (unsigned)((d->cin >> 4) / cw));
-#define EPN_USH_CW(NT_, KT_, GP_, NB_, CW_)                                                                                \
-    do {                                                                                                                  \
-        if (bf16) EPN_LAUNCH((inter_ungroup_shared_kernel<NT_, KT_, __bf16, GP_, NB_, false, CW_>), grid, dim3(64 * GP_), 0, st, A, order); \
-        else EPN_LAUNCH((inter_ungroup_shared_kernel<NT_, KT_, float, GP_, NB_, false, CW_>), grid, dim3(64 * GP_), 0, st, A, order);      \
-    } while (0)
+        // Chunks per anchor step: the weights of an anchor are generated once for CW * CS chunks; CW of them share one
+        // barrier pair (LDS tile 16 CW channels wide), CS such groups follow each other on the same tile.
+        // Measured per layer (ms, one chunk per step -> grouped): CW = 4: fp32 K = 16 1.93 -> 1.77, K = 32 1.36 -> 1.26;
+        // bf16 K = 32 1.60 -> 1.39; at K = 64 (8 waves per workgroup) the 150 KB tile of CW = 4 leaves one workgroup per CU
+        // (1.5 -> 1.9-2.6) and sequential groups (CS = 4) lose to independent workgroups (1.50 -> 1.73): one chunk per step there.
+        const bool wide = d->cin % 64 == 0 && nt <= 2;
+        const int cs = 1;       // CS = 4 at K = 64 measured 1.50 -> 1.73 ms: fewer, longer workgroups hide the barrier stalls worse
+        A.col_tiles_per_wg = wide ? 4 : cs;
+        const dim3 grid((unsigned)(d->b * (d->p2 / gp)), (unsigned)((d->cin >> 4) / A.col_tiles_per_wg));
 #define EPN_USH(NT_, KT_, GP_)                                                                                            \
     do {                                                                                                                  \
         constexpr int nb_ = ((NT_ == 1 && GP_ == 8) ? 2 : 1);                                                             \
-        constexpr int e_ = GP_ * 16 * NT_;                                                                                \
-        if (cw == 4 && (size_t)nb_ * e_ * 68 * 4 <= 140 * 1024) EPN_USH_CW(NT_, KT_, GP_, nb_, 4);                         \
-        else if (cw >= 2 && (size_t)nb_ * e_ * 36 * 4 <= 140 * 1024) { A.col_tiles_per_wg = 2;                             \
-            const dim3 grid2(grid.x, (unsigned)((d->cin >> 4) / 2));                                                      \
-            if (bf16) EPN_LAUNCH((inter_ungroup_shared_kernel<NT_, KT_, __bf16, GP_, nb_, false, 2>), grid2, dim3(64 * GP_), 0, st, A, order); \
-            else EPN_LAUNCH((inter_ungroup_shared_kernel<NT_, KT_, float, GP_, nb_, false, 2>), grid2, dim3(64 * GP_), 0, st, A, order); }     \
-        else { A.col_tiles_per_wg = 1;                                                                                    \
-            const dim3 grid1(grid.x, (unsigned)(d->cin >> 4));                                                            \
-            if (bf16) EPN_LAUNCH((inter_ungroup_shared_kernel<NT_, KT_, __bf16, GP_, nb_>), grid1, dim3(64 * GP_), 0, st, A, order); \
-            else EPN_LAUNCH((inter_ungroup_shared_kernel<NT_, KT_, float, GP_, nb_>), grid1, dim3(64 * GP_), 0, st, A, order); }     \
+        if (wide) {                                                                                                       \
+            if constexpr ((size_t)nb_ * GP_ * 16 * NT_ * 68 * 4 <= 140 * 1024) {                                          \
+                if (bf16) EPN_LAUNCH((inter_ungroup_shared_kernel<NT_, KT_, __bf16, GP_, nb_, false, 4, 1>), grid, dim3(64 * GP_), 0, st, A, order); \
+                else EPN_LAUNCH((inter_ungroup_shared_kernel<NT_, KT_, float, GP_, nb_, false, 4, 1>), grid, dim3(64 * GP_), 0, st, A, order);      \
+            }                                                                                                             \
+        } else if (cs == 4) {                                                                                             \
+            if (bf16) EPN_LAUNCH((inter_ungroup_shared_kernel<NT_, KT_, __bf16, GP_, nb_, false, 1, 4>), grid, dim3(64 * GP_), 0, st, A, order); \
+            else EPN_LAUNCH((inter_ungroup_shared_kernel<NT_, KT_, float, GP_, nb_, false, 1, 4>), grid, dim3(64 * GP_), 0, st, A, order);      \
+        } else if (cs == 2) {                                                                                             \
+            if (bf16) EPN_LAUNCH((inter_ungroup_shared_kernel<NT_, KT_, __bf16, GP_, nb_, false, 1, 2>), grid, dim3(64 * GP_), 0, st, A, order); \
+            else EPN_LAUNCH((inter_ungroup_shared_kernel<NT_, KT_, float, GP_, nb_, false, 1, 2>), grid, dim3(64 * GP_), 0, st, A, order);      \
+        } else {                                                                                                          \
+            if (bf16) EPN_LAUNCH((inter_ungroup_shared_kernel<NT_, KT_, __bf16, GP_, nb_>), grid, dim3(64 * GP_), 0, st, A, order); \
+            else EPN_LAUNCH((inter_ungroup_shared_kernel<NT_, KT_, float, GP_, nb_>), grid, dim3(64 * GP_), 0, st, A, order);      \
+        }                                                                                                                 \
     } while (0)
         const int kt = (d->ks + 15) / 16;
         if (kt == 1) {
@@ -1815,7 +1818,6 @@ int launch_inter_ungroup_mfma(const epn_inter_desc *d, const float *rk4, const v
             else if (nt <= 4) { if (gp == 8) EPN_USH(4, 2, 8); else EPN_USH(4, 2, 4); }
             else EPN_USH(8, 2, 2);
         }
-#undef EPN_USH_CW
 #undef EPN_USH
         EPN_CHECK_LAUNCH();
         return 0;
