@@ -19,7 +19,7 @@ def short(n):
     m = re.match(r"(Cijk_[A-Za-z]+_[A-Za-z]+)_.*?_(MT\d+x\d+x\d+)_", n)   # Tensile (rocBLAS / hipBLASLt) GEMM kernels
     if m:
         return f"{m.group(1)}_{m.group(2)}"
-    return n.replace("void ", "").replace("epn::(anonymous namespace)::", "epn::").split("(")[0]
+    return n.replace("void ", "").replace("(anonymous namespace)::", "").split("(")[0]
 
 
 root, out = sys.argv[1], sys.argv[2]
@@ -32,7 +32,7 @@ for d in sorted(glob.glob(os.path.join(root, "pmc_*"))):
     disp = collections.defaultdict(set)
     for r in csv.DictReader(open(f)):
         k = short(r["Kernel_Name"])
-        if not k.startswith(("epn::", "Cijk_")):
+        if not k.startswith(("epn::", "Cijk_", "_ZN3epn", "fps_", "ball_query", "gather_")):
             continue
         agg[k][r["Counter_Name"]] += float(r["Counter_Value"])
         disp[k].add(r["Dispatch_Id"])
