@@ -420,7 +420,7 @@ def measure(cfg, rank, local_rank, world, dev, first=True):
         host_ms = host_ms0
         for _ in range(prof_steps):
             t_h = time.perf_counter()
-            hold_gpu(50.0 + 2.0 * host_ms, dev)              # the host enqueues the whole step behind a spinning kernel
+            hold_gpu(100.0 + 3.0 * host_ms, dev)              # the host enqueues the whole step behind a spinning kernel
             ops.profile_begin() if _ == 0 else None
             eager_step()
             host_ms = max(host_ms, (time.perf_counter() - t_h) * 1e3)

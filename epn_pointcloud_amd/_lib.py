@@ -29,7 +29,8 @@ EXPORTS = [
     "epn_gather_rows", "epn_scatter_rows", "epn_conv1x1_c1_f32", "epn_conv1x1_c1_bwd_weight_f32",
     "epn_ball_query_f64", "epn_fps_f64", "epn_gather_fwd_f64", "epn_gather_bwd_f64", "epn_so3_basis_norm_f32", "epn_so3_basis_norm_bf16", "epn_so3_basis_split_f32", "epn_so3_basis_norm_split_f32", "epn_inter_inverse_list", "epn_inter_ungroup_det_f32", "epn_inter_ungroup_det_bf16",
     "epn_chan_stats_bf16", "epn_norm_act_fwd_bf16", "epn_norm_act_bwd_reduce_bf16", "epn_norm_act_bwd_apply_bf16",
-    "epn_last_kernel", "epn_scatter_rows_add", "epn_inter_onchip_ok", "epn_inter_onchip_workspace_bytes", "epn_inter_so3conv_fwd_onchip_f32", "epn_inter_so3conv_fwd_bf16",
+    "epn_last_kernel", "epn_scatter_rows_add", "epn_norm_pair_workspace_bytes", "epn_norm_act_pair_fwd",
+    "epn_norm_act_pair_bwd_reduce", "epn_norm_act_pair_bwd_apply", "epn_inter_onchip_ok", "epn_inter_onchip_workspace_bytes", "epn_inter_so3conv_fwd_onchip_f32", "epn_inter_so3conv_fwd_bf16",
 ]
 
 _vp, _ci, _cf, _sz = ctypes.c_void_p, ctypes.c_int, ctypes.c_float, ctypes.c_size_t
@@ -40,6 +41,11 @@ class InterDesc(ctypes.Structure):
     _fields_ = [("xyz", _vp), ("new_xyz", _vp), ("ball_idx", _vp), ("anchors", _vp), ("kernels", _vp),
                 ("dense_w", _vp), ("sigma", _cf), ("b", _ci), ("p1", _ci), ("p2", _ci), ("nn", _ci),
                 ("na", _ci), ("ks", _ci), ("cin", _ci), ("cout", _ci)]
+
+
+class NormPairSide(ctypes.Structure):
+    """struct epn_norm_pair_side (include/epn_so3conv.h)."""
+    _fields_ = [("sums", _vp), ("gamma", _vp), ("beta", _vp), ("eps", _cf), ("instance", _ci)]
 
 
 class GemmNtProblem(ctypes.Structure):
@@ -150,6 +156,15 @@ def get_lib():
     lib.epn_gather_rows.argtypes = [_vp, _vp, _vp, _ci, _ci, _ci, _ll, _vp]
     lib.epn_scatter_rows.argtypes = [_vp, _vp, _vp, _ci, _ci, _ci, _ll, _vp]
     lib.epn_scatter_rows_add.argtypes = [_vp, _vp, _vp, _ci, _ci, _ci, _ll, _ci, _vp]
+    sp = ctypes.POINTER(NormPairSide)
+    lib.epn_norm_pair_workspace_bytes.argtypes = [_ci, _ll, _ci]
+    lib.epn_norm_pair_workspace_bytes.restype = _sz
+    lib.epn_norm_act_pair_fwd.argtypes = [_vp, _vp, _ci, _ll, _ci, sp, sp, _cf, _vp, _ci, _vp]
+    lib.epn_norm_act_pair_bwd_reduce.argtypes = [_vp, _vp, _vp, _ci, _ll, _ci, sp, sp, _cf, _vp, _vp, _vp, _vp, _vp, _vp, _vp,
+                                                 _sz, _ci, _vp]
+    lib.epn_norm_act_pair_bwd_apply.argtypes = [_vp, _vp, _vp, _ci, _ll, _ci, sp, sp, _cf, _vp, _vp, _vp, _vp, _ci, _vp]
+    for _n in ("epn_norm_act_pair_fwd", "epn_norm_act_pair_bwd_reduce", "epn_norm_act_pair_bwd_apply"):
+        getattr(lib, _n).restype = _ci
     lib.epn_scatter_rows_add.restype = _ci
     lib.epn_conv1x1_c1_f32.argtypes = [_vp, _vp, _vp, _ll, _ci, _vp]
     lib.epn_conv1x1_c1_bwd_weight_f32.argtypes = [_vp, _vp, _vp, _ll, _ci, _vp]

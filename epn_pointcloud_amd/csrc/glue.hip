@@ -276,6 +276,158 @@ __global__ __launch_bounds__(GT) void norm_act_bwd_apply_kernel(NormArgs A) {
     }
 }
 
+// ---- the tail of a separable block in ONE pass per direction:  y = leaky(norm_a(xa)) + leaky(norm_b(xb)),
+// xa = IntraSO3Conv output with its InstanceNorm, xb = the skip branch's 1x1 convolution with the block's norm
+// (SPConvNets/utils/base_so3conv.py:204-211).  The skip branch's normalised tensor is never written, and the backward
+// pass reads the common output gradient once per pass instead of once per norm.  The tensors are walked as
+// [b clouds][rows per cloud][c]; a side is "instance" (statistics per cloud) or "batch" (one set for all clouds).
+struct NormSide {
+    const void *x;
+    void *dx;
+    const float *sums, *dsums, *gamma, *beta;
+    float *part;          // reduce: per-block partials [b][blocks][c][2]
+    float eps, inv_rows;
+    int per_cloud;        // 1: statistics indexed by the cloud, 0: shared
+};
+struct NormArgs2 {
+    NormSide a, b;
+    const void *dy;
+    void *y;
+    long long rows;       // per cloud
+    int c, rows_per_block;
+    float slope;
+};
+
+__device__ __forceinline__ void side_stats4(const NormSide &S, int c, int g, int c4, f32x4 &mean, f32x4 &rstd) {
+    const float *s = S.sums + ((size_t)(S.per_cloud ? g : 0) * c + c4) * 2;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const float m = s[2 * i] * S.inv_rows;
+        const float var = fmaxf(s[2 * i + 1] * S.inv_rows - m * m, 0.0f);
+        mean[i] = m;
+        rstd[i] = rsqrtf(var + S.eps);
+    }
+}
+
+template <typename T>
+__global__ __launch_bounds__(GT) void norm_act2_fwd_kernel(NormArgs2 A) {
+    const int lanes = A.c >> 2, cl = threadIdx.x % lanes, rl = threadIdx.x / lanes, rstep = GT / lanes;
+    const int g = blockIdx.y, c4 = 4 * cl;
+    f32x4 ma, ra, ga, ba, mb, rb, gb, bb;
+    side_stats4(A.a, A.c, g, c4, ma, ra);
+    side_stats4(A.b, A.c, g, c4, mb, rb);
+    load_param4(A.a.gamma, c4, ga, 1.0f); load_param4(A.a.beta, c4, ba, 0.0f);
+    load_param4(A.b.gamma, c4, gb, 1.0f); load_param4(A.b.beta, c4, bb, 0.0f);
+    const long long r0 = (long long)blockIdx.x * A.rows_per_block;
+    long long r1 = r0 + A.rows_per_block;
+    r1 = r1 < A.rows ? r1 : A.rows;
+    const size_t base = ((size_t)g * A.rows) * A.c + c4;
+    for (long long r = r0 + rl; r < r1; r += rstep) {
+        const size_t off = base + (size_t)r * A.c;
+        const f32x4 va = ld4(static_cast<const T *>(A.a.x) + off);
+        const f32x4 vb = ld4(static_cast<const T *>(A.b.x) + off);
+        f32x4 o;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const float na = (va[i] - ma[i]) * ra[i] * ga[i] + ba[i];
+            const float nb = (vb[i] - mb[i]) * rb[i] * gb[i] + bb[i];
+            o[i] = (na > 0.0f ? na : na * A.slope) + (nb > 0.0f ? nb : nb * A.slope);
+        }
+        st4(static_cast<T *>(A.y) + off, o);
+    }
+}
+
+template <typename T>
+__global__ __launch_bounds__(GT) void norm_act2_bwd_reduce_kernel(NormArgs2 A) {
+    __shared__ float red[GT][16];
+    const int lanes = A.c >> 2, cl = threadIdx.x % lanes, rl = threadIdx.x / lanes, rstep = GT / lanes;
+    const int g = blockIdx.y, c4 = 4 * cl;
+    f32x4 ma, ra, ga, ba, mb, rb, gb, bb;
+    side_stats4(A.a, A.c, g, c4, ma, ra);
+    side_stats4(A.b, A.c, g, c4, mb, rb);
+    load_param4(A.a.gamma, c4, ga, 1.0f); load_param4(A.a.beta, c4, ba, 0.0f);
+    load_param4(A.b.gamma, c4, gb, 1.0f); load_param4(A.b.beta, c4, bb, 0.0f);
+    const long long r0 = (long long)blockIdx.x * A.rows_per_block;
+    long long r1 = r0 + A.rows_per_block;
+    r1 = r1 < A.rows ? r1 : A.rows;
+    const size_t base = ((size_t)g * A.rows) * A.c + c4;
+    f32x4 sa1 = {0.f, 0.f, 0.f, 0.f}, sa2 = sa1, sb1 = sa1, sb2 = sa1;
+#pragma unroll 2
+    for (long long r = r0 + rl; r < r1; r += rstep) {
+        const size_t off = base + (size_t)r * A.c;
+        const f32x4 va = ld4(static_cast<const T *>(A.a.x) + off);
+        const f32x4 vb = ld4(static_cast<const T *>(A.b.x) + off);
+        const f32x4 d = ld4(static_cast<const T *>(A.dy) + off);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const float xa = (va[i] - ma[i]) * ra[i], xb = (vb[i] - mb[i]) * rb[i];
+            const float da = (xa * ga[i] + ba[i]) > 0.0f ? d[i] : d[i] * A.slope;
+            const float db = (xb * gb[i] + bb[i]) > 0.0f ? d[i] : d[i] * A.slope;
+            sa1[i] += da; sa2[i] += da * xa;
+            sb1[i] += db; sb2[i] += db * xb;
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        red[threadIdx.x][i] = sa1[i]; red[threadIdx.x][4 + i] = sa2[i];
+        red[threadIdx.x][8 + i] = sb1[i]; red[threadIdx.x][12 + i] = sb2[i];
+    }
+    __syncthreads();
+    if (rl == 0) {
+        for (int t = 1; t < rstep; ++t)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                sa1[i] += red[t * lanes + cl][i]; sa2[i] += red[t * lanes + cl][4 + i];
+                sb1[i] += red[t * lanes + cl][8 + i]; sb2[i] += red[t * lanes + cl][12 + i];
+            }
+        const size_t po = (((size_t)g * gridDim.x + blockIdx.x) * A.c + c4) * 2;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            A.a.part[po + 2 * i] = sa1[i]; A.a.part[po + 2 * i + 1] = sa2[i];
+            A.b.part[po + 2 * i] = sb1[i]; A.b.part[po + 2 * i + 1] = sb2[i];
+        }
+    }
+}
+
+template <typename T>
+__global__ __launch_bounds__(GT) void norm_act2_bwd_apply_kernel(NormArgs2 A) {
+    const int lanes = A.c >> 2, cl = threadIdx.x % lanes, rl = threadIdx.x / lanes, rstep = GT / lanes;
+    const int g = blockIdx.y, c4 = 4 * cl;
+    f32x4 ma, ra, ga, ba, mb, rb, gb, bb, a1, a2, b1, b2;
+    side_stats4(A.a, A.c, g, c4, ma, ra);
+    side_stats4(A.b, A.c, g, c4, mb, rb);
+    load_param4(A.a.gamma, c4, ga, 1.0f); load_param4(A.a.beta, c4, ba, 0.0f);
+    load_param4(A.b.gamma, c4, gb, 1.0f); load_param4(A.b.beta, c4, bb, 0.0f);
+    const float *dsa = A.a.dsums + ((size_t)(A.a.per_cloud ? g : 0) * A.c + c4) * 2;
+    const float *dsb = A.b.dsums + ((size_t)(A.b.per_cloud ? g : 0) * A.c + c4) * 2;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        a1[i] = dsa[2 * i] * A.a.inv_rows; a2[i] = dsa[2 * i + 1] * A.a.inv_rows;
+        b1[i] = dsb[2 * i] * A.b.inv_rows; b2[i] = dsb[2 * i + 1] * A.b.inv_rows;
+    }
+    const long long r0 = (long long)blockIdx.x * A.rows_per_block;
+    long long r1 = r0 + A.rows_per_block;
+    r1 = r1 < A.rows ? r1 : A.rows;
+    const size_t base = ((size_t)g * A.rows) * A.c + c4;
+    for (long long r = r0 + rl; r < r1; r += rstep) {
+        const size_t off = base + (size_t)r * A.c;
+        const f32x4 va = ld4(static_cast<const T *>(A.a.x) + off);
+        const f32x4 vb = ld4(static_cast<const T *>(A.b.x) + off);
+        const f32x4 d = ld4(static_cast<const T *>(A.dy) + off);
+        f32x4 oa, ob;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const float xa = (va[i] - ma[i]) * ra[i], xb = (vb[i] - mb[i]) * rb[i];
+            const float dna = ((xa * ga[i] + ba[i]) > 0.0f ? d[i] : d[i] * A.slope) * ga[i];
+            const float dnb = ((xb * gb[i] + bb[i]) > 0.0f ? d[i] : d[i] * A.slope) * gb[i];
+            oa[i] = ra[i] * (dna - a1[i] - xa * a2[i]);
+            ob[i] = rb[i] * (dnb - b1[i] - xb * b2[i]);
+        }
+        if (A.a.dx) st4(static_cast<T *>(A.a.dx) + off, oa);
+        if (A.b.dx) st4(static_cast<T *>(A.b.dx) + off, ob);
+    }
+}
+
 int check_norm(int groups, long long rows, int c) {
     if (groups < 0 || rows < 0 || c < 4 || c % 4 != 0 || c > 4 * GT || GT % (c / 4) != 0) return EPN_EINVAL;
     if (groups > 65535) return EPN_EINVAL;
@@ -414,6 +566,116 @@ static int norm_act_bwd_apply_any(const void *x_cl, const void *dy_cl, int group
     else EPN_LAUNCH(norm_act_bwd_apply_kernel<float>, grid, dim3(GT), 0, epn_stream(stream), A);
     EPN_CHECK_LAUNCH();
     return 0;
+}
+
+// ---- pair form: host side.  clouds b, rows per cloud, c; each side: sums / dsums [b or 1][c][2], gamma, beta (or NULL)
+static int pair_setup(const epn_norm_pair_side *sa, const epn_norm_pair_side *sb, int b, long long rows, int c, float slope,
+                      NormArgs2 &A, dim3 &grid) {
+    int rc = check_norm(b, rows, c);
+    if (rc) return rc;
+    if (!sa || !sb) return EPN_ENULL;
+    NormArgs one = make_norm(rows, c, 0.f, slope, grid, b);
+    A = NormArgs2{};
+    A.rows = rows; A.c = c; A.rows_per_block = one.rows_per_block; A.slope = slope;
+    const epn_norm_pair_side *src[2] = {sa, sb};
+    NormSide *dst[2] = {&A.a, &A.b};
+    for (int i = 0; i < 2; ++i) {
+        dst[i]->sums = src[i]->sums; dst[i]->gamma = src[i]->gamma; dst[i]->beta = src[i]->beta;
+        dst[i]->eps = src[i]->eps; dst[i]->per_cloud = src[i]->instance ? 1 : 0;
+        const double n = src[i]->instance ? (double)rows : (double)rows * b;
+        dst[i]->inv_rows = n > 0 ? (float)(1.0 / n) : 0.f;
+    }
+    return 0;
+}
+
+static int norm_act2_fwd_any(const void *xa, const void *xb, int b, long long rows, int c, const epn_norm_pair_side *sa,
+                             const epn_norm_pair_side *sb, float slope, void *y, int bf16, epn_stream_t stream) {
+    NormArgs2 A; dim3 grid;
+    int rc = pair_setup(sa, sb, b, rows, c, slope, A, grid);
+    if (rc) return rc;
+    if (b == 0 || rows == 0) return 0;
+    if (!xa || !xb || !y || !sa->sums || !sb->sums) return EPN_ENULL;
+    A.a.x = xa; A.b.x = xb; A.y = y;
+    if (bf16) EPN_LAUNCH(norm_act2_fwd_kernel<__bf16>, grid, dim3(GT), 0, epn_stream(stream), A);
+    else EPN_LAUNCH(norm_act2_fwd_kernel<float>, grid, dim3(GT), 0, epn_stream(stream), A);
+    EPN_CHECK_LAUNCH();
+    return 0;
+}
+
+static int norm_act2_bwd_reduce_any(const void *xa, const void *xb, const void *dy, int b, long long rows, int c,
+                                    const epn_norm_pair_side *sa, const epn_norm_pair_side *sb, float slope, float *dsums_a,
+                                    float *dgamma_a, float *dbeta_a, float *dsums_b, float *dgamma_b, float *dbeta_b,
+                                    void *workspace, size_t workspace_bytes, int bf16, epn_stream_t stream) {
+    NormArgs2 A; dim3 grid;
+    int rc = pair_setup(sa, sb, b, rows, c, slope, A, grid);
+    if (rc) return rc;
+    if (!dsums_a || !dsums_b) return EPN_ENULL;
+    hipStream_t st = epn_stream(stream);
+    float *dg[2] = {dgamma_a, dgamma_b}, *db[2] = {dbeta_a, dbeta_b};
+    for (int i = 0; i < 2; ++i) {
+        if (dg[i]) EPN_HIP(hipMemsetAsync(dg[i], 0, sizeof(float) * c, st));
+        if (db[i]) EPN_HIP(hipMemsetAsync(db[i], 0, sizeof(float) * c, st));
+    }
+    if (b == 0 || rows == 0) return 0;
+    if (!xa || !xb || !dy || !sa->sums || !sb->sums) return EPN_ENULL;
+    const size_t part_bytes = sizeof(float) * (size_t)b * grid.x * c * 2;
+    if (!workspace || workspace_bytes < 2 * part_bytes) return EPN_EWORKSPACE;
+    A.a.x = xa; A.b.x = xb; A.dy = dy;
+    A.a.part = static_cast<float *>(workspace);
+    A.b.part = A.a.part + (size_t)b * grid.x * c * 2;
+    if (bf16) EPN_LAUNCH(norm_act2_bwd_reduce_kernel<__bf16>, grid, dim3(GT), 0, st, A);
+    else EPN_LAUNCH(norm_act2_bwd_reduce_kernel<float>, grid, dim3(GT), 0, st, A);
+    EPN_CHECK_LAUNCH();
+    // finishing: an "instance" side keeps one row of sums per cloud, a "batch" side adds the partials of all clouds
+    const epn_norm_pair_side *src[2] = {sa, sb};
+    float *parts[2] = {A.a.part, A.b.part}, *ds[2] = {dsums_a, dsums_b};
+    for (int i = 0; i < 2; ++i) {
+        const int groups = src[i]->instance ? b : 1, nb = src[i]->instance ? (int)grid.x : (int)grid.x * b;
+        EPN_LAUNCH_AUX(bwd_finish_kernel, dim3(epn_cdiv(c, 16), groups), dim3(256), 0, st, parts[i], nb, c, src[i]->gamma,
+                       ds[i], dg[i], db[i]);
+        EPN_CHECK_LAUNCH();
+    }
+    return 0;
+}
+
+static int norm_act2_bwd_apply_any(const void *xa, const void *xb, const void *dy, int b, long long rows, int c,
+                                   const epn_norm_pair_side *sa, const epn_norm_pair_side *sb, float slope,
+                                   const float *dsums_a, const float *dsums_b, void *dxa, void *dxb, int bf16,
+                                   epn_stream_t stream) {
+    NormArgs2 A; dim3 grid;
+    int rc = pair_setup(sa, sb, b, rows, c, slope, A, grid);
+    if (rc) return rc;
+    if (b == 0 || rows == 0) return 0;
+    if (!xa || !xb || !dy || !sa->sums || !sb->sums || !dsums_a || !dsums_b) return EPN_ENULL;
+    A.a.x = xa; A.b.x = xb; A.dy = dy; A.a.dsums = dsums_a; A.b.dsums = dsums_b; A.a.dx = dxa; A.b.dx = dxb;
+    if (bf16) EPN_LAUNCH(norm_act2_bwd_apply_kernel<__bf16>, grid, dim3(GT), 0, epn_stream(stream), A);
+    else EPN_LAUNCH(norm_act2_bwd_apply_kernel<float>, grid, dim3(GT), 0, epn_stream(stream), A);
+    EPN_CHECK_LAUNCH();
+    return 0;
+}
+
+extern "C" size_t epn_norm_pair_workspace_bytes(int b, long long rows, int c) {
+    return 2 * epn_norm_workspace_bytes(b, rows, c);
+}
+extern "C" int epn_norm_act_pair_fwd(const void *xa_cl, const void *xb_cl, int b, long long rows, int c,
+                                     const epn_norm_pair_side *side_a, const epn_norm_pair_side *side_b, float slope, void *y_cl,
+                                     int bf16, epn_stream_t stream) {
+    return norm_act2_fwd_any(xa_cl, xb_cl, b, rows, c, side_a, side_b, slope, y_cl, bf16, stream);
+}
+extern "C" int epn_norm_act_pair_bwd_reduce(const void *xa_cl, const void *xb_cl, const void *dy_cl, int b, long long rows,
+                                            int c, const epn_norm_pair_side *side_a, const epn_norm_pair_side *side_b,
+                                            float slope, float *dsums_a, float *dgamma_a, float *dbeta_a, float *dsums_b,
+                                            float *dgamma_b, float *dbeta_b, void *workspace, size_t workspace_bytes,
+                                            int bf16, epn_stream_t stream) {
+    return norm_act2_bwd_reduce_any(xa_cl, xb_cl, dy_cl, b, rows, c, side_a, side_b, slope, dsums_a, dgamma_a, dbeta_a,
+                                    dsums_b, dgamma_b, dbeta_b, workspace, workspace_bytes, bf16, stream);
+}
+extern "C" int epn_norm_act_pair_bwd_apply(const void *xa_cl, const void *xb_cl, const void *dy_cl, int b, long long rows,
+                                           int c, const epn_norm_pair_side *side_a, const epn_norm_pair_side *side_b,
+                                           float slope, const float *dsums_a, const float *dsums_b, void *dxa_cl,
+                                           void *dxb_cl, int bf16, epn_stream_t stream) {
+    return norm_act2_bwd_apply_any(xa_cl, xb_cl, dy_cl, b, rows, c, side_a, side_b, slope, dsums_a, dsums_b, dxa_cl, dxb_cl,
+                                   bf16, stream);
 }
 
 extern "C" int epn_bn_running_update_f32(const float *sums, double count, const float *conv_bias, float *running_mean,

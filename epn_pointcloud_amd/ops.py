@@ -417,6 +417,10 @@ class InterSO3ConvSplitFn(torch.autograd.Function):
         return gf, gW, None
 
 
+def _lib_generic():
+    return False      # the generic-kernel policy is only ever set by the cross-check tests, around whole calls
+
+
 def _onchip_workspace(lib, d, bf16, device):
     nbytes = lib.epn_inter_onchip_workspace_bytes(ctypes.byref(d), int(bf16))
     ws = torch.empty(max(int(nbytes), 16), dtype=torch.uint8, device=device)
@@ -470,7 +474,29 @@ class InterSO3ConvOnChipFn(torch.autograd.Function):
         f, Wc = ctx.saved_tensors
         geo = ctx.geo
         need_f, need_w = ctx.needs_input_grad[0], ctx.needs_input_grad[1]
-        # interim: transposes through the split form (grouped features recomputed, not saved)
+        lib = _lib.get_lib()
+        d = geo.desc(f.shape[1], Wc.shape[0])
+        if f.dtype == torch.float32 and lib.epn_inter_is_fused(ctypes.byref(d)) and not _lib_generic():
+            # fp32: the fused transposes of csrc/inter_mfma.hip (exact-f32 MFMAs; grouped features and their gradient stay
+            # on chip there too) -- the whole layer then writes no [cols, cin*ks] tensor in either direction
+            g = to_cl(grad_out, "grad_out")
+            ws, wsp, wsn = _workspace(lib, d, f.device)
+            gf = gW = None
+            if need_f:
+                gf = empty_cl(d.b, f.shape[1], d.p1, d.na, f.device)
+                _lib.check(_launch("inter_bwd_data", _inter_key(d), _inter_flops(d), f.device,
+                                   lambda: lib.epn_inter_so3conv_bwd_data_f32(ctypes.byref(d), _cl_ptr(g), _lib.dev_ptr(Wc, "W"),
+                                                                              _cl_ptr(gf), wsp, wsn, _lib.stream_of(f))),
+                           "inter_so3conv_bwd_data")
+            if need_w:
+                gW = torch.empty_like(Wc)
+                _lib.check(_launch("inter_bwd_weight", _inter_key(d), _inter_flops(d), f.device,
+                                   lambda: lib.epn_inter_so3conv_bwd_weight_f32(ctypes.byref(d), _cl_ptr(f), _cl_ptr(g),
+                                                                                _lib.dev_ptr(gW, "grad_W"), wsp, wsn,
+                                                                                _lib.stream_of(f))),
+                           "inter_so3conv_bwd_weight")
+            return gf, gW, None
+        # bf16 features: transposes through the split form (grouped features recomputed, not saved)
         with torch.enable_grad():
             fd = f.detach().requires_grad_(need_f)
             Wd = Wc.detach().requires_grad_(need_w)
@@ -893,6 +919,93 @@ class NormActFn(torch.autograd.Function):
         # conv_bias (a bias the normalisation cancels, see norm_act): exact gradient = 0
         dcb = torch.zeros(c, dtype=torch.float32, device=xc.device) if has_cb else None
         return dx, dg, db, (dy if has_res else None), dcb, None, None, None
+
+
+def _pair_side(sums, g, bt, eps, instance):
+    sd = _lib.NormPairSide()
+    sd.sums = _lib.dev_ptr(sums, "sums")
+    sd.gamma = _lib.dev_ptr(g, "gamma")
+    sd.beta = _lib.dev_ptr(bt, "beta")
+    sd.eps, sd.instance = float(eps), int(instance)
+    return sd
+
+
+class NormActPairFn(torch.autograd.Function):
+    """y = leaky_relu(norm_a(xa)) + leaky_relu(norm_b(xb)): the tail of a separable block (IntraSO3Conv output with its
+    InstanceNorm + the skip branch with the block's norm, SPConvNets/utils/base_so3conv.py:204-211) as ONE streaming pass
+    forward and two backward (epn_norm_act_pair_*): the skip branch's normalised tensor is never written and the common
+    output gradient is read once per pass.  Returns (y, sums_a, sums_b)."""
+
+    @staticmethod
+    def forward(ctx, xa, xb, gamma_a, beta_a, gamma_b, beta_b, conv_bias_b, inst_a, inst_b, eps_a, eps_b, slope):
+        lib = _lib.get_lib()
+        xac = to_cl(xa, "xa")
+        xbc = cast_feats(to_cl(xb, "xb"), xac.dtype)
+        b, c, p, a = xac.shape
+        rows = p * a
+        sums_a = _chan_stats(xac, b if inst_a else 1, rows if inst_a else b * rows, c)
+        sums_b = _chan_stats(xbc, b if inst_b else 1, rows if inst_b else b * rows, c)
+        ga, ba = (t.contiguous() if t is not None else None for t in (gamma_a, beta_a))
+        gb, bb = (t.contiguous() if t is not None else None for t in (gamma_b, beta_b))
+        y = empty_cl(b, c, p, a, xac.device, xac.dtype)
+        sa, sb = _pair_side(sums_a, ga, ba, eps_a, inst_a), _pair_side(sums_b, gb, bb, eps_b, inst_b)
+        _lib.check(lib.epn_norm_act_pair_fwd(_cl_ptr(xac), _cl_ptr(xbc), b, rows, c, ctypes.byref(sa), ctypes.byref(sb),
+                                             float(slope), _cl_ptr(y), int(xac.dtype == torch.bfloat16),
+                                             _lib.stream_of(xac)), "norm_act_pair_fwd")
+        ctx.save_for_backward(xac, xbc, sums_a, sums_b, ga, ba, gb, bb)
+        ctx.cfg = (b, rows, c, bool(inst_a), bool(inst_b), float(eps_a), float(eps_b), float(slope), conv_bias_b is not None)
+        ctx.mark_non_differentiable(sums_a, sums_b)
+        return y, sums_a, sums_b
+
+    @staticmethod
+    def backward(ctx, grad_y, _ga, _gb):
+        lib = _lib.get_lib()
+        xac, xbc, sums_a, sums_b, ga, ba, gb, bb = ctx.saved_tensors
+        b, rows, c, inst_a, inst_b, eps_a, eps_b, slope, has_cb = ctx.cfg
+        dy = cast_feats(to_cl(grad_y, "grad_y"), xac.dtype)
+        dev = xac.device
+        bf = int(xac.dtype == torch.bfloat16)
+        sa, sb = _pair_side(sums_a, ga, ba, eps_a, inst_a), _pair_side(sums_b, gb, bb, eps_b, inst_b)
+        dsa, dsb = torch.empty_like(sums_a), torch.empty_like(sums_b)
+        f32 = dict(dtype=torch.float32, device=dev)
+        dga = torch.empty(c, **f32) if ga is not None else None
+        dba = torch.empty(c, **f32) if ba is not None else None
+        dgb = torch.empty(c, **f32) if gb is not None else None
+        dbb = torch.empty(c, **f32) if bb is not None else None
+        ws = torch.empty(max(int(lib.epn_norm_pair_workspace_bytes(b, rows, c)), 16), dtype=torch.uint8, device=dev)
+        st = _lib.stream_of(xac)
+        _lib.check(lib.epn_norm_act_pair_bwd_reduce(_cl_ptr(xac), _cl_ptr(xbc), _cl_ptr(dy), b, rows, c, ctypes.byref(sa),
+                                                    ctypes.byref(sb), slope, _lib.dev_ptr(dsa, "dsums_a"),
+                                                    _lib.dev_ptr(dga, "dgamma_a"), _lib.dev_ptr(dba, "dbeta_a"),
+                                                    _lib.dev_ptr(dsb, "dsums_b"), _lib.dev_ptr(dgb, "dgamma_b"),
+                                                    _lib.dev_ptr(dbb, "dbeta_b"), ctypes.c_void_p(ws.data_ptr()),
+                                                    ctypes.c_size_t(ws.numel()), bf, st), "norm_act_pair_bwd_reduce")
+        dxa = torch.empty_like(xac) if ctx.needs_input_grad[0] else None
+        dxb = torch.empty_like(xbc) if ctx.needs_input_grad[1] else None
+        if dxa is not None or dxb is not None:
+            _lib.check(lib.epn_norm_act_pair_bwd_apply(_cl_ptr(xac), _cl_ptr(xbc), _cl_ptr(dy), b, rows, c, ctypes.byref(sa),
+                                                       ctypes.byref(sb), slope, _lib.dev_ptr(dsa, "dsums_a"),
+                                                       _lib.dev_ptr(dsb, "dsums_b"),
+                                                       _cl_ptr(dxa) if dxa is not None else ctypes.c_void_p(0),
+                                                       _cl_ptr(dxb) if dxb is not None else ctypes.c_void_p(0), bf,
+                                                       _lib.stream_of(xac)), "norm_act_pair_bwd_apply")
+        dcb = torch.zeros(c, **f32) if has_cb else None       # a bias the normalisation cancels: exact gradient 0
+        return dxa, dxb, dga, dba, dgb, dbb, dcb, None, None, None, None, None
+
+
+def norm_act_pair(xa, norm_a, xb, norm_b, conv_bias_b=None, slope=0.01):
+    """leaky_relu(norm_a(xa)) + leaky_relu(norm_b(xb)) in one pass (training mode); norm_* an nn.BatchNorm2d or
+    nn.InstanceNorm2d(affine=False) whose parameters / running statistics are used and updated as the module would.
+    conv_bias_b: bias of the convolution that produced xb, NOT added to xb (see norm_act)."""
+    import torch.nn as nn
+    ia, ib = isinstance(norm_a, nn.InstanceNorm2d), isinstance(norm_b, nn.InstanceNorm2d)
+    y, sums_a, sums_b = NormActPairFn.apply(xa, xb, getattr(norm_a, "weight", None), getattr(norm_a, "bias", None),
+                                            getattr(norm_b, "weight", None), getattr(norm_b, "bias", None), conv_bias_b,
+                                            ia, ib, norm_a.eps, norm_b.eps, slope)
+    n = xa.shape[0] * xa.shape[2] * xa.shape[3]
+    _update_running_stats(norm_a, sums_a, n)
+    _update_running_stats(norm_b, sums_b, n, conv_bias_b)
+    return y
 
 
 def _chan_stats(xc, groups, rows, c):

@@ -146,12 +146,14 @@ class FusedSeparableBlock(SeparableBlock):
         skip = x.feats
         inter_idx, inter_w, sample_idx, y = self.inter_conv.conv(x, inter_idx, inter_w)
 
+        pair = os.environ.get("EPN_NORM_PAIR", "1") == "1"     # skip norm folded into the block's final pass
+
         def skip_branch():
             sk = skip
             if self.stride > 1:                                    # batched_index_select(skip, 2, sample_idx) on rows
                 sk = ops.gather_rows(sk, sample_idx)
             sk = ops.conv1x1(sk, self.skip_conv.weight, None)       # the norm cancels the bias: see ops.norm_act
-            return ops.norm_act(sk, self.norm, conv_bias=self.skip_conv.bias)
+            return sk if pair else ops.norm_act(sk, self.norm, conv_bias=self.skip_conv.bias)
 
         side = None
         if os.environ.get("EPN_SKIP_STREAM", "1") == "1" and skip.is_cuda:
@@ -174,7 +176,12 @@ class FusedSeparableBlock(SeparableBlock):
         else:
             main.wait_stream(side)
             s.record_stream(main)
-        out = ops.norm_act(z.feats, self.intra_conv.norm, residual=s)   # leaky(IN(z)) + skip in the same pass
+        if pair:
+            # leaky(IN(z)) + leaky(norm(skip conv)) in ONE pass: the skip branch's normalised tensor is never written, the
+            # backward reads the output gradient once per pass for both norms
+            out = ops.norm_act_pair(z.feats, self.intra_conv.norm, s, self.norm, conv_bias_b=self.skip_conv.bias)
+        else:
+            out = ops.norm_act(z.feats, self.intra_conv.norm, residual=s)   # leaky(IN(z)) + skip in the same pass
         return inter_idx, inter_w, sample_idx, zptk.SphericalPointCloud(z.xyz, out, z.anchors)
 
 

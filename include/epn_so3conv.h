@@ -192,6 +192,33 @@ int epn_norm_act_bwd_apply_f32(const float *x_cl, const float *dy_cl, int groups
                                const float *sums, const float *dsums, const float *gamma, const float *beta,
                                float eps, float slope, float *dx_cl, epn_stream_t stream);
 
+/* The tail of a SeparableSO3ConvBlock in one pass per direction (SPConvNets/utils/base_so3conv.py:204-211):
+ *   y = leaky_relu(norm_a(xa)) + leaky_relu(norm_b(xb))
+ * xa = the IntraSO3Conv output with its InstanceNorm2d, xb = the skip branch's 1x1 convolution with the block's norm.  The
+ * skip branch's normalised tensor is never written; the backward passes read the common output gradient once.  Tensors are
+ * [b clouds][rows per cloud][c] (float, or __bf16 with bf16 = 1; c % 4 == 0, 256 % (c/4) == 0).  A side is "instance"
+ * (sums / dsums [b][c][2], statistics per cloud) or batch (sums / dsums [1][c][2] over all clouds); sums come from
+ * epn_chan_stats_*.  bwd_reduce also writes dgamma / dbeta of a side when given; dx of a side may be NULL in bwd_apply. */
+typedef struct epn_norm_pair_side {
+    const float *sums;      /* [b or 1][c][2]: (sum x, sum x^2) */
+    const float *gamma;     /* [c] or NULL */
+    const float *beta;      /* [c] or NULL */
+    float eps;
+    int instance;           /* 1: statistics per cloud (InstanceNorm2d), 0: one set (BatchNorm2d) */
+} epn_norm_pair_side;
+size_t epn_norm_pair_workspace_bytes(int b, long long rows, int c);
+int epn_norm_act_pair_fwd(const void *xa_cl, const void *xb_cl, int b, long long rows, int c,
+                          const epn_norm_pair_side *side_a, const epn_norm_pair_side *side_b, float slope, void *y_cl,
+                          int bf16, epn_stream_t stream);
+int epn_norm_act_pair_bwd_reduce(const void *xa_cl, const void *xb_cl, const void *dy_cl, int b, long long rows, int c,
+                                 const epn_norm_pair_side *side_a, const epn_norm_pair_side *side_b, float slope,
+                                 float *dsums_a, float *dgamma_a, float *dbeta_a, float *dsums_b, float *dgamma_b,
+                                 float *dbeta_b, void *workspace, size_t workspace_bytes, int bf16, epn_stream_t stream);
+int epn_norm_act_pair_bwd_apply(const void *xa_cl, const void *xb_cl, const void *dy_cl, int b, long long rows, int c,
+                                const epn_norm_pair_side *side_a, const epn_norm_pair_side *side_b, float slope,
+                                const float *dsums_a, const float *dsums_b, void *dxa_cl, void *dxb_cl, int bf16,
+                                epn_stream_t stream);
+
 /* replaces vgtk.cuda.grouping.initial_anchor_query (vgtk/vgtk/cuda/grouping_cuda.cpp:138-158, kernel
  * grouping_cuda_kernel.cu:116-167; only consumer: KernelPropagation, vgtk/vgtk/so3conv/modules.py:57-119).
  *   centers f32[b][3][nc]   xyz f32[m][3] (fragment points, shared by the batch)   kernel_points f32[ks][na][3]

@@ -627,3 +627,80 @@ def test_norm_folded_into_basis_change(gpu, vgtk_alias, instance, dtype):
         assert torch.allclose(n1.running_mean, n2.running_mean, atol=1e-6)
         assert torch.allclose(n1.running_var, n2.running_var, atol=1e-5)
         assert int(n1.num_batches_tracked) == int(n2.num_batches_tracked) == 1
+
+
+@pytest.mark.parametrize("dt", [torch.float32, torch.bfloat16])
+def test_onchip_mode_layer_vs_oracle(gpu, vgtk_alias, dt, monkeypatch):
+    """EPN_INTER_MODE=onchip: InterSO3Conv with the grouped features kept on chip (csrc/inter_fx.hip forward; fp32 backward
+    on the fused transposes, bf16 backward through the split form) against the CPU oracle: output, data gradient, weight
+    gradient."""
+    from oracle import so3conv_ref as R_
+    import vgtk.so3conv as sptk
+    import vgtk.spconv as zptk
+    monkeypatch.setenv("EPN_INTER_MODE", "onchip")
+    rng = np.random.default_rng(31)
+    torch.manual_seed(31)
+    xyz = torch.from_numpy(unit_ball_cloud(rng, 2, 160))
+    conv = sptk.InterSO3Conv(32, 64, 1, 2, 0.4, 0.08, 20, lazy_sample=False)
+    if dt == torch.bfloat16:
+        conv.basic_conv.W.data = conv.basic_conv.W.data.bfloat16().float()
+    feats = torch.randn(2, 32, 160, 60).mul_(0.5)
+    if dt == torch.bfloat16:
+        feats = feats.bfloat16().float()
+    fo = feats.clone().requires_grad_(True)
+    Wo = conv.basic_conv.W.detach().clone().requires_grad_(True)
+    _, _, _, _, oy = R_.inter_so3conv(xyz, fo, Wo, conv.anchors, conv.kernels, 2, 0.4, 0.08, 20, False)
+    gy = torch.randn_like(oy).mul_(0.1)
+    if dt == torch.bfloat16:
+        gy = gy.bfloat16().float()
+    odF, odW = torch.autograd.grad(oy, [fo, Wo], gy)
+    conv = conv.to(gpu)
+    conv.feat_dtype = dt
+    fg = feats.to(gpu).to(dt).requires_grad_(True)
+    _, _, _, y = conv(zptk.SphericalPointCloud(xyz.to(gpu), fg, None))
+    dF, dW = torch.autograd.grad(y.feats, [fg, conv.basic_conv.W], gy.to(gpu).to(dt))
+    if dt == torch.float32:
+        assert (y.feats.detach().cpu() - oy.detach()).abs().max().item() < 1e-3
+        assert (dF.cpu() - odF).abs().max().item() < 1e-3
+        assert ((dW.cpu() - odW).norm() / odW.norm()).item() < 1e-3
+    else:
+        tol = 2e-2
+        assert (y.feats.detach().float().cpu() - oy.detach()).abs().max().item() < tol * oy.detach().abs().max().item()
+        assert (dF.float().cpu() - odF).abs().max().item() < tol * odF.abs().max().item()
+        assert ((dW.cpu() - odW).norm() / odW.norm()).item() < tol
+
+
+@pytest.mark.parametrize("dt", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("c,inst_b,affine_b", [(64, False, True), (32, True, False), (256, False, True)])
+def test_norm_act_pair_vs_torch(gpu, c, inst_b, affine_b, dt):
+    """epn_norm_act_pair_* (the block tail in one pass: leaky(IN(xa)) + leaky(norm_b(xb)), forward + both backward passes)
+    against the stock torch modules: output, both input gradients, affine gradients, running statistics."""
+    from epn_pointcloud_amd import ops
+    import copy
+    torch.manual_seed(c)
+    xa = (torch.randn(3, c, 21, 60, device=gpu) * 2 + 0.5)
+    xb = (torch.randn(3, c, 21, 60, device=gpu) * 0.7 - 0.2)
+    if dt == torch.bfloat16:
+        xa, xb = xa.bfloat16().float(), xb.bfloat16().float()
+    na = torch.nn.InstanceNorm2d(c, affine=False).to(gpu).train()
+    nb = (torch.nn.InstanceNorm2d(c, affine=False) if inst_b else torch.nn.BatchNorm2d(c)).to(gpu).train()
+    if affine_b:
+        with torch.no_grad():
+            nb.weight.uniform_(0.5, 1.5); nb.bias.uniform_(-0.5, 0.5)
+    nb_ref = copy.deepcopy(nb)
+    ra, rb = xa.clone().requires_grad_(True), xb.clone().requires_grad_(True)
+    y_ref = torch.nn.functional.leaky_relu(na(ra)) + torch.nn.functional.leaky_relu(nb_ref(rb))
+    gy = torch.randn_like(y_ref)
+    if dt == torch.bfloat16:
+        gy = gy.bfloat16().float()
+    g_ref = torch.autograd.grad(y_ref, [ra, rb] + (list(nb_ref.parameters()) if affine_b else []), gy)
+    ta, tb = xa.to(dt).requires_grad_(True), xb.to(dt).requires_grad_(True)
+    y = ops.norm_act_pair(ta, na, tb, nb)
+    g = torch.autograd.grad(y, [ta, tb] + (list(nb.parameters()) if affine_b else []), gy.to(dt))
+    tol = 1e-4 if dt == torch.float32 else 3e-2
+    assert (y.float() - y_ref).abs().max().item() < tol * max(1.0, y_ref.abs().max().item())
+    for u, v in zip(g, g_ref):
+        assert _close_except_kinks(u.float(), v, 1e-3 if dt == torch.float32 else 5e-2, max_frac=1e-4 if dt == torch.float32 else 2e-3)
+    if not inst_b:
+        assert torch.allclose(nb.running_mean, nb_ref.running_mean, atol=1e-5)
+        assert torch.allclose(nb.running_var, nb_ref.running_var, atol=1e-4)
