@@ -156,8 +156,14 @@ __global__ __launch_bounds__(256) void bwd_finish_kernel(const float *__restrict
         const float ga = gamma ? gamma[ch] : 1.0f;
         dsums[((size_t)g * c + ch) * 2] = sa * ga;
         dsums[((size_t)g * c + ch) * 2 + 1] = sb * ga;
-        if (dgamma) atomicAdd(dgamma + ch, sb);
-        if (dbeta) atomicAdd(dbeta + ch, sa);
+        // one group (BatchNorm2d, the only norm here with affine parameters): this thread is the channel's only writer
+        if (gridDim.y == 1) {
+            if (dgamma) dgamma[ch] = sb;
+            if (dbeta) dbeta[ch] = sa;
+        } else {
+            if (dgamma) atomicAdd(dgamma + ch, sb);
+            if (dbeta) atomicAdd(dbeta + ch, sa);
+        }
     }
 }
 
@@ -544,8 +550,10 @@ static int norm_act_bwd_reduce_any(const void *x_cl, const void *dy_cl, int grou
     if (bf16) EPN_LAUNCH(norm_act_bwd_reduce_kernel<__bf16>, grid, dim3(GT), 0, st, A);
     else EPN_LAUNCH(norm_act_bwd_reduce_kernel<float>, grid, dim3(GT), 0, st, A);
     EPN_CHECK_LAUNCH();
-    if (dgamma) EPN_HIP(hipMemsetAsync(dgamma, 0, sizeof(float) * c, st));
-    if (dbeta) EPN_HIP(hipMemsetAsync(dbeta, 0, sizeof(float) * c, st));
+    if (groups > 1) {                        // several groups accumulate with atomics; one group stores
+        if (dgamma) EPN_HIP(hipMemsetAsync(dgamma, 0, sizeof(float) * c, st));
+        if (dbeta) EPN_HIP(hipMemsetAsync(dbeta, 0, sizeof(float) * c, st));
+    }
     EPN_LAUNCH_AUX(bwd_finish_kernel, dim3(epn_cdiv(c, 16), groups), dim3(256), 0, st, A.out_sums, (int)grid.x, c, gamma,
                        dsums, dgamma, dbeta);
     EPN_CHECK_LAUNCH();
@@ -612,9 +620,13 @@ static int norm_act2_bwd_reduce_any(const void *xa, const void *xb, const void *
     if (!dsums_a || !dsums_b) return EPN_ENULL;
     hipStream_t st = epn_stream(stream);
     float *dg[2] = {dgamma_a, dgamma_b}, *db[2] = {dbeta_a, dbeta_b};
-    for (int i = 0; i < 2; ++i) {
-        if (dg[i]) EPN_HIP(hipMemsetAsync(dg[i], 0, sizeof(float) * c, st));
-        if (db[i]) EPN_HIP(hipMemsetAsync(db[i], 0, sizeof(float) * c, st));
+    {
+        const epn_norm_pair_side *sd[2] = {sa, sb};
+        for (int i = 0; i < 2; ++i) {
+            if (!(sd[i]->instance && b > 1) && b > 0 && rows > 0) continue;     // one group: the finishing kernel stores
+            if (dg[i]) EPN_HIP(hipMemsetAsync(dg[i], 0, sizeof(float) * c, st));
+            if (db[i]) EPN_HIP(hipMemsetAsync(db[i], 0, sizeof(float) * c, st));
+        }
     }
     if (b == 0 || rows == 0) return 0;
     if (!xa || !xb || !dy || !sa->sums || !sb->sums) return EPN_ENULL;

@@ -87,14 +87,16 @@ __global__ __launch_bounds__(64 * SB_WAVES) void so3_basis_kernel(SbArgs A) {
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int x = lane & 15, j = lane >> 4;
-    const int ncb = A.c >> 6;
+    const int ncb = (A.c + 63) >> 6;      // c % 32 == 0: the last block of a 32 (mod 64) width is half empty (lanes x >= 8)
     const int nst = A.na >> 2;        // contraction steps of 4 rows (na % 4 == 0, launcher)
     for (int it = 0; it < SB_TPW; ++it) {
         const long long task = ((long long)blockIdx.x * SB_WAVES + wave) * SB_TPW + it;
         if (task >= A.pts * ncb) return;
         const long long pt = task / ncb;
         const int cb = (int)(task - pt * ncb);
-        const int choff = 64 * cb + 4 * x;
+        const int choff0 = 64 * cb + 4 * x;
+        const bool cval = choff0 < A.c;        // this lane's 4 channels exist
+        const int choff = cval ? choff0 : 0;
 
         auto row_addr = [&](int spec, int r) -> size_t {   // float offset of row r of this point
             if (spec) return ((size_t)bs[r] * A.pts + (size_t)pt * d2s[r] + (r - bs[r])) * A.c + choff;
@@ -109,7 +111,7 @@ __global__ __launch_bounds__(64 * SB_WAVES) void so3_basis_kernel(SbArgs A) {
         f32x4 bv[16];
 #pragma unroll
         for (int st = 0; st < 16; ++st)
-            if (st < nst) bv[st] = sb_ld(static_cast<const T *>(A.in) + row_addr(A.in_spec, 4 * st + j));
+            if (st < nst) bv[st] = cval ? sb_ld(static_cast<const T *>(A.in) + row_addr(A.in_spec, 4 * st + j)) : f32x4{0.f, 0.f, 0.f, 0.f};
         if (A.nsums) {
             SbNorm N;
             sb_norm_load(A, pt, choff, N);
@@ -141,7 +143,7 @@ __global__ __launch_bounds__(64 * SB_WAVES) void so3_basis_kernel(SbArgs A) {
 #pragma unroll
             for (int rr = 0; rr < 4; ++rr) {
                 const int r = 16 * mt + 4 * j + rr;
-                if (r < A.na) {
+                if (r < A.na && cval) {
                     const f32x4 v = {acc[mt][0][rr], acc[mt][1][rr], acc[mt][2][rr], acc[mt][3][rr]};
                     sb_st(static_cast<T *>(A.out) + row_addr(A.out_spec, r), v);
                 }
@@ -179,7 +181,7 @@ __global__ __launch_bounds__(64 * SB_WAVES) void so3_basis_bf16_kernel(SbArgs A)
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int x = lane & 15, j = lane >> 4;
-    const int ncb = A.c >> 6;
+    const int ncb = (A.c + 63) >> 6;      // c % 32 == 0: the last block of a 32 (mod 64) width is half empty (lanes x >= 8)
     const __bf16 *in = static_cast<const __bf16 *>(A.in);
     __bf16 *out = static_cast<__bf16 *>(A.out);
     for (int it = 0; it < SB_TPW; ++it) {
@@ -187,7 +189,9 @@ __global__ __launch_bounds__(64 * SB_WAVES) void so3_basis_bf16_kernel(SbArgs A)
         if (task >= A.pts * ncb) return;
         const long long pt = task / ncb;
         const int cb = (int)(task - pt * ncb);
-        const int choff = 64 * cb + 4 * x;
+        const int choff0 = 64 * cb + 4 * x;
+        const bool cval = choff0 < A.c;        // this lane's 4 channels exist
+        const int choff = cval ? choff0 : 0;
         auto row_addr = [&](int spec, int r) -> size_t {
             if (spec) return ((size_t)bs[r] * A.pts + (size_t)pt * d2s[r] + (r - bs[r])) * A.c + choff;
             return ((size_t)pt * A.na + r) * A.c + choff;
@@ -198,7 +202,7 @@ __global__ __launch_bounds__(64 * SB_WAVES) void so3_basis_bf16_kernel(SbArgs A)
 #pragma unroll
             for (int e = 0; e < 8; ++e) {
                 const int r = 32 * ks + 8 * j + e;
-                raw[ks][e] = r < A.na ? *reinterpret_cast<const sbu32x2 *>(in + row_addr(A.in_spec, r)) : sbu32x2{0u, 0u};
+                raw[ks][e] = (r < A.na && cval) ? *reinterpret_cast<const sbu32x2 *>(in + row_addr(A.in_spec, r)) : sbu32x2{0u, 0u};
             }
         if (A.nsums) {
             SbNorm N;
@@ -252,7 +256,7 @@ __global__ __launch_bounds__(64 * SB_WAVES) void so3_basis_bf16_kernel(SbArgs A)
 #pragma unroll
             for (int rr = 0; rr < 4; ++rr) {
                 const int r = 16 * mt + 4 * j + rr;
-                if (r < A.na) {
+                if (r < A.na && cval) {
                     const f32x4 v = {acc[mt][0][rr], acc[mt][1][rr], acc[mt][2][rr], acc[mt][3][rr]};
                     sb_st(out + row_addr(A.out_spec, r), v);
                 }
@@ -307,7 +311,7 @@ __global__ __launch_bounds__(64 * SB_WAVES) __attribute__((amdgpu_waves_per_eu(2
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int x = lane & 15, j = lane >> 4;
-    const int ncb = A.c >> 6;
+    const int ncb = (A.c + 63) >> 6;      // c % 32 == 0: the last block of a 32 (mod 64) width is half empty (lanes x >= 8)
     const float *in = static_cast<const float *>(A.in);
     float *out = static_cast<float *>(A.out);
     for (int it = 0; it < SB_TPW; ++it) {
@@ -315,7 +319,9 @@ __global__ __launch_bounds__(64 * SB_WAVES) __attribute__((amdgpu_waves_per_eu(2
         if (task >= A.pts * ncb) return;
         const long long pt = task / ncb;
         const int cb = (int)(task - pt * ncb);
-        const int choff = 64 * cb + 4 * x;
+        const int choff0 = 64 * cb + 4 * x;
+        const bool cval = choff0 < A.c;        // this lane's 4 channels exist
+        const int choff = cval ? choff0 : 0;
         auto row_addr = [&](int spec, int r) -> size_t {
             if (spec) return ((size_t)bs[r] * A.pts + (size_t)pt * d2s[r] + (r - bs[r])) * A.c + choff;
             return ((size_t)pt * A.na + r) * A.c + choff;
@@ -326,7 +332,7 @@ __global__ __launch_bounds__(64 * SB_WAVES) __attribute__((amdgpu_waves_per_eu(2
 #pragma unroll
             for (int e = 0; e < 8; ++e) {
                 const int r = 32 * ks + 8 * j + e;
-                raw[ks][e] = r < A.na ? sb_ld(in + row_addr(A.in_spec, r)) : f32x4{0.f, 0.f, 0.f, 0.f};
+                raw[ks][e] = (r < A.na && cval) ? sb_ld(in + row_addr(A.in_spec, r)) : f32x4{0.f, 0.f, 0.f, 0.f};
             }
         if (A.nsums) {
             SbNorm N;
@@ -378,7 +384,7 @@ __global__ __launch_bounds__(64 * SB_WAVES) __attribute__((amdgpu_waves_per_eu(2
 #pragma unroll
             for (int rr = 0; rr < 4; ++rr) {
                 const int r = 16 * mt + 4 * j + rr;
-                if (r < A.na) {
+                if (r < A.na && cval) {
                     const f32x4 v = {acc[mt][0][rr], acc[mt][1][rr], acc[mt][2][rr], acc[mt][3][rr]};
                     sb_st(out + row_addr(A.out_spec, r), v);
                 }
@@ -401,7 +407,7 @@ struct SbNormHost {
 static int so3_basis_any(const void *in, const float *M, const int32_t *blocks, long long pts, int na, int c,
                         int in_spectral, int out_spectral, void *out, int bf16, epn_stream_t stream,
                         const SbNormHost *nh = nullptr) {
-    if (pts < 0 || na < 4 || na > 64 || (na & 3) || c < 64 || (c & 63)) return EPN_EINVAL;
+    if (pts < 0 || na < 4 || na > 64 || (na & 3) || c < 32 || (c & 31)) return EPN_EINVAL;
     if (pts == 0) return 0;
     if (!in || !M || !blocks || !out) return EPN_ENULL;
     SbArgs A;
@@ -417,7 +423,7 @@ static int so3_basis_any(const void *in, const float *M, const int32_t *blocks, 
         A.ngroups = nh->groups; A.npts_per_group = nh->groups > 1 ? nh->pts_per_group : pts;
         A.ninv_rows = 1.0f / ((float)A.npts_per_group * (float)na);
     }
-    const long long tasks = pts * (c >> 6);
+    const long long tasks = pts * ((c + 63) >> 6);
     const long long per_wg = (long long)SB_WAVES * SB_TPW;
     const dim3 grid((unsigned)((tasks + per_wg - 1) / per_wg));
     if (bf16 == 1) EPN_LAUNCH(so3_basis_bf16_kernel, grid, dim3(64 * SB_WAVES), 0, epn_stream(stream), A);

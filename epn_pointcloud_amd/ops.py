@@ -1182,7 +1182,7 @@ def _device_bytes(device):
 
 def intra_mode():
     """EPN_INTRA_MODE = fused | split | spectral | auto (default).  auto: the block-diagonal ("spectral") form when both
-    widths are multiples of 64 and the index table is a regular group action, else the split form (gather kernel +
+    widths are multiples of 32 and the index table is a regular group action, else the split form (gather kernel +
     library GEMMs) for multiples of 16, else the fused / generic kernels."""
     return os.environ.get("EPN_INTRA_MODE", "auto")
 
@@ -1194,7 +1194,7 @@ def intra_so3conv_fused(feats, W, intra_idx32):
 def intra_takes_spectral(cin, cout, intra_idx32, is_cuda=True):
     """Will intra_so3conv run the block-diagonal form for these widths / this table?  (Then a preceding norm + leaky_relu
     can be folded into its basis change: intra_so3conv(..., pre_norm=).)"""
-    return (intra_mode() in ("auto", "spectral") and is_cuda and cin % 64 == 0 and cout % 64 == 0
+    return (intra_mode() in ("auto", "spectral") and is_cuda and cin % 32 == 0 and cout % 32 == 0
             and intra_idx32.shape[1] > 1 and spectral_basis(intra_idx32) is not None)
 
 
@@ -1204,7 +1204,7 @@ def intra_so3conv(feats, W, intra_idx32, pre_norm=None):
     mode = intra_mode()
     cin, cout = feats.shape[1], W.shape[0]
     bf = feats.dtype == torch.bfloat16
-    if mode in ("auto", "spectral") and feats.is_cuda and cin % 64 == 0 and cout % 64 == 0 and intra_idx32.shape[1] > 1:
+    if mode in ("auto", "spectral") and feats.is_cuda and cin % 32 == 0 and cout % 32 == 0 and intra_idx32.shape[1] > 1:
         basis = spectral_basis(intra_idx32)
         if basis is not None:
             return intra_so3conv_spectral(feats, W, intra_idx32, basis, pre_norm=pre_norm)

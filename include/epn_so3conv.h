@@ -279,7 +279,7 @@ int epn_intra_group_f32(const float *feats_cl, const int32_t *intra_idx, float *
  * anchor permutations of L.intra_so3conv_grouping (vgtk/vgtk/so3conv/functional.py:255-268) are simultaneously
  * block-diagonalised by one orthogonal matrix U, so IntraSO3Conv.forward (modules.py:197-200) becomes: U^T, one GEMM per
  * irreducible block, U -- 2.95x fewer flops than the 12-neighbour contraction and no grouped tensor.
- *   out[pt][r][ch] = sum_s M[r][s] * in[pt][s][ch]      M f32[na][na] row-major, pts points, c channels (c % 64 == 0)
+ *   out[pt][r][ch] = sum_s M[r][s] * in[pt][s][ch]      M f32[na][na] row-major, pts points, c channels (c % 32 == 0)
  * `*_spectral` = 0: plain channels-last rows ((pt*na + r)*c);  1: row f of a point lives in its block's buffer at
  * ((blocks[f][0]*pts + pt*blocks[f][1] + (f - blocks[f][0]))*c), blocks i32[na][2] = (first row of the block, d*d), so
  * each block is a dense row-major [pts*d][d*c] matrix.  Forward transform: M = U^T, out_spectral = 1; inverse: M = U,

@@ -237,8 +237,8 @@ def test_inter_bf16_vs_oracle(gpu, vgtk_alias, cin, cout, stride, K):
 
 @pytest.mark.parametrize("cin,cout,p", [(64, 64, 48), (128, 64, 16), (32, 32, 40), (32, 64, 24)])
 def test_intra_bf16_vs_oracle(gpu, vgtk_alias, cin, cout, p):
-    """64-multiples take the spectral form (bf16 basis change + bf16 block GEMMs), the 32-channel layers of the
-    rotation / 3DMatch schedules the split form."""
+    """32-multiples take the spectral form (bf16 basis change + bf16 block GEMMs; round 3: also the 32-channel layers of the
+    rotation / 3DMatch schedules, whose half-empty 64-channel block is masked in the basis-change kernels)."""
     sptk, zptk = _mods(vgtk_alias)
     torch.manual_seed(cin + p)
     conv = sptk.IntraSO3Conv(cin, cout)

@@ -146,7 +146,7 @@ def test_inter_vs_oracle(gpu, vgtk_alias, inter_mode, cin, cout, stride, K, lazy
 
 
 @pytest.mark.parametrize("cin,cout,p", [(8, 8, 40), (5, 3, 17), (16, 16, 64), (32, 64, 33), (64, 64, 128), (128, 128, 16),
-                                        (64, 192, 21)])
+                                        (64, 192, 21), (32, 32, 50), (96, 32, 19)])     # 32 (mod 64) widths: half-empty channel blocks of the basis change
 def test_intra_vs_oracle(gpu, vgtk_alias, intra_mode, cin, cout, p):
     sptk, zptk = _mods(vgtk_alias)
     torch.manual_seed(cin * 7 + p)

@@ -25,6 +25,6 @@ with profile(activities=[ProfilerActivity.CPU, ProfilerActivity.CUDA], record_sh
     step()
     torch.cuda.synchronize()
 rows = [e for e in prof.key_averages(group_by_input_shape=True) if e.key.startswith("aten::") and e.device_time_total > 0]
-rows.sort(key=lambda e: -e.count)
+rows.sort(key=lambda e: -e.device_time_total)
 for e in rows[:45]:
     print(f"{e.count:4d} x {e.device_time_total / max(e.count, 1):7.1f} us  {e.key:28s} {str(e.input_shapes)[:110]}")
