@@ -27,14 +27,17 @@ def _deps_mtime():
 
 
 TUNING = os.environ.get("EPN_TUNING", "0") == "1"      # tools/ builds: keep the A/B kernel policies (epn_set_kernel_policy 0x100..0x4ff)
+# A/B builds of the tools: EPN_BUILD_TAG=x EPN_EXTRA_FLAGS="-DFOO=1" -> libepn_so3conv_x.so (load with EPN_LIB=...)
+TAG = os.environ.get("EPN_BUILD_TAG", "")
+EXTRA = os.environ.get("EPN_EXTRA_FLAGS", "").split()
 
 
 def _compile(src, force):
-    obj = os.path.join(OBJ, os.path.basename(src)[:-4] + (".tuning.o" if TUNING else ".o"))
+    obj = os.path.join(OBJ, os.path.basename(src)[:-4] + (f".{TAG}" if TAG else "") + (".tuning.o" if TUNING else ".o"))
     if (not force and os.path.exists(obj) and os.path.getmtime(obj) >= os.path.getmtime(src)
             and os.path.getmtime(obj) >= _deps_mtime()):
         return obj, False
-    subprocess.check_call([HIPCC] + FLAGS + (["-DEPN_TUNING"] if TUNING else []) + ["-c", src, "-o", obj])
+    subprocess.check_call([HIPCC] + FLAGS + (["-DEPN_TUNING"] if TUNING else []) + EXTRA + ["-c", src, "-o", obj])
     return obj, True
 
 
@@ -44,7 +47,8 @@ def build(force=False, verbose=False, tuning=None):
     global TUNING, LIB
     if tuning is not None:
         TUNING = bool(tuning)
-    lib_path = os.path.join(PKG, "libepn_so3conv_tuning.so") if TUNING else LIB
+    lib_path = os.path.join(PKG, "libepn_so3conv_tuning.so") if TUNING else (
+        os.path.join(PKG, f"libepn_so3conv_{TAG}.so") if TAG else LIB)
     os.makedirs(OBJ, exist_ok=True)
     srcs = _sources()
     with concurrent.futures.ThreadPoolExecutor(max_workers=min(8, len(srcs))) as ex:
