@@ -31,6 +31,8 @@ EXPORTS = [
     "epn_chan_stats_bf16", "epn_norm_act_fwd_bf16", "epn_norm_act_bwd_reduce_bf16", "epn_norm_act_bwd_apply_bf16",
     "epn_last_kernel", "epn_scatter_rows_add", "epn_norm_pair_workspace_bytes", "epn_norm_act_pair_fwd",
     "epn_norm_act_pair_bwd_reduce", "epn_norm_act_pair_bwd_apply", "epn_inter_onchip_ok", "epn_inter_onchip_workspace_bytes", "epn_inter_so3conv_fwd_onchip_f32", "epn_inter_so3conv_fwd_bf16",
+    "epn_inter_group_packed_ok", "epn_inter_packed_position", "epn_inter_group_packed_f32", "epn_inter_group_packed_bf16",
+    "epn_inter_pack_weights_f32", "epn_inter_pack_weights_bf16", "epn_inter_unpack_weight_grad_f32",
 ]
 
 _vp, _ci, _cf, _sz = ctypes.c_void_p, ctypes.c_int, ctypes.c_float, ctypes.c_size_t
@@ -106,6 +108,14 @@ def get_lib():
     lib.epn_inter_group_workspace_bytes.restype = _sz
     lib.epn_inter_group_f32.argtypes = [dp, _vp, _vp, _vp, _sz, _vp]
     lib.epn_inter_ungroup_f32.argtypes = [dp, _vp, _vp, _vp, _sz, _vp]
+    lib.epn_inter_group_packed_ok.argtypes = [dp]
+    lib.epn_inter_group_packed_ok.restype = _ci
+    lib.epn_inter_packed_position.argtypes = [_ci, _ci, _vp]
+    lib.epn_inter_group_packed_f32.argtypes = [dp, _vp, _vp, _vp, _sz, _vp]
+    lib.epn_inter_group_packed_bf16.argtypes = [dp, _vp, _vp, _vp, _sz, _vp]
+    lib.epn_inter_pack_weights_f32.argtypes = [_vp, _ci, _ci, _ci, _vp, _vp]
+    lib.epn_inter_pack_weights_bf16.argtypes = [_vp, _ci, _ci, _ci, _vp, _vp]
+    lib.epn_inter_unpack_weight_grad_f32.argtypes = [_vp, _ci, _ci, _ci, _vp, _vp]
     lib.epn_intra_group_f32.argtypes = [_vp, _vp, _vp, _ci, _ci, _ci, _ci, _ci, _vp]
     for _n in ("epn_zp_inter_fwd_f32", "epn_zp_inter_bwd_f32", "epn_zp_intra_fwd_f32", "epn_zp_intra_bwd_f32"):
         getattr(lib, _n).argtypes = [_vp, _vp, _vp, _ci, _ci, _ci, _ci, _ci, _ci, _ci, _vp, _vp]
@@ -192,7 +202,7 @@ def get_lib():
 
 # Host-only entry points (no stream argument, nothing launched): handed out unwrapped.
 _HOST_ONLY = {"epn_version", "epn_strerror", "epn_set_kernel_policy", "epn_last_kernel", "epn_inter_is_fused",
-              "epn_intra_is_fused", "epn_inter_onchip_ok"}
+              "epn_intra_is_fused", "epn_inter_onchip_ok", "epn_inter_group_packed_ok", "epn_inter_packed_position"}
 CALL_HOOK = None      # ops.profile_begin(): callable(name, fn, args) -> rc, brackets every launching call with HIP events
 
 

@@ -276,7 +276,7 @@ extern "C" int epn_inter_so3conv_fwd_bf16(const epn_inter_desc *d, const void *f
 }
 
 static int inter_group_any(const epn_inter_desc *d, const void *feats_cl, void *grouped, void *workspace,
-                           size_t workspace_bytes, int bf16, epn_stream_t stream) {
+                           size_t workspace_bytes, int bf16, epn_stream_t stream, int packed = 0) {
     hipStream_t st = epn_stream(stream);
     InterWs ws;
     float *base = nullptr;
@@ -287,9 +287,9 @@ static int inter_group_any(const epn_inter_desc *d, const void *feats_cl, void *
     if (inter_group_mfma_ok(d) && !force_generic()) {
         rc = launch_inter_tables_mfma(d, base + ws.rk_off, base + ws.rk4_off, base + ws.beta_off, st);
         if (rc) return rc;
-        return launch_inter_group_mfma(d, base + ws.rk4_off, feats_cl, grouped, bf16, st);
+        return launch_inter_group_mfma(d, base + ws.rk4_off, feats_cl, grouped, bf16, st, packed);
     }
-    if (bf16) return EPN_EINVAL;   // the bf16 feature path needs cin % 16 == 0 (every layer but the first, which is c1)
+    if (bf16 || packed) return EPN_EINVAL;   // the bf16 feature path needs cin % 16 == 0 (every layer but the first, which is c1)
     return launch_inter_group(d, base + ws.rk_off, static_cast<const float *>(feats_cl), static_cast<float *>(grouped), st);
 }
 
@@ -322,6 +322,47 @@ extern "C" int epn_inter_group_bf16(const epn_inter_desc *d, const void *feats_c
                                     size_t workspace_bytes, epn_stream_t stream) {
     return inter_group_any(d, feats_cl, grouped, workspace, workspace_bytes, 1, stream);
 }
+// ---- packed column order of the grouped features (contiguous stores in the grouping kernel); W's columns follow
+extern "C" int epn_inter_group_packed_ok(const epn_inter_desc *d) {
+    return d && !check_desc(d) && inter_group_packed_ok(d) && !force_generic() ? 1 : 0;
+}
+extern "C" int epn_inter_packed_position(int cin, int ks, int32_t *position) {
+    if (cin < 32 || cin % 32 || ks < 4 || ks > EPN_KS_MAX || ks % 4) return EPN_EINVAL;
+    if (!position) return EPN_ENULL;
+    for (int c = 0; c < cin; ++c)
+        for (int k = 0; k < ks; ++k) position[c * ks + k] = inter_packed_position(c, k, cin, ks);
+    return 0;
+}
+extern "C" int epn_inter_group_packed_f32(const epn_inter_desc *d, const float *feats_cl, float *grouped, void *workspace,
+                                          size_t workspace_bytes, epn_stream_t stream) {
+    if (!epn_inter_group_packed_ok(d)) return EPN_EINVAL;
+    return inter_group_any(d, feats_cl, grouped, workspace, workspace_bytes, 0, stream, 1);
+}
+extern "C" int epn_inter_group_packed_bf16(const epn_inter_desc *d, const void *feats_cl, void *grouped, void *workspace,
+                                           size_t workspace_bytes, epn_stream_t stream) {
+    if (!epn_inter_group_packed_ok(d)) return EPN_EINVAL;
+    return inter_group_any(d, feats_cl, grouped, workspace, workspace_bytes, 1, stream, 1);
+}
+static int pack_args_ok(int cout, int cin, int ks) {
+    return cout >= 0 && cin >= 32 && cin % 32 == 0 && ks >= 4 && ks <= EPN_KS_MAX && ks % 4 == 0;
+}
+extern "C" int epn_inter_pack_weights_f32(const float *W, int cout, int cin, int ks, float *packed, epn_stream_t stream) {
+    if (!pack_args_ok(cout, cin, ks)) return EPN_EINVAL;
+    if (cout && (!W || !packed)) return EPN_ENULL;
+    return launch_inter_pack_weights(W, cout, cin, ks, packed, 0, epn_stream(stream));
+}
+extern "C" int epn_inter_pack_weights_bf16(const float *W, int cout, int cin, int ks, void *packed, epn_stream_t stream) {
+    if (!pack_args_ok(cout, cin, ks)) return EPN_EINVAL;
+    if (cout && (!W || !packed)) return EPN_ENULL;
+    return launch_inter_pack_weights(W, cout, cin, ks, packed, 1, epn_stream(stream));
+}
+extern "C" int epn_inter_unpack_weight_grad_f32(const float *grad_packed, int cout, int cin, int ks, float *grad_W,
+                                                epn_stream_t stream) {
+    if (!pack_args_ok(cout, cin, ks)) return EPN_EINVAL;
+    if (cout && (!grad_packed || !grad_W)) return EPN_ENULL;
+    return launch_inter_unpack_weight_grad(grad_packed, cout, cin, ks, grad_W, epn_stream(stream));
+}
+
 extern "C" int epn_inter_ungroup_f32(const epn_inter_desc *d, const float *grad_grouped, float *grad_feats_cl,
                                      void *workspace, size_t workspace_bytes, epn_stream_t stream) {
     return inter_ungroup_any(d, grad_grouped, grad_feats_cl, workspace, workspace_bytes, 0, stream);

@@ -69,8 +69,32 @@ static inline bool inter_group_mfma_ok(const epn_inter_desc *d) {
            d->nn <= EPN_NN_MAX && (long long)d->p1 * d->na * d->cin < (1LL << 31);
 }
 // bf16 != 0: feats / G (group) and dG (ungroup) are bf16; the scatter target dF is fp32 either way
+// Packed column order of the grouped features (epn_inter_group_packed_*).  The plain order G[col][c*ks + k] makes a wave's
+// store instruction -- 16 lanes of one kernel-point quad = 16 channels -- 16 separate 64-byte (k < 16) or 32-byte pieces,
+// ks*4 bytes apart (4*ks*4 in the wide kernel, whose lanes own every CG-th channel).  Packed: all k < 16 columns first, in
+// the order the wide kernel's lanes hold the channels (group g of 16 CG channels, then the lane's channel e, then lane x),
+// then the k >= 16 columns the same way: every store instruction covers ONE contiguous 1 KiB / 512 B range of the row.
+// The weight contraction permutes W's columns instead (epn_inter_pack_weights_*): a GEMM does not care.
+__host__ __device__ inline int inter_packed_cg(int cin) { return cin % 64 == 0 ? 4 : 2; }
+__host__ __device__ inline int inter_packed_slot(int c, int cg) {
+    const int gw = 16 * cg, cl = c % gw;
+    return c - cl + 16 * (cl % cg) + cl / cg;
+}
+__host__ __device__ inline int inter_packed_position(int c, int k, int cin, int ks) {
+    const int slot = inter_packed_slot(c, inter_packed_cg(cin));
+    const int w0 = ks < 16 ? ks : 16;
+    return k < 16 ? slot * w0 + k : w0 * cin + slot * (ks - 16) + (k - 16);
+}
+// packed != 0: G in the packed column order (needs inter_group_packed_ok)
+static inline bool inter_group_packed_ok(const epn_inter_desc *d) {
+    return inter_group_mfma_ok(d) && d->na >= 16 && d->cin % 32 == 0 && d->nn <= 64;
+}
 int launch_inter_group_mfma(const epn_inter_desc *d, const float *rk4, const void *feats, void *G, int bf16,
-                            hipStream_t st);
+                            hipStream_t st, int packed = 0);
+// W[cout][cin*ks] (fp32) -> the same matrix with its columns in the packed order (fp32 or bf16), and the inverse for a
+// weight gradient computed against packed grouped features
+int launch_inter_pack_weights(const float *W, int cout, int cin, int ks, void *Wp, int bf16, hipStream_t st);
+int launch_inter_unpack_weight_grad(const float *gWp, int cout, int cin, int ks, float *gW, hipStream_t st);
 // order: b*p2 int32 of scratch for the Morton order of the output points (nullptr: per-slot atomic scatter)
 int launch_inter_ungroup_mfma(const epn_inter_desc *d, const float *rk4, const void *dG, float *dF, int32_t *order,
                               int bf16, hipStream_t st);

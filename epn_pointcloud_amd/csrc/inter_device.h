@@ -24,7 +24,9 @@ struct InterArgs {
     int b, p1, p2, nn, na, ks, cin, cout, wk;
     long long ncol;
     int col_tiles_per_wg;  // bwd_weight only
+    int packed;            // grouping: write G in the packed column order (inter_packed_position)
 };
+
 
 // max(x, 0) as ONE instruction: the integer maximum of the bit patterns (negative floats are negative integers).
 // fmaxf(x, 0.0f) compiles to two v_max_f32 (IEEE canonicalisation of the operand first); the weight generation does

@@ -841,7 +841,15 @@ __global__ __launch_bounds__(64 * NW) void inter_group_wide_kernel(InterArgs A) 
             gather(i + 1 < sg.cnt ? a + 1 : a, fnext);          // last column re-reads its own rows (cache hit, unused)
             f32x4 w[KT][NT];
             make_weights<NT, KT>(A, a, x, j, sg.h, w);           // once per column, for all CG chunks
+            // element steps of the store address: chunk e -> e + 1 (k < 16 block, k >= 16 block), k < 16 -> k >= 16
             TF *grow = G + (size_t)(sg.jc0 + i) * gss + (size_t)coff * A.ks + 4 * j;
+            int es0 = A.ks, es1 = A.ks, kstep = 16;
+            if (A.packed) {
+                const int s0 = (int)blockIdx.y * 16 * CG + x, w0 = A.ks < 16 ? A.ks : 16;   // slot of the lane's channel e = 0
+                grow = G + (size_t)(sg.jc0 + i) * gss + s0 * w0 + 4 * j;
+                es0 = 16 * w0; es1 = 16 * (A.ks - 16);
+                kstep = w0 * A.cin + s0 * (A.ks - 16) - s0 * w0;
+            }
 #pragma unroll
             for (int e = 0; e < CG; ++e) {
                 if constexpr (BF) {
@@ -868,7 +876,7 @@ __global__ __launch_bounds__(64 * NW) void inter_group_wide_kernel(InterArgs A) 
 #pragma unroll
                             for (int t = 0; t < NT; ++t) g = mfma_bf16_k16(pack4(w[kt][t]), fb4[t], g);
                         }
-                        if (16 * kt + 4 * j < A.ks) st4f(grow + e * A.ks + 16 * kt, g);
+                        if (16 * kt + 4 * j < A.ks) st4f(grow + e * (kt ? es1 : es0) + kt * kstep, g);
                     }
                 } else {
 #pragma unroll
@@ -879,7 +887,7 @@ __global__ __launch_bounds__(64 * NW) void inter_group_wide_kernel(InterArgs A) 
 #pragma unroll
                             for (int r = 0; r < 4; ++r)
                                 g = mfma4(w[kt][t][r], sg.h.ok[t][r] ? __uint_as_float(fcur[t][r][e]) : 0.0f, g);
-                        if (16 * kt + 4 * j < A.ks) st4f(grow + e * A.ks + 16 * kt, g);
+                        if (16 * kt + 4 * j < A.ks) st4f(grow + e * (kt ? es1 : es0) + kt * kstep, g);
                     }
                 }
             }
@@ -1435,7 +1443,7 @@ InterArgs make_args(const epn_inter_desc *d, const float *rk4) {
     A.feats = nullptr; A.W = nullptr; A.gout = nullptr; A.out = nullptr;
     A.sigma_inv = 1.0f / d->sigma;
     A.b = d->b; A.p1 = d->p1; A.p2 = d->p2; A.nn = d->nn; A.na = d->na; A.ks = d->ks; A.cin = d->cin;
-    A.cout = d->cout; A.wk = 0;
+    A.cout = d->cout; A.wk = 0; A.packed = 0;
     A.ncol = (long long)d->b * d->p2 * d->na;
     A.col_tiles_per_wg = 1;
     return A;
@@ -1642,14 +1650,18 @@ int launch_inter_bwd_weight_mfma(const epn_inter_desc *d, const float *rk4, cons
 static int chunks_per_row(int bf16 = 0) { return bf16 ? 4 : 2; }
 
 int launch_inter_group_mfma(const epn_inter_desc *d, const float *rk4, const void *feats, void *G, int bf16,
-                            hipStream_t st) {
+                            hipStream_t st, int packed) {
     InterArgs A = make_args(d, rk4);
     A.feats = static_cast<const float *>(feats); A.out = static_cast<float *>(G);
     const unsigned grid = (unsigned)((A.ncol + 16 * NW - 1) / (16 * NW));
     // wide-gather form (a lane owns 4 or 2 consecutive channels).  Measured per layer, B=32/64 schedules: bf16 0.85-0.89 vs
     // 1.35 ms (K = 64), 1.18 vs 1.49 ms (K = 32) -- the bf16 kernel is bound by its gather instructions; fp32 1.18-1.28 vs
-    // 1.32 ms at K = 32 but 2.05-2.44 vs 1.97 ms at K = 16, where the stores of G bound the kernel either way
-    if (d->na >= 16 && d->cin % 32 == 0 && d->nn <= 64 && (bf16 || d->nn > 16)) {
+    // 1.32 ms at K = 32 but 2.05-2.44 vs 1.97 ms at K = 16 in the PLAIN column order, where its stores are 64-byte pieces
+    // 384 bytes apart.  Packed order (contiguous stores): 1.53-1.72 ms at K = 16, 1.04-1.09 at K = 32 (plain 1.21-1.34);
+    // bf16 1.00 / 0.78-0.81 ms (K = 32 / 64; plain 1.24-1.26 / 0.84-0.88) -- the wide kernel serves every packed call
+    A.packed = packed;
+    if (packed && !inter_group_packed_ok(d)) return EPN_EINVAL;
+    if (d->na >= 16 && d->cin % 32 == 0 && d->nn <= 64 && (bf16 || d->nn > 16 || packed)) {
         const int cg = d->cin % 64 == 0 ? 4 : 2;
         const unsigned gyw = (unsigned)(d->cin / (16 * cg));
 #define EPN_GRPW(NT_, KT_, dummy)                                                                                              \
@@ -1673,6 +1685,39 @@ int launch_inter_group_mfma(const epn_inter_desc *d, const float *rk4, const voi
     } while (0)
     EPN_DISPATCH_NT_KT(EPN_GRP, 0);
 #undef EPN_GRP
+    EPN_CHECK_LAUNCH();
+    return 0;
+}
+
+// Column permutation of the weights for packed grouped features.  One thread per element of the PLAIN matrix (coalesced on
+// the plain side; the packed side moves in runs of ks - 16 .. 16 elements -- the matrices are a few MB, read from L2).
+template <typename TO, bool UNPACK>
+__global__ __launch_bounds__(256) void inter_pack_cols_kernel(const float *__restrict__ src, TO *__restrict__ dst,
+                                                              int rows, int cin, int ks) {
+    const int ck = cin * ks;
+    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= (long long)rows * ck) return;
+    const int r = (int)(i / ck), q = (int)(i - (long long)r * ck);
+    const int c = q / ks, k = q - c * ks;
+    const size_t pk = (size_t)r * ck + inter_packed_position(c, k, cin, ks);
+    if constexpr (UNPACK) dst[i] = (TO)src[pk];
+    else dst[pk] = (TO)src[i];
+}
+
+int launch_inter_pack_weights(const float *W, int cout, int cin, int ks, void *Wp, int bf16, hipStream_t st) {
+    const long long n = (long long)cout * cin * ks;
+    if (n == 0) return 0;
+    const unsigned grid = (unsigned)((n + 255) / 256);
+    if (bf16) EPN_LAUNCH((inter_pack_cols_kernel<__bf16, false>), dim3(grid), dim3(256), 0, st, W, static_cast<__bf16 *>(Wp), cout, cin, ks);
+    else EPN_LAUNCH((inter_pack_cols_kernel<float, false>), dim3(grid), dim3(256), 0, st, W, static_cast<float *>(Wp), cout, cin, ks);
+    EPN_CHECK_LAUNCH();
+    return 0;
+}
+
+int launch_inter_unpack_weight_grad(const float *gWp, int cout, int cin, int ks, float *gW, hipStream_t st) {
+    const long long n = (long long)cout * cin * ks;
+    if (n == 0) return 0;
+    EPN_LAUNCH((inter_pack_cols_kernel<float, true>), dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, gWp, gW, cout, cin, ks);
     EPN_CHECK_LAUNCH();
     return 0;
 }

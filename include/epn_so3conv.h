@@ -267,6 +267,31 @@ int epn_inter_group_f32(const epn_inter_desc *d, const float *feats_cl, float *g
 int epn_inter_ungroup_f32(const epn_inter_desc *d, const float *grad_grouped, float *grad_feats_cl, void *workspace,
                           size_t workspace_bytes, epn_stream_t stream);
 
+/* Packed column order of `grouped` (what the split convolution of this package uses between its own kernels).  In the
+ * element order c*ks + k above, one store instruction of the grouping kernel -- four kernel points of 16 channels -- is 16
+ * pieces of 64 (or 32) bytes, ks*4 bytes or more apart; the kernel is bound by those stores (6 GB per 64-channel layer at
+ * B=32).  In the packed order every store instruction covers one contiguous 1 KiB / 512 B range of the row: 8-20 % less
+ * kernel time.  A matrix product does not care about the order of its contraction index as long as both operands agree, so
+ * the WEIGHTS are permuted instead (a few MB): same result as the plain order bit for bit up to summation order.
+ *   epn_inter_packed_position(cin, ks, position[cin*ks]) : host table, position[c*ks + k] = column of element (c, k):
+ *       CG = 4 if cin % 64 == 0 else 2;  slot(c) = c - c % (16 CG) + 16 (c % CG) + (c % (16 CG)) / CG;
+ *       k < 16:  slot * min(ks, 16) + k;   k >= 16:  min(ks, 16) * cin + slot * (ks - 16) + (k - 16)
+ *   epn_inter_group_packed_{f32,bf16} : as epn_inter_group_*, columns in packed order; shapes: epn_inter_group_packed_ok
+ *       (the MFMA grouping kernel's shapes with na >= 16, cin % 32 == 0, nn <= 64), EPN_EINVAL otherwise
+ *   epn_inter_pack_weights_{f32,bf16} : packed[o][position[q]] = W[o][q]   (fp32 master weights -> fp32 / bf16 operand)
+ *   epn_inter_unpack_weight_grad_f32  : grad_W[o][q] = grad_packed[o][position[q]]   (gradient computed against packed G)
+ * The gradient of `grouped` stays in the plain order (epn_inter_ungroup_*: its reads are not what bounds that kernel). */
+int epn_inter_group_packed_ok(const epn_inter_desc *d);
+int epn_inter_packed_position(int cin, int ks, int32_t *position);
+int epn_inter_group_packed_f32(const epn_inter_desc *d, const float *feats_cl, float *grouped, void *workspace,
+                               size_t workspace_bytes, epn_stream_t stream);
+int epn_inter_group_packed_bf16(const epn_inter_desc *d, const void *feats_cl, void *grouped, void *workspace,
+                                size_t workspace_bytes, epn_stream_t stream);
+int epn_inter_pack_weights_f32(const float *W, int cout, int cin, int ks, float *packed, epn_stream_t stream);
+int epn_inter_pack_weights_bf16(const float *W, int cout, int cin, int ks, void *packed, epn_stream_t stream);
+int epn_inter_unpack_weight_grad_f32(const float *grad_packed, int cout, int cin, int ks, float *grad_W,
+                                     epn_stream_t stream);
+
 /* IntraSO3Conv grouping as a tensor: replaces L.intra_so3conv_grouping (vgtk/vgtk/so3conv/functional.py:255-268,
  * feats[..., intra_idx]); IntraSO3Conv's BasicSO3Conv matmul (modules.py:197-200) then runs on the caller's BLAS.
  *   grouped f32[b*p*na][kn*c]   element k*c + ci = feats_cl[b][p][intra_idx[a][k]][ci]   (anchor-neighbour major, so

@@ -44,6 +44,30 @@ def test_workspace_query_is_host_only():
     assert n >= 2 * 128 * 60 * 1 * 24 * 4           # generic path: grouped features are materialised
 
 
+def test_packed_position_table_is_the_documented_permutation():
+    """epn_inter_packed_position (host-only) against the formula in include/epn_so3conv.h, for both channel-group widths
+    and a ragged second kernel-point tile; refusals for widths the packed grouping does not serve."""
+    import numpy as np
+    from epn_pointcloud_amd import _lib
+    lib = _lib.get_lib()
+    for cin, ks in ((32, 24), (64, 24), (96, 24), (256, 24), (64, 16), (64, 12), (128, 20)):
+        pos = np.full(cin * ks, -1, dtype=np.int32)
+        assert lib.epn_inter_packed_position(cin, ks, pos.ctypes.data) == 0
+        cg = 4 if cin % 64 == 0 else 2
+        w0 = min(ks, 16)
+        for c in range(cin):
+            cl = c % (16 * cg)
+            slot = c - cl + 16 * (cl % cg) + cl // cg
+            for k in range(ks):
+                want = slot * w0 + k if k < 16 else w0 * cin + slot * (ks - 16) + (k - 16)
+                assert pos[c * ks + k] == want
+        assert sorted(pos.tolist()) == list(range(cin * ks))
+    buf = np.zeros(16 * 24, dtype=np.int32)
+    assert lib.epn_inter_packed_position(16, 24, buf.ctypes.data) != 0      # cin % 32
+    assert lib.epn_inter_packed_position(64, 22, buf.ctypes.data) != 0      # ks % 4
+    assert lib.epn_inter_packed_position(64, 24, None) != 0
+
+
 def test_missing_library_fails_loudly(monkeypatch):
     from epn_pointcloud_amd import _lib
     monkeypatch.setattr(_lib, "_lib", None)

@@ -439,6 +439,81 @@ def test_group_ungroup_abi_vs_oracle(gpu, vgtk_alias, cin, K, na_sel, stride, n)
     assert (dF.cpu() - o_dF).abs().max().item() < TOL
 
 
+@pytest.mark.parametrize("cin,K,ks,dt", [(32, 16, 24, "f32"), (64, 16, 24, "f32"), (64, 32, 24, "f32"), (128, 24, 24, "f32"),
+                                         (96, 16, 24, "f32"), (64, 16, 16, "f32"), (32, 32, 12, "f32"), (64, 64, 24, "bf16"),
+                                         (32, 32, 24, "bf16"), (128, 16, 20, "bf16")])
+def test_packed_grouping_is_the_plain_grouping_permuted(gpu, vgtk_alias, cin, K, ks, dt):
+    """epn_inter_group_packed_* writes the grouped features of epn_inter_group_* with the columns in the order of
+    epn_inter_packed_position: bit for bit the same numbers (the plain kernel is the one checked against the oracle above),
+    for both lane -> channel maps of the wide kernel (cin % 64 == 0 / cin % 32 == 0), one and two kernel-point tiles, and a
+    ragged second tile (ks = 20).  epn_inter_pack_weights_* / epn_inter_unpack_weight_grad_f32 apply the same table."""
+    import ctypes
+    from epn_pointcloud_amd import ops, _lib
+    from epn_pointcloud_amd.vgtk import pc as pctk
+    from epn_pointcloud_amd.vgtk.so3conv import functional as L
+    from epn_pointcloud_amd.vgtk import functional as fr
+    rng = np.random.default_rng(cin + K + ks)
+    torch.manual_seed(cin + K + ks)
+    lib = _lib.get_lib()
+    dtype = torch.bfloat16 if dt == "bf16" else torch.float32
+    b, n, radius, sigma = 2, 96, 0.45, 0.09
+    xyz = T(unit_ball_cloud(rng, b, n)).to(gpu)
+    anchors = T(L.get_anchors(60)).to(gpu)
+    kernels = R.scaled_kernel_points(T(fr.kernel_points_raw(24)), radius)[:ks].contiguous().to(gpu)
+    _, new_xyz = pctk.furthest_sample(xyz, n // 2, False)
+    idx = pctk.ball_query_index(new_xyz, xyz, radius, K)
+    geo = ops.InterGeometry(xyz, new_xyz, idx, anchors, kernels, sigma)
+    f = ops.to_cl(torch.randn(b, cin, n, 60, device=gpu).to(dtype))
+    d = geo.desc(cin, 16)
+    assert lib.epn_inter_group_packed_ok(ctypes.byref(d)) == 1
+    pos = np.empty(cin * ks, dtype=np.int32)
+    assert lib.epn_inter_packed_position(cin, ks, pos.ctypes.data) == 0
+    assert sorted(pos.tolist()) == list(range(cin * ks))
+    G = ops.inter_group(f, geo)
+    Gp = torch.full_like(G, float("nan"))
+    ws, wsp, wsn = ops._group_workspace(lib, d, gpu)
+    _lib.check(ops._entry(lib, "inter_group_packed", dtype)(ctypes.byref(d), ops._cl_ptr(f), Gp.data_ptr(), wsp, wsn,
+                                                            _lib.stream_of(f)), "inter_group_packed")
+    assert "inter_group_wide_kernel" in lib.epn_last_kernel().decode()
+    post = torch.from_numpy(pos.astype(np.int64)).to(gpu)
+    assert torch.equal(Gp[:, post].float(), G.float())
+    # the weights follow: packed[o][pos[q]] = W[o][q], and back
+    cout = 48
+    W = torch.randn(cout, cin * ks, device=gpu)
+    Wp = torch.empty((cout, cin * ks), dtype=dtype, device=gpu)
+    _lib.check(ops._entry(lib, "inter_pack_weights", dtype)(W.data_ptr(), cout, cin, ks, Wp.data_ptr(), _lib.stream_of(W)),
+               "inter_pack_weights")
+    assert torch.equal(Wp[:, post], W.to(dtype))
+    back = torch.empty_like(W)
+    Wp32 = Wp.float().contiguous()
+    _lib.check(lib.epn_inter_unpack_weight_grad_f32(Wp32.data_ptr(), cout, cin, ks, back.data_ptr(), _lib.stream_of(W)),
+               "inter_unpack_weight_grad")
+    assert torch.equal(back, W.to(dtype).float())
+
+
+def test_packed_grouping_refuses_other_shapes(gpu, vgtk_alias):
+    """Shapes outside epn_inter_group_packed_ok (here cin = 16) are refused, not silently written in the plain order."""
+    import ctypes
+    from epn_pointcloud_amd import ops, _lib
+    from epn_pointcloud_amd.vgtk import pc as pctk
+    from epn_pointcloud_amd.vgtk.so3conv import functional as L
+    from epn_pointcloud_amd.vgtk import functional as fr
+    lib = _lib.get_lib()
+    rng = np.random.default_rng(3)
+    xyz = T(unit_ball_cloud(rng, 1, 64)).to(gpu)
+    anchors = T(L.get_anchors(60)).to(gpu)
+    kernels = R.scaled_kernel_points(T(fr.kernel_points_raw(24)), 0.45).to(gpu)
+    idx = pctk.ball_query_index(xyz, xyz, 0.45, 16)
+    geo = ops.InterGeometry(xyz, xyz, idx, anchors, kernels, 0.09)
+    d = geo.desc(16, 16)
+    assert lib.epn_inter_group_packed_ok(ctypes.byref(d)) == 0
+    f = ops.to_cl(torch.randn(1, 16, 64, 60, device=gpu))
+    G = torch.empty(64 * 60, 16 * 24, device=gpu)
+    ws, wsp, wsn = ops._group_workspace(lib, d, gpu)
+    assert lib.epn_inter_group_packed_f32(ctypes.byref(d), ops._cl_ptr(f), G.data_ptr(), wsp, wsn, _lib.stream_of(f)) != 0
+    assert lib.epn_inter_packed_position(16, 24, 0) != 0
+
+
 def test_arbitrary_index_rows_are_not_deduplicated(gpu, vgtk_alias, inter_mode):
     """The data-gradient scatter merges the cyclically padded slots of a ball-query row.  Index tensors handed in by a
     caller need not be cyclic (here: random rows with accidental repeats of slot 0, shadow indices, a constant row);
