@@ -1038,9 +1038,11 @@ __global__ __launch_bounds__(64 * GP) void inter_ungroup_shared_kernel(InterArgs
     __shared__ int off[E + 1];         // CSR over distinct destinations ...
     __shared__ int list[E];            // ... of the slots that feed them
     __shared__ int chunk_cnt[CH];
-    __shared__ __attribute__((aligned(16))) float Tb[NB * E * SS];
+    constexpr int BS = (E + 1) * SS;   // floats per tile buffer: E slot rows + one row of zeros (slot id E, see `ent`)
+    __shared__ __attribute__((aligned(16))) float Tb[NB * BS];
     int *tab = reinterpret_cast<int *>(Tb);   // set-up only: input point -> first slot naming it
-    static_assert(NB * E * SS >= USH_TAB, "direct-address table must fit the tile buffers");
+    static_assert(NB * BS >= USH_TAB, "direct-address table must fit the tile buffers");
+    static_assert(E < 1024, "slot ids are packed in 10 bits");
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -1163,6 +1165,17 @@ __global__ __launch_bounds__(64 * GP) void inter_ungroup_shared_kernel(InterArgs
         __syncthreads();
     }
 
+    // The gather-sum of a step used to walk off[] -> list[] -> tile row per (destination, channel): 2 + 2 len dependent
+    // LDS round trips.  pk[u] (slot_of[], dead by now) holds the first three slots of destination u, 10 bits each (unused
+    // ones name the zero row) and whether the list goes on: one read, then the tile reads back to back.
+    int *pk = slot_of;                          // (its readers finished before the barrier above)
+    for (int u = tid; u < U; u += NTH) {
+        const int k0 = off[u], len = off[u + 1] - k0;
+        const unsigned s0 = list[k0], s1 = len > 1 ? list[k0 + 1] : E, s2 = len > 2 ? list[k0 + 2] : E;
+        pk[u] = (int)(s0 | (s1 << 10) | (s2 << 20) | (len > 3 ? 1u << 30 : 0u));
+    }
+    for (int i = tid; i < NB * SS; i += NTH) Tb[(i / SS) * BS + E * SS + i % SS] = 0.0f;
+
     float gB[NT], alphaN[NT];
 #pragma unroll
     for (int t = 0; t < NT; ++t) {
@@ -1172,10 +1185,34 @@ __global__ __launch_bounds__(64 * GP) void inter_ungroup_shared_kernel(InterArgs
     for (int ct = ct0; ct < ct1; ct += CW * CS) {
     const TG *dG = reinterpret_cast<const TG *>(A.gout) + ((size_t)bb * A.p2 + pp) * A.na * gss + (size_t)(16 * ct + x) * A.ks;
     float *dcloud = A.out + ((size_t)bb * A.p1) * A.na * A.cin + 16 * ct;
+    // dG fragments and kernel-table rows of the NEXT anchor are requested before this anchor's MFMAs: a step is ~1000 cycles
+    // of work per wave, an HBM round trip as long again -- without the prefetch every step of every wave waited it out
+    typedef typename std::conditional<sizeof(TG) == 2, bf16x4_t, f32x4>::type frag_t;
+    auto load_dg = [&](int a, int cs, frag_t (&d)[CW][KT]) {
+#pragma unroll
+        for (int cw = 0; cw < CW; ++cw)
+#pragma unroll
+            for (int kt = 0; kt < KT; ++kt) {
+                const int jj = 16 * kt + 4 * j < A.ks ? j : 0;
+                const TG *src = dG + (size_t)a * gss + (size_t)(16 * (cs * CW + cw)) * A.ks + 16 * kt + 4 * jj;
+                if constexpr (sizeof(TG) == 2) d[cw][kt] = *reinterpret_cast<const bf16x4_t *>(src);
+                else d[cw][kt] = ld4f(src);
+            }
+    };
+    auto load_rk = [&](int a, float (&r)[KT]) {
+#pragma unroll
+        for (int kt = 0; kt < KT; ++kt) r[kt] = A.rk4[((size_t)a * EPN_KS_MAX + 16 * kt + x) * 4 + j];
+    };
+    frag_t dnext[CW][KT];
+    float rknext[KT];
+    if constexpr (CS == 1) load_dg(0, 0, dnext);
+    load_rk(0, rknext);
     for (int a = 0; a < A.na; ++a) {
         float rk[KT];
 #pragma unroll
-        for (int kt = 0; kt < KT; ++kt) rk[kt] = A.rk4[((size_t)a * EPN_KS_MAX + 16 * kt + x) * 4 + j];
+        for (int kt = 0; kt < KT; ++kt) rk[kt] = rknext[kt];
+        const int an = a + 1 < A.na ? a + 1 : a;       // last anchor re-reads its own rows (cache hits, unused)
+        load_rk(an, rknext);
         // weights of this anchor: generated once, used by every chunk of the group
         typename std::conditional<sizeof(TG) == 2, bf16x4_t, f32x4>::type wgt[NT][KT];
 #pragma unroll
@@ -1195,22 +1232,30 @@ __global__ __launch_bounds__(64 * GP) void inter_ungroup_shared_kernel(InterArgs
 #pragma unroll
         for (int cs = 0; cs < CS; ++cs) {
             const int ph = (((ct - ct0) / (CW * CS)) * A.na + a) * CS + cs;     // tile buffers alternate across steps
-            float *buf = Tb + (ph & (NB - 1)) * E * SS + wave * EW * SS + x;
-            typename std::conditional<sizeof(TG) == 2, bf16x4_t, f32x4>::type dgc[CW][KT];
+            float *buf = Tb + (ph & (NB - 1)) * BS + wave * EW * SS + x;
+            frag_t dgc[CW][KT];
+            if constexpr (CS == 1) {
 #pragma unroll
-            for (int cw = 0; cw < CW; ++cw)
+                for (int cw = 0; cw < CW; ++cw)
 #pragma unroll
-                for (int kt = 0; kt < KT; ++kt) {
-                    const int jj = 16 * kt + 4 * j < A.ks ? j : 0;
-                    const TG *src = dG + (size_t)a * gss + (size_t)(16 * (cs * CW + cw)) * A.ks + 16 * kt + 4 * jj;
-                    if constexpr (sizeof(TG) == 2) dgc[cw][kt] = *reinterpret_cast<const bf16x4_t *>(src);
-                    else dgc[cw][kt] = ld4f(src);
-                }
+                    for (int kt = 0; kt < KT; ++kt) dgc[cw][kt] = dnext[cw][kt];
+#ifdef EPN_TUNING
+                if (!(A.wk & 16) || a == 0)
+#endif
+                load_dg(an, 0, dnext);
+            } else {
+                load_dg(a, cs, dgc);
+            }
 #pragma unroll
             for (int t = 0; t < NT; ++t)
 #pragma unroll
                 for (int cw = 0; cw < CW; ++cw) {
                     f32x4 tt = {0.f, 0.f, 0.f, 0.f};
+#ifdef EPN_TUNING
+                    if (A.wk & 8) {
+                        tt[0] = (float)dgc[cw][0][0] + (float)wgt[t][0][0]; tt[1] = (float)dgc[cw][KT - 1][1]; tt[2] = (float)wgt[t][KT - 1][2];
+                    } else
+#endif
                     if constexpr (sizeof(TG) == 2) {
                         // bf16 dG: the contraction over the kernel points on the bf16 MFMA (both 16-point tiles in one K = 32)
                         if constexpr (KT == 2) tt = mfma_bf16_k32(wgt[t][0], wgt[t][1], dgc[cw][0], dgc[cw][1], tt);
@@ -1224,19 +1269,33 @@ __global__ __launch_bounds__(64 * GP) void inter_ungroup_shared_kernel(InterArgs
                     // tt: lane (x = c, j), register r -> slot n = 16t + 4j + r
 #pragma unroll
                     for (int r = 0; r < 4; ++r)
+#ifdef EPN_TUNING
+                        if (!(A.wk & 4) || tt[r] == 12345.678f)
+#endif
                         if (h.mul[t][r] != 0.0f) buf[(16 * t + 4 * j + r) * SS + 16 * cw] = tt[r] * h.mul[t][r];
                 }
             __syncthreads();
-            const float *rb = Tb + (ph & (NB - 1)) * E * SS;
+            const float *rb = Tb + (ph & (NB - 1)) * BS;
+#ifdef EPN_TUNING
+            if (!(A.wk & 2))
+#endif
             for (int i = tid; i < U * 16 * CW; i += NTH) {
                 const int u = i / (16 * CW), c = i % (16 * CW);
-                float sum = 0.0f;
-                const int k1 = off[u + 1];
-                for (int k = off[u]; k < k1; ++k) sum += rb[list[k] * SS + c];
+                const unsigned e = (unsigned)pk[u];
+                float sum = rb[(e & 1023u) * SS + c];
+                sum += rb[((e >> 10) & 1023u) * SS + c];
+                sum += rb[((e >> 20) & 1023u) * SS + c];
+                if (e >> 30) {
+                    const int k1 = off[u + 1];
+                    for (int k = off[u] + 3; k < k1; ++k) sum += rb[list[k] * SS + c];
+                }
                 if constexpr (DET) {
                     TG *srow = reinterpret_cast<TG *>(A.out) + ((size_t)cnt[u] * A.na + a) * A.cin + 16 * ct + c;
                     if constexpr (sizeof(TG) == 2) *srow = (__bf16)sum; else *srow = sum;
                 } else {
+#ifdef EPN_TUNING
+                    if (!(A.wk & 1) || sum == 12345.678f)
+#endif
                     atomicAdd(dcloud + ((size_t)uq[u] * A.na + a) * A.cin + 16 * cs * CW + c, sum);
                 }
             }
@@ -1812,6 +1871,9 @@ int launch_inter_ungroup_mfma(const epn_inter_desc *d, const float *rk4, const v
                               int bf16, hipStream_t st) {
     InterArgs A = make_args(d, rk4);
     A.gout = static_cast<const float *>(dG); A.out = dF;
+#ifdef EPN_TUNING
+    if ((kernel_policy() & 0xf00) == 0x800) A.wk = kernel_policy() & 0xff;   // ablation bits of inter_ungroup_shared_kernel
+#endif
     // LDS pre-reduced scatter over Morton-adjacent output points (see inter_ungroup_shared_kernel); kernel policy
     // 0x400 | 1 keeps the per-slot atomic scatter for A/B measurements
     const int nt = (d->nn + 15) / 16;
@@ -1829,23 +1891,16 @@ int launch_inter_ungroup_mfma(const epn_inter_desc *d, const float *rk4, const v
         // bf16 K = 32 1.60 -> 1.39; at K = 64 (8 waves per workgroup) the 150 KB tile of CW = 4 leaves one workgroup per CU
         // (1.5 -> 1.9-2.6) and sequential groups (CS = 4) lose to independent workgroups (1.50 -> 1.73): one chunk per step there.
         const bool wide = d->cin % 64 == 0 && nt <= 2;
-        const int cs = 1;       // CS = 4 at K = 64 measured 1.50 -> 1.73 ms: fewer, longer workgroups hide the barrier stalls worse
-        A.col_tiles_per_wg = wide ? 4 : cs;
+        A.col_tiles_per_wg = wide ? 4 : 1;   // (CS = 4 at K = 64 measured 1.50 -> 1.73 ms: not instantiated)
         const dim3 grid((unsigned)(d->b * (d->p2 / gp)), (unsigned)((d->cin >> 4) / A.col_tiles_per_wg));
 #define EPN_USH(NT_, KT_, GP_)                                                                                            \
     do {                                                                                                                  \
         constexpr int nb_ = ((NT_ == 1 && GP_ == 8) ? 2 : 1);                                                             \
         if (wide) {                                                                                                       \
-            if constexpr ((size_t)nb_ * GP_ * 16 * NT_ * 68 * 4 <= 140 * 1024) {                                          \
+            if constexpr (NT_ <= 2) {                                                                                     \
                 if (bf16) EPN_LAUNCH((inter_ungroup_shared_kernel<NT_, KT_, __bf16, GP_, nb_, false, 4, 1>), grid, dim3(64 * GP_), 0, st, A, order); \
                 else EPN_LAUNCH((inter_ungroup_shared_kernel<NT_, KT_, float, GP_, nb_, false, 4, 1>), grid, dim3(64 * GP_), 0, st, A, order);      \
             }                                                                                                             \
-        } else if (cs == 4) {                                                                                             \
-            if (bf16) EPN_LAUNCH((inter_ungroup_shared_kernel<NT_, KT_, __bf16, GP_, nb_, false, 1, 4>), grid, dim3(64 * GP_), 0, st, A, order); \
-            else EPN_LAUNCH((inter_ungroup_shared_kernel<NT_, KT_, float, GP_, nb_, false, 1, 4>), grid, dim3(64 * GP_), 0, st, A, order);      \
-        } else if (cs == 2) {                                                                                             \
-            if (bf16) EPN_LAUNCH((inter_ungroup_shared_kernel<NT_, KT_, __bf16, GP_, nb_, false, 1, 2>), grid, dim3(64 * GP_), 0, st, A, order); \
-            else EPN_LAUNCH((inter_ungroup_shared_kernel<NT_, KT_, float, GP_, nb_, false, 1, 2>), grid, dim3(64 * GP_), 0, st, A, order);      \
         } else {                                                                                                          \
             if (bf16) EPN_LAUNCH((inter_ungroup_shared_kernel<NT_, KT_, __bf16, GP_, nb_>), grid, dim3(64 * GP_), 0, st, A, order); \
             else EPN_LAUNCH((inter_ungroup_shared_kernel<NT_, KT_, float, GP_, nb_>), grid, dim3(64 * GP_), 0, st, A, order);      \
