@@ -33,6 +33,7 @@ EXPORTS = [
     "epn_norm_act_pair_bwd_reduce", "epn_norm_act_pair_bwd_apply", "epn_inter_onchip_ok", "epn_inter_onchip_workspace_bytes", "epn_inter_so3conv_fwd_onchip_f32", "epn_inter_so3conv_fwd_bf16",
     "epn_inter_group_packed_ok", "epn_inter_packed_position", "epn_inter_group_packed_f32", "epn_inter_group_packed_bf16",
     "epn_inter_pack_weights_f32", "epn_inter_pack_weights_bf16", "epn_inter_unpack_weight_grad_f32",
+    "epn_inter_ungroup_acc_f32", "epn_inter_ungroup_acc_bf16",
 ]
 
 _vp, _ci, _cf, _sz = ctypes.c_void_p, ctypes.c_int, ctypes.c_float, ctypes.c_size_t
@@ -108,6 +109,8 @@ def get_lib():
     lib.epn_inter_group_workspace_bytes.restype = _sz
     lib.epn_inter_group_f32.argtypes = [dp, _vp, _vp, _vp, _sz, _vp]
     lib.epn_inter_ungroup_f32.argtypes = [dp, _vp, _vp, _vp, _sz, _vp]
+    lib.epn_inter_ungroup_acc_f32.argtypes = [dp, _vp, _vp, _vp, _sz, _vp]
+    lib.epn_inter_ungroup_acc_bf16.argtypes = [dp, _vp, _vp, _vp, _sz, _vp]
     lib.epn_inter_group_packed_ok.argtypes = [dp]
     lib.epn_inter_group_packed_ok.restype = _ci
     lib.epn_inter_packed_position.argtypes = [_ci, _ci, _vp]

@@ -294,14 +294,15 @@ static int inter_group_any(const epn_inter_desc *d, const void *feats_cl, void *
 }
 
 static int inter_ungroup_any(const epn_inter_desc *d, const void *grad_grouped, float *grad_feats_cl, void *workspace,
-                             size_t workspace_bytes, int bf16, epn_stream_t stream) {
+                             size_t workspace_bytes, int bf16, epn_stream_t stream, bool accumulate = false) {
     hipStream_t st = epn_stream(stream);
     InterWs ws;
     float *base = nullptr;
     int rc = prep_tables(d, workspace, workspace_bytes, ws, base, st);
     if (rc) return rc;
     if (!grad_feats_cl) return EPN_ENULL;
-    EPN_HIP(hipMemsetAsync(grad_feats_cl, 0, sizeof(float) * (size_t)d->b * d->p1 * d->na * d->cin, st));
+    if (!accumulate)
+        EPN_HIP(hipMemsetAsync(grad_feats_cl, 0, sizeof(float) * (size_t)d->b * d->p1 * d->na * d->cin, st));
     if (d->b == 0 || d->p2 == 0) return 0;
     if (!grad_grouped) return EPN_ENULL;
     if (inter_group_mfma_ok(d) && !force_generic()) {
@@ -370,6 +371,16 @@ extern "C" int epn_inter_ungroup_f32(const epn_inter_desc *d, const float *grad_
 extern "C" int epn_inter_ungroup_bf16(const epn_inter_desc *d, const void *grad_grouped, float *grad_feats_cl,
                                       void *workspace, size_t workspace_bytes, epn_stream_t stream) {
     return inter_ungroup_any(d, grad_grouped, grad_feats_cl, workspace, workspace_bytes, 1, stream);
+}
+
+// the same, ADDED to what grad_feats_cl holds (a gradient that reached the same tensor by another path)
+extern "C" int epn_inter_ungroup_acc_f32(const epn_inter_desc *d, const float *grad_grouped, float *grad_feats_cl,
+                                         void *workspace, size_t workspace_bytes, epn_stream_t stream) {
+    return inter_ungroup_any(d, grad_grouped, grad_feats_cl, workspace, workspace_bytes, 0, stream, true);
+}
+extern "C" int epn_inter_ungroup_acc_bf16(const epn_inter_desc *d, const void *grad_grouped, float *grad_feats_cl,
+                                          void *workspace, size_t workspace_bytes, epn_stream_t stream) {
+    return inter_ungroup_any(d, grad_grouped, grad_feats_cl, workspace, workspace_bytes, 1, stream, true);
 }
 
 extern "C" int epn_inter_inverse_list(const int32_t *ball_idx, int b, int p1, int p2, int nn, int32_t *offsets,

@@ -327,8 +327,14 @@ class InterSO3ConvSplitFn(torch.autograd.Function):
     training-time choice on a 288 GB part; InterSO3ConvFn / InterSO3ConvOnChipFn are the forms that never write it."""
 
     @staticmethod
-    def forward(ctx, feats, W, geo):
+    def forward(ctx, feats, W, geo, share_input=False):
+        """share_input: also return `feats` itself as a second output.  A caller that feeds the same tensor to another
+        branch (the skip path of a SeparableSO3ConvBlock) uses THAT output there: the other branch's gradient then arrives
+        here, and the transpose of the grouping accumulates onto it (epn_inter_ungroup_acc_*) -- no zero-fill of the
+        scatter target and no separate addition pass over the two [b, cin, p1, na] gradients."""
         lib = _lib.get_lib()
+        ctx.set_materialize_grads(False)
+        ctx.share_input = share_input
         f = to_cl(feats)
         Wc = W.contiguous()
         cout, ck = Wc.shape
@@ -356,16 +362,19 @@ class InterSO3ConvSplitFn(torch.autograd.Function):
         out2d = _launch("inter_gemm", _inter_key(d), 2.0 * cols * cout * ck, f.device, lambda: gemm.gemm_nt(G, Wd))
         ctx.save_for_backward(G, Wc)
         ctx.geo, ctx.cin, ctx.packed = geo, cin, packed
-        return out2d.view(d.b, d.p2, d.na, cout).permute(0, 3, 1, 2)
+        out = out2d.view(d.b, d.p2, d.na, cout).permute(0, 3, 1, 2)
+        return (out, feats) if share_input else out
 
     @staticmethod
-    def backward(ctx, grad_out):
+    def backward(ctx, grad_out, grad_shared=None):
         lib = _lib.get_lib()
         G, Wc = ctx.saved_tensors
         geo, cin = ctx.geo, ctx.cin
         cout, ck = Wc.shape
         d = geo.desc(cin, cout)
         cols = d.b * d.p2 * d.na
+        if grad_out is None:                   # only the shared input was used downstream
+            return (grad_shared if ctx.needs_input_grad[0] else None), None, None, None
         g = cast_feats(to_cl(grad_out, "grad_out"), G.dtype)
         g2d = g.permute(0, 2, 3, 1).reshape(cols, cout)   # view of the channels-last buffer
         need_f, need_w = ctx.needs_input_grad[0], ctx.needs_input_grad[1]
@@ -378,8 +387,14 @@ class InterSO3ConvSplitFn(torch.autograd.Function):
                 _lib.check(lib.epn_inter_unpack_weight_grad_f32(gWp.data_ptr(), cout, cin, d.ks, gW.data_ptr(),
                                                                 _lib.stream_of(G)), "inter_unpack_weight_grad")
         if need_f:
-            gf = empty_cl(d.b, cin, d.p1, d.na, G.device)           # fp32: the scatter target of either dtype
             mode = os.environ.get("EPN_INTER_BWD_DATA", "auto")
+            # the other branch's gradient of the shared input: fp32 -> the scatter accumulates onto it; otherwise added below
+            onto = (grad_shared is not None and grad_shared.dtype == torch.float32 and G.dtype == torch.float32
+                    and mode != "fused" and not deterministic_bwd(G.dtype))
+            if onto:
+                gf, grad_shared = to_cl(grad_shared, "grad_shared"), None
+            else:
+                gf = empty_cl(d.b, cin, d.p1, d.na, G.device)       # fp32: the scatter target of either dtype
             if G.dtype != torch.float32 or deterministic_bwd(G.dtype):
                 mode = "split"          # bf16 features / deterministic mode: dG GEMM + (atomic-free) transpose of the grouping
             elif mode == "auto":
@@ -419,13 +434,17 @@ class InterSO3ConvSplitFn(torch.autograd.Function):
                                                    _lib.dev_ptr(ent, "entries", torch.int32),
                                                    ctypes.c_void_p(slab.data_ptr()), slab.numel() * slab.element_size(),
                                                    wsp, wsn, _lib.stream_of(G))), "inter_ungroup_det")
-                    return gf, gW, None
-                ungrp = _entry(lib, "inter_ungroup", G.dtype)
+                    if grad_shared is not None:
+                        gf = gf + grad_shared.to(gf.dtype)
+                    return gf, gW, None, None
+                ungrp = _entry(lib, "inter_ungroup_acc" if onto else "inter_ungroup", G.dtype)
                 _lib.check(_launch("inter_ungroup", _inter_key(d), gflops, G.device,
                                    lambda: ungrp(ctypes.byref(d), ctypes.c_void_p(dG.data_ptr()), _cl_ptr(gf), wsp, wsn,
                                                  _lib.stream_of(G))), "inter_ungroup")
             gf = cast_feats(gf, G.dtype)
-        return gf, gW, None
+            if grad_shared is not None:
+                gf = gf + grad_shared.to(gf.dtype)
+        return gf, gW, None, None
 
 
 def _lib_generic():
@@ -1163,9 +1182,23 @@ def inter_mode():
     return os.environ.get("EPN_INTER_MODE", "auto")
 
 
-def inter_so3conv(feats, W, geo, out_dtype=None):
+def inter_so3conv(feats, W, geo, out_dtype=None, share_input=False):
     """InterSO3Conv's compute.  out_dtype (default: the dtype of feats) lets the fp32 first layer (cin = 1, all-ones
-    occupancy features) hand bf16 features to the rest of a bf16 network."""
+    occupancy features) hand bf16 features to the rest of a bf16 network.  share_input: return (out, feats') where feats'
+    is `feats` for the caller's OTHER uses of it (InterSO3ConvSplitFn.forward: its gradient is then folded into the
+    convolution's own data gradient; the forms without that fold return `feats` itself)."""
+    if share_input:
+        mode = inter_mode()
+        plain = (feats.shape[1] % 16 != 0 or isinstance(geo, DenseInterWeights) or not feats.is_cuda or mode not in ("auto", "split")
+                 or feats.dtype not in FEATURE_DTYPES or os.environ.get("EPN_SHARE_INPUT_GRAD", "1") != "1")
+        if not plain and feats.dtype == torch.float32:
+            g_bytes = (geo.ball_idx.shape[0] * geo.ball_idx.shape[1] * geo.anchors.shape[0] * feats.shape[1] *
+                       geo.kernels.shape[0] * 4)
+            plain = mode == "auto" and g_bytes > _device_bytes(feats.device) // 8
+        if plain:
+            return inter_so3conv(feats, W, geo, out_dtype), feats
+        out, shared = InterSO3ConvSplitFn.apply(feats, W, geo, True)
+        return cast_feats(out, out_dtype or feats.dtype), shared
     mode = inter_mode()
     out_dtype = out_dtype or feats.dtype
     split_ok = feats.shape[1] % 16 == 0 and not isinstance(geo, DenseInterWeights)

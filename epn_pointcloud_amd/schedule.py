@@ -143,8 +143,17 @@ class FusedSeparableBlock(SeparableBlock):
         if (not self.training) or self.dropout is not None or not ops.norm_act_supported(c_out) or not self.use_intra:
             return super().forward(x, inter_idx, inter_w)
         import os
-        skip = x.feats
-        inter_idx, inter_w, sample_idx, y = self.inter_conv.conv(x, inter_idx, inter_w)
+        conv = self.inter_conv.conv
+        # x.feats feeds the inter convolution AND the skip branch: the convolution hands back the tensor for the second use
+        # and folds that branch's gradient into its own data gradient (ops.InterSO3ConvSplitFn; EPN_SHARE_INPUT_GRAD=0: off)
+        conv.share_input_grad = True
+        try:
+            inter_idx, inter_w, sample_idx, y = conv(x, inter_idx, inter_w)
+        finally:
+            conv.share_input_grad = False
+        skip = conv.__dict__.pop("_shared_input", None)
+        if skip is None:
+            skip = x.feats
 
         pair = os.environ.get("EPN_NORM_PAIR", "1") == "1"     # skip norm folded into the block's final pass
 

@@ -128,7 +128,11 @@ class InterSO3Conv(nn.Module):
                 handle = inter_w
             else:
                 handle = ops.DenseInterWeights(inter_idx.int().contiguous(), inter_w, xyz.shape[2])
-        out = ops.inter_so3conv(feats, self.basic_conv.W, handle, self.feat_dtype)
+        if getattr(self, "share_input_grad", False) and feats is x.feats:
+            # (set by a block whose skip branch reads x.feats too: see ops.InterSO3ConvSplitFn.forward)
+            out, self._shared_input = ops.inter_so3conv(feats, self.basic_conv.W, handle, self.feat_dtype, share_input=True)
+        else:
+            out = ops.inter_so3conv(feats, self.basic_conv.W, handle, self.feat_dtype)
         return inter_idx, inter_w, sample_idx, SphericalPointCloud(new_xyz, out, self.anchors)
 
 

@@ -266,6 +266,14 @@ int epn_inter_group_f32(const epn_inter_desc *d, const float *feats_cl, float *g
                         size_t workspace_bytes, epn_stream_t stream);
 int epn_inter_ungroup_f32(const epn_inter_desc *d, const float *grad_grouped, float *grad_feats_cl, void *workspace,
                           size_t workspace_bytes, epn_stream_t stream);
+/* epn_inter_ungroup_acc_{f32,bf16}: the same transpose ADDED to the contents of grad_feats_cl (fp32) instead of written
+ * over zeros -- for a tensor whose gradient also arrives by another path (the input of a SeparableSO3ConvBlock feeds the
+ * inter convolution AND the skip branch, base_so3conv.py:186-207): hand in the other path's gradient and neither a
+ * zero-fill nor a separate addition pass is needed. */
+int epn_inter_ungroup_acc_f32(const epn_inter_desc *d, const float *grad_grouped, float *grad_feats_cl, void *workspace,
+                              size_t workspace_bytes, epn_stream_t stream);
+int epn_inter_ungroup_acc_bf16(const epn_inter_desc *d, const void *grad_grouped, float *grad_feats_cl, void *workspace,
+                               size_t workspace_bytes, epn_stream_t stream);
 
 /* Packed column order of `grouped` (what the split convolution of this package uses between its own kernels).  In the
  * element order c*ks + k above, one store instruction of the grouping kernel -- four kernel points of 16 channels -- is 16

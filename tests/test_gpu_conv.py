@@ -491,6 +491,55 @@ def test_packed_grouping_is_the_plain_grouping_permuted(gpu, vgtk_alias, cin, K,
     assert torch.equal(back, W.to(dtype).float())
 
 
+@pytest.mark.parametrize("dt", ["f32", "bf16"])
+def test_shared_input_gradient_is_folded_into_the_data_gradient(gpu, vgtk_alias, dt, monkeypatch):
+    """ops.inter_so3conv(..., share_input=True) hands the input back for a second consumer; that consumer's gradient is
+    accumulated by the transpose of the grouping itself (epn_inter_ungroup_acc_*, fp32) or added (bf16).  Same forward and
+    the same gradients as the two-consumer graph autograd would sum (EPN_SHARE_INPUT_GRAD=0), incl. the cases where only one
+    of the two outputs is used."""
+    from epn_pointcloud_amd import ops
+    from epn_pointcloud_amd.vgtk import pc as pctk
+    from epn_pointcloud_amd.vgtk.so3conv import functional as L
+    from epn_pointcloud_amd.vgtk import functional as fr
+    rng = np.random.default_rng(5)
+    torch.manual_seed(5)
+    dtype = torch.bfloat16 if dt == "bf16" else torch.float32
+    b, n, cin, cout, K, radius, sigma = 2, 96, 32, 48, 16, 0.45, 0.09
+    xyz = T(unit_ball_cloud(rng, b, n)).to(gpu)
+    anchors = T(L.get_anchors(60)).to(gpu)
+    kernels = R.scaled_kernel_points(T(fr.kernel_points_raw(24)), radius).to(gpu)
+    _, new_xyz = pctk.furthest_sample(xyz, n // 2, False)
+    idx = pctk.ball_query_index(new_xyz, xyz, radius, K)
+    geo = ops.InterGeometry(xyz, new_xyz, idx, anchors, kernels, sigma)
+    feats = torch.randn(b, cin, n, 60, device=gpu).to(dtype)
+    W = torch.randn(cout, cin * 24, device=gpu) / (cin * 24) ** 0.5
+    side_w = torch.randn(b, cin, n, 60, device=gpu)
+
+    def run(share, use_out=True, use_side=True):
+        monkeypatch.setenv("EPN_SHARE_INPUT_GRAD", "1" if share else "0")
+        f = feats.clone().requires_grad_(True)
+        w = W.clone().requires_grad_(True)
+        h = f * 1.0                                       # a non-leaf input, as inside a network
+        out, h2 = ops.inter_so3conv(h, w, geo, share_input=True)
+        loss = 0.0
+        if use_out:
+            loss = loss + (out.float() ** 2).sum()
+        if use_side:
+            loss = loss + (h2.float() * side_w).sum()
+        loss.backward()
+        return out.detach().float(), f.grad.float(), (w.grad if use_out else None)
+
+    tol = 2e-2 if dt == "bf16" else 1e-4
+    for use_out, use_side in ((True, True), (True, False), (False, True)):
+        o0, gf0, gw0 = run(False, use_out, use_side)
+        o1, gf1, gw1 = run(True, use_out, use_side)
+        assert torch.equal(o0, o1)
+        scale = gf0.abs().max().item() + 1e-12
+        assert (gf0 - gf1).abs().max().item() <= tol * scale, (use_out, use_side)
+        if use_out:
+            assert (gw0 - gw1).abs().max().item() <= 1e-5 * gw0.abs().max().item()
+
+
 def test_packed_grouping_refuses_other_shapes(gpu, vgtk_alias):
     """Shapes outside epn_inter_group_packed_ok (here cin = 16) are refused, not silently written in the plain order."""
     import ctypes
