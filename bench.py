@@ -33,13 +33,15 @@ PEAK_TFLOPS = {"f32": 157.3, "bf16": 2500.0}
 HBM_PEAK_GBS = 8000.0
 
 PMC_FILE = os.path.join(ROOT, "profiles", "r03_pmc_per_kernel.json")   # tools/collect_profiles.sh + pmc_summary.py
+PMC_FILES = {"cls_f32": PMC_FILE,                                        # which committed pass profiled which workload
+             "reg_bf16": os.path.join(ROOT, "profiles", "r03_reg_bf16_pmc_per_kernel.json")}
 
 
-def recorded_traffic(kernel_family):
+def recorded_traffic(kernel_family, pmc_file=PMC_FILE):
     """HBM bytes per launch of one kernel family from the committed rocprofv3 --pmc passes (FETCH_SIZE and WRITE_SIZE
     in separate runs, x1024, read side doubled per MI355X_MICROARCH.md): PMC counters cannot be read live here."""
     try:
-        pmc = json.load(open(PMC_FILE))
+        pmc = json.load(open(pmc_file))
     except OSError:
         return None
     tot = n = 0.0
@@ -204,7 +206,7 @@ def roofline_of(records, prof_steps, dtype_name, split_gemm, with_traffic, graph
     def roof(k):
         d = agg[k]
         ach = d["flops"] / (d["ms"] * 1e-3) / 1e12
-        traffic = recorded_traffic(k) if with_traffic else None
+        traffic = recorded_traffic(k, with_traffic) if with_traffic else None
         if "_x3_" in k or k.endswith("true>") or (k.startswith("epn::inter_fx") and "<float" in k):
             # split form: every fp32 multiply-add is six bf16 MFMA multiply-adds (fp32 accumulate); the roof is the
             # bf16 matrix pipe and `achieved` the flops it EXECUTES; the fp32-equivalent rate is reported beside it
@@ -224,7 +226,7 @@ def roofline_of(records, prof_steps, dtype_name, split_gemm, with_traffic, graph
         d = agg[k]
         ach = d["bytes"] / (d["ms"] * 1e-3) / 1e9
         return {"bound": "hbm", "kernel": k, "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": recorded_traffic(k) if with_traffic else None,
+                "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": recorded_traffic(k, with_traffic) if with_traffic else None,
                 "launches": d["launches"], "avg_launch_ms": round(d["ms"] / d["launches"], 4),
                 "algorithmic_bytes_per_launch": round(d["bytes"] / d["launches"])}
 
@@ -240,7 +242,8 @@ def roofline_of(records, prof_steps, dtype_name, split_gemm, with_traffic, graph
         if gem:
             roofline["dominant_mfma_kernel"] = roof(gem)
     roofline["traffic_note"] = ("HBM bytes/launch (avg over the kernel's launches) from the committed rocprofv3 "
-                                "--pmc passes, " + os.path.relpath(PMC_FILE, ROOT))
+                                "--pmc passes, " + os.path.relpath(with_traffic or PMC_FILE, ROOT)
+                                + ("" if with_traffic else " (this workload was not profiled: traffic null)"))
     roofline["per_kernel_ms_per_step"] = {k: round(v["ms"] / prof_steps, 3) for k, v in sorted(agg.items())}
     roofline["per_kernel_ms_sum"] = round(sum(v["ms"] for v in agg.values()) / prof_steps, 3)
     roofline["per_kernel_launches_per_step"] = {k: round(v["launches"] / prof_steps, 1) for k, v in sorted(agg.items())}
@@ -452,9 +455,10 @@ def measure(cfg, rank, local_rank, world, dev, first=True):
                    "parallelism": f"dp{world}"},
     }
     if rank == 0:
+        # PMC passes exist for the cls fp32 step (B=32) and the rotation network's bf16 step (B=64): their kernels' traffic
+        profiled = (not cfg.forward_only) and ((cfg.model, batch, dtype_name) in (("cls", 32, "f32"), ("reg", 64, "bf16")))
         out["roofline"] = roofline_of(records, prof_steps, dtype_name, split_gemm,
-                                      cfg.model == "cls" and batch == 32 and dtype_name == "f32" and not cfg.forward_only,
-                                      graph is not None)
+                                      PMC_FILES.get(f"{cfg.model}_{dtype_name}") if profiled else None, graph is not None)
     handles = dict(model=model, layers=layers, flat_pts=flat_pts, compute=compute, finish=finish, opt=opt, graph=graph,
                    head=head, points=points, batch=batch, split_gemm=split_gemm)
     return out, handles
