@@ -132,15 +132,31 @@ __device__ __forceinline__ void load_hood(const InterArgs &A, int bb, int pp, in
     }
 }
 
-// w[kt][t] (4 registers each) for one column: lane (x, j), register r  ->  k = 16kt + x, n = 16t + 4j + r
-template <int NT, int KT>
-__device__ __forceinline__ void make_weights(const InterArgs &A, int a, int x, int j, const Hood<NT> &h,
-                                             f32x4 (&w)[KT][NT]) {
+// Rotated-kernel table entries of one anchor as a lane needs them.  They are LOADS: a kernel that walks the anchors of a
+// point must request the next anchor's entries a whole column ahead (with the next column's feature rows) -- read where they
+// are used, hipcc waits for them with s_waitcnt vmcnt(0), which (the counter is in order) also waits for every store of the
+// previous column and for the feature rows just requested: the grouping kernel ran its stores and its MFMAs strictly one
+// after the other (1.75 = 0.97 + 0.8 ms on a 64-channel K = 16 layer) until round 3 found this in the ISA.
+template <int KT>
+struct RkRow { float rk[KT], beta[KT]; };
+
+template <int KT>
+__device__ __forceinline__ void load_rk_row(const InterArgs &A, int a, int x, int j, RkRow<KT> &r) {
 #pragma unroll
     for (int kt = 0; kt < KT; ++kt) {
         const float *e = A.rk4 + ((size_t)a * EPN_KS_MAX + 16 * kt + x) * 4;
-        const float rk = j == 3 ? 1.0f : e[j];
-        const float beta = e[3];
+        r.rk[kt] = e[j];            // lane group j = 3 multiplies alpha by 1: patched in make_weights_from
+        r.beta[kt] = e[3];
+    }
+}
+
+// w[kt][t] (4 registers each) for one column: lane (x, j), register r  ->  k = 16kt + x, n = 16t + 4j + r
+template <int NT, int KT>
+__device__ __forceinline__ void make_weights_from(const RkRow<KT> &rr, int j, const Hood<NT> &h, f32x4 (&w)[KT][NT]) {
+#pragma unroll
+    for (int kt = 0; kt < KT; ++kt) {
+        const float rk = j == 3 ? 1.0f : rr.rk[kt];
+        const float beta = rr.beta[kt];
 #pragma unroll
         for (int t = 0; t < NT; ++t) {
             f32x4 s = {beta, beta, beta, beta};
@@ -150,6 +166,14 @@ __device__ __forceinline__ void make_weights(const InterArgs &A, int a, int x, i
             w[kt][t] = s;
         }
     }
+}
+
+template <int NT, int KT>
+__device__ __forceinline__ void make_weights(const InterArgs &A, int a, int x, int j, const Hood<NT> &h,
+                                             f32x4 (&w)[KT][NT]) {
+    RkRow<KT> rr;
+    load_rk_row<KT>(A, a, x, j, rr);
+    make_weights_from<NT, KT>(rr, j, h, w);
 }
 
 // Grouped features of 16 columns x 16 channels into the wave-private LDS tile Gs[col][c_local*ks + k].
@@ -262,14 +286,17 @@ __device__ __forceinline__ void group_segment_bf16(const InterArgs &A, const Seg
     // wave-uniform: first element of channel chunk ct of anchor a0 in this cloud's feature block
     const unsigned short *rb = reinterpret_cast<const unsigned short *>(sg.fbase) + (size_t)sg.a0 * A.cin + 16 * ct;
     unsigned fcur[NT][4], fnext[NT][4];
+    RkRow<KT> rcur, rnext;
+    load_rk_row<KT>(A, sg.a0, x, j, rcur);
     load_f_raw<NT>(rb, rh, fcur);
     const unsigned lane_st = (unsigned)(x * A.ks + 4 * j);
     for (int i = 0; i < sg.cnt; ++i) {
-        const int a = sg.a0 + i;
         const int inext = i + 1 < sg.cnt ? i + 1 : i;   // last column re-reads its own rows (cache hit, result unused)
+        load_rk_row<KT>(A, sg.a0 + inext, x, j, rnext);
         load_f_raw<NT>(rb + (size_t)inext * A.cin, rh, fnext);
         f32x4 w[KT][NT];
-        make_weights<NT, KT>(A, a, x, j, sg.h, w);     // relu already applied
+        make_weights_from<NT, KT>(rcur, j, sg.h, w);    // relu already applied
+        rcur = rnext;
         bf16x4_t fb4[NT];
 #pragma unroll
         for (int t = 0; t < NT; ++t) fb4[t] = pack_f_raw<NT>(rh, fcur, t);
@@ -304,13 +331,17 @@ __device__ __forceinline__ void group_segment(const InterArgs &A, const Seg<NT> 
     }
     const int coff = 16 * ct + x;
     float fcur[NT][4], fnext[NT][4];
+    RkRow<KT> rcur, rnext;
+    load_rk_row<KT>(A, sg.a0, x, j, rcur);
     load_f<NT, TF>(A, sg, sg.a0, coff, fcur);
     for (int i = 0; i < sg.cnt; ++i) {
         const int a = sg.a0 + i;
         const int an = i + 1 < sg.cnt ? a + 1 : a;   // last column re-reads its own rows (cache hit, result unused)
+        load_rk_row<KT>(A, an, x, j, rnext);
         load_f<NT, TF>(A, sg, an, coff, fnext);
         f32x4 w[KT][NT];
-        make_weights<NT, KT>(A, a, x, j, sg.h, w);
+        make_weights_from<NT, KT>(rcur, j, sg.h, w);
+        rcur = rnext;
 #pragma unroll
         for (int kt = 0; kt < KT; ++kt) {
             f32x4 g = {0.f, 0.f, 0.f, 0.f};

@@ -827,7 +827,21 @@ __global__ __launch_bounds__(64 * NW) void inter_group_wide_kernel(InterArgs A) 
     for (int si = 0; si < 2; ++si) {
         const Seg<NT> &sg = seg[si];
         if (sg.cnt <= 0) continue;
-        uvec fcur[NT][4], fnext[NT][4];
+        // store offsets (bytes) of the lane's D fragments: [kt] = lane part (0x80000000 = no such kernel points),
+        // est[kt] = step from chunk e to e + 1
+        unsigned vst[KT];
+        int est[KT];
+#pragma unroll
+        for (int kt = 0; kt < KT; ++kt) {
+            int o = coff * A.ks + 16 * kt + 4 * j;
+            est[kt] = A.ks * (int)sizeof(TF);
+            if (A.packed) {
+                const int s0 = (int)blockIdx.y * 16 * CG + x, w0 = A.ks < 16 ? A.ks : 16;   // slot of the lane's channel e = 0
+                o = kt == 0 ? s0 * w0 + 4 * j : w0 * A.cin + s0 * (A.ks - 16) + 4 * j;
+                est[kt] = 16 * (kt == 0 ? w0 : A.ks - 16) * (int)sizeof(TF);
+            }
+            vst[kt] = 16 * kt + 4 * j < A.ks ? (unsigned)o * (unsigned)sizeof(TF) : 0x80000000u;
+        }
         auto gather = [&](int a, uvec (&f)[NT][4]) {
             const TF *fb = reinterpret_cast<const TF *>(sg.fbase) + (size_t)a * A.cin + coff;
 #pragma unroll
@@ -835,21 +849,24 @@ __global__ __launch_bounds__(64 * NW) void inter_group_wide_kernel(InterArgs A) 
 #pragma unroll
                 for (int r = 0; r < 4; ++r) f[t][r] = *reinterpret_cast<const uvec *>(fb + sg.h.q[t][r]);
         };
-        gather(sg.a0, fcur);
-        for (int i = 0; i < sg.cnt; ++i) {
+        // One column: request column i + 1's feature rows and kernel-table entries into (fnext, rnext), then compute column
+        // i from (fcur, rcur).  The two register sets swap ROLES between consecutive columns (the loop below is unrolled by
+        // two): a copy "cur = next" at the end of an iteration would have to wait for the loads it copies -- with the
+        // in-order counter that is s_waitcnt vmcnt(0), i.e. for every store of the column as well.  (Measured further:
+        // branch-free buffer stores + counted dummy stores in the preheader bring hipcc's waits to the exact vmcnt(8..15) --
+        // no store ever waited for -- and change nothing: 7.72-7.81 vs 7.78-7.79 ms per cls step, the other waves of the
+        // SIMD already cover what is left.)
+        auto column = [&](int i, const uvec (&fcur)[NT][4], const RkRow<KT> &rcur, uvec (&fnext)[NT][4], RkRow<KT> &rnext) {
             const int a = sg.a0 + i;
-            gather(i + 1 < sg.cnt ? a + 1 : a, fnext);          // last column re-reads its own rows (cache hit, unused)
+            const int an = i + 1 < sg.cnt ? a + 1 : a;          // last column re-reads its own rows (cache hit, unused)
+            load_rk_row<KT>(A, an, x, j, rnext);
+#ifdef EPN_TUNING
+            if (!(A.wk & 2) || i == 0)
+#endif
+            gather(an, fnext);
             f32x4 w[KT][NT];
-            make_weights<NT, KT>(A, a, x, j, sg.h, w);           // once per column, for all CG chunks
-            // element steps of the store address: chunk e -> e + 1 (k < 16 block, k >= 16 block), k < 16 -> k >= 16
-            TF *grow = G + (size_t)(sg.jc0 + i) * gss + (size_t)coff * A.ks + 4 * j;
-            int es0 = A.ks, es1 = A.ks, kstep = 16;
-            if (A.packed) {
-                const int s0 = (int)blockIdx.y * 16 * CG + x, w0 = A.ks < 16 ? A.ks : 16;   // slot of the lane's channel e = 0
-                grow = G + (size_t)(sg.jc0 + i) * gss + s0 * w0 + 4 * j;
-                es0 = 16 * w0; es1 = 16 * (A.ks - 16);
-                kstep = w0 * A.cin + s0 * (A.ks - 16) - s0 * w0;
-            }
+            make_weights_from<NT, KT>(rcur, j, sg.h, w);         // once per column, for all CG chunks
+            const unsigned rowoff = (unsigned)(sg.jc0 + i) * (unsigned)gss * (unsigned)sizeof(TF);   // wave-uniform
 #pragma unroll
             for (int e = 0; e < CG; ++e) {
                 if constexpr (BF) {
@@ -876,7 +893,11 @@ __global__ __launch_bounds__(64 * NW) void inter_group_wide_kernel(InterArgs A) 
 #pragma unroll
                             for (int t = 0; t < NT; ++t) g = mfma_bf16_k16(pack4(w[kt][t]), fb4[t], g);
                         }
-                        if (16 * kt + 4 * j < A.ks) st4f(grow + e * (kt ? es1 : es0) + kt * kstep, g);
+#ifdef EPN_TUNING      // tools/group_ablation.py: 1 = no stores (kept alive by an impossible value), 2 = gathers once, 4 = no MFMAs
+                        if (!(A.wk & 1) || g[0] == 12345.678f)
+#endif
+                        if (vst[kt] != 0x80000000u)
+                            st4f(reinterpret_cast<TF *>(reinterpret_cast<char *>(G) + rowoff + vst[kt] + e * est[kt]), g);
                     }
                 } else {
 #pragma unroll
@@ -885,16 +906,28 @@ __global__ __launch_bounds__(64 * NW) void inter_group_wide_kernel(InterArgs A) 
 #pragma unroll
                         for (int t = 0; t < NT; ++t)
 #pragma unroll
-                            for (int r = 0; r < 4; ++r)
+                            for (int r = 0; r < 4; ++r) {
+#ifdef EPN_TUNING
+                                if (A.wk & 4) { g[r] += w[kt][t][r] + __uint_as_float(fcur[t][r][e]); continue; }
+#endif
                                 g = mfma4(w[kt][t][r], sg.h.ok[t][r] ? __uint_as_float(fcur[t][r][e]) : 0.0f, g);
-                        if (16 * kt + 4 * j < A.ks) st4f(grow + e * (kt ? es1 : es0) + kt * kstep, g);
+                            }
+#ifdef EPN_TUNING      // tools/group_ablation.py: 1 = no stores (kept alive by an impossible value), 2 = gathers once, 4 = no MFMAs
+                        if (!(A.wk & 1) || g[0] == 12345.678f)
+#endif
+                        if (vst[kt] != 0x80000000u)
+                            st4f(reinterpret_cast<TF *>(reinterpret_cast<char *>(G) + rowoff + vst[kt] + e * est[kt]), g);
                     }
                 }
             }
-#pragma unroll
-            for (int t = 0; t < NT; ++t)
-#pragma unroll
-                for (int r = 0; r < 4; ++r) fcur[t][r] = fnext[t][r];
+        };
+        uvec f0[NT][4], f1[NT][4];
+        RkRow<KT> r0, r1;
+        load_rk_row<KT>(A, sg.a0, x, j, r0);
+        gather(sg.a0, f0);
+        for (int i = 0; i < sg.cnt; i += 2) {
+            column(i, f0, r0, f1, r1);
+            if (i + 1 < sg.cnt) column(i + 1, f1, r1, f0, r0);
         }
     }
 }
@@ -1719,6 +1752,9 @@ int launch_inter_group_mfma(const epn_inter_desc *d, const float *rk4, const voi
     // 384 bytes apart.  Packed order (contiguous stores): 1.53-1.72 ms at K = 16, 1.04-1.09 at K = 32 (plain 1.21-1.34);
     // bf16 1.00 / 0.78-0.81 ms (K = 32 / 64; plain 1.24-1.26 / 0.84-0.88) -- the wide kernel serves every packed call
     A.packed = packed;
+#ifdef EPN_TUNING
+    if ((kernel_policy() & 0xf00) == 0x800) A.wk = kernel_policy() & 0xff;   // ablation bits of inter_group_wide_kernel
+#endif
     if (packed && !inter_group_packed_ok(d)) return EPN_EINVAL;
     if (d->na >= 16 && d->cin % 32 == 0 && d->nn <= 64 && (bf16 || d->nn > 16 || packed)) {
         const int cg = d->cin % 64 == 0 ? 4 : 2;
