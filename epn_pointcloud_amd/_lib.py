@@ -33,7 +33,8 @@ EXPORTS = [
     "epn_norm_act_pair_bwd_reduce", "epn_norm_act_pair_bwd_apply", "epn_inter_onchip_ok", "epn_inter_onchip_workspace_bytes", "epn_inter_so3conv_fwd_onchip_f32", "epn_inter_so3conv_fwd_bf16",
     "epn_inter_group_packed_ok", "epn_inter_packed_position", "epn_inter_group_packed_f32", "epn_inter_group_packed_bf16",
     "epn_inter_pack_weights_f32", "epn_inter_pack_weights_bf16", "epn_inter_unpack_weight_grad_f32",
-    "epn_inter_ungroup_acc_f32", "epn_inter_ungroup_acc_bf16",
+    "epn_inter_ungroup_acc_f32", "epn_inter_ungroup_acc_bf16", "epn_stats_finish", "epn_stats_finish_workspace_bytes",
+    "epn_so3_basis_stats_f32", "epn_so3_basis_stats_split_f32", "epn_so3_basis_stats_bf16",
 ]
 
 _vp, _ci, _cf, _sz = ctypes.c_void_p, ctypes.c_int, ctypes.c_float, ctypes.c_size_t
@@ -54,7 +55,7 @@ class NormPairSide(ctypes.Structure):
 class GemmNtProblem(ctypes.Structure):
     """struct epn_gemm_nt_problem (include/epn_so3conv.h)."""
     _fields_ = [("A", _vp), ("Bt", _vp), ("C", _vp), ("M", ctypes.c_longlong), ("lda", ctypes.c_longlong),
-                ("ldb", ctypes.c_longlong), ("ldc", ctypes.c_longlong), ("N", _ci), ("K", _ci)]
+                ("ldb", ctypes.c_longlong), ("ldc", ctypes.c_longlong), ("N", _ci), ("K", _ci), ("col_stats", _vp)]
 
 
 class GemmTnProblem(ctypes.Structure):
@@ -109,6 +110,11 @@ def get_lib():
     lib.epn_inter_group_workspace_bytes.restype = _sz
     lib.epn_inter_group_f32.argtypes = [dp, _vp, _vp, _vp, _sz, _vp]
     lib.epn_inter_ungroup_f32.argtypes = [dp, _vp, _vp, _vp, _sz, _vp]
+    for _n in ("epn_so3_basis_stats_f32", "epn_so3_basis_stats_split_f32", "epn_so3_basis_stats_bf16"):
+        getattr(lib, _n).argtypes = [_vp, _vp, _vp, ctypes.c_longlong, _ci, _ci, _ci, _ci, _vp, _vp, _vp]
+    lib.epn_stats_finish.argtypes = [_vp, _ci, ctypes.c_longlong, _ci, _vp, _vp, _sz, _vp]
+    lib.epn_stats_finish_workspace_bytes.argtypes = [_ci, ctypes.c_longlong, _ci]
+    lib.epn_stats_finish_workspace_bytes.restype = _sz
     lib.epn_inter_ungroup_acc_f32.argtypes = [dp, _vp, _vp, _vp, _sz, _vp]
     lib.epn_inter_ungroup_acc_bf16.argtypes = [dp, _vp, _vp, _vp, _sz, _vp]
     lib.epn_inter_group_packed_ok.argtypes = [dp]

@@ -15,6 +15,7 @@ struct GemmNtProb {        // C[M][N] = A[M][K] . Bt[N][K]^T
     unsigned tile0;        // first workgroup of this problem inside the grouped launch (a multiple of 8)
     unsigned ntile;        // its tiles; workgroups tile0 + ntile .. next tile0 are padding
     const void *Bp;        // split GEMM (gemm_x3.hip): the three bf16 planes [3][N][K] of Bt, filled by its launcher
+    float *stats;          // optional: per-column (sum, sum of squares) of every 32-row block of C, [M/32][N][2] (M % 32 == 0)
 };
 struct GemmNtBatch {
     int nprob;
@@ -38,6 +39,41 @@ struct GemmTnBatch {       // up to GEMM_MAX_PROB problems in ONE launch (the ir
     unsigned nblocks;
     GemmTnArgs p[GEMM_MAX_PROB];
 };
+
+#ifdef __HIPCC__
+// Column statistics of an NT tile, taken from the accumulators in the epilogue (the per-channel sums a following
+// BatchNorm / InstanceNorm needs: SURVEY 8f.1 -- no separate pass over C).  acc[i][j]: 32 x 32 MFMA tile i (rows) x j
+// (columns) of the wave, D[row = (r&3) + 8 (r>>2) + 4 lj][col = li]; part[(row / 32)][n][2].  The sums are those of the
+// values as STORED (rounded to bf16 first when C is bf16): what a statistics pass over C would read.
+typedef float gemm_f32x16 __attribute__((ext_vector_type(16)));
+template <int TM, int TN, typename TO>
+__device__ __forceinline__ void nt_col_stats(const gemm_f32x16 (&acc)[TM][TN], float *__restrict__ part, long long M, int N,
+                                             long long row0, int col0, int li, int lj) {
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+        const long long rb = row0 + 32 * i;
+        if (rb >= M) continue;                  // wave-uniform; M % 32 == 0: a 32-row block is valid or not as a whole
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+            float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                float v = acc[i][j][r];
+                if constexpr (sizeof(TO) == 2) v = (float)(__bf16)v;
+                s1 += v;
+                s2 = fmaf(v, v, s2);
+            }
+            s1 += __shfl_xor(s1, 32, 64);       // the two 16-row halves of the tile (lane groups lj = 0, 1)
+            s2 += __shfl_xor(s2, 32, 64);
+            const int n = col0 + 32 * j + li;
+            if (lj == 0 && n < N) {
+                float2 *o = reinterpret_cast<float2 *>(part + (((size_t)(rb >> 5)) * N + n) * 2);
+                *o = make_float2(s1, s2);
+            }
+        }
+    }
+}
+#endif
 
 int kernel_policy();   // c_api.hip: epn_set_kernel_policy (0x100 | cfg = NT tile override of the tuning tool)
 

@@ -211,6 +211,7 @@ __global__ __launch_bounds__(64 * WGM * WGN) void gemm_nt_kernel(GemmNtBatch B) 
 
     // ---- epilogue: D[row = (r&3) + 8 (r>>2) + 4 lj][col = li]
     TO *__restrict__ C = static_cast<TO *>(P.C);
+    if (P.stats) nt_col_stats<TM, TN, TO>(acc, P.stats, P.M, P.N, m0 + wm * TM * 32, n0 + wn * TN * 32, li, lj);
     if (m0 + BM <= P.M && n0 + BN <= P.N && (long long)BM * P.ldc < (1LL << 30)) {
         // interior tile: wave-uniform base + 32-bit lane offset; one scalar multiply and one vector add per output row.
         // (The checked form below costs ~15 VALU instructions per element -- 128 elements per lane: measured as a fixed
@@ -860,6 +861,23 @@ __global__ void cast_kernel(const TI *__restrict__ src, TO *__restrict__ dst, si
         dst[i] = (TO)(float)src[i];
 }
 
+// column statistics of the generic path: one thread per (32-row block, column) reads C back
+template <typename TO>
+__global__ void nt_stats_from_c_kernel(const TO *__restrict__ C, long long M, int N, long long ldc, float *__restrict__ part) {
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (M >> 5) * N) return;
+    const long long rb = i / N;
+    const int n = (int)(i % N);
+    float s1 = 0.f, s2 = 0.f;
+    for (int r = 0; r < 32; ++r) {
+        const float v = (float)C[(rb * 32 + r) * ldc + n];
+        s1 += v;
+        s2 = fmaf(v, v, s2);
+    }
+    part[i * 2] = s1;
+    part[i * 2 + 1] = s2;
+}
+
 // generic fallbacks (any shape, VALU): one thread per output element
 template <typename T, typename TO>
 __global__ void gemm_nt_generic_kernel(const T *__restrict__ A, const T *__restrict__ Bt, TO *__restrict__ C, long long M,
@@ -914,7 +932,7 @@ int launch_nt_typed(GemmNtBatch &B, hipStream_t st) {
     int maxn = 0, minn = 1 << 30;
     for (int i = 0; i < B.nprob; ++i) {
         const GemmNtProb &p = B.p[i];
-        if (p.M < 0 || p.N < 1 || p.K < 1) return EPN_EINVAL;
+        if (p.M < 0 || p.N < 1 || p.K < 1 || (p.stats && p.M % 32)) return EPN_EINVAL;
         if (!p.A || !p.Bt || !p.C) return EPN_ENULL;
         if (p.K % (4 * E16) || p.lda % E16 || p.ldb % E16 || ((uintptr_t)p.A & 15) || ((uintptr_t)p.Bt & 15)) fast = false;
         if (p.K % (8 * E16)) half_k = true;      // K a multiple of 4 slots only: the short-K-step kernels
@@ -930,6 +948,12 @@ int launch_nt_typed(GemmNtBatch &B, hipStream_t st) {
                                static_cast<const T *>(p.A), static_cast<const T *>(p.Bt), static_cast<TO *>(p.C), p.M,
                                p.N, p.K, p.lda, p.ldb, p.ldc);
             EPN_CHECK_LAUNCH();
+            if (p.stats) {
+                const long long ns = (p.M >> 5) * p.N;
+                EPN_LAUNCH_AUX((nt_stats_from_c_kernel<TO>), dim3((unsigned)((ns + 255) / 256)), dim3(256), 0, st,
+                               static_cast<const TO *>(p.C), p.M, p.N, p.ldc, p.stats);
+                EPN_CHECK_LAUNCH();
+            }
         }
         return 0;
     }
@@ -1255,7 +1279,7 @@ static int nt_entry(int nprob, const epn_gemm_nt_problem *probs, int dtype, int 
             const epn_gemm_nt_problem &q = probs[i0 + i];
             GemmNtProb &p = B.p[i];
             p.A = q.A; p.Bt = q.Bt; p.C = q.C; p.M = q.M; p.N = q.N; p.K = q.K; p.lda = q.lda; p.ldb = q.ldb; p.ldc = q.ldc;
-            p.tiles_n = 0; p.tile0 = 0;
+            p.tiles_n = 0; p.tile0 = 0; p.stats = q.col_stats;
         }
         int rc = launch_gemm_nt(B, dtype, out_dtype, st);
         if (rc) return rc;

@@ -213,6 +213,7 @@ __global__ __launch_bounds__(64 * WGM * WGN) void gemm_nt_x3_kernel(GemmNtBatch 
 
     // ---- epilogue: D[row = (r&3) + 8 (r>>2) + 4 lj][col = li]   (as gemm_nt_kernel)
     float *__restrict__ C = static_cast<float *>(P.C);
+    if (P.stats) nt_col_stats<TM, TN, float>(acc, P.stats, P.M, P.N, m0 + wm * TM * 32, n0 + wn * TN * 32, li, lj);
     if (m0 + BM <= P.M && n0 + BN <= P.N && (long long)BM * P.ldc < (1LL << 30)) {
         float *__restrict__ cw = C + (size_t)(m0 + wm * TM * 32) * P.ldc + (n0 + wn * TN * 32);
         const unsigned ldc = (unsigned)P.ldc;
@@ -270,6 +271,7 @@ bool gemm_nt_x3_ok(const GemmNtBatch &B) {
     for (int i = 0; i < B.nprob; ++i) {
         const GemmNtProb &p = B.p[i];
         if (p.M < 1 || p.N < 1 || p.K < 32 || p.K % 32 || p.lda % 4 || ((uintptr_t)p.A & 15) || !p.A || !p.Bt || !p.C) return false;
+        if (p.stats && p.M % 32) return false;     // (launch_gemm_nt reports the error)
     }
     return B.nprob >= 1 && B.nprob <= GEMM_MAX_PROB;
 }
@@ -348,7 +350,7 @@ extern "C" int epn_gemm_nt_split_f32(int nprob, const epn_gemm_nt_problem *probs
             const epn_gemm_nt_problem &q = probs[i0 + i];
             GemmNtProb &p = B.p[i];
             p.A = q.A; p.Bt = q.Bt; p.C = q.C; p.M = q.M; p.N = q.N; p.K = q.K; p.lda = q.lda; p.ldb = q.ldb; p.ldc = q.ldc;
-            p.tiles_n = 0; p.tile0 = 0; p.ntile = 0; p.Bp = nullptr;
+            p.tiles_n = 0; p.tile0 = 0; p.ntile = 0; p.Bp = nullptr; p.stats = q.col_stats;
         }
         const size_t need = gemm_nt_x3_workspace(B);
         int rc = launch_gemm_nt_x3(B, need <= left ? w : nullptr, need <= left ? need : 0, st);

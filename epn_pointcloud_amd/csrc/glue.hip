@@ -119,6 +119,29 @@ __global__ __launch_bounds__(256) void stats_finish_kernel(const float *__restri
     }
 }
 
+// First level for long partial lists: part2[g][z][e] = sum of blocks [256 z, 256 z + 256) of part[g][.][e].
+// 256 threads = 64 entries (coalesced) x 4 slices of the block range; fixed order -> deterministic.
+__global__ __launch_bounds__(256) void stats_reduce_kernel(const float *__restrict__ part, int nb, int c2,
+                                                           float *__restrict__ part2) {
+    __shared__ float red[4][64];
+    const int el = threadIdx.x & 63, sl = threadIdx.x >> 6;
+    const int e = blockIdx.x * 64 + el, z = blockIdx.y, g = blockIdx.z;
+    const int b0 = z * 256, b1 = min(b0 + 256, nb);
+    float a4[4] = {0.f, 0.f, 0.f, 0.f};
+    if (e < c2) {
+        const float *p = part + (size_t)g * nb * c2 + e;
+        int b = b0 + sl;
+        for (; b + 12 < b1; b += 16)
+#pragma unroll
+            for (int u = 0; u < 4; ++u) a4[u] += p[(size_t)(b + 4 * u) * c2];
+        for (; b < b1; b += 4) a4[0] += p[(size_t)b * c2];
+    }
+    red[sl][el] = (a4[0] + a4[1]) + (a4[2] + a4[3]);
+    __syncthreads();
+    if (sl == 0 && e < c2)
+        part2[((size_t)g * gridDim.y + z) * c2 + e] = (red[0][el] + red[1][el]) + (red[2][el] + red[3][el]);
+}
+
 // backward: per (g, ch): (sa, sb) = sum_b part;  dsums = gamma * (sa, sb);  dgamma / dbeta accumulate over groups
 // (groups > 1 only for InstanceNorm, which has no affine parameters -> plain stores suffice when groups == 1)
 __global__ __launch_bounds__(256) void bwd_finish_kernel(const float *__restrict__ part, int nb, int c,
@@ -697,6 +720,38 @@ extern "C" int epn_bn_running_update_f32(const float *sums, double count, const 
     if (!sums || !running_mean || !running_var || !num_batches_tracked) return EPN_ENULL;
     EPN_LAUNCH(bn_running_update_kernel, dim3(1), dim3(1024), 0, epn_stream(stream), sums, (float)count, conv_bias,
                        running_mean, running_var, num_batches_tracked, momentum, c);
+    EPN_CHECK_LAUNCH();
+    return 0;
+}
+
+// epilogue partials are one row per 32 tensor rows (30720 of them for the first cls layer): reduced 256 rows at a time
+// first, then by stats_finish_kernel
+constexpr int STATS_ZB = 256;
+static long long stats_finish_nz(long long blocks) { return blocks > 2048 ? (blocks + STATS_ZB - 1) / STATS_ZB : 0; }
+
+extern "C" size_t epn_stats_finish_workspace_bytes(int groups, long long blocks_per_group, int c) {
+    if (groups < 1 || blocks_per_group < 1 || c < 1) return 0;
+    return sizeof(float) * (size_t)groups * stats_finish_nz(blocks_per_group) * c * 2;
+}
+
+extern "C" int epn_stats_finish(const float *partials, int groups, long long blocks_per_group, int c, float *sums,
+                                void *workspace, size_t workspace_bytes, epn_stream_t stream) {
+    if (groups < 0 || blocks_per_group < 0 || c < 1 || blocks_per_group > 0x7fffffffLL) return EPN_EINVAL;
+    if (groups == 0) return 0;
+    if (!sums || (blocks_per_group && !partials)) return EPN_ENULL;
+    hipStream_t st = epn_stream(stream);
+    const long long nz = stats_finish_nz(blocks_per_group);
+    if (nz) {
+        if (!workspace || workspace_bytes < epn_stats_finish_workspace_bytes(groups, blocks_per_group, c)) return EPN_EWORKSPACE;
+        float *part2 = static_cast<float *>(workspace);
+        EPN_LAUNCH(stats_reduce_kernel, dim3(epn_cdiv(2 * c, 64), (unsigned)nz, groups), dim3(256), 0, st, partials,
+                   (int)blocks_per_group, c * 2, part2);
+        EPN_CHECK_LAUNCH();
+        partials = part2;
+        blocks_per_group = nz;
+    }
+    EPN_LAUNCH(stats_finish_kernel, dim3(epn_cdiv(2 * c, 16), groups), dim3(256), 0, st, partials, (int)blocks_per_group,
+               c * 2, sums);
     EPN_CHECK_LAUNCH();
     return 0;
 }

@@ -28,6 +28,9 @@ struct SbArgs {
     float neps, nslope, ninv_rows;
     int ngroups;
     long long npts_per_group;
+    // optional: per-channel (sum, sum of squares) over the na output rows of every point, pstats[pt][c][2] -- the block
+    // partials of the statistics a norm after the transform needs (epn_stats_finish sums them), from the accumulators
+    float *pstats;
 };
 
 // per-lane normalisation of its 4 channels: n = (v - mean) * rstd * gamma + beta, leaky (the formula of glue.hip's
@@ -65,6 +68,36 @@ __device__ __forceinline__ f32x4 sb_ld(const __bf16 *p) {
     const sbf16x4 v = *reinterpret_cast<const sbf16x4 *>(p);
     return f32x4{(float)v[0], (float)v[1], (float)v[2], (float)v[3]};
 }
+// acc[mt][nt][rr] = output row 16 mt + 4 j + rr, channel choff0 + nt of one point (rows >= na are exact zeros: M is zero
+// padded): per-channel sums over the rows, of the values as stored (BF: rounded to bf16), lane groups j combined by DPP-free
+// shuffles, lanes of group j = 0 write their 4 channels
+template <bool BF>
+__device__ __forceinline__ void sb_point_stats(const f32x4 (&acc)[4][4], float *__restrict__ pstats, long long pt, int c,
+                                               int choff0, bool cval, int j) {
+    float s1[4], s2[4];
+#pragma unroll
+    for (int nt = 0; nt < 4; ++nt) {
+        float a = 0.f, b = 0.f;
+#pragma unroll
+        for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+            for (int rr = 0; rr < 4; ++rr) {
+                float v = acc[mt][nt][rr];
+                if constexpr (BF) v = (float)(__bf16)v;
+                a += v;
+                b = fmaf(v, v, b);
+            }
+        a += __shfl_xor(a, 16, 64); b += __shfl_xor(b, 16, 64);
+        a += __shfl_xor(a, 32, 64); b += __shfl_xor(b, 32, 64);
+        s1[nt] = a; s2[nt] = b;
+    }
+    if (j == 0 && cval) {
+        f32x4 *o = reinterpret_cast<f32x4 *>(pstats + ((size_t)pt * c + choff0) * 2);
+        o[0] = f32x4{s1[0], s2[0], s1[1], s2[1]};
+        o[1] = f32x4{s1[2], s2[2], s1[3], s2[3]};
+    }
+}
+
 __device__ __forceinline__ void sb_st(float *p, f32x4 v) { *reinterpret_cast<f32x4 *>(p) = v; }
 __device__ __forceinline__ void sb_st(__bf16 *p, f32x4 v) {
     *reinterpret_cast<sbf16x4 *>(p) = sbf16x4{(__bf16)v[0], (__bf16)v[1], (__bf16)v[2], (__bf16)v[3]};
@@ -137,6 +170,7 @@ __global__ __launch_bounds__(64 * SB_WAVES) void so3_basis_kernel(SbArgs A) {
                 }
             }
         }
+        if (A.pstats) sb_point_stats<sizeof(T) == 2>(acc, A.pstats, pt, A.c, choff0, cval, j);
         // acc[mt][nt][rr]: output row 16 mt + 4 j + rr, channel 4 x + nt
 #pragma unroll
         for (int mt = 0; mt < 4; ++mt)
@@ -250,6 +284,7 @@ __global__ __launch_bounds__(64 * SB_WAVES) void so3_basis_bf16_kernel(SbArgs A)
                 }
             }
         }
+        if (A.pstats) sb_point_stats<true>(acc, A.pstats, pt, A.c, choff0, cval, j);
         // acc[mt][nt][rr]: output row 16 mt + 4 j + rr, channel 4 x + nt
 #pragma unroll
         for (int mt = 0; mt < 4; ++mt)
@@ -378,6 +413,7 @@ __global__ __launch_bounds__(64 * SB_WAVES) __attribute__((amdgpu_waves_per_eu(2
 #undef EPN_SB_TERM
             }
         }
+        if (A.pstats) sb_point_stats<false>(acc, A.pstats, pt, A.c, choff0, cval, j);
         // acc[mt][nt][rr]: output row 16 mt + 4 j + rr, channel 4 x + nt
 #pragma unroll
         for (int mt = 0; mt < 4; ++mt)
@@ -406,12 +442,12 @@ struct SbNormHost {
 
 static int so3_basis_any(const void *in, const float *M, const int32_t *blocks, long long pts, int na, int c,
                         int in_spectral, int out_spectral, void *out, int bf16, epn_stream_t stream,
-                        const SbNormHost *nh = nullptr) {
+                        const SbNormHost *nh = nullptr, float *point_stats = nullptr) {
     if (pts < 0 || na < 4 || na > 64 || (na & 3) || c < 32 || (c & 31)) return EPN_EINVAL;
     if (pts == 0) return 0;
     if (!in || !M || !blocks || !out) return EPN_ENULL;
     SbArgs A;
-    A.in = in; A.M = M; A.blk = blocks; A.out = out; A.pts = pts; A.na = na; A.c = c;
+    A.in = in; A.M = M; A.blk = blocks; A.out = out; A.pts = pts; A.na = na; A.c = c; A.pstats = point_stats;
     A.in_spec = in_spectral; A.out_spec = out_spectral;
     A.nsums = nullptr; A.ngamma = A.nbeta = nullptr; A.neps = 0.f; A.nslope = 0.f; A.ninv_rows = 0.f; A.ngroups = 1;
     A.npts_per_group = pts;
@@ -444,6 +480,27 @@ extern "C" int epn_so3_basis_split_f32(const float *in, const float *M, const in
 extern "C" int epn_so3_basis_bf16(const void *in, const float *M, const int32_t *blocks, long long pts, int na, int c,
                                   int in_spectral, int out_spectral, void *out, epn_stream_t stream) {
     return so3_basis_any(in, M, blocks, pts, na, c, in_spectral, out_spectral, out, 1, stream);
+}
+
+// the change of basis + per-point block partials of the output's per-channel statistics (see SbArgs::pstats)
+extern "C" int epn_so3_basis_stats_f32(const float *in, const float *M, const int32_t *blocks, long long pts, int na, int c,
+                                       int in_spectral, int out_spectral, float *out, float *point_stats, epn_stream_t stream) {
+    if (!point_stats) return EPN_ENULL;
+    if (out_spectral) return EPN_EINVAL;      // statistics over the ANCHOR rows of a point: plain output layout only
+    return so3_basis_any(in, M, blocks, pts, na, c, in_spectral, out_spectral, out, 0, stream, nullptr, point_stats);
+}
+extern "C" int epn_so3_basis_stats_split_f32(const float *in, const float *M, const int32_t *blocks, long long pts, int na,
+                                             int c, int in_spectral, int out_spectral, float *out, float *point_stats,
+                                             epn_stream_t stream) {
+    if (!point_stats) return EPN_ENULL;
+    if (out_spectral) return EPN_EINVAL;      // statistics over the ANCHOR rows of a point: plain output layout only
+    return so3_basis_any(in, M, blocks, pts, na, c, in_spectral, out_spectral, out, 2, stream, nullptr, point_stats);
+}
+extern "C" int epn_so3_basis_stats_bf16(const void *in, const float *M, const int32_t *blocks, long long pts, int na, int c,
+                                        int in_spectral, int out_spectral, void *out, float *point_stats, epn_stream_t stream) {
+    if (!point_stats) return EPN_ENULL;
+    if (out_spectral) return EPN_EINVAL;      // statistics over the ANCHOR rows of a point: plain output layout only
+    return so3_basis_any(in, M, blocks, pts, na, c, in_spectral, out_spectral, out, 1, stream, nullptr, point_stats);
 }
 
 // leaky_relu(norm(in)) applied on load, then the change of basis (in plain layout only): sums[g][c] = (sum x, sum x^2)

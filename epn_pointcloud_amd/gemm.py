@@ -53,9 +53,11 @@ def _problem(A, Bt, C):
     return p
 
 
-def gemm_nt_grouped(problems, out_dtype=None):
+def gemm_nt_grouped(problems, out_dtype=None, col_stats=None):
     """problems: list of (A [M,K], Bt [N,K], C [M,N] or None); one grouped launch per 6 problems.  Returns the C list.
-    All operands share one dtype (fp32 or bf16); C is that dtype unless out_dtype says float32."""
+    All operands share one dtype (fp32 or bf16); C is that dtype unless out_dtype says float32.  col_stats: optional list
+    (one entry per problem) of fp32 [M/32, N, 2] tensors the kernels fill with per-column (sum, sum of squares) of every
+    32-row block of C from their accumulators (None entries: off)."""
     lib = _lib.get_lib()
     arr = (_lib.GemmNtProblem * len(problems))()
     outs, keep = [], []
@@ -74,6 +76,12 @@ def gemm_nt_grouped(problems, out_dtype=None):
         elif C.dtype != odt or C.stride(1) != 1 or tuple(C.shape) != (A.shape[0], Bt.shape[0]):
             raise ValueError("gemm_nt: output must be row-major [M,N] of the output dtype")
         arr[i] = _problem(A, Bt, C)
+        if col_stats is not None and col_stats[i] is not None:
+            part = col_stats[i]
+            if (part.dtype != torch.float32 or not part.is_contiguous() or A.shape[0] % 32
+                    or part.numel() != A.shape[0] // 32 * Bt.shape[0] * 2):
+                raise ValueError("gemm_nt: col_stats must be a contiguous fp32 [M/32, N, 2] tensor, M % 32 == 0")
+            arr[i].col_stats = part.data_ptr()
         outs.append(C)
         keep += [A, Bt]
     st = _lib.stream_of(outs[0])
@@ -89,8 +97,14 @@ def gemm_nt_grouped(problems, out_dtype=None):
     return outs
 
 
-def gemm_nt(A, Bt, out=None, out_dtype=None):
-    return gemm_nt_grouped([(A, Bt, out)], out_dtype)[0]
+def gemm_nt(A, Bt, out=None, out_dtype=None, col_stats=False):
+    """col_stats=True: returns (C, partials [M/32, N, 2] or None when M % 32 != 0) -- the per-channel statistics of C
+    from the kernel's epilogue (ops.sums_from_partials finishes them)."""
+    if not col_stats:
+        return gemm_nt_grouped([(A, Bt, out)], out_dtype)[0]
+    M, N = A.shape[0], Bt.shape[0]
+    part = torch.empty((M // 32, N, 2), dtype=torch.float32, device=A.device) if M % 32 == 0 and M > 0 else None
+    return gemm_nt_grouped([(A, Bt, out)], out_dtype, [part])[0], part
 
 
 def gemm_tn(X, Y, out=None):
@@ -175,15 +189,22 @@ class MatmulNT(torch.autograd.Function):
     dA = dC @ W (NT against W^T), dW = dC^T @ A (TN, fp32)."""
 
     @staticmethod
-    def forward(ctx, A, W):
+    def forward(ctx, A, W, col_stats=False):
         from . import ops
         Wc = W if W.dtype == A.dtype else cast(W, A.dtype)
         ctx.save_for_backward(A, W)
         M, K, N = A.shape[0], A.shape[1], W.shape[0]
-        return ops._launch("conv1x1_gemm", ("nt", M, N, K), 2.0 * M * N * K, A.device, lambda: gemm_nt(A, Wc))
+        if not col_stats:
+            return ops._launch("conv1x1_gemm", ("nt", M, N, K), 2.0 * M * N * K, A.device, lambda: gemm_nt(A, Wc))
+        # (C, partial column statistics of C from the kernel's epilogue; an empty tensor when M % 32 != 0)
+        C, part = ops._launch("conv1x1_gemm", ("nt", M, N, K), 2.0 * M * N * K, A.device,
+                              lambda: gemm_nt(A, Wc, col_stats=True))
+        part = part if part is not None else torch.empty(0, dtype=torch.float32, device=A.device)
+        ctx.mark_non_differentiable(part)
+        return C, part
 
     @staticmethod
-    def backward(ctx, dC):
+    def backward(ctx, dC, _dpart=None):
         A, W = ctx.saved_tensors
         dC = dC if dC.dtype == A.dtype else dC.to(A.dtype)
         from . import ops
@@ -194,8 +215,8 @@ class MatmulNT(torch.autograd.Function):
             dA = ops._launch("conv1x1_gemm", ("nt", M, K, N), 2.0 * M * N * K, A.device, lambda: gemm_nt(dC, Wt))
         if ctx.needs_input_grad[1]:
             dW = ops._launch("conv1x1_gemm_dw", ("tn", M, N, K), 2.0 * M * N * K, A.device, lambda: gemm_tn(dC, A))
-        return dA, dW
+        return dA, dW, None
 
 
-def matmul_nt(A, W):
-    return MatmulNT.apply(A, W)
+def matmul_nt(A, W, col_stats=False):
+    return MatmulNT.apply(A, W, col_stats)

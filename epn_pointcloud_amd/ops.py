@@ -106,7 +106,7 @@ def empty_cl(b, c, p, a, device, dtype=torch.float32):
 def _entry(lib, base, dtype):
     """C entry point of `base` for a feature dtype: epn_<base>_f32 | epn_<base>_bf16; the fp32 change of basis has a
     split form (bf16 matrix pipe, fp32 accuracy) that follows the GEMMs' switch (gemm.FP32_MODE)."""
-    if dtype != torch.bfloat16 and base in ("so3_basis", "so3_basis_norm") and gemm.FP32_MODE == "split":
+    if dtype != torch.bfloat16 and base in ("so3_basis", "so3_basis_norm", "so3_basis_stats") and gemm.FP32_MODE == "split":
         return getattr(lib, f"epn_{base}_split_f32")
     return getattr(lib, f"epn_{base}_{'bf16' if dtype == torch.bfloat16 else 'f32'}")
 
@@ -359,14 +359,22 @@ class InterSO3ConvSplitFn(torch.autograd.Function):
                                                                   _lib.stream_of(f)), "inter_pack_weights")
         else:
             Wd = gemm.cast(Wc, f.dtype)                              # fp32 master weights; bf16 copy per call
-        out2d = _launch("inter_gemm", _inter_key(d), 2.0 * cols * cout * ck, f.device, lambda: gemm.gemm_nt(G, Wd))
+        if share_input:        # a block asks: its norm follows -- per-channel statistics from the GEMM's epilogue
+            out2d, part = _launch("inter_gemm", _inter_key(d), 2.0 * cols * cout * ck, f.device,
+                                  lambda: gemm.gemm_nt(G, Wd, col_stats=True))
+            part = part if part is not None else torch.empty(0, dtype=torch.float32, device=f.device)
+        else:
+            out2d = _launch("inter_gemm", _inter_key(d), 2.0 * cols * cout * ck, f.device, lambda: gemm.gemm_nt(G, Wd))
         ctx.save_for_backward(G, Wc)
         ctx.geo, ctx.cin, ctx.packed = geo, cin, packed
         out = out2d.view(d.b, d.p2, d.na, cout).permute(0, 3, 1, 2)
-        return (out, feats) if share_input else out
+        if share_input:
+            ctx.mark_non_differentiable(part)
+            return out, feats, part
+        return out
 
     @staticmethod
-    def backward(ctx, grad_out, grad_shared=None):
+    def backward(ctx, grad_out, grad_shared=None, _grad_part=None):
         lib = _lib.get_lib()
         G, Wc = ctx.saved_tensors
         geo, cin = ctx.geo, ctx.cin
@@ -816,21 +824,33 @@ class FromSpectralFn(torch.autograd.Function):
     """flat spectral buffer -> [b,c,p,a] channels-last (out[a] = sum_f U[a,f] y[f]); backward is ToSpectral."""
 
     @staticmethod
-    def forward(ctx, y, basis, b, p, c):
+    def forward(ctx, y, basis, b, p, c, out_stats=False):
         lib = _lib.get_lib()
         out = empty_cl(b, c, p, basis.na, y.device, y.dtype)
-        _basis_call(lib, y.contiguous(), basis.U, basis, b * p, c, 1, 0, out, "so3_basis")
         ctx.basis, ctx.dims = basis, (b, c, p)
-        return out
+        if not out_stats:
+            _basis_call(lib, y.contiguous(), basis.U, basis, b * p, c, 1, 0, out, "so3_basis")
+            return out
+        # + per-point partials of out's per-channel statistics, from the accumulators (epn_so3_basis_stats_*)
+        part = torch.empty((b * p, c, 2), dtype=torch.float32, device=y.device)
+        src = y.contiguous()
+        fn = _entry(lib, "so3_basis_stats", src.dtype)
+        _lib.check(_launch("so3_basis", ("so3_basis", b * p, c), 2.0 * b * p * basis.na * basis.na * c, src.device,
+                           lambda: fn(ctypes.c_void_p(src.data_ptr()), _lib.dev_ptr(basis.U, "M"),
+                                      _lib.dev_ptr(basis.blocks, "blocks", torch.int32), ctypes.c_longlong(b * p), basis.na,
+                                      c, 1, 0, ctypes.c_void_p(out.data_ptr()), ctypes.c_void_p(part.data_ptr()),
+                                      _lib.stream_of(src))), "so3_basis_stats")
+        ctx.mark_non_differentiable(part)
+        return out, part
 
     @staticmethod
-    def backward(ctx, gout):
+    def backward(ctx, gout, _gpart=None):
         lib = _lib.get_lib()
         b, c, p = ctx.dims
         g = to_cl(gout, "grad_out")
         gy = torch.empty(ctx.basis.na * b * p * c, dtype=g.dtype, device=g.device)
         _basis_call(lib, g, ctx.basis.Ut, ctx.basis, b * p, c, 0, 1, gy, "so3_basis")
-        return gy, None, None, None, None
+        return gy, None, None, None, None, None
 
 
 class _BlockGemmsFn(torch.autograd.Function):
@@ -882,7 +902,7 @@ class _BlockGemmsFn(torch.autograd.Function):
         return (gy, None, None, None, None, *gws)
 
 
-def intra_so3conv_spectral(feats, W, intra_idx32, basis, pre_norm=None, pre_slope=0.01):
+def intra_so3conv_spectral(feats, W, intra_idx32, basis, pre_norm=None, pre_slope=0.01, pre_part=None, out_stats=False):
     """IntraSO3Conv.forward (vgtk/vgtk/so3conv/modules.py:197-200) in the block-diagonal anchor basis: same result up to
     fp32 rounding, 244 instead of 720 multiply-adds per (point, cin, cout), no [cols, 12*cin] grouped tensor; gradients
     by autograd through the same pieces (GEMMs and transforms on this library's HIP kernels)."""
@@ -897,7 +917,7 @@ def intra_so3conv_spectral(feats, W, intra_idx32, basis, pre_norm=None, pre_slop
         import torch.nn as nn
         inst = isinstance(pre_norm, nn.InstanceNorm2d)
         y, sums = NormToSpectralFn.apply(f, getattr(pre_norm, "weight", None), getattr(pre_norm, "bias", None), None,
-                                         inst, pre_norm.eps, pre_slope, basis)
+                                         inst, pre_norm.eps, pre_slope, basis, pre_part)
         _update_running_stats(pre_norm, sums, b * p * na)
     else:
         y = ToSpectralFn.apply(f, basis)
@@ -906,7 +926,7 @@ def intra_so3conv_spectral(feats, W, intra_idx32, basis, pre_norm=None, pre_slop
     whats = [wh_all[:, base:base + d * d].reshape(cout, cin, d, d).permute(3, 1, 2, 0).reshape(d * cin, d * cout)
              for d, base in zip(basis.dims, basis.bases)]
     z = _BlockGemmsFn.apply(y, basis, pts, cin, cout, *whats)
-    return FromSpectralFn.apply(z, basis, b, p, cout)
+    return FromSpectralFn.apply(z, basis, b, p, cout, out_stats)      # out_stats: (out, per-point statistics partials)
 
 
 def norm_act_supported(c):
@@ -969,14 +989,17 @@ class NormActPairFn(torch.autograd.Function):
     output gradient is read once per pass.  Returns (y, sums_a, sums_b)."""
 
     @staticmethod
-    def forward(ctx, xa, xb, gamma_a, beta_a, gamma_b, beta_b, conv_bias_b, inst_a, inst_b, eps_a, eps_b, slope):
+    def forward(ctx, xa, xb, gamma_a, beta_a, gamma_b, beta_b, conv_bias_b, inst_a, inst_b, eps_a, eps_b, slope,
+                part_b=None, part_a=None):
         lib = _lib.get_lib()
         xac = to_cl(xa, "xa")
-        xbc = cast_feats(to_cl(xb, "xb"), xac.dtype)
+        xbc = to_cl(xb, "xb")
+        if xbc.dtype != xac.dtype:
+            xbc, part_b = cast_feats(xbc, xac.dtype), None      # statistics of the values the kernel will read
         b, c, p, a = xac.shape
         rows = p * a
-        sums_a = _chan_stats(xac, b if inst_a else 1, rows if inst_a else b * rows, c)
-        sums_b = _chan_stats(xbc, b if inst_b else 1, rows if inst_b else b * rows, c)
+        sums_a = _stats(xac, b if inst_a else 1, rows if inst_a else b * rows, c, part_a, a)   # one block per point
+        sums_b = _stats(xbc, b if inst_b else 1, rows if inst_b else b * rows, c, part_b)
         ga, ba = (t.contiguous() if t is not None else None for t in (gamma_a, beta_a))
         gb, bb = (t.contiguous() if t is not None else None for t in (gamma_b, beta_b))
         y = empty_cl(b, c, p, a, xac.device, xac.dtype)
@@ -1022,18 +1045,20 @@ class NormActPairFn(torch.autograd.Function):
                                                        _cl_ptr(dxb) if dxb is not None else ctypes.c_void_p(0), bf,
                                                        _lib.stream_of(xac)), "norm_act_pair_bwd_apply")
         dcb = torch.zeros(c, **f32) if has_cb else None       # a bias the normalisation cancels: exact gradient 0
-        return dxa, dxb, dga, dba, dgb, dbb, dcb, None, None, None, None, None
+        return dxa, dxb, dga, dba, dgb, dbb, dcb, None, None, None, None, None, None, None
 
 
-def norm_act_pair(xa, norm_a, xb, norm_b, conv_bias_b=None, slope=0.01):
+def norm_act_pair(xa, norm_a, xb, norm_b, conv_bias_b=None, slope=0.01, part_b=None, part_a=None):
     """leaky_relu(norm_a(xa)) + leaky_relu(norm_b(xb)) in one pass (training mode); norm_* an nn.BatchNorm2d or
     nn.InstanceNorm2d(affine=False) whose parameters / running statistics are used and updated as the module would.
-    conv_bias_b: bias of the convolution that produced xb, NOT added to xb (see norm_act)."""
+    conv_bias_b: bias of the convolution that produced xb, NOT added to xb (see norm_act).  part_b: block partials of xb's
+    per-channel statistics from the epilogue of the GEMM that produced it (conv1x1(..., col_stats=True)); part_a: per-point
+    partials of xa's from the inverse basis change (intra_so3conv(..., out_stats=True))."""
     import torch.nn as nn
     ia, ib = isinstance(norm_a, nn.InstanceNorm2d), isinstance(norm_b, nn.InstanceNorm2d)
     y, sums_a, sums_b = NormActPairFn.apply(xa, xb, getattr(norm_a, "weight", None), getattr(norm_a, "bias", None),
                                             getattr(norm_b, "weight", None), getattr(norm_b, "bias", None), conv_bias_b,
-                                            ia, ib, norm_a.eps, norm_b.eps, slope)
+                                            ia, ib, norm_a.eps, norm_b.eps, slope, part_b, part_a)
     n = xa.shape[0] * xa.shape[2] * xa.shape[3]
     _update_running_stats(norm_a, sums_a, n)
     _update_running_stats(norm_b, sums_b, n, conv_bias_b)
@@ -1049,6 +1074,27 @@ def _chan_stats(xc, groups, rows, c):
                                                    ctypes.c_void_p(ws.data_ptr()), ctypes.c_size_t(ws.numel()),
                                                    _lib.stream_of(xc)), "chan_stats")
     return sums
+
+
+def sums_from_partials(part, groups, rows, c, block_rows=32):
+    """sums[g][c][2] from the [rows_total / block_rows, c, 2] block partials a producer wrote from its accumulators
+    (gemm_nt(..., col_stats=True): 32-row blocks; the inverse basis change: one block per point = na rows); None when they
+    do not apply (no partials, or a group's rows are not whole blocks)."""
+    if part is None or part.numel() == 0 or rows % block_rows or part.numel() != groups * (rows // block_rows) * c * 2:
+        return None
+    lib = _lib.get_lib()
+    nb = rows // block_rows
+    sums = torch.empty((groups, c, 2), dtype=torch.float32, device=part.device)
+    ws = torch.empty(max(int(lib.epn_stats_finish_workspace_bytes(groups, nb, c)), 16), dtype=torch.uint8, device=part.device)
+    _lib.check(lib.epn_stats_finish(part.data_ptr(), groups, nb, c, sums.data_ptr(), ws.data_ptr(), ws.numel(),
+                                    _lib.stream_of(part)), "stats_finish")
+    return sums
+
+
+def _stats(xc, groups, rows, c, part=None, block_rows=32):
+    """Per-channel statistics of xc: finished from its producer's epilogue partials when there are any, else a pass over xc."""
+    sums = sums_from_partials(part, groups, rows, c, block_rows) if part is not None else None
+    return sums if sums is not None else _chan_stats(xc, groups, rows, c)
 
 
 def _norm_act_backward(xc, dy, sums, g, bt, groups, rows, c, eps, slope, need_dx):
@@ -1080,12 +1126,12 @@ class NormToSpectralFn(torch.autograd.Function):
     inverse transform of the spectral gradient, then the two norm passes of NormActFn.  Returns (y_spectral, sums)."""
 
     @staticmethod
-    def forward(ctx, x, gamma, beta, conv_bias, instance, eps, slope, basis):
+    def forward(ctx, x, gamma, beta, conv_bias, instance, eps, slope, basis, part=None):
         lib = _lib.get_lib()
         xc = to_cl(x, "x")
         b, c, p, na = xc.shape
         groups, rows = (b, p * na) if instance else (1, b * p * na)
-        sums = _chan_stats(xc, groups, rows, c)
+        sums = _stats(xc, groups, rows, c, part)           # part: block partials from the epilogue of x's producer
         g = gamma.contiguous() if gamma is not None else None
         bt = beta.contiguous() if beta is not None else None
         y = torch.empty(na * b * p * c, dtype=xc.dtype, device=xc.device)
@@ -1111,7 +1157,7 @@ class NormToSpectralFn(torch.autograd.Function):
         _basis_call(lib, cast_feats(gy.contiguous(), xc.dtype), ctx.basis.U, ctx.basis, b * p, c, 1, 0, gf, "so3_basis")
         dx, dg, db = _norm_act_backward(xc, gf, sums, g, bt, groups, rows, c, eps, slope, ctx.needs_input_grad[0])
         dcb = torch.zeros(c, dtype=torch.float32, device=xc.device) if has_cb else None
-        return dx, dg, db, dcb, None, None, None, None
+        return dx, dg, db, dcb, None, None, None, None, None
 
 
 def _update_running_stats(norm, sums, n, conv_bias=None):
@@ -1186,9 +1232,10 @@ def inter_mode():
 
 def inter_so3conv(feats, W, geo, out_dtype=None, share_input=False):
     """InterSO3Conv's compute.  out_dtype (default: the dtype of feats) lets the fp32 first layer (cin = 1, all-ones
-    occupancy features) hand bf16 features to the rest of a bf16 network.  share_input: return (out, feats') where feats'
-    is `feats` for the caller's OTHER uses of it (InterSO3ConvSplitFn.forward: its gradient is then folded into the
-    convolution's own data gradient; the forms without that fold return `feats` itself)."""
+    occupancy features) hand bf16 features to the rest of a bf16 network.  share_input: return (out, feats', part) where
+    feats' is `feats` for the caller's OTHER uses of it (InterSO3ConvSplitFn.forward: its gradient is then folded into the
+    convolution's own data gradient; the forms without that fold return `feats` itself) and part the block partials of
+    out's per-channel statistics from the GEMM epilogue (or None)."""
     if share_input:
         mode = inter_mode()
         plain = (feats.shape[1] % 16 != 0 or isinstance(geo, DenseInterWeights) or not feats.is_cuda or mode not in ("auto", "split")
@@ -1198,9 +1245,11 @@ def inter_so3conv(feats, W, geo, out_dtype=None, share_input=False):
                        geo.kernels.shape[0] * 4)
             plain = mode == "auto" and g_bytes > _device_bytes(feats.device) // 8
         if plain:
-            return inter_so3conv(feats, W, geo, out_dtype), feats
-        out, shared = InterSO3ConvSplitFn.apply(feats, W, geo, True)
-        return cast_feats(out, out_dtype or feats.dtype), shared
+            return inter_so3conv(feats, W, geo, out_dtype), feats, None
+        out, shared, part = InterSO3ConvSplitFn.apply(feats, W, geo, True)
+        if (out_dtype or feats.dtype) != out.dtype:
+            return cast_feats(out, out_dtype), shared, None      # statistics must be those of the values handed on
+        return out, shared, (part if part.numel() else None)
     mode = inter_mode()
     out_dtype = out_dtype or feats.dtype
     split_ok = feats.shape[1] % 16 == 0 and not isinstance(geo, DenseInterWeights)
@@ -1251,16 +1300,27 @@ def intra_takes_spectral(cin, cout, intra_idx32, is_cuda=True):
             and intra_idx32.shape[1] > 1 and spectral_basis(intra_idx32) is not None)
 
 
-def intra_so3conv(feats, W, intra_idx32, pre_norm=None):
+def intra_so3conv(feats, W, intra_idx32, pre_norm=None, pre_part=None, out_stats=False):
     """pre_norm: an nn.BatchNorm2d / nn.InstanceNorm2d(affine=False) whose leaky_relu(norm(feats)) is the actual input
-    (training mode); only with intra_takes_spectral(...) -- other forms get the normalised tensor from ops.norm_act."""
+    (training mode); only with intra_takes_spectral(...) -- other forms get the normalised tensor from ops.norm_act.
+    pre_part: block partials of feats' per-channel statistics from its producer's epilogue (spectral form only).
+    out_stats: return (out, part) -- part = per-point partials of out's statistics (spectral form) or None."""
+    if out_stats:
+        mode = intra_mode()
+        cin, cout = feats.shape[1], W.shape[0]
+        if mode in ("auto", "spectral") and feats.is_cuda and cin % 32 == 0 and cout % 32 == 0 and intra_idx32.shape[1] > 1:
+            basis = spectral_basis(intra_idx32)
+            if basis is not None:
+                return intra_so3conv_spectral(feats, W, intra_idx32, basis, pre_norm=pre_norm, pre_part=pre_part,
+                                              out_stats=True)
+        return intra_so3conv(feats, W, intra_idx32, pre_norm, pre_part), None
     mode = intra_mode()
     cin, cout = feats.shape[1], W.shape[0]
     bf = feats.dtype == torch.bfloat16
     if mode in ("auto", "spectral") and feats.is_cuda and cin % 32 == 0 and cout % 32 == 0 and intra_idx32.shape[1] > 1:
         basis = spectral_basis(intra_idx32)
         if basis is not None:
-            return intra_so3conv_spectral(feats, W, intra_idx32, basis, pre_norm=pre_norm)
+            return intra_so3conv_spectral(feats, W, intra_idx32, basis, pre_norm=pre_norm, pre_part=pre_part)
     if pre_norm is not None:
         feats = norm_act(feats, pre_norm)
     if (bf and cin % 8 == 0 and cout % 8 == 0) or mode == "split" or \
@@ -1414,12 +1474,15 @@ class Conv1x1C1Fn(torch.autograd.Function):
         return gx, gw
 
 
-def conv1x1(x, weight, bias=None):
+def conv1x1(x, weight, bias=None, col_stats=False):
     """nn.Conv2d(cin, cout, 1) on a [b,c,p,a] tensor, channels-last in and out with no layout copy: one NT GEMM
     [cols, cin] x [cout, cin]^T on the zero-copy 2-D view (fp32 master weight, cast per call for bf16 features).
     bf16 widths that are only multiples of 16 run the fp32 intra GEMM kernel (single, identity anchor neighbour);
-    cin = 1 (the occupancy feature of the first block) is an outer product; odd shapes go to torch."""
+    cin = 1 (the occupancy feature of the first block) is an outer product; odd shapes go to torch.
+    col_stats=True (bias must be None): returns (y, part) -- part = the block partials of y's per-channel statistics from the
+    GEMM's epilogue (sums_from_partials / norm_act_pair(part_b=...)), or None on the paths that do not produce them."""
     cout, cin = weight.shape[0], weight.shape[1]
+    part = None
     if x.is_cuda and ((x.dtype == torch.bfloat16 and cin % 32 == 0) or (x.dtype == torch.float32 and cin % 16 == 0)):
         xc = to_cl(x)                   # K = cin is a whole number of 64-byte half K steps: the MFMA GEMM kernels
         b, c, p, a = xc.shape
@@ -1427,7 +1490,10 @@ def conv1x1(x, weight, bias=None):
         pad = (-cout) % 8               # the weight-gradient (TN) kernels want output widths that are whole 16-byte
         if pad:                         # groups: zero rows are appended (a 1- or 4-channel head), sliced off again
             w2 = torch.cat((w2, w2.new_zeros(pad, cin)), 0)
-        y2d = gemm.matmul_nt(xc.permute(0, 2, 3, 1).reshape(-1, c), w2)
+        if col_stats and not pad and bias is None:
+            y2d, part = gemm.matmul_nt(xc.permute(0, 2, 3, 1).reshape(-1, c), w2, True)
+        else:
+            y2d = gemm.matmul_nt(xc.permute(0, 2, 3, 1).reshape(-1, c), w2)
         if pad:
             y2d = y2d[:, :cout]
         y = y2d.reshape(b, p, a, cout).permute(0, 3, 1, 2)
@@ -1444,7 +1510,8 @@ def conv1x1(x, weight, bias=None):
         y = (to_cl(x).permute(0, 2, 3, 1).float() * weight.reshape(cout)).permute(0, 3, 1, 2)
     else:
         y = torch.nn.functional.conv2d(x.float(), weight.reshape(cout, cin, 1, 1))
-    return y if bias is None else y + bias.view(1, -1, 1, 1)
+    y = y if bias is None else y + bias.view(1, -1, 1, 1)
+    return (y, part) if col_stats else y
 
 
 def linear(x, weight, bias=None):

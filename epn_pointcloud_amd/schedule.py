@@ -154,6 +154,11 @@ class FusedSeparableBlock(SeparableBlock):
         skip = conv.__dict__.pop("_shared_input", None)
         if skip is None:
             skip = x.feats
+        # per-channel statistics of the two GEMM outputs that a norm follows (inter convolution, skip convolution) come from
+        # the GEMMs' epilogues (block partials; EPN_EPILOGUE_STATS=0: separate passes over the tensors)
+        epi = os.environ.get("EPN_EPILOGUE_STATS", "1") == "1"
+        y_part = conv.__dict__.pop("_out_stats", None)
+        y_part = y_part if epi else None
 
         pair = os.environ.get("EPN_NORM_PAIR", "1") == "1"     # skip norm folded into the block's final pass
 
@@ -161,8 +166,10 @@ class FusedSeparableBlock(SeparableBlock):
             sk = skip
             if self.stride > 1:                                    # batched_index_select(skip, 2, sample_idx) on rows
                 sk = ops.gather_rows(sk, sample_idx)
+            if pair and epi:
+                return ops.conv1x1(sk, self.skip_conv.weight, None, col_stats=True)     # (tensor, partial statistics)
             sk = ops.conv1x1(sk, self.skip_conv.weight, None)       # the norm cancels the bias: see ops.norm_act
-            return sk if pair else ops.norm_act(sk, self.norm, conv_bias=self.skip_conv.bias)
+            return (sk, None) if pair else (ops.norm_act(sk, self.norm, conv_bias=self.skip_conv.bias), None)
 
         side = None
         if os.environ.get("EPN_SKIP_STREAM", "1") == "1" and skip.is_cuda:
@@ -172,23 +179,33 @@ class FusedSeparableBlock(SeparableBlock):
             side = ops._side_stream(skip.device)
             side.wait_stream(main)
             with torch.cuda.stream(side):
-                s = skip_branch()
+                s, s_part = skip_branch()
         if os.environ.get("EPN_NORM_ON_LOAD", "1") == "1" and self.intra_conv.conv.takes_spectral_form(y.feats.is_cuda):
             # norm + leaky_relu of the inter convolution applied as the intra convolution's basis change loads its
             # rows: the normalised tensor is never written
-            z = self.intra_conv.conv(zptk.SphericalPointCloud(y.xyz, y.feats, y.anchors), pre_norm=self.inter_conv.norm)
+            iconv = self.intra_conv.conv
+            iconv.want_out_stats = epi and pair
+            try:
+                z = iconv(zptk.SphericalPointCloud(y.xyz, y.feats, y.anchors), pre_norm=self.inter_conv.norm, pre_part=y_part)
+            finally:
+                iconv.want_out_stats = False
+            z_part = iconv.__dict__.pop("_out_stats", None)
         else:
             feat = ops.norm_act(y.feats, self.inter_conv.norm)
             z = self.intra_conv.conv(zptk.SphericalPointCloud(y.xyz, feat, y.anchors))
+            z_part = None
         if side is None:
-            s = skip_branch()
+            s, s_part = skip_branch()
         else:
             main.wait_stream(side)
             s.record_stream(main)
+            if s_part is not None:
+                s_part.record_stream(main)
         if pair:
             # leaky(IN(z)) + leaky(norm(skip conv)) in ONE pass: the skip branch's normalised tensor is never written, the
             # backward reads the output gradient once per pass for both norms
-            out = ops.norm_act_pair(z.feats, self.intra_conv.norm, s, self.norm, conv_bias_b=self.skip_conv.bias)
+            out = ops.norm_act_pair(z.feats, self.intra_conv.norm, s, self.norm, conv_bias_b=self.skip_conv.bias,
+                                    part_b=s_part, part_a=z_part)
         else:
             out = ops.norm_act(z.feats, self.intra_conv.norm, residual=s)   # leaky(IN(z)) + skip in the same pass
         return inter_idx, inter_w, sample_idx, zptk.SphericalPointCloud(z.xyz, out, z.anchors)

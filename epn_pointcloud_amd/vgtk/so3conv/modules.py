@@ -130,7 +130,8 @@ class InterSO3Conv(nn.Module):
                 handle = ops.DenseInterWeights(inter_idx.int().contiguous(), inter_w, xyz.shape[2])
         if getattr(self, "share_input_grad", False) and feats is x.feats:
             # (set by a block whose skip branch reads x.feats too: see ops.InterSO3ConvSplitFn.forward)
-            out, self._shared_input = ops.inter_so3conv(feats, self.basic_conv.W, handle, self.feat_dtype, share_input=True)
+            out, self._shared_input, self._out_stats = ops.inter_so3conv(feats, self.basic_conv.W, handle, self.feat_dtype,
+                                                                         share_input=True)
         else:
             out = ops.inter_so3conv(feats, self.basic_conv.W, handle, self.feat_dtype)
         return inter_idx, inter_w, sample_idx, SphericalPointCloud(new_xyz, out, self.anchors)
@@ -160,10 +161,15 @@ class IntraSO3Conv(nn.Module):
             self._idx32_cache, self._idx32_key = src.int().contiguous(), key
         return self._idx32_cache
 
-    def forward(self, x, pre_norm=None):
+    def forward(self, x, pre_norm=None, pre_part=None):
         """pre_norm (extension, used by schedule.FusedSeparableBlock): the norm module whose leaky_relu(norm(x.feats)) is the
-        input -- folded into the convolution's basis change when it takes the block-diagonal form."""
-        feats = ops.intra_so3conv(x.feats, self.basic_conv.W, self._idx32(), pre_norm=pre_norm)
+        input -- folded into the convolution's basis change when it takes the block-diagonal form; pre_part: partial
+        per-channel statistics of x.feats from the epilogue of the GEMM that produced it."""
+        if getattr(self, "want_out_stats", False):       # set by a block whose norm follows: see ops.intra_so3conv
+            feats, self._out_stats = ops.intra_so3conv(x.feats, self.basic_conv.W, self._idx32(), pre_norm=pre_norm,
+                                                       pre_part=pre_part, out_stats=True)
+        else:
+            feats = ops.intra_so3conv(x.feats, self.basic_conv.W, self._idx32(), pre_norm=pre_norm, pre_part=pre_part)
         return SphericalPointCloud(x.xyz, feats, self.anchors)
 
     def takes_spectral_form(self, is_cuda=True):

@@ -319,6 +319,17 @@ int epn_intra_group_f32(const float *feats_cl, const int32_t *intra_idx, float *
  * in_spectral = 1 (each is the other's transpose, i.e. its backward). */
 int epn_so3_basis_f32(const float *in, const float *M, const int32_t *blocks, long long pts, int na, int c,
                       int in_spectral, int out_spectral, float *out, epn_stream_t stream);
+/* The same transform (out_spectral must be 0) that also writes point_stats[pt][c][2] = (sum, sum of squares) over the na
+ * output rows of every point, from the accumulators: the block partials (one block per point) of the per-channel statistics
+ * of `out` for epn_stats_finish -- the InstanceNorm that follows IntraSO3Conv (base_so3conv.py:204-211) without a
+ * statistics pass over `out`.  _split_f32: fp32 on the bf16 matrix pipe; _bf16: bf16 features (sums of the
+ * rounded values). */
+int epn_so3_basis_stats_f32(const float *in, const float *M, const int32_t *blocks, long long pts, int na, int c,
+                            int in_spectral, int out_spectral, float *out, float *point_stats, epn_stream_t stream);
+int epn_so3_basis_stats_split_f32(const float *in, const float *M, const int32_t *blocks, long long pts, int na, int c,
+                                  int in_spectral, int out_spectral, float *out, float *point_stats, epn_stream_t stream);
+int epn_so3_basis_stats_bf16(const void *in, const float *M, const int32_t *blocks, long long pts, int na, int c,
+                             int in_spectral, int out_spectral, void *out, float *point_stats, epn_stream_t stream);
 
 /* ---------------------------------------------------------------------------------------------------------------------
  * PointnetSO3Conv: the aggregation tail of every shipped model
@@ -388,8 +399,19 @@ typedef struct epn_gemm_nt_problem {
     void *C;
     long long M, lda, ldb, ldc;
     int N, K;
+    /* Optional (NULL: off): per-column statistics of C taken from the accumulators in the kernel's epilogue --
+     * col_stats[(m / 32)][n][2] = (sum, sum of squares) of rows 32 (m / 32) .. + 31 of column n, as stored (bf16 outputs:
+     * of the rounded values); M % 32 == 0.  epn_stats_finish turns them into the sums[groups][N][2] the norm entry points
+     * take: the per-channel statistics pass of a following BatchNorm / InstanceNorm (base_so3conv.py:196-204) without
+     * reading C again. */
+    float *col_stats;
 } epn_gemm_nt_problem;
 int epn_gemm_nt_f32(int nprob, const epn_gemm_nt_problem *probs, epn_stream_t stream);
+/* sums[g][c][2] = sum over the blocks_per_group consecutive 32-row blocks of group g of partials[block][c][2] (fixed
+ * order: deterministic).  groups = 1 for BatchNorm2d, the number of clouds for InstanceNorm2d (rows per cloud % 32 == 0). */
+size_t epn_stats_finish_workspace_bytes(int groups, long long blocks_per_group, int c);
+int epn_stats_finish(const float *partials, int groups, long long blocks_per_group, int c, float *sums, void *workspace,
+                     size_t workspace_bytes, epn_stream_t stream);
 int epn_gemm_nt_bf16(int nprob, const epn_gemm_nt_problem *probs, int out_f32, epn_stream_t stream);
 /* Split form of the fp32 NT contraction: the same fp32 operands and fp32 result, computed on the bf16 matrix pipe.
  * Every fp32 value is split WITHOUT LOSS into three bf16 pieces (round-to-nearest remainders); the six piece products

@@ -68,6 +68,37 @@ def test_gemm_nt_vs_fp64(gpu, fp32_mode, dt, M, N, K):
 
 
 @pytest.mark.parametrize("dt", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("M,N,K", [(1024, 64, 256), (992, 192, 320), (4096, 256, 1536), (1600, 200, 64), (96, 24, 40),
+                                   (3840, 128, 128), (7680, 32, 64), (98304, 64, 64)])
+def test_gemm_nt_epilogue_column_statistics(gpu, fp32_mode, dt, M, N, K):
+    """col_stats of the NT kernels (per-column sum / sum of squares of every 32-row block of C, taken from the accumulators
+    in the epilogue) against the same sums of the tensor the kernel stored -- all tile shapes incl. a ragged last row tile
+    (M = 992), ragged column tiles (N = 200, 24), the generic kernel (K = 40), bf16 outputs (sums of the ROUNDED values) --
+    and epn_stats_finish's group sums (BatchNorm: 1 group, InstanceNorm: one per cloud; M = 98304: the two-level reduction
+    of long partial lists)."""
+    from epn_pointcloud_amd import gemm, ops
+    if dt != torch.float32 and fp32_mode == "native":
+        pytest.skip("mode only concerns fp32 operands")
+    torch.manual_seed(M + N + K)
+    A = (torch.randn(M, K, device=gpu) + 0.3).to(dt)
+    B = torch.randn(N, K, device=gpu).to(dt)
+    C, part = gemm.gemm_nt(A, B, col_stats=True)
+    assert torch.equal(C, gemm.gemm_nt(A, B))                       # the output itself is untouched
+    assert tuple(part.shape) == (M // 32, N, 2)
+    blocks = C.double().reshape(M // 32, 32, N)
+    want = torch.stack((blocks.sum(1), (blocks * blocks).sum(1)), -1)
+    scale = want.abs().amax(dim=(0, 1))
+    assert ((part.double() - want).abs().amax(dim=(0, 1)) <= 1e-5 * scale).all()
+    for groups in (1, 2, 4):
+        if (M // 32) % groups:
+            continue
+        sums = ops.sums_from_partials(part, groups, M // groups, N)
+        ref = want.reshape(groups, M // 32 // groups, N, 2).sum(1)
+        assert ((sums.double() - ref).abs() <= 2e-5 * ref.abs().amax(dim=(0, 1))).all()
+    assert ops.sums_from_partials(part, 1, M + 32, N) is None        # partials of another shape are refused
+
+
+@pytest.mark.parametrize("dt", [torch.float32, torch.bfloat16])
 @pytest.mark.parametrize("R_,N1,N2", [(4096, 64, 512), (2048, 128, 192), (960, 32, 768), (1024, 256, 256), (100, 20, 36),
                                       (61440, 64, 1536), (32, 8, 8)])
 def test_gemm_tn_vs_fp64(gpu, fp32_mode, dt, R_, N1, N2):

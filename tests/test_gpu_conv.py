@@ -520,7 +520,7 @@ def test_shared_input_gradient_is_folded_into_the_data_gradient(gpu, vgtk_alias,
         f = feats.clone().requires_grad_(True)
         w = W.clone().requires_grad_(True)
         h = f * 1.0                                       # a non-leaf input, as inside a network
-        out, h2 = ops.inter_so3conv(h, w, geo, share_input=True)
+        out, h2, _part = ops.inter_so3conv(h, w, geo, share_input=True)
         loss = 0.0
         if use_out:
             loss = loss + (out.float() ** 2).sum()
@@ -659,6 +659,39 @@ def test_so3_basis_kernel_and_block_layout(gpu, vgtk_alias):
             prod = anchors[a] @ anchors[g]
             tab[a, k] = int(np.argmin([np.abs(prod - anchors[t]).max() for t in range(12)]))
     assert ops.spectral_basis(T(tab).int().to(gpu)) is None
+
+
+@pytest.mark.parametrize("dt,mode", [("f32", "split"), ("f32", "native"), ("bf16", "split")])
+@pytest.mark.parametrize("c", [64, 96, 256])
+def test_so3_basis_epilogue_statistics(gpu, vgtk_alias, dt, mode, c):
+    """epn_so3_basis_stats_*: the inverse transform's output is unchanged and its per-point partial statistics (sum, sum of
+    squares over the 60 anchor rows of each point and channel, of the values as stored) match the tensor it wrote; finished
+    per cloud (InstanceNorm) and over the batch (BatchNorm) they are what epn_chan_stats computes from the tensor."""
+    from epn_pointcloud_amd import ops, gemm
+    from epn_pointcloud_amd.vgtk.so3conv import functional as L
+    old = gemm.FP32_MODE
+    gemm.set_fp32_mode(mode)
+    try:
+        dtype = torch.bfloat16 if dt == "bf16" else torch.float32
+        basis = ops.spectral_basis(T(L.get_intra_idx()).int().to(gpu))
+        torch.manual_seed(c)
+        b, p = 3, 40
+        y = (torch.randn(60 * b * p * c, device=gpu) + 0.2).to(dtype)
+        out0 = ops.FromSpectralFn.apply(y, basis, b, p, c)
+        out, part = ops.FromSpectralFn.apply(y, basis, b, p, c, True)
+        assert torch.equal(out, out0) and tuple(part.shape) == (b * p, c, 2)
+        rows = out.permute(0, 2, 3, 1).reshape(b * p, 60, c).double()
+        want = torch.stack((rows.sum(1), (rows * rows).sum(1)), -1)
+        assert ((part.double() - want).abs() <= 1e-5 * want.abs().amax(dim=(0, 1))).all()
+        for groups, rpg in ((b, p * 60), (1, b * p * 60)):
+            sums = ops.sums_from_partials(part, groups, rpg, c, 60)
+            ref = want.reshape(groups, -1, c, 2).sum(1)
+            assert ((sums.double() - ref).abs() <= 1e-5 * ref.abs().amax(dim=(0, 1))).all()
+            if ops.norm_act_supported(c):          # and what the statistics pass computes from the tensor itself
+                ref32 = ops._chan_stats(ops.to_cl(out), groups, rpg, c)
+                assert ((sums - ref32).abs() <= 1e-5 * ref32.abs().amax(dim=(0, 1))).all()
+    finally:
+        gemm.set_fp32_mode(old)
 
 
 def test_intra_forms_agree_at_full_size(gpu, vgtk_alias):
