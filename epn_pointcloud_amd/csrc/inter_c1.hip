@@ -34,16 +34,22 @@ __device__ __forceinline__ void group_column(const C1Args &A, long long col, flo
     //   alpha_n + beta_k + (2/sigma) g_n . (R_a kappa_k),  alpha_n = 1 - |g_n|^2/sigma,  beta_k = -|kappa_k|^2/sigma
     // 5 VALU operations per (neighbour, kernel point) instead of 9; differs from the literal form by fp32 rounding
     // (<= 5e-7 on w)
-    float rx[EPN_KS_MAX], ry[EPN_KS_MAX], rz[EPN_KS_MAX], beta[EPN_KS_MAX];
+    // kernel points in PAIRS: the per-(neighbour, kernel point) arithmetic below is written on two-float vectors so that
+    // hipcc emits v_pk_fma_f32 / v_pk_add_f32 (two fp32 operations per lane and instruction on this part): 3.5 instead of 6
+    // VALU instructions per weight -- this kernel is nothing but that loop (15k instructions per column at K = 128)
+    typedef float f32x2_t __attribute__((ext_vector_type(2)));
+    constexpr int KP = EPN_KS_MAX / 2;
+    f32x2_t rx[KP], ry[KP], rz[KP], beta[KP], g2[KP];
     const float two_si = 2.0f * A.sigma_inv;
 #pragma unroll
     for (int k = 0; k < EPN_KS_MAX; ++k) {
         const float *e = A.rk + ((size_t)a * A.ks + (k < A.ks ? k : 0)) * 3;
         const float x = e[0], y = e[1], z = e[2];
-        beta[k] = -(x * x + y * y + z * z) * A.sigma_inv;
-        rx[k] = two_si * x; ry[k] = two_si * y; rz[k] = two_si * z;
-        g[k] = 0.f;
+        beta[k >> 1][k & 1] = -(x * x + y * y + z * z) * A.sigma_inv;
+        rx[k >> 1][k & 1] = two_si * x; ry[k >> 1][k & 1] = two_si * y; rz[k >> 1][k & 1] = two_si * z;
+        g2[k >> 1][k & 1] = 0.f;
     }
+    const int kpairs = (A.ks + 1) >> 1;          // an odd ks: the pad slot repeats kernel point 0 and is dropped below
     const int32_t *row = A.idx + ((size_t)bb * A.p2 + pp) * A.nn;
     const float *s = A.xyz + (size_t)bb * 3 * A.p1;
     const float *c = A.new_xyz + (size_t)bb * 3 * A.p2;
@@ -55,15 +61,24 @@ __device__ __forceinline__ void group_column(const C1Args &A, long long col, flo
         const float gx = s[q] - cx, gy = s[A.p1 + q] - cy, gz = s[2 * A.p1 + q] - cz;
         const float alpha = 1.0f - (gx * gx + gy * gy + gz * gz) * A.sigma_inv;
         const float fv = f[(size_t)q * A.na];
+        const f32x2_t a2 = {alpha, alpha}, gx2 = {gx, gx}, gy2 = {gy, gy}, gz2 = {gz, gz}, fv2 = {fv, fv};
 #pragma unroll
-        for (int k = 0; k < EPN_KS_MAX; ++k) {
-            if (k < A.ks) {
-                const float sv = (alpha + beta[k]) + gx * rx[k] + gy * ry[k] + gz * rz[k];
-                const int sb = __builtin_bit_cast(int, sv);
-                g[k] += fv * __builtin_bit_cast(float, sb > 0 ? sb : 0);
+        for (int kp = 0; kp < KP; ++kp) {
+            if (kp < kpairs) {
+                // same operation order per element as the scalar form: ((alpha + beta) + gx rx) + gy ry) + gz rz
+                f32x2_t sv = (a2 + beta[kp]) + gx2 * rx[kp];
+                sv = sv + gy2 * ry[kp];
+                sv = sv + gz2 * rz[kp];
+                // (scalar temporaries: __builtin_bit_cast applied to a vector ELEMENT reads element 0 for both -- hipcc)
+                const float e0 = sv[0], e1 = sv[1];
+                const int s0 = __float_as_int(e0), s1 = __float_as_int(e1);
+                const f32x2_t w = {__int_as_float(s0 > 0 ? s0 : 0), __int_as_float(s1 > 0 ? s1 : 0)};
+                g2[kp] = g2[kp] + fv2 * w;
             }
         }
     }
+#pragma unroll
+    for (int k = 0; k < EPN_KS_MAX; ++k) g[k] = k < A.ks ? g2[k >> 1][k & 1] : 0.f;
 }
 
 __global__ __launch_bounds__(256) void inter_c1_fwd_kernel(C1Args A) {
