@@ -540,6 +540,41 @@ def test_shared_input_gradient_is_folded_into_the_data_gradient(gpu, vgtk_alias,
             assert (gw0 - gw1).abs().max().item() <= 1e-5 * gw0.abs().max().item()
 
 
+@pytest.mark.parametrize("dt", ["f32", "bf16"])
+def test_ungroup_acc_adds_to_what_is_there(gpu, vgtk_alias, dt):
+    """epn_inter_ungroup_acc_*: the transpose of the grouping ADDED to the contents of grad_feats_cl, against
+    base + epn_inter_ungroup_* (which zero-fills first); fp32 atomics in a different order -> 1e-5 of the scale."""
+    import ctypes
+    from epn_pointcloud_amd import ops, _lib
+    from epn_pointcloud_amd.vgtk import pc as pctk
+    from epn_pointcloud_amd.vgtk.so3conv import functional as L
+    from epn_pointcloud_amd.vgtk import functional as fr
+    lib = _lib.get_lib()
+    rng = np.random.default_rng(9)
+    torch.manual_seed(9)
+    dtype = torch.bfloat16 if dt == "bf16" else torch.float32
+    b, n, cin, K, radius = 2, 128, 32, 16, 0.45
+    xyz = T(unit_ball_cloud(rng, b, n)).to(gpu)
+    anchors = T(L.get_anchors(60)).to(gpu)
+    kernels = R.scaled_kernel_points(T(fr.kernel_points_raw(24)), radius).to(gpu)
+    _, new_xyz = pctk.furthest_sample(xyz, n // 2, False)
+    idx = pctk.ball_query_index(new_xyz, xyz, radius, K)
+    geo = ops.InterGeometry(xyz, new_xyz, idx, anchors, kernels, 0.09)
+    d = geo.desc(cin, 16)
+    dG = torch.randn(b * (n // 2) * 60, cin * 24, device=gpu).to(dtype)
+    base = torch.randn(b, n, 60, cin, device=gpu)                      # channels-last storage of [b, cin, n, 60]
+    ws, wsp, wsn = ops._group_workspace(lib, d, gpu)
+    plain = torch.empty_like(base)
+    _lib.check(ops._entry(lib, "inter_ungroup", dtype)(ctypes.byref(d), dG.data_ptr(), plain.data_ptr(), wsp, wsn,
+                                                      _lib.stream_of(dG)), "inter_ungroup")
+    acc = base.clone()
+    _lib.check(ops._entry(lib, "inter_ungroup_acc", dtype)(ctypes.byref(d), dG.data_ptr(), acc.data_ptr(), wsp, wsn,
+                                                          _lib.stream_of(dG)), "inter_ungroup_acc")
+    want = base + plain
+    assert (acc - want).abs().max().item() <= 1e-5 * want.abs().max().item()
+    assert plain.abs().max().item() > 0.1                               # (the scatter did something)
+
+
 def test_packed_grouping_refuses_other_shapes(gpu, vgtk_alias):
     """Shapes outside epn_inter_group_packed_ok (here cin = 16) are refused, not silently written in the plain order."""
     import ctypes
