@@ -1059,17 +1059,21 @@ __global__ __launch_bounds__(64 * GP) void inter_ungroup_shared_kernel(InterArgs
                                                                        unsigned char *__restrict__ canon = nullptr) {
     constexpr int EW = 16 * NT;        // neighbour slots per point (padded)
     constexpr int E = GP * EW;         // slots of the workgroup (128 or 256)
-    constexpr int SS = 16 * CW + 4;    // floats per slot row: 16 CW channels + 4 (rows 4 apart fall on distinct banks)
+    // floats per slot row: 16 CW channels + 4 (rows 4 apart fall on distinct banks).  CW = 2 (the K = 64 instances): + 2
+    // spreads the four lane groups over the banks just as evenly, and with 16-bit index arrays the tile is 78 KB -- TWO
+    // workgroups per CU (at 86 KB, one: 1.68-1.78 -> 1.76-1.89 ms per layer)
+    constexpr int SS = 16 * CW + (CW == 2 ? 2 : 4);
+    typedef typename std::conditional<CW == 2, short, int>::type ix_t;   // destinations < 32768 (p1 <= USH_TAB), slots < 1024
     static_assert((CW == 1 && CS == 1) || !DET, "the deterministic form handles one chunk per step");
     constexpr int NTH = 64 * GP;
     constexpr int CH = E / 64;         // 64-slot chunks
     constexpr int EPT = (E + NTH - 1) / NTH;   // slots per thread in the set-up passes
-    __shared__ int qlist[E];           // destination of each slot, -1 when masked or a cyclic repeat
+    __shared__ ix_t qlist[E];          // destination of each slot, -1 when masked or a cyclic repeat
     __shared__ int slot_of[E];         // slot -> distinct-destination number
-    __shared__ int uq[E];              // distinct destination -> input point
+    __shared__ ix_t uq[E];             // distinct destination -> input point
     __shared__ int cnt[E];
-    __shared__ int off[E + 1];         // CSR over distinct destinations ...
-    __shared__ int list[E];            // ... of the slots that feed them
+    __shared__ ix_t off[E + 1];        // CSR over distinct destinations ...
+    __shared__ ix_t list[E];           // ... of the slots that feed them
     __shared__ int chunk_cnt[CH];
     constexpr int BS = (E + 1) * SS;   // floats per tile buffer: E slot rows + one row of zeros (slot id E, see `ent`)
     __shared__ __attribute__((aligned(16))) float Tb[NB * BS];
@@ -1927,7 +1931,10 @@ int launch_inter_ungroup_mfma(const epn_inter_desc *d, const float *rk4, const v
         // bf16 K = 32 1.60 -> 1.39; at K = 64 (8 waves per workgroup) the 150 KB tile of CW = 4 leaves one workgroup per CU
         // (1.5 -> 1.9-2.6) and sequential groups (CS = 4) lose to independent workgroups (1.50 -> 1.73): one chunk per step there.
         const bool wide = d->cin % 64 == 0 && nt <= 2;
-        A.col_tiles_per_wg = wide ? 4 : 1;   // (CS = 4 at K = 64 measured 1.50 -> 1.73 ms: not instantiated)
+        // K = 64 (nt = 4, 8 points per workgroup): two chunks per step -- the weights of an anchor generated once per 32 channels
+        // (and the 32-channel K = 32 layers, which the four-chunk form does not take)
+        const bool wide2 = !wide && d->cin % 32 == 0 && ((nt > 2 && nt <= 4 && gp == 8) || nt == 2);
+        A.col_tiles_per_wg = wide ? 4 : (wide2 ? 2 : 1);   // (CS = 4 at K = 64 measured 1.50 -> 1.73 ms: not instantiated)
         const dim3 grid((unsigned)(d->b * (d->p2 / gp)), (unsigned)((d->cin >> 4) / A.col_tiles_per_wg));
 #define EPN_USH(NT_, KT_, GP_)                                                                                            \
     do {                                                                                                                  \
@@ -1936,6 +1943,11 @@ int launch_inter_ungroup_mfma(const epn_inter_desc *d, const float *rk4, const v
             if constexpr (NT_ <= 2) {                                                                                     \
                 if (bf16) EPN_LAUNCH((inter_ungroup_shared_kernel<NT_, KT_, __bf16, GP_, nb_, false, 4, 1>), grid, dim3(64 * GP_), 0, st, A, order); \
                 else EPN_LAUNCH((inter_ungroup_shared_kernel<NT_, KT_, float, GP_, nb_, false, 4, 1>), grid, dim3(64 * GP_), 0, st, A, order);      \
+            }                                                                                                             \
+        } else if (wide2) {                                                                                               \
+            if constexpr ((NT_ == 4 && GP_ == 8) || NT_ == 2) {                                                           \
+                if (bf16) EPN_LAUNCH((inter_ungroup_shared_kernel<NT_, KT_, __bf16, GP_, nb_, false, 2, 1>), grid, dim3(64 * GP_), 0, st, A, order); \
+                else EPN_LAUNCH((inter_ungroup_shared_kernel<NT_, KT_, float, GP_, nb_, false, 2, 1>), grid, dim3(64 * GP_), 0, st, A, order);      \
             }                                                                                                             \
         } else {                                                                                                          \
             if (bf16) EPN_LAUNCH((inter_ungroup_shared_kernel<NT_, KT_, __bf16, GP_, nb_>), grid, dim3(64 * GP_), 0, st, A, order); \
