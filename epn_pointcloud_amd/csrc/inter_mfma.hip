@@ -1921,7 +1921,10 @@ int launch_inter_ungroup_mfma(const epn_inter_desc *d, const float *rk4, const v
     // than slots, 8: 3x) but cost LDS and a wider barrier.  Measured per layer (ModelNet / rotation / 3DMatch schedules):
     // K = 16: 8 points, two tile buffers (16: +7 %); K = 32: 16 points, one buffer (-5 % fp32, -12 % bf16);
     // K = 64: 8 points, one buffer; K = 128: 2.  K = 32 / 64 fall back to half the group when p2 does not divide.
-    const int gp = ungroup_group_points(d, nt);
+    int gp = ungroup_group_points(d, nt);
+    // the 32-channel K = 32 layers run two chunks per step (below) in a 39 KB tile with 8 points: four workgroups per CU beat
+    // the 16-point form there (1.64 -> 1.43 ms); with 64-channel groups 16 points stay ahead (1.26 vs 1.75 fp32, 1.39 vs 1.45 bf16)
+    if (nt == 2 && d->cin % 64 != 0 && d->cin % 32 == 0 && d->p2 % 8 == 0) gp = 8;
     if (order && d->p2 % gp == 0 && d->p2 <= MORTON_MAX && d->p1 <= USH_TAB && kernel_policy() != (0x400 | 1)) {
         EPN_LAUNCH_AUX(morton_order_kernel, dim3(d->b), dim3(1024), 0, st, d->new_xyz, d->p2, order);
         EPN_CHECK_LAUNCH();
