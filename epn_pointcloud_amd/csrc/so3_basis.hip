@@ -428,10 +428,103 @@ __global__ __launch_bounds__(64 * SB_WAVES) __attribute__((amdgpu_waves_per_eu(2
     }
 }
 
+// ---- the convolution weights in the block-diagonal basis:  What^rho[(j, c), (i, o)] = sum_k W[o, c, k] rho(g_k)[i, j]
+// (so3_fourier.py).  Every training step re-expresses the weights of every IntraSO3Conv; as torch glue that was a [cout*cin,
+// 12] x [60, 12]^T product on the generic kernel plus five slice / permute / clone chains per layer and their autograd
+// transposes (~25 small launches per layer and direction).  One thread per (c, o) pair: its twelve weights in registers, the
+// table R[f][k] = rho(g_k)[i, j] (f = base + i d + j) in LDS, 60 results.  TR: the same values in the transposed block layout
+// What^T[(i, o), (j, c)] (the Bt operand of the forward GEMM), thread index c-fastest so that both layouts are written
+// coalesced.  Flat buffers: block rho at offset base_rho * cin * cout.
+constexpr int SW_KN_MAX = 16, SW_NA_MAX = 64;
+template <bool TR>
+__global__ __launch_bounds__(256) void spectral_weights_kernel(const float *__restrict__ W, const float *__restrict__ R,
+                                                               const int32_t *__restrict__ blk, int cout, int cin, int kn,
+                                                               int na, float *__restrict__ out) {
+    __shared__ float Rs[SW_NA_MAX * SW_KN_MAX];
+    __shared__ int bs[SW_NA_MAX], d2s[SW_NA_MAX];
+    for (int i = threadIdx.x; i < na * kn; i += blockDim.x) Rs[(i / kn) * SW_KN_MAX + i % kn] = R[i];
+    if ((int)threadIdx.x < na) { bs[threadIdx.x] = blk[2 * threadIdx.x]; d2s[threadIdx.x] = blk[2 * threadIdx.x + 1]; }
+    __syncthreads();
+    const long long id = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (id >= (long long)cin * cout) return;
+    const int c = TR ? (int)(id % cin) : (int)(id / cout), o = TR ? (int)(id / cin) : (int)(id % cout);
+    float w[SW_KN_MAX];
+#pragma unroll
+    for (int k = 0; k < SW_KN_MAX; ++k) w[k] = k < kn ? W[((size_t)o * cin + c) * kn + k] : 0.0f;
+    for (int f = 0; f < na; ++f) {
+        float v = 0.0f;
+#pragma unroll
+        for (int k = 0; k < SW_KN_MAX; ++k) v = fmaf(w[k], k < kn ? Rs[f * SW_KN_MAX + k] : 0.0f, v);
+        const int base = bs[f], d2 = d2s[f];
+        const int d = d2 == 1 ? 1 : (d2 == 4 ? 2 : (d2 == 9 ? 3 : (d2 == 16 ? 4 : (d2 == 25 ? 5 : (d2 == 36 ? 6 : 7)))));
+        const int e = f - base, i = e / d, j = e - i * d;
+        float *ob = out + (size_t)base * cin * cout;
+        if (TR) ob[((size_t)i * cout + o) * ((size_t)d * cin) + (size_t)j * cin + c] = v;
+        else ob[((size_t)j * cin + c) * ((size_t)d * cout) + (size_t)i * cout + o] = v;
+    }
+}
+
+// transpose of the above: dW[o, c, k] = sum_f dWhat^rho[(j, c), (i, o)] R[f][k]
+__global__ __launch_bounds__(256) void spectral_weights_bwd_kernel(const float *__restrict__ gwhat, const float *__restrict__ R,
+                                                                   const int32_t *__restrict__ blk, int cout, int cin, int kn,
+                                                                   int na, float *__restrict__ gW) {
+    __shared__ float Rs[SW_NA_MAX * SW_KN_MAX];
+    __shared__ int bs[SW_NA_MAX], d2s[SW_NA_MAX];
+    for (int i = threadIdx.x; i < na * kn; i += blockDim.x) Rs[(i / kn) * SW_KN_MAX + i % kn] = R[i];
+    if ((int)threadIdx.x < na) { bs[threadIdx.x] = blk[2 * threadIdx.x]; d2s[threadIdx.x] = blk[2 * threadIdx.x + 1]; }
+    __syncthreads();
+    const long long id = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (id >= (long long)cin * cout) return;
+    const int c = (int)(id / cout), o = (int)(id % cout);
+    float acc[SW_KN_MAX];
+#pragma unroll
+    for (int k = 0; k < SW_KN_MAX; ++k) acc[k] = 0.0f;
+    for (int f = 0; f < na; ++f) {
+        const int base = bs[f], d2 = d2s[f];
+        const int d = d2 == 1 ? 1 : (d2 == 4 ? 2 : (d2 == 9 ? 3 : (d2 == 16 ? 4 : (d2 == 25 ? 5 : (d2 == 36 ? 6 : 7)))));
+        const int e = f - base, i = e / d, j = e - i * d;
+        const float g = gwhat[(size_t)base * cin * cout + ((size_t)j * cin + c) * ((size_t)d * cout) + (size_t)i * cout + o];
+#pragma unroll
+        for (int k = 0; k < SW_KN_MAX; ++k) acc[k] = fmaf(g, k < kn ? Rs[f * SW_KN_MAX + k] : 0.0f, acc[k]);
+    }
+#pragma unroll
+    for (int k = 0; k < SW_KN_MAX; ++k)
+        if (k < kn) gW[((size_t)o * cin + c) * kn + k] = acc[k];
+}
+
 }  // namespace
 }  // namespace epn
 
 using namespace epn;
+
+static int sw_check(const void *a, const void *R, const int32_t *blocks, int cout, int cin, int kn, int na) {
+    if (cout < 1 || cin < 1 || kn < 1 || kn > SW_KN_MAX || na < 1 || na > SW_NA_MAX) return EPN_EINVAL;
+    if (!a || !R || !blocks) return EPN_ENULL;
+    return 0;
+}
+
+extern "C" int epn_spectral_weights_f32(const float *W, const float *R, const int32_t *blocks, int cout, int cin, int kn,
+                                        int na, float *what, float *what_t, epn_stream_t stream) {
+    int rc = sw_check(W, R, blocks, cout, cin, kn, na);
+    if (rc) return rc;
+    if (!what && !what_t) return EPN_ENULL;
+    const unsigned grid = (unsigned)(((long long)cin * cout + 255) / 256);
+    if (what) EPN_LAUNCH(spectral_weights_kernel<false>, dim3(grid), dim3(256), 0, epn_stream(stream), W, R, blocks, cout, cin, kn, na, what);
+    if (what_t) EPN_LAUNCH(spectral_weights_kernel<true>, dim3(grid), dim3(256), 0, epn_stream(stream), W, R, blocks, cout, cin, kn, na, what_t);
+    EPN_CHECK_LAUNCH();
+    return 0;
+}
+
+extern "C" int epn_spectral_weights_bwd_f32(const float *grad_what, const float *R, const int32_t *blocks, int cout, int cin,
+                                            int kn, int na, float *grad_W, epn_stream_t stream) {
+    int rc = sw_check(grad_what, R, blocks, cout, cin, kn, na);
+    if (rc) return rc;
+    if (!grad_W) return EPN_ENULL;
+    const unsigned grid = (unsigned)(((long long)cin * cout + 255) / 256);
+    EPN_LAUNCH(spectral_weights_bwd_kernel, dim3(grid), dim3(256), 0, epn_stream(stream), grad_what, R, blocks, cout, cin, kn, na, grad_W);
+    EPN_CHECK_LAUNCH();
+    return 0;
+}
 
 struct SbNormHost {
     const float *sums, *gamma, *beta;

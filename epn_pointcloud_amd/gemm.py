@@ -133,8 +133,9 @@ def gemm_tn(X, Y, out=None):
     return out
 
 
-def gemm_tn_grouped(problems):
-    """problems: list of (X [R,N1], Y [R,N2]) of one dtype -> list of fp32 X^T Y, ONE launch (+ one reduction launch)."""
+def gemm_tn_grouped(problems, outs_into=None):
+    """problems: list of (X [R,N1], Y [R,N2]) of one dtype -> list of fp32 X^T Y, ONE launch (+ one reduction launch).
+    outs_into: optional list of row-major fp32 [N1,N2] tensors to write the results into (e.g. slices of one buffer)."""
     lib = _lib.get_lib()
     arr = (_lib.GemmTnProblem * len(problems))()
     outs, keep, bf = [], [], None
@@ -146,7 +147,12 @@ def gemm_tn_grouped(problems):
         if _is_bf16(Y) != b or (bf is not None and bf != b):
             raise TypeError("gemm_tn: mixed operand dtypes")
         bf = b
-        C = torch.empty((X.shape[1], Y.shape[1]), dtype=torch.float32, device=X.device)
+        if outs_into is not None:
+            C = outs_into[i]
+            if C.dtype != torch.float32 or tuple(C.shape) != (X.shape[1], Y.shape[1]) or not C.is_contiguous():
+                raise ValueError("gemm_tn_grouped: outputs must be contiguous fp32 [N1,N2]")
+        else:
+            C = torch.empty((X.shape[1], Y.shape[1]), dtype=torch.float32, device=X.device)
         p = arr[i]
         p.X, p.Y, p.C = X.data_ptr(), Y.data_ptr(), C.data_ptr()
         p.R, p.N1, p.N2 = X.shape[0], X.shape[1], Y.shape[1]

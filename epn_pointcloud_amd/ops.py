@@ -853,6 +853,55 @@ class FromSpectralFn(torch.autograd.Function):
         return gy, None, None, None, None, None
 
 
+class SpectralWeightsFn(torch.autograd.Function):
+    """IntraSO3Conv's fp32 weights [cout, cin*kn] -> the five block matrices What^rho [d*cin, d*cout] (views of one flat
+    buffer) and, without gradient, their transposes (the Bt operands of the forward GEMMs): ONE pass of
+    epn_spectral_weights_f32 per layout instead of a small GEMM + five slice / permute / clone chains, and one
+    epn_spectral_weights_bwd_f32 instead of their autograd transposes."""
+
+    @staticmethod
+    def forward(ctx, W, basis, cin, cout):
+        lib = _lib.get_lib()
+        Wc = W.contiguous()
+        na, kn = basis.rho_all_t.shape
+        n = na * cin * cout
+        flat = torch.empty(n, dtype=torch.float32, device=W.device)
+        flat_t = torch.empty(n, dtype=torch.float32, device=W.device)
+        _lib.check(lib.epn_spectral_weights_f32(Wc.data_ptr(), basis.rho_all_t.data_ptr(), basis.blocks.data_ptr(), cout, cin,
+                                                kn, na, flat.data_ptr(), flat_t.data_ptr(), _lib.stream_of(Wc)),
+                   "spectral_weights")
+        cc = cin * cout
+        whats = [flat[b0 * cc:(b0 + d * d) * cc].view(d * cin, d * cout) for d, b0 in zip(basis.dims, basis.bases)]
+        whats_t = [flat_t[b0 * cc:(b0 + d * d) * cc].view(d * cout, d * cin) for d, b0 in zip(basis.dims, basis.bases)]
+        ctx.basis, ctx.cfg = basis, (cin, cout, tuple(W.shape))
+        ctx.mark_non_differentiable(*whats_t)
+        return (*whats, *whats_t)
+
+    @staticmethod
+    def backward(ctx, *grads):
+        lib = _lib.get_lib()
+        basis = ctx.basis
+        cin, cout, wshape = ctx.cfg
+        na, kn = basis.rho_all_t.shape
+        cc = cin * cout
+        gs = grads[:len(basis.dims)]
+        dev = basis.rho_all_t.device
+        # the weight-gradient GEMMs write their results as consecutive slices of one buffer (_BlockGemmsFn.backward): use it
+        flat = None
+        if all(g is not None and g.dtype == torch.float32 and g.is_contiguous() for g in gs):
+            p0 = gs[0].data_ptr()
+            if all(g.data_ptr() == p0 + 4 * b0 * cc for g, b0 in zip(gs, basis.bases)) and \
+                    gs[0].untyped_storage().nbytes() - gs[0].storage_offset() * 4 >= 4 * na * cc:
+                flat = gs[0]
+        if flat is None:
+            flat = torch.cat([(g.float().reshape(-1) if g is not None else torch.zeros(d * d * cc, device=dev))
+                              for g, d in zip(gs, basis.dims)])
+        gW = torch.empty(cout * cin * kn, dtype=torch.float32, device=dev)
+        _lib.check(lib.epn_spectral_weights_bwd_f32(flat.data_ptr(), basis.rho_all_t.data_ptr(), basis.blocks.data_ptr(), cout,
+                                                    cin, kn, na, gW.data_ptr(), _lib.stream_of(flat)), "spectral_weights_bwd")
+        return gW.view(wshape), None, None, None
+
+
 class _BlockGemmsFn(torch.autograd.Function):
     """All irreducible blocks of one layer: Z^rho = Y^rho @ What^rho as ONE grouped launch of the library's NT GEMM
     kernel (csrc/gemm.hip), written straight into the slices of one spectral output buffer (no concatenation), and
@@ -860,13 +909,15 @@ class _BlockGemmsFn(torch.autograd.Function):
     whats[i]: What^rho [d*cin, d*cout]."""
 
     @staticmethod
-    def forward(ctx, y, basis, pts, cin, cout, *whats):
+    def forward(ctx, y, basis, pts, cin, cout, whats_t, *whats):
+        """whats_t: the transposed blocks when the caller already has them in y's dtype (SpectralWeightsFn), else None."""
         z = torch.empty(basis.na * pts * cout, dtype=y.dtype, device=y.device)
         probs, fl = [], 0.0
-        for d, base, wh in zip(basis.dims, basis.bases, whats):
+        for bi, (d, base, wh) in enumerate(zip(basis.dims, basis.bases, whats)):
             A = y[base * pts * cin:(base + d * d) * pts * cin].view(pts * d, d * cin)
             O = z[base * pts * cout:(base + d * d) * pts * cout].view(pts * d, d * cout)
-            probs.append((A, gemm.transpose_cast(wh, y.dtype), O))          # Bt = What^T [d*cout, d*cin]
+            wt = whats_t[bi] if whats_t is not None and whats_t[bi].dtype == y.dtype else gemm.transpose_cast(wh, y.dtype)
+            probs.append((A, wt, O))                                        # Bt = What^T [d*cout, d*cin]
             fl += 2.0 * pts * d * d * cin * d * cout
         _launch("intra_gemm", ("spectral", pts, cin, cout), fl, y.device, lambda: gemm.gemm_nt_grouped(probs))
         ctx.save_for_backward(y, *whats)
@@ -888,18 +939,22 @@ class _BlockGemmsFn(torch.autograd.Function):
                 gA = gy[base * pts * cin:(base + d * d) * pts * cin].view(pts * d, d * cin)
                 probs.append((G, gemm.cast(wh, y.dtype), gA))               # dY = dZ What^T: Bt = What [d*cin, d*cout]
                 fl += f1
-            if ctx.needs_input_grad[5 + bi]:
+            if ctx.needs_input_grad[6 + bi]:
                 tprobs.append((A, G))
                 tidx.append(bi)
                 flw += f1
-        if tprobs:      # the five weight-gradient GEMMs, each too small to fill the chip alone: ONE grouped TN launch
+        if tprobs:      # the five weight-gradient GEMMs, each too small to fill the chip alone: ONE grouped TN launch,
+            cc = cin * cout                        # results as consecutive slices of one buffer (SpectralWeightsFn.backward)
+            gw_flat = torch.empty(basis.na * cc, dtype=torch.float32, device=y.device)
+            into = [gw_flat[basis.bases[bi] * cc:(basis.bases[bi] + basis.dims[bi] ** 2) * cc].view(
+                basis.dims[bi] * cin, basis.dims[bi] * cout) for bi in tidx]
             outs = _launch("intra_gemm_dw", ("spectral_dw", pts, cin, cout), flw, y.device,
-                           lambda: gemm.gemm_tn_grouped(tprobs))
+                           lambda: gemm.gemm_tn_grouped(tprobs, into))
             for bi, o in zip(tidx, outs):
                 gws[bi] = o
         if probs:
             _launch("intra_gemm", ("spectral_dA", pts, cin, cout), fl, y.device, lambda: gemm.gemm_nt_grouped(probs))
-        return (gy, None, None, None, None, *gws)
+        return (gy, None, None, None, None, None, *gws)
 
 
 def intra_so3conv_spectral(feats, W, intra_idx32, basis, pre_norm=None, pre_slope=0.01, pre_part=None, out_stats=False):
@@ -922,10 +977,15 @@ def intra_so3conv_spectral(feats, W, intra_idx32, basis, pre_norm=None, pre_slop
     else:
         y = ToSpectralFn.apply(f, basis)
     # What^rho[(j, c), (i, o)] = sum_k W[o, c, k] rho(g_k)[i, j]: one small GEMM for all blocks, then a re-layout each
-    wh_all = gemm.matmul_nt(W.reshape(cout * cin, kn), basis.rho_all_t)     # [cout*cin, na]
-    whats = [wh_all[:, base:base + d * d].reshape(cout, cin, d, d).permute(3, 1, 2, 0).reshape(d * cin, d * cout)
-             for d, base in zip(basis.dims, basis.bases)]
-    z = _BlockGemmsFn.apply(y, basis, pts, cin, cout, *whats)
+    if W.dtype == torch.float32 and kn <= 16 and os.environ.get("EPN_SPECTRAL_WEIGHTS", "fused") == "fused":
+        outs = SpectralWeightsFn.apply(W, basis, cin, cout)                 # one kernel per layout (include/epn_so3conv.h)
+        whats, whats_t = outs[:len(basis.dims)], outs[len(basis.dims):]
+    else:
+        wh_all = gemm.matmul_nt(W.reshape(cout * cin, kn), basis.rho_all_t)     # [cout*cin, na]
+        whats = [wh_all[:, base:base + d * d].reshape(cout, cin, d, d).permute(3, 1, 2, 0).reshape(d * cin, d * cout)
+                 for d, base in zip(basis.dims, basis.bases)]
+        whats_t = None
+    z = _BlockGemmsFn.apply(y, basis, pts, cin, cout, whats_t, *whats)
     return FromSpectralFn.apply(z, basis, b, p, cout, out_stats)      # out_stats: (out, per-point statistics partials)
 
 

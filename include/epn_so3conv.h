@@ -324,6 +324,17 @@ int epn_so3_basis_f32(const float *in, const float *M, const int32_t *blocks, lo
  * of `out` for epn_stats_finish -- the InstanceNorm that follows IntraSO3Conv (base_so3conv.py:204-211) without a
  * statistics pass over `out`.  _split_f32: fp32 on the bf16 matrix pipe; _bf16: bf16 features (sums of the
  * rounded values). */
+/* IntraSO3Conv's weights in the block-diagonal basis (so3_fourier.py): for every irreducible block rho (dimension d, first
+ * spectral row `base`, blocks[f] = (base, d*d) as above) What^rho[(j, c), (i, o)] = sum_k W[o, c, k] R[base + i d + j][k],
+ * R f32[na][kn] = the representation matrices rho(g_k)[i, j] of the kn anchor neighbours.  what: flat, block rho at offset
+ * base * cin * cout as a row-major [d*cin][d*cout] matrix; what_t: the same blocks transposed ([d*cout][d*cin], the Bt
+ * operand of epn_gemm_nt for the forward product); either may be NULL.  epn_spectral_weights_bwd_f32 is the transpose
+ * (grad_W[o][c][k] from grad_what in the `what` layout).  Replaces nothing in the reference (the spectral form is this
+ * library's); it replaces ~25 small torch launches per layer and direction. */
+int epn_spectral_weights_f32(const float *W, const float *R, const int32_t *blocks, int cout, int cin, int kn, int na,
+                             float *what, float *what_t, epn_stream_t stream);
+int epn_spectral_weights_bwd_f32(const float *grad_what, const float *R, const int32_t *blocks, int cout, int cin, int kn,
+                                 int na, float *grad_W, epn_stream_t stream);
 int epn_so3_basis_stats_f32(const float *in, const float *M, const int32_t *blocks, long long pts, int na, int c,
                             int in_spectral, int out_spectral, float *out, float *point_stats, epn_stream_t stream);
 int epn_so3_basis_stats_split_f32(const float *in, const float *M, const int32_t *blocks, long long pts, int na, int c,

@@ -729,6 +729,51 @@ def test_so3_basis_epilogue_statistics(gpu, vgtk_alias, dt, mode, c):
         gemm.set_fp32_mode(old)
 
 
+@pytest.mark.parametrize("cin,cout", [(32, 64), (64, 64), (128, 96)])
+def test_spectral_weights_kernels_vs_torch_glue(gpu, vgtk_alias, cin, cout, monkeypatch):
+    """epn_spectral_weights_f32 / _bwd_f32 (IntraSO3Conv's weights re-expressed per irreducible block, both layouts, and
+    the transpose) against the torch formulation they replace (small GEMM + slice / permute chains and autograd): the five
+    blocks, their transposes, and the weight gradient through a spectral IntraSO3Conv."""
+    from epn_pointcloud_amd import ops
+    from epn_pointcloud_amd.vgtk.so3conv import functional as L
+    torch.manual_seed(cin + cout)
+    idx32 = T(L.get_intra_idx()).int().to(gpu)
+    basis = ops.spectral_basis(idx32)
+    kn = idx32.shape[1]
+    W = torch.randn(cout, cin * kn, device=gpu, requires_grad=True)
+    outs = ops.SpectralWeightsFn.apply(W, basis, cin, cout)
+    nb = len(basis.dims)
+    wh_all = W.detach().reshape(cout * cin, kn) @ basis.rho_all_t.t()
+    gsum = 0.0
+    for (d, base), wh, wt in zip(zip(basis.dims, basis.bases), outs[:nb], outs[nb:]):
+        want = wh_all[:, base:base + d * d].reshape(cout, cin, d, d).permute(3, 1, 2, 0).reshape(d * cin, d * cout)
+        assert tuple(wh.shape) == (d * cin, d * cout) and tuple(wt.shape) == (d * cout, d * cin)
+        assert (wh - want).abs().max().item() < 1e-5
+        assert torch.equal(wt, wh.detach().t())
+        gsum = gsum + (wh * torch.cos(want)).sum()
+    (gW,) = torch.autograd.grad(gsum, W)
+    W2 = W.detach().clone().requires_grad_(True)
+    wh2 = W2.reshape(cout * cin, kn) @ basis.rho_all_t.t()
+    g2 = 0.0
+    for d, base in zip(basis.dims, basis.bases):
+        blk = wh2[:, base:base + d * d].reshape(cout, cin, d, d).permute(3, 1, 2, 0).reshape(d * cin, d * cout)
+        g2 = g2 + (blk * torch.cos(blk.detach())).sum()
+    (gW2,) = torch.autograd.grad(g2, W2)
+    assert (gW - gW2).abs().max().item() < 1e-4 * gW2.abs().max().item()
+    # and through the convolution: fused weights vs the torch glue (EPN_SPECTRAL_WEIGHTS=torch)
+    b, p = 2, 24
+    x = torch.randn(b, cin, p, 60, device=gpu)
+    res = []
+    for mode in ("fused", "torch"):
+        monkeypatch.setenv("EPN_SPECTRAL_WEIGHTS", mode)
+        Wm = W.detach().clone().requires_grad_(True)
+        y = ops.intra_so3conv_spectral(x, Wm, idx32, basis)
+        (g,) = torch.autograd.grad((y * y).sum(), Wm)
+        res.append((y.detach(), g))
+    assert (res[0][0] - res[1][0]).abs().max().item() < 1e-4
+    assert (res[0][1] - res[1][1]).abs().max().item() < 1e-4 * res[1][1].abs().max().item()
+
+
 def test_intra_forms_agree_at_full_size(gpu, vgtk_alias):
     """BASELINE configs[1] size (B=32, 512 points, 64 channels, A=60: 983 040 columns): the block-diagonal (spectral)
     form, the split form and the fused kernels of IntraSO3Conv are three independent implementations; outputs and
