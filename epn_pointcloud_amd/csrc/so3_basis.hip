@@ -451,7 +451,11 @@ __global__ __launch_bounds__(256) void spectral_weights_kernel(const float *__re
     float w[SW_KN_MAX];
 #pragma unroll
     for (int k = 0; k < SW_KN_MAX; ++k) w[k] = k < kn ? W[((size_t)o * cin + c) * kn + k] : 0.0f;
-    for (int f = 0; f < na; ++f) {
+    // blockIdx.y: a slice of the spectral rows (a 64-channel layer is only 16 workgroups of (c, o) pairs, and one thread's
+    // 60 rows in sequence were the whole kernel: 41-64 us per launch)
+    const int fper = (na + (int)gridDim.y - 1) / (int)gridDim.y;
+    const int f0 = (int)blockIdx.y * fper, f1 = min(f0 + fper, na);
+    for (int f = f0; f < f1; ++f) {
         float v = 0.0f;
 #pragma unroll
         for (int k = 0; k < SW_KN_MAX; ++k) v = fmaf(w[k], k < kn ? Rs[f * SW_KN_MAX + k] : 0.0f, v);
@@ -473,13 +477,18 @@ __global__ __launch_bounds__(256) void spectral_weights_bwd_kernel(const float *
     for (int i = threadIdx.x; i < na * kn; i += blockDim.x) Rs[(i / kn) * SW_KN_MAX + i % kn] = R[i];
     if ((int)threadIdx.x < na) { bs[threadIdx.x] = blk[2 * threadIdx.x]; d2s[threadIdx.x] = blk[2 * threadIdx.x + 1]; }
     __syncthreads();
-    const long long id = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (id >= (long long)cin * cout) return;
+    // four lanes per (c, o) pair, each a quarter of the spectral rows, combined by two shuffles per weight
+    const long long tid = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    const int part = (int)(tid & 3);
+    const long long id0 = tid >> 2;
+    const bool live = id0 < (long long)cin * cout;
+    const long long id = live ? id0 : 0;
     const int c = (int)(id / cout), o = (int)(id % cout);
     float acc[SW_KN_MAX];
 #pragma unroll
     for (int k = 0; k < SW_KN_MAX; ++k) acc[k] = 0.0f;
-    for (int f = 0; f < na; ++f) {
+    const int fper = (na + 3) >> 2;
+    for (int f = part * fper; f < min((part + 1) * fper, na); ++f) {
         const int base = bs[f], d2 = d2s[f];
         const int d = d2 == 1 ? 1 : (d2 == 4 ? 2 : (d2 == 9 ? 3 : (d2 == 16 ? 4 : (d2 == 25 ? 5 : (d2 == 36 ? 6 : 7)))));
         const int e = f - base, i = e / d, j = e - i * d;
@@ -488,8 +497,15 @@ __global__ __launch_bounds__(256) void spectral_weights_bwd_kernel(const float *
         for (int k = 0; k < SW_KN_MAX; ++k) acc[k] = fmaf(g, k < kn ? Rs[f * SW_KN_MAX + k] : 0.0f, acc[k]);
     }
 #pragma unroll
-    for (int k = 0; k < SW_KN_MAX; ++k)
-        if (k < kn) gW[((size_t)o * cin + c) * kn + k] = acc[k];
+    for (int k = 0; k < SW_KN_MAX; ++k) {
+        acc[k] += __shfl_xor(acc[k], 1, 64);
+        acc[k] += __shfl_xor(acc[k], 2, 64);
+    }
+    if (live && part == 0) {
+#pragma unroll
+        for (int k = 0; k < SW_KN_MAX; ++k)
+            if (k < kn) gW[((size_t)o * cin + c) * kn + k] = acc[k];
+    }
 }
 
 }  // namespace
@@ -509,8 +525,9 @@ extern "C" int epn_spectral_weights_f32(const float *W, const float *R, const in
     if (rc) return rc;
     if (!what && !what_t) return EPN_ENULL;
     const unsigned grid = (unsigned)(((long long)cin * cout + 255) / 256);
-    if (what) EPN_LAUNCH(spectral_weights_kernel<false>, dim3(grid), dim3(256), 0, epn_stream(stream), W, R, blocks, cout, cin, kn, na, what);
-    if (what_t) EPN_LAUNCH(spectral_weights_kernel<true>, dim3(grid), dim3(256), 0, epn_stream(stream), W, R, blocks, cout, cin, kn, na, what_t);
+    const unsigned fy = grid >= 1024 ? 4 : (grid >= 256 ? 6 : 12);          // slices of the spectral rows
+    if (what) EPN_LAUNCH(spectral_weights_kernel<false>, dim3(grid, fy), dim3(256), 0, epn_stream(stream), W, R, blocks, cout, cin, kn, na, what);
+    if (what_t) EPN_LAUNCH(spectral_weights_kernel<true>, dim3(grid, fy), dim3(256), 0, epn_stream(stream), W, R, blocks, cout, cin, kn, na, what_t);
     EPN_CHECK_LAUNCH();
     return 0;
 }
@@ -520,7 +537,7 @@ extern "C" int epn_spectral_weights_bwd_f32(const float *grad_what, const float 
     int rc = sw_check(grad_what, R, blocks, cout, cin, kn, na);
     if (rc) return rc;
     if (!grad_W) return EPN_ENULL;
-    const unsigned grid = (unsigned)(((long long)cin * cout + 255) / 256);
+    const unsigned grid = (unsigned)((4LL * cin * cout + 255) / 256);
     EPN_LAUNCH(spectral_weights_bwd_kernel, dim3(grid), dim3(256), 0, epn_stream(stream), grad_what, R, blocks, cout, cin, kn, na, grad_W);
     EPN_CHECK_LAUNCH();
     return 0;
