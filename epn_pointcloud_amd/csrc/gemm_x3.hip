@@ -69,6 +69,32 @@ __global__ void split_planes_kernel(const float *__restrict__ W, long long ldw, 
     planes[2 * plane + i] = pack_rne(r0 - lo_f(mp), r1 - hi_f(mp));
 }
 
+// the weights of all problems of a grouped launch (the five blocks of a spectral IntraSO3Conv) in ONE launch: blockIdx.y =
+// problem (98 -> 42 splitting launches per cls training step)
+struct SplitBatch {
+    const float *W[GEMM_MAX_PROB];
+    unsigned *planes[GEMM_MAX_PROB];
+    long long ldw[GEMM_MAX_PROB];
+    int N[GEMM_MAX_PROB], K[GEMM_MAX_PROB];
+};
+__global__ void split_planes_batch_kernel(SplitBatch S) {
+    const int q = blockIdx.y;
+    const float *__restrict__ W = S.W[q];
+    unsigned *__restrict__ planes = S.planes[q];
+    const int N = S.N[q], k2 = S.K[q] >> 1;
+    const size_t plane = (size_t)N * k2;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < (long long)N * k2; i += (long long)gridDim.x * blockDim.x) {
+        const int n = (int)(i / k2), k = 2 * (int)(i % k2);
+        const float x0 = W[n * S.ldw[q] + k], x1 = W[n * S.ldw[q] + k + 1];
+        const unsigned hp = pack_rne(x0, x1);
+        const float r0 = x0 - lo_f(hp), r1 = x1 - hi_f(hp);
+        const unsigned mp = pack_rne(r0, r1);
+        planes[i] = hp;
+        planes[plane + i] = mp;
+        planes[2 * plane + i] = pack_rne(r0 - lo_f(mp), r1 - hi_f(mp));
+    }
+}
+
 template <int WGM, int WGN, int TM, int TN, int NSTG>
 __global__ __launch_bounds__(64 * WGM * WGN) void gemm_nt_x3_kernel(GemmNtBatch B) {
     constexpr int NW = WGM * WGN;
@@ -287,17 +313,27 @@ int launch_gemm_nt_x3(GemmNtBatch &B, void *ws, size_t ws_bytes, hipStream_t st)
         return launch_gemm_nt(B, 0, 0, st);      // the planes are read with 16-byte direct-to-LDS loads
     char *w = static_cast<char *>(ws);
     int maxn = 0, minn = 1 << 30;
+    SplitBatch S;
+    long long maxpairs = 0;
     for (int i = 0; i < B.nprob; ++i) {
         GemmNtProb &p = B.p[i];
         const long long pairs = (long long)p.N * (p.K / 2);
-        EPN_LAUNCH_AUX(split_planes_kernel, dim3((unsigned)((pairs + 255) / 256)), dim3(256), 0, st,
-                           static_cast<const float *>(p.Bt), p.ldb, p.N, p.K, reinterpret_cast<unsigned *>(w));
-        EPN_CHECK_LAUNCH();
+        S.W[i] = static_cast<const float *>(p.Bt); S.planes[i] = reinterpret_cast<unsigned *>(w); S.ldw[i] = p.ldb;
+        S.N[i] = p.N; S.K[i] = p.K;
+        maxpairs = pairs > maxpairs ? pairs : maxpairs;
         p.Bp = w;
         w += planes_bytes(p);
         maxn = p.N > maxn ? p.N : maxn;
         minn = p.N < minn ? p.N : minn;
     }
+    if (B.nprob == 1) {
+        EPN_LAUNCH_AUX(split_planes_kernel, dim3((unsigned)((maxpairs + 255) / 256)), dim3(256), 0, st, S.W[0], S.ldw[0], S.N[0],
+                       S.K[0], S.planes[0]);
+    } else {
+        const unsigned gx = (unsigned)((maxpairs + 255) / 256 < 4096 ? (maxpairs + 255) / 256 : 4096);
+        EPN_LAUNCH_AUX(split_planes_batch_kernel, dim3(gx, B.nprob), dim3(256), 0, st, S);
+    }
+    EPN_CHECK_LAUNCH();
     const int pol = kernel_policy();
     if ((pol & ~0xff) == 0x100) {               // tuning override (tools/x3_probe.py)
         switch (pol & 0xff) {
