@@ -436,10 +436,10 @@ __global__ __launch_bounds__(64 * SB_WAVES) __attribute__((amdgpu_waves_per_eu(2
 // What^T[(i, o), (j, c)] (the Bt operand of the forward GEMM), thread index c-fastest so that both layouts are written
 // coalesced.  Flat buffers: block rho at offset base_rho * cin * cout.
 constexpr int SW_KN_MAX = 16, SW_NA_MAX = 64;
-template <bool TR>
+template <bool TR, typename TO = float>      // TO = __bf16: the operand copies of a bf16 network (no cast / transpose-cast launches)
 __global__ __launch_bounds__(256) void spectral_weights_kernel(const float *__restrict__ W, const float *__restrict__ R,
                                                                const int32_t *__restrict__ blk, int cout, int cin, int kn,
-                                                               int na, float *__restrict__ out) {
+                                                               int na, TO *__restrict__ out) {
     __shared__ float Rs[SW_NA_MAX * SW_KN_MAX];
     __shared__ int bs[SW_NA_MAX], d2s[SW_NA_MAX];
     for (int i = threadIdx.x; i < na * kn; i += blockDim.x) Rs[(i / kn) * SW_KN_MAX + i % kn] = R[i];
@@ -462,9 +462,9 @@ __global__ __launch_bounds__(256) void spectral_weights_kernel(const float *__re
         const int base = bs[f], d2 = d2s[f];
         const int d = d2 == 1 ? 1 : (d2 == 4 ? 2 : (d2 == 9 ? 3 : (d2 == 16 ? 4 : (d2 == 25 ? 5 : (d2 == 36 ? 6 : 7)))));
         const int e = f - base, i = e / d, j = e - i * d;
-        float *ob = out + (size_t)base * cin * cout;
-        if (TR) ob[((size_t)i * cout + o) * ((size_t)d * cin) + (size_t)j * cin + c] = v;
-        else ob[((size_t)j * cin + c) * ((size_t)d * cout) + (size_t)i * cout + o] = v;
+        TO *ob = out + (size_t)base * cin * cout;
+        if (TR) ob[((size_t)i * cout + o) * ((size_t)d * cin) + (size_t)j * cin + c] = (TO)v;
+        else ob[((size_t)j * cin + c) * ((size_t)d * cout) + (size_t)i * cout + o] = (TO)v;
     }
 }
 
@@ -528,6 +528,19 @@ extern "C" int epn_spectral_weights_f32(const float *W, const float *R, const in
     const unsigned fy = grid >= 1024 ? 4 : (grid >= 256 ? 6 : 12);          // slices of the spectral rows
     if (what) EPN_LAUNCH(spectral_weights_kernel<false>, dim3(grid, fy), dim3(256), 0, epn_stream(stream), W, R, blocks, cout, cin, kn, na, what);
     if (what_t) EPN_LAUNCH(spectral_weights_kernel<true>, dim3(grid, fy), dim3(256), 0, epn_stream(stream), W, R, blocks, cout, cin, kn, na, what_t);
+    EPN_CHECK_LAUNCH();
+    return 0;
+}
+
+extern "C" int epn_spectral_weights_bf16(const float *W, const float *R, const int32_t *blocks, int cout, int cin, int kn,
+                                         int na, void *what, void *what_t, epn_stream_t stream) {
+    int rc = sw_check(W, R, blocks, cout, cin, kn, na);
+    if (rc) return rc;
+    if (!what && !what_t) return EPN_ENULL;
+    const unsigned grid = (unsigned)(((long long)cin * cout + 255) / 256);
+    const unsigned fy = grid >= 1024 ? 4 : (grid >= 256 ? 6 : 12);
+    if (what) EPN_LAUNCH((spectral_weights_kernel<false, __bf16>), dim3(grid, fy), dim3(256), 0, epn_stream(stream), W, R, blocks, cout, cin, kn, na, static_cast<__bf16 *>(what));
+    if (what_t) EPN_LAUNCH((spectral_weights_kernel<true, __bf16>), dim3(grid, fy), dim3(256), 0, epn_stream(stream), W, R, blocks, cout, cin, kn, na, static_cast<__bf16 *>(what_t));
     EPN_CHECK_LAUNCH();
     return 0;
 }

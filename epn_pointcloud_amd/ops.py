@@ -860,22 +860,41 @@ class SpectralWeightsFn(torch.autograd.Function):
     epn_spectral_weights_bwd_f32 instead of their autograd transposes."""
 
     @staticmethod
-    def forward(ctx, W, basis, cin, cout):
+    def forward(ctx, W, basis, cin, cout, bf16_ops=False):
+        """Returns (whats fp32 x5 [differentiable], forward operands What^T x5, backward operands What x5): the operand sets
+        are fp32 (the second = the differentiable blocks themselves) or, bf16_ops, bf16 copies written by the same kernel."""
         lib = _lib.get_lib()
         Wc = W.contiguous()
         na, kn = basis.rho_all_t.shape
         n = na * cin * cout
-        flat = torch.empty(n, dtype=torch.float32, device=W.device)
-        flat_t = torch.empty(n, dtype=torch.float32, device=W.device)
-        _lib.check(lib.epn_spectral_weights_f32(Wc.data_ptr(), basis.rho_all_t.data_ptr(), basis.blocks.data_ptr(), cout, cin,
-                                                kn, na, flat.data_ptr(), flat_t.data_ptr(), _lib.stream_of(Wc)),
-                   "spectral_weights")
         cc = cin * cout
-        whats = [flat[b0 * cc:(b0 + d * d) * cc].view(d * cin, d * cout) for d, b0 in zip(basis.dims, basis.bases)]
-        whats_t = [flat_t[b0 * cc:(b0 + d * d) * cc].view(d * cout, d * cin) for d, b0 in zip(basis.dims, basis.bases)]
+        dev = W.device
+        st = _lib.stream_of(Wc)
+        R, blk = basis.rho_all_t.data_ptr(), basis.blocks.data_ptr()
+
+        def views(buf, t):
+            return [buf[b0 * cc:(b0 + d * d) * cc].view(*((d * cout, d * cin) if t else (d * cin, d * cout)))
+                    for d, b0 in zip(basis.dims, basis.bases)]
+        flat = torch.empty(n, dtype=torch.float32, device=dev)
+        if bf16_ops:
+            fb, fbt = (torch.empty(n, dtype=torch.bfloat16, device=dev) for _ in range(2))
+            _lib.check(lib.epn_spectral_weights_f32(Wc.data_ptr(), R, blk, cout, cin, kn, na, flat.data_ptr(), None, st),
+                       "spectral_weights")
+            _lib.check(lib.epn_spectral_weights_bf16(Wc.data_ptr(), R, blk, cout, cin, kn, na, fb.data_ptr(), fbt.data_ptr(), st),
+                       "spectral_weights_bf16")
+            ops_t, ops_n = views(fbt, True), views(fb, False)
+        else:
+            flat_t = torch.empty(n, dtype=torch.float32, device=dev)
+            _lib.check(lib.epn_spectral_weights_f32(Wc.data_ptr(), R, blk, cout, cin, kn, na, flat.data_ptr(), flat_t.data_ptr(),
+                                                    st), "spectral_weights")
+            ops_t, ops_n = views(flat_t, True), None
+        whats = views(flat, False)
         ctx.basis, ctx.cfg = basis, (cin, cout, tuple(W.shape))
-        ctx.mark_non_differentiable(*whats_t)
-        return (*whats, *whats_t)
+        if ops_n is None:
+            ctx.mark_non_differentiable(*ops_t)
+            return (*whats, *ops_t)
+        ctx.mark_non_differentiable(*ops_t, *ops_n)
+        return (*whats, *ops_t, *ops_n)
 
     @staticmethod
     def backward(ctx, *grads):
@@ -899,7 +918,7 @@ class SpectralWeightsFn(torch.autograd.Function):
         gW = torch.empty(cout * cin * kn, dtype=torch.float32, device=dev)
         _lib.check(lib.epn_spectral_weights_bwd_f32(flat.data_ptr(), basis.rho_all_t.data_ptr(), basis.blocks.data_ptr(), cout,
                                                     cin, kn, na, gW.data_ptr(), _lib.stream_of(flat)), "spectral_weights_bwd")
-        return gW.view(wshape), None, None, None
+        return gW.view(wshape), None, None, None, None
 
 
 class _BlockGemmsFn(torch.autograd.Function):
@@ -910,7 +929,11 @@ class _BlockGemmsFn(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, y, basis, pts, cin, cout, whats_t, *whats):
-        """whats_t: the transposed blocks when the caller already has them in y's dtype (SpectralWeightsFn), else None."""
+        """whats_t: None, or (What^T x5, What x5 or None) in y's dtype when the caller already has them (SpectralWeightsFn):
+        the Bt operands of the forward and of the data-gradient GEMMs."""
+        whats_n = None
+        if whats_t is not None:
+            whats_t, whats_n = whats_t
         z = torch.empty(basis.na * pts * cout, dtype=y.dtype, device=y.device)
         probs, fl = [], 0.0
         for bi, (d, base, wh) in enumerate(zip(basis.dims, basis.bases, whats)):
@@ -922,6 +945,7 @@ class _BlockGemmsFn(torch.autograd.Function):
         _launch("intra_gemm", ("spectral", pts, cin, cout), fl, y.device, lambda: gemm.gemm_nt_grouped(probs))
         ctx.save_for_backward(y, *whats)
         ctx.cfg = (basis, pts, cin, cout)
+        ctx.ops_n = whats_n if whats_n is not None and whats_n[0].dtype == y.dtype else None
         return z
 
     @staticmethod
@@ -937,7 +961,8 @@ class _BlockGemmsFn(torch.autograd.Function):
             f1 = 2.0 * pts * d * d * cin * d * cout
             if gy is not None:
                 gA = gy[base * pts * cin:(base + d * d) * pts * cin].view(pts * d, d * cin)
-                probs.append((G, gemm.cast(wh, y.dtype), gA))               # dY = dZ What^T: Bt = What [d*cin, d*cout]
+                wn = ctx.ops_n[bi] if ctx.ops_n is not None else gemm.cast(wh, y.dtype)
+                probs.append((G, wn, gA))                                   # dY = dZ What^T: Bt = What [d*cin, d*cout]
                 fl += f1
             if ctx.needs_input_grad[6 + bi]:
                 tprobs.append((A, G))
@@ -978,8 +1003,10 @@ def intra_so3conv_spectral(feats, W, intra_idx32, basis, pre_norm=None, pre_slop
         y = ToSpectralFn.apply(f, basis)
     # What^rho[(j, c), (i, o)] = sum_k W[o, c, k] rho(g_k)[i, j]: one small GEMM for all blocks, then a re-layout each
     if W.dtype == torch.float32 and kn <= 16 and os.environ.get("EPN_SPECTRAL_WEIGHTS", "fused") == "fused":
-        outs = SpectralWeightsFn.apply(W, basis, cin, cout)                 # one kernel per layout (include/epn_so3conv.h)
-        whats, whats_t = outs[:len(basis.dims)], outs[len(basis.dims):]
+        nb_ = len(basis.dims)
+        outs = SpectralWeightsFn.apply(W, basis, cin, cout, y.dtype == torch.bfloat16)   # one kernel per layout and dtype
+        whats = outs[:nb_]
+        whats_t = (outs[nb_:2 * nb_], outs[2 * nb_:] if len(outs) > 2 * nb_ else None)
     else:
         wh_all = gemm.matmul_nt(W.reshape(cout * cin, kn), basis.rho_all_t)     # [cout*cin, na]
         whats = [wh_all[:, base:base + d * d].reshape(cout, cin, d, d).permute(3, 1, 2, 0).reshape(d * cin, d * cout)

@@ -333,6 +333,9 @@ int epn_so3_basis_f32(const float *in, const float *M, const int32_t *blocks, lo
  * library's); it replaces ~25 small torch launches per layer and direction. */
 int epn_spectral_weights_f32(const float *W, const float *R, const int32_t *blocks, int cout, int cin, int kn, int na,
                              float *what, float *what_t, epn_stream_t stream);
+/* the same blocks rounded to bf16 (fp32 master weights -> the operands of a bf16 network's GEMMs) */
+int epn_spectral_weights_bf16(const float *W, const float *R, const int32_t *blocks, int cout, int cin, int kn, int na,
+                              void *what, void *what_t, epn_stream_t stream);
 int epn_spectral_weights_bwd_f32(const float *grad_what, const float *R, const int32_t *blocks, int cout, int cin, int kn,
                                  int na, float *grad_W, epn_stream_t stream);
 int epn_so3_basis_stats_f32(const float *in, const float *M, const int32_t *blocks, long long pts, int na, int c,
