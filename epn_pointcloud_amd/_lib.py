@@ -35,7 +35,7 @@ EXPORTS = [
     "epn_inter_pack_weights_f32", "epn_inter_pack_weights_bf16", "epn_inter_unpack_weight_grad_f32",
     "epn_inter_ungroup_acc_f32", "epn_inter_ungroup_acc_bf16", "epn_stats_finish", "epn_stats_finish_workspace_bytes",
     "epn_so3_basis_stats_f32", "epn_so3_basis_stats_split_f32", "epn_so3_basis_stats_bf16",
-    "epn_spectral_weights_f32", "epn_spectral_weights_bwd_f32", "epn_spectral_weights_bf16",
+    "epn_spectral_weights_f32", "epn_spectral_weights_bwd_f32", "epn_spectral_weights_bf16", "epn_cast_add_bf16",
 ]
 
 _vp, _ci, _cf, _sz = ctypes.c_void_p, ctypes.c_int, ctypes.c_float, ctypes.c_size_t
@@ -114,6 +114,7 @@ def get_lib():
     for _n in ("epn_so3_basis_stats_f32", "epn_so3_basis_stats_split_f32", "epn_so3_basis_stats_bf16"):
         getattr(lib, _n).argtypes = [_vp, _vp, _vp, ctypes.c_longlong, _ci, _ci, _ci, _ci, _vp, _vp, _vp]
     lib.epn_spectral_weights_f32.argtypes = [_vp, _vp, _vp, _ci, _ci, _ci, _ci, _vp, _vp, _vp]
+    lib.epn_cast_add_bf16.argtypes = [_vp, _vp, _vp, _sz, _vp]
     lib.epn_spectral_weights_bf16.argtypes = [_vp, _vp, _vp, _ci, _ci, _ci, _ci, _vp, _vp, _vp]
     lib.epn_spectral_weights_bwd_f32.argtypes = [_vp, _vp, _vp, _ci, _ci, _ci, _ci, _vp, _vp]
     lib.epn_stats_finish.argtypes = [_vp, _ci, ctypes.c_longlong, _ci, _vp, _vp, _sz, _vp]

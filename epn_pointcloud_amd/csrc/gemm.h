@@ -92,5 +92,6 @@ void gemm_tn_tile(int dtype, int N1, int N2, int *bn1, int *bn2);   // dtype: 0 
 int gemm_tn_splits(int dtype, long long R, int N1, int N2);
 int launch_transpose_cast(const void *src, void *dst, int rows, int cols, int src_bf16, int dst_bf16, hipStream_t st);
 int launch_cast(const void *src, void *dst, size_t n, int src_bf16, int dst_bf16, hipStream_t st);
+int launch_cast_add(const float *src, const void *add_bf16, void *dst_bf16, size_t n, hipStream_t st);
 
 }  // namespace epn

@@ -856,9 +856,34 @@ __global__ void transpose_cast_kernel(const TI *__restrict__ src, TO *__restrict
 }
 
 template <typename TI, typename TO>
-__global__ void cast_kernel(const TI *__restrict__ src, TO *__restrict__ dst, size_t n) {
+__global__ void cast_scalar_kernel(const TI *__restrict__ src, TO *__restrict__ dst, size_t n) {
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x)
         dst[i] = (TO)(float)src[i];
+}
+
+// four elements per thread and step (16 / 8-byte accesses; both pointers 16-byte aligned: launcher), scalar tail.
+// ADD: dst = (TO)(src + (float)add[i]) -- the fp32 scatter target of a bf16 network's data gradient converted and added to the
+// gradient that reached the same tensor by the other branch, in one pass
+template <typename TI, typename TO, bool ADD = false>
+__global__ void cast_kernel(const TI *__restrict__ src, TO *__restrict__ dst, size_t n, const TO *__restrict__ add = nullptr) {
+    typedef TI vin __attribute__((ext_vector_type(4)));
+    typedef TO vout __attribute__((ext_vector_type(4)));
+    const size_t n4 = n >> 2, stride = (size_t)gridDim.x * blockDim.x, t0 = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    for (size_t i = t0; i < n4; i += stride) {
+        const vin v = reinterpret_cast<const vin *>(src)[i];
+        float f[4] = {(float)v[0], (float)v[1], (float)v[2], (float)v[3]};
+        if constexpr (ADD) {
+            const vout a = reinterpret_cast<const vout *>(add)[i];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) f[q] += (float)a[q];
+        }
+        reinterpret_cast<vout *>(dst)[i] = vout{(TO)f[0], (TO)f[1], (TO)f[2], (TO)f[3]};
+    }
+    for (size_t i = 4 * n4 + t0; i < n; i += stride) {
+        float f = (float)src[i];
+        if constexpr (ADD) f += (float)add[i];
+        dst[i] = (TO)f;
+    }
 }
 
 // column statistics of the generic path: one thread per (32-row block, column) reads C back
@@ -1256,10 +1281,28 @@ int launch_transpose_cast(const void *src, void *dst, int rows, int cols, int sr
 int launch_cast(const void *src, void *dst, size_t n, int src_bf16, int dst_bf16, hipStream_t st) {
     if (n == 0) return 0;
     if (!src || !dst) return EPN_ENULL;
-    const dim3 grid((unsigned)((n + 255) / 256 < 4096 ? (n + 255) / 256 : 4096)), blk(256);
-    if (!src_bf16 && dst_bf16) EPN_LAUNCH((cast_kernel<float, __bf16>), grid, blk, 0, st, (const float *)src, (__bf16 *)dst, n);
-    else if (src_bf16 && !dst_bf16) EPN_LAUNCH((cast_kernel<__bf16, float>), grid, blk, 0, st, (const __bf16 *)src, (float *)dst, n);
-    else return EPN_EINVAL;
+    // vector accesses need 16-byte aligned pointers; anything else runs the scalar tail loop over everything
+    const bool al = !(((uintptr_t)src | (uintptr_t)dst) & 15);
+    const size_t nv = al ? n : 0, work = al ? (n + 3) / 4 : n;
+    const dim3 grid((unsigned)((work + 255) / 256 < 8192 ? (work + 255) / 256 : 8192)), blk(256);
+    if (!src_bf16 && dst_bf16) {
+        if (al) EPN_LAUNCH((cast_kernel<float, __bf16>), grid, blk, 0, st, (const float *)src, (__bf16 *)dst, nv, nullptr);
+        else EPN_LAUNCH((cast_scalar_kernel<float, __bf16>), grid, blk, 0, st, (const float *)src, (__bf16 *)dst, n);
+    } else if (src_bf16 && !dst_bf16) {
+        if (al) EPN_LAUNCH((cast_kernel<__bf16, float>), grid, blk, 0, st, (const __bf16 *)src, (float *)dst, nv, nullptr);
+        else EPN_LAUNCH((cast_scalar_kernel<__bf16, float>), grid, blk, 0, st, (const __bf16 *)src, (float *)dst, n);
+    } else return EPN_EINVAL;
+    EPN_CHECK_LAUNCH();
+    return 0;
+}
+
+int launch_cast_add(const float *src, const void *add_bf16, void *dst_bf16, size_t n, hipStream_t st) {
+    if (n == 0) return 0;
+    if (!src || !add_bf16 || !dst_bf16) return EPN_ENULL;
+    if (((uintptr_t)src | (uintptr_t)add_bf16 | (uintptr_t)dst_bf16) & 15) return EPN_EINVAL;
+    const size_t work = (n + 3) / 4;
+    const dim3 grid((unsigned)((work + 255) / 256 < 8192 ? (work + 255) / 256 : 8192)), blk(256);
+    EPN_LAUNCH((cast_kernel<float, __bf16, true>), grid, blk, 0, st, src, (__bf16 *)dst_bf16, n, (const __bf16 *)add_bf16);
     EPN_CHECK_LAUNCH();
     return 0;
 }
@@ -1351,4 +1394,7 @@ extern "C" int epn_transpose_cast(const void *src, void *dst, int rows, int cols
 }
 extern "C" int epn_cast(const void *src, void *dst, size_t n, int src_bf16, int dst_bf16, epn_stream_t stream) {
     return launch_cast(src, dst, n, src_bf16, dst_bf16, epn_stream(stream));
+}
+extern "C" int epn_cast_add_bf16(const float *src, const void *add, void *dst, size_t n, epn_stream_t stream) {
+    return launch_cast_add(src, add, dst, n, epn_stream(stream));
 }

@@ -451,6 +451,13 @@ class InterSO3ConvSplitFn(torch.autograd.Function):
                 _lib.check(_launch("inter_ungroup", _inter_key(d), gflops, G.device,
                                    lambda: ungrp(ctypes.byref(d), ctypes.c_void_p(dG.data_ptr()), _cl_ptr(gf), wsp, wsn,
                                                  _lib.stream_of(G))), "inter_ungroup")
+            if (grad_shared is not None and G.dtype == torch.bfloat16 and gf.dtype == torch.float32
+                    and grad_shared.dtype == torch.bfloat16):
+                gs = to_cl(grad_shared, "grad_shared")           # bf16(gf) + the other branch's gradient in one pass
+                out = empty_cl(d.b, cin, d.p1, d.na, G.device, torch.bfloat16)
+                _lib.check(lib.epn_cast_add_bf16(gf.data_ptr(), gs.data_ptr(), out.data_ptr(), gf.numel(), _lib.stream_of(gf)),
+                           "cast_add")
+                return out, gW, None, None
             gf = cast_feats(gf, G.dtype)
             if grad_shared is not None:
                 gf = gf + grad_shared.to(gf.dtype)

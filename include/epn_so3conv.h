@@ -463,6 +463,10 @@ int epn_gemm_tn_grouped(int bf16, int nprob, const epn_gemm_tn_problem *probs, v
  * bf16 copies of the fp32 master weights); epn_cast converts a flat array. */
 int epn_transpose_cast(const void *src, void *dst, int rows, int cols, int src_bf16, int dst_bf16, epn_stream_t stream);
 int epn_cast(const void *src, void *dst, size_t n, int src_bf16, int dst_bf16, epn_stream_t stream);
+/* dst bf16[n] = bf16(src f32[n] + float(add bf16[n])) in one pass (16-byte aligned pointers): the fp32 scatter target of a
+ * bf16 network's InterSO3Conv data gradient converted AND added to the gradient that reached the same tensor through the
+ * block's skip branch. */
+int epn_cast_add_bf16(const float *src, const void *add, void *dst, size_t n, epn_stream_t stream);
 
 /* ---------------------------------------------------------------------------------------------------------------------
  * bf16 feature path (BASELINE configs 3-4: "bf16 features / fp32 accumulate"; the reference dispatches float/double only,
