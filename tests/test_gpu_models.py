@@ -153,6 +153,76 @@ def test_full_width_cls_step_matches_oracle_loss(gpu):
         assert grad_close(u, v), n
 
 
+@pytest.mark.parametrize("dt", ["f32", "bf16"])
+def test_captured_step_reproduces_the_eager_gradients(gpu, dt):
+    """bench.py times a HIP-graph replay of forward + loss + backward.  The replayed graph must compute what the eager step
+    computes: loss and every parameter gradient of the full-width classification network (2 clouds), eager vs replay of a
+    capture -- with the skip branch on its second stream, the shared-input gradient accumulated in place by the scatter,
+    the epilogue statistics and the packed grouping all inside the capture.  Tolerance: the fp32 atomics of the scatter
+    land in a different order from run to run (1e-4 of each gradient's scale; bf16 features: 2e-2)."""
+    from epn_pointcloud_amd import models as M, schedule as S
+    torch.manual_seed(3)
+    layers = S.cls_so3net_schedule(1024)
+    m = M.ClsSO3ConvModel(layers, out_mlps=(256,), pooling="attention").to(gpu).train()
+    if dt == "bf16":
+        S.set_feature_dtype(m, torch.bfloat16)
+    pts = S.synthetic_clouds(2, 1024, gpu, seed=4)
+    labels = torch.tensor([3, 17], device=gpu)
+    params = [p for p in m.parameters() if p.requires_grad]
+
+    def compute():
+        for p in params:
+            p.grad = None
+        loss = torch.nn.functional.cross_entropy(m(pts)[0], labels)
+        loss.backward()
+        return loss
+
+    # BatchNorm running statistics advance on every step: restored so that eager and replay start from the same state
+    # (only those: the index tables are cache keys of the library's derived tables -- rewriting them would rebuild the tables
+    # on the host in the middle of the capture)
+    stats = {k: v for k, v in m.named_buffers() if "running_" in k or "num_batches" in k}
+    saved = {k: v.clone() for k, v in stats.items()}
+
+    def restore():
+        with torch.no_grad():
+            for k, v in stats.items():
+                v.copy_(saved[k])
+    side = torch.cuda.Stream(device=gpu)
+    side.wait_stream(torch.cuda.current_stream(gpu))
+    with torch.cuda.stream(side):                        # eager steps off the default stream, as torch asks before a capture
+        compute()
+        restore()
+        loss_e = compute().detach().clone()
+        ge = [p.grad.detach().clone() for p in params]
+        restore()
+    torch.cuda.current_stream(gpu).wait_stream(side)
+    torch.cuda.synchronize(gpu)
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(graph, capture_error_mode="thread_local"):
+        loss_c = compute()
+    graph.replay()
+    torch.cuda.synchronize(gpu)
+    tol = 2e-2 if dt == "bf16" else 1e-4
+    assert abs(loss_c.item() - loss_e.item()) <= tol * max(1.0, abs(loss_e.item()))
+    # Parameters whose exact gradient is ZERO are left out: the first block's skip convolution (a constant occupancy feature
+    # times a weight, then BatchNorm: the output does not depend on the weight) and the biases a normalisation cancels -- what
+    # they hold is the atomics' rounding noise (|g| < 1e-3 of the largest gradient in the network), different on every run.
+    gmax = max(g.abs().max().item() for g in ge)
+    bad, checked = [], 0
+    for (n, p), g in zip(((n, p) for n, p in m.named_parameters() if p.requires_grad), ge):
+        scale = g.abs().max().item()
+        # (bf16 features: the rounded products of that first skip convolution are no longer exactly constant, and the BatchNorm
+        # behind it divides their noise by sqrt(eps): an O(1) gradient made of nothing but rounding, left out by name)
+        if scale < 1e-3 * gmax or n == "backbone.0.blocks.0.skip_conv.weight":
+            continue
+        checked += 1
+        err = (p.grad - g).abs().max().item()
+        if err > tol * scale:
+            bad.append((n, err, scale))
+    assert not bad, bad
+    assert checked > 40
+
+
 def test_cls_model_kanchor20_vs_reference_golden(gpu):
     """Reduced-anchor configuration: every block is an InterSO3ConvBlock (no intra conv, no skip); outputs and two
     gradients against the reference's own build of that network."""
