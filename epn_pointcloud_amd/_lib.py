@@ -90,7 +90,7 @@ def get_lib():
     lib.epn_initial_anchor_query_f32.argtypes = [_vp, _vp, _vp, _ci, _ci, _ci, _ci, _ci, _cf, _cf, _vp, _vp, _vp]
     lib.epn_gather_fwd_f32.argtypes = [_vp, _vp, _ci, _ci, _ci, _ci, _vp, _vp]
     lib.epn_gather_bwd_f32.argtypes = [_vp, _vp, _ci, _ci, _ci, _ci, _vp, _vp]
-    lib.epn_ball_query_f64.argtypes = [_vp, _vp, _ci, _ci, _ci, ctypes.c_double, _ci, _vp, _vp]
+    lib.epn_ball_query_f64.argtypes = [_vp, _vp, _ci, _ci, _ci, ctypes.c_float, _ci, _vp, _vp]
     lib.epn_fps_f64.argtypes = [_vp, _ci, _ci, _ci, _vp, _vp, _vp]
     lib.epn_gather_fwd_f64.argtypes = lib.epn_gather_fwd_f32.argtypes
     lib.epn_gather_bwd_f64.argtypes = lib.epn_gather_bwd_f32.argtypes

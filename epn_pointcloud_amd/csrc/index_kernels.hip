@@ -213,7 +213,7 @@ __device__ __forceinline__ double sq3_t(double a, double b, double c) {
 template <typename T>   // float, or double (the reference dispatches on both: grouping_cuda_kernel.cu:477)
 __global__ __launch_bounds__(256) void ball_query_kernel(const T *__restrict__ new_xyz,
                                                          const T *__restrict__ xyz, int n, int m,
-                                                         T radius, int nsample,
+                                                         float radius, int nsample,
                                                          int32_t *__restrict__ idx) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -225,7 +225,9 @@ __global__ __launch_bounds__(256) void ball_query_kernel(const T *__restrict__ n
     const T *q = new_xyz + (size_t)bi * 3 * m;
     const T *s = xyz + (size_t)bi * 3 * n;
     const T qx = q[j], qy = q[m + j], qz = q[2 * m + j];
-    const T radius2 = radius * radius;      // one rounded multiply in T (no contraction possible)
+    // reference: kernel parameter `float radius`, `scalar_t radius2 = radius * radius;` (grouping_cuda_kernel.cu:67,80):
+    // the square is ONE rounded FLOAT multiply, widened to T afterwards -- also for T = double
+    const T radius2 = (T)__fmul_rn(radius, radius);
 
     for (int t = lane; t < nsample; t += 64) row[t] = 0;  // reference zero-initialises idx
 
@@ -522,7 +524,7 @@ extern "C" int epn_initial_anchor_query_f32(const float *centers, const float *x
 }
 
 // ---- fp64 dispatch of the index / gather extensions (AT_DISPATCH_FLOATING_TYPES in the reference: double callers)
-extern "C" int epn_ball_query_f64(const double *new_xyz, const double *xyz, int b, int n, int m, double radius,
+extern "C" int epn_ball_query_f64(const double *new_xyz, const double *xyz, int b, int n, int m, float radius,
                                   int nsample, int32_t *idx, epn_stream_t stream) {
     if (b < 0 || n < 1 || m < 0 || nsample < 1 || nsample > 4096) return EPN_EINVAL;
     if (b == 0 || m == 0) return 0;

@@ -27,14 +27,15 @@ def free_port():
 def launch(world, argv=None, env=None, timeout=None):
     """Run `argv` (default: this very command line) as `world` rank processes on this node, one per GPU, with the
     torchrun environment (RANK / LOCAL_RANK / WORLD_SIZE / MASTER_ADDR=127.0.0.1 / MASTER_PORT).  Rank 0 inherits
-    stdout.  The children are POLLED: the first one that exits non-zero (or the watchdog: `timeout` seconds, default
-    EPN_DP_TIMEOUT or 1500) gets the others terminated -- a dead rank must not leave its peers blocked inside a collective
+    stdout.  The children are POLLED: the first one that exits non-zero (or the watchdog: `timeout` seconds; None = no
+    limit, which is the default -- a stand-in for torchrun must not kill a long job; bench.py and the tests pass one)
+    gets the others terminated -- a dead rank must not leave its peers blocked inside a collective
     until some outer limit kills the job -- and its exit code is returned (124 for the watchdog); 0 when all ranks succeed.
     What `python -m torch.distributed.run --nproc-per-node N` would do, for callers that start the program without a
     launcher."""
     import time
     argv = list(argv) if argv is not None else [sys.executable] + sys.argv
-    timeout = float(os.environ.get("EPN_DP_TIMEOUT", "1500")) if timeout is None else float(timeout)
+    timeout = float("inf") if timeout is None else float(timeout)
     port = free_port()
     procs = []
     for r in range(world):

@@ -75,8 +75,10 @@ int epn_gather_bwd_f32(const float *grad_out, const int32_t *idx, int b, int c, 
  * (AT_DISPATCH_FLOATING_TYPES: grouping_cuda_kernel.cu:477 ball query, :638-726 FPS; gathering_cuda_kernel.cu:117,151).
  * Same semantics with double coordinates / features; indices stay int32.  epn_fps_f64 takes the reference's `temp`
  * buffer (f64[b,n], grouping_cuda.cpp:167-168; initialised to 1e10 here) because it keeps the running minima there, as the
- * reference kernel does -- fp64 sampling is a compatibility path, not a tuned one. */
-int epn_ball_query_f64(const double *new_xyz, const double *xyz, int b, int n, int m, double radius, int nsample,
+ * reference kernel does -- fp64 sampling is a compatibility path, not a tuned one.  `radius` stays a FLOAT and is squared in
+ * float before it is widened, as the reference's templated kernel does (`float radius`, `scalar_t radius2 = radius *
+ * radius;`, grouping_cuda_kernel.cu:67,80; host side grouping_cuda.cpp:74). */
+int epn_ball_query_f64(const double *new_xyz, const double *xyz, int b, int n, int m, float radius, int nsample,
                        int32_t *idx, epn_stream_t stream);
 int epn_fps_f64(const double *xyz, int b, int n, int m, double *temp, int32_t *idx, epn_stream_t stream);
 int epn_gather_fwd_f64(const double *points, const int32_t *idx, int b, int c, int n, int m, double *out,

@@ -26,11 +26,34 @@
 #include <stdlib.h>
 #include <string.h>
 
+/* The CUDA source does not pin the evaluation order (nvcc contracts by default).  Order 0 is the canonical one, shared bit
+ * for bit with the HIP kernels; orders 1-3 are the other forms a contracting compiler could have emitted for
+ * `a*a + b*b + c*c`, selectable ONLY so that tests/test_fp_order.py can count how many FPS / ball-query decisions on the
+ * benchmark inputs depend on the choice (float kernels only; nothing in the product reads this switch). */
+static int g_sq3_order = 0;
+void epn_oracle_set_sq3_order(int order) { g_sq3_order = order; }
+
 static inline float sq3(float a, float b, float c) {
-    float t = a * a;
-    t = fmaf(b, b, t);
-    t = fmaf(c, c, t);
-    return t;
+    float t;
+    switch (g_sq3_order) {
+    default: /* 0: mul, fma, fma */
+        t = a * a;
+        t = fmaf(b, b, t);
+        return fmaf(c, c, t);
+    case 1: { /* no contraction at all: three rounded products, two rounded sums, left to right */
+        const float aa = a * a, bb = b * b, cc = c * c;
+        t = aa + bb;
+        return t + cc;
+    }
+    case 2: /* innermost product last: fma(a,a, fma(b,b, c*c)) */
+        t = c * c;
+        t = fmaf(b, b, t);
+        return fmaf(a, a, t);
+    case 3: /* LLVM-style contraction of ((a*a + b*b) + c*c): the FIRST product of each sum is fused: fma(c,c, fma(a,a, b*b)) */
+        t = b * b;
+        t = fmaf(a, a, t);
+        return fmaf(c, c, t);
+    }
 }
 
 /* grouping_cuda_kernel.cu:29-33 : block = min(1024, 2^floor(log2(n))), >= 1 */
@@ -190,7 +213,8 @@ void epn_oracle_initial_anchor_query_f32(const float *centers, const float *xyz,
 /* ------------------------------------------------------------------------------------------------------------------
  * fp64 variants: the reference dispatches these kernels on float AND double (AT_DISPATCH_FLOATING_TYPES,
  * grouping_cuda_kernel.cu:477,638-726, gathering_cuda_kernel.cu:117,151).  Same algorithms with scalar_t = double;
- * the radius / temp / 1e-3 threshold arithmetic follows the templates (radius2 = radius*radius in scalar_t, the
+ * the radius / temp / 1e-3 threshold arithmetic follows the templates (radius2 = (scalar_t)(radius*radius) with the product in
+ * float -- `radius` is a float kernel parameter, grouping_cuda_kernel.cu:67,80 --, the
  * magnitude test compares a double with the double literal).  Canonical squared distance as above, in double.
  */
 static inline double sq3d(double a, double b, double c) {
@@ -200,9 +224,12 @@ static inline double sq3d(double a, double b, double c) {
     return t;
 }
 
-void epn_oracle_ball_query_f64(const double *new_xyz, const double *xyz, int b, int n, int m, double radius,
+void epn_oracle_ball_query_f64(const double *new_xyz, const double *xyz, int b, int n, int m, float radius,
                                int nsample, int32_t *idx) {
-    const double radius2 = radius * radius;
+    /* grouping_cuda_kernel.cu:67,80: `float radius` is a kernel parameter of every instantiation and
+     * `scalar_t radius2 = radius * radius;` squares it in FLOAT; the double kernel widens the rounded product. */
+    const float radius2f = radius * radius;
+    const double radius2 = (double)radius2f;
     memset(idx, 0, sizeof(int32_t) * (size_t)b * m * nsample);
     for (int bi = 0; bi < b; ++bi) {
         const double *q = new_xyz + (size_t)bi * 3 * m;

@@ -54,14 +54,29 @@ def _load():
         lib.epn_oracle_initial_anchor_query_f32.argtypes = [f32p, f32p, f32p, ci, ci, ci, ci, ci, ctypes.c_float,
                                                             ctypes.c_float, f32p, f32p]
         f64p = ctypes.POINTER(ctypes.c_double)
-        lib.epn_oracle_ball_query_f64.argtypes = [f64p, f64p, ci, ci, ci, ctypes.c_double, ci, i32p]
+        lib.epn_oracle_ball_query_f64.argtypes = [f64p, f64p, ci, ci, ci, ctypes.c_float, ci, i32p]
         lib.epn_oracle_fps_f64.argtypes = [f64p, ci, ci, ci, f64p, i32p]
         lib.epn_oracle_gather_fwd_f64.argtypes = [f64p, i32p, ci, ci, ci, ci, f64p]
         lib.epn_oracle_gather_bwd_f64.argtypes = [f64p, i32p, ci, ci, ci, ci, f64p]
+        lib.epn_oracle_set_sq3_order.argtypes = [ci]
         lib.epn_oracle_opt_n_threads.argtypes = [ci]
         lib.epn_oracle_opt_n_threads.restype = ci
         _lib = lib
     return _lib
+
+
+class sq3_order:
+    """with sq3_order(k): the float FPS / ball query evaluate squared distances in one of the alternative orders of
+    epn_oracle.c (0 = canonical).  For tests/test_fp_order.py only."""
+
+    def __init__(self, order):
+        self.order = int(order)
+
+    def __enter__(self):
+        _load().epn_oracle_set_sq3_order(self.order)
+
+    def __exit__(self, *exc):
+        _load().epn_oracle_set_sq3_order(0)
 
 
 def _f32(t):

@@ -77,3 +77,26 @@ BALLQ.append(dict(name="strict_inequality", query=_q([0]), support=_support, rad
 # radius 10: q x=3.5: everything is inside; the scan stops at cnt == nsample -> the FIRST four indices        -> [0,1,2,3]
 BALLQ.append(dict(name="first_nsample_hits_in_index_order", query=_q([3.5]), support=_support, radius=10.0, nsample=4,
                   idx=[[0, 1, 2, 3]]))
+
+
+# ---- fp64 coordinates only.  The templated reference kernel keeps `float radius` as its parameter and squares it in FLOAT
+#  (`scalar_t radius2 = radius * radius;`, grouping_cuda_kernel.cu:67,80): with scalar_t = double the threshold is the float
+#  product widened, NOT the double product of a double radius.  radius = 0.2:
+#    float(0.2)                 = 0.20000000298023224
+#    its exact square           = 0.04000000119209290...; the float32 neighbours are 0.03999999910593033 and
+#                                 0.04000000283122063 (spacing 3.7e-9): the product rounds to 0.04000000283122063
+#    threshold as the reference has it   r2 = 0.04000000283122063
+#    threshold of a double radius        0.2 * 0.2 = 0.04000000000000001   (what round 3's f64 path used)
+#  support k=1 at x = 0.2000000025: d2 = 0.04000000100000000625 -- BETWEEN the two.  Reference: d2 < r2 -> hit.
+#  q x=0, support x = [0, 0.2000000025, 5], nsample 4: hits k=0 (d2 = 0), k=1 -> cnt 2 < 3 -> cyclic fill -> [0,1,0,1]
+#  (a double-squared radius would give one hit: [0,0,0,0]).
+BALLQ_F64 = []
+_s64 = np.zeros((1, 3, 3), dtype=np.float64)
+_s64[0, 0] = [0.0, 0.2000000025, 5.0]
+BALLQ_F64.append(dict(name="radius_is_squared_in_float_then_widened", query=np.zeros((1, 3, 1), dtype=np.float64), support=_s64,
+                      radius=0.2, nsample=4, idx=[[0, 1, 0, 1]]))
+# the other side: x = 0.20000000715 -> d2 = 0.0400000028600000511 > r2 = 0.04000000283122063 -> only k=0 -> cnt 1 -> [0,0,0,0]
+_s64b = _s64.copy()
+_s64b[0, 0, 1] = 0.20000000715
+BALLQ_F64.append(dict(name="just_outside_the_float_squared_radius", query=np.zeros((1, 3, 1), dtype=np.float64), support=_s64b,
+                      radius=0.2, nsample=4, idx=[[0, 0, 0, 0]]))

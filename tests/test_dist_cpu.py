@@ -65,7 +65,7 @@ def test_launcher_gradbuckets_two_ranks(tmp_path):
     backward hook, two consecutive steps, results equal to the single-process gradients."""
     import sys as _sys
     from epn_pointcloud_amd import dp
-    rc = dp.launch(2, [_sys.executable, os.path.join(ROOT, "tests", "dp_worker.py"), str(tmp_path)])
+    rc = dp.launch(2, [_sys.executable, os.path.join(ROOT, "tests", "dp_worker.py"), str(tmp_path)], timeout=600)
     assert rc == 0
     r0 = torch.load(tmp_path / "r0.pt")
     r1 = torch.load(tmp_path / "r1.pt")
@@ -104,7 +104,7 @@ def test_launcher_stops_the_other_ranks_when_one_dies(tmp_path):
             "open(os.path.join(sys.argv[1], f'started{r}'), 'w').close()\n"
             "sys.exit(3) if r == 1 and sys.argv[2] == 'die' else time.sleep(60)\n")
     t0 = time.monotonic()
-    rc = dp.launch(2, [_sys.executable, "-c", prog, str(tmp_path), "die"])
+    rc = dp.launch(2, [_sys.executable, "-c", prog, str(tmp_path), "die"], timeout=600)
     assert rc == 3 and time.monotonic() - t0 < 30
     assert (tmp_path / "started0").exists() and (tmp_path / "started1").exists()
     t0 = time.monotonic()

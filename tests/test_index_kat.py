@@ -4,7 +4,7 @@ import numpy as np
 import pytest
 import torch
 
-from kat_index import BALLQ, FPS
+from kat_index import BALLQ, BALLQ_F64, FPS
 
 T = torch.from_numpy
 
@@ -48,7 +48,7 @@ def test_fps_kat_oracle_f64(case):
     assert idx.tolist() == [case["idx"]]
 
 
-@pytest.mark.parametrize("case", BALLQ, ids=[c["name"] for c in BALLQ])
+@pytest.mark.parametrize("case", BALLQ + BALLQ_F64, ids=[c["name"] for c in BALLQ + BALLQ_F64])
 def test_ball_query_kat_oracle_f64(case):
     from oracle import index_ref
     idx = index_ref.ball_query(T(case["query"]).double(), T(case["support"]).double(), case["radius"], case["nsample"])
@@ -64,7 +64,7 @@ def test_fps_kat_hip_f64(gpu, vgtk_alias, case):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("case", BALLQ, ids=[c["name"] for c in BALLQ])
+@pytest.mark.parametrize("case", BALLQ + BALLQ_F64, ids=[c["name"] for c in BALLQ + BALLQ_F64])
 def test_ball_query_kat_hip_f64(gpu, vgtk_alias, case):
     import vgtk.cuda.grouping as cuda_nn
     idx = cuda_nn.ball_query(T(case["query"]).double().to(gpu), T(case["support"]).double().to(gpu), case["radius"],
