@@ -36,6 +36,10 @@ EXPORTS = [
     "epn_inter_ungroup_acc_f32", "epn_inter_ungroup_acc_bf16", "epn_stats_finish", "epn_stats_finish_workspace_bytes",
     "epn_so3_basis_stats_f32", "epn_so3_basis_stats_split_f32", "epn_so3_basis_stats_bf16",
     "epn_spectral_weights_f32", "epn_spectral_weights_bwd_f32", "epn_spectral_weights_bf16", "epn_cast_add_bf16",
+    "epn_inter_c1_ok", "epn_inter_so3conv_fwd_c1_f32", "epn_inter_so3conv_bwd_weight_c1_f32",
+    "epn_inter_split_ok", "epn_inter_split_saved_bytes", "epn_inter_split_workspace_bytes",
+    "epn_inter_so3conv_fwd_split_f32", "epn_inter_so3conv_fwd_split_bf16", "epn_inter_so3conv_bwd_split_f32",
+    "epn_inter_so3conv_bwd_split_bf16",
 ]
 
 _vp, _ci, _cf, _sz = ctypes.c_void_p, ctypes.c_int, ctypes.c_float, ctypes.c_size_t
@@ -107,6 +111,20 @@ def get_lib():
     lib.epn_inter_onchip_workspace_bytes.restype = _sz
     lib.epn_inter_so3conv_fwd_onchip_f32.argtypes = [dp, _vp, _vp, _vp, _vp, _sz, _vp]
     lib.epn_inter_so3conv_fwd_bf16.argtypes = [dp, _vp, _vp, _vp, _vp, _sz, _vp]
+    lib.epn_inter_c1_ok.argtypes = [dp]
+    lib.epn_inter_c1_ok.restype = _ci
+    lib.epn_inter_so3conv_fwd_c1_f32.argtypes = [dp, _vp, _vp, _vp, _vp, _vp, _sz, _vp]
+    lib.epn_inter_so3conv_bwd_weight_c1_f32.argtypes = [dp, _vp, _vp, _vp, _vp]
+    lib.epn_inter_split_ok.argtypes = [dp]
+    lib.epn_inter_split_ok.restype = _ci
+    lib.epn_inter_split_saved_bytes.argtypes = [dp, _ci]
+    lib.epn_inter_split_saved_bytes.restype = _sz
+    lib.epn_inter_split_workspace_bytes.argtypes = [dp, _ci, _ci]
+    lib.epn_inter_split_workspace_bytes.restype = _sz
+    for _n in ("epn_inter_so3conv_fwd_split_f32", "epn_inter_so3conv_fwd_split_bf16"):
+        getattr(lib, _n).argtypes = [dp, _vp, _vp, _vp, _vp, _vp, _sz, _vp, _sz, _vp]
+    for _n in ("epn_inter_so3conv_bwd_split_f32", "epn_inter_so3conv_bwd_split_bf16"):
+        getattr(lib, _n).argtypes = [dp, _vp, _vp, _vp, _sz, _vp, _ci, _vp, _vp, _sz, _vp]
     lib.epn_inter_group_workspace_bytes.argtypes = [dp]
     lib.epn_inter_group_workspace_bytes.restype = _sz
     lib.epn_inter_group_f32.argtypes = [dp, _vp, _vp, _vp, _sz, _vp]
@@ -215,14 +233,16 @@ def get_lib():
 
 
 # Host-only entry points (no stream argument, nothing launched): handed out unwrapped.
-_HOST_ONLY = {"epn_version", "epn_strerror", "epn_set_kernel_policy", "epn_last_kernel", "epn_inter_is_fused",
+_HOST_ONLY = {"epn_version", "epn_strerror", "epn_set_kernel_policy", "epn_last_kernel", "epn_inter_is_fused", "epn_inter_split_ok", "epn_inter_c1_ok",
+              "epn_inter_split_saved_bytes",
               "epn_intra_is_fused", "epn_inter_onchip_ok", "epn_inter_group_packed_ok", "epn_inter_packed_position"}
 CALL_HOOK = None      # ops.profile_begin(): callable(name, fn, args) -> rc, brackets every launching call with HIP events
 
 
 class _StreamArg(ctypes.c_void_p):
-    """epn_stream_t argument that remembers the device to switch back to after the call (stream_of)."""
+    """epn_stream_t argument that remembers its device, and the device to switch back to after the call (stream_of)."""
     restore = None
+    device = None
 
 
 class _LibProxy:
@@ -242,10 +262,17 @@ class _LibProxy:
 
         def call(*args):
             hook = CALL_HOOK
+            st = args[-1] if args else None
+            prev = getattr(st, "restore", None)
+            dev = getattr(st, "device", None)
+            if dev is not None and torch.cuda.current_device() != dev:
+                # a stream argument used for a SECOND call (stream_of()'s switch was undone when the first returned): the
+                # proxy makes the stream's device current itself and restores whatever was current
+                prev = torch.cuda.current_device() if prev is None else prev
+                torch.cuda.set_device(dev)
             try:
                 return fn(*args) if hook is None else hook(name, fn, args)
             finally:
-                prev = getattr(args[-1], "restore", None) if args else None
                 if prev is not None:
                     torch.cuda.set_device(prev)
         call.__name__ = name
@@ -276,6 +303,7 @@ def stream_of(t):
     proxy restores it when the call returns -- the scoped guard the reference's extensions get from ATen."""
     dev = t.device
     arg = _StreamArg(torch.cuda.current_stream(dev).cuda_stream)
+    arg.device = dev.index
     if dev.index is not None and torch.cuda.current_device() != dev.index:
         arg.restore = torch.cuda.current_device()
         torch.cuda.set_device(dev)

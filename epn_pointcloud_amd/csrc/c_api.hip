@@ -77,7 +77,7 @@ static int check_desc(const epn_inter_desc *d) {
     if (!d) return EPN_ENULL;
     if (d->b < 0 || d->p1 < 1 || d->p2 < 0 || d->nn < 1 || d->na < 1 || d->ks < 1 || d->cin < 1 || d->cout < 1)
         return EPN_EINVAL;
-    if (d->ks > EPN_KS_MAX) return EPN_EINVAL;
+    if (d->ks > EPN_KS_GENERIC_MAX) return EPN_EINVAL;   // fused kernels: ks <= EPN_KS_MAX (inter_mfma_shape_ok); generic beyond
     if (!(d->sigma > 0.f) && !d->dense_w) return EPN_EINVAL;
     if (!d->ball_idx) return EPN_ENULL;
     if (!d->dense_w && (!d->xyz || !d->new_xyz || !d->anchors || !d->kernels)) return EPN_ENULL;
@@ -86,7 +86,9 @@ static int check_desc(const epn_inter_desc *d) {
 
 static bool use_mfma(const epn_inter_desc *d) { return inter_uses_mfma(d) && !force_generic() && !d->dense_w; }
 
-extern "C" const char *epn_version(void) { return "epn_so3conv 0.1 (gfx950)"; }
+// 0.2: epn_gemm_nt_problem gained the trailing `col_stats` member (round 3) and epn_ball_query_f64 takes `float radius`
+// (round 4) -- callers compiled against the 0.1 header must be rebuilt; INTEGRATION.md "ABI revisions"
+extern "C" const char *epn_version(void) { return "epn_so3conv 0.2 (gfx950)"; }
 
 extern "C" const char *epn_strerror(int code) {
     switch (code) {
@@ -165,6 +167,33 @@ extern "C" int epn_inter_so3conv_fwd_f32(const epn_inter_desc *d, const float *f
     rc = launch_inter_group(d, base + ws.rk_off, feats_cl, G, st);
     if (rc) return rc;
     return launch_rowgemm_nt(G, W, (size_t)d->b * d->p2 * d->na, d->cin * d->ks, d->cout, out_cl, st);
+}
+
+// ---- cin = 1 (first layer of every model) with the grouped values kept for the weight gradient
+extern "C" int epn_inter_c1_ok(const epn_inter_desc *d) {
+    return d && !check_desc(d) && inter_c1_fwd_ok(d) && inter_c1_bwd_weight_ok(d) && !force_generic() ? 1 : 0;
+}
+extern "C" int epn_inter_so3conv_fwd_c1_f32(const epn_inter_desc *d, const float *feats_cl, const float *W, float *out_cl,
+                                            float *grouped, void *workspace, size_t workspace_bytes, epn_stream_t stream) {
+    if (!epn_inter_c1_ok(d)) return EPN_EINVAL;
+    hipStream_t st = epn_stream(stream);
+    InterWs ws;
+    float *base = nullptr;
+    int rc = prep(d, workspace, workspace_bytes, false, ws, base, st);
+    if (rc) return rc;
+    if (!feats_cl || !W || !out_cl) return EPN_ENULL;
+    if (d->b == 0 || d->p2 == 0) return 0;
+    return launch_inter_c1_fwd(d, base + ws.rk_off, feats_cl, W, out_cl, st, grouped);
+}
+extern "C" int epn_inter_so3conv_bwd_weight_c1_f32(const epn_inter_desc *d, const float *grouped, const float *grad_out_cl,
+                                                   float *grad_W, epn_stream_t stream) {
+    if (!epn_inter_c1_ok(d)) return EPN_EINVAL;
+    if (!grad_W) return EPN_ENULL;
+    hipStream_t st = epn_stream(stream);
+    EPN_HIP(hipMemsetAsync(grad_W, 0, sizeof(float) * (size_t)d->cout * d->ks, st));
+    if (d->b == 0 || d->p2 == 0) return 0;
+    if (!grouped || !grad_out_cl) return EPN_ENULL;
+    return launch_inter_c1_bwd_weight(d, nullptr, nullptr, grad_out_cl, grad_W, st, grouped);
 }
 
 extern "C" int epn_inter_so3conv_bwd_data_f32(const epn_inter_desc *d, const float *grad_out_cl, const float *W,

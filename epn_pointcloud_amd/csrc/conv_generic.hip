@@ -263,16 +263,24 @@ int launch_inter_weights(const epn_inter_desc *d, float *w, hipStream_t st) {
 
 int launch_inter_group(const epn_inter_desc *d, const float *rk, const float *feats, float *G, hipStream_t st) {
     const size_t total = (size_t)d->b * d->p2 * d->na * d->cin;
-    EPN_LAUNCH(inter_group_kernel<EPN_KS_MAX>, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st,
-                       make_geo(d), rk, d->dense_w, d->sigma, feats, d->b, d->na, d->ks, d->cin, G);
+    if (d->ks <= EPN_KS_MAX)
+        EPN_LAUNCH(inter_group_kernel<EPN_KS_MAX>, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st,
+                           make_geo(d), rk, d->dense_w, d->sigma, feats, d->b, d->na, d->ks, d->cin, G);
+    else   // kpsphere66 (kernel_size = 3, vgtk/vgtk/so3conv/functional.py:86-96)
+        EPN_LAUNCH(inter_group_kernel<EPN_KS_GENERIC_MAX>, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st,
+                           make_geo(d), rk, d->dense_w, d->sigma, feats, d->b, d->na, d->ks, d->cin, G);
     EPN_CHECK_LAUNCH();
     return 0;
 }
 
 int launch_inter_scatter(const epn_inter_desc *d, const float *rk, const float *dG, float *dF, hipStream_t st) {
     const size_t total = (size_t)d->b * d->p2 * d->na * d->cin;
-    EPN_LAUNCH(inter_scatter_kernel<EPN_KS_MAX>, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st,
-                       make_geo(d), rk, d->dense_w, d->sigma, dG, d->b, d->na, d->ks, d->cin, dF);
+    if (d->ks <= EPN_KS_MAX)
+        EPN_LAUNCH(inter_scatter_kernel<EPN_KS_MAX>, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st,
+                           make_geo(d), rk, d->dense_w, d->sigma, dG, d->b, d->na, d->ks, d->cin, dF);
+    else
+        EPN_LAUNCH(inter_scatter_kernel<EPN_KS_GENERIC_MAX>, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st,
+                           make_geo(d), rk, d->dense_w, d->sigma, dG, d->b, d->na, d->ks, d->cin, dF);
     EPN_CHECK_LAUNCH();
     return 0;
 }

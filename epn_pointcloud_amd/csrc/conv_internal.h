@@ -3,6 +3,7 @@
 #include "epn_common.h"
 
 #define EPN_KS_MAX 32   // kernel points per anchor are padded to 32 slots (reference uses 24)
+#define EPN_KS_GENERIC_MAX 96   // the any-shape kernels take the reference's larger kernel-point sets (kernel_size 2 / 3: 30 / 66 points)
 #define EPN_NN_MAX 128  // neighbours per output point supported by the fused kernels
 
 namespace epn {
@@ -51,9 +52,9 @@ int launch_intra_bwd_weight_generic(const float *feats, const float *dOut, const
 bool inter_c1_fwd_ok(const epn_inter_desc *d);
 bool inter_c1_bwd_weight_ok(const epn_inter_desc *d);
 int launch_inter_c1_fwd(const epn_inter_desc *d, const float *rk, const float *feats, const float *W, float *out,
-                        hipStream_t st);
+                        hipStream_t st, float *grouped_save = nullptr);
 int launch_inter_c1_bwd_weight(const epn_inter_desc *d, const float *rk, const float *feats, const float *dOut,
-                               float *dW, hipStream_t st);
+                               float *dW, hipStream_t st, const float *grouped_saved = nullptr);
 
 // inter_mfma.hip / intra_mfma.hip (fused MFMA kernels; cin, cout multiples of 16)
 int launch_inter_tables_mfma(const epn_inter_desc *d, const float *rk, float *rk4, float *beta, hipStream_t st);

@@ -737,6 +737,8 @@ extern "C" size_t epn_stats_finish_workspace_bytes(int groups, long long blocks_
 extern "C" int epn_stats_finish(const float *partials, int groups, long long blocks_per_group, int c, float *sums,
                                 void *workspace, size_t workspace_bytes, epn_stream_t stream) {
     if (groups < 0 || blocks_per_group < 0 || c < 1 || blocks_per_group > 0x7fffffffLL) return EPN_EINVAL;
+    // the first level launches one grid row (gridDim.y) per 256 blocks and one grid plane (gridDim.z) per group
+    if (stats_finish_nz(blocks_per_group) > 65535 || groups > 65535) return EPN_EINVAL;
     if (groups == 0) return 0;
     if (!sums || (blocks_per_group && !partials)) return EPN_ENULL;
     hipStream_t st = epn_stream(stream);

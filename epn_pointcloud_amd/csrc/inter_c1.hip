@@ -19,6 +19,8 @@ struct C1Args {
     const float *W;       // fwd: [cout][ks]
     const float *gout;    // bwd: [ncol][cout]
     float *out;           // fwd: [ncol][cout];  bwd: dW [cout][ks]
+    float *gsave;         // fwd, optional: the grouped values G[ncol][ks] kept for the weight gradient
+    const float *gload;   // bwd, optional: G from the forward pass (no weight generation in the backward pass)
     float sigma_inv;
     int p1, p2, nn, na, ks, cout;
     long long ncol;
@@ -89,6 +91,19 @@ __global__ __launch_bounds__(256) void inter_c1_fwd_kernel(C1Args A) {
     if (col >= A.ncol) return;
     float g[EPN_KS_MAX];
     group_column(A, col, g);
+    if (A.gsave) {   // 96 bytes per lane, consecutive lanes consecutive rows: the weight gradient re-reads this instead of
+                     // regenerating 24 x K weights per column (the backward kernel WAS that loop a second time)
+        float *gs = A.gsave + col * A.ks;
+        if ((A.ks & 3) == 0) {
+#pragma unroll
+            for (int k = 0; k < EPN_KS_MAX; k += 4)
+                if (k < A.ks) *reinterpret_cast<f32x4 *>(gs + k) = f32x4{g[k], g[k + 1], g[k + 2], g[k + 3]};
+        } else {
+#pragma unroll
+            for (int k = 0; k < EPN_KS_MAX; ++k)
+                if (k < A.ks) gs[k] = g[k];
+        }
+    }
     float *o = A.out + col * A.cout;
     for (int o4 = 0; o4 < A.cout; o4 += 4) {   // cout % 4 == 0 (launcher)
         f32x4 acc = {0.f, 0.f, 0.f, 0.f};
@@ -124,16 +139,41 @@ __global__ __launch_bounds__(256) void inter_c1_bwd_weight_kernel(C1Args A) {
         const long long base = ((long long)blockIdx.x * A.groups_per_wg + it) * 256;
         if (base >= A.ncol) break;
         const long long col = base + threadIdx.x;
-        float g[EPN_KS_MAX];
-        if (col < A.ncol) {
-            group_column(A, col, g);
+        if (A.gload) {
+            // the wave's 64 rows of saved G are one contiguous run of 64 ks floats: coalesced loads, scattered to the tile
+            const long long w0 = base + wave * 64;
+            const long long wn = A.ncol - w0 < 64 ? A.ncol - w0 : 64;       // rows of this wave inside the tensor (may be <= 0)
+            const float *src = A.gload + w0 * A.ks;
+            const int total = wn > 0 ? (int)wn * A.ks : 0;
+            if ((A.ks & 3) == 0 && ((reinterpret_cast<size_t>(src) & 15) == 0)) {
+                for (int e = 4 * lane; e < 64 * A.ks; e += 256) {
+                    const f32x4 v = e < total ? *reinterpret_cast<const f32x4 *>(src + e) : f32x4{0.f, 0.f, 0.f, 0.f};
+                    const int r = e / A.ks, k0 = e - r * A.ks;
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) Gs[wave * 64 + r][k0 + q] = v[q];
+                }
+            } else {
+                for (int e = lane; e < 64 * A.ks; e += 64) {
+                    const int r = e / A.ks;
+                    Gs[wave * 64 + r][e - r * A.ks] = e < total ? src[e] : 0.f;
+                }
+            }
+            for (int e = lane; e < 64 * (EPN_KS_MAX - A.ks); e += 64) {       // zero padding up to 32 kernel points
+                const int r = e / (EPN_KS_MAX - A.ks);
+                Gs[wave * 64 + r][A.ks + e - r * (EPN_KS_MAX - A.ks)] = 0.f;
+            }
         } else {
+            float g[EPN_KS_MAX];
+            if (col < A.ncol) {
+                group_column(A, col, g);
+            } else {
 #pragma unroll
-            for (int k = 0; k < EPN_KS_MAX; ++k) g[k] = 0.f;
+                for (int k = 0; k < EPN_KS_MAX; ++k) g[k] = 0.f;
+            }
+            // only this wave reads the rows it writes: wave-level ordering is enough
+#pragma unroll
+            for (int k = 0; k < EPN_KS_MAX; ++k) Gs[threadIdx.x][k] = k < A.ks ? g[k] : 0.f;
         }
-        // only this wave reads the rows it writes: wave-level ordering is enough
-#pragma unroll
-        for (int k = 0; k < EPN_KS_MAX; ++k) Gs[threadIdx.x][k] = k < A.ks ? g[k] : 0.f;
         __builtin_amdgcn_wave_barrier();
         const long long wbase = base + wave * 64;
 #pragma unroll 4
@@ -169,7 +209,7 @@ __global__ __launch_bounds__(256) void inter_c1_bwd_weight_kernel(C1Args A) {
 C1Args make_c1(const epn_inter_desc *d, const float *rk) {
     C1Args A;
     A.xyz = d->xyz; A.new_xyz = d->new_xyz; A.idx = d->ball_idx; A.rk = rk;
-    A.feats = nullptr; A.W = nullptr; A.gout = nullptr; A.out = nullptr;
+    A.feats = nullptr; A.W = nullptr; A.gout = nullptr; A.out = nullptr; A.gsave = nullptr; A.gload = nullptr;
     A.sigma_inv = 1.0f / d->sigma;
     A.p1 = d->p1; A.p2 = d->p2; A.nn = d->nn; A.na = d->na; A.ks = d->ks; A.cout = d->cout;
     A.ncol = (long long)d->b * d->p2 * d->na;
@@ -189,9 +229,9 @@ bool inter_c1_bwd_weight_ok(const epn_inter_desc *d) {
 }
 
 int launch_inter_c1_fwd(const epn_inter_desc *d, const float *rk, const float *feats, const float *W, float *out,
-                        hipStream_t st) {
+                        hipStream_t st, float *grouped_save) {
     C1Args A = make_c1(d, rk);
-    A.feats = feats; A.W = W; A.out = out;
+    A.feats = feats; A.W = W; A.out = out; A.gsave = grouped_save;
     const unsigned grid = (unsigned)((A.ncol + 255) / 256);
     EPN_LAUNCH(inter_c1_fwd_kernel, dim3(grid), dim3(256), (size_t)d->cout * d->ks * sizeof(float), st, A);
     EPN_CHECK_LAUNCH();
@@ -199,9 +239,9 @@ int launch_inter_c1_fwd(const epn_inter_desc *d, const float *rk, const float *f
 }
 
 int launch_inter_c1_bwd_weight(const epn_inter_desc *d, const float *rk, const float *feats, const float *dOut,
-                               float *dW, hipStream_t st) {
+                               float *dW, hipStream_t st, const float *grouped_saved) {
     C1Args A = make_c1(d, rk);
-    A.feats = feats; A.gout = dOut; A.out = dW;
+    A.feats = feats; A.gout = dOut; A.out = dW; A.gload = grouped_saved;
     const long long groups = (A.ncol + 255) / 256;
     // two rounds of workgroups: each ends in cout*ks atomics onto the same 1536 addresses (2048 workgroups: 1.48 ms,
     // of which ~0.9 ms contention; 512: see DESIGN 5)

@@ -6,6 +6,7 @@ any other layout is converted once on entry.
 """
 import ctypes
 import os
+import weakref
 
 import torch
 
@@ -237,12 +238,24 @@ class InterSO3ConvFn(torch.autograd.Function):
                              f"b={d.b} p1={d.p1} na={d.na} ks={d.ks}")
         out = empty_cl(d.b, cout, d.p2, d.na, f.device)
         ws, wsp, wsn = _workspace(lib, d, f.device)
-        _lib.check(_launch("inter_fwd", _inter_key(d), _inter_flops(d), f.device,
-                           lambda: lib.epn_inter_so3conv_fwd_f32(ctypes.byref(d), _cl_ptr(f), _lib.dev_ptr(Wc, "W"),
-                                                                 _cl_ptr(out), wsp, wsn, _lib.stream_of(f))),
-                   "inter_so3conv_fwd")
+        grouped = None
+        if cin == 1 and lib.epn_inter_c1_ok(ctypes.byref(d)) and os.environ.get("EPN_C1_SAVE", "1") == "1":
+            # first layer: keep the 24 grouped values per column for the weight gradient (96 B per column) instead of
+            # regenerating the ks x nn weights there -- only when a weight gradient can be asked for
+            if ctx.needs_input_grad[1]:
+                grouped = torch.empty((d.b * d.p2 * d.na, d.ks), dtype=torch.float32, device=f.device)
+            _lib.check(_launch("inter_fwd", _inter_key(d), _inter_flops(d), f.device,
+                               lambda: lib.epn_inter_so3conv_fwd_c1_f32(ctypes.byref(d), _cl_ptr(f), _lib.dev_ptr(Wc, "W"),
+                                                                        _cl_ptr(out), grouped.data_ptr() if grouped is not None
+                                                                        else None, wsp, wsn, _lib.stream_of(f))),
+                       "inter_so3conv_fwd_c1")
+        else:
+            _lib.check(_launch("inter_fwd", _inter_key(d), _inter_flops(d), f.device,
+                               lambda: lib.epn_inter_so3conv_fwd_f32(ctypes.byref(d), _cl_ptr(f), _lib.dev_ptr(Wc, "W"),
+                                                                     _cl_ptr(out), wsp, wsn, _lib.stream_of(f))),
+                       "inter_so3conv_fwd")
         ctx.save_for_backward(f, Wc)
-        ctx.geo = geo
+        ctx.geo, ctx.grouped = geo, grouped
         return out
 
     @staticmethod
@@ -263,7 +276,14 @@ class InterSO3ConvFn(torch.autograd.Function):
                                                                           _lib.dev_ptr(Wc, "W"), _cl_ptr(gf), wsp,
                                                                           wsn, _lib.stream_of(f))),
                        "inter_so3conv_bwd_data")
-        if ctx.needs_input_grad[1]:
+        if ctx.needs_input_grad[1] and ctx.grouped is not None:
+            gW = torch.empty_like(Wc)
+            fl = 2.0 * d.b * d.p2 * d.na * cout * d.ks
+            _lib.check(_launch("inter_bwd_weight_c1", _inter_key(d), fl, f.device,
+                               lambda: lib.epn_inter_so3conv_bwd_weight_c1_f32(ctypes.byref(d), ctx.grouped.data_ptr(), _cl_ptr(g),
+                                                                               _lib.dev_ptr(gW, "grad_W"), _lib.stream_of(f))),
+                       "inter_so3conv_bwd_weight_c1")
+        elif ctx.needs_input_grad[1]:
             gW = torch.empty_like(Wc)
             _lib.check(_launch("inter_bwd_weight", _inter_key(d), _inter_flops(d), f.device,
                                lambda: lib.epn_inter_so3conv_bwd_weight_f32(ctypes.byref(d), _cl_ptr(f), _cl_ptr(g),
@@ -331,7 +351,13 @@ class InterSO3ConvSplitFn(torch.autograd.Function):
         """share_input: also return `feats` itself as a second output.  A caller that feeds the same tensor to another
         branch (the skip path of a SeparableSO3ConvBlock) uses THAT output there: the other branch's gradient then arrives
         here, and the transpose of the grouping accumulates onto it (epn_inter_ungroup_acc_*) -- no zero-fill of the
-        scatter target and no separate addition pass over the two [b, cin, p1, na] gradients."""
+        scatter target and no separate addition pass over the two [b, cin, p1, na] gradients.  That accumulation writes INTO
+        the incoming gradient tensor, which autograd only tolerates for a buffer nobody else can see: backward() checks what
+        it can (not a view; the shared output neither retains its gradient nor carries hooks -- `shared_ref`, set by
+        ops.inter_so3conv) and otherwise adds out of place.  What it cannot see is a consumer whose backward hands ONE tensor
+        to two inputs (`shared + other`): callers of share_input=True promise a consumer with a private gradient buffer, as
+        this library's row gather / 1x1 convolution are (EPN_SHARE_INPUT_GRAD=0 turns the fold off).
+        share_input="stats": only the epilogue statistics are wanted -> returns (out, part)."""
         lib = _lib.get_lib()
         ctx.set_materialize_grads(False)
         ctx.share_input = share_input
@@ -368,13 +394,29 @@ class InterSO3ConvSplitFn(torch.autograd.Function):
         ctx.save_for_backward(G, Wc)
         ctx.geo, ctx.cin, ctx.packed = geo, cin, packed
         out = out2d.view(d.b, d.p2, d.na, cout).permute(0, 3, 1, 2)
+        if share_input == "stats":
+            ctx.mark_non_differentiable(part)
+            return out, part
         if share_input:
             ctx.mark_non_differentiable(part)
             return out, feats, part
         return out
 
     @staticmethod
+    def _may_write_into(ctx, grad_shared):
+        """May the scatter accumulate in place into the incoming gradient of the shared output?  (see forward)"""
+        if grad_shared._base is not None:                       # a view: the base belongs to somebody else
+            return False
+        ref = getattr(ctx, "shared_ref", None)
+        shared = ref() if ref is not None else None
+        if shared is not None and (shared.retains_grad or shared._backward_hooks):
+            return False                                        # the very tensor would be observed as `.grad` / by a hook
+        return True
+
+    @staticmethod
     def backward(ctx, grad_out, grad_shared=None, _grad_part=None):
+        if ctx.share_input == "stats":
+            grad_shared = None
         lib = _lib.get_lib()
         G, Wc = ctx.saved_tensors
         geo, cin = ctx.geo, ctx.cin
@@ -400,7 +442,8 @@ class InterSO3ConvSplitFn(torch.autograd.Function):
             # (bf16 features: starting the fp32 scatter target from the converted gradient instead of zeros measured no gain --
             # 1444 vs 1455 point-clouds/s on the rotation network -- so that path keeps the plain addition)
             onto = (grad_shared is not None and grad_shared.dtype == torch.float32 and G.dtype == torch.float32
-                    and mode != "fused" and not deterministic_bwd(G.dtype))
+                    and mode != "fused" and not deterministic_bwd(G.dtype)
+                    and InterSO3ConvSplitFn._may_write_into(ctx, grad_shared))
             if onto:
                 gf, grad_shared = to_cl(grad_shared, "grad_shared").detach(), None
             else:
@@ -1340,7 +1383,15 @@ def inter_so3conv(feats, W, geo, out_dtype=None, share_input=False):
             plain = mode == "auto" and g_bytes > _device_bytes(feats.device) // 8
         if plain:
             return inter_so3conv(feats, W, geo, out_dtype), feats, None
-        out, shared, part = InterSO3ConvSplitFn.apply(feats, W, geo, True)
+        if not feats.requires_grad:
+            # nothing flows back into `feats` (frozen / detached trunk): handing it out as a differentiable output would make
+            # it require grad through W and cost a discarded dA GEMM (+ scatter) in the skip branch's backward
+            out, part = InterSO3ConvSplitFn.apply(feats, W, geo, "stats")
+            shared = feats
+        else:
+            out, shared, part = InterSO3ConvSplitFn.apply(feats, W, geo, True)
+            if out.grad_fn is not None:
+                out.grad_fn.shared_ref = weakref.ref(shared)    # backward(): is anybody watching this tensor's gradient?
         if (out_dtype or feats.dtype) != out.dtype:
             return cast_feats(out, out_dtype), shared, None      # statistics must be those of the values handed on
         return out, shared, (part if part.numel() else None)

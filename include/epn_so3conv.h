@@ -127,6 +127,20 @@ int epn_inter_so3conv_bwd_weight_f32(const epn_inter_desc *d, const float *feats
                                      const float *grad_out_cl, float *grad_W, void *workspace,
                                      size_t workspace_bytes, epn_stream_t stream);
 
+/* The first layer of every model (cin = 1: the occupancy feature of get_occupancy_features, so3conv/functional.py:25-44;
+ * InterSO3Conv(1 -> cout), cls_so3net_pn.py:101) is not matrix work: its cost is generating the ks x nn kernel-influence
+ * weights per column on the VALU -- and round 3's weight gradient paid it a second time.  These two entry points keep the
+ * 24 grouped values of a column (`grouped` f32[b*p2*na][ks], 96 bytes per column: 94 MB at B=32 against the 3 GB inter_w
+ * the reference keeps for the same purpose) from the forward pass, and the weight gradient contracts grad_out with them:
+ *   epn_inter_so3conv_fwd_c1_f32        : as epn_inter_so3conv_fwd_f32 for cin = 1; `grouped` may be NULL (inference)
+ *   epn_inter_so3conv_bwd_weight_c1_f32 : grad_W f32[cout][ks] = grad_out^T . grouped (zero-filled here, then accumulated)
+ * Shapes: epn_inter_c1_ok (cin = 1, no dense inter_w, cout in {16, 32, 48, 64}, ks <= 32); EPN_EINVAL otherwise. */
+int epn_inter_c1_ok(const epn_inter_desc *d);
+int epn_inter_so3conv_fwd_c1_f32(const epn_inter_desc *d, const float *feats_cl, const float *W, float *out_cl,
+                                 float *grouped, void *workspace, size_t workspace_bytes, epn_stream_t stream);
+int epn_inter_so3conv_bwd_weight_c1_f32(const epn_inter_desc *d, const float *grouped, const float *grad_out_cl,
+                                        float *grad_W, epn_stream_t stream);
+
 /* 1 when the fused MFMA kernels serve this descriptor, 0 when the generic kernels do. */
 int epn_inter_is_fused(const epn_inter_desc *d);
 
@@ -301,6 +315,43 @@ int epn_inter_pack_weights_f32(const float *W, int cout, int cin, int ks, float 
 int epn_inter_pack_weights_bf16(const float *W, int cout, int cin, int ks, void *packed, epn_stream_t stream);
 int epn_inter_unpack_weight_grad_f32(const float *grad_packed, int cout, int cin, int ks, float *grad_W,
                                      epn_stream_t stream);
+
+/* ---------------------------------------------------------------------------------------------------------------------
+ * Composed split form: InterSO3Conv forward / backward as ONE call per direction on the kernel chain the benchmark times
+ * replaces InterSO3Conv.forward (vgtk/vgtk/so3conv/modules.py:157-174: L.inter_so3conv_grouping, so3conv/functional.py:118-178,
+ * then BasicSO3Conv's matmul, modules.py:48-55) and the autograd transposes of both -- the same boundary as
+ * epn_inter_so3conv_{fwd,bwd_data,bwd_weight}_f32 above (the fused fp32-MFMA kernels), but running
+ *   forward : epn_inter_group_packed_* (plain order where the packed one does not apply) -> epn_inter_pack_weights_* ->
+ *             epn_gemm_nt_split_f32 (fp32: lossless 3 x bf16 split, fp32 accuracy) / epn_gemm_nt_bf16
+ *   backward: epn_gemm_tn_split_f32 / _bf16 (+ epn_inter_unpack_weight_grad_f32) for grad_W;
+ *             epn_transpose_cast -> epn_gemm_nt_* -> epn_inter_ungroup[_acc]_* for grad_feats
+ * i.e. exactly what epn_pointcloud_amd/ops.py's InterSO3ConvSplitFn issues; a binding of the reference's four-call surface
+ * (grouping_cuda.cpp:176-181 + the two matmul gradients) gets the benchmarked path.  Buffers are the caller's:
+ *   saved     : the grouped features G[b*p2*na][cin*ks] (feature dtype) written by forward and read by backward --
+ *               epn_inter_split_saved_bytes(d, bf16); column order is an implementation detail of the pair
+ *   workspace : scratch of one call -- epn_inter_split_workspace_bytes(d, bf16, backward_pass); the backward scratch holds
+ *               the gradient of the grouped features (same size as `saved`)
+ *   out_col_stats (optional, NULL: off): per-32-row-block column statistics of out_cl, see epn_gemm_nt_problem::col_stats
+ *   backward: grad_feats_cl (fp32 scatter target for either feature dtype; NULL: not wanted; accumulate != 0: ADD to its
+ *             contents, see epn_inter_ungroup_acc_*), grad_W f32[cout][cin*ks] (NULL: not wanted).
+ * Shapes: the MFMA grouping kernels' (no dense inter_w, cin % 16 == 0, ks % 4 == 0, ks <= 32, nn <= 128) -- epn_inter_split_ok;
+ * EPN_EINVAL otherwise (use the fused entry points).  feats_cl / out_cl / grad_out_cl are float (…_f32) or bf16 (…_bf16);
+ * W and grad_W are always fp32 (master weights). */
+int epn_inter_split_ok(const epn_inter_desc *d);
+size_t epn_inter_split_saved_bytes(const epn_inter_desc *d, int bf16);
+size_t epn_inter_split_workspace_bytes(const epn_inter_desc *d, int bf16, int backward_pass);
+int epn_inter_so3conv_fwd_split_f32(const epn_inter_desc *d, const float *feats_cl, const float *W, float *out_cl,
+                                    float *out_col_stats, void *saved, size_t saved_bytes, void *workspace,
+                                    size_t workspace_bytes, epn_stream_t stream);
+int epn_inter_so3conv_fwd_split_bf16(const epn_inter_desc *d, const void *feats_cl, const float *W, void *out_cl,
+                                     float *out_col_stats, void *saved, size_t saved_bytes, void *workspace,
+                                     size_t workspace_bytes, epn_stream_t stream);
+int epn_inter_so3conv_bwd_split_f32(const epn_inter_desc *d, const float *grad_out_cl, const float *W, const void *saved,
+                                    size_t saved_bytes, float *grad_feats_cl, int accumulate, float *grad_W,
+                                    void *workspace, size_t workspace_bytes, epn_stream_t stream);
+int epn_inter_so3conv_bwd_split_bf16(const epn_inter_desc *d, const void *grad_out_cl, const float *W, const void *saved,
+                                     size_t saved_bytes, float *grad_feats_cl, int accumulate, float *grad_W,
+                                     void *workspace, size_t workspace_bytes, epn_stream_t stream);
 
 /* IntraSO3Conv grouping as a tensor: replaces L.intra_so3conv_grouping (vgtk/vgtk/so3conv/functional.py:255-268,
  * feats[..., intra_idx]); IntraSO3Conv's BasicSO3Conv matmul (modules.py:197-200) then runs on the caller's BLAS.

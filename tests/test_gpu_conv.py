@@ -54,6 +54,27 @@ def test_inter_module_golden(gpu, vgtk_alias, inter_mode):
         assert torch.allclose(dF.cpu(), T(g["dF"]), atol=TOL)
 
 
+@pytest.mark.parametrize("ksz,ks,cin,stride,lazy", [(2, 30, 6, 2, False), (3, 66, 4, 1, True)])
+def test_inter_module_larger_kernel_point_sets_golden(gpu, vgtk_alias, ksz, ks, cin, stride, lazy):
+    """kernel_size = 2 / 3 -> kpsphere30 / kpsphere66 (vgtk/vgtk/so3conv/functional.py:86-96): the module builds its kernel
+    points from the shipped tables and runs on the any-shape kernels (ks = 30 is not a multiple of 4, 66 exceeds the fused
+    kernels' 32 slots); outputs and both gradients against the imported reference."""
+    sptk, zptk = _mods(vgtk_alias)
+    g = golden(f"inter_module_ks{ksz}.npz")
+    conv = sptk.InterSO3Conv(cin, 8, ksz, stride, 0.4, 0.08, 16, lazy_sample=lazy, kanchor=60)
+    assert tuple(conv.kernels.shape) == (ks, 3) and torch.allclose(conv.kernels, T(g["kernels"]), atol=1e-7)
+    conv.load_state_dict({"anchors": T(g["anchors"]), "kernels": T(g["kernels"]), "basic_conv.W": T(g["W"])})
+    conv = conv.to(gpu)
+    feats = T(g["feats"]).to(gpu).requires_grad_(True)
+    iidx, iw, sidx, y = conv(zptk.SphericalPointCloud(T(g["xyz"]).to(gpu), feats, None))
+    assert np.array_equal(iidx.cpu().numpy(), g["inter_idx"]) and np.array_equal(y.xyz.cpu().numpy(), g["new_xyz"])
+    assert tuple(iw.shape) == (2, g["inter_idx"].shape[1], 60, ks, 16)
+    assert torch.allclose(iw.dense()[:, ::32].cpu(), T(g["inter_w_sub"]), atol=1e-5)
+    assert torch.allclose(y.feats.detach().cpu(), T(g["out"]), atol=TOL)
+    dW, dF = torch.autograd.grad(y.feats, [conv.basic_conv.W, feats], T(g["gy"]).to(gpu))
+    assert _rel(dW.cpu(), T(g["dW"])) < TOL and torch.allclose(dF.cpu(), T(g["dF"]), atol=TOL)
+
+
 def test_intra_module_golden(gpu, vgtk_alias, intra_mode):
     sptk, zptk = _mods(vgtk_alias)
     g = golden("intra_module.npz")
@@ -539,6 +560,33 @@ def test_shared_input_gradient_is_folded_into_the_data_gradient(gpu, vgtk_alias,
         if use_out:
             assert (gw0 - gw1).abs().max().item() <= 1e-5 * gw0.abs().max().item()
 
+    # autograd forbids backward() from modifying a gradient it was handed when somebody else can see that tensor: with
+    # retain_grad() (or a hook) on the shared output the scatter must NOT accumulate in place -- the retained gradient is the
+    # side consumer's alone, the input gradient still the sum (advisor finding, round 3)
+    monkeypatch.setenv("EPN_SHARE_INPUT_GRAD", "1")
+    _, gf_ref, _ = run(True)
+    for watch in ("retain_grad", "hook"):
+        f = feats.clone().requires_grad_(True)
+        w = W.clone().requires_grad_(True)
+        out, h2, _part = ops.inter_so3conv(f * 1.0, w, geo, share_input=True)
+        seen = []
+        if watch == "retain_grad":
+            h2.retain_grad()
+        else:
+            h2.register_hook(lambda g: seen.append(g))
+        ((out.float() ** 2).sum() + (h2.float() * side_w).sum()).backward()
+        torch.cuda.synchronize()
+        kept = h2.grad if watch == "retain_grad" else seen[0]
+        assert torch.allclose(kept.float(), side_w, atol=1e-2 if dt == "bf16" else 0.0), watch
+        assert (f.grad.float() - gf_ref).abs().max().item() <= tol * (gf_ref.abs().max().item() + 1e-12), watch
+
+    # a frozen input: no differentiable alias is handed out, W still gets its gradient, statistics still come back
+    w = W.clone().requires_grad_(True)
+    out, h2, part = ops.inter_so3conv(feats, w, geo, share_input=True)
+    assert h2 is feats and not h2.requires_grad and out.requires_grad
+    (out.float() ** 2).sum().backward()
+    assert torch.isfinite(w.grad).all() and w.grad.abs().max().item() > 0
+
 
 @pytest.mark.parametrize("dt", ["f32", "bf16"])
 def test_ungroup_acc_adds_to_what_is_there(gpu, vgtk_alias, dt):
@@ -941,3 +989,51 @@ def test_norm_act_pair_vs_torch(gpu, c, inst_b, affine_b, dt):
     if not inst_b:
         assert torch.allclose(nb.running_mean, nb_ref.running_mean, atol=1e-5)
         assert torch.allclose(nb.running_var, nb_ref.running_var, atol=1e-4)
+
+
+@pytest.mark.parametrize("cout,K,n", [(32, 32, 200), (64, 16, 96), (16, 64, 130)])
+def test_first_layer_weight_gradient_from_saved_grouped_values(gpu, vgtk_alias, monkeypatch, cout, K, n):
+    """cin = 1 (InterSO3Conv(1 -> cout), the first layer of every model): the forward pass keeps the ks grouped values of every
+    column (epn_inter_so3conv_fwd_c1_f32) and the weight gradient contracts the output gradient with them
+    (epn_inter_so3conv_bwd_weight_c1_f32) instead of regenerating ks x nn weights per column.  Same output bit for bit, same
+    gradient as the regenerating kernel (EPN_C1_SAVE=0) up to the atomics' order, and both against the oracle; column counts
+    that are not multiples of the 256-column groups."""
+    from epn_pointcloud_amd import ops
+    from epn_pointcloud_amd.vgtk import pc as pctk
+    from epn_pointcloud_amd.vgtk.so3conv import functional as L
+    from epn_pointcloud_amd.vgtk import functional as fr
+    rng = np.random.default_rng(cout + K)
+    torch.manual_seed(cout + K)
+    b, radius, sigma = 3, 0.4, 0.08
+    xyz = T(unit_ball_cloud(rng, b, n)).to(gpu)
+    anchors = T(L.get_anchors(60)).to(gpu)
+    kernels = R.scaled_kernel_points(T(fr.kernel_points_raw(24)), radius).to(gpu)
+    _, new_xyz = pctk.furthest_sample(xyz, n // 2, False)
+    idx = pctk.ball_query_index(new_xyz, xyz, radius, K)
+    geo = ops.InterGeometry(xyz, new_xyz, idx, anchors, kernels, sigma)
+    feats = torch.rand(b, 1, n, 60, device=gpu) + 0.5
+    W = torch.randn(cout, 24, device=gpu)
+    gout = torch.randn(b, cout, n // 2, 60, device=gpu)
+
+    def run(save):
+        monkeypatch.setenv("EPN_C1_SAVE", "1" if save else "0")
+        w = W.clone().requires_grad_(True)
+        out = ops.InterSO3ConvFn.apply(feats, w, geo)
+        out.backward(gout)
+        return out.detach(), w.grad
+
+    o1, g1 = run(True)
+    o0, g0 = run(False)
+    assert torch.equal(o0, o1)
+    assert (g0 - g1).abs().max().item() <= 1e-5 * g0.abs().max().item()
+    with torch.no_grad():                      # inference: nothing is kept
+        o2 = ops.InterSO3ConvFn.apply(feats, W, geo)
+    assert torch.equal(o2, o1)
+    fo = feats.cpu()
+    wo = W.cpu().requires_grad_(True)
+    grouped = R.group_nd(R.add_shadow_point(xyz.cpu()), idx.cpu()) - new_xyz.cpu().unsqueeze(3)
+    w_ref = R.inter_weights(grouped, anchors.cpu(), kernels.cpu(), sigma)
+    oo = R.basic_conv(wo, R.inter_feat_grouping(idx.cpu(), w_ref, R.add_shadow_feature(fo)))
+    (dWo,) = torch.autograd.grad(oo, [wo], gout.cpu())
+    assert torch.allclose(o1.cpu(), oo.detach(), atol=TOL)
+    assert _rel(g1.cpu(), dWo) < TOL

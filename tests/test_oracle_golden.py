@@ -135,6 +135,25 @@ def test_intra_module_vs_reference():
     assert torch.allclose(dF, T(g["dF"]), atol=1e-4)
 
 
+def test_inter_module_with_the_larger_kernel_point_sets_vs_reference():
+    """kernel_size = 2 / 3 (kpsphere30 / kpsphere66, so3conv/functional.py:86-96): oracle against the imported reference
+    (tests/golden/gen_golden_kernel_sets.py), and the shipped tables give the module's `kernels` buffer."""
+    from epn_pointcloud_amd.vgtk.so3conv import functional as L
+    for ksz, ks in ((2, 30), (3, 66)):
+        g = golden(f"inter_module_ks{ksz}.npz")
+        assert g["kernels"].shape == (ks, 3)
+        assert np.allclose(L.get_sphereical_kernel_points_from_ply(0.7 * 0.4, ksz), g["kernels"], atol=1e-7)
+        feats = T(g["feats"]).requires_grad_(True)
+        W = T(g["W"]).requires_grad_(True)
+        idx, w, sidx, new_xyz, out = R.inter_so3conv(T(g["xyz"]), feats, W, T(g["anchors"]), T(g["kernels"]),
+                                                     int(g["stride"]), 0.4, 0.08, 16, bool(g["lazy"]))
+        assert torch.equal(idx, T(g["inter_idx"])) and torch.equal(new_xyz, T(g["new_xyz"]))
+        assert torch.allclose(w[:, ::32], T(g["inter_w_sub"]), atol=1e-6)
+        assert torch.allclose(out, T(g["out"]), atol=1e-4)
+        dW, dF = torch.autograd.grad(out, [W, feats], T(g["gy"]))
+        assert torch.allclose(dW, T(g["dW"]), atol=1e-3, rtol=1e-4) and torch.allclose(dF, T(g["dF"]), atol=1e-4)
+
+
 def test_kernel_point_scaling():
     g = golden("tables.npz")
     k = R.scaled_kernel_points(T(g["kpsphere24"]), 0.4)
