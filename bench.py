@@ -293,13 +293,28 @@ def roofline_of(records, prof_steps, dtype_name, with_traffic, graph_mode):
     # the other roof of the pair: the heaviest kernel bound by it
     all_priced = {k: price(k, agg[k], dtype_name, traffic(k)) for k in priced}
     other = "hbm" if roofline["bound"] == "mfma" else "mfma"
-    cand = [k for k in priced if all_priced[k]["bound"] == other]
+    # (the cin = 1 first layer and the point-wise head are VALU / latency kernels: never the representative of a roof)
+    cand = [k for k in priced if all_priced[k]["bound"] == other and "inter_c1" not in k and "pointnet" not in k]
     if cand:
         k2 = max(cand, key=lambda k: agg[k]["ms"])
         o = all_priced[k2]
         roofline["dominant_memory_bound_kernel" if other == "hbm" else "dominant_mfma_kernel"] = {
             x: o[x] for x in ("kernel", "achieved", "unit", "frac", "traffic", "avg_launch_ms")}
+    # the same records per (call kind, layer dimensions): which LAYER a kernel family is slow on
+    esz = 4 if dtype_name == "f32" else 2
+    calls = {}
+    for kind, key, flops, e0, e1, kname in records:
+        if not key:
+            continue
+        c = calls.setdefault((kind, tuple(key), kname), [0.0, 0, flops, algo_bytes(kind, key, esz)])
+        c[0] += e0.elapsed_time(e1) if e1 is not None else float(e0)
+        c[1] += 1
+    per_call = [{"kind": kind, "key": list(key), "kernel": short_kernel(kname or ""), "launches_per_step": round(n / prof_steps, 2),
+                 "avg_ms": round(ms / n, 4), "GB/s": round(by / (ms / n) / 1e6, 1) if by else None,
+                 "TFLOP/s": round(fl / (ms / n) / 1e9, 1) if fl else None}
+                for (kind, key, kname), (ms, n, fl, by) in sorted(calls.items(), key=lambda kv: -kv[1][0])]
     detail = {
+        "per_call": per_call,
         "per_kernel": {k: dict(all_priced.get(k, {}), kernel_exact=k, ms_per_step=round(v["ms"] / prof_steps, 3),
                                launches_per_step=round(v["launches"] / prof_steps, 1))
                        for k, v in sorted(agg.items())},
