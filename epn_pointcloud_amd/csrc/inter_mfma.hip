@@ -810,8 +810,16 @@ __global__ __launch_bounds__(64 * NW) void inter_group_kernel(InterArgs A) {
 // contiguous bytes per 16 lanes -- serves CG chunks, and the weights of a column are generated once for all of them.
 // "Chunk" e of the group is the channel set {16 CG g + CG x + e}: only the lane -> channel map changes, the layout of G
 // does not (a D fragment is still four consecutive kernel points of one channel = one 16 / 8-byte store).
+// amdgpu_waves_per_eu(2): a register budget of 256 (no instance with K <= 64 needs more) -- with the 512 that
+// __launch_bounds__(256) alone allows, hipcc places the MFMA results in AGPRs and copies every one of them back
+// (v_accvgpr_read_b32: 64 per column at K = 64, the largest single VALU item of the kernel)
 template <int NT, int KT, typename TF, int CG>
-__global__ __launch_bounds__(64 * NW) void inter_group_wide_kernel(InterArgs A) {
+#ifdef EPN_GRP_NO_WPE
+__global__ __launch_bounds__(64 * NW)
+#else
+__global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(NT <= 4 ? 2 : 1)))
+#endif
+void inter_group_wide_kernel(InterArgs A) {
     constexpr bool BF = sizeof(TF) == 2;
     typedef unsigned uvec __attribute__((ext_vector_type(BF ? CG / 2 : CG)));   // one lane's CG channels of one row
     const int lane = threadIdx.x & 63;
@@ -842,12 +850,68 @@ __global__ __launch_bounds__(64 * NW) void inter_group_wide_kernel(InterArgs A) 
             }
             vst[kt] = 16 * kt + 4 * j < A.ks ? (unsigned)o * (unsigned)sizeof(TF) : 0x80000000u;
         }
+        // Gathers, table reads and stores as BUFFER instructions (round 4): descriptor = the cloud's feature block / the
+        // wave's 16 rows of G in SGPRs, a per-lane 32-bit byte offset that does not change from column to column (neighbour
+        // row + channel; kernel points of the lane), a wave-uniform scalar offset per column (anchor; row of G + chunk).
+        // The flat form paid one 64-bit address add per gather and per store, and an exec-mask branch around every store of
+        // the lanes without kernel points (ks = 24: lane groups j >= 2 of the second 16) -- ~45 % of the kernel's VALU + SALU
+        // instructions at K = 64, where only two waves fit a SIMD; a lane without kernel points now stores out of range,
+        // which the buffer bounds check drops.
+        const unsigned fbytes = (unsigned)A.p1 * (unsigned)A.na * (unsigned)A.cin * (unsigned)sizeof(TF);
+        const __amdgpu_buffer_rsrc_t rF = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(sg.fbase), 0, (int)fbytes, 0x00020000);
+        const unsigned gbytes = 16u * (unsigned)gss * (unsigned)sizeof(TF);
+        const __amdgpu_buffer_rsrc_t rG = __builtin_amdgcn_make_buffer_rsrc(G, 0, (int)gbytes, 0x00020000);
+        unsigned vq[NT][4];
+#pragma unroll
+        for (int t = 0; t < NT; ++t)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) vq[t][r] = ((unsigned)sg.h.q[t][r] + (unsigned)coff) * (unsigned)sizeof(TF);
         auto gather = [&](int a, uvec (&f)[NT][4]) {
-            const TF *fb = reinterpret_cast<const TF *>(sg.fbase) + (size_t)a * A.cin + coff;
+            const unsigned soff = (unsigned)a * (unsigned)A.cin * (unsigned)sizeof(TF);       // wave-uniform
 #pragma unroll
             for (int t = 0; t < NT; ++t)
 #pragma unroll
-                for (int r = 0; r < 4; ++r) f[t][r] = *reinterpret_cast<const uvec *>(fb + sg.h.q[t][r]);
+                for (int r = 0; r < 4; ++r) {
+                    if constexpr (sizeof(uvec) == 16)
+                        f[t][r] = __builtin_bit_cast(uvec, __builtin_amdgcn_raw_buffer_load_b128(rF, vq[t][r], soff, 0));
+                    else if constexpr (sizeof(uvec) == 8)
+                        f[t][r] = __builtin_bit_cast(uvec, __builtin_amdgcn_raw_buffer_load_b64(rF, vq[t][r], soff, 0));
+                    else
+                        f[t][r] = __builtin_bit_cast(uvec, __builtin_amdgcn_raw_buffer_load_b32(rF, vq[t][r], soff, 0));
+                }
+        };
+        const __amdgpu_buffer_rsrc_t rT = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(A.rk4), 0,
+                                                                            A.na * EPN_KS_MAX * 16, 0x00020000);
+        auto load_rk = [&](int a, RkRow<KT> &r) {
+            const unsigned soff = (unsigned)a * (EPN_KS_MAX * 16u);
+#pragma unroll
+            for (int kt = 0; kt < KT; ++kt) {
+                const unsigned v = (unsigned)(16 * kt + x) * 16u;
+                r.rk[kt] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rT, v + 4u * (unsigned)j, soff, 0));
+                r.beta[kt] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rT, v + 12u, soff, 0));
+            }
+        };
+        auto store_g = [&](unsigned voff, unsigned soff, f32x4 g) {
+#ifdef EPN_GRP_FLAT_ST
+            if (voff != 0x80000000u) st4f(reinterpret_cast<TF *>(reinterpret_cast<char *>(G) + soff + voff), g);
+            return;
+#endif
+            // The whole offset goes into the VGPR offset, the scalar offset stays the literal 0.  With the row offset in an
+            // SGPR (`buffer_store_dwordx4 v[66:69], v59, s[4:7], s52 offen`) hipcc assumes the hardware interlocks a later
+            // write of the data registers (GCNHazardRecognizer: "this hazard only exists if the instruction is not using a
+            // register in the soffset field") and scheduled `v_cndmask_b32 v66, ...` two instructions behind the store; on
+            // gfx950 the store then delivered the NEW v66 in lanes 12-15 / 28-31 of ~0.3 % of the rows of a full-size layer
+            // (found with the VGPR-form MFMAs of this round, whose register allocation put such a pair together; the ISA scan
+            // is in tools/isa_hazards.py).  One v_add_u32 per store buys the documented wait state.
+            const unsigned off = voff + soff;
+            if constexpr (BF) {
+                typedef unsigned u32x2_s __attribute__((ext_vector_type(2)));
+                const bf16x4_t b = {(__bf16)g[0], (__bf16)g[1], (__bf16)g[2], (__bf16)g[3]};
+                __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2_s, b), rG, off, 0, 0);
+            } else {
+                typedef unsigned u32x4_s __attribute__((ext_vector_type(4)));
+                __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4_s, g), rG, off, 0, 0);
+            }
         };
         // One column: request column i + 1's feature rows and kernel-table entries into (fnext, rnext), then compute column
         // i from (fcur, rcur).  The two register sets swap ROLES between consecutive columns (the loop below is unrolled by
@@ -859,7 +923,7 @@ __global__ __launch_bounds__(64 * NW) void inter_group_wide_kernel(InterArgs A) 
         auto column = [&](int i, const uvec (&fcur)[NT][4], const RkRow<KT> &rcur, uvec (&fnext)[NT][4], RkRow<KT> &rnext) {
             const int a = sg.a0 + i;
             const int an = i + 1 < sg.cnt ? a + 1 : a;          // last column re-reads its own rows (cache hit, unused)
-            load_rk_row<KT>(A, an, x, j, rnext);
+            load_rk(an, rnext);
 #ifdef EPN_TUNING
             if (!(A.wk & 2) || i == 0)
 #endif
@@ -867,20 +931,38 @@ __global__ __launch_bounds__(64 * NW) void inter_group_wide_kernel(InterArgs A) 
             f32x4 w[KT][NT];
             make_weights_from<NT, KT>(rcur, j, sg.h, w);         // once per column, for all CG chunks
             const unsigned rowoff = (unsigned)(sg.jc0 + i) * (unsigned)gss * (unsigned)sizeof(TF);   // wave-uniform
+            // bf16: the A fragments (weights rounded to bf16) once per column -- round 3 packed them again for every chunk e
+            // (ISA: 64 v_cvt_pk_bf16_f32 per column instead of 16) -- and the B fragments assembled with byte permutes: the
+            // fragment of chunk e holds channel e of FOUR gathered rows (r = 0..3), i.e. one 16-bit half of two dwords each:
+            // v_perm_b32 picks both halves in one instruction (was: shift / and / select / or per value, ~14 VALU per fragment,
+            // now 2 + 2 for the validity mask).  Masked slots also carry weight 0 (alpha = -1e30 in load_hood); the AND keeps
+            // a non-finite value in feature row 0 from turning 0 * x into NaN.
+            typedef unsigned u32x2_t __attribute__((ext_vector_type(2)));
+            bf16x4_t wp[BF ? KT : 1][BF ? NT : 1];
+            unsigned okm[BF ? NT : 1][2];
+            if constexpr (BF) {
+#pragma unroll
+                for (int kt = 0; kt < KT; ++kt)
+#pragma unroll
+                    for (int t = 0; t < NT; ++t) wp[kt][t] = pack4(w[kt][t]);
+#pragma unroll
+                for (int t = 0; t < NT; ++t) {
+                    okm[t][0] = (sg.h.ok[t][0] ? 0xffffu : 0u) | (sg.h.ok[t][1] ? 0xffff0000u : 0u);
+                    okm[t][1] = (sg.h.ok[t][2] ? 0xffffu : 0u) | (sg.h.ok[t][3] ? 0xffff0000u : 0u);
+                }
+            }
+            f32x4 gprev[KT], gcur[KT];
 #pragma unroll
             for (int e = 0; e < CG; ++e) {
                 if constexpr (BF) {
                     bf16x4_t fb4[NT];
+                    constexpr unsigned SEL_LO = 0x05040100u, SEL_HI = 0x07060302u;   // D = {S1.half, S0.half}: S1 = low result half
 #pragma unroll
                     for (int t = 0; t < NT; ++t) {
-                        unsigned v[4];
-#pragma unroll
-                        for (int r = 0; r < 4; ++r) {
-                            const unsigned d = fcur[t][r][e >> 1];
-                            v[r] = sg.h.ok[t][r] ? ((e & 1) ? d >> 16 : d & 0xffffu) : 0u;
-                        }
-                        typedef unsigned u32x2_t __attribute__((ext_vector_type(2)));
-                        fb4[t] = __builtin_bit_cast(bf16x4_t, u32x2_t{v[0] | (v[1] << 16), v[2] | (v[3] << 16)});
+                        const unsigned sel = (e & 1) ? SEL_HI : SEL_LO;
+                        const unsigned p01 = __builtin_amdgcn_perm(fcur[t][1][e >> 1], fcur[t][0][e >> 1], sel) & okm[t][0];
+                        const unsigned p23 = __builtin_amdgcn_perm(fcur[t][3][e >> 1], fcur[t][2][e >> 1], sel) & okm[t][1];
+                        fb4[t] = __builtin_bit_cast(bf16x4_t, u32x2_t{p01, p23});
                     }
 #pragma unroll
                     for (int kt = 0; kt < KT; ++kt) {
@@ -888,16 +970,12 @@ __global__ __launch_bounds__(64 * NW) void inter_group_wide_kernel(InterArgs A) 
                         if constexpr (NT % 2 == 0) {
 #pragma unroll
                             for (int t = 0; t < NT; t += 2)
-                                g = mfma_bf16_k32(pack4(w[kt][t]), pack4(w[kt][t + 1]), fb4[t], fb4[t + 1], g);
+                                g = mfma_bf16_k32(wp[kt][t], wp[kt][t + 1], fb4[t], fb4[t + 1], g);
                         } else {
 #pragma unroll
-                            for (int t = 0; t < NT; ++t) g = mfma_bf16_k16(pack4(w[kt][t]), fb4[t], g);
+                            for (int t = 0; t < NT; ++t) g = mfma_bf16_k16(wp[kt][t], fb4[t], g);
                         }
-#ifdef EPN_TUNING      // tools/group_ablation.py: 1 = no stores (kept alive by an impossible value), 2 = gathers once, 4 = no MFMAs
-                        if (!(A.wk & 1) || g[0] == 12345.678f)
-#endif
-                        if (vst[kt] != 0x80000000u)
-                            st4f(reinterpret_cast<TF *>(reinterpret_cast<char *>(G) + rowoff + vst[kt] + e * est[kt]), g);
+                        gcur[kt] = g;
                     }
                 } else {
 #pragma unroll
@@ -912,18 +990,44 @@ __global__ __launch_bounds__(64 * NW) void inter_group_wide_kernel(InterArgs A) 
 #endif
                                 g = mfma4(w[kt][t][r], sg.h.ok[t][r] ? __uint_as_float(fcur[t][r][e]) : 0.0f, g);
                             }
-#ifdef EPN_TUNING      // tools/group_ablation.py: 1 = no stores (kept alive by an impossible value), 2 = gathers once, 4 = no MFMAs
-                        if (!(A.wk & 1) || g[0] == 12345.678f)
-#endif
-                        if (vst[kt] != 0x80000000u)
-                            st4f(reinterpret_cast<TF *>(reinterpret_cast<char *>(G) + rowoff + vst[kt] + e * est[kt]), g);
+                        gcur[kt] = g;
                     }
                 }
+                // The stores of a chunk are issued one chunk LATE, behind the next chunk's MFMAs (and 32 idle cycles after the
+                // last one).  Measured on gfx950 with this toolchain: a buffer_store whose data registers are the direct
+                // (VGPR-form) result of the MFMA just before it reads dword 0 of lanes 12-15 / 28-31 -- the last
+                // write-back pass -- too early in ~0.3 % of the rows of a full-size layer (tools/scratch history);
+                // the AGPR form (a v_accvgpr_read in between) and flat stores under a branch never showed it.  Distance is
+                // the cure the ISA manual prescribes for XDL-write -> VMEM-read hazards; here it is made explicit.
+                __builtin_amdgcn_sched_barrier(0);
+                if (e > 0) {
+#pragma unroll
+                    for (int kt = 0; kt < KT; ++kt)
+#ifdef EPN_TUNING      // tools/group_ablation.py: 1 = no stores (kept alive by an impossible value), 2 = gathers once, 4 = no MFMAs
+                        if (!(A.wk & 1) || gprev[kt][0] == 12345.678f)
+#endif
+                        store_g(vst[kt], rowoff + (unsigned)((e - 1) * est[kt]), gprev[kt]);   // vst = 0x80000000: out of range, dropped
+                    asm volatile("s_nop 4" ::: "memory");     // nothing rewrites the data registers for five more cycles
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+#pragma unroll
+                for (int kt = 0; kt < KT; ++kt) gprev[kt] = gcur[kt];
+                __builtin_amdgcn_sched_barrier(0);
             }
+            asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int kt = 0; kt < KT; ++kt)
+#ifdef EPN_TUNING
+                if (!(A.wk & 1) || gprev[kt][0] == 12345.678f)
+#endif
+                store_g(vst[kt], rowoff + (unsigned)((CG - 1) * est[kt]), gprev[kt]);
+            asm volatile("s_nop 4" ::: "memory");
+            __builtin_amdgcn_sched_barrier(0);
         };
         uvec f0[NT][4], f1[NT][4];
         RkRow<KT> r0, r1;
-        load_rk_row<KT>(A, sg.a0, x, j, r0);
+        load_rk(sg.a0, r0);
         gather(sg.a0, f0);
         for (int i = 0; i < sg.cnt; i += 2) {
             column(i, f0, r0, f1, r1);
@@ -1303,13 +1407,16 @@ __global__ __launch_bounds__(64 * GP) void inter_ungroup_shared_kernel(InterArgs
 #pragma unroll
                             for (int r = 0; r < 4; ++r) tt = mfma4(wgt[t][kt][r], dgc[cw][kt][r], tt);
                     }
-                    // tt: lane (x = c, j), register r -> slot n = 16t + 4j + r
+                    // tt: lane (x = c, j), register r -> slot n = 16t + 4j + r.  Every slot row is written, also the masked
+                    // ones (cyclic repeats, shadow indices: mul = 0): no destination list names them, so nobody reads those
+                    // rows -- round 3 skipped them with `if (mul != 0)`, i.e. an exec-mask save / branch / restore around each
+                    // of the 16 NT CW LDS stores of a step (149 s_and_saveexec + 106 s_cbranch_execz in the K = 64 instance)
 #pragma unroll
                     for (int r = 0; r < 4; ++r)
 #ifdef EPN_TUNING
                         if (!(A.wk & 4) || tt[r] == 12345.678f)
 #endif
-                        if (h.mul[t][r] != 0.0f) buf[(16 * t + 4 * j + r) * SS + 16 * cw] = tt[r] * h.mul[t][r];
+                        buf[(16 * t + 4 * j + r) * SS + 16 * cw] = tt[r] * h.mul[t][r];
                 }
             __syncthreads();
             const float *rb = Tb + (ph & (NB - 1)) * BS;
