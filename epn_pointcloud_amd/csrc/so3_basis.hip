@@ -103,10 +103,62 @@ __device__ __forceinline__ void sb_st(__bf16 *p, f32x4 v) {
     *reinterpret_cast<sbf16x4 *>(p) = sbf16x4{(__bf16)v[0], (__bf16)v[1], (__bf16)v[2], (__bf16)v[3]};
 }
 
-template <typename T>
+// ---- row addressing, 32-bit form (round 4).  For BOTH layouts the byte offset of row r of point pt is
+//     off(r, pt) = rb[r] + pt * rs[r]  (+ the lane's channel offset)
+// plain:    rb = r c esz,                                   rs = na c esz
+// spectral: rb = (base_r pts + (r - base_r)) c esz,         rs = d2_r c esz
+// so the two tables (rb, rs) per side are built once per workgroup in LDS and a row costs ONE v_mad_u32_u24 + one add, issued
+// as a buffer load / store with that 32-bit offset.  Round 3 evaluated the size_t expression per row -- two 64-bit
+// multiplies each (192 v_mul_lo_u32 + 98 v_mad_u64_u32 per task in the ISA), ~1700 VALU instructions per (point, 64-channel
+// block) against 64-256 MFMAs: the "HBM-bound streaming kernel" was bound by its address arithmetic (0.33-0.45 of the HBM
+// roof).  Rows >= na and lanes without channels carry the offset 0x80000000: loads return zeros, stores are dropped by the
+// buffer bounds check -- no branches (the two markers do not wrap when added).  Condition (launcher): the tensor is smaller than
+// 2 GiB; larger ones keep the 64-bit path.
+struct SbTables { unsigned rbi[64], rsi[64], rbo[64], rso[64]; };
+constexpr unsigned SB_OOB = 0x80000000u;       // table entry of a row >= na
+constexpr unsigned SB_CHO_OOB = 0x7fffff00u;   // channel offset of a lane without channels: OOB alone, and no 32-bit wrap with SB_OOB
+
+template <int ESZ>
+__device__ __forceinline__ void sb_make_tables(const SbArgs &A, SbTables &T) {
+    const int r = threadIdx.x;
+    if (r < 64) {
+        unsigned bi = SB_OOB, si = 0u, bo = SB_OOB, so = 0u;
+        if (r < A.na) {
+            const unsigned base = (unsigned)A.blk[2 * r], d2 = (unsigned)A.blk[2 * r + 1];
+            const unsigned row = (unsigned)A.c * ESZ;
+            const unsigned spec_b = (unsigned)(((unsigned long long)base * (unsigned long long)A.pts + (r - base)) * row);
+            const unsigned spec_s = d2 * row, plain_b = (unsigned)r * row, plain_s = (unsigned)A.na * row;
+            bi = A.in_spec ? spec_b : plain_b; si = A.in_spec ? spec_s : plain_s;
+            bo = A.out_spec ? spec_b : plain_b; so = A.out_spec ? spec_s : plain_s;
+        }
+        T.rbi[r] = bi; T.rsi[r] = si; T.rbo[r] = bo; T.rso[r] = so;
+    }
+}
+__device__ __forceinline__ unsigned sb_off(const unsigned *rb, const unsigned *rs, int r, unsigned pt, unsigned cho) {
+    return __umul24(pt, rs[r]) + rb[r] + cho;       // pt < 2^24, rs < 2^24 (launcher)
+}
+typedef unsigned sb_u32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned sb_u32x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ f32x4 sb_bld128(__amdgpu_buffer_rsrc_t rs, unsigned off) {
+    return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, off, 0, 0));
+}
+__device__ __forceinline__ sb_u32x2 sb_bld64(__amdgpu_buffer_rsrc_t rs, unsigned off) {
+    return __builtin_amdgcn_raw_buffer_load_b64(rs, off, 0, 0);
+}
+// (scalar offset literal 0: see store_g in inter_mfma.hip for what an SGPR offset costs on gfx950)
+__device__ __forceinline__ void sb_bst(float *, __amdgpu_buffer_rsrc_t rs, unsigned off, f32x4 v) {
+    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(sb_u32x4, v), rs, off, 0, 0);
+}
+__device__ __forceinline__ void sb_bst(__bf16 *, __amdgpu_buffer_rsrc_t rs, unsigned off, f32x4 v) {
+    const sbf16x4 b = {(__bf16)v[0], (__bf16)v[1], (__bf16)v[2], (__bf16)v[3]};
+    __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(sb_u32x2, b), rs, off, 0, 0);
+}
+
+template <typename T, bool SMALL>
 __global__ __launch_bounds__(64 * SB_WAVES) void so3_basis_kernel(SbArgs A) {
     __shared__ float Ms[64 * SB_LD];
     __shared__ int bs[64], d2s[64];
+    __shared__ SbTables tab;
     for (int i = threadIdx.x; i < 64 * 64; i += blockDim.x) {
         const int r = i >> 6, s = i & 63;
         Ms[r * SB_LD + s] = (r < A.na && s < A.na) ? A.M[r * A.na + s] : 0.0f;
@@ -116,7 +168,11 @@ __global__ __launch_bounds__(64 * SB_WAVES) void so3_basis_kernel(SbArgs A) {
         bs[threadIdx.x] = A.blk[2 * f];
         d2s[threadIdx.x] = A.blk[2 * f + 1];
     }
+    if constexpr (SMALL) sb_make_tables<(int)sizeof(T)>(A, tab);
     __syncthreads();
+    const unsigned nbytes = SMALL ? (unsigned)(A.pts * A.na * A.c * (long long)sizeof(T)) : 0u;
+    const __amdgpu_buffer_rsrc_t rin = __builtin_amdgcn_make_buffer_rsrc(const_cast<void *>(A.in), 0, (int)nbytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rout = __builtin_amdgcn_make_buffer_rsrc(A.out, 0, (int)nbytes, 0x00020000);
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int x = lane & 15, j = lane >> 4;
@@ -141,10 +197,14 @@ __global__ __launch_bounds__(64 * SB_WAVES) void so3_basis_kernel(SbArgs A) {
         for (int mt = 0; mt < 4; ++mt)
 #pragma unroll
             for (int nt = 0; nt < 4; ++nt) acc[mt][nt] = f32x4{0.f, 0.f, 0.f, 0.f};
+        const unsigned cho = cval ? (unsigned)choff0 * (unsigned)sizeof(T) : SB_CHO_OOB, upt = (unsigned)pt;
         f32x4 bv[16];
 #pragma unroll
         for (int st = 0; st < 16; ++st)
-            if (st < nst) bv[st] = cval ? sb_ld(static_cast<const T *>(A.in) + row_addr(A.in_spec, 4 * st + j)) : f32x4{0.f, 0.f, 0.f, 0.f};
+            if (st < nst) {
+                if constexpr (SMALL && sizeof(T) == 4) bv[st] = sb_bld128(rin, sb_off(tab.rbi, tab.rsi, 4 * st + j, upt, cho));
+                else bv[st] = cval ? sb_ld(static_cast<const T *>(A.in) + row_addr(A.in_spec, 4 * st + j)) : f32x4{0.f, 0.f, 0.f, 0.f};
+            }
         if (A.nsums) {
             SbNorm N;
             sb_norm_load(A, pt, choff, N);
@@ -177,11 +237,11 @@ __global__ __launch_bounds__(64 * SB_WAVES) void so3_basis_kernel(SbArgs A) {
 #pragma unroll
             for (int rr = 0; rr < 4; ++rr) {
                 const int r = 16 * mt + 4 * j + rr;
-                if (r < A.na && cval) {
-                    const f32x4 v = {acc[mt][0][rr], acc[mt][1][rr], acc[mt][2][rr], acc[mt][3][rr]};
-                    sb_st(static_cast<T *>(A.out) + row_addr(A.out_spec, r), v);
-                }
+                const f32x4 v = {acc[mt][0][rr], acc[mt][1][rr], acc[mt][2][rr], acc[mt][3][rr]};
+                if constexpr (SMALL) sb_bst(static_cast<T *>(nullptr), rout, sb_off(tab.rbo, tab.rso, r, upt, cho), v);
+                else if (r < A.na && cval) sb_st(static_cast<T *>(A.out) + row_addr(A.out_spec, r), v);
             }
+        if constexpr (SMALL) asm volatile("s_nop 4" ::: "memory");   // store data registers are the next task's accumulators
     }
 }
 
@@ -195,10 +255,16 @@ typedef __bf16 sbf16x8 __attribute__((ext_vector_type(8)));
 typedef unsigned sbu32x2 __attribute__((ext_vector_type(2)));
 typedef unsigned sbu32x4 __attribute__((ext_vector_type(4)));
 
+template <bool SMALL>
 __global__ __launch_bounds__(64 * SB_WAVES) void so3_basis_bf16_kernel(SbArgs A) {
     __shared__ __attribute__((aligned(16))) __bf16 Mh[64 * SBH_LD];
     __shared__ __attribute__((aligned(16))) __bf16 Ml[64 * SBH_LD];
     __shared__ int bs[64], d2s[64];
+    __shared__ SbTables tab;
+    if constexpr (SMALL) sb_make_tables<2>(A, tab);
+    const unsigned nbytes = SMALL ? (unsigned)(A.pts * A.na * A.c * 2LL) : 0u;
+    const __amdgpu_buffer_rsrc_t rin = __builtin_amdgcn_make_buffer_rsrc(const_cast<void *>(A.in), 0, (int)nbytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rout = __builtin_amdgcn_make_buffer_rsrc(A.out, 0, (int)nbytes, 0x00020000);
     for (int i = threadIdx.x; i < 64 * 64; i += blockDim.x) {
         const int r = i >> 6, q = i & 63;
         const float m = (r < A.na && q < A.na) ? A.M[r * A.na + q] : 0.0f;
@@ -230,13 +296,15 @@ __global__ __launch_bounds__(64 * SB_WAVES) void so3_basis_bf16_kernel(SbArgs A)
             if (spec) return ((size_t)bs[r] * A.pts + (size_t)pt * d2s[r] + (r - bs[r])) * A.c + choff;
             return ((size_t)pt * A.na + r) * A.c + choff;
         };
+        const unsigned cho = cval ? (unsigned)choff0 * 2u : SB_CHO_OOB, upt = (unsigned)pt;
         sbu32x2 raw[2][8];
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks)
 #pragma unroll
             for (int e = 0; e < 8; ++e) {
                 const int r = 32 * ks + 8 * j + e;
-                raw[ks][e] = (r < A.na && cval) ? *reinterpret_cast<const sbu32x2 *>(in + row_addr(A.in_spec, r)) : sbu32x2{0u, 0u};
+                if constexpr (SMALL) raw[ks][e] = __builtin_bit_cast(sbu32x2, sb_bld64(rin, sb_off(tab.rbi, tab.rsi, r, upt, cho)));
+                else raw[ks][e] = (r < A.na && cval) ? *reinterpret_cast<const sbu32x2 *>(in + row_addr(A.in_spec, r)) : sbu32x2{0u, 0u};
             }
         if (A.nsums) {
             SbNorm N;
@@ -291,11 +359,11 @@ __global__ __launch_bounds__(64 * SB_WAVES) void so3_basis_bf16_kernel(SbArgs A)
 #pragma unroll
             for (int rr = 0; rr < 4; ++rr) {
                 const int r = 16 * mt + 4 * j + rr;
-                if (r < A.na && cval) {
-                    const f32x4 v = {acc[mt][0][rr], acc[mt][1][rr], acc[mt][2][rr], acc[mt][3][rr]};
-                    sb_st(out + row_addr(A.out_spec, r), v);
-                }
+                const f32x4 v = {acc[mt][0][rr], acc[mt][1][rr], acc[mt][2][rr], acc[mt][3][rr]};
+                if constexpr (SMALL) sb_bst(out, rout, sb_off(tab.rbo, tab.rso, r, upt, cho), v);
+                else if (r < A.na && cval) sb_st(out + row_addr(A.out_spec, r), v);
             }
+        if constexpr (SMALL) asm volatile("s_nop 4" ::: "memory");
     }
 }
 
@@ -324,9 +392,15 @@ __device__ __forceinline__ void sb_split3(const float (&x)[8], sbf16x8 &h, sbf16
     h = __builtin_bit_cast(sbf16x8, H); m = __builtin_bit_cast(sbf16x8, M); l = __builtin_bit_cast(sbf16x8, L);
 }
 
+template <bool SMALL>
 __global__ __launch_bounds__(64 * SB_WAVES) __attribute__((amdgpu_waves_per_eu(2, 2))) void so3_basis_x3_kernel(SbArgs A) {
     __shared__ __attribute__((aligned(16))) __bf16 Mp[3][64 * SBH_LD];
     __shared__ int bs[64], d2s[64];
+    __shared__ SbTables tab;
+    if constexpr (SMALL) sb_make_tables<4>(A, tab);
+    const unsigned nbytes = SMALL ? (unsigned)(A.pts * A.na * A.c * 4LL) : 0u;
+    const __amdgpu_buffer_rsrc_t rin = __builtin_amdgcn_make_buffer_rsrc(const_cast<void *>(A.in), 0, (int)nbytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rout = __builtin_amdgcn_make_buffer_rsrc(A.out, 0, (int)nbytes, 0x00020000);
     for (int i = threadIdx.x; i < 64 * 64; i += blockDim.x) {
         const int r = i >> 6, q = i & 63;
         const float v = (r < A.na && q < A.na) ? A.M[r * A.na + q] : 0.0f;
@@ -361,13 +435,15 @@ __global__ __launch_bounds__(64 * SB_WAVES) __attribute__((amdgpu_waves_per_eu(2
             if (spec) return ((size_t)bs[r] * A.pts + (size_t)pt * d2s[r] + (r - bs[r])) * A.c + choff;
             return ((size_t)pt * A.na + r) * A.c + choff;
         };
+        const unsigned cho = cval ? (unsigned)choff0 * 4u : SB_CHO_OOB, upt = (unsigned)pt;
         f32x4 raw[2][8];          // row 32 ks + 8 j + e, channels 4x .. 4x+3
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks)
 #pragma unroll
             for (int e = 0; e < 8; ++e) {
                 const int r = 32 * ks + 8 * j + e;
-                raw[ks][e] = (r < A.na && cval) ? sb_ld(in + row_addr(A.in_spec, r)) : f32x4{0.f, 0.f, 0.f, 0.f};
+                if constexpr (SMALL) raw[ks][e] = sb_bld128(rin, sb_off(tab.rbi, tab.rsi, r, upt, cho));
+                else raw[ks][e] = (r < A.na && cval) ? sb_ld(in + row_addr(A.in_spec, r)) : f32x4{0.f, 0.f, 0.f, 0.f};
             }
         if (A.nsums) {
             SbNorm N;
@@ -420,11 +496,11 @@ __global__ __launch_bounds__(64 * SB_WAVES) __attribute__((amdgpu_waves_per_eu(2
 #pragma unroll
             for (int rr = 0; rr < 4; ++rr) {
                 const int r = 16 * mt + 4 * j + rr;
-                if (r < A.na && cval) {
-                    const f32x4 v = {acc[mt][0][rr], acc[mt][1][rr], acc[mt][2][rr], acc[mt][3][rr]};
-                    sb_st(out + row_addr(A.out_spec, r), v);
-                }
+                const f32x4 v = {acc[mt][0][rr], acc[mt][1][rr], acc[mt][2][rr], acc[mt][3][rr]};
+                if constexpr (SMALL) sb_bst(out, rout, sb_off(tab.rbo, tab.rso, r, upt, cho), v);
+                else if (r < A.na && cval) sb_st(out + row_addr(A.out_spec, r), v);
             }
+        if constexpr (SMALL) asm volatile("s_nop 4" ::: "memory");
     }
 }
 
@@ -585,9 +661,19 @@ static int so3_basis_any(const void *in, const float *M, const int32_t *blocks, 
     const long long tasks = pts * ((c + 63) >> 6);
     const long long per_wg = (long long)SB_WAVES * SB_TPW;
     const dim3 grid((unsigned)((tasks + per_wg - 1) / per_wg));
-    if (bf16 == 1) EPN_LAUNCH(so3_basis_bf16_kernel, grid, dim3(64 * SB_WAVES), 0, epn_stream(stream), A);
-    else if (bf16 == 2) EPN_LAUNCH(so3_basis_x3_kernel, grid, dim3(64 * SB_WAVES), 0, epn_stream(stream), A);   // fp32, split form
-    else EPN_LAUNCH(so3_basis_kernel<float>, grid, dim3(64 * SB_WAVES), 0, epn_stream(stream), A);
+    // 32-bit row offsets + buffer instructions when the tensor is below 2 GiB and the per-point strides fit 24 bits
+    const long long bytes = pts * na * c * (bf16 == 1 ? 2LL : 4LL);
+    const bool small_t = bytes < 0x7fffff00LL && pts < (1LL << 24) && (long long)na * c * 4 < (1LL << 24);
+    if (bf16 == 1) {
+        if (small_t) EPN_LAUNCH(so3_basis_bf16_kernel<true>, grid, dim3(64 * SB_WAVES), 0, epn_stream(stream), A);
+        else EPN_LAUNCH(so3_basis_bf16_kernel<false>, grid, dim3(64 * SB_WAVES), 0, epn_stream(stream), A);
+    } else if (bf16 == 2) {                                                  // fp32, split form
+        if (small_t) EPN_LAUNCH(so3_basis_x3_kernel<true>, grid, dim3(64 * SB_WAVES), 0, epn_stream(stream), A);
+        else EPN_LAUNCH(so3_basis_x3_kernel<false>, grid, dim3(64 * SB_WAVES), 0, epn_stream(stream), A);
+    } else {
+        if (small_t) EPN_LAUNCH((so3_basis_kernel<float, true>), grid, dim3(64 * SB_WAVES), 0, epn_stream(stream), A);
+        else EPN_LAUNCH((so3_basis_kernel<float, false>), grid, dim3(64 * SB_WAVES), 0, epn_stream(stream), A);
+    }
     EPN_CHECK_LAUNCH();
     return 0;
 }

@@ -745,6 +745,37 @@ def test_so3_basis_kernel_and_block_layout(gpu, vgtk_alias):
 
 
 @pytest.mark.parametrize("dt,mode", [("f32", "split"), ("f32", "native"), ("bf16", "split")])
+@pytest.mark.parametrize("c,pts", [(32, 70), (96, 33), (64, 140000), (64, 280000)])
+def test_so3_basis_row_addressing_both_forms(gpu, vgtk_alias, monkeypatch, dt, mode, c, pts):
+    """The basis-change kernels address their rows with 32-bit offsets + buffer instructions when the tensor is below 2 GiB
+    (one multiply-add per row from two LDS tables; rows >= na and lanes without channels read zeros / are dropped by the
+    bounds check) and with the 64-bit expression above that.  Both directions against torch.einsum on the first and last
+    points: widths with a half-empty last channel block (32, 96), and tensors on either side of the 2 GiB line (fp32: 140 000
+    points x 60 x 64 x 4 B = 2.15 GB -> 64-bit path; bf16: the same shape is 1.07 GB -> 32-bit path, 280 000 points -> 64-bit)."""
+    from epn_pointcloud_amd import ops, gemm
+    from epn_pointcloud_amd.vgtk.so3conv import functional as L
+    if pts > 1000 and mode == "native":
+        pytest.skip("one fp32 kernel family is enough at 2 GB")
+    monkeypatch.setattr(gemm, "FP32_MODE", mode)
+    dtype = torch.bfloat16 if dt == "bf16" else torch.float32
+    basis = ops.spectral_basis(T(L.get_intra_idx()).int().to(gpu))
+    torch.manual_seed(c + pts)
+    x = torch.randn(1, c, pts, 60, device=gpu).to(dtype).contiguous(memory_format=torch.channels_last)
+    y = ops.ToSpectralFn.apply(x, basis)
+    tol = 3e-2 if dt == "bf16" else 1e-4
+    sel = torch.cat([torch.arange(0, min(pts, 40)), torch.arange(max(pts - 40, 0), pts)]).unique().to(gpu)
+    rows = x.permute(0, 2, 3, 1).reshape(pts, 60, c)[sel].float()
+    want = torch.einsum('af,qac->qfc', basis.U, rows)
+    for d, base in zip(basis.dims, basis.bases):
+        blk = y[base * pts * c:(base + d * d) * pts * c].view(pts, d * d, c)[sel].float()
+        assert (blk - want[:, base:base + d * d]).abs().max().item() < tol * max(1.0, want.abs().max().item()), (d, base)
+    back = ops.FromSpectralFn.apply(y, basis, 1, pts, c)
+    got = back.permute(0, 2, 3, 1).reshape(pts, 60, c)[sel].float()
+    assert (got - rows).abs().max().item() < tol * max(1.0, rows.abs().max().item())
+    assert torch.isfinite(back.float()).all()
+
+
+@pytest.mark.parametrize("dt,mode", [("f32", "split"), ("f32", "native"), ("bf16", "split")])
 @pytest.mark.parametrize("c", [64, 96, 256])
 def test_so3_basis_epilogue_statistics(gpu, vgtk_alias, dt, mode, c):
     """epn_so3_basis_stats_*: the inverse transform's output is unchanged and its per-point partial statistics (sum, sum of
