@@ -32,6 +32,9 @@ template <> struct ElemOf<__bf16> { static constexpr int PER16 = 8; };
 __device__ __forceinline__ void glds16(const void *g, char *lds_wave_base) {
     __builtin_amdgcn_global_load_lds((glb_void *)g, (lds_void *)lds_wave_base, 16, 0, 0);
 }
+__device__ __forceinline__ void glds16_nt(const void *g, char *lds_wave_base) {      // non-temporal: a stream read once
+    __builtin_amdgcn_global_load_lds((glb_void *)g, (lds_void *)lds_wave_base, 16, 0, 2);
+}
 
 __device__ __forceinline__ void store_out(float *p, float v) { *p = v; }
 __device__ __forceinline__ void store_out(__bf16 *p, float v) { *p = (__bf16)v; }
@@ -95,6 +98,9 @@ __global__ __launch_bounds__(64 * WGM * WGN) void gemm_nt_kernel(GemmNtBatch B) 
     auto stage_one = [&](int buf, int i) {
         const int g = wave + i * NW;
         if (NG % NW == 0 || g < NG) {
+#ifdef EPN_NT_NTA
+            if (RPG * g < BM) glds16_nt(src[i], smem + buf * (ROWS * ROWB) + g * 1024); else
+#endif
             glds16(src[i], smem + buf * (ROWS * ROWB) + g * 1024);
             src[i] += BKE;
         }
@@ -556,6 +562,9 @@ __global__ __launch_bounds__(64 * WGM * WGN) void gemm_tn_x3_kernel(GemmTnBatch 
         for (int i = 0; i < IPW; ++i) {
             const int q = wave + i * NW;
             if (NI % NW == 0 || q < NI) {
+#ifdef EPN_TN_NTY
+                if (q >= NIX) glds16_nt(src[i], smem + buf * STAGE_B + q * 1024); else
+#endif
                 glds16(src[i], smem + buf * STAGE_B + q * 1024);
                 src[i] += sstep[i];
             }

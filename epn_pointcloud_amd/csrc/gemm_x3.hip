@@ -32,6 +32,9 @@ typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 __device__ __forceinline__ void glds16(const void *g, char *lds_wave_base) {
     __builtin_amdgcn_global_load_lds((glb_void *)g, (lds_void *)lds_wave_base, 16, 0, 0);
 }
+__device__ __forceinline__ void glds16_nt(const void *g, char *lds_wave_base) {      // non-temporal: a stream read once
+    __builtin_amdgcn_global_load_lds((glb_void *)g, (lds_void *)lds_wave_base, 16, 0, 2);
+}
 __device__ __forceinline__ unsigned pack_rne(float a, float b) {   // v_cvt_pk_bf16_f32
     const f32x2 v = {a, b};
     return __builtin_bit_cast(unsigned, __builtin_convertvector(v, bf16x2));
@@ -147,6 +150,9 @@ __global__ __launch_bounds__(64 * WGM * WGN) void gemm_nt_x3_kernel(GemmNtBatch 
     auto stage_one = [&](int buf, int i) {
         const int g = wave + i * NW;
         if (NG % NW == 0 || g < NG) {
+#ifdef EPN_X3_NTA
+            if (g < NGA) glds16_nt(src[i], smem + buf * STAGE + g * 1024); else
+#endif
             glds16(src[i], smem + buf * STAGE + g * 1024);
             src[i] += adv[i];
         }
@@ -250,7 +256,13 @@ __global__ __launch_bounds__(64 * WGM * WGN) void gemm_nt_x3_kernel(GemmNtBatch 
             for (int r = 0; r < 16; ++r) {
                 const unsigned o = lane_off + (unsigned)(i * 32 + (r & 3) + 8 * (r >> 2)) * ldc;
 #pragma unroll
-                for (int j = 0; j < TN; ++j) cw[o + j * 32] = acc[i][j][r];
+                for (int j = 0; j < TN; ++j) {
+#ifdef EPN_X3_NTC
+                    __builtin_nontemporal_store(acc[i][j][r], cw + o + j * 32);
+#else
+                    cw[o + j * 32] = acc[i][j][r];
+#endif
+                }
             }
         return;
     }

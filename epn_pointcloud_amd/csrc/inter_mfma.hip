@@ -813,6 +813,9 @@ __global__ __launch_bounds__(64 * NW) void inter_group_kernel(InterArgs A) {
 // amdgpu_waves_per_eu(2): a register budget of 256 (no instance with K <= 64 needs more) -- with the 512 that
 // __launch_bounds__(256) alone allows, hipcc places the MFMA results in AGPRs and copies every one of them back
 // (v_accvgpr_read_b32: 64 per column at K = 64, the largest single VALU item of the kernel)
+#ifndef EPN_G_STORE_AUX
+#define EPN_G_STORE_AUX 2     // cache policy of the stores of G (gfx940+: bit 0 = sc0, bit 1 = nt, bit 4 = sc1)
+#endif
 template <int NT, int KT, typename TF, int CG>
 #ifdef EPN_GRP_NO_WPE
 __global__ __launch_bounds__(64 * NW)
@@ -907,10 +910,10 @@ void inter_group_wide_kernel(InterArgs A) {
             if constexpr (BF) {
                 typedef unsigned u32x2_s __attribute__((ext_vector_type(2)));
                 const bf16x4_t b = {(__bf16)g[0], (__bf16)g[1], (__bf16)g[2], (__bf16)g[3]};
-                __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2_s, b), rG, off, 0, 0);
+                __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2_s, b), rG, off, 0, EPN_G_STORE_AUX);
             } else {
                 typedef unsigned u32x4_s __attribute__((ext_vector_type(4)));
-                __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4_s, g), rG, off, 0, 0);
+                __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4_s, g), rG, off, 0, EPN_G_STORE_AUX);
             }
         };
         // One column: request column i + 1's feature rows and kernel-table entries into (fnext, rnext), then compute column
@@ -1314,6 +1317,10 @@ __global__ __launch_bounds__(64 * GP) void inter_ungroup_shared_kernel(InterArgs
         const int k0 = off[u], len = off[u + 1] - k0;
         const unsigned s0 = list[k0], s1 = len > 1 ? list[k0 + 1] : E, s2 = len > 2 ? list[k0 + 2] : E;
         pk[u] = (int)(s0 | (s1 << 10) | (s2 << 20) | (len > 3 ? 1u << 30 : 0u));
+        // element offset of the destination's gradient row inside the cloud (cnt[] is dead by now unless DET keeps its slab
+        // rows there): the atomic's address becomes a wave-uniform 64-bit base + this 32-bit offset -- round 3 rebuilt it per
+        // atomic as ((size_t)uq * na + a) * cin: two quarter-rate v_mul_lo_u32 and two 64-bit multiply-adds per fp32 added
+        if constexpr (!DET) cnt[u] = (int)uq[u] * A.na * A.cin;
     }
     for (int i = tid; i < NB * SS; i += NTH) Tb[(i / SS) * BS + E * SS + i % SS] = 0.0f;
 
@@ -1336,8 +1343,13 @@ __global__ __launch_bounds__(64 * GP) void inter_ungroup_shared_kernel(InterArgs
             for (int kt = 0; kt < KT; ++kt) {
                 const int jj = 16 * kt + 4 * j < A.ks ? j : 0;
                 const TG *src = dG + (size_t)a * gss + (size_t)(16 * (cs * CW + cw)) * A.ks + 16 * kt + 4 * jj;
+#ifdef EPN_UNG_NT
+                if constexpr (sizeof(TG) == 2) d[cw][kt] = __builtin_nontemporal_load(reinterpret_cast<const bf16x4_t *>(src));
+                else d[cw][kt] = __builtin_nontemporal_load(reinterpret_cast<const f32x4 *>(src));
+#else
                 if constexpr (sizeof(TG) == 2) d[cw][kt] = *reinterpret_cast<const bf16x4_t *>(src);
                 else d[cw][kt] = ld4f(src);
+#endif
             }
     };
     auto load_rk = [&](int a, float (&r)[KT]) {
@@ -1420,6 +1432,7 @@ __global__ __launch_bounds__(64 * GP) void inter_ungroup_shared_kernel(InterArgs
                 }
             __syncthreads();
             const float *rb = Tb + (ph & (NB - 1)) * BS;
+            float *dstep = dcloud + (size_t)a * A.cin + 16 * cs * CW;      // wave-uniform
 #ifdef EPN_TUNING
             if (!(A.wk & 2))
 #endif
@@ -1440,7 +1453,7 @@ __global__ __launch_bounds__(64 * GP) void inter_ungroup_shared_kernel(InterArgs
 #ifdef EPN_TUNING
                     if (!(A.wk & 1) || sum == 12345.678f)
 #endif
-                    atomicAdd(dcloud + ((size_t)uq[u] * A.na + a) * A.cin + 16 * cs * CW + c, sum);
+                    atomicAdd(dstep + ((unsigned)cnt[u] + (unsigned)c), sum);
                 }
             }
             if constexpr (NB == 1) __syncthreads();
