@@ -22,6 +22,7 @@ struct SbArgs {
     void *out;
     long long pts;
     int na, c, in_spec, out_spec;
+    int pair;                 // c == 32, 32-bit addressing: two points per task (see the kernels)
     // optional: leaky_relu(norm(.)) applied to the input rows as they are loaded ("norm on load": the block glue's first
     // normalisation folded into the basis change) -- nsums[g][c] = (sum x, sum x^2) as epn_chan_stats writes
     const float *nsums, *ngamma, *nbeta;
@@ -180,11 +181,15 @@ __global__ __launch_bounds__(64 * SB_WAVES) void so3_basis_kernel(SbArgs A) {
     const int nst = A.na >> 2;        // contraction steps of 4 rows (na % 4 == 0, launcher)
     for (int it = 0; it < SB_TPW; ++it) {
         const long long task = ((long long)blockIdx.x * SB_WAVES + wave) * SB_TPW + it;
-        if (task >= A.pts * ncb) return;
-        const long long pt = task / ncb;
-        const int cb = (int)(task - pt * ncb);
-        const int choff0 = 64 * cb + 4 * x;
-        const bool cval = choff0 < A.c;        // this lane's 4 channels exist
+        // c == 32 (the first two blocks of the rotation / 3DMatch networks): a 64-channel block would leave lanes x >= 8 idle
+        // (round 3: "half empty"); instead a task is TWO points, lanes x >= 8 carry the second one -- only the per-lane point
+        // index of the loads, stores and statistics changes, M is the same for every column
+        const bool pair = SMALL && A.pair;
+        if (task >= (pair ? (A.pts + 1) >> 1 : A.pts * ncb)) return;
+        const long long pt = pair ? 2 * task + (x >> 3) : task / ncb;
+        const int cb = pair ? 0 : (int)(task - pt * ncb);
+        const int choff0 = pair ? 4 * (x & 7) : 64 * cb + 4 * x;
+        const bool cval = pair ? pt < A.pts : choff0 < A.c;        // this lane's 4 channels exist
         const int choff = cval ? choff0 : 0;
 
         auto row_addr = [&](int spec, int r) -> size_t {   // float offset of row r of this point
@@ -207,7 +212,7 @@ __global__ __launch_bounds__(64 * SB_WAVES) void so3_basis_kernel(SbArgs A) {
             }
         if (A.nsums) {
             SbNorm N;
-            sb_norm_load(A, pt, choff, N);
+            sb_norm_load(A, cval ? pt : 0, choff, N);
 #pragma unroll
             for (int st = 0; st < 16; ++st)
                 if (st < nst) {
@@ -286,11 +291,15 @@ __global__ __launch_bounds__(64 * SB_WAVES) void so3_basis_bf16_kernel(SbArgs A)
     __bf16 *out = static_cast<__bf16 *>(A.out);
     for (int it = 0; it < SB_TPW; ++it) {
         const long long task = ((long long)blockIdx.x * SB_WAVES + wave) * SB_TPW + it;
-        if (task >= A.pts * ncb) return;
-        const long long pt = task / ncb;
-        const int cb = (int)(task - pt * ncb);
-        const int choff0 = 64 * cb + 4 * x;
-        const bool cval = choff0 < A.c;        // this lane's 4 channels exist
+        // c == 32 (the first two blocks of the rotation / 3DMatch networks): a 64-channel block would leave lanes x >= 8 idle
+        // (round 3: "half empty"); instead a task is TWO points, lanes x >= 8 carry the second one -- only the per-lane point
+        // index of the loads, stores and statistics changes, M is the same for every column
+        const bool pair = SMALL && A.pair;
+        if (task >= (pair ? (A.pts + 1) >> 1 : A.pts * ncb)) return;
+        const long long pt = pair ? 2 * task + (x >> 3) : task / ncb;
+        const int cb = pair ? 0 : (int)(task - pt * ncb);
+        const int choff0 = pair ? 4 * (x & 7) : 64 * cb + 4 * x;
+        const bool cval = pair ? pt < A.pts : choff0 < A.c;        // this lane's 4 channels exist
         const int choff = cval ? choff0 : 0;
         auto row_addr = [&](int spec, int r) -> size_t {
             if (spec) return ((size_t)bs[r] * A.pts + (size_t)pt * d2s[r] + (r - bs[r])) * A.c + choff;
@@ -308,7 +317,7 @@ __global__ __launch_bounds__(64 * SB_WAVES) void so3_basis_bf16_kernel(SbArgs A)
             }
         if (A.nsums) {
             SbNorm N;
-            sb_norm_load(A, pt, choff, N);
+            sb_norm_load(A, cval ? pt : 0, choff, N);
 #pragma unroll
             for (int ks = 0; ks < 2; ++ks)
 #pragma unroll
@@ -425,11 +434,15 @@ __global__ __launch_bounds__(64 * SB_WAVES) __attribute__((amdgpu_waves_per_eu(2
     float *out = static_cast<float *>(A.out);
     for (int it = 0; it < SB_TPW; ++it) {
         const long long task = ((long long)blockIdx.x * SB_WAVES + wave) * SB_TPW + it;
-        if (task >= A.pts * ncb) return;
-        const long long pt = task / ncb;
-        const int cb = (int)(task - pt * ncb);
-        const int choff0 = 64 * cb + 4 * x;
-        const bool cval = choff0 < A.c;        // this lane's 4 channels exist
+        // c == 32 (the first two blocks of the rotation / 3DMatch networks): a 64-channel block would leave lanes x >= 8 idle
+        // (round 3: "half empty"); instead a task is TWO points, lanes x >= 8 carry the second one -- only the per-lane point
+        // index of the loads, stores and statistics changes, M is the same for every column
+        const bool pair = SMALL && A.pair;
+        if (task >= (pair ? (A.pts + 1) >> 1 : A.pts * ncb)) return;
+        const long long pt = pair ? 2 * task + (x >> 3) : task / ncb;
+        const int cb = pair ? 0 : (int)(task - pt * ncb);
+        const int choff0 = pair ? 4 * (x & 7) : 64 * cb + 4 * x;
+        const bool cval = pair ? pt < A.pts : choff0 < A.c;        // this lane's 4 channels exist
         const int choff = cval ? choff0 : 0;
         auto row_addr = [&](int spec, int r) -> size_t {
             if (spec) return ((size_t)bs[r] * A.pts + (size_t)pt * d2s[r] + (r - bs[r])) * A.c + choff;
@@ -447,7 +460,7 @@ __global__ __launch_bounds__(64 * SB_WAVES) __attribute__((amdgpu_waves_per_eu(2
             }
         if (A.nsums) {
             SbNorm N;
-            sb_norm_load(A, pt, choff, N);
+            sb_norm_load(A, cval ? pt : 0, choff, N);
 #pragma unroll
             for (int ks = 0; ks < 2; ++ks)
 #pragma unroll
@@ -658,7 +671,9 @@ static int so3_basis_any(const void *in, const float *M, const int32_t *blocks, 
         A.ngroups = nh->groups; A.npts_per_group = nh->groups > 1 ? nh->pts_per_group : pts;
         A.ninv_rows = 1.0f / ((float)A.npts_per_group * (float)na);
     }
-    const long long tasks = pts * ((c + 63) >> 6);
+    const long long bytes_ = pts * na * c * (bf16 == 1 ? 2LL : 4LL);
+    A.pair = (c == 32 && bytes_ < 0x7fffff00LL && pts < (1LL << 24)) ? 1 : 0;
+    const long long tasks = A.pair ? (pts + 1) / 2 : pts * ((c + 63) >> 6);
     const long long per_wg = (long long)SB_WAVES * SB_TPW;
     const dim3 grid((unsigned)((tasks + per_wg - 1) / per_wg));
     // 32-bit row offsets + buffer instructions when the tensor is below 2 GiB and the per-point strides fit 24 bits

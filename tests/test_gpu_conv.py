@@ -745,7 +745,7 @@ def test_so3_basis_kernel_and_block_layout(gpu, vgtk_alias):
 
 
 @pytest.mark.parametrize("dt,mode", [("f32", "split"), ("f32", "native"), ("bf16", "split")])
-@pytest.mark.parametrize("c,pts", [(32, 70), (96, 33), (64, 140000), (64, 280000)])
+@pytest.mark.parametrize("c,pts", [(32, 70), (32, 71), (96, 33), (64, 140000), (64, 280000)])
 def test_so3_basis_row_addressing_both_forms(gpu, vgtk_alias, monkeypatch, dt, mode, c, pts):
     """The basis-change kernels address their rows with 32-bit offsets + buffer instructions when the tensor is below 2 GiB
     (one multiply-add per row from two LDS tables; rows >= na and lanes without channels read zeros / are dropped by the
@@ -776,7 +776,7 @@ def test_so3_basis_row_addressing_both_forms(gpu, vgtk_alias, monkeypatch, dt, m
 
 
 @pytest.mark.parametrize("dt,mode", [("f32", "split"), ("f32", "native"), ("bf16", "split")])
-@pytest.mark.parametrize("c", [64, 96, 256])
+@pytest.mark.parametrize("c", [32, 64, 96, 256])
 def test_so3_basis_epilogue_statistics(gpu, vgtk_alias, dt, mode, c):
     """epn_so3_basis_stats_*: the inverse transform's output is unchanged and its per-point partial statistics (sum, sum of
     squares over the 60 anchor rows of each point and channel, of the values as stored) match the tensor it wrote; finished
@@ -907,7 +907,8 @@ def test_conv1x1_single_input_channel(gpu, cout):
 
 @pytest.mark.parametrize("instance", [False, True])
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
-def test_norm_folded_into_basis_change(gpu, vgtk_alias, instance, dtype):
+@pytest.mark.parametrize("c,p", [(64, 10), (32, 11)])        # c = 32: two points per task, odd point count (a tail lane)
+def test_norm_folded_into_basis_change(gpu, vgtk_alias, instance, dtype, c, p):
     """intra_so3conv(x, pre_norm=norm) -- the block's first norm + leaky_relu applied as the basis change loads its rows
     (epn_so3_basis_norm_*) -- against intra_so3conv(norm_act(x, norm)): outputs, all gradients and BatchNorm's running
     statistics (SPConvNets/utils/base_so3conv.py:196-204)."""
@@ -916,7 +917,7 @@ def test_norm_folded_into_basis_change(gpu, vgtk_alias, instance, dtype):
     from epn_pointcloud_amd import ops
     from epn_pointcloud_amd.vgtk.so3conv import functional as L
     torch.manual_seed(3)
-    b, c, co, p = 3, 64, 128, 10
+    b, co = 3, 128
     idx = torch.from_numpy(L.get_intra_idx()).int().to(gpu)
     x = (torch.randn(b, c, p, 60, device=gpu) * 2 + 0.5).to(dtype)
     W = (torch.randn(co, c * 12, device=gpu) / (c * 12) ** 0.5)
