@@ -36,6 +36,7 @@ EXPORTS = [
     "epn_inter_ungroup_acc_f32", "epn_inter_ungroup_acc_bf16", "epn_stats_finish", "epn_stats_finish_workspace_bytes",
     "epn_so3_basis_stats_f32", "epn_so3_basis_stats_split_f32", "epn_so3_basis_stats_bf16",
     "epn_spectral_weights_f32", "epn_spectral_weights_bwd_f32", "epn_spectral_weights_bf16", "epn_cast_add_bf16",
+    "epn_so3_basis_dstats_f32", "epn_so3_basis_dstats_split_f32", "epn_so3_basis_dstats_bf16", "epn_norm_bwd_finish",
     "epn_inter_c1_ok", "epn_inter_so3conv_fwd_c1_f32", "epn_inter_so3conv_bwd_weight_c1_f32",
     "epn_inter_split_ok", "epn_inter_split_saved_bytes", "epn_inter_split_workspace_bytes",
     "epn_inter_so3conv_fwd_split_f32", "epn_inter_so3conv_fwd_split_bf16", "epn_inter_so3conv_bwd_split_f32",
@@ -111,6 +112,10 @@ def get_lib():
     lib.epn_inter_onchip_workspace_bytes.restype = _sz
     lib.epn_inter_so3conv_fwd_onchip_f32.argtypes = [dp, _vp, _vp, _vp, _vp, _sz, _vp]
     lib.epn_inter_so3conv_fwd_bf16.argtypes = [dp, _vp, _vp, _vp, _vp, _sz, _vp]
+    for _n in ("epn_so3_basis_dstats_f32", "epn_so3_basis_dstats_split_f32", "epn_so3_basis_dstats_bf16"):
+        getattr(lib, _n).argtypes = [_vp, _vp, _vp, ctypes.c_longlong, _ci, _ci, _vp, _vp, _vp, _ci, ctypes.c_longlong, _vp, _vp,
+                                     _cf, _cf, _vp, _vp]
+    lib.epn_norm_bwd_finish.argtypes = [_vp, _ci, ctypes.c_longlong, _ci, _vp, _vp, _vp, _vp, _vp, _sz, _vp]
     lib.epn_inter_c1_ok.argtypes = [dp]
     lib.epn_inter_c1_ok.restype = _ci
     lib.epn_inter_so3conv_fwd_c1_f32.argtypes = [dp, _vp, _vp, _vp, _vp, _vp, _sz, _vp]

@@ -758,6 +758,37 @@ extern "C" int epn_stats_finish(const float *partials, int groups, long long blo
     return 0;
 }
 
+// dsums / dgamma / dbeta of a norm's backward pass from block partials part[g][block][c][2] = (sum d, sum d xhat) that
+// another kernel's epilogue produced (epn_so3_basis_dstats_*: one block per point): what norm_act_bwd_reduce's own finishing
+// step does, as an entry point.  Workspace: epn_stats_finish_workspace_bytes(groups, blocks_per_group, c).
+extern "C" int epn_norm_bwd_finish(const float *partials, int groups, long long blocks_per_group, int c, const float *gamma,
+                                   float *dsums, float *dgamma, float *dbeta, void *workspace, size_t workspace_bytes,
+                                   epn_stream_t stream) {
+    if (groups < 0 || blocks_per_group < 1 || c < 1 || blocks_per_group > 0x7fffffffLL) return EPN_EINVAL;
+    if (stats_finish_nz(blocks_per_group) > 65535 || groups > 65535) return EPN_EINVAL;
+    if (groups == 0) return 0;
+    if (!partials || !dsums) return EPN_ENULL;
+    hipStream_t st = epn_stream(stream);
+    const long long nz = stats_finish_nz(blocks_per_group);
+    if (nz) {
+        if (!workspace || workspace_bytes < epn_stats_finish_workspace_bytes(groups, blocks_per_group, c)) return EPN_EWORKSPACE;
+        float *part2 = static_cast<float *>(workspace);
+        EPN_LAUNCH_AUX(stats_reduce_kernel, dim3(epn_cdiv(2 * c, 64), (unsigned)nz, groups), dim3(256), 0, st, partials,
+                       (int)blocks_per_group, c * 2, part2);
+        EPN_CHECK_LAUNCH();
+        partials = part2;
+        blocks_per_group = nz;
+    }
+    if (groups > 1) {                        // several groups accumulate with atomics; one group stores
+        if (dgamma) EPN_HIP(hipMemsetAsync(dgamma, 0, sizeof(float) * c, st));
+        if (dbeta) EPN_HIP(hipMemsetAsync(dbeta, 0, sizeof(float) * c, st));
+    }
+    EPN_LAUNCH(bwd_finish_kernel, dim3(epn_cdiv(c, 16), groups), dim3(256), 0, st, partials, (int)blocks_per_group, c, gamma,
+               dsums, dgamma, dbeta);
+    EPN_CHECK_LAUNCH();
+    return 0;
+}
+
 extern "C" int epn_chan_stats_f32(const float *x_cl, int groups, long long rows, int c, float *sums, void *workspace,
                                   size_t workspace_bytes, epn_stream_t stream) {
     return chan_stats_any(x_cl, groups, rows, c, sums, workspace, workspace_bytes, 0, stream);

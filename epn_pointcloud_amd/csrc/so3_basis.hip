@@ -32,6 +32,12 @@ struct SbArgs {
     // optional: per-channel (sum, sum of squares) over the na output rows of every point, pstats[pt][c][2] -- the block
     // partials of the statistics a norm after the transform needs (epn_stats_finish sums them), from the accumulators
     float *pstats;
+    // optional (inverse transform of a gradient, 32-bit addressing only): dstat_x = the tensor x whose leaky_relu(norm(x)) fed
+    // the forward transform (plain layout, as `out`).  The kernel then also writes pstats[pt][c][2] = (sum d, sum d * xhat)
+    // over the point's na rows, d = dy * leaky'(norm(x)) -- the block partials of the norm's backward reduction
+    // (glue.hip norm_act_bwd_reduce_kernel) taken from the accumulators that hold dy; nsums / ngamma / nbeta / neps /
+    // nslope describe that norm and are NOT applied to the input rows in this mode
+    const void *dstat_x;
 };
 
 // per-lane normalisation of its 4 channels: n = (v - mean) * rstd * gamma + beta, leaky (the formula of glue.hip's
@@ -155,6 +161,54 @@ __device__ __forceinline__ void sb_bst(__bf16 *, __amdgpu_buffer_rsrc_t rs, unsi
     __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(sb_u32x2, b), rs, off, 0, 0);
 }
 
+// backward reduction of the norm in front of the forward transform, from the accumulators that hold dy (see SbArgs::dstat_x):
+// x is read at the rows this lane is about to store (same offsets, plain layout), four rows at a time
+template <bool BF>
+__device__ __forceinline__ void sb_point_dstats(const f32x4 (&acc)[4][4], const SbArgs &A, const SbTables &tab,
+                                                __amdgpu_buffer_rsrc_t rx, unsigned upt, unsigned cho, long long pt, int choff0,
+                                                int choff, bool cval, int j) {
+    SbNorm N;
+    sb_norm_load(A, cval ? pt : 0, choff, N);
+    float sa[4] = {0.f, 0.f, 0.f, 0.f}, sb[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int mt = 0; mt < 4; ++mt) {
+        f32x4 xv[4];
+#pragma unroll
+        for (int rr = 0; rr < 4; ++rr) {
+            const unsigned off = sb_off(tab.rbo, tab.rso, 16 * mt + 4 * j + rr, upt, cho);     // rows >= na: zeros
+            if constexpr (BF) {
+                const sb_u32x2 w = sb_bld64(rx, off);
+                xv[rr] = f32x4{__builtin_bit_cast(float, w[0] << 16), __builtin_bit_cast(float, w[0] & 0xffff0000u),
+                               __builtin_bit_cast(float, w[1] << 16), __builtin_bit_cast(float, w[1] & 0xffff0000u)};
+            } else {
+                xv[rr] = sb_bld128(rx, off);
+            }
+        }
+#pragma unroll
+        for (int rr = 0; rr < 4; ++rr)
+#pragma unroll
+            for (int nt = 0; nt < 4; ++nt) {
+                float d = acc[mt][nt][rr];                      // rows >= na: exactly 0 (M is zero padded)
+                if constexpr (BF) d = (float)(__bf16)d;        // the value the apply pass will read back
+                const float xh = (xv[rr][nt] - N.mean[nt]) * N.rstd[nt];
+                const float n = xh * N.ga[nt] + N.be[nt];
+                const float dd = n > 0.0f ? d : d * N.slope;
+                sa[nt] += dd;
+                sb[nt] = fmaf(dd, xh, sb[nt]);
+            }
+    }
+#pragma unroll
+    for (int nt = 0; nt < 4; ++nt) {
+        sa[nt] += __shfl_xor(sa[nt], 16, 64); sb[nt] += __shfl_xor(sb[nt], 16, 64);
+        sa[nt] += __shfl_xor(sa[nt], 32, 64); sb[nt] += __shfl_xor(sb[nt], 32, 64);
+    }
+    if (j == 0 && cval) {
+        f32x4 *o = reinterpret_cast<f32x4 *>(A.pstats + ((size_t)pt * A.c + choff0) * 2);
+        o[0] = f32x4{sa[0], sb[0], sa[1], sb[1]};
+        o[1] = f32x4{sa[2], sb[2], sa[3], sb[3]};
+    }
+}
+
 template <typename T, bool SMALL>
 __global__ __launch_bounds__(64 * SB_WAVES) void so3_basis_kernel(SbArgs A) {
     __shared__ float Ms[64 * SB_LD];
@@ -174,6 +228,7 @@ __global__ __launch_bounds__(64 * SB_WAVES) void so3_basis_kernel(SbArgs A) {
     const unsigned nbytes = SMALL ? (unsigned)(A.pts * A.na * A.c * (long long)sizeof(T)) : 0u;
     const __amdgpu_buffer_rsrc_t rin = __builtin_amdgcn_make_buffer_rsrc(const_cast<void *>(A.in), 0, (int)nbytes, 0x00020000);
     const __amdgpu_buffer_rsrc_t rout = __builtin_amdgcn_make_buffer_rsrc(A.out, 0, (int)nbytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rxs = __builtin_amdgcn_make_buffer_rsrc(const_cast<void *>(A.dstat_x ? A.dstat_x : A.in), 0, (int)nbytes, 0x00020000);
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int x = lane & 15, j = lane >> 4;
@@ -210,7 +265,7 @@ __global__ __launch_bounds__(64 * SB_WAVES) void so3_basis_kernel(SbArgs A) {
                 if constexpr (SMALL && sizeof(T) == 4) bv[st] = sb_bld128(rin, sb_off(tab.rbi, tab.rsi, 4 * st + j, upt, cho));
                 else bv[st] = cval ? sb_ld(static_cast<const T *>(A.in) + row_addr(A.in_spec, 4 * st + j)) : f32x4{0.f, 0.f, 0.f, 0.f};
             }
-        if (A.nsums) {
+        if (A.nsums && !A.dstat_x) {
             SbNorm N;
             sb_norm_load(A, cval ? pt : 0, choff, N);
 #pragma unroll
@@ -235,7 +290,10 @@ __global__ __launch_bounds__(64 * SB_WAVES) void so3_basis_kernel(SbArgs A) {
                 }
             }
         }
-        if (A.pstats) sb_point_stats<sizeof(T) == 2>(acc, A.pstats, pt, A.c, choff0, cval, j);
+        if constexpr (SMALL) {
+            if (A.dstat_x) sb_point_dstats<sizeof(T) == 2>(acc, A, tab, rxs, upt, cho, pt, choff0, choff, cval, j);
+            else if (A.pstats) sb_point_stats<sizeof(T) == 2>(acc, A.pstats, pt, A.c, choff0, cval, j);
+        } else if (A.pstats) sb_point_stats<sizeof(T) == 2>(acc, A.pstats, pt, A.c, choff0, cval, j);
         // acc[mt][nt][rr]: output row 16 mt + 4 j + rr, channel 4 x + nt
 #pragma unroll
         for (int mt = 0; mt < 4; ++mt)
@@ -270,6 +328,7 @@ __global__ __launch_bounds__(64 * SB_WAVES) void so3_basis_bf16_kernel(SbArgs A)
     const unsigned nbytes = SMALL ? (unsigned)(A.pts * A.na * A.c * 2LL) : 0u;
     const __amdgpu_buffer_rsrc_t rin = __builtin_amdgcn_make_buffer_rsrc(const_cast<void *>(A.in), 0, (int)nbytes, 0x00020000);
     const __amdgpu_buffer_rsrc_t rout = __builtin_amdgcn_make_buffer_rsrc(A.out, 0, (int)nbytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rxs = __builtin_amdgcn_make_buffer_rsrc(const_cast<void *>(A.dstat_x ? A.dstat_x : A.in), 0, (int)nbytes, 0x00020000);
     for (int i = threadIdx.x; i < 64 * 64; i += blockDim.x) {
         const int r = i >> 6, q = i & 63;
         const float m = (r < A.na && q < A.na) ? A.M[r * A.na + q] : 0.0f;
@@ -315,7 +374,7 @@ __global__ __launch_bounds__(64 * SB_WAVES) void so3_basis_bf16_kernel(SbArgs A)
                 if constexpr (SMALL) raw[ks][e] = __builtin_bit_cast(sbu32x2, sb_bld64(rin, sb_off(tab.rbi, tab.rsi, r, upt, cho)));
                 else raw[ks][e] = (r < A.na && cval) ? *reinterpret_cast<const sbu32x2 *>(in + row_addr(A.in_spec, r)) : sbu32x2{0u, 0u};
             }
-        if (A.nsums) {
+        if (A.nsums && !A.dstat_x) {
             SbNorm N;
             sb_norm_load(A, cval ? pt : 0, choff, N);
 #pragma unroll
@@ -361,7 +420,10 @@ __global__ __launch_bounds__(64 * SB_WAVES) void so3_basis_bf16_kernel(SbArgs A)
                 }
             }
         }
-        if (A.pstats) sb_point_stats<true>(acc, A.pstats, pt, A.c, choff0, cval, j);
+        if constexpr (SMALL) {
+            if (A.dstat_x) sb_point_dstats<true>(acc, A, tab, rxs, upt, cho, pt, choff0, choff, cval, j);
+            else if (A.pstats) sb_point_stats<true>(acc, A.pstats, pt, A.c, choff0, cval, j);
+        } else if (A.pstats) sb_point_stats<true>(acc, A.pstats, pt, A.c, choff0, cval, j);
         // acc[mt][nt][rr]: output row 16 mt + 4 j + rr, channel 4 x + nt
 #pragma unroll
         for (int mt = 0; mt < 4; ++mt)
@@ -410,6 +472,7 @@ __global__ __launch_bounds__(64 * SB_WAVES) __attribute__((amdgpu_waves_per_eu(2
     const unsigned nbytes = SMALL ? (unsigned)(A.pts * A.na * A.c * 4LL) : 0u;
     const __amdgpu_buffer_rsrc_t rin = __builtin_amdgcn_make_buffer_rsrc(const_cast<void *>(A.in), 0, (int)nbytes, 0x00020000);
     const __amdgpu_buffer_rsrc_t rout = __builtin_amdgcn_make_buffer_rsrc(A.out, 0, (int)nbytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rxs = __builtin_amdgcn_make_buffer_rsrc(const_cast<void *>(A.dstat_x ? A.dstat_x : A.in), 0, (int)nbytes, 0x00020000);
     for (int i = threadIdx.x; i < 64 * 64; i += blockDim.x) {
         const int r = i >> 6, q = i & 63;
         const float v = (r < A.na && q < A.na) ? A.M[r * A.na + q] : 0.0f;
@@ -458,7 +521,7 @@ __global__ __launch_bounds__(64 * SB_WAVES) __attribute__((amdgpu_waves_per_eu(2
                 if constexpr (SMALL) raw[ks][e] = sb_bld128(rin, sb_off(tab.rbi, tab.rsi, r, upt, cho));
                 else raw[ks][e] = (r < A.na && cval) ? sb_ld(in + row_addr(A.in_spec, r)) : f32x4{0.f, 0.f, 0.f, 0.f};
             }
-        if (A.nsums) {
+        if (A.nsums && !A.dstat_x) {
             SbNorm N;
             sb_norm_load(A, cval ? pt : 0, choff, N);
 #pragma unroll
@@ -502,7 +565,10 @@ __global__ __launch_bounds__(64 * SB_WAVES) __attribute__((amdgpu_waves_per_eu(2
 #undef EPN_SB_TERM
             }
         }
-        if (A.pstats) sb_point_stats<false>(acc, A.pstats, pt, A.c, choff0, cval, j);
+        if constexpr (SMALL) {
+            if (A.dstat_x) sb_point_dstats<false>(acc, A, tab, rxs, upt, cho, pt, choff0, choff, cval, j);
+            else if (A.pstats) sb_point_stats<false>(acc, A.pstats, pt, A.c, choff0, cval, j);
+        } else if (A.pstats) sb_point_stats<false>(acc, A.pstats, pt, A.c, choff0, cval, j);
         // acc[mt][nt][rr]: output row 16 mt + 4 j + rr, channel 4 x + nt
 #pragma unroll
         for (int mt = 0; mt < 4; ++mt)
@@ -654,18 +720,18 @@ struct SbNormHost {
 
 static int so3_basis_any(const void *in, const float *M, const int32_t *blocks, long long pts, int na, int c,
                         int in_spectral, int out_spectral, void *out, int bf16, epn_stream_t stream,
-                        const SbNormHost *nh = nullptr, float *point_stats = nullptr) {
+                        const SbNormHost *nh = nullptr, float *point_stats = nullptr, const void *dstat_x = nullptr) {
     if (pts < 0 || na < 4 || na > 64 || (na & 3) || c < 32 || (c & 31)) return EPN_EINVAL;
     if (pts == 0) return 0;
     if (!in || !M || !blocks || !out) return EPN_ENULL;
     SbArgs A;
     A.in = in; A.M = M; A.blk = blocks; A.out = out; A.pts = pts; A.na = na; A.c = c; A.pstats = point_stats;
-    A.in_spec = in_spectral; A.out_spec = out_spectral;
+    A.in_spec = in_spectral; A.out_spec = out_spectral; A.dstat_x = dstat_x;
     A.nsums = nullptr; A.ngamma = A.nbeta = nullptr; A.neps = 0.f; A.nslope = 0.f; A.ninv_rows = 0.f; A.ngroups = 1;
     A.npts_per_group = pts;
     if (nh) {
         if (!nh->sums) return EPN_ENULL;
-        if (in_spectral || nh->groups < 1 || nh->pts_per_group < 1 || (nh->groups > 1 && nh->groups * nh->pts_per_group != pts))
+        if ((in_spectral && !dstat_x) || nh->groups < 1 || nh->pts_per_group < 1 || (nh->groups > 1 && nh->groups * nh->pts_per_group != pts))
             return EPN_EINVAL;
         A.nsums = nh->sums; A.ngamma = nh->gamma; A.nbeta = nh->beta; A.neps = nh->eps; A.nslope = nh->slope;
         A.ngroups = nh->groups; A.npts_per_group = nh->groups > 1 ? nh->pts_per_group : pts;
@@ -678,6 +744,7 @@ static int so3_basis_any(const void *in, const float *M, const int32_t *blocks, 
     const dim3 grid((unsigned)((tasks + per_wg - 1) / per_wg));
     // 32-bit row offsets + buffer instructions when the tensor is below 2 GiB and the per-point strides fit 24 bits
     const long long bytes = pts * na * c * (bf16 == 1 ? 2LL : 4LL);
+    if (dstat_x && (!(bytes < 0x7fffff00LL && pts < (1LL << 24)) || !point_stats || !nh || out_spectral)) return EPN_EINVAL;
     const bool small_t = bytes < 0x7fffff00LL && pts < (1LL << 24) && (long long)na * c * 4 < (1LL << 24);
     if (bf16 == 1) {
         if (small_t) EPN_LAUNCH(so3_basis_bf16_kernel<true>, grid, dim3(64 * SB_WAVES), 0, epn_stream(stream), A);
@@ -725,6 +792,39 @@ extern "C" int epn_so3_basis_stats_bf16(const void *in, const float *M, const in
     if (!point_stats) return EPN_ENULL;
     if (out_spectral) return EPN_EINVAL;      // statistics over the ANCHOR rows of a point: plain output layout only
     return so3_basis_any(in, M, blocks, pts, na, c, in_spectral, out_spectral, out, 1, stream, nullptr, point_stats);
+}
+
+// Inverse transform of a spectral GRADIENT + the block partials of the backward reduction of the norm that preceded the
+// forward transform (SbArgs::dstat_x): dy = U . grad (plain layout), point_dstats[pt][c][2] = (sum d, sum d xhat) over the
+// point's anchors with d = dy * leaky'(norm(x)).  epn_norm_bwd_finish turns the partials into dsums / dgamma / dbeta.
+// Tensors of 2 GiB or more: EPN_EINVAL (use epn_so3_basis_* + epn_norm_act_bwd_reduce_*).
+static int so3_basis_dstats_any(const void *in, const float *M, const int32_t *blocks, long long pts, int na, int c, void *out,
+                                const void *x_cl, const float *sums, int groups, long long pts_per_group, const float *gamma,
+                                const float *beta, float eps, float slope, float *point_dstats, int bf16, epn_stream_t stream) {
+    if (!x_cl || !point_dstats) return EPN_ENULL;
+    const SbNormHost nh = {sums, gamma, beta, groups, pts_per_group, eps, slope};
+    return so3_basis_any(in, M, blocks, pts, na, c, 1, 0, out, bf16, stream, &nh, point_dstats, x_cl);
+}
+extern "C" int epn_so3_basis_dstats_f32(const float *in, const float *M, const int32_t *blocks, long long pts, int na, int c,
+                                        float *out, const float *x_cl, const float *sums, int groups, long long pts_per_group,
+                                        const float *gamma, const float *beta, float eps, float slope, float *point_dstats,
+                                        epn_stream_t stream) {
+    return so3_basis_dstats_any(in, M, blocks, pts, na, c, out, x_cl, sums, groups, pts_per_group, gamma, beta, eps, slope,
+                                point_dstats, 0, stream);
+}
+extern "C" int epn_so3_basis_dstats_split_f32(const float *in, const float *M, const int32_t *blocks, long long pts, int na,
+                                              int c, float *out, const float *x_cl, const float *sums, int groups,
+                                              long long pts_per_group, const float *gamma, const float *beta, float eps,
+                                              float slope, float *point_dstats, epn_stream_t stream) {
+    return so3_basis_dstats_any(in, M, blocks, pts, na, c, out, x_cl, sums, groups, pts_per_group, gamma, beta, eps, slope,
+                                point_dstats, 2, stream);
+}
+extern "C" int epn_so3_basis_dstats_bf16(const void *in, const float *M, const int32_t *blocks, long long pts, int na, int c,
+                                         void *out, const void *x_cl, const float *sums, int groups, long long pts_per_group,
+                                         const float *gamma, const float *beta, float eps, float slope, float *point_dstats,
+                                         epn_stream_t stream) {
+    return so3_basis_dstats_any(in, M, blocks, pts, na, c, out, x_cl, sums, groups, pts_per_group, gamma, beta, eps, slope,
+                                point_dstats, 1, stream);
 }
 
 // leaky_relu(norm(in)) applied on load, then the change of basis (in plain layout only): sums[g][c] = (sum x, sum x^2)

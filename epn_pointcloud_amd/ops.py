@@ -107,7 +107,7 @@ def empty_cl(b, c, p, a, device, dtype=torch.float32):
 def _entry(lib, base, dtype):
     """C entry point of `base` for a feature dtype: epn_<base>_f32 | epn_<base>_bf16; the fp32 change of basis has a
     split form (bf16 matrix pipe, fp32 accuracy) that follows the GEMMs' switch (gemm.FP32_MODE)."""
-    if dtype != torch.bfloat16 and base in ("so3_basis", "so3_basis_norm", "so3_basis_stats") and gemm.FP32_MODE == "split":
+    if dtype != torch.bfloat16 and base in ("so3_basis", "so3_basis_norm", "so3_basis_stats", "so3_basis_dstats") and gemm.FP32_MODE == "split":
         return getattr(lib, f"epn_{base}_split_f32")
     return getattr(lib, f"epn_{base}_{'bf16' if dtype == torch.bfloat16 else 'f32'}")
 
@@ -1291,6 +1291,35 @@ class NormToSpectralFn(torch.autograd.Function):
         xc, sums, g, bt = ctx.saved_tensors
         groups, rows, c, eps, slope, has_cb, (b, _, p, na) = ctx.cfg
         gf = empty_cl(b, c, p, na, gy.device, xc.dtype)
+        fused = (os.environ.get("EPN_NORM_BWD_EPILOGUE", "1") == "1" and ctx.needs_input_grad[0]
+                 and xc.numel() * xc.element_size() < 0x7fffff00 and b * p < (1 << 24))
+        if fused:
+            # the norm's backward reduction from the accumulators of the inverse basis change that produces its output gradient
+            # (epn_so3_basis_dstats_*): no norm_act_bwd_reduce pass over x and dy
+            gyc = cast_feats(gy.contiguous(), xc.dtype)
+            pd = torch.empty((b * p, c, 2), dtype=torch.float32, device=gy.device)
+            fn = _entry(lib, "so3_basis_dstats", xc.dtype)
+            _lib.check(_launch("so3_basis", ("so3_basis", b * p, c), 2.0 * b * p * na * na * c, gy.device,
+                               lambda: fn(ctypes.c_void_p(gyc.data_ptr()), _lib.dev_ptr(ctx.basis.U, "M"),
+                                          _lib.dev_ptr(ctx.basis.blocks, "blocks", torch.int32), ctypes.c_longlong(b * p), na, c,
+                                          _cl_ptr(gf), _cl_ptr(xc), _lib.dev_ptr(sums, "sums"), groups, ctypes.c_longlong(p),
+                                          _lib.dev_ptr(g, "gamma"), _lib.dev_ptr(bt, "beta"), float(eps), float(slope),
+                                          pd.data_ptr(), _lib.stream_of(gf))), "so3_basis_dstats")
+            dsums = torch.empty_like(sums)
+            dg = torch.empty(c, dtype=torch.float32, device=gy.device) if g is not None else None
+            db = torch.empty(c, dtype=torch.float32, device=gy.device) if bt is not None else None
+            bpg = b * p // groups
+            ws = torch.empty(max(int(lib.epn_stats_finish_workspace_bytes(groups, bpg, c)), 16), dtype=torch.uint8, device=gy.device)
+            _lib.check(lib.epn_norm_bwd_finish(pd.data_ptr(), groups, ctypes.c_longlong(bpg), c, _lib.dev_ptr(g, "gamma"),
+                                               _lib.dev_ptr(dsums, "dsums"), _lib.dev_ptr(dg, "dgamma"), _lib.dev_ptr(db, "dbeta"),
+                                               ws.data_ptr(), ws.numel(), _lib.stream_of(gf)), "norm_bwd_finish")
+            dx = torch.empty_like(xc)
+            _lib.check(_entry(lib, "norm_act_bwd_apply", xc.dtype)(_cl_ptr(xc), _cl_ptr(gf), groups, rows, c,
+                                                                  _lib.dev_ptr(sums, "sums"), _lib.dev_ptr(dsums, "dsums"),
+                                                                  _lib.dev_ptr(g, "gamma"), _lib.dev_ptr(bt, "beta"), eps, slope,
+                                                                  _cl_ptr(dx), _lib.stream_of(gf)), "norm_act_bwd_apply")
+            dcb = torch.zeros(c, dtype=torch.float32, device=xc.device) if has_cb else None
+            return dx, dg, db, dcb, None, None, None, None, None
         _basis_call(lib, cast_feats(gy.contiguous(), xc.dtype), ctx.basis.U, ctx.basis, b * p, c, 1, 0, gf, "so3_basis")
         dx, dg, db = _norm_act_backward(xc, gf, sums, g, bt, groups, rows, c, eps, slope, ctx.needs_input_grad[0])
         dcb = torch.zeros(c, dtype=torch.float32, device=xc.device) if has_cb else None

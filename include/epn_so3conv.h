@@ -557,6 +557,28 @@ int epn_so3_basis_split_f32(const float *in, const float *M, const int32_t *bloc
 int epn_so3_basis_norm_split_f32(const float *in, const float *M, const int32_t *blocks, long long pts, int na, int c,
                                  int out_spectral, float *out, const float *sums, int groups, long long pts_per_group,
                                  const float *gamma, const float *beta, float eps, float slope, epn_stream_t stream);
+/* The backward reduction of the block's FIRST norm (InterSO3ConvBlock's norm + leaky_relu in front of IntraSO3Conv,
+ * SPConvNets/utils/base_so3conv.py:196-204) taken from the kernel that produces its output gradient: the inverse basis change
+ * of the spectral gradient writes dy (plain layout) AND, from its accumulators, per point the partial sums
+ *   point_dstats[pt][c][2] = (sum_a d, sum_a d * xhat),   d = dy * leaky'(norm(x)),  xhat = (x - mean) * rstd
+ * of the tensor x_cl the forward transform normalised (sums / groups / pts_per_group / gamma / beta / eps / slope as for
+ * epn_so3_basis_norm_*).  epn_norm_bwd_finish reduces block partials part[g][block][c][2] to the dsums[g][c][2], dgamma[c],
+ * dbeta[c] that epn_norm_act_bwd_apply_* takes (workspace: epn_stats_finish_workspace_bytes(groups, blocks_per_group, c));
+ * together they replace epn_norm_act_bwd_reduce_* (one full read of x and dy) for that norm.  Tensors of 2 GiB or more:
+ * EPN_EINVAL (keep the separate reduction). */
+int epn_so3_basis_dstats_f32(const float *in, const float *M, const int32_t *blocks, long long pts, int na, int c, float *out,
+                             const float *x_cl, const float *sums, int groups, long long pts_per_group, const float *gamma,
+                             const float *beta, float eps, float slope, float *point_dstats, epn_stream_t stream);
+int epn_so3_basis_dstats_split_f32(const float *in, const float *M, const int32_t *blocks, long long pts, int na, int c,
+                                   float *out, const float *x_cl, const float *sums, int groups, long long pts_per_group,
+                                   const float *gamma, const float *beta, float eps, float slope, float *point_dstats,
+                                   epn_stream_t stream);
+int epn_so3_basis_dstats_bf16(const void *in, const float *M, const int32_t *blocks, long long pts, int na, int c, void *out,
+                              const void *x_cl, const float *sums, int groups, long long pts_per_group, const float *gamma,
+                              const float *beta, float eps, float slope, float *point_dstats, epn_stream_t stream);
+int epn_norm_bwd_finish(const float *partials, int groups, long long blocks_per_group, int c, const float *gamma,
+                        float *dsums, float *dgamma, float *dbeta, void *workspace, size_t workspace_bytes,
+                        epn_stream_t stream);
 int epn_chan_stats_bf16(const void *x_cl, int groups, long long rows, int c, float *sums, void *workspace,
                         size_t workspace_bytes, epn_stream_t stream);
 int epn_norm_act_fwd_bf16(const void *x_cl, int groups, long long rows, int c, const float *sums, const float *gamma,

@@ -907,13 +907,19 @@ def test_conv1x1_single_input_channel(gpu, cout):
 
 @pytest.mark.parametrize("instance", [False, True])
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
-@pytest.mark.parametrize("c,p", [(64, 10), (32, 11)])        # c = 32: two points per task, odd point count (a tail lane)
-def test_norm_folded_into_basis_change(gpu, vgtk_alias, instance, dtype, c, p):
+@pytest.mark.parametrize("c,p", [(64, 10), (32, 11), (64, 700)])   # c = 32: two points per task, odd count; 2100 points: two-level finish
+@pytest.mark.parametrize("bwd_epilogue", ["1", "0"])
+def test_norm_folded_into_basis_change(gpu, vgtk_alias, monkeypatch, instance, dtype, c, p, bwd_epilogue):
     """intra_so3conv(x, pre_norm=norm) -- the block's first norm + leaky_relu applied as the basis change loads its rows
     (epn_so3_basis_norm_*) -- against intra_so3conv(norm_act(x, norm)): outputs, all gradients and BatchNorm's running
-    statistics (SPConvNets/utils/base_so3conv.py:196-204)."""
+    statistics (SPConvNets/utils/base_so3conv.py:196-204).  bwd_epilogue: the norm's backward reduction taken from the
+    accumulators of the inverse basis change that produces its output gradient (epn_so3_basis_dstats_* + epn_norm_bwd_finish;
+    round 4) or by the separate pass over x and dy -- same gradients for x, gamma and beta either way."""
     import copy
     import torch.nn as nn
+    monkeypatch.setenv("EPN_NORM_BWD_EPILOGUE", bwd_epilogue)
+    if p > 100 and (bwd_epilogue == "0" or dtype == torch.bfloat16):
+        pytest.skip("the large case exists for the two-level finish of the epilogue partials")
     from epn_pointcloud_amd import ops
     from epn_pointcloud_amd.vgtk.so3conv import functional as L
     torch.manual_seed(3)
