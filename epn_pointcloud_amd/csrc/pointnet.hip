@@ -178,10 +178,18 @@ __global__ __launch_bounds__(256) void pointnet_fwd_mfma_kernel(PnArgs A) {
                 Ws[ol * WLD + cl] = (cl < cc && o < A.co) ? A.W[(size_t)o * ce + c0 + cl] : 0.f;
             }
             __syncthreads();
+            // the feature fragments of step s + 1 are requested before the MFMAs of step s (round 4): loaded where they are
+            // used, every 16-channel step of every wave waited out an L2 / HBM round trip (64 steps per workgroup)
+            f32x4 afn[4];
+#pragma unroll
+            for (int mt = 0; mt < 4; ++mt) afn[mt] = *reinterpret_cast<const f32x4 *>(frow[mt] + c0);
             for (int s16 = 0; s16 < cc; s16 += 16) {
                 f32x4 af[4], bf[2];
 #pragma unroll
-                for (int mt = 0; mt < 4; ++mt) af[mt] = *reinterpret_cast<const f32x4 *>(frow[mt] + c0 + s16);
+                for (int mt = 0; mt < 4; ++mt) af[mt] = afn[mt];
+                const int sn = s16 + 16 < cc ? s16 + 16 : s16;               // last step re-reads its own fragment (unused)
+#pragma unroll
+                for (int mt = 0; mt < 4; ++mt) afn[mt] = *reinterpret_cast<const f32x4 *>(frow[mt] + c0 + sn);
 #pragma unroll
                 for (int nt = 0; nt < 2; ++nt)
                     bf[nt] = *reinterpret_cast<const f32x4 *>(Ws + (32 * wave + 16 * nt + x) * WLD + s16 + 4 * j);

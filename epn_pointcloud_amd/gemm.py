@@ -197,6 +197,7 @@ class MatmulNT(torch.autograd.Function):
     @staticmethod
     def forward(ctx, A, W, col_stats=False):
         from . import ops
+        ctx.set_materialize_grads(False)   # (C, part): no zero-filled gradient for the statistics partials
         Wc = W if W.dtype == A.dtype else cast(W, A.dtype)
         ctx.save_for_backward(A, W)
         M, K, N = A.shape[0], A.shape[1], W.shape[0]
@@ -211,6 +212,8 @@ class MatmulNT(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, dC, _dpart=None):
+        if dC is None:
+            return None, None, None
         A, W = ctx.saved_tensors
         dC = dC if dC.dtype == A.dtype else dC.to(A.dtype)
         from . import ops

@@ -876,6 +876,7 @@ class FromSpectralFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, y, basis, b, p, c, out_stats=False):
         lib = _lib.get_lib()
+        ctx.set_materialize_grads(False)   # else autograd zero-fills a gradient for every non-differentiable output, every step
         out = empty_cl(b, c, p, basis.na, y.device, y.dtype)
         ctx.basis, ctx.dims = basis, (b, c, p)
         if not out_stats:
@@ -895,6 +896,8 @@ class FromSpectralFn(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, gout, _gpart=None):
+        if gout is None:
+            return None, None, None, None, None, None
         lib = _lib.get_lib()
         b, c, p = ctx.dims
         g = to_cl(gout, "grad_out")
@@ -913,6 +916,7 @@ class SpectralWeightsFn(torch.autograd.Function):
     def forward(ctx, W, basis, cin, cout, bf16_ops=False):
         """Returns (whats fp32 x5 [differentiable], forward operands What^T x5, backward operands What x5): the operand sets
         are fp32 (the second = the differentiable blocks themselves) or, bf16_ops, bf16 copies written by the same kernel."""
+        ctx.set_materialize_grads(False)   # else autograd zero-fills a gradient for every non-differentiable output, every step
         lib = _lib.get_lib()
         Wc = W.contiguous()
         na, kn = basis.rho_all_t.shape
@@ -1079,6 +1083,7 @@ class NormActFn(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, x, gamma, beta, residual, conv_bias, instance, eps, slope):
+        ctx.set_materialize_grads(False)   # else autograd zero-fills a gradient for every non-differentiable output, every step
         lib = _lib.get_lib()
         xc = to_cl(x, "x")
         b, c, p, a = xc.shape
@@ -1101,6 +1106,8 @@ class NormActFn(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, grad_y, _grad_sums):
+        if grad_y is None:
+            return (None,) * 8
         xc, sums, g, bt = ctx.saved_tensors
         groups, rows, c, eps, slope, has_res, has_cb = ctx.cfg
         dy = cast_feats(to_cl(grad_y, "grad_y"), xc.dtype)
@@ -1128,6 +1135,7 @@ class NormActPairFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, xa, xb, gamma_a, beta_a, gamma_b, beta_b, conv_bias_b, inst_a, inst_b, eps_a, eps_b, slope,
                 part_b=None, part_a=None):
+        ctx.set_materialize_grads(False)   # else autograd zero-fills a gradient for every non-differentiable output, every step
         lib = _lib.get_lib()
         xac = to_cl(xa, "xa")
         xbc = to_cl(xb, "xb")
@@ -1151,6 +1159,8 @@ class NormActPairFn(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, grad_y, _ga, _gb):
+        if grad_y is None:
+            return (None,) * 14
         lib = _lib.get_lib()
         xac, xbc, sums_a, sums_b, ga, ba, gb, bb = ctx.saved_tensors
         b, rows, c, inst_a, inst_b, eps_a, eps_b, slope, has_cb = ctx.cfg
@@ -1264,6 +1274,7 @@ class NormToSpectralFn(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, x, gamma, beta, conv_bias, instance, eps, slope, basis, part=None):
+        ctx.set_materialize_grads(False)   # else autograd zero-fills a gradient for every non-differentiable output, every step
         lib = _lib.get_lib()
         xc = to_cl(x, "x")
         b, c, p, na = xc.shape
@@ -1287,6 +1298,8 @@ class NormToSpectralFn(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, gy, _grad_sums):
+        if gy is None:
+            return (None,) * 9
         lib = _lib.get_lib()
         xc, sums, g, bt = ctx.saved_tensors
         groups, rows, c, eps, slope, has_cb, (b, _, p, na) = ctx.cfg
