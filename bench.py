@@ -33,9 +33,16 @@ if ROOT not in sys.path:
 PEAK_TFLOPS = {"f32": 157.3, "bf16": 2500.0}
 HBM_PEAK_GBS = 8000.0
 
-PMC_FILE = os.path.join(ROOT, "profiles", "r03_pmc_per_kernel.json")   # tools/collect_profiles.sh + pmc_summary.py
+def _latest_profile(suffix):
+    """profiles/r0N_<suffix> of the latest round that committed one (tools/collect_round.sh)."""
+    import glob
+    found = sorted(glob.glob(os.path.join(ROOT, "profiles", "r0?_" + suffix)))
+    return found[-1] if found else os.path.join(ROOT, "profiles", "r04_" + suffix)
+
+
+PMC_FILE = _latest_profile("pmc_per_kernel.json")                        # tools/collect_profiles.sh + pmc_summary.py
 PMC_FILES = {"cls_f32": PMC_FILE,                                        # which committed pass profiled which workload
-             "reg_bf16": os.path.join(ROOT, "profiles", "r03_reg_bf16_pmc_per_kernel.json")}
+             "reg_bf16": _latest_profile("reg_bf16_pmc_per_kernel.json")}
 
 
 def recorded_traffic(kernel_family, pmc_file=PMC_FILE):

@@ -4,7 +4,7 @@
 #   per-replay kernel times (replay_profile.sh), and the bench lines of every configuration.
 # usage (GPU box): tools/collect_round.sh <tag>      -> gpurun_out/<tag>/...
 R=$(cd "$(dirname "$0")/.." && pwd)
-TAG=${1:-r03}
+TAG=${1:-r04}
 OUT=$R/gpurun_out/$TAG
 mkdir -p $OUT
 cd $R
@@ -13,19 +13,22 @@ EPN_BENCH_ARGS="--model reg --dtype bf16" bash tools/collect_profiles.sh ${TAG}_
 for f in kernel_stats.csv pmc_per_kernel.json bench_under_rocprof.json; do cp gpurun_out/${TAG}_reg/$f $OUT/reg_bf16_$f; done
 bash tools/replay_profile.sh ${TAG}_replay > $OUT/replay.log 2>&1
 cp gpurun_out/${TAG}_replay/per_replay.csv $OUT/per_replay_cls.csv
-python bench.py > $OUT/bench_cls.json 2> $OUT/bench_cls.err
-python bench.py --model reg --dtype bf16 --no-cpu-baseline --steps 20 > $OUT/bench_reg.json 2>/dev/null
-python bench.py --model inv --dtype bf16 --no-cpu-baseline --steps 20 > $OUT/bench_inv.json 2>/dev/null
-python bench.py --forward-only --no-cpu-baseline --steps 20 > $OUT/bench_cls_fwd.json 2>/dev/null
-python bench.py --model reg --dtype f32 --no-cpu-baseline > $OUT/bench_reg_f32.json 2>/dev/null
-python bench.py --dtype bf16 --no-cpu-baseline > $OUT/bench_cls_bf16.json 2>/dev/null
-EPN_GEMM_FP32=native python bench.py --no-cpu-baseline --no-native-line > $OUT/bench_cls_native_fp32_mfma.json 2>/dev/null
+# the driver's own command form first: ONE stdout line (< 3 KB) + the complete record in the detail file
+EPN_BENCH_DETAIL=$OUT/bench_cls_detail.json python bench.py --gpus 1 --steps 20 --warmup 5 > $OUT/bench_cls.json 2> $OUT/bench_cls.err
+b() { n=$1; shift; EPN_BENCH_DETAIL=$OUT/bench_${n}_detail.json python bench.py "$@" > $OUT/bench_$n.json 2>/dev/null; }
+b reg --model reg --dtype bf16 --no-cpu-baseline --steps 20
+b inv --model inv --dtype bf16 --no-cpu-baseline --steps 20
+b cls_fwd --forward-only --no-cpu-baseline --steps 20
+b reg_f32 --model reg --dtype f32 --no-cpu-baseline
+b cls_bf16 --dtype bf16 --no-cpu-baseline
+EPN_GEMM_FP32=native b cls_native_fp32_mfma --no-cpu-baseline --no-native-line
 (cd tools && python x3_probe.py 2>&1 | grep -v amdgpu.ids > $OUT/x3_probe.txt; python x3_err.py 2>&1 | grep -v amdgpu.ids > $OUT/x3_err.txt)
 python tools/gemm_bench.py > $OUT/gemm_bench_f32.txt 2>&1
 python tools/gemm_bench.py --dtype bf16 > $OUT/gemm_bench_bf16.txt 2>&1
 python tools/hbm_probe.py > $OUT/hbm_probe.txt 2>&1
+(cd tools && python nt_shortk_probe.py 2>&1 | grep -v amdgpu.ids > $OUT/nt_shortk_probe.txt; python nt_shortk_probe.py --bf16 2>&1 | grep -v amdgpu.ids >> $OUT/nt_shortk_probe.txt)
 rm -rf gpurun_out/${TAG}_reg gpurun_out/${TAG}_replay $OUT/pmc_*.log $OUT/stats.log
-for f in $OUT/bench_*.json; do python - <<PY
+for f in $(ls $OUT/bench_*.json | grep -v _detail); do python - <<PY
 import json
 d = json.loads(open("$f").read().strip().splitlines()[-1])
 r = d.get("roofline", {})
