@@ -57,12 +57,32 @@ __device__ __forceinline__ void group_column(const C1Args &A, long long col, flo
     const float *c = A.new_xyz + (size_t)bb * 3 * A.p2;
     const float cx = c[pp], cy = c[A.p2 + pp], cz = c[2 * A.p2 + pp];
     const float *f = A.feats + ((size_t)bb * A.p1) * A.na + a;
-    for (int n = 0; n < A.nn; ++n) {
-        const int q = row[n];
-        if (q < 0 || q >= A.p1) continue;   // shadow index: zero feature row (spconv/functional.py:91-95)
-        const float gx = s[q] - cx, gy = s[A.p1 + q] - cy, gz = s[2 * A.p1 + q] - cz;
+    // Neighbours in batches of four (round 4): index -> coordinates -> feature is a chain of dependent loads, and with one
+    // neighbour per iteration (and a `continue` the compiler cannot hoist loads across) every neighbour cost a full L2 / HBM
+    // round trip per wave -- at two or three waves per SIMD the K = 64 / 128 first layers of the rotation / 3DMatch networks
+    // were bound by that latency (1.0 / 1.75 ms), not by the 3.5 VALU instructions per weight.  A shadow index reads row 0
+    // with feature value 0 instead of being skipped: same sum.
+    constexpr int NB4 = 4;
+    for (int n0 = 0; n0 < A.nn; n0 += NB4) {
+        int qv[NB4];
+        bool okv[NB4];
+#pragma unroll
+        for (int u = 0; u < NB4; ++u) {
+            const int q = n0 + u < A.nn ? row[n0 + u] : -1;
+            okv[u] = q >= 0 && q < A.p1;       // shadow index: zero feature row (spconv/functional.py:91-95)
+            qv[u] = okv[u] ? q : 0;
+        }
+        float gxv[NB4], gyv[NB4], gzv[NB4], fvv[NB4];
+#pragma unroll
+        for (int u = 0; u < NB4; ++u) {
+            gxv[u] = s[qv[u]]; gyv[u] = s[A.p1 + qv[u]]; gzv[u] = s[2 * A.p1 + qv[u]];
+            fvv[u] = f[(size_t)qv[u] * A.na];
+        }
+#pragma unroll
+        for (int u = 0; u < NB4; ++u) {
+        const float gx = gxv[u] - cx, gy = gyv[u] - cy, gz = gzv[u] - cz;
         const float alpha = 1.0f - (gx * gx + gy * gy + gz * gz) * A.sigma_inv;
-        const float fv = f[(size_t)q * A.na];
+        const float fv = okv[u] ? fvv[u] : 0.0f;
         const f32x2_t a2 = {alpha, alpha}, gx2 = {gx, gx}, gy2 = {gy, gy}, gz2 = {gz, gz}, fv2 = {fv, fv};
 #pragma unroll
         for (int kp = 0; kp < KP; ++kp) {
@@ -77,6 +97,7 @@ __device__ __forceinline__ void group_column(const C1Args &A, long long col, flo
                 const f32x2_t w = {__int_as_float(s0 > 0 ? s0 : 0), __int_as_float(s1 > 0 ? s1 : 0)};
                 g2[kp] = g2[kp] + fv2 * w;
             }
+        }
         }
     }
 #pragma unroll
