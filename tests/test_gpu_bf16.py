@@ -348,7 +348,14 @@ def test_config_full_size_bf16(gpu, model, points, batch):
         for p in net.parameters():
             p.grad = None
         out = net(inp)
-        loss = out[0].float().square().mean() + (out[1].float().square().mean() if model == "reg" else 0.0)
+        if model == "reg":
+            loss = out[0].float().square().mean() + out[1].float().square().mean()
+        else:                                   # descriptors are unit vectors (their squared mean is a constant, and the pairwise
+            # products bench.py pushes apart are small differences: a 0.4 % output error reads as 19 % of that loss's gradient):
+            # a fixed random linear functional of the descriptors is the well-conditioned probe of the backward pass
+            gen = torch.Generator(device="cpu").manual_seed(5)
+            probe = torch.randn(out[0].shape, generator=gen).to(out[0].device)
+            loss = (out[0].float() * probe).sum()
         loss.backward()
         feats = out[0].detach().float().cpu()
         g = torch.cat([p.grad.flatten().float().cpu() for p in net.parameters() if p.grad is not None])
@@ -358,9 +365,20 @@ def test_config_full_size_bf16(gpu, model, points, batch):
     S.set_feature_dtype(net, torch.bfloat16)
     l16, f16, g16 = run()
     assert np.isfinite(l16) and torch.isfinite(f16).all() and torch.isfinite(g16).all()
-    # 7-8 blocks deep, each rounding its activations to 8 bits: a few percent at the output
-    assert abs(l16 - l32) <= 0.1 * abs(l32) + 1e-6
-    assert rel_l2(f16, f32) < 0.15
+    dl, df, dg = abs(l16 - l32) / abs(l32), rel_l2(f16, f32), rel_l2(g16, g32)
+    print(f"{model}: bf16 vs fp32 network: loss {dl:.4f}, output rel-L2 {df:.4f}, gradient rel-L2 {dg:.4f}")
+    # 7-8 blocks deep, each rounding its activations to 8 bits.  Measured (round 4): rotation network loss 3e-5, output
+    # rel-L2 1.1e-3, all parameter gradients together rel-L2 8.4e-3; 3DMatch output 3.9e-3.  Round 3 asserted 10 % / 15 % --
+    # loose enough to hide a wrong layer (review); the bounds below are ~5x what is measured, and the GRADIENT is checked too.
+    assert dl <= 0.01
+    assert df < 0.02
+    # gradients: the rotation network's are well conditioned (8.4e-3 measured).  The 3DMatch head is not: softmax over raw
+    # attention logits -> max over 64 points -> L2 normalisation.  Control (tools/scratch/inv_grad_dbg.py): the FP32 network with
+    # only the head's INPUT rounded to bf16 (output moves by 2.7e-4) already moves every backbone gradient by 3 % and the
+    # head's by 2-5 %; the bf16 backbone moves the head's input 14x more (3.9e-3) and the gradients by 13-27 %, growing
+    # smoothly from the head towards the first block.  The per-layer B = 64 slices against the oracle
+    # (test_gpu_fullsize.py) are what pins the backward kernels; here the bound only has to catch a broken layer.
+    assert dg < (0.05 if model == "reg" else 0.40)
 
 
 @pytest.mark.parametrize("b,p1,p2,nn", [(3, 300, 150, 20), (2, 1024, 1024, 32), (2, 4096, 40, 16), (2, 700, 1100, 32)])
