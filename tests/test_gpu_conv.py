@@ -745,7 +745,7 @@ def test_so3_basis_kernel_and_block_layout(gpu, vgtk_alias):
 
 
 @pytest.mark.parametrize("dt,mode", [("f32", "split"), ("f32", "native"), ("bf16", "split")])
-@pytest.mark.parametrize("c,pts", [(32, 70), (32, 71), (96, 33), (64, 140000), (64, 280000)])
+@pytest.mark.parametrize("c,pts", [(32, 70), (32, 71), (96, 33), (64, 20000), (32, 16385), (64, 140000), (64, 280000)])
 def test_so3_basis_row_addressing_both_forms(gpu, vgtk_alias, monkeypatch, dt, mode, c, pts):
     """The basis-change kernels address their rows with 32-bit offsets + buffer instructions when the tensor is below 2 GiB
     (one multiply-add per row from two LDS tables; rows >= na and lanes without channels read zeros / are dropped by the
@@ -763,7 +763,10 @@ def test_so3_basis_row_addressing_both_forms(gpu, vgtk_alias, monkeypatch, dt, m
     x = torch.randn(1, c, pts, 60, device=gpu).to(dtype).contiguous(memory_format=torch.channels_last)
     y = ops.ToSpectralFn.apply(x, basis)
     tol = 3e-2 if dt == "bf16" else 1e-4
-    sel = torch.cat([torch.arange(0, min(pts, 40)), torch.arange(max(pts - 40, 0), pts)]).unique().to(gpu)
+    # every point up to 20 000 of them (a store hazard of round 4 corrupted ~0.3 % of the rows, and only beyond the first
+    # ~2000: a sample would not see it); first and last 40 of the 2 GB tensors
+    sel = (torch.arange(pts) if pts <= 20000 else
+           torch.cat([torch.arange(0, 40), torch.arange(pts - 40, pts)])).to(gpu)
     rows = x.permute(0, 2, 3, 1).reshape(pts, 60, c)[sel].float()
     want = torch.einsum('af,qac->qfc', basis.U, rows)
     for d, base in zip(basis.dims, basis.bases):
