@@ -15,6 +15,7 @@ LIB_PATH = os.environ.get("EPN_LIB", os.path.join(_PKG, "libepn_so3conv.so"))   
 EXPORTS = [
     "epn_version", "epn_strerror", "epn_set_kernel_policy",
     "epn_ball_query_f32", "epn_fps_f32", "epn_gather_fwd_f32", "epn_gather_bwd_f32", "epn_initial_anchor_query_f32",
+    "epn_initial_anchor_query_f64", "epn_anchor_query_f64",
     "epn_inter_workspace_bytes", "epn_inter_is_fused", "epn_inter_so3conv_fwd_f32",
     "epn_inter_so3conv_bwd_data_f32", "epn_inter_so3conv_bwd_weight_f32", "epn_inter_weights_f32",
     "epn_intra_workspace_bytes", "epn_intra_is_fused", "epn_intra_so3conv_fwd_f32",
@@ -93,6 +94,7 @@ def get_lib():
     lib.epn_ball_query_f32.argtypes = [_vp, _vp, _ci, _ci, _ci, _cf, _ci, _vp, _vp]
     lib.epn_fps_f32.argtypes = [_vp, _ci, _ci, _ci, _vp, _vp]
     lib.epn_initial_anchor_query_f32.argtypes = [_vp, _vp, _vp, _ci, _ci, _ci, _ci, _ci, _cf, _cf, _vp, _vp, _vp]
+    lib.epn_initial_anchor_query_f64.argtypes = lib.epn_initial_anchor_query_f32.argtypes
     lib.epn_gather_fwd_f32.argtypes = [_vp, _vp, _ci, _ci, _ci, _ci, _vp, _vp]
     lib.epn_gather_bwd_f32.argtypes = [_vp, _vp, _ci, _ci, _ci, _ci, _vp, _vp]
     lib.epn_ball_query_f64.argtypes = [_vp, _vp, _ci, _ci, _ci, ctypes.c_float, _ci, _vp, _vp]
@@ -157,6 +159,7 @@ def get_lib():
     for _n in ("epn_zp_inter_fwd_f32", "epn_zp_inter_bwd_f32", "epn_zp_intra_fwd_f32", "epn_zp_intra_bwd_f32"):
         getattr(lib, _n).argtypes = [_vp, _vp, _vp, _ci, _ci, _ci, _ci, _ci, _ci, _ci, _vp, _vp]
     lib.epn_anchor_query_f32.argtypes = [_vp, _vp, _vp, _ci, _ci, _ci, _ci, _ci, _vp, _vp]
+    lib.epn_anchor_query_f64.argtypes = lib.epn_anchor_query_f32.argtypes
     lib.epn_so3_basis_f32.argtypes = [_vp, _vp, _vp, ctypes.c_longlong, _ci, _ci, _ci, _ci, _vp, _vp]
     lib.epn_so3_basis_norm_f32.argtypes = [_vp, _vp, _vp, ctypes.c_longlong, _ci, _ci, _ci, _vp, _vp, _ci, ctypes.c_longlong,
                                            _vp, _vp, _cf, _cf, _vp]

@@ -437,37 +437,42 @@ namespace {
 constexpr int AQ_T = 256;
 constexpr int AQ_OUT = 8;      // outputs per thread: ks*na <= AQ_T*AQ_OUT (24*60 = 1440)
 
-__global__ __launch_bounds__(AQ_T) void initial_anchor_query_kernel(const float *__restrict__ centers,
-                                                                    const float *__restrict__ xyz,
-                                                                    const float *__restrict__ kp, int nc, int m,
+__device__ __forceinline__ float aq_sqrt(float v) { return sqrtf(v); }
+__device__ __forceinline__ double aq_sqrt(double v) { return sqrt(v); }
+
+template <typename T>   // float, or double (AT_DISPATCH_FLOATING_TYPES on xyz.type(), grouping_cuda_kernel.cu:558-563); radius and
+// sigma stay FLOAT kernel parameters in either instantiation, as in the reference (:127-128)
+__global__ __launch_bounds__(AQ_T) void initial_anchor_query_kernel(const T *__restrict__ centers,
+                                                                    const T *__restrict__ xyz,
+                                                                    const T *__restrict__ kp, int nc, int m,
                                                                     int na, int ks, float radius, float sigma,
-                                                                    float *__restrict__ wts, float *__restrict__ cnt) {
-    __shared__ float lst[AQ_T][3];
+                                                                    T *__restrict__ wts, T *__restrict__ cnt) {
+    __shared__ T lst[AQ_T][3];
     __shared__ int wcount[AQ_T / 64];
     const int pn = blockIdx.x, bn = blockIdx.y, t = threadIdx.x;
     const int lane = t & 63, wave = t >> 6;
-    const float *c = centers + (size_t)bn * 3 * nc;
-    const float cx = c[pn], cy = c[nc + pn], cz = c[2 * nc + pn];
+    const T *c = centers + (size_t)bn * 3 * nc;
+    const T cx = c[pn], cy = c[nc + pn], cz = c[2 * nc + pn];
     const int nout = ks * na;
-    float kx[AQ_OUT], ky[AQ_OUT], kz[AQ_OUT], acc[AQ_OUT];
+    T kx[AQ_OUT], ky[AQ_OUT], kz[AQ_OUT], acc[AQ_OUT];
 #pragma unroll
     for (int u = 0; u < AQ_OUT; ++u) {
         const int o = t + AQ_T * u;                  // o = kn * na + an
         const bool ok = o < nout;
-        kx[u] = ok ? kp[(size_t)o * 3] + cx : 0.f;
-        ky[u] = ok ? kp[(size_t)o * 3 + 1] + cy : 0.f;
-        kz[u] = ok ? kp[(size_t)o * 3 + 2] + cz : 0.f;
-        acc[u] = 0.f;
+        kx[u] = ok ? kp[(size_t)o * 3] + cx : (T)0;
+        ky[u] = ok ? kp[(size_t)o * 3 + 1] + cy : (T)0;
+        kz[u] = ok ? kp[(size_t)o * 3 + 2] + cz : (T)0;
+        acc[u] = (T)0;
     }
     int total = 0;
     for (int m0 = 0; m0 < m; m0 += AQ_T) {
         const int pm = m0 + t;
-        float x = 0.f, y = 0.f, z = 0.f;
+        T x = 0, y = 0, z = 0;
         bool in = false;
         if (pm < m) {
             x = xyz[(size_t)3 * pm]; y = xyz[(size_t)3 * pm + 1]; z = xyz[(size_t)3 * pm + 2];
-            const float dx = cx - x, dy = cy - y, dz = cz - z;
-            in = sqrtf(dx * dx + dy * dy + dz * dz) <= radius;
+            const T dx = cx - x, dy = cy - y, dz = cz - z;
+            in = aq_sqrt(dx * dx + dy * dy + dz * dz) <= (T)radius;
         }
         const unsigned long long bal = __ballot(in);
         if (lane == 0) wcount[wave] = __popcll(bal);
@@ -484,13 +489,13 @@ __global__ __launch_bounds__(AQ_T) void initial_anchor_query_kernel(const float 
         }
         __syncthreads();
         for (int i = 0; i < n_in; ++i) {
-            const float px = lst[i][0], py = lst[i][1], pz = lst[i][2];   // LDS broadcast
+            const T px = lst[i][0], py = lst[i][1], pz = lst[i][2];   // LDS broadcast
 #pragma unroll
             for (int u = 0; u < AQ_OUT; ++u) {
-                const float dx = kx[u] - px, dy = ky[u] - py, dz = kz[u] - pz;
-                const float d = sqrtf(dx * dx + dy * dy + dz * dz);     // as written in the reference: sqrt, then square
-                const float w = 1.0f - d * d / sigma;
-                acc[u] += w > 0.0f ? w : 0.0f;
+                const T dx = kx[u] - px, dy = ky[u] - py, dz = kz[u] - pz;
+                const T d = aq_sqrt(dx * dx + dy * dy + dz * dz);     // as written in the reference: sqrt, then square
+                const T w = (T)1 - d * d / (T)sigma;
+                acc[u] += w > (T)0 ? w : (T)0;
             }
         }
         total += n_in;
@@ -503,7 +508,7 @@ __global__ __launch_bounds__(AQ_T) void initial_anchor_query_kernel(const float 
             const int kn = o / na, an = o - kn * na;
             const size_t at = (((size_t)bn * ks + kn) * nc + pn) * na + an;
             wts[at] = acc[u];
-            cnt[at] = (float)total;
+            cnt[at] = (T)total;
         }
     }
 }
@@ -517,7 +522,20 @@ extern "C" int epn_initial_anchor_query_f32(const float *centers, const float *x
     if ((long long)ks * na > (long long)AQ_T * AQ_OUT) return EPN_EINVAL;
     if (b == 0 || nc == 0) return 0;
     if (!centers || !kernel_points || !anchor_weights || !anchor_ctn || (m > 0 && !xyz)) return EPN_ENULL;
-    EPN_LAUNCH(initial_anchor_query_kernel, dim3((unsigned)nc, (unsigned)b), dim3(AQ_T), 0, epn_stream(stream),
+    EPN_LAUNCH(initial_anchor_query_kernel<float>, dim3((unsigned)nc, (unsigned)b), dim3(AQ_T), 0, epn_stream(stream),
+                       centers, xyz, kernel_points, nc, m, na, ks, radius, sigma, anchor_weights, anchor_ctn);
+    EPN_CHECK_LAUNCH();
+    return 0;
+}
+
+extern "C" int epn_initial_anchor_query_f64(const double *centers, const double *xyz, const double *kernel_points, int b,
+                                            int nc, int m, int na, int ks, float radius, float sigma,
+                                            double *anchor_weights, double *anchor_ctn, epn_stream_t stream) {
+    if (b < 0 || nc < 0 || m < 0 || na < 1 || ks < 1 || !(sigma > 0.f)) return EPN_EINVAL;
+    if ((long long)ks * na > (long long)AQ_T * AQ_OUT) return EPN_EINVAL;
+    if (b == 0 || nc == 0) return 0;
+    if (!centers || !kernel_points || !anchor_weights || !anchor_ctn || (m > 0 && !xyz)) return EPN_ENULL;
+    EPN_LAUNCH(initial_anchor_query_kernel<double>, dim3((unsigned)nc, (unsigned)b), dim3(AQ_T), 0, epn_stream(stream),
                        centers, xyz, kernel_points, nc, m, na, ks, radius, sigma, anchor_weights, anchor_ctn);
     EPN_CHECK_LAUNCH();
     return 0;

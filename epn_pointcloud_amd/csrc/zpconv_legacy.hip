@@ -165,8 +165,14 @@ extern "C" int epn_zp_intra_bwd_f32(const int32_t *anchor_neighbors, const float
 // part of the reference signature but unused by its kernel, and so here.
 namespace epn {
 namespace {
-__global__ void anchor_query_kernel(const float *__restrict__ gxyz, const float *__restrict__ anchors,
-                                    const float *__restrict__ kp, float *__restrict__ w, int b, int np, int nn, int na,
+__device__ __forceinline__ float aq_sqrt(float v) { return sqrtf(v); }
+__device__ __forceinline__ double aq_sqrt(double v) { return sqrt(v); }
+__device__ __forceinline__ float aq_acos(float v) { return acosf(v); }
+__device__ __forceinline__ double aq_acos(double v) { return acos(v); }
+
+template <typename T>   // float / double (AT_DISPATCH_FLOATING_TYPES, grouping_cuda_kernel.cu:505-510)
+__global__ void anchor_query_kernel(const T *__restrict__ gxyz, const T *__restrict__ anchors,
+                                    const T *__restrict__ kp, T *__restrict__ w, int b, int np, int nn, int na,
                                     int ks) {
     const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     const long long per_b = (long long)np * nn;
@@ -175,14 +181,16 @@ __global__ void anchor_query_kernel(const float *__restrict__ gxyz, const float 
     const long long r = i - (long long)bi * per_b;       // p*nn + n
     const long long pi = r / nn;
     const int ni = (int)(r - pi * nn);
-    const float *g = gxyz + (size_t)bi * 3 * per_b;
-    const float x = g[r], y = g[per_b + r], z = g[2 * per_b + r];
-    const float norm = sqrtf(x * x + y * y + z * z) + 1e-6f;
-    float *o = w + (((size_t)bi * np + pi) * na) * ks * nn + ni;
+    const T *g = gxyz + (size_t)bi * 3 * per_b;
+    const T x = g[r], y = g[per_b + r], z = g[2 * per_b + r];
+    // `scalar_t norm = sqrt(x*x + y*y + z*z) + 1e-6;` (:221): the literal is a DOUBLE -- with scalar_t = float the sum is
+    // formed in double and rounded once on assignment (not a float add of 1e-6f: the two differ in the last bit at times)
+    const T norm = (T)((double)aq_sqrt(x * x + y * y + z * z) + 1e-6);
+    T *o = w + (((size_t)bi * np + pi) * na) * ks * nn + ni;
     for (int a = 0; a < na; ++a) {
-        const float theta = acosf((x * anchors[3 * a] + y * anchors[3 * a + 1] + z * anchors[3 * a + 2]) / norm);
+        const T theta = aq_acos((x * anchors[3 * a] + y * anchors[3 * a + 1] + z * anchors[3 * a + 2]) / norm);
         for (int k = 0; k < ks; ++k) {
-            const float d0 = kp[2 * k] - norm, d1 = (kp[2 * k + 1] - theta) * norm;
+            const T d0 = kp[2 * k] - norm, d1 = (kp[2 * k + 1] - theta) * norm;
             o[((size_t)a * ks + k) * nn] = d0 * d0 + d1 * d1;
         }
     }
@@ -196,7 +204,19 @@ extern "C" int epn_anchor_query_f32(const float *grouped_xyz, const float *ancho
     const long long total = (long long)b * np * nn;
     if (total == 0) return 0;
     if (!grouped_xyz || !anchors || !kernel_points || !anchor_weights) return EPN_ENULL;
-    EPN_LAUNCH(epn::anchor_query_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, epn_stream(stream),
+    EPN_LAUNCH(epn::anchor_query_kernel<float>, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, epn_stream(stream),
+                       grouped_xyz, anchors, kernel_points, anchor_weights, b, np, nn, na, ks);
+    EPN_CHECK_LAUNCH();
+    return 0;
+}
+
+extern "C" int epn_anchor_query_f64(const double *grouped_xyz, const double *anchors, const double *kernel_points, int b,
+                                    int np, int nn, int na, int ks, double *anchor_weights, epn_stream_t stream) {
+    if (b < 0 || np < 0 || nn < 1 || na < 1 || ks < 1) return EPN_EINVAL;
+    const long long total = (long long)b * np * nn;
+    if (total == 0) return 0;
+    if (!grouped_xyz || !anchors || !kernel_points || !anchor_weights) return EPN_ENULL;
+    EPN_LAUNCH(epn::anchor_query_kernel<double>, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, epn_stream(stream),
                        grouped_xyz, anchors, kernel_points, anchor_weights, b, np, nn, na, ks);
     EPN_CHECK_LAUNCH();
     return 0;

@@ -246,6 +246,12 @@ int epn_norm_act_pair_bwd_apply(const void *xa_cl, const void *xb_cl, const void
 int epn_initial_anchor_query_f32(const float *centers, const float *xyz, const float *kernel_points, int b, int nc,
                                  int m, int na, int ks, float radius, float sigma, float *anchor_weights,
                                  float *anchor_ctn, epn_stream_t stream);
+/* the scalar_t = double instantiation of the same kernel (AT_DISPATCH_FLOATING_TYPES on xyz.type(),
+ * grouping_cuda_kernel.cu:558-563; outputs take the inputs' dtype, grouping_cuda.cpp:149-154).  radius and sigma stay
+ * FLOAT parameters as in the reference (:127-128) and are widened where they meet a double. */
+int epn_initial_anchor_query_f64(const double *centers, const double *xyz, const double *kernel_points, int b, int nc,
+                                 int m, int na, int ks, float radius, float sigma, double *anchor_weights,
+                                 double *anchor_ctn, epn_stream_t stream);
 
 /* InterSO3Conv with the grouped features kept ON CHIP (north_star: "the [B,N,K,A,C] tile staged through LDS"): the same
  * result as epn_inter_so3conv_fwd_f32 -- vgtk/vgtk/so3conv/modules.py:157-174 = inter_so3conv_grouping
@@ -439,6 +445,11 @@ int epn_pointnet_so3conv_bwd_weight_f32(const float *grad_out, const int32_t *ar
  * The reference's sample_idx / grouped_indices / nq arguments are unused by its kernel and not part of this entry. */
 int epn_anchor_query_f32(const float *grouped_xyz, const float *anchors, const float *kernel_points, int b, int np,
                          int nn, int na, int ks, float *anchor_weights, epn_stream_t stream);
+/* scalar_t = double (grouping_cuda_kernel.cu:505-510; the output takes grouped_xyz's dtype, grouping_cuda.cpp:103-104).
+ * In BOTH instantiations `+ 1e-6` adds a double literal (:221): the f32 entry forms |g| + 1e-6 in double and rounds
+ * once. */
+int epn_anchor_query_f64(const double *grouped_xyz, const double *anchors, const double *kernel_points, int b, int np,
+                         int nn, int na, int ks, double *anchor_weights, epn_stream_t stream);
 int epn_zp_inter_fwd_f32(const int32_t *anchor_neighbors, const float *anchor_weights, const float *feats, int b, int c,
                          int np, int nq, int na, int ks, int ann, float *anchor_feats, epn_stream_t stream);
 int epn_zp_inter_bwd_f32(const int32_t *anchor_neighbors, const float *anchor_weights, const float *grad_anchor_feats,

@@ -310,3 +310,32 @@ void epn_oracle_gather_bwd_f64(const double *grad_out, const int32_t *idx, int b
                 grad_points[((size_t)bi * c + ci) * n + idx[(size_t)bi * m + j]] +=
                     grad_out[((size_t)bi * c + ci) * m + j];
 }
+
+/* initial_anchor_query with scalar_t = double (dispatch grouping_cuda_kernel.cu:558-563); radius / sigma are float kernel
+ * parameters in both instantiations (:127-128) and are widened at the comparison / division. */
+void epn_oracle_initial_anchor_query_f64(const double *centers, const double *xyz, const double *kp, int b, int nc, int m,
+                                         int na, int ks, float radius, float sigma, double *wts, double *ctn) {
+    memset(wts, 0, sizeof(double) * (size_t)b * ks * nc * na);
+    memset(ctn, 0, sizeof(double) * (size_t)b * ks * nc * na);
+    for (int bn = 0; bn < b; ++bn) {
+        const double *c = centers + (size_t)bn * 3 * nc;
+        for (int pn = 0; pn < nc; ++pn) {
+            const double cx = c[pn], cy = c[nc + pn], cz = c[2 * nc + pn];
+            for (int pm = 0; pm < m; ++pm) {
+                const double x = xyz[3 * pm], y = xyz[3 * pm + 1], z = xyz[3 * pm + 2];
+                const double d2c = sqrt((cx - x) * (cx - x) + (cy - y) * (cy - y) + (cz - z) * (cz - z));
+                if (!(d2c <= (double)radius)) continue;
+                for (int kn = 0; kn < ks; ++kn)
+                    for (int an = 0; an < na; ++an) {
+                        const double kx = kp[(kn * na + an) * 3] + cx, ky = kp[(kn * na + an) * 3 + 1] + cy,
+                                     kz = kp[(kn * na + an) * 3 + 2] + cz;
+                        const double d = sqrt((kx - x) * (kx - x) + (ky - y) * (ky - y) + (kz - z) * (kz - z));
+                        const double w = 1.0 - (d * d / (double)sigma);
+                        const size_t at = (((size_t)bn * ks + kn) * nc + pn) * na + an;
+                        if (w > 0.0) wts[at] += w;
+                        ctn[at] += 1.0;
+                    }
+            }
+        }
+    }
+}

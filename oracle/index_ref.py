@@ -58,6 +58,8 @@ def _load():
         lib.epn_oracle_fps_f64.argtypes = [f64p, ci, ci, ci, f64p, i32p]
         lib.epn_oracle_gather_fwd_f64.argtypes = [f64p, i32p, ci, ci, ci, ci, f64p]
         lib.epn_oracle_gather_bwd_f64.argtypes = [f64p, i32p, ci, ci, ci, ci, f64p]
+        lib.epn_oracle_initial_anchor_query_f64.argtypes = [f64p, f64p, f64p, ci, ci, ci, ci, ci, ctypes.c_float,
+                                                            ctypes.c_float, f64p, f64p]
         lib.epn_oracle_set_sq3_order.argtypes = [ci]
         lib.epn_oracle_opt_n_threads.argtypes = [ci]
         lib.epn_oracle_opt_n_threads.restype = ci
@@ -178,6 +180,16 @@ def initial_anchor_query(centers, xyz, kernel_points, radius, sigma):
     b, _, nc = centers.shape
     m = xyz.shape[0]
     ks, na = kernel_points.shape[0], kernel_points.shape[1]
+    if _is64(xyz):                       # dispatch on xyz.type(), grouping_cuda_kernel.cu:558
+        ca, cp = _f64(centers)
+        xa, xp = _f64(xyz)
+        ka, kpp = _f64(kernel_points)
+        w = np.zeros((b, ks, nc, na), dtype=np.float64)
+        c = np.zeros((b, ks, nc, na), dtype=np.float64)
+        f64p = ctypes.POINTER(ctypes.c_double)
+        lib.epn_oracle_initial_anchor_query_f64(cp, xp, kpp, b, nc, m, na, ks, float(radius), float(sigma),
+                                                w.ctypes.data_as(f64p), c.ctypes.data_as(f64p))
+        return [torch.from_numpy(w), torch.from_numpy(c)]
     ca, cp = _f32(centers)
     xa, xp = _f32(xyz)
     ka, kpp = _f32(kernel_points)
@@ -194,16 +206,19 @@ def opt_n_threads(work_size):
 
 
 def anchor_query(sample_idx, grouped_indices, grouped_xyz, anchors, kernel_points, nq):
-    """vgtk.cuda.grouping.anchor_query restated in numpy float32 (grouping_cuda.cpp:88-108, kernel
-    grouping_cuda_kernel.cu:180-247): w[b,p,a,k,n] = (kw - norm)^2 + ((kh - theta) norm)^2 with
-    norm = |g| + 1e-6, theta = acos(g . anchor_a / norm).  Elementwise float arithmetic (sqrt, acos): the HIP kernel is
-    compared within 1e-5, not bit-exactly.  sample_idx / grouped_indices / nq are unused by the reference kernel."""
-    g = grouped_xyz.detach().cpu().numpy().astype(np.float32)                    # [b,3,p,nn]
-    A = anchors.detach().cpu().numpy().astype(np.float32)                        # [na,3]
-    K = kernel_points.detach().cpu().numpy().astype(np.float32)                  # [ks,2]
-    norm = (np.sqrt((g * g).sum(1)) + np.float32(1e-6)).astype(np.float32)       # [b,p,nn]
-    dot = np.einsum('bcpn,ac->bpan', g, A).astype(np.float32)                    # [b,p,na,nn]
-    theta = np.arccos(np.clip(dot / norm[:, :, None, :], -1.0, 1.0)).astype(np.float32)
+    """vgtk.cuda.grouping.anchor_query restated in numpy, float32 or float64 after grouped_xyz (grouping_cuda.cpp:88-108,
+    kernel grouping_cuda_kernel.cu:180-247, dispatch :505-510): w[b,p,a,k,n] = (kw - norm)^2 + ((kh - theta) norm)^2
+    with norm = |g| + 1e-6, theta = acos(g . anchor_a / norm).  `+ 1e-6` is a DOUBLE literal in the reference (:221), so
+    the float instantiation forms the sum in double and rounds once.  Elementwise float arithmetic (sqrt, acos): the HIP
+    kernel is compared within a few ulp, not bit-exactly.  sample_idx / grouped_indices / nq are unused by the reference
+    kernel."""
+    T = np.float64 if _is64(grouped_xyz) else np.float32
+    g = grouped_xyz.detach().cpu().numpy().astype(T)                             # [b,3,p,nn]
+    A = anchors.detach().cpu().numpy().astype(T)                                 # [na,3]
+    K = kernel_points.detach().cpu().numpy().astype(T)                           # [ks,2]
+    norm = (np.sqrt((g * g).sum(1)).astype(np.float64) + 1e-6).astype(T)         # [b,p,nn]
+    dot = np.einsum('bcpn,ac->bpan', g, A).astype(T)                             # [b,p,na,nn]
+    theta = np.arccos(np.clip(dot / norm[:, :, None, :], -1.0, 1.0)).astype(T)
     d0 = K[None, None, None, :, 0, None] - norm[:, :, None, None, :]             # [b,p,1,ks,nn]
     d1 = (K[None, None, None, :, 1, None] - theta[:, :, :, None, :]) * norm[:, :, None, None, :]
-    return [torch.from_numpy((d0 * d0 + d1 * d1).astype(np.float32))]
+    return [torch.from_numpy((d0 * d0 + d1 * d1).astype(T))]

@@ -142,6 +142,30 @@ def test_initial_anchor_query_vs_oracle(gpu, vgtk_alias, b, nc, m, na, ks, radiu
     assert (w.cpu() - w_ref).abs().max().item() <= 1e-5 * max(1.0, w_ref.abs().max().item())
 
 
+@pytest.mark.parametrize("b,nc,m,na,ks,radius,sigma", [(2, 16, 500, 60, 24, 0.4, 0.08), (1, 5, 1, 12, 24, 0.3, 0.05),
+                                                        (3, 7, 777, 60, 13, 0.25, 0.03)])
+def test_initial_anchor_query_f64_vs_oracle(gpu, vgtk_alias, b, nc, m, na, ks, radius, sigma):
+    """The scalar_t = double instantiation (dispatch grouping_cuda_kernel.cu:558-563): outputs are float64, counts
+    exact, weights to fp64 rounding of the summation order.  radius / sigma are FLOAT parameters in the reference: a
+    fragment point placed between float(radius) and the double value of the same literal tells the two apart."""
+    import vgtk.cuda.grouping as cuda_nn
+    from oracle import index_ref
+    rng = np.random.default_rng(m + nc + 1)
+    centers = torch.from_numpy(unit_ball_cloud(rng, b, nc).astype(np.float64))
+    frag = torch.from_numpy(rng.uniform(-0.6, 0.6, (m, 3)))
+    # float(0.4) = 0.4000000059604645 > 0.4: this point is inside only when the radius is the float value
+    frag[0] = centers[0, :, 0] + torch.tensor([0.5 * (float(np.float32(radius)) + radius), 0.0, 0.0], dtype=torch.float64)
+    kp = torch.from_numpy(rng.standard_normal((ks, na, 3)) * 0.2)
+    w_ref, c_ref = index_ref.initial_anchor_query(centers, frag, kp, radius, sigma)
+    w, c = cuda_nn.initial_anchor_query(centers.to(gpu), frag.to(gpu), kp.to(gpu), radius, sigma)
+    assert w.dtype == torch.float64 and c.dtype == torch.float64
+    assert torch.equal(c.cpu(), c_ref)
+    assert (w.cpu() - w_ref).abs().max().item() <= 1e-13 * max(1.0, w_ref.abs().max().item())
+    # and it differs from the float32 run beyond float rounding somewhere (the f64 entry is not the f32 one widened)
+    w32, _ = cuda_nn.initial_anchor_query(centers.float().to(gpu), frag.float().to(gpu), kp.float().to(gpu), radius, sigma)
+    assert w32.dtype == torch.float32
+
+
 def test_kernel_propagation_module(gpu, vgtk_alias):
     """KernelPropagation.forward (vgtk/vgtk/so3conv/modules.py:57-119) end to end against the oracle pieces."""
     import vgtk.so3conv as sptk
@@ -223,6 +247,40 @@ def test_anchor_query_vs_oracle(gpu, vgtk_alias):
     z = torch.zeros(1, 1, dtype=torch.int32, device=gpu)
     w = cuda_nn.anchor_query(z, z.view(1, 1, 1), g1.to(gpu), a1.to(gpu), k1.to(gpu), 1)[0].cpu().flatten()
     assert abs(w[0].item() - 1.0) < 1e-4 and abs(w[1].item() - (1.0 + np.pi ** 2)) < 1e-4
+
+
+def test_anchor_query_f64_vs_oracle(gpu, vgtk_alias):
+    """scalar_t = double (dispatch grouping_cuda_kernel.cu:505-510): float64 output within fp64 rounding of the numpy
+    restatement; and the float32 entry's `norm` is float(double(|g|) + 1e-6), the double literal of :221 -- checked on
+    the kw - norm term alone (anchor +g direction: theta = 0, kh = 0), where it is the only rounding that differs."""
+    import vgtk.cuda.grouping as cuda_nn
+    from oracle import index_ref
+    rng = np.random.default_rng(6)
+    b, p, nn, na, ks = 2, 37, 9, 12, 5
+    g = torch.from_numpy(rng.standard_normal((b, 3, p, nn)) * 0.3)
+    anc = rng.standard_normal((na, 3))
+    anc = torch.from_numpy(anc / np.linalg.norm(anc, axis=1, keepdims=True))
+    kp = torch.from_numpy(rng.random((ks, 2)))
+    sidx = torch.zeros(b, p, dtype=torch.int32)
+    gidx = torch.zeros(b, p, nn, dtype=torch.int32)
+    want = index_ref.anchor_query(sidx, gidx, g, anc, kp, 100)[0]
+    got = cuda_nn.anchor_query(sidx.to(gpu), gidx.to(gpu), g.to(gpu), anc.to(gpu), kp.to(gpu), 100)[0]
+    assert got.dtype == torch.float64 and tuple(got.shape) == (b, p, na, ks, nn)
+    assert (got.cpu() - want).abs().max().item() < 1e-12
+    # float32: g = (0, 0, z), anchor +x (dot = 0, theta = acos(0)), kernel point (0, float(pi/2)): the angular term
+    # vanishes and w = norm * norm in float
+    z = np.float32(1e-7) + np.arange(1, 4097, dtype=np.float32) * np.float32(2.0 ** -47)  # consecutive floats near 1e-7
+    g1 = torch.zeros(1, 3, 1, z.size)
+    g1[0, 2, 0] = torch.from_numpy(z)
+    a1 = torch.tensor([[1.0, 0.0, 0.0]])
+    k1 = torch.tensor([[0.0, float(np.float32(np.pi / 2))]])
+    zi = torch.zeros(1, 1, dtype=torch.int32, device=gpu)
+    w = cuda_nn.anchor_query(zi, torch.zeros(1, 1, z.size, dtype=torch.int32, device=gpu), g1.to(gpu), a1.to(gpu),
+                             k1.to(gpu), 1)[0].cpu().flatten().numpy()
+    norm_d = (z.astype(np.float64) + 1e-6).astype(np.float32)            # double add, one rounding (the reference)
+    norm_f = z + np.float32(1e-6)                                        # float add of the float literal
+    assert (norm_d != norm_f).sum() > 50                                 # the two differ on this range ...
+    assert np.array_equal(w, norm_d * norm_d)                            # ... and the kernel follows the reference's
 
 
 @pytest.mark.parametrize("b,n,m", [(1, 1, 1), (2, 3, 2), (3, 63, 17), (2, 100, 33), (4, 513, 200), (1, 5000, 64)])

@@ -177,6 +177,17 @@ def test_initial_anchor_query_oracle_properties():
     d2 = ((K - X[:, None, :, None]) ** 2).sum(-1)                            # [b, ks, nc, na, m]
     ww = np.maximum(1.0 - d2 / 0.1, 0.0) * inside[:, None, :, None, :]
     assert np.allclose(w.numpy(), ww.sum(-1), atol=1e-4)
+    # scalar_t = double (dispatch grouping_cuda_kernel.cu:558-563): float64 outputs, the same closed form to fp64
+    # rounding; the radius is still the FLOAT parameter (0.5 is exact in both)
+    w64, c64 = index_ref.initial_anchor_query(centers.double(), frag.double(), kp.double(), 0.5, 0.1)
+    assert w64.dtype == torch.float64 and c64.dtype == torch.float64
+    C, X = C.astype(np.float64), X.astype(np.float64)
+    inside = np.sqrt(((C - X) ** 2).sum(-1)) <= 0.5
+    assert np.array_equal(c64.numpy(), np.broadcast_to(inside.sum(-1)[:, None, :, None], c64.shape).astype(np.float64))
+    K = kp.double().numpy()[None, :, None, :, None, :] + C[:, None, :, None, :, :]
+    d2 = ((K - X[:, None, :, None]) ** 2).sum(-1)
+    ww = np.maximum(1.0 - d2 / float(np.float32(0.1)), 0.0) * inside[:, None, :, None, :]
+    assert np.allclose(w64.numpy(), ww.sum(-1), atol=1e-12)
 
 
 def test_legacy_zpconv_oracle_against_reference_naive_golden():
