@@ -281,6 +281,55 @@ __device__ __forceinline__ void split3(const float (&x)[8], bf16x8 &h, bf16x8 &m
 
 // X3: both operands split in registers (the narrow / grouped problems, where a separate splitting pass over X would cost
 // as much as the GEMM); the wide weight gradients run on gemm_tn_x3_kernel below.
+#ifndef EPN_TN_XCD
+#define EPN_TN_XCD 1
+#endif
+#ifndef EPN_TN_NARROW           // exact narrow tiles + ring of stages for the bf16 1x1-convolution weight gradients
+#define EPN_TN_NARROW 1
+#endif
+#ifndef EPN_TN_WIDE_RING        // 1: grouped 128 x 256 launches on the ring kernel; 2: single problems too
+#define EPN_TN_WIDE_RING 1
+#endif
+#ifndef EPN_TN_GROUP_TARGET_BF16
+#define EPN_TN_GROUP_TARGET_BF16 768
+#endif
+#ifndef EPN_TN_SINGLE_TARGET_BF16
+#define EPN_TN_SINGLE_TARGET_BF16 512
+#endif
+#ifndef EPN_TN_WIDE_NSTG
+#define EPN_TN_WIDE_NSTG 3
+#endif
+#ifndef EPN_TN_REDUCE_SP        // shared-quad reduction of the partial slabs for small outputs
+#define EPN_TN_REDUCE_SP 1
+#endif
+#ifndef EPN_TN_NARROW_NSTG
+#define EPN_TN_NARROW_NSTG 4
+#endif
+#ifndef EPN_TN_NARROW_STAGE_KB  // stage size aimed at (a stage = a power-of-two number of 32-row contraction steps)
+#define EPN_TN_NARROW_STAGE_KB 32
+#endif
+constexpr int tn_ring_kr(int wgm, int wgn, int tm, int tn) {
+    const int step_b = 32 * 2 * 16 * (wgm * tm + wgn * tn);      // bytes of one 32-row step of [BN1 + BN2] bf16
+    int kr = 1;
+    while (2 * kr * step_b <= EPN_TN_NARROW_STAGE_KB * 1024 && 2 * kr * step_b * EPN_TN_NARROW_NSTG <= 160 * 1024) kr *= 2;
+    return kr;
+}
+#ifndef EPN_TN_NARROW_WGS       // resident workgroups per CU the split count aims at
+#define EPN_TN_NARROW_WGS 1
+#endif
+// Workgroup -> (tile, split) of a TN problem.  Launch order is split-major (all tiles of one K range, then the next
+// range); every tile row streams the whole Y panel and every tile column the whole X panel, so the tiles of ONE K range
+// running on ONE XCD read each operand row once from HBM and again from that XCD's L2.  Workgroup b runs on XCD b % 8:
+// the bijective remap of epn_common.h hands every XCD a contiguous run of that order (a problem's first workgroup is a
+// multiple of 8, tn_plan).  Placement only: the partial slabs and their fixed-order reduction are unchanged.
+__device__ __forceinline__ unsigned tn_tile_of(unsigned lb, unsigned ntiles, unsigned nsplit) {
+#if EPN_TN_XCD
+    return epn_xcd_tile(lb, (ntiles * nsplit + 7u) & ~7u);
+#else
+    return lb;
+#endif
+}
+
 template <int WGM, int WGN, int TM, int TN, int BR, bool X3 = false>
 __global__ __launch_bounds__(64 * WGM * WGN) void gemm_tn_f32_kernel(GemmTnBatch B) {
     constexpr int NW = WGM * WGN;
@@ -299,8 +348,9 @@ __global__ __launch_bounds__(64 * WGM * WGN) void gemm_tn_f32_kernel(GemmTnBatch
     for (int i = 1; i < GEMM_MAX_PROB; ++i)
         if (i < B.nprob && blockIdx.x >= B.p[i].block0) pi = i;
     const GemmTnArgs &G = B.p[pi];
-    const unsigned lb = blockIdx.x - G.block0;
-    const unsigned tile = lb % G.ntiles, split = lb / G.ntiles;
+    const unsigned tile = tn_tile_of(blockIdx.x - G.block0, G.ntiles, (unsigned)G.nsplit) % G.ntiles;
+    const unsigned split = tn_tile_of(blockIdx.x - G.block0, G.ntiles, (unsigned)G.nsplit) / G.ntiles;
+    if (split >= (unsigned)G.nsplit) return;           // padding workgroup of a grouped launch (uniform per workgroup)
     const int n1_0 = (int)(tile / G.tiles_n2) * BN1, n2_0 = (int)(tile % G.tiles_n2) * BN2;
     const long long nchunk = G.R / BR;
     const long long c0 = nchunk * split / G.nsplit, c1 = nchunk * (split + 1) / G.nsplit;
@@ -528,8 +578,9 @@ __global__ __launch_bounds__(64 * WGM * WGN) void gemm_tn_x3_kernel(GemmTnBatch 
     for (int i = 1; i < GEMM_MAX_PROB; ++i)
         if (i < B.nprob && blockIdx.x >= B.p[i].block0) pi = i;
     const GemmTnArgs &G = B.p[pi];
-    const unsigned lb = blockIdx.x - G.block0;
-    const unsigned tile = lb % G.ntiles, split = lb / G.ntiles;
+    const unsigned tile = tn_tile_of(blockIdx.x - G.block0, G.ntiles, (unsigned)G.nsplit) % G.ntiles;
+    const unsigned split = tn_tile_of(blockIdx.x - G.block0, G.ntiles, (unsigned)G.nsplit) / G.ntiles;
+    if (split >= (unsigned)G.nsplit) return;           // padding workgroup of a grouped launch (uniform per workgroup)
     const int n1_0 = (int)(tile / G.tiles_n2) * BN1, n2_0 = (int)(tile % G.tiles_n2) * BN2;
     const long long nchunk = G.R / BR;
     const long long c0 = nchunk * split / G.nsplit, c1 = nchunk * (split + 1) / G.nsplit;
@@ -683,8 +734,9 @@ __global__ __launch_bounds__(64 * WGM * WGN) void gemm_tn_bf16_kernel(GemmTnBatc
     for (int i = 1; i < GEMM_MAX_PROB; ++i)
         if (i < B.nprob && blockIdx.x >= B.p[i].block0) pi = i;
     const GemmTnArgs &G = B.p[pi];
-    const unsigned lb = blockIdx.x - G.block0;
-    const unsigned tile = lb % G.ntiles, split = lb / G.ntiles;
+    const unsigned tile = tn_tile_of(blockIdx.x - G.block0, G.ntiles, (unsigned)G.nsplit) % G.ntiles;
+    const unsigned split = tn_tile_of(blockIdx.x - G.block0, G.ntiles, (unsigned)G.nsplit) / G.ntiles;
+    if (split >= (unsigned)G.nsplit) return;           // padding workgroup of a grouped launch (uniform per workgroup)
     const int n1_0 = (int)(tile / G.tiles_n2) * BN1, n2_0 = (int)(tile % G.tiles_n2) * BN2;
     const long long nchunk = G.R / BR;
     const long long c0 = nchunk * split / G.nsplit, c1 = nchunk * (split + 1) / G.nsplit;
@@ -804,6 +856,163 @@ __global__ __launch_bounds__(64 * WGM * WGN) void gemm_tn_bf16_kernel(GemmTnBatc
             }
 }
 
+// ------------------------------------------------------------------------------------------------ TN (bf16), ring form
+// The streaming weight gradients (1x1 convolutions: N1, N2 <= 256 outputs over 10^5..10^6 rows) -- same fragments and
+// MFMA as gemm_tn_bf16_kernel, but (a) the tile IS the output (no columns of loads wasted on a 256-wide tile), (b) a
+// stage holds KR contraction steps and NSTG stages form a ring with NSTG - 1 requested ahead: the wait in front of the
+// barrier counts the younger stages' loads instead of draining them, (c) the transposed LDS reads are inline assembly --
+// behind the builtin the compiler puts `s_waitcnt vmcnt(0)` in front of the first read of every step (it cannot tell the
+// stage being read from the stages the LDS-direct loads are still writing), which empties the ring -- and are waited for
+// by hand (the empty asm statements tie each fragment register to that wait).  Few, long workgroups: measured cold
+// (tools/tn_probe.py), 256 workgroups stream faster than 512 or 1024 (fewer concurrent DRAM streams).
+template <int WGM, int WGN, int TM, int TN, int NSTG, int KR>
+__global__ __launch_bounds__(64 * WGM * WGN) void gemm_tn_bf16_ring_kernel(GemmTnBatch B) {
+    constexpr int NW = WGM * WGN;
+    constexpr int BN1 = WGM * TM * 16, BN2 = WGN * TN * 16;
+    constexpr int ROWE = BN1 + BN2;                 // bf16 per staged row
+    constexpr int BR = 32 * KR;                     // rows per stage
+    constexpr int STAGE_B = BR * ROWE * 2;
+    constexpr int NI = STAGE_B / 1024;
+    constexpr int IPW = (NI + NW - 1) / NW;
+    static_assert(STAGE_B % 1024 == 0, "stage must be a whole number of 1 KiB pieces");
+    static_assert(NSTG >= 3 && NSTG <= 4 && NSTG * STAGE_B <= 160 * 1024, "ring of 3 or 4 stages in LDS");
+    static_assert(IPW * (NSTG - 2) <= 63, "vmcnt range");
+    __shared__ __attribute__((aligned(1024))) char smem[NSTG * STAGE_B];
+
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    int pi = 0;
+#pragma unroll
+    for (int i = 1; i < GEMM_MAX_PROB; ++i)
+        if (i < B.nprob && blockIdx.x >= B.p[i].block0) pi = i;
+    const GemmTnArgs &G = B.p[pi];
+    const unsigned tile = tn_tile_of(blockIdx.x - G.block0, G.ntiles, (unsigned)G.nsplit) % G.ntiles;
+    const unsigned split = tn_tile_of(blockIdx.x - G.block0, G.ntiles, (unsigned)G.nsplit) / G.ntiles;
+    if (split >= (unsigned)G.nsplit) return;           // padding workgroup (uniform per workgroup)
+    const int n1_0 = (int)(tile / G.tiles_n2) * BN1, n2_0 = (int)(tile % G.tiles_n2) * BN2;
+    const long long nchunk = G.R / 32;              // 32-row contraction steps
+    const long long c0 = nchunk * split / G.nsplit, c1 = nchunk * (split + 1) / G.nsplit;
+    const int nk = (int)(c1 - c0);                  // steps of this split
+    const int nst = (nk + KR - 1) / KR;             // stages (the last one may be partly used)
+    const __bf16 *__restrict__ X = static_cast<const __bf16 *>(G.X);
+    const __bf16 *__restrict__ Y = static_cast<const __bf16 *>(G.Y);
+
+    // every wave issues IPW loads per stage so that one vmcnt value holds for all (a wave past the last piece requests
+    // piece q - NI again: same bytes to the same place); rows past the end of the operands (last stage of the last
+    // split) are clamped to the last row -- loaded, never multiplied
+    const __bf16 *src[IPW], *lim[IPW];
+    long long sstep[IPW];
+#pragma unroll
+    for (int i = 0; i < IPW; ++i) {
+        const int q = (wave + i * NW) % NI;
+        const int eo = 512 * q + 8 * lane;            // bf16 offset inside the [BR][ROWE] image
+        const int r = eo / ROWE, c = eo % ROWE;
+        if (c < BN1) {
+            int n = n1_0 + c;
+            n = n < G.N1 - 8 ? n : G.N1 - 8;
+            src[i] = X + (c0 * 32 + r) * G.ldx + n;
+            lim[i] = X + (G.R - 1) * G.ldx + n;
+            sstep[i] = (long long)BR * G.ldx;
+        } else {
+            int n = n2_0 + (c - BN1);
+            n = n < G.N2 - 8 ? n : G.N2 - 8;
+            src[i] = Y + (c0 * 32 + r) * G.ldy + n;
+            lim[i] = Y + (G.R - 1) * G.ldy + n;
+            sstep[i] = (long long)BR * G.ldy;
+        }
+    }
+    auto stage = [&](int buf) {
+#pragma unroll
+        for (int i = 0; i < IPW; ++i) {
+            const int q = (wave + i * NW) % NI;
+            glds16(KR > 1 && src[i] > lim[i] ? lim[i] : src[i], smem + buf * STAGE_B + q * 1024);
+            src[i] += sstep[i];
+        }
+    };
+
+    const int wm = wave / WGN, wn = wave % WGN;
+    const int li = lane & 15, lg = lane >> 4;
+    const int tr_row = 8 * lg + (li >> 2), tr_col = 4 * (li & 3);      // see gemm_tn_bf16_kernel
+
+    f32x4 acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+#pragma unroll
+    for (int s = 0; s < NSTG - 1; ++s)
+        if (s < nst) stage(s);
+    typedef short s16x8 __attribute__((ext_vector_type(8)));
+    for (int kt = 0; kt < nst; ++kt) {
+        // stage kt has landed; up to NSTG - 2 younger stages (IPW loads each, this wave's) may still be on their way
+        const int ahead = nst - 1 - kt;
+        if (NSTG == 4 && ahead >= 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * IPW) : "memory");
+        else if (ahead >= 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(IPW) : "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+        const char *sbase = smem + (kt % NSTG) * STAGE_B;
+#pragma unroll
+        for (int ks = 0; ks < KR; ++ks) {
+            if (KR > 1 && kt * KR + ks >= nk) break;
+            const char *base = sbase + ks * (32 * ROWE * 2);
+            // Y fragments first, then X's: row i of MFMAs starts when its X fragment (and all of Y) has arrived
+            s16x4 lo[TM + TN], hi[TM + TN];
+#pragma unroll
+            for (int f = 0; f < TM + TN; ++f) {
+                const int col = f < TN ? BN1 + (wn * TN + f) * 16 + tr_col : (wm * TM + (f - TN)) * 16 + tr_col;
+                const unsigned ad =
+                    (unsigned)(uintptr_t)(__attribute__((address_space(3))) char *)(base + (tr_row * ROWE + col) * 2);
+                asm volatile("ds_read_b64_tr_b16 %0, %1" : "=v"(lo[f]) : "v"(ad));
+                asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(hi[f]) : "v"(ad), "n"(4 * ROWE * 2));
+            }
+            bf16x8 b[TN];
+#pragma unroll
+            for (int i = 0; i < TM; ++i) {
+                // reads return in order: all but the 2 (TM - 1 - i) youngest have landed
+                asm volatile("s_waitcnt lgkmcnt(%0)" ::"n"(2 * (TM - 1 - i)) : "memory");
+                if (i == 0) {
+#pragma unroll
+                    for (int j = 0; j < TN; ++j) {
+                        asm volatile("" : "+v"(lo[j]), "+v"(hi[j]));
+                        const s16x8 v = {lo[j][0], lo[j][1], lo[j][2], lo[j][3], hi[j][0], hi[j][1], hi[j][2], hi[j][3]};
+                        b[j] = __builtin_bit_cast(bf16x8, v);
+                    }
+                }
+                asm volatile("" : "+v"(lo[TN + i]), "+v"(hi[TN + i]));
+                const s16x8 va = {lo[TN + i][0], lo[TN + i][1], lo[TN + i][2], lo[TN + i][3],
+                                  hi[TN + i][0], hi[TN + i][1], hi[TN + i][2], hi[TN + i][3]};
+                const bf16x8 a = __builtin_bit_cast(bf16x8, va);
+#pragma unroll
+                for (int j = 0; j < TN; ++j) {
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b[j], acc[i][j], 0, 0, 0);
+                    if (ks == 0 && i == 0 && j == 0) {
+                        __builtin_amdgcn_sched_barrier(0);
+                        if (kt + NSTG - 1 < nst) stage((kt + NSTG - 1) % NSTG);   // the buffer of stage kt - 1 (all waves past it)
+                        __builtin_amdgcn_sched_barrier(0);
+                    }
+                }
+            }
+        }
+    }
+
+    // D[row = 4 lg + r][col = li]
+    float *__restrict__ C = G.nsplit > 1 ? static_cast<float *>(G.part) + (size_t)split * G.N1 * G.N2
+                                         : static_cast<float *>(G.C);
+    const long long ldc = G.nsplit > 1 ? G.N2 : G.ldc;
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int n1 = n1_0 + (wm * TM + i) * 16 + 4 * lg + r;
+                const int n2 = n2_0 + (wn * TN + j) * 16 + li;
+                if (n1 < G.N1 && n2 < G.N2) C[(long long)n1 * ldc + n2] = acc[i][j][r];
+            }
+}
+
 // sum the split partials in a fixed order (deterministic): C[i] = sum_s part[s][i].  Streaming: 16-byte loads, eight
 // splits in flight per thread (a scalar loop over the splits ran at a third of the HBM rate).
 __global__ __launch_bounds__(256) void gemm_tn_reduce_kernel(GemmTnBatch B) {      // blockIdx.y = problem
@@ -844,6 +1053,55 @@ __global__ __launch_bounds__(256) void gemm_tn_reduce_kernel(GemmTnBatch B) {   
         float s = 0.f;
         for (int k = 0; k < G.nsplit; ++k) s += part[(size_t)k * n + i];
         C[(i / G.N2) * G.ldc + (i % G.N2)] = s;
+    }
+}
+
+// The same sum for SMALL outputs with MANY partials (the narrow weight gradients: 32 x 32 .. 256 x 128 outputs, 256
+// partial slabs): one thread per output quad walks all the slabs in rounds of eight dependent-latency loads -- 32 rounds,
+// ~40 us, as long as the GEMM itself.  Here SP threads share a quad: thread g of them sums slabs g, g + SP, g + 2 SP, ...
+// (four in flight), the SP partial sums are added in the order g = 0 .. SP-1 through LDS.  Fixed order: deterministic.
+template <int SP>
+__global__ __launch_bounds__(256) void gemm_tn_reduce_sp_kernel(GemmTnBatch B) {      // blockIdx.y = problem
+    constexpr int QB = 256 / SP;                   // output quads per workgroup
+    __shared__ f32x4 red[SP][QB];
+    const GemmTnArgs &G = B.p[blockIdx.y];
+    if (G.nsplit <= 1) return;
+    const f32x4 *__restrict__ part = static_cast<const f32x4 *>(G.part);
+    float *__restrict__ C = static_cast<float *>(G.C);
+    const size_t n4 = ((size_t)G.N1 * G.N2) >> 2;
+    const int ql = threadIdx.x % QB, g = threadIdx.x / QB;
+    for (size_t q0 = (size_t)blockIdx.x * QB; q0 < n4; q0 += (size_t)gridDim.x * QB) {      // uniform per workgroup
+        const size_t q = q0 + ql;
+        f32x4 a[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) a[u] = f32x4{0.f, 0.f, 0.f, 0.f};
+        if (q < n4) {
+            int k = g;
+            for (; k + 3 * SP < G.nsplit; k += 4 * SP)
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const f32x4 v = part[(size_t)(k + u * SP) * n4 + q];
+                    a[u][0] += v[0]; a[u][1] += v[1]; a[u][2] += v[2]; a[u][3] += v[3];
+                }
+            for (; k < G.nsplit; k += SP) {
+                const f32x4 v = part[(size_t)k * n4 + q];
+                a[0][0] += v[0]; a[0][1] += v[1]; a[0][2] += v[2]; a[0][3] += v[3];
+            }
+        }
+        f32x4 r;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) r[e] = (a[0][e] + a[1][e]) + (a[2][e] + a[3][e]);
+        red[g][ql] = r;
+        __syncthreads();
+        if (g == 0 && q < n4) {
+            for (int j = 1; j < SP; ++j) {
+                const f32x4 v = red[j][ql];
+                r[0] += v[0]; r[1] += v[1]; r[2] += v[2]; r[3] += v[3];
+            }
+            const size_t e0 = q << 2;
+            *reinterpret_cast<f32x4 *>(C + (e0 / G.N2) * G.ldc + (e0 % G.N2)) = r;
+        }
+        __syncthreads();
     }
 }
 
@@ -1074,7 +1332,7 @@ size_t tn_plan(GemmTnBatch &B, int *bn1_out, int *bn2_out, void *ws, bool x3 = f
     } else {
         // smallest steps-per-workgroup S (>= 8) whose launch fits `target` workgroups (whole rounds of the 256 CUs: these
         // tiles take a CU's LDS each); every problem gets ceil(chunks / S) splits
-        const long long target = 256;   // one round: fewer, longer workgroups = fewer partial slabs (256/512/1024/2048: 6.2/6.7/7.4/7.9 ms per step)
+        const long long target = bf == 1 ? EPN_TN_GROUP_TARGET_BF16 : 256;   // one round: fewer, longer workgroups = fewer partial slabs (256/512/1024/2048: 6.2/6.7/7.4/7.9 ms per step)
         long long S = 8;
         for (long long cand = 8; cand <= 8192; ++cand) {
             long long blocks = 0;
@@ -1093,7 +1351,7 @@ size_t tn_plan(GemmTnBatch &B, int *bn1_out, int *bn2_out, void *ws, bool x3 = f
     for (int i = 0; i < B.nprob; ++i) {
         GemmTnArgs &G = B.p[i];
         G.block0 = blk;
-        blk += G.ntiles * (unsigned)G.nsplit;
+        blk += (G.ntiles * (unsigned)G.nsplit + 7u) & ~7u;      // whole octets: workgroup % 8 (= XCD) holds per problem
         G.part = nullptr; G.part_bytes = 0;
         if (G.nsplit > 1) {
             const size_t nb = (size_t)G.nsplit * G.N1 * G.N2 * sizeof(float);
@@ -1174,11 +1432,30 @@ int launch_tn_typed(GemmTnBatch &B, void *ws, size_t ws_bytes, hipStream_t st, b
 #undef EPN_TN
 #undef EPN_TX
     } else {
-        if (bn1 == 32) EPN_LAUNCH((gemm_tn_bf16_kernel<1, 4, 2, 4>), grid, dim3(256), 0, st, B);        // 4 waves: fewer,
+#define EPN_TNR(...)                                                                                                     \
+    EPN_LAUNCH((gemm_tn_bf16_ring_kernel<__VA_ARGS__, EPN_TN_NARROW_NSTG, tn_ring_kr(__VA_ARGS__)>), grid, dim3(256), 0, st, B)
+        if (bn2 <= 128 && B.nprob == 1) {               // narrow single problems (gemm_tn_tile): 2 x 2 waves, ring of stages
+            if (bn1 == 32 && bn2 == 32) EPN_TNR(2, 2, 1, 1);
+            else if (bn1 == 64 && bn2 == 32) EPN_TNR(2, 2, 2, 1);
+            else if (bn1 == 32 && bn2 == 64) EPN_TNR(2, 2, 1, 2);
+            else if (bn1 == 64 && bn2 == 64) EPN_TNR(2, 2, 2, 2);
+            else if (bn1 == 128 && bn2 == 64) EPN_TNR(2, 2, 4, 2);
+            else if (bn1 == 256 && bn2 == 64) EPN_TNR(2, 2, 8, 2);
+            else if (bn1 == 32 && bn2 == 128) EPN_TNR(2, 2, 1, 4);
+            else if (bn1 == 64 && bn2 == 128) EPN_TNR(2, 2, 2, 4);
+            else if (bn1 == 128 && bn2 == 128) EPN_TNR(2, 2, 4, 4);
+            else EPN_TNR(2, 2, 8, 4);                   // 256 x 128
+        }
+#undef EPN_TNR
+        else if (bn1 == 32) EPN_LAUNCH((gemm_tn_bf16_kernel<1, 4, 2, 4>), grid, dim3(256), 0, st, B);        // 4 waves: fewer,
         else if (bn1 == 64) EPN_LAUNCH((gemm_tn_bf16_kernel<1, 4, 4, 4>), grid, dim3(256), 0, st, B);   // larger wave tiles
         // 128 x 256 tile on FOUR waves (64 x 128 per wave: 32 MFMAs per 12 transposed LDS reads).  The 8-wave form (16 MFMAs
         // per 16 reads) was LDS-bandwidth bound -- 3 workgroups x 64 KB of fragment reads per 1024 cycles > 128 B/clk:
         // 245760 x 256 x 6144: 1.63 -> 1.23 ms (630 TFLOP/s)
+#if EPN_TN_WIDE_RING
+        else if (B.nprob > 1 || EPN_TN_WIDE_RING > 1)
+            EPN_LAUNCH((gemm_tn_bf16_ring_kernel<2, 2, 4, 8, EPN_TN_WIDE_NSTG, 1>), grid, dim3(256), 0, st, B);
+#endif
         else EPN_LAUNCH((gemm_tn_bf16_kernel<2, 2, 4, 8>), grid, dim3(256), 0, st, B);
     }
     EPN_CHECK_LAUNCH();
@@ -1191,8 +1468,26 @@ int launch_tn_typed(GemmTnBatch &B, void *ws, size_t ws_bytes, hipStream_t st, b
     }
     if (any_split) {
         const size_t nv = (nmax + 3) / 4;               // one thread per four outputs
-        const unsigned gx = (unsigned)((nv + 255) / 256 < 2048 ? (nv + 255) / 256 : 2048);
-        EPN_LAUNCH_AUX(gemm_tn_reduce_kernel, dim3(gx, B.nprob), dim3(256), 0, st, B);
+        bool quads = true;                              // (the shared-quad form needs the 16-byte path of every problem)
+        int smax = 1;
+        for (int i = 0; i < B.nprob; ++i) {
+            const GemmTnArgs &G = B.p[i];
+            quads = quads && (G.N2 & 3) == 0 && (G.ldc & 3) == 0 && !((uintptr_t)G.C & 15);
+            smax = G.nsplit > smax ? G.nsplit : smax;
+        }
+        // few outputs, many partials: SP threads per quad so that the launch has >= 32 k threads and a thread >= 4 slabs
+        int sp = 1;
+        while (EPN_TN_REDUCE_SP && quads && sp < 64 && nv * B.nprob * sp < 32768 && smax >= 16 * sp) sp *= 4;
+        if (sp > 1) {
+            const size_t qb = 256 / sp;
+            const unsigned gx = (unsigned)((nv + qb - 1) / qb < 2048 ? (nv + qb - 1) / qb : 2048);
+            if (sp == 4) EPN_LAUNCH_AUX(gemm_tn_reduce_sp_kernel<4>, dim3(gx, B.nprob), dim3(256), 0, st, B);
+            else if (sp == 16) EPN_LAUNCH_AUX(gemm_tn_reduce_sp_kernel<16>, dim3(gx, B.nprob), dim3(256), 0, st, B);
+            else EPN_LAUNCH_AUX(gemm_tn_reduce_sp_kernel<64>, dim3(gx, B.nprob), dim3(256), 0, st, B);
+        } else {
+            const unsigned gx = (unsigned)((nv + 255) / 256 < 2048 ? (nv + 255) / 256 : 2048);
+            EPN_LAUNCH_AUX(gemm_tn_reduce_kernel, dim3(gx, B.nprob), dim3(256), 0, st, B);
+        }
         EPN_CHECK_LAUNCH();
     }
     return 0;
@@ -1203,6 +1498,12 @@ int launch_tn_typed(GemmTnBatch &B, void *ws, size_t ws_bytes, hipStream_t st, b
 // block tile of the TN kernels for an output of N1 x N2 (shared with the workspace query)
 void gemm_tn_tile(int dtype, int N1, int N2, int *bn1, int *bn2) {   // dtype: 0 fp32, 1 bf16, 2 fp32 split form
     if (dtype == 1) {
+        if (N2 <= 128 && EPN_TN_NARROW) {        // 1x1 convolutions: the tile IS the output, ring form (gemm_tn_bf16_ring_kernel)
+            *bn2 = N2 <= 32 ? 32 : (N2 <= 64 ? 64 : 128);
+            *bn1 = N1 <= 32 ? 32 : (N1 <= 64 ? 64 : (N1 <= 128 ? 128 : 256));
+            if (*bn2 == 32 && *bn1 > 64) *bn1 = 64;
+            return;
+        }
         if (N1 <= 32) { *bn1 = 32; *bn2 = 256; }
         else if (N1 <= 64) { *bn1 = 64; *bn2 = 256; }
         else { *bn1 = 128; *bn2 = 256; }
@@ -1229,12 +1530,19 @@ int gemm_tn_splits(int dtype, long long R, int N1, int N2) {
     const long long tiles = (long long)((N1 + bn1 - 1) / bn1) * ((N2 + bn2 - 1) / bn2);
     const long long chunks = R / 32;
     const int pol = kernel_policy();
-    const long long target = (pol & ~0xff) == 0x200 ? 256LL * (pol & 0xff) : 512;    // 0x200 | v: tuning override
+    const long long target = (pol & ~0xff) == 0x200 ? 256LL * (pol & 0xff) : (dtype == 1 ? EPN_TN_SINGLE_TARGET_BF16 : 512);    // 0x200 | v: tuning override
     // two rounds of the 256 CUs.  With the split count rounded down (below) 512 / 1024 / 1536 / 2048 workgroups run the dW
     // shapes of the ModelNet schedule within 1.5 % of each other (18.7 / 18.8 / 18.9 / 19.0 ms summed, fp32 partial slabs and
     // their fixed-order reduction included); fewer workgroups = fewer partial slabs
     // rounded DOWN: the wide tiles take a whole CU's LDS, so 2048 workgroups are exactly 8 rounds of the 256 CUs and one
     // workgroup more is a ninth round that runs 16 workgroups wide (24 tiles x 86 splits = 2064: measured 118 -> 129 TFLOP/s)
+    if (dtype == 1 && N2 <= 128 && EPN_TN_NARROW && (pol & ~0xff) != 0x200) {
+        // ring form: EPN_TN_NARROW_WGS workgroups per CU, all resident; >= 16 steps per split
+        long long sn = 256LL * EPN_TN_NARROW_WGS / tiles;
+        const long long cap = chunks / 16 > 1 ? chunks / 16 : 1;
+        sn = sn > cap ? cap : sn;
+        return (int)(sn < 1 ? 1 : sn);
+    }
     long long s = target / tiles;
     // at least 32 K steps per split: a split ends in an N1 x N2 fp32 slab write (+ its share of the reduction), which
     // for the short-and-wide problems (spectral blocks: R = pts*d rows, up to 1280 x 1280 outputs) outweighs 8 steps of loads

@@ -100,7 +100,14 @@ def test_gemm_nt_epilogue_column_statistics(gpu, fp32_mode, dt, M, N, K):
 
 @pytest.mark.parametrize("dt", [torch.float32, torch.bfloat16])
 @pytest.mark.parametrize("R_,N1,N2", [(4096, 64, 512), (2048, 128, 192), (960, 32, 768), (1024, 256, 256), (100, 20, 36),
-                                      (61440, 64, 1536), (32, 8, 8)])
+                                      (61440, 64, 1536), (32, 8, 8),
+                                      # narrow outputs (1x1-convolution weight gradients; bf16: every tile of the ring-of-
+                                      # stages kernel, row counts that end inside a stage, ragged N1 / N2, and enough
+                                      # rows for 16+ partial slabs = the shared-quad reduction)
+                                      (1184, 32, 32), (7200, 64, 32), (4128, 32, 64), (9696, 64, 64), (3232, 128, 64),
+                                      (2080, 256, 64), (2080, 24, 128), (4160, 56, 120), (8352, 128, 128),
+                                      (4128, 256, 128), (99968, 40, 24), (245760, 32, 32), (122880, 64, 64),
+                                      (61440, 256, 128)])
 def test_gemm_tn_vs_fp64(gpu, fp32_mode, dt, R_, N1, N2):
     from epn_pointcloud_amd import gemm
     if dt != torch.float32 and fp32_mode == "native":
