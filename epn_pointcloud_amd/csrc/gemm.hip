@@ -1475,9 +1475,10 @@ int launch_tn_typed(GemmTnBatch &B, void *ws, size_t ws_bytes, hipStream_t st, b
             quads = quads && (G.N2 & 3) == 0 && (G.ldc & 3) == 0 && !((uintptr_t)G.C & 15);
             smax = G.nsplit > smax ? G.nsplit : smax;
         }
-        // few outputs, many partials: SP threads per quad so that the launch has >= 32 k threads and a thread >= 4 slabs
+        // many partials: SP threads per quad so that a thread walks its slabs in at most ~4 rounds of four loads (while
+        // the launch stays under a million threads)
         int sp = 1;
-        while (EPN_TN_REDUCE_SP && quads && sp < 64 && nv * B.nprob * sp < 32768 && smax >= 16 * sp) sp *= 4;
+        while (EPN_TN_REDUCE_SP && quads && sp < 64 && smax > 16 * sp && nv * B.nprob * sp * 4 <= (1u << 20)) sp *= 4;
         if (sp > 1) {
             const size_t qb = 256 / sp;
             const unsigned gx = (unsigned)((nv + qb - 1) / qb < 2048 ? (nv + qb - 1) / qb : 2048);
@@ -1518,7 +1519,7 @@ void gemm_tn_tile(int dtype, int N1, int N2, int *bn1, int *bn2) {   // dtype: 0
             else { *bn1 = 128; *bn2 = 512; }
             return;
         }
-        if (N1 <= 32) { *bn1 = 32; *bn2 = 512; }
+        if (N1 <= 32 && N2 > 128) { *bn1 = 32; *bn2 = 512; }      // (narrow N2: the 64-row tiles below, not a 512-column tile)
         else if (N1 <= 64) { *bn1 = 64; *bn2 = N2 >= 512 ? 512 : (N2 > 128 ? 256 : (N2 > 64 ? 128 : 64)); }
         else { *bn1 = 128; *bn2 = N2 >= 512 ? 512 : (N2 > 128 ? 256 : (N2 > 64 ? 128 : 64)); }
     }
