@@ -26,6 +26,7 @@ EPN_GEMM_FP32=native b cls_native_fp32_mfma --no-cpu-baseline --no-native-line
 python tools/gemm_bench.py > $OUT/gemm_bench_f32.txt 2>&1
 python tools/gemm_bench.py --dtype bf16 > $OUT/gemm_bench_bf16.txt 2>&1
 python tools/hbm_probe.py > $OUT/hbm_probe.txt 2>&1
+python tools/tn_probe.py --dtype bf16 2>&1 | grep -v amdgpu.ids > $OUT/tn_probe.txt; python tools/tn_probe.py --dtype f32 2>&1 | grep -v amdgpu.ids >> $OUT/tn_probe.txt
 (cd tools && python nt_shortk_probe.py 2>&1 | grep -v amdgpu.ids > $OUT/nt_shortk_probe.txt; python nt_shortk_probe.py --bf16 2>&1 | grep -v amdgpu.ids >> $OUT/nt_shortk_probe.txt)
 rm -rf gpurun_out/${TAG}_reg gpurun_out/${TAG}_replay $OUT/pmc_*.log $OUT/stats.log
 for f in $(ls $OUT/bench_*.json | grep -v _detail); do python - <<PY
