@@ -1291,8 +1291,12 @@ int launch_nt_typed(GemmNtBatch &B, hipStream_t st) {
 
 constexpr int tn_waves(int wgm, int wgn, int, int, int) { return wgm * wgn; }
 // split form: single wide weight gradients take the pre-split planes kernel, narrow / grouped ones split in the kernel
-// (N2 = the narrowest output; groups of c = 128 blocks measured slower with the extra pass over X: 1.43 vs 1.34 ms)
-inline bool tn_planes_form(int nprob, int N2) { return N2 >= (nprob == 1 ? 512 : 256); }
+// (N2 = the narrowest output; groups of c = 128 blocks measured slower with the extra pass over X: 1.43 vs 1.34 ms,
+// c = 256 ones too once timed cold -- X is as large as Y in a spectral block, so the pre-split is a full extra pass)
+#ifndef EPN_TN_GROUP_PLANES     // narrowest output from which a GROUP takes the pre-split planes kernel (256 x 256 tiles)
+#define EPN_TN_GROUP_PLANES 512  // cold, tools/tn_probe.py: c = 256 groups 1.05 ms in-kernel split vs 1.14 planes; c = 512: 2.40 vs 1.48
+#endif
+inline bool tn_planes_form(int nprob, int N2) { return N2 >= (nprob == 1 ? 512 : EPN_TN_GROUP_PLANES); }
 
 template <typename T>
 bool tn_fast_ok(const GemmTnArgs &G) {
@@ -1313,7 +1317,7 @@ size_t tn_plan(GemmTnBatch &B, int *bn1_out, int *bn2_out, void *ws, bool x3 = f
     }
     int bn1, bn2;
     gemm_tn_tile(B.nprob > 1 && bf == 2 ? 0 : bf, max1, B.nprob > 1 && min2 < 256 ? 256 : min2, &bn1, &bn2);   // groups: the wide tiles
-    if (B.nprob > 1 && bf == 2 && min2 >= 256) {       // wide spectral groups (c >= 256), split form: 256 x 256 tiles
+    if (B.nprob > 1 && bf == 2 && min2 >= EPN_TN_GROUP_PLANES) {       // wide spectral groups (c >= 512), split form: 256 x 256 tiles
         int min1 = 1 << 30;                             // halve the re-reads of X and Y (every tile row / column streams
         for (int i = 0; i < B.nprob; ++i) min1 = B.p[i].N1 < min1 ? B.p[i].N1 : min1;   // the other operand again)
         if (min1 >= 256) { bn1 = 256; bn2 = 256; }

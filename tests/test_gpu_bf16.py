@@ -145,7 +145,7 @@ def test_gemm_tn_grouped(gpu, fp32_mode, dt):
     if dt != torch.float32 and fp32_mode == "native":
         pytest.skip("mode only concerns fp32 operands")
     torch.manual_seed(8)
-    for w1, w2 in ((64, 32), (256, 256)):       # (256, 256): every output >= 256 wide -- the split form pre-splits X
+    for w1, w2 in ((64, 32), (256, 256), (512, 512)):   # (512, 512): every output >= 512 wide -- the split form pre-splits X
         probs = [(torch.randn(2048 * d, w1 * d, device=gpu).to(dt), torch.randn(2048 * d, w2 * d, device=gpu).to(dt))
                  for d in (1, 3, 3, 4, 5)]
         outs = gemm.gemm_tn_grouped(probs)
