@@ -23,7 +23,8 @@ EXPORTS = [
     "epn_norm_workspace_bytes", "epn_bn_running_update_f32", "epn_chan_stats_f32", "epn_norm_act_fwd_f32", "epn_norm_act_bwd_reduce_f32", "epn_norm_act_bwd_apply_f32",
     "epn_inter_group_workspace_bytes", "epn_inter_group_f32", "epn_inter_ungroup_f32", "epn_intra_group_f32", "epn_so3_basis_f32",
     "epn_anchor_query_f32", "epn_zp_inter_fwd_f32", "epn_zp_inter_bwd_f32", "epn_zp_intra_fwd_f32", "epn_zp_intra_bwd_f32",
-    "epn_pointnet_so3conv_fwd_f32", "epn_pointnet_so3conv_bwd_data_f32", "epn_pointnet_so3conv_bwd_weight_f32",
+    "epn_pointnet_so3conv_fwd_f32", "epn_pointnet_so3conv_bwd_data_f32", "epn_pointnet_max_f32", "epn_pointnet_dz_f32", "epn_pointnet_dz_bf16", "epn_pointnet_bwd_coord_f32",
+    "epn_pointnet_so3conv_bwd_weight_f32",
     "epn_gemm_nt_f32", "epn_gemm_nt_bf16", "epn_gemm_nt_split_workspace_bytes", "epn_gemm_nt_split_f32", "epn_gemm_tn_workspace_bytes", "epn_gemm_tn_f32", "epn_gemm_tn_split_f32", "epn_gemm_tn_bf16",
     "epn_transpose_cast", "epn_cast", "epn_gemm_tn_grouped_workspace_bytes", "epn_gemm_tn_grouped",
     "epn_inter_group_bf16", "epn_inter_ungroup_bf16", "epn_intra_group_bf16", "epn_so3_basis_bf16",

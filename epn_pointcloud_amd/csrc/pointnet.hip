@@ -11,6 +11,9 @@
 namespace epn {
 namespace {
 
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef int i32x4 __attribute__((ext_vector_type(4)));
+
 constexpr int PN_T = 128;    // threads = output channels per workgroup
 constexpr int PN_P = 32;     // points per tile
 constexpr int PN_C = 64;     // channels per tile
@@ -331,6 +334,147 @@ __global__ __launch_bounds__(256) void pointnet_bwd_weight_kernel(PnArgs A) {
     }
 }
 
+// ---- GEMM-composed form (round 4).  The embedding's feature part Z[b][p][a][o] = sum_c W[o][c] F[b][p][a][c] is a plain
+// [b p a, c] x [c, co] contraction: on the library's GEMM (bf16 pipe: bf16 features directly, fp32 ones in the split form) it
+// runs 3-4x faster than the fused kernel above, whose workgroups each restage W and whose four waves each load the whole
+// feature slab (40 TFLOP/s).  What is left is streaming: the max / arg-max over points with the three coordinate channels
+// and the bias added on the way, and in the backward pass the gradient routed through the arg-max point written as the
+// (one non-zero per column) dense dZ that two more GEMMs turn into dF and dW.
+struct PnMaxArgs {
+    const float *Z, *xyz, *anchors, *W, *bias, *gout, *centre_in;
+    const int32_t *arg_in;
+    float *out, *centre, *dW, *dbias;
+    int32_t *arg;
+    void *dZ;
+    int b, p, a, c, co;
+};
+
+__global__ __launch_bounds__(256) void pointnet_max_kernel(PnMaxArgs A) {
+    constexpr int PT = 64;
+    __shared__ float Es[PT][4];
+    __shared__ float ctr_s[3];
+    const int t = threadIdx.x;
+    const int bb = blockIdx.x / A.a, ai = blockIdx.x % A.a;
+    const int o = blockIdx.y * 256 + t;
+    const bool ok = o < A.co;
+    const int ce = A.c + 3;
+    if (t < 3) {   // centre of the cloud: plain sequential mean, as the fused kernels (every workgroup gets the same bits)
+        const float *s = A.xyz + ((size_t)bb * 3 + t) * A.p;
+        float m = 0.f;
+        for (int i = 0; i < A.p; ++i) m += s[i];
+        m /= (float)A.p;
+        ctr_s[t] = m;
+        if (ai == 0 && blockIdx.y == 0) A.centre[bb * 3 + t] = m;
+    }
+    __syncthreads();
+    const float ctr[3] = {ctr_s[0], ctr_s[1], ctr_s[2]};
+    const int oo = ok ? o : 0;
+    const float w3[3] = {A.W[(size_t)oo * ce + A.c], A.W[(size_t)oo * ce + A.c + 1], A.W[(size_t)oo * ce + A.c + 2]};
+    const float bias = A.bias ? A.bias[oo] : 0.f;
+    const float *z = A.Z + ((size_t)bb * A.p * A.a + ai) * A.co + oo;        // + p * a * co
+    const size_t zs = (size_t)A.a * A.co;
+    float best = -INFINITY;
+    int bestp = 0;
+    for (int p0 = 0; p0 < A.p; p0 += PT) {
+        __syncthreads();
+        if (t < PT) {
+            float e[3] = {0.f, 0.f, 0.f};
+            if (p0 + t < A.p) {
+                PnArgs X = {};
+                X.xyz = A.xyz; X.anchors = A.anchors; X.p = A.p;
+                ext_xyz(X, bb, ai, p0 + t, ctr, e);
+            }
+            Es[t][0] = e[0]; Es[t][1] = e[1]; Es[t][2] = e[2];
+        }
+        __syncthreads();
+        const int np = min(PT, A.p - p0);
+        int i = 0;
+        for (; i + 8 <= np; i += 8) {          // eight rows in flight
+            float v[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) v[u] = z[(size_t)(p0 + i + u) * zs];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const float w = v[u] + bias + w3[0] * Es[i + u][0] + w3[1] * Es[i + u][1] + w3[2] * Es[i + u][2];
+                if (w > best) { best = w; bestp = p0 + i + u; }              // ascending p: first maximum wins
+            }
+        }
+        for (; i < np; ++i) {
+            const float w = z[(size_t)(p0 + i) * zs] + bias + w3[0] * Es[i][0] + w3[1] * Es[i][1] + w3[2] * Es[i][2];
+            if (w > best) { best = w; bestp = p0 + i; }
+        }
+    }
+    if (ok) {
+        const size_t at = ((size_t)bb * A.a + ai) * A.co + o;
+        A.out[at] = best;
+        A.arg[at] = bestp;
+    }
+}
+
+// dZ[b][p][a][o] = arg[b][a][o] == p ? dOut[b][a][o] : 0 -- every element written (no memset), eight channels per thread
+template <typename T>
+__global__ __launch_bounds__(256) void pointnet_dz_kernel(PnMaxArgs A) {
+    const long long oct = (long long)blockIdx.x * 256 + threadIdx.x;
+    const int co8 = A.co >> 3;
+    const long long n = (long long)A.b * A.p * A.a * co8;
+    if (oct >= n) return;
+    const int o = (int)(oct % co8) * 8;
+    const long long row = oct / co8;               // (b, p, a)
+    const int ai = (int)(row % A.a);
+    const long long bp = row / A.a;
+    const int pp = (int)(bp % A.p), bb = (int)(bp / A.p);
+    const size_t at = ((size_t)bb * A.a + ai) * A.co + o;
+    const i32x4 a0 = *reinterpret_cast<const i32x4 *>(A.arg_in + at), a1 = *reinterpret_cast<const i32x4 *>(A.arg_in + at + 4);
+    const f32x4 g0 = *reinterpret_cast<const f32x4 *>(A.gout + at), g1 = *reinterpret_cast<const f32x4 *>(A.gout + at + 4);
+    float v[8];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+        v[u] = a0[u] == pp ? g0[u] : 0.f;
+        v[4 + u] = a1[u] == pp ? g1[u] : 0.f;
+    }
+    T *d = static_cast<T *>(A.dZ) + (size_t)row * A.co + o;
+    if constexpr (sizeof(T) == 2) {
+        bf16x8 h;
+#pragma unroll
+        for (int u = 0; u < 8; ++u) h[u] = (__bf16)v[u];
+        *reinterpret_cast<bf16x8 *>(d) = h;
+    } else {
+        *reinterpret_cast<f32x4 *>(d) = f32x4{v[0], v[1], v[2], v[3]};
+        *reinterpret_cast<f32x4 *>(d + 4) = f32x4{v[4], v[5], v[6], v[7]};
+    }
+}
+
+// dW[o][c + j] = sum_{b,a} dOut[b,a,o] ext_j[b, arg[b,a,o], a], dbias[o] = sum_{b,a} dOut[b,a,o]: one workgroup per output
+// channel, fixed-order tree over its 256 partial sums (deterministic)
+__global__ __launch_bounds__(256) void pointnet_bwd_coord_kernel(PnMaxArgs A) {
+    __shared__ float red[4][256];
+    const int o = blockIdx.x, t = threadIdx.x;
+    const long long nba = (long long)A.b * A.a;
+    float acc[4] = {0.f, 0.f, 0.f, 0.f};
+    PnArgs X = {};
+    X.xyz = A.xyz; X.anchors = A.anchors; X.p = A.p;
+    for (long long q = t; q < nba; q += 256) {
+        const int bb = (int)(q / A.a), ai = (int)(q % A.a);
+        const float g = A.gout[q * A.co + o];
+        const int ps = A.arg_in[q * A.co + o];
+        const float ctr[3] = {A.centre_in[bb * 3], A.centre_in[bb * 3 + 1], A.centre_in[bb * 3 + 2]};
+        float e[3];
+        ext_xyz(X, bb, ai, ps, ctr, e);
+        acc[0] += g * e[0]; acc[1] += g * e[1]; acc[2] += g * e[2]; acc[3] += g;
+    }
+#pragma unroll
+    for (int u = 0; u < 4; ++u) red[u][t] = acc[u];
+    __syncthreads();
+    for (int s = 128; s >= 1; s >>= 1) {
+        if (t < s)
+#pragma unroll
+            for (int u = 0; u < 4; ++u) red[u][t] += red[u][t + s];
+        __syncthreads();
+    }
+    if (t < 3) A.dW[(size_t)o * (A.c + 3) + A.c + t] = red[t][0];
+    if (t == 3 && A.dbias) A.dbias[o] = red[3][0];
+}
+
 PnArgs make_pn(int b, int p, int a, int c, int co) {
     PnArgs A = {};
     A.b = b; A.p = p; A.a = a; A.c = c; A.co = co; A.slices = 1;
@@ -402,6 +546,68 @@ extern "C" int epn_pointnet_so3conv_bwd_weight_f32(const float *grad_out, const 
     const long long nba = (long long)b * a;
     A.slices = (int)(nba < 16 ? nba : 16);
     EPN_LAUNCH(pointnet_bwd_weight_kernel, dim3((unsigned)co, (unsigned)A.slices), dim3(256), 0, st, A);
+    EPN_CHECK_LAUNCH();
+    return 0;
+}
+
+static PnMaxArgs make_pnmax(int b, int p, int a, int c, int co) {
+    PnMaxArgs A = {};
+    A.b = b; A.p = p; A.a = a; A.c = c; A.co = co;
+    return A;
+}
+
+extern "C" int epn_pointnet_max_f32(const float *Z, const float *xyz, const float *anchors, const float *W,
+                                    const float *bias, float *out, int32_t *argmax, float *centre, int b, int p, int a,
+                                    int c, int co, epn_stream_t stream) {
+    int rc = check_pn(b, p, a, c, co);
+    if (rc) return rc;
+    if (b == 0) return 0;
+    if (!Z || !xyz || !W || !out || !argmax || !centre) return EPN_ENULL;
+    PnMaxArgs A = make_pnmax(b, p, a, c, co);
+    A.Z = Z; A.xyz = xyz; A.anchors = anchors; A.W = W; A.bias = bias; A.out = out; A.arg = argmax; A.centre = centre;
+    EPN_LAUNCH(pointnet_max_kernel, dim3((unsigned)(b * a), (unsigned)epn_cdiv(co, 256)), dim3(256), 0, epn_stream(stream), A);
+    EPN_CHECK_LAUNCH();
+    return 0;
+}
+
+static int pn_dz(const float *grad_out, const int32_t *argmax, void *dZ, int b, int p, int a, int co, bool bf16,
+                 epn_stream_t stream) {
+    int rc = check_pn(b, p, a, 1, co);
+    if (rc) return rc;
+    if (co % 8) return EPN_EINVAL;
+    if (b == 0) return 0;
+    if (!grad_out || !argmax || !dZ) return EPN_ENULL;
+    if (((uintptr_t)grad_out | (uintptr_t)argmax | (uintptr_t)dZ) & 15) return EPN_EINVAL;
+    PnMaxArgs A = make_pnmax(b, p, a, 0, co);
+    A.gout = grad_out; A.arg_in = argmax; A.dZ = dZ;
+    const long long n = (long long)b * p * a * (co / 8);
+    if ((n + 255) / 256 > 0x7fffffffLL) return EPN_EINVAL;
+    const dim3 grid((unsigned)((n + 255) / 256));
+    if (bf16) EPN_LAUNCH(pointnet_dz_kernel<__bf16>, grid, dim3(256), 0, epn_stream(stream), A);
+    else EPN_LAUNCH(pointnet_dz_kernel<float>, grid, dim3(256), 0, epn_stream(stream), A);
+    EPN_CHECK_LAUNCH();
+    return 0;
+}
+extern "C" int epn_pointnet_dz_f32(const float *grad_out, const int32_t *argmax, float *dZ, int b, int p, int a, int co,
+                                   epn_stream_t stream) {
+    return pn_dz(grad_out, argmax, dZ, b, p, a, co, false, stream);
+}
+extern "C" int epn_pointnet_dz_bf16(const float *grad_out, const int32_t *argmax, void *dZ, int b, int p, int a, int co,
+                                    epn_stream_t stream) {
+    return pn_dz(grad_out, argmax, dZ, b, p, a, co, true, stream);
+}
+
+extern "C" int epn_pointnet_bwd_coord_f32(const float *grad_out, const int32_t *argmax, const float *xyz,
+                                          const float *anchors, const float *centre, float *grad_W, float *grad_bias,
+                                          int b, int p, int a, int c, int co, epn_stream_t stream) {
+    int rc = check_pn(b, p, a, c, co);
+    if (rc) return rc;
+    if (!grad_W) return EPN_ENULL;
+    if (b > 0 && (!grad_out || !argmax || !xyz || !centre)) return EPN_ENULL;
+    PnMaxArgs A = make_pnmax(b, p, a, c, co);
+    A.gout = grad_out; A.arg_in = argmax; A.xyz = xyz; A.anchors = anchors; A.centre_in = centre; A.dW = grad_W;
+    A.dbias = grad_bias;
+    EPN_LAUNCH(pointnet_bwd_coord_kernel, dim3((unsigned)co), dim3(256), 0, epn_stream(stream), A);   // b == 0: writes zeros
     EPN_CHECK_LAUNCH();
     return 0;
 }

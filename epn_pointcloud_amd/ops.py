@@ -1719,6 +1719,87 @@ def linear(x, weight, bias=None):
     return y if bias is None else y + bias
 
 
+class PointnetSO3ConvGemmFn(torch.autograd.Function):
+    """PointnetSO3Conv.forward (vgtk/vgtk/so3conv/modules.py:219-235) composed with the library's GEMMs (csrc/pointnet.hip,
+    "GEMM-composed form"): Z = F W[:, :c]^T on the matrix pipe of the features' dtype (fp32 result), then one streaming pass
+    adds the three coordinate channels and the bias and takes the max / arg-max over points.  Backward: the gradient routed
+    through the arg-max point as a dense dZ, dF = dZ W and dW[:, :c] = dZ^T F as GEMMs, coordinate columns and bias by a
+    small fixed-order reduction.  Same semantics as PointnetSO3ConvFn (first maximum wins)."""
+
+    @staticmethod
+    def forward(ctx, feats, xyz, anchors, weight, bias):
+        lib = _lib.get_lib()
+        fc = to_cl(feats, "feats")
+        b, c, p, a = fc.shape
+        co = weight.shape[0]
+        if weight.numel() != co * (c + 3):
+            raise ValueError(f"embed weight must be [co, c+3, 1, 1] with c={c}, got {tuple(weight.shape)}")
+        if tuple(xyz.shape) != (b, 3, p):
+            raise ValueError(f"xyz must be [b,3,p]=({b},3,{p}), got {tuple(xyz.shape)}")
+        w = weight.reshape(co, c + 3).contiguous().float()
+        xyz = xyz.contiguous()
+        anc = anchors.contiguous() if (anchors is not None and a > 1) else None
+        F2 = fc.permute(0, 2, 3, 1).reshape(b * p * a, c)            # view of the channels-last buffer
+        wc = gemm.cast(w[:, :c].contiguous(), fc.dtype)              # [co, c] in the features' dtype
+        Z = _launch("pointnet_fwd", ("pointnet", b, p, a, c, co), 2.0 * b * p * a * co * (c + 3), fc.device,
+                    lambda: gemm.gemm_nt(F2, wc, out_dtype=torch.float32))
+        out = torch.empty((b, a, co), dtype=torch.float32, device=fc.device)
+        arg = torch.empty((b, a, co), dtype=torch.int32, device=fc.device)
+        ctr = torch.empty((b, 3), dtype=torch.float32, device=fc.device)
+        bs = bias.contiguous().float() if bias is not None else None
+        _lib.check(lib.epn_pointnet_max_f32(_lib.dev_ptr(Z, "Z"), _lib.dev_ptr(xyz, "xyz"), _lib.dev_ptr(anc, "anchors"),
+                                            _lib.dev_ptr(w, "weight"), _lib.dev_ptr(bs, "bias"), _lib.dev_ptr(out, "out"),
+                                            _lib.dev_ptr(arg, "argmax", torch.int32), _lib.dev_ptr(ctr, "centre"),
+                                            b, p, a, c, co, _lib.stream_of(fc)), "pointnet_max")
+        ctx.save_for_backward(fc, xyz, anc, w, wc, arg, ctr)
+        ctx.cfg = (b, p, a, c, co, tuple(weight.shape), bias is not None, weight.dtype)
+        return out.permute(0, 2, 1)
+
+    @staticmethod
+    def backward(ctx, grad_out):
+        lib = _lib.get_lib()
+        fc, xyz, anc, w, wc, arg, ctr = ctx.saved_tensors
+        b, p, a, c, co, wshape, has_bias, wdtype = ctx.cfg
+        g = grad_out.permute(0, 2, 1).contiguous().float()          # [b][a][co]
+        st = _lib.stream_of(fc)
+        need_f = ctx.needs_input_grad[0]
+        need_w = ctx.needs_input_grad[3] or (has_bias and ctx.needs_input_grad[4])
+        dF = dW = db = None
+        dZ = torch.empty((b * p * a, co), dtype=fc.dtype, device=fc.device)
+        dz = lib.epn_pointnet_dz_bf16 if fc.dtype == torch.bfloat16 else lib.epn_pointnet_dz_f32
+        _lib.check(dz(_lib.dev_ptr(g, "grad_out"), _lib.dev_ptr(arg, "argmax", torch.int32),
+                      ctypes.c_void_p(dZ.data_ptr()), b, p, a, co, st), "pointnet_dz")
+        F2 = fc.permute(0, 2, 3, 1).reshape(b * p * a, c)
+        if need_f:
+            dF = empty_cl(b, c, p, a, fc.device, fc.dtype)
+            dF2 = dF.permute(0, 2, 3, 1).reshape(b * p * a, c)
+            wt = gemm.transpose_cast(w[:, :c].contiguous(), fc.dtype)   # [c, co]: dF = dZ W as an NT GEMM
+            _launch("pointnet_bwd_data", ("pointnet", b, p, a, c, co), 2.0 * b * p * a * co * c, fc.device,
+                    lambda: gemm.gemm_nt(dZ, wt, out=dF2))
+        if need_w:
+            dW = torch.empty((co, c + 3), dtype=torch.float32, device=fc.device)
+            db = torch.empty(co, dtype=torch.float32, device=fc.device) if has_bias else None
+            _launch("pointnet_bwd_weight", ("pointnet", b, p, a, c, co), 2.0 * b * p * a * co * c, fc.device,
+                    lambda: gemm.gemm_tn(dZ, F2, out=dW[:, :c]))
+            _lib.check(lib.epn_pointnet_bwd_coord_f32(_lib.dev_ptr(g, "grad_out"), _lib.dev_ptr(arg, "argmax", torch.int32),
+                                                      _lib.dev_ptr(xyz, "xyz"), _lib.dev_ptr(anc, "anchors"),
+                                                      _lib.dev_ptr(ctr, "centre"), _lib.dev_ptr(dW, "grad_W"),
+                                                      _lib.dev_ptr(db, "grad_bias"), b, p, a, c, co, st),
+                       "pointnet_bwd_coord")
+            dW = dW.view(wshape).to(wdtype)
+        return dF, None, None, dW, db
+
+
 def pointnet_so3conv(feats, xyz, anchors, weight, bias):
-    """bf16 features are converted once (the aggregation tail is < 1 % of a step and runs its fp32 kernels)."""
+    """The GEMM-composed form for feature widths the GEMM kernels take (c % 16 == 0, co % 8 == 0) and at least 16 k feature
+    rows, in the features' own dtype (classification / rotation heads, 122 880 rows: rotation network 1794-1809 -> 1850
+    clouds/s in an A/B on one box; the 3DMatch head has 4096 rows and its six extra launches cost more than they save);
+    otherwise, and with EPN_POINTNET=fused, the fused fp32 kernels (bf16 features converted once).  EPN_POINTNET=gemm forces
+    the composed form wherever the widths allow."""
+    c, co = feats.shape[1], weight.shape[0]
+    form = os.environ.get("EPN_POINTNET", "auto")
+    rows = feats.shape[0] * feats.shape[2] * feats.shape[3]
+    if (feats.is_cuda and c % 16 == 0 and co % 8 == 0 and feats.dtype in FEATURE_DTYPES and form != "fused"
+            and (form == "gemm" or rows >= 16384)):
+        return PointnetSO3ConvGemmFn.apply(feats, xyz, anchors, weight, bias)
     return PointnetSO3ConvFn.apply(cast_feats(feats, torch.float32), xyz, anchors, weight, bias)

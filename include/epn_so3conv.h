@@ -426,6 +426,30 @@ int epn_pointnet_so3conv_bwd_weight_f32(const float *grad_out, const int32_t *ar
                                         const float *xyz, const float *anchors, const float *centre, float *grad_W,
                                         float *grad_bias, int b, int p, int a, int c, int co, epn_stream_t stream);
 
+/* PointnetSO3Conv composed with the library's GEMMs (same module, vgtk/vgtk/so3conv/modules.py:219-235; the form the
+ * benchmarked networks run for c % 16 == 0): the caller forms the embedding's feature part with epn_gemm_nt_*
+ *     Z[b][p][a][o] = sum_c W[o][c] F[b][p][a][c]          (rows = the channels-last feature rows; fp32 result)
+ * and these entries do the rest.
+ *   epn_pointnet_max_f32:  out[b][a][o] = max_p (Z + sum_j W[o][c+j] ext_j[b][p][a] + bias[o]), argmax = first maximum,
+ *                          centre[b][3] = mean_p xyz (ext = R_a^T (xyz - centre); anchors NULL: identity).  W is the
+ *                          full [co][c+3] weight, of which only the three coordinate columns are read.
+ *   epn_pointnet_dz_*:     dZ[b][p][a][o] = argmax[b][a][o] == p ? grad_out[b][a][o] : 0 (every element written;
+ *                          co % 8 == 0, 16-byte aligned pointers) -- then dF = dZ W (epn_gemm_nt_*), dW[:, :c] = dZ^T F
+ *                          (epn_gemm_tn_*).  _bf16: dZ in bf16 for bf16 features.
+ *   epn_pointnet_bwd_coord_f32: grad_W[o][c + j] = sum_{b,a} grad_out ext_j[b][argmax][a] (the other columns of the
+ *                          [co][c+3] buffer are not touched), grad_bias[o] = sum_{b,a} grad_out (may be NULL); fixed
+ *                          summation order. */
+int epn_pointnet_max_f32(const float *Z, const float *xyz, const float *anchors, const float *W, const float *bias,
+                         float *out, int32_t *argmax, float *centre, int b, int p, int a, int c, int co,
+                         epn_stream_t stream);
+int epn_pointnet_dz_f32(const float *grad_out, const int32_t *argmax, float *dZ, int b, int p, int a, int co,
+                        epn_stream_t stream);
+int epn_pointnet_dz_bf16(const float *grad_out, const int32_t *argmax, void *dZ, int b, int p, int a, int co,
+                         epn_stream_t stream);
+int epn_pointnet_bwd_coord_f32(const float *grad_out, const int32_t *argmax, const float *xyz, const float *anchors,
+                               const float *centre, float *grad_W, float *grad_bias, int b, int p, int a, int c, int co,
+                               epn_stream_t stream);
+
 /* ---------------------------------------------------------------------------------------------------------------------
  * vgtk.cuda.zpconv: grouping functions of the legacy ZPConv path (unreachable from the shipped models,
  * provided for API completeness).  Layouts are the reference's (channel-major, contiguous).

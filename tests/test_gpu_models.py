@@ -46,12 +46,15 @@ def test_pointnet_vs_reference_golden(gpu, tag):
     assert (dB.cpu() - T(g["dB"])).abs().max().item() < TOL
 
 
+@pytest.mark.parametrize("form", ["gemm", "fused"])
 @pytest.mark.parametrize("b,c,co,p,na", [(2, 128, 128, 64, 60), (1, 70, 200, 33, 60), (3, 16, 8, 129, 1),
-                                         (2, 256, 300, 40, 12)])
-def test_pointnet_vs_oracle(gpu, b, c, co, p, na):
-    """Tile edges: channels not a multiple of the 64-channel tile, more than 128 outputs, ragged point counts."""
+                                         (2, 256, 300, 40, 12), (2, 256, 304, 40, 12), (4, 64, 40, 70, 60)])
+def test_pointnet_vs_oracle(gpu, monkeypatch, form, b, c, co, p, na):
+    """Tile edges: channels not a multiple of the 64-channel tile, more than 128 outputs, ragged point counts.  Both forms:
+    the GEMM-composed one (c % 16 == 0 and co % 8 == 0; the others fall back) and the fused fp32 kernels."""
     from oracle import so3conv_ref as R
     from epn_pointcloud_amd import ops
+    monkeypatch.setenv("EPN_POINTNET", form)
     rng = np.random.default_rng(b * 1000 + c)
     torch.manual_seed(c)
     xyz = T(unit_ball_cloud(rng, b, p))
@@ -67,6 +70,34 @@ def test_pointnet_vs_oracle(gpu, b, c, co, p, na):
     assert (y.detach().cpu() - yr.detach()).abs().max().item() < TOL
     for u, v, n in zip(got, ref, ("dF", "dW", "dB")):
         assert (u.cpu() - v).abs().max().item() < TOL * max(1.0, v.abs().max().item()), n
+
+
+def test_pointnet_bf16_features(gpu):
+    """bf16 features go through the GEMM-composed form in bf16 (bf16 matrix pipe, fp32 accumulate, bf16 dZ / dF): against
+    the fp32 oracle on the bf16-rounded inputs, within bf16 rounding of the operands; the arg-max may move between
+    near-ties, so the gradients are compared in rel-L2."""
+    from oracle import so3conv_ref as R
+    from epn_pointcloud_amd import ops
+    b, c, co, p, na = 2, 128, 128, 64, 60
+    rng = np.random.default_rng(11)
+    torch.manual_seed(11)
+    xyz = T(unit_ball_cloud(rng, b, p))
+    f = torch.randn(b, c, p, na).bfloat16().float()
+    anchors = torch.linalg.qr(torch.randn(na, 3, 3))[0].contiguous()
+    w = (torch.randn(co, c + 3, 1, 1) / (c ** 0.5))
+    w[:, :c] = w[:, :c].bfloat16().float()
+    bias, gy = torch.randn(co), torch.randn(b, co, na)
+    fr, wr, br = f.clone().requires_grad_(True), w.clone().requires_grad_(True), bias.clone().requires_grad_(True)
+    yr = R.pointnet_so3conv(xyz, fr, anchors, wr, br)
+    ref = torch.autograd.grad(yr, [fr, wr, br], gy)
+    fg = f.to(gpu).bfloat16().requires_grad_(True)
+    wg, bg = (t.to(gpu).requires_grad_(True) for t in (w, bias))
+    y = ops.pointnet_so3conv(fg, xyz.to(gpu), anchors.to(gpu), wg, bg)
+    got = torch.autograd.grad(y, [fg, wg, bg], gy.to(gpu))
+    assert y.dtype == torch.float32 and got[0].dtype == torch.bfloat16 and got[1].dtype == torch.float32
+    assert (y.detach().cpu() - yr.detach()).abs().max().item() < 1e-4 * max(1.0, yr.abs().max().item())
+    for u, v, n, tol in zip(got, ref, ("dF", "dW", "dB"), (1e-2, 1e-2, 1e-5)):
+        assert ((u.float().cpu() - v).norm() / v.norm()).item() < tol, n
 
 
 def test_pointnet_rejects_bad_arguments(gpu):
