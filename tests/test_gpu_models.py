@@ -109,6 +109,28 @@ def test_pointnet_rejects_bad_arguments(gpu):
         ops.pointnet_so3conv(f, torch.randn(1, 3, 5, device=gpu), None, torch.randn(4, 8, 1, 1, device=gpu), None)
     with pytest.raises(RuntimeError):
         ops.pointnet_so3conv(f.cpu(), torch.randn(1, 3, 5), None, torch.randn(4, 11, 1, 1), None)
+    # the same checks in front of the GEMM-composed form (c % 16 == 0, co % 8 == 0), and its C entries' own
+    monkey = pytest.MonkeyPatch()
+    monkey.setenv("EPN_POINTNET", "gemm")
+    try:
+        f16 = torch.randn(1, 16, 5, 4, device=gpu)
+        with pytest.raises(ValueError):
+            ops.pointnet_so3conv(f16, torch.randn(1, 3, 6, device=gpu), None, torch.randn(8, 19, 1, 1, device=gpu), None)
+        with pytest.raises(ValueError):
+            ops.pointnet_so3conv(f16, torch.randn(1, 3, 5, device=gpu), None, torch.randn(8, 16, 1, 1, device=gpu), None)
+    finally:
+        monkey.undo()
+    import ctypes
+    from epn_pointcloud_amd import _lib
+    lib = _lib.get_lib()
+    g = torch.zeros(1, 4, 12, device=gpu)
+    a = torch.zeros(1, 4, 12, dtype=torch.int32, device=gpu)
+    dz = torch.zeros(5 * 4 * 12, device=gpu)
+    vp = lambda t: ctypes.c_void_p(t.data_ptr())
+    assert lib.epn_pointnet_dz_f32(vp(g), vp(a), vp(dz), 1, 5, 4, 12, None) == -1     # EPN_EINVAL: co % 8 != 0
+    assert lib.epn_pointnet_dz_f32(vp(g), None, vp(dz), 1, 5, 4, 8, None) == -3
+    assert lib.epn_pointnet_max_f32(None, vp(g), None, vp(g), None, vp(g), vp(a), vp(g), 1, 5, 4, 16, 8, None) == -3
+    assert lib.epn_pointnet_bwd_coord_f32(vp(g), vp(a), vp(g), None, vp(g), None, None, 1, 5, 4, 16, 8, None) == -3
 
 
 def _set_glue(model, fused):
