@@ -293,6 +293,9 @@ __device__ __forceinline__ void split3(const float (&x)[8], bf16x8 &h, bf16x8 &m
 #ifndef EPN_TN_GROUP_TARGET_BF16
 #define EPN_TN_GROUP_TARGET_BF16 768
 #endif
+#ifndef EPN_TN_GROUP_TARGET_F32
+#define EPN_TN_GROUP_TARGET_F32 1024
+#endif
 #ifndef EPN_TN_SINGLE_TARGET_BF16
 #define EPN_TN_SINGLE_TARGET_BF16 512
 #endif
@@ -1334,9 +1337,15 @@ size_t tn_plan(GemmTnBatch &B, int *bn1_out, int *bn2_out, void *ws, bool x3 = f
     if (B.nprob == 1) {
         B.p[0].nsplit = gemm_tn_splits(bf, B.p[0].R, B.p[0].N1, B.p[0].N2);
     } else {
-        // smallest steps-per-workgroup S (>= 8) whose launch fits `target` workgroups (whole rounds of the 256 CUs: these
-        // tiles take a CU's LDS each); every problem gets ceil(chunks / S) splits
-        const long long target = bf == 1 ? EPN_TN_GROUP_TARGET_BF16 : 256;   // one round: fewer, longer workgroups = fewer partial slabs (256/512/1024/2048: 6.2/6.7/7.4/7.9 ms per step)
+        // smallest steps-per-workgroup S (>= 8) whose launch fits `target` workgroups; every problem gets ceil(chunks / S)
+        // splits.  The five problems of a group are ragged (d = 1, 3, 3, 4, 5 times the rows AND the width): with ONE round
+        // of 256 workgroups the launch ends when its longest ones do (76 % of the CU-time used, SQ_BUSY / GRBM 3.1 against
+        // 3.85 for the single-problem kernels); several rounds of shorter workgroups fill in behind each other.  fp32 groups,
+        // cold (tools/tn_probe.py), 256 / 384 / 512 / 768 / 1024 / 1536 / 2048 workgroups: c = 64: 0.64 / 0.49 / 0.52 / 0.42 /
+        // 0.43 / 0.45 / 0.48 ms, c = 128: 0.84 / 0.67 / 0.71 / 0.60 / 0.61 / 0.64 / 0.67, c = 256: 0.98 / 1.03 / 0.91 / 0.97 /
+        // 0.94 / 0.97 / 1.00.  (Round 2 measured the opposite, 6.2 / 6.7 / 7.4 / 7.9 ms per step for 256 / 512 / 1024 / 2048:
+        // that was the cost of its slab reduction, one thread per output quad walking every slab -- gemm_tn_reduce_sp_kernel.)
+        const long long target = bf == 1 ? EPN_TN_GROUP_TARGET_BF16 : EPN_TN_GROUP_TARGET_F32;
         long long S = 8;
         for (long long cand = 8; cand <= 8192; ++cand) {
             long long blocks = 0;
