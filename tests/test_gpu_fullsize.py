@@ -266,3 +266,39 @@ def test_onchip_inter_conv_full_size_slice_vs_oracle(gpu, vgtk_alias, pyramid, l
     _, _, _, _, oy = R.inter_so3conv(xyz[PICK].cpu(), feats[PICK].cpu(), W.cpu(), conv.anchors.cpu(), conv.kernels.cpu(),
                                      l.stride, l.radius, l.sigma, l.nn, l.lazy)
     assert (y[PICK].cpu() - oy).abs().max().item() < TOL
+
+
+@pytest.mark.parametrize("dt", [torch.float32, torch.bfloat16])
+def test_pointnet_head_at_production_size(gpu, monkeypatch, dt):
+    """The aggregation head of the classification / rotation networks at its production size (32 clouds x 64 points x 60
+    anchors, 256 -> 256 channels: 122 880 feature rows).  The GEMM-composed form (what the benchmark runs) against the
+    oracle on two clouds (fp32: 1e-3, north_star) and against the fused fp32 kernels on the whole batch: outputs within
+    fp32 / bf16 rounding; gradients in rel-L2 -- the two forms sum in different orders, so a few of the 491 520 maxima
+    over 64 points flip between near-tied points and move whole gradient rows (3.5e-3 rel-L2 measured in fp32)."""
+    from epn_pointcloud_amd import ops
+    b, c, co, p, na = 32, 256, 256, 64, 60
+    g = torch.Generator().manual_seed(5)
+    xyz = (torch.rand(b, 3, p, generator=g) - 0.5)
+    f = torch.randn(b, c, p, na, generator=g).to(dt).float()
+    anchors = torch.linalg.qr(torch.randn(na, 3, 3, generator=g))[0].contiguous()
+    w = torch.randn(co, c + 3, 1, 1, generator=g) / (c ** 0.5)
+    if dt == torch.bfloat16:
+        w[:, :c] = w[:, :c].bfloat16().float()
+    bias, gy = torch.randn(co, generator=g), torch.randn(b, co, na, generator=g)
+
+    def run(form, dtype):
+        monkeypatch.setenv("EPN_POINTNET", form)
+        fg = f.to(gpu).to(dtype).requires_grad_(True)
+        wg, bg = w.to(gpu).requires_grad_(True), bias.to(gpu).requires_grad_(True)
+        y = ops.pointnet_so3conv(fg, xyz.to(gpu), anchors.to(gpu), wg, bg)
+        return [y.detach().float().cpu()] + [t.float().cpu() for t in torch.autograd.grad(y, [fg, wg, bg], gy.to(gpu))]
+
+    got = run("gemm", dt)
+    ref = run("fused", torch.float32)                # the fused kernels take fp32 features (the same bf16-rounded values)
+    tol = 1e-3 if dt == torch.float32 else 2e-3
+    assert (got[0] - ref[0]).abs().max().item() < tol
+    for u, v, n in zip(got[1:], ref[1:], ("dF", "dW", "dB")):
+        assert ((u - v).norm() / v.norm()).item() < (1e-2 if dt == torch.float32 else 3e-2), n
+    # oracle on two clouds (fp32 forward value)
+    yo = R.pointnet_so3conv(xyz[PICK], f[PICK], anchors, w, bias)
+    assert (got[0][PICK] - yo).abs().max().item() < tol
