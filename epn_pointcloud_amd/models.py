@@ -12,6 +12,8 @@ and Linear layers (attention logits, class logits, the pair head's 60 x 60 ancho
 (ops.conv1x1 / ops.linear).  What remains on torch are elementwise tails on [b, c, a]-sized tensors (BatchNorm1d,
 softmax, relu).
 """
+import os
+
 import torch
 import torch.nn as nn
 import torch.nn.functional as F
@@ -151,11 +153,15 @@ class _SO3ConvModel(nn.Module):
         self.na_in = kanchor
         self.invariance = True
 
+    HEAD_TAKES_BF16 = False     # the head's first operation is PointnetSO3Conv, which reads bf16 features itself
+
     def features(self, pts):
         x = S.preprocess_input(pts, self.na_in)
         for stage in self.backbone:
             x = stage(x)
-        if x.feats.dtype != torch.float32:          # bf16 feature path: the heads run in fp32 (their inputs are small)
+        if x.feats.dtype != torch.float32 and not (self.HEAD_TAKES_BF16 and x.feats.is_cuda
+                                                   and os.environ.get("EPN_HEAD_BF16", "1") == "1"):
+            # bf16 feature path: the heads run in fp32 (their inputs are small)
             x = zptk.SphericalPointCloud(x.xyz, ops.cast_feats(x.feats, torch.float32), x.anchors)
         return x
 
@@ -195,6 +201,8 @@ class RegSO3ConvModel(_SO3ConvModel):
     """forward(x [b, 2, n, 3]) -> (confidence [b, na, na], rotations [b, 4 | 6, na, na]); the two clouds of a pair go
     through the backbone as one batch of 2b (reg_so3net.py:31-33)."""
     MODEL = "reg"
+    HEAD_TAKES_BF16 = True      # RelSO3OutBlockR starts with PointnetSO3Conv: bf16 GEMMs on the bf16 features, fp32 from its
+                                # max over points onwards (ops.pointnet_so3conv; its fused fall-back converts by itself)
 
     def __init__(self, layers, out_mlps=(256, 128, 64), kanchor=60, representation='quat', temperature=3.0,
                  fused_glue=True, dropout_rate=0.0):
