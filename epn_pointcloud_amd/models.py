@@ -121,8 +121,22 @@ class RelSO3OutBlockR(nn.Module):
         return F.relu(self.pointnet(zptk.SphericalPointCloud(xyz, feats, None)))
 
     def forward(self, f1, f2, x1, x2):
+        # bf16 feature networks: the 60 x 60 anchor-pair tensor ([b, 2c, a, a]: 115 200 rows x 512 channels, the largest
+        # tensor of the head) and its 1x1 MLP follow the backbone's storage format -- bf16 values, fp32 accumulation in the
+        # GEMMs, fp32 again from the two output convolutions on (softmax, rotation regressor); EPN_REG_MLP_BF16=0: all fp32
+        low = f1.dtype == torch.bfloat16 and f1.is_cuda and os.environ.get("EPN_REG_MLP_BF16", "1") == "1"
         f1, f2 = self._pooling(x1, f1), self._pooling(x2, f2)
         nb, _, na = f1.shape
+        if low:
+            f1t, f2t = f1.permute(0, 2, 1).bfloat16(), f2.permute(0, 2, 1).bfloat16()
+            pair = torch.cat((f1t.unsqueeze(1).expand(-1, na, -1, -1), f2t.unsqueeze(2).expand(-1, -1, na, -1)), 3)
+            pair = pair.permute(0, 3, 1, 2)
+            for lin in self.linear:
+                pair = F.relu(ops.conv1x1(pair, lin.weight.flatten(1)) + lin.bias.to(pair.dtype).view(1, -1, 1, 1))
+            att = ops.conv1x1(pair, self.attention_layer.weight.flatten(1)).float() + self.attention_layer.bias.view(1, -1, 1, 1)
+            confidence = F.softmax(att.reshape(nb, na, na) * self.temperature, dim=1)
+            y = ops.conv1x1(pair, self.regressor_layer.weight.flatten(1)).float() + self.regressor_layer.bias.view(1, -1, 1, 1)
+            return confidence, y
         if f1.is_cuda:
             # the reference's pair tensor cat(f1[b,:,None,j], f2[b,:,i,None]) built directly channels-last ([b][i][j][2c]),
             # so that the 1x1 MLP on the 60 x 60 anchor pairs is a chain of NT GEMMs on this library's kernels (through
