@@ -1674,8 +1674,12 @@ def conv1x1(x, weight, bias=None, col_stats=False):
         xc = to_cl(x)                   # K = cin is a whole number of 64-byte half K steps: the MFMA GEMM kernels
         b, c, p, a = xc.shape
         w2 = weight.reshape(cout, cin)
-        pad = (-cout) % 8               # the weight-gradient (TN) kernels want output widths that are whole 16-byte
-        if pad:                         # groups: zero rows are appended (a 1- or 4-channel head), sliced off again
+        # output widths padded with zero rows (a 1- or 4-channel head), sliced off again: the data-gradient GEMM contracts
+        # over cout and takes the MFMA kernels only for whole 64-byte half K steps (32 bf16 / 16 fp32 values) -- padded to 8
+        # (what the weight-gradient kernels need) the two output convolutions of the rotation head ran their data
+        # gradients on the any-shape kernel, 0.07 ms each
+        pad = (-cout) % (32 if x.dtype == torch.bfloat16 else 16)
+        if pad:
             w2 = torch.cat((w2, w2.new_zeros(pad, cin)), 0)
         if col_stats and not pad and bias is None:
             y2d, part = gemm.matmul_nt(xc.permute(0, 2, 3, 1).reshape(-1, c), w2, True)
