@@ -206,6 +206,8 @@ def short_kernel(name):
                             or ("bf16" if tok.group(3) else "float" if tok.group(4) else "double"))
         return base + ("<" + ",".join(args) + ">" if args else "")
     name = norm_kernel_name(name)
+    # (the C++ demangler predates 'DF16b' = __bf16 and renders some instances as 'bool _Accum': display only)
+    name = name.replace("bool _Accum", "bf16")
     for pre in ("epn::", "at::native::", "at::cuda::"):
         name = name.replace(pre, "")
     return name.replace(", ", ",")[:72]
