@@ -279,10 +279,18 @@ class InterSO3ConvFn(torch.autograd.Function):
         if ctx.needs_input_grad[1] and ctx.grouped is not None:
             gW = torch.empty_like(Wc)
             fl = 2.0 * d.b * d.p2 * d.na * cout * d.ks
-            _lib.check(_launch("inter_bwd_weight_c1", _inter_key(d), fl, f.device,
-                               lambda: lib.epn_inter_so3conv_bwd_weight_c1_f32(ctypes.byref(d), ctx.grouped.data_ptr(), _cl_ptr(g),
-                                                                               _lib.dev_ptr(gW, "grad_W"), _lib.stream_of(f))),
-                       "inter_so3conv_bwd_weight_c1")
+            if os.environ.get("EPN_C1_DW", "gemm") == "gemm" and g.dtype == torch.float32:
+                # dW[o][k] = sum_col dOut[col][o] G[col][k] is a tall-skinny weight-gradient GEMM (2e6 x 32 x 24): the
+                # library's TN kernels stream it at 3-4.5 TB/s, the dedicated kernel (one unpipelined stage per
+                # workgroup, 1536 atomics each) ran at 0.7 TB/s
+                _launch("inter_bwd_weight_c1", _inter_key(d), fl, f.device,
+                        lambda: gemm.gemm_tn(g.permute(0, 2, 3, 1).reshape(-1, cout), ctx.grouped, out=gW))
+            else:
+                _lib.check(_launch("inter_bwd_weight_c1", _inter_key(d), fl, f.device,
+                                   lambda: lib.epn_inter_so3conv_bwd_weight_c1_f32(ctypes.byref(d), ctx.grouped.data_ptr(),
+                                                                                   _cl_ptr(g), _lib.dev_ptr(gW, "grad_W"),
+                                                                                   _lib.stream_of(f))),
+                           "inter_so3conv_bwd_weight_c1")
         elif ctx.needs_input_grad[1]:
             gW = torch.empty_like(Wc)
             _lib.check(_launch("inter_bwd_weight", _inter_key(d), _inter_flops(d), f.device,

@@ -1032,7 +1032,7 @@ def test_norm_act_pair_vs_torch(gpu, c, inst_b, affine_b, dt):
         assert torch.allclose(nb.running_var, nb_ref.running_var, atol=1e-4)
 
 
-@pytest.mark.parametrize("cout,K,n", [(32, 32, 200), (64, 16, 96), (16, 64, 130)])
+@pytest.mark.parametrize("cout,K,n", [(32, 32, 200), (64, 16, 96), (16, 64, 130), (32, 64, 256)])   # last: columns % 32 == 0 (tiled TN GEMM)
 def test_first_layer_weight_gradient_from_saved_grouped_values(gpu, vgtk_alias, monkeypatch, cout, K, n):
     """cin = 1 (InterSO3Conv(1 -> cout), the first layer of every model): the forward pass keeps the ks grouped values of every
     column (epn_inter_so3conv_fwd_c1_f32) and the weight gradient contracts the output gradient with them
@@ -1056,8 +1056,9 @@ def test_first_layer_weight_gradient_from_saved_grouped_values(gpu, vgtk_alias, 
     W = torch.randn(cout, 24, device=gpu)
     gout = torch.randn(b, cout, n // 2, 60, device=gpu)
 
-    def run(save):
+    def run(save, dw="gemm"):
         monkeypatch.setenv("EPN_C1_SAVE", "1" if save else "0")
+        monkeypatch.setenv("EPN_C1_DW", dw)        # default: the library's TN GEMM over the saved values; "kernel": dedicated
         w = W.clone().requires_grad_(True)
         out = ops.InterSO3ConvFn.apply(feats, w, geo)
         out.backward(gout)
@@ -1065,8 +1066,10 @@ def test_first_layer_weight_gradient_from_saved_grouped_values(gpu, vgtk_alias, 
 
     o1, g1 = run(True)
     o0, g0 = run(False)
-    assert torch.equal(o0, o1)
+    o3, g3 = run(True, "kernel")
+    assert torch.equal(o0, o1) and torch.equal(o3, o1)
     assert (g0 - g1).abs().max().item() <= 1e-5 * g0.abs().max().item()
+    assert (g3 - g1).abs().max().item() <= 1e-5 * g0.abs().max().item()
     with torch.no_grad():                      # inference: nothing is kept
         o2 = ops.InterSO3ConvFn.apply(feats, W, geo)
     assert torch.equal(o2, o1)
