@@ -162,7 +162,8 @@ extern "C" int epn_inter_so3conv_fwd_f32(const epn_inter_desc *d, const float *f
         return launch_inter_fwd_mfma(d, base + ws.rk4_off, base + ws.beta_off, feats_cl, W, out_cl, st);
     }
     if (inter_c1_fwd_ok(d) && !force_generic())
-        return launch_inter_c1_fwd(d, base + ws.rk_off, feats_cl, W, out_cl, st);
+        return launch_inter_c1_fwd(d, base + ws.rk_off, feats_cl, W, out_cl, st, nullptr,
+                                   reinterpret_cast<unsigned *>(base + ws.beta_off));   // (beta table: unused by cin = 1)
     float *G = base + ws.big_off;
     rc = launch_inter_group(d, base + ws.rk_off, feats_cl, G, st);
     if (rc) return rc;
@@ -183,7 +184,8 @@ extern "C" int epn_inter_so3conv_fwd_c1_f32(const epn_inter_desc *d, const float
     if (rc) return rc;
     if (!feats_cl || !W || !out_cl) return EPN_ENULL;
     if (d->b == 0 || d->p2 == 0) return 0;
-    return launch_inter_c1_fwd(d, base + ws.rk_off, feats_cl, W, out_cl, st, grouped);
+    return launch_inter_c1_fwd(d, base + ws.rk_off, feats_cl, W, out_cl, st, grouped,
+                               reinterpret_cast<unsigned *>(base + ws.beta_off));       // (beta table: unused by cin = 1)
 }
 extern "C" int epn_inter_so3conv_bwd_weight_c1_f32(const epn_inter_desc *d, const float *grouped, const float *grad_out_cl,
                                                    float *grad_W, epn_stream_t stream) {

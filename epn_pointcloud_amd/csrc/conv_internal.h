@@ -52,7 +52,7 @@ int launch_intra_bwd_weight_generic(const float *feats, const float *dOut, const
 bool inter_c1_fwd_ok(const epn_inter_desc *d);
 bool inter_c1_bwd_weight_ok(const epn_inter_desc *d);
 int launch_inter_c1_fwd(const epn_inter_desc *d, const float *rk, const float *feats, const float *W, float *out,
-                        hipStream_t st, float *grouped_save = nullptr);
+                        hipStream_t st, float *grouped_save = nullptr, unsigned *flag = nullptr);   // flag: 4 B of workspace
 int launch_inter_c1_bwd_weight(const epn_inter_desc *d, const float *rk, const float *feats, const float *dOut,
                                float *dW, hipStream_t st, const float *grouped_saved = nullptr);
 

@@ -25,6 +25,7 @@ struct C1Args {
     int p1, p2, nn, na, ks, cout;
     long long ncol;
     int groups_per_wg;
+    unsigned *flag;       // fwd, optional: 0 = the features do not depend on the anchor (matrix-pipe kernel runs), else the VALU kernel
 };
 
 // grouped values of one column into g[0..ks)
@@ -106,6 +107,7 @@ __device__ __forceinline__ void group_column(const C1Args &A, long long col, flo
 
 __global__ __launch_bounds__(256) void inter_c1_fwd_kernel(C1Args A) {
     extern __shared__ __attribute__((aligned(16))) float Ws[];   // [cout][ks]
+    if (A.flag && *A.flag == 0) return;                          // anchor-independent features: inter_c1_fwd_mfma_kernel ran
     for (int i = threadIdx.x; i < A.cout * A.ks; i += blockDim.x) Ws[i] = A.W[i];
     __syncthreads();
     const long long col = (long long)blockIdx.x * blockDim.x + threadIdx.x;
@@ -136,6 +138,220 @@ __global__ __launch_bounds__(256) void inter_c1_fwd_kernel(C1Args A) {
             }
         }
         *reinterpret_cast<f32x4 *>(o + o4) = acc;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// The same layer on the matrix pipe, for features that do not depend on the anchor (the occupancy feature: ones, or
+// zeros / ones with use_center) -- checked on the device by c1_feats_check_kernel, anything else takes the kernel above.
+//
+// The VALU kernel spends 3.5 instructions per (neighbour, kernel point) weight and measured 2.0-2.5 weights per clock and
+// SIMD (dependent index -> coordinate loads repeated by the 60 anchor lanes of a point).  The argument of the relu,
+//     s[n][(a,k)] = alpha_n + beta_k + (2/sigma) g_n . (R_a kappa_k),
+// is a rank-5 product  [g_x g_y g_z alpha 1]_n . [r_x r_y r_z 1 beta]_(a,k):  one v_mfma_f32_16x16x32_bf16 per 16 neighbours
+// x 16 (anchor, kernel point) columns with both sides split WITHOUT LOSS into three bf16 pieces (h, m, l) and the six
+// products hh, hm, mh, hl, lh, mm of every term laid along the contraction (4 terms x 6 + 3 for beta = 27 of 32 slots):
+// fp32-grade s (the dropped ml / lm / ll products are < 2^-24 of a term), 256 values per 16 matrix-pipe cycles.  What is
+// left for the VALU per MFMA: four v_max (relu) and two packed FMAs with the neighbours' feature values.
+//   * one wave = one output point (all anchors): index row and neighbour coordinates are loaded once per point; the A
+//     fragments (nn/16 x 4 registers) stay in registers while the wave walks the 90 column tiles;
+//   * the B fragments (constants of the launch: 90 tiles x 1 KB) are built once per workgroup into LDS; 256 persistent
+//     workgroups of 8 waves;
+//   * D rows = neighbours, so the sum over neighbours is in-lane + one cross-row step (v_permlane{32,16}_swap);
+//   * every two anchors (3 column tiles = 48 grouped values) the wave contracts them with W (lane = output channel, its 24
+//     weights in registers, grouped values broadcast from LDS) and writes 2 x cout contiguous outputs.
+typedef float c1f2 __attribute__((ext_vector_type(2)));
+typedef unsigned c1u4 __attribute__((ext_vector_type(4)));
+typedef __bf16 c1bf8 __attribute__((ext_vector_type(8)));
+typedef __bf16 c1bf2 __attribute__((ext_vector_type(2)));
+
+__device__ __forceinline__ unsigned c1_bf(float a) {   // bf16 bits (RNE) of a, in the low half
+    const c1f2 v = {a, 0.f};
+    return __builtin_bit_cast(unsigned, __builtin_convertvector(v, c1bf2)) & 0xffffu;
+}
+__device__ __forceinline__ void c1_split(float xv, unsigned &h, unsigned &m, unsigned &l) {   // xv = h + m + l exactly
+    h = c1_bf(xv);
+    const float r = xv - __uint_as_float(h << 16);
+    m = c1_bf(r);
+    l = c1_bf(r - __uint_as_float(m << 16));
+}
+__device__ __forceinline__ float c1_rows_sum(float v) {   // sum over the four 16-lane rows, result in every lane
+    unsigned u = __float_as_uint(v);
+    auto r = __builtin_amdgcn_permlane32_swap(u, u, false, false);
+    v = __uint_as_float(r[0]) + __uint_as_float(r[1]);
+    u = __float_as_uint(v);
+    auto q = __builtin_amdgcn_permlane16_swap(u, u, false, false);
+    return __uint_as_float(q[0]) + __uint_as_float(q[1]);
+}
+
+// flag |= "some feats[row][a] differs from feats[row][0]"   (flag zeroed by the launcher); 64 lanes per row, na <= 128
+__global__ void c1_feats_check_kernel(const float *__restrict__ feats, long long rows, int na, unsigned *flag) {
+    const int lane = threadIdx.x & 63;
+    bool bad = false;
+    for (long long r = (long long)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6); r < rows; r += (long long)gridDim.x * (blockDim.x >> 6)) {
+        const float *f = feats + r * na;
+        const float f0 = f[0];
+        for (int a = lane; a < na; a += 64) bad = bad || !(f[a] == f0);
+    }
+    if (bad) *flag = 1u;
+}
+
+#define EPN_C1M_KS 24   // kernel points per anchor of the matrix-pipe form (3 column tiles per anchor pair)
+
+template <int NRT, int PTS, int NW>   // row tiles (16 neighbours) per point, points per wave and B fragment, waves
+__global__ __launch_bounds__(64 * NW) void inter_c1_fwd_mfma_kernel(C1Args A) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char c1_smem[];
+    if (*A.flag != 0) return;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, nw = NW;
+    const int x = lane & 15, j = lane >> 4;
+    const int ncols = A.na * EPN_C1M_KS, nct = ncols >> 4;           // na even (launcher): nct = 3 na / 2
+    c1u4 *Btab = reinterpret_cast<c1u4 *>(c1_smem);                   // [nct][64]
+    float *stage = reinterpret_cast<float *>(Btab + (size_t)nct * 64) + (size_t)wave * PTS * 64;       // [PTS][48 + pad]
+    float *phis = reinterpret_cast<float *>(Btab + (size_t)nct * 64) + (size_t)nw * PTS * 64 + (size_t)wave * PTS * NRT * 16;
+    const float two_si = 2.0f * A.sigma_inv;
+    for (int e = tid; e < nct * 64; e += blockDim.x) {
+        const int ct = e >> 6, l = e & 63, xx = l & 15, jj = l >> 4;
+        const int col = 16 * ct + xx, a = col / EPN_C1M_KS, k = col - a * EPN_C1M_KS;
+        const float *r = A.rk + ((size_t)a * A.ks + k) * 3;
+        const float rx = r[0], ry = r[1], rz = r[2];
+        const float v = jj == 0 ? two_si * rx : jj == 1 ? two_si * ry : jj == 2 ? two_si * rz : 1.0f;
+        const float beta = -(rx * rx + ry * ry + rz * rz) * A.sigma_inv;
+        unsigned h, m, l3, bh, bm, bl;
+        c1_split(v, h, m, l3);
+        c1_split(beta, bh, bm, bl);
+        c1u4 w;                                                      // B slots: h m h l h m | beta pieces against A's 1.0
+        w[0] = h | (m << 16); w[1] = h | (l3 << 16); w[2] = h | (m << 16);
+        w[3] = jj == 0 ? (bh | (bm << 16)) : jj == 1 ? bl : 0u;
+        Btab[e] = w;
+    }
+    const int o = lane % A.cout, asel = lane / A.cout, aslots = 64 / A.cout;   // cout in {16, 32, 64} (launcher)
+    const int sidx = 16 * j + x;       // this lane's slot of an anchor pair's staging row: column 16 j + x = 24 aa + k
+    float Wr[EPN_C1M_KS];
+#pragma unroll
+    for (int k = 0; k < EPN_C1M_KS; ++k) Wr[k] = A.W[o * A.ks + k];
+    __syncthreads();
+    const long long npts = A.ncol / A.na;
+    const long long nunits = (npts + PTS - 1) / PTS;
+    const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
+    for (long long u = (long long)blockIdx.x * nw + wave; u < nunits; u += (long long)gridDim.x * nw) {
+        c1bf8 af[PTS][NRT];
+        c1f2 ph01[PTS][NRT], ph23[PTS][NRT];
+        long long ptv[PTS];
+#pragma unroll
+        for (int p = 0; p < PTS; ++p) {
+            const long long pt0 = u * PTS + p;
+            const long long pt = pt0 < npts ? pt0 : npts - 1;   // odd tail: the last point twice (same values stored twice)
+            ptv[p] = pt;
+            const int bb = (int)(pt / A.p2), pp = (int)(pt - (long long)bb * A.p2);
+            const int32_t *row = A.idx + (size_t)pt * A.nn;
+            const float *s = A.xyz + (size_t)bb * 3 * A.p1;
+            const float *c = A.new_xyz + (size_t)bb * 3 * A.p2;
+            const float cx = c[pp], cy = c[A.p2 + pp], cz = c[2 * A.p2 + pp];
+            const float *f = A.feats + (size_t)bb * A.p1 * A.na;
+            int qv[NRT];
+            bool okv[NRT];
+#pragma unroll
+            for (int rt = 0; rt < NRT; ++rt) {
+                const int n = 16 * rt + x;
+                const int q = n < A.nn ? row[n] : -1;
+                okv[rt] = q >= 0 && q < A.p1;          // shadow index: zero feature row (spconv/functional.py:91-95)
+                qv[rt] = okv[rt] ? q : 0;
+            }
+#pragma unroll
+            for (int rt = 0; rt < NRT; ++rt) {
+                const float gx = s[qv[rt]] - cx, gy = s[A.p1 + qv[rt]] - cy, gz = s[2 * A.p1 + qv[rt]] - cz;
+                const float alpha = 1.0f - (gx * gx + gy * gy + gz * gz) * A.sigma_inv;
+                const float v = j == 0 ? gx : j == 1 ? gy : j == 2 ? gz : alpha;
+                unsigned h, m, l3;
+                c1_split(v, h, m, l3);
+                c1u4 w;                                              // A slots: h h m h l m | 1.0 against beta's pieces
+                w[0] = h | (h << 16); w[1] = m | (h << 16); w[2] = l3 | (m << 16);
+                w[3] = j == 0 ? 0x3f803f80u : j == 1 ? 0x00003f80u : 0u;
+                if (!okv[rt]) w = c1u4{0u, 0u, 0u, 0u};
+                af[p][rt] = __builtin_bit_cast(c1bf8, w);
+                if (j == 0) phis[p * NRT * 16 + 16 * rt + x] = okv[rt] ? f[(size_t)qv[rt] * A.na] : 0.0f;
+            }
+        }
+        __builtin_amdgcn_wave_barrier();
+#pragma unroll
+        for (int p = 0; p < PTS; ++p)
+#pragma unroll
+            for (int rt = 0; rt < NRT; ++rt) {
+                const f32x4 t = *reinterpret_cast<const f32x4 *>(phis + p * NRT * 16 + 16 * rt + 4 * j);   // rows 4j .. 4j+3
+                ph01[p][rt] = c1f2{t[0], t[1]};
+                ph23[p][rt] = c1f2{t[2], t[3]};
+            }
+        // per point: where its grouped values / outputs go (offsets inside a point are small ints)
+        float *gsp[PTS], *outp[PTS];
+#pragma unroll
+        for (int p = 0; p < PTS; ++p) {
+            gsp[p] = A.gsave ? A.gsave + (size_t)ptv[p] * A.na * EPN_C1M_KS + x : nullptr;
+            outp[p] = A.out + (size_t)ptv[p] * A.na * A.cout + o;
+        }
+        constexpr int NM = 3 * PTS * NRT;            // MFMAs per anchor pair
+        c1u4 bw[3];
+#pragma unroll
+        for (int t = 0; t < 3; ++t) bw[t] = Btab[t * 64 + lane];
+        for (int ap = 0; ap < (A.na >> 1); ++ap) {
+            c1bf8 bf[3];
+#pragma unroll
+            for (int t = 0; t < 3; ++t) bf[t] = __builtin_bit_cast(c1bf8, bw[t]);
+            if (ap + 1 < (A.na >> 1)) {              // next pair's B fragments while this pair computes
+#pragma unroll
+                for (int t = 0; t < 3; ++t) bw[t] = Btab[(3 * (ap + 1) + t) * 64 + lane];
+            }
+            // software pipeline over the pair's MFMAs: MFMA i+1 is issued before the six VALU instructions that consume MFMA i
+            f32x4 dn = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[0][0], bf[0], zero4, 0, 0, 0);
+            c1f2 acc = {0.f, 0.f}, acd = {0.f, 0.f};     // (two chains: a packed FMA depending on the previous one costs a wait state)
+            float vt[PTS][3];                            // per tile: this lane's sum over its rows of all row tiles
+#pragma unroll
+            for (int i = 0; i < NM; ++i) {
+                const int t = i / (PTS * NRT), p = (i / NRT) % PTS, rt = i % NRT;
+                const f32x4 d = dn;
+                if (i + 1 < NM) {
+                    const int t1 = (i + 1) / (PTS * NRT), p1 = ((i + 1) / NRT) % PTS, rt1 = (i + 1) % NRT;
+                    dn = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[p1][rt1], bf[t1], zero4, 0, 0, 0);
+                }
+                if (rt == 0) { acc = c1f2{0.f, 0.f}; acd = c1f2{0.f, 0.f}; }
+                // relu on the bit patterns (v_max_i32: one instruction, no canonicalisation), as in the VALU kernel
+                const int i0 = __float_as_int(d[0]), i1 = __float_as_int(d[1]), i2 = __float_as_int(d[2]), i3 = __float_as_int(d[3]);
+                const c1f2 r01 = {__int_as_float(i0 > 0 ? i0 : 0), __int_as_float(i1 > 0 ? i1 : 0)};
+                const c1f2 r23 = {__int_as_float(i2 > 0 ? i2 : 0), __int_as_float(i3 > 0 ? i3 : 0)};
+                acc = r01 * ph01[p][rt] + acc;
+                acd = r23 * ph23[p][rt] + acd;
+                if (rt == NRT - 1) {
+                    const c1f2 a2 = acc + acd;
+                    vt[p][t] = a2[0] + a2[1];
+                }
+            }
+            // sum over the four 16-lane rows, transposing: lane group j ends with the total of tile j (3 swaps + 3 adds per point)
+#pragma unroll
+            for (int p = 0; p < PTS; ++p) {
+                auto s02 = __builtin_amdgcn_permlane32_swap(__float_as_uint(vt[p][0]), __float_as_uint(vt[p][2]), false, false);
+                auto s13 = __builtin_amdgcn_permlane32_swap(__float_as_uint(vt[p][1]), 0u, false, false);
+                const float e = __uint_as_float(s02[0]) + __uint_as_float(s02[1]);   // rows 0-1: tile 0 halves summed, rows 2-3: tile 2
+                const float f = __uint_as_float(s13[0]) + __uint_as_float(s13[1]);   // rows 0-1: tile 1, rows 2-3: nothing
+                auto sw = __builtin_amdgcn_permlane16_swap(__float_as_uint(e), __float_as_uint(f), false, false);
+                const float g = __uint_as_float(sw[0]) + __uint_as_float(sw[1]);     // row j: total of tile j (row 3: 0)
+                stage[p * 64 + sidx] = g;                                             // (row 3 writes the pad slots 48 ...)
+                if (A.gsave && j < 3) gsp[p][2 * ap * EPN_C1M_KS + 16 * j] = g;      // 48 contiguous floats per store
+            }
+            __builtin_amdgcn_wave_barrier();
+#pragma unroll
+            for (int p = 0; p < PTS; ++p)
+                for (int aa = asel; aa < 2; aa += aslots) {
+                    const float *gs = stage + p * 64 + EPN_C1M_KS * aa;
+                    float r = 0.f;
+#pragma unroll
+                    for (int k4 = 0; k4 < EPN_C1M_KS; k4 += 4) {
+                        const f32x4 gv = *reinterpret_cast<const f32x4 *>(gs + k4);      // same address in all lanes of an anchor
+#pragma unroll
+                        for (int q = 0; q < 4; ++q) r += Wr[k4 + q] * gv[q];
+                    }
+                    outp[p][(2 * ap + aa) * A.cout] = r;
+                }
+            __builtin_amdgcn_wave_barrier();
+        }
     }
 }
 
@@ -235,6 +451,7 @@ C1Args make_c1(const epn_inter_desc *d, const float *rk) {
     A.p1 = d->p1; A.p2 = d->p2; A.nn = d->nn; A.na = d->na; A.ks = d->ks; A.cout = d->cout;
     A.ncol = (long long)d->b * d->p2 * d->na;
     A.groups_per_wg = 1;
+    A.flag = nullptr;
     return A;
 }
 
@@ -249,13 +466,53 @@ bool inter_c1_bwd_weight_ok(const epn_inter_desc *d) {
     return d->cin == 1 && !d->dense_w && d->ks <= EPN_KS_MAX && d->cout % 16 == 0 && d->cout <= 64;
 }
 
+// matrix-pipe form: 24 kernel points, anchors in pairs, cout lanes per anchor, the B table + staging within the 160 KB of LDS
+static bool c1_mfma_ok(const epn_inter_desc *d) {
+    const char *e = getenv("EPN_C1_MFMA");       // "0": the VALU kernel for every input (A/B, tests)
+    return !(e && e[0] == '0') && d->ks == EPN_C1M_KS && d->na % 2 == 0 && d->na <= 128 && d->nn >= 1 && d->nn <= 128 &&
+           (d->cout == 16 || d->cout == 32 || d->cout == 64);
+}
+
+template <int NRT, int PTS, int NW>
+static int launch_c1_mfma(const C1Args &A, hipStream_t st) {
+    const int nct = A.na * EPN_C1M_KS / 16;
+    const size_t lds = (size_t)nct * 1024 + (size_t)NW * PTS * 64 * 4 + (size_t)NW * PTS * NRT * 16 * 4;
+    EPN_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&inter_c1_fwd_mfma_kernel<NRT, PTS, NW>),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    const long long units = (A.ncol / A.na + PTS - 1) / PTS;
+    const unsigned grid = (unsigned)((units + NW - 1) / NW < 256 ? (units + NW - 1) / NW : 256);
+    EPN_LAUNCH((inter_c1_fwd_mfma_kernel<NRT, PTS, NW>), dim3(grid), dim3(64 * NW), lds, st, A);
+    EPN_CHECK_LAUNCH();
+    return 0;
+}
+
 int launch_inter_c1_fwd(const epn_inter_desc *d, const float *rk, const float *feats, const float *W, float *out,
-                        hipStream_t st, float *grouped_save) {
+                        hipStream_t st, float *grouped_save, unsigned *flag) {
     C1Args A = make_c1(d, rk);
     A.feats = feats; A.W = W; A.out = out; A.gsave = grouped_save;
+    const bool mf = flag && c1_mfma_ok(d);
+    if (mf) {
+        // features that do not depend on the anchor (checked here, on the device): the matrix-pipe kernel; the VALU kernel
+        // returns at once unless the check found a difference (it is launched first so that epn_last_kernel() names the
+        // kernel that does the work for the occupancy feature)
+        A.flag = flag;
+        EPN_HIP(hipMemsetAsync(flag, 0, sizeof(unsigned), st));
+        const long long rows = (long long)d->b * d->p1;
+        EPN_LAUNCH_AUX(c1_feats_check_kernel, dim3((unsigned)((rows + 3) / 4 < 4096 ? (rows + 3) / 4 : 4096)), dim3(256), 0, st,
+                       feats, rows, d->na, flag);
+        EPN_CHECK_LAUNCH();
+    }
     const unsigned grid = (unsigned)((A.ncol + 255) / 256);
     EPN_LAUNCH(inter_c1_fwd_kernel, dim3(grid), dim3(256), (size_t)d->cout * d->ks * sizeof(float), st, A);
     EPN_CHECK_LAUNCH();
+    if (mf) {
+        // waves per workgroup (= per CU: the B table takes 90 KB of LDS): as many as the registers allow -- measured
+        // 8 / 12 / 16 waves: K = 32 0.243 / 0.233 / 0.205 ms, K = 64 0.459 / 0.420 / 0.403, K = 128 0.647 / 0.623 / - (152 VGPRs)
+        if (d->nn <= 16) return launch_c1_mfma<1, 2, 16>(A, st);
+        if (d->nn <= 32) return launch_c1_mfma<2, 2, 16>(A, st);
+        if (d->nn <= 64) return launch_c1_mfma<4, 1, 16>(A, st);
+        return launch_c1_mfma<8, 1, 12>(A, st);
+    }
     return 0;
 }
 

@@ -134,7 +134,12 @@ int epn_inter_so3conv_bwd_weight_f32(const epn_inter_desc *d, const float *feats
  * the reference keeps for the same purpose) from the forward pass, and the weight gradient contracts grad_out with them:
  *   epn_inter_so3conv_fwd_c1_f32        : as epn_inter_so3conv_fwd_f32 for cin = 1; `grouped` may be NULL (inference)
  *   epn_inter_so3conv_bwd_weight_c1_f32 : grad_W f32[cout][ks] = grad_out^T . grouped (zero-filled here, then accumulated)
- * Shapes: epn_inter_c1_ok (cin = 1, no dense inter_w, cout in {16, 32, 48, 64}, ks <= 32); EPN_EINVAL otherwise. */
+ * Shapes: epn_inter_c1_ok (cin = 1, no dense inter_w, cout in {16, 32, 48, 64}, ks <= 32); EPN_EINVAL otherwise.
+ * Forward, ks = 24, even na, cout in {16, 32, 64}, nn <= 128: when the features do not depend on the anchor (checked on
+ * the device, no host synchronisation; true for the occupancy feature) the relu arguments come off the matrix pipe
+ * (inter_c1_fwd_mfma_kernel: rank-5 product, operands split without loss into 3 x bf16), otherwise -- or with
+ * EPN_C1_MFMA=0 -- from the VALU kernel.  Outputs of the two agree to ~2e-6 of the tensor maximum.  The weight gradient
+ * equals epn_gemm_tn_split_f32(grad_out rows, grouped), which is what the Python host calls (3-5x faster; EPN_C1_DW). */
 int epn_inter_c1_ok(const epn_inter_desc *d);
 int epn_inter_so3conv_fwd_c1_f32(const epn_inter_desc *d, const float *feats_cl, const float *W, float *out_cl,
                                  float *grouped, void *workspace, size_t workspace_bytes, epn_stream_t stream);

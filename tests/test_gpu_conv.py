@@ -1032,6 +1032,63 @@ def test_norm_act_pair_vs_torch(gpu, c, inst_b, affine_b, dt):
         assert torch.allclose(nb.running_var, nb_ref.running_var, atol=1e-4)
 
 
+@pytest.mark.parametrize("cout,K,n,na", [(32, 32, 200, 60), (64, 16, 98, 60), (16, 64, 130, 60), (32, 128, 300, 60), (64, 40, 111, 60),
+                                         (32, 32, 90, 20), (16, 64, 64, 40)])
+@pytest.mark.parametrize("feat", ["ones", "center", "per_point"])
+def test_first_layer_on_the_matrix_pipe(gpu, vgtk_alias, monkeypatch, cout, K, n, na, feat):
+    """cin = 1 with features that do not depend on the anchor (get_occupancy_features: ones, or zeros at the centre point;
+    here also arbitrary per-point values of both signs): inter_c1_fwd_mfma_kernel (relu argument as a rank-5 product on
+    v_mfma_f32_16x16x32_bf16, operands split without loss into three bf16 pieces) against the VALU kernel (EPN_C1_MFMA=0) and
+    the oracle; neighbour counts 16 ... 128 incl. one that is not a multiple of 16, odd point counts (two points per wave at
+    K <= 32), shadow neighbours (radius smaller than the cloud), 60 / 40 / 20 anchors; the saved grouped values through the weight
+    gradient.  Anchor-dependent features keep taking the VALU kernel (device-side check): test above."""
+    from epn_pointcloud_amd import ops
+    from epn_pointcloud_amd.vgtk import pc as pctk
+    from epn_pointcloud_amd.vgtk.so3conv import functional as L
+    from epn_pointcloud_amd.vgtk import functional as fr
+    rng = np.random.default_rng(cout + K + n)
+    torch.manual_seed(cout + K + n)
+    b, radius, sigma = 3, 0.35, 0.06
+    xyz = T(unit_ball_cloud(rng, b, n)).to(gpu)
+    anchors = T(L.get_anchors(na)).to(gpu)
+    kernels = R.scaled_kernel_points(T(fr.kernel_points_raw(24)), radius).to(gpu)
+    p2 = (n + 1) // 2
+    _, new_xyz = pctk.furthest_sample(xyz, p2, False)
+    idx = pctk.ball_query_index(new_xyz, xyz, radius, K)
+    geo = ops.InterGeometry(xyz, new_xyz, idx, anchors, kernels, sigma)
+    if feat == "ones":
+        feats = torch.ones(b, 1, n, na, device=gpu)
+    elif feat == "center":
+        feats = torch.ones(b, 1, n, na, device=gpu)
+        feats[:, :, 0, :] = 0.0
+    else:
+        feats = (torch.randn(b, 1, n, 1, device=gpu) * (torch.rand(b, 1, n, 1, device=gpu) > 0.2)).expand(b, 1, n, na).contiguous()
+    W = torch.randn(cout, 24, device=gpu)
+    gout = torch.randn(b, cout, p2, na, device=gpu)
+
+    def run(mfma):
+        monkeypatch.setenv("EPN_C1_MFMA", "1" if mfma else "0")
+        w = W.clone().requires_grad_(True)
+        out = ops.InterSO3ConvFn.apply(feats, w, geo)
+        out.backward(gout)
+        return out.detach(), w.grad
+
+    o1, g1 = run(True)
+    o0, g0 = run(False)
+    scale = o0.abs().max().item()
+    assert not torch.equal(o1, o0)      # (different roundings: the matrix-pipe kernel did take the launch)
+    assert (o1 - o0).abs().max().item() <= 2e-6 * scale, ((o1 - o0).abs().max().item(), scale)
+    assert (g1 - g0).abs().max().item() <= 1e-5 * g0.abs().max().item()
+    fo = feats.cpu()
+    wo = W.cpu().requires_grad_(True)
+    grouped = R.group_nd(R.add_shadow_point(xyz.cpu()), idx.cpu()) - new_xyz.cpu().unsqueeze(3)
+    w_ref = R.inter_weights(grouped, anchors.cpu(), kernels.cpu(), sigma)
+    oo = R.basic_conv(wo, R.inter_feat_grouping(idx.cpu(), w_ref, R.add_shadow_feature(fo)))
+    (dWo,) = torch.autograd.grad(oo, [wo], gout.cpu())
+    assert torch.allclose(o1.cpu(), oo.detach(), atol=TOL)
+    assert _rel(g1.cpu(), dWo) < TOL
+
+
 @pytest.mark.parametrize("cout,K,n", [(32, 32, 200), (64, 16, 96), (16, 64, 130), (32, 64, 256)])   # last: columns % 32 == 0 (tiled TN GEMM)
 def test_first_layer_weight_gradient_from_saved_grouped_values(gpu, vgtk_alias, monkeypatch, cout, K, n):
     """cin = 1 (InterSO3Conv(1 -> cout), the first layer of every model): the forward pass keeps the ks grouped values of every

@@ -8,12 +8,27 @@ import torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from epn_pointcloud_amd import ops, schedule  # noqa: E402
 from epn_pointcloud_amd.vgtk.so3conv import modules as M  # noqa: E402
-from tn_probe import timeit  # noqa: E402
+
+
+def timeit(fns, reps=5):
+    """Device time per call, plain stream timing (these launches are 0.1-1.5 ms each)."""
+    for f in fns:
+        f()
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(reps):
+        for f in fns:
+            f()
+    e1.record()
+    torch.cuda.synchronize()
+    return e0.elapsed_time(e1) / (reps * len(fns))
 
 
 def main():
     dev = torch.device("cuda:0")
     torch.manual_seed(0)
+    print("EPN_C1_MFMA =", os.environ.get("EPN_C1_MFMA", "1"), flush=True)
     for name, b, n, sched in [("cls", 32, 1024, schedule.cls_so3net_schedule()), ("reg", 64, 1024, schedule.reg_so3net_schedule()),
                               ("inv", 64, 2048, schedule.inv_so3net_schedule())]:
         l = sched[0]
@@ -25,11 +40,12 @@ def main():
         with torch.no_grad():
             _, geo, _, _ = conv(sp)
         outs = {}
+        g = None
         for mode in ("gemm", "kernel"):
             os.environ["EPN_C1_DW"] = mode
             Wm = W.detach().clone().requires_grad_(True)
             out = ops.InterSO3ConvFn.apply(sp.feats, Wm, geo)
-            g = torch.randn_like(out)
+            g = torch.randn_like(out) if g is None else g
             outs[mode] = torch.autograd.grad(out, [Wm], g)[0].clone()
 
             def fb(Wm=Wm, g=g):
