@@ -6,6 +6,9 @@
 //   out[o] = sum_k W[o][k] * G[k]                                                  (modules.py:52)
 // The weight gradient reduces dOut (x) G over all columns with MFMAs (M = kernel point, N = output channel,
 // contraction = columns), the grouped values passing through LDS once.
+// Round 4: for features that do not depend on the anchor (the occupancy feature itself) the relu arguments come off the
+// matrix pipe instead -- inter_c1_fwd_mfma_kernel below, one wave per output point -- and the host computes the weight
+// gradient from the saved grouped values with the library's TN GEMM (ops.InterSO3ConvFn.backward).
 #include "conv_internal.h"
 
 namespace epn {
