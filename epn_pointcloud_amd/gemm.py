@@ -222,6 +222,9 @@ class MatmulNT(torch.autograd.Function):
         if ctx.needs_input_grad[0]:
             Wt = transpose_cast(W, A.dtype)
             dA = ops._launch("conv1x1_gemm", ("nt", M, K, N), 2.0 * M * N * K, A.device, lambda: gemm_nt(dC, Wt))
+            # a fresh buffer that is the gradient of exactly one tensor (A): a consumer that receives a re-layout VIEW of it
+            # through autograd's view nodes may accumulate into it (ops.InterSO3ConvSplitFn._may_write_into)
+            dA._epn_private = True
         if ctx.needs_input_grad[1]:
             dW = ops._launch("conv1x1_gemm_dw", ("tn", M, N, K), 2.0 * M * N * K, A.device, lambda: gemm_tn(dC, A))
         return dA, dW, None

@@ -413,8 +413,15 @@ class InterSO3ConvSplitFn(torch.autograd.Function):
     @staticmethod
     def _may_write_into(ctx, grad_shared):
         """May the scatter accumulate in place into the incoming gradient of the shared output?  (see forward)"""
-        if grad_shared._base is not None:                       # a view: the base belongs to somebody else
-            return False
+        base = grad_shared._base
+        if base is not None:
+            # a view: the base belongs to somebody else -- unless it is the fresh data gradient of the skip branch's 1x1
+            # convolution (gemm.MatmulNT.backward marks it), re-laid-out by autograd's view nodes ([rows, c] -> [b, c, p, a]):
+            # the whole buffer, seen by this Function alone (stride-1 blocks: three additions + three zero fills of a
+            # [32, c, p, 60] tensor per classification step otherwise)
+            if not (getattr(base, "_epn_private", False) and base.numel() == grad_shared.numel()
+                    and base.data_ptr() == grad_shared.data_ptr() and base.is_contiguous()):
+                return False
         ref = getattr(ctx, "shared_ref", None)
         shared = ref() if ref is not None else None
         if shared is not None and (shared.retains_grad or shared._backward_hooks):

@@ -580,6 +580,38 @@ def test_shared_input_gradient_is_folded_into_the_data_gradient(gpu, vgtk_alias,
         assert torch.allclose(kept.float(), side_w, atol=1e-2 if dt == "bf16" else 0.0, rtol=1e-2 if dt == "bf16" else 0.0), watch
         assert (f.grad.float() - gf_ref).abs().max().item() <= tol * (gf_ref.abs().max().item() + 1e-12), watch
 
+    # the side consumer of a stride-1 block is a 1x1 convolution: its data gradient reaches the Function as a VIEW of the GEMM's
+    # fresh [rows, c] output -- accepted as scatter target (marked private by gemm.MatmulNT.backward), same gradients as the
+    # out-of-place form; a view of anything else is not accepted
+    if dt == "f32":
+        wskip = torch.randn(cout, cin, 1, 1, device=gpu) / cin ** 0.5
+        taken = []
+        orig = ops.InterSO3ConvSplitFn._may_write_into
+        monkeypatch.setattr(ops.InterSO3ConvSplitFn, "_may_write_into",
+                            staticmethod(lambda ctx, g: taken.append((g._base is not None, orig(ctx, g))) or taken[-1][1]))
+
+        def run_skip(share):
+            monkeypatch.setenv("EPN_SHARE_INPUT_GRAD", "1" if share else "0")
+            f = feats.clone().requires_grad_(True)
+            w, ws = W.clone().requires_grad_(True), wskip.clone().requires_grad_(True)
+            out, h2, _part = ops.inter_so3conv(f * 1.0, w, geo, share_input=True)
+            sk = ops.conv1x1(h2, ws, None)
+            ((out ** 2).sum() + (sk ** 2).sum()).backward()
+            return f.grad, w.grad, ws.grad
+
+        r0 = run_skip(False)
+        del taken[:]
+        r1 = run_skip(True)
+        assert taken == [(True, True)], taken          # a view, and accepted
+        for a0, a1 in zip(r0, r1):
+            assert (a0 - a1).abs().max().item() <= 1e-4 * (a0.abs().max().item() + 1e-12)
+        f = feats.clone().requires_grad_(True)
+        out, h2, _part = ops.inter_so3conv(f * 1.0, W.clone().requires_grad_(True), geo, share_input=True)
+        del taken[:]
+        ((out ** 2).sum() + (h2.permute(0, 2, 3, 1).reshape(-1, cin) * 2.0).sum()).backward()   # a view of torch's own buffer
+        assert taken and taken[0][1] == (not taken[0][0]), taken
+        monkeypatch.setattr(ops.InterSO3ConvSplitFn, "_may_write_into", orig)
+
     # a frozen input: no differentiable alias is handed out, W still gets its gradient, statistics still come back
     w = W.clone().requires_grad_(True)
     out, h2, part = ops.inter_so3conv(feats, w, geo, share_input=True)
