@@ -29,6 +29,7 @@ EXPORTS = [
     "epn_transpose_cast", "epn_cast", "epn_gemm_tn_grouped_workspace_bytes", "epn_gemm_tn_grouped",
     "epn_inter_group_bf16", "epn_inter_ungroup_bf16", "epn_intra_group_bf16", "epn_so3_basis_bf16",
     "epn_gather_rows", "epn_scatter_rows", "epn_conv1x1_c1_f32", "epn_conv1x1_c1_bwd_weight_f32",
+    "epn_anchor_softmax_pool_fwd_f32", "epn_anchor_softmax_pool_bwd_f32",
     "epn_ball_query_f64", "epn_fps_f64", "epn_gather_fwd_f64", "epn_gather_bwd_f64", "epn_so3_basis_norm_f32", "epn_so3_basis_norm_bf16", "epn_so3_basis_split_f32", "epn_so3_basis_norm_split_f32", "epn_inter_inverse_list", "epn_inter_ungroup_det_f32", "epn_inter_ungroup_det_bf16",
     "epn_chan_stats_bf16", "epn_norm_act_fwd_bf16", "epn_norm_act_bwd_reduce_bf16", "epn_norm_act_bwd_apply_bf16",
     "epn_last_kernel", "epn_scatter_rows_add", "epn_norm_pair_workspace_bytes", "epn_norm_act_pair_fwd",
@@ -219,6 +220,8 @@ def get_lib():
     lib.epn_scatter_rows_add.restype = _ci
     lib.epn_conv1x1_c1_f32.argtypes = [_vp, _vp, _vp, _ll, _ci, _vp]
     lib.epn_conv1x1_c1_bwd_weight_f32.argtypes = [_vp, _vp, _vp, _ll, _ci, _vp]
+    lib.epn_anchor_softmax_pool_fwd_f32.argtypes = [_vp, _vp, _vp, _vp, _ll, _ci, _ci, _vp]
+    lib.epn_anchor_softmax_pool_bwd_f32.argtypes = [_vp, _vp, _vp, _vp, _vp, _vp, _ll, _ci, _ci, _vp]
     lib.epn_gather_rows.restype = lib.epn_scatter_rows.restype = _ci
     lib.epn_inter_inverse_list.argtypes = [_vp, _ci, _ci, _ci, _ci, _vp, _vp, _vp]
     lib.epn_inter_inverse_list.restype = _ci

@@ -85,8 +85,7 @@ class InvOutBlockMVD(nn.Module):
         nb = x.feats.shape[0]
         a0, a2 = self.attention_layer[0], self.attention_layer[2]
         attn = ops.conv1x1(F.relu(ops.conv1x1(x.feats, a0.weight, a0.bias)), a2.weight, a2.bias)
-        attn = F.softmax(attn, dim=3)
-        pooled = (x.feats * attn).sum(-1, keepdim=True)                    # [b, c, p, 1]
+        attn, pooled = ops.anchor_softmax_pool(x.feats, attn)              # softmax over the anchors, [b, c, p, 1]
         y = self.pointnet(zptk.SphericalPointCloud(x.xyz, pooled, None)).reshape(nb, -1)
         return F.normalize(y, p=2, dim=1), attn
 

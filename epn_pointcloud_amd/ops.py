@@ -1647,6 +1647,52 @@ def gather_rows(feats, sample_idx):
     return torch.gather(feats, 2, idx)
 
 
+class AnchorSoftmaxPoolFn(torch.autograd.Function):
+    """(attn, pooled) = (softmax(logits, dim=3), (feats * attn).sum(3)) of InvOutBlockMVD.forward
+    (SPConvNets/utils/base_so3conv.py:603-606) in one pass over the channels-last tensors, and one pass backward
+    (epn_anchor_softmax_pool_{fwd,bwd}_f32).  feats, logits [b, c, p, a] fp32 -> attn [b, c, p, a], pooled [b, c, p, 1]."""
+
+    @staticmethod
+    def forward(ctx, feats, logits):
+        ctx.set_materialize_grads(False)
+        lib = _lib.get_lib()
+        f, l = to_cl(feats), to_cl(logits, "logits")
+        b, c, p, a = f.shape
+        attn = empty_cl(b, c, p, a, f.device)
+        pooled = torch.empty((b, p, c), dtype=torch.float32, device=f.device)
+        _lib.check(lib.epn_anchor_softmax_pool_fwd_f32(_cl_ptr(f), _cl_ptr(l), _cl_ptr(attn), pooled.data_ptr(), b * p, a, c,
+                                                       _lib.stream_of(f)), "anchor_softmax_pool_fwd")
+        ctx.save_for_backward(f, attn)
+        return attn, pooled.permute(0, 2, 1).unsqueeze(-1)
+
+    @staticmethod
+    def backward(ctx, g_attn, g_pooled):
+        f, attn = ctx.saved_tensors
+        if g_attn is None and g_pooled is None:
+            return None, None
+        lib = _lib.get_lib()
+        b, c, p, a = f.shape
+        ga = to_cl(g_attn.float(), "grad_attn") if g_attn is not None else None
+        gp = g_pooled.float().reshape(b, c, p).permute(0, 2, 1).contiguous() if g_pooled is not None else None
+        gf = empty_cl(b, c, p, a, f.device) if ctx.needs_input_grad[0] and gp is not None else None
+        gl = empty_cl(b, c, p, a, f.device)
+        _lib.check(lib.epn_anchor_softmax_pool_bwd_f32(_cl_ptr(f), _cl_ptr(attn), gp.data_ptr() if gp is not None else None,
+                                                       _cl_ptr(ga) if ga is not None else None,
+                                                       _cl_ptr(gf) if gf is not None else None, _cl_ptr(gl), b * p, a, c,
+                                                       _lib.stream_of(f)), "anchor_softmax_pool_bwd")
+        return gf, gl
+
+
+def anchor_softmax_pool(feats, logits):
+    """-> (attn [b,c,p,a], pooled [b,c,p,1]): the 3DMatch head's attention pooling over the anchors; CUDA fp32 tensors with at
+    most 64 anchors run the fused kernels, anything else the reference's torch composition."""
+    if (feats.is_cuda and feats.dtype == torch.float32 and logits.dtype == torch.float32 and feats.dim() == 4
+            and feats.shape == logits.shape and feats.shape[3] <= 64 and os.environ.get("EPN_ATTN_POOL", "1") == "1"):
+        return AnchorSoftmaxPoolFn.apply(feats, logits)
+    attn = torch.nn.functional.softmax(logits, dim=3)
+    return attn, (feats * attn).sum(-1, keepdim=True)
+
+
 class Conv1x1C1Fn(torch.autograd.Function):
     """nn.Conv2d(1, cout, 1) on channels-last rows: y[row][c] = x[row] * w[c] (epn_conv1x1_c1_f32); the weight gradient is
     one streaming reduction (epn_conv1x1_c1_bwd_weight_f32).  x is the occupancy feature of the first block (an input)."""

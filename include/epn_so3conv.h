@@ -680,6 +680,18 @@ int epn_conv1x1_c1_f32(const float *x, const float *w, float *y, long long rows,
 int epn_conv1x1_c1_bwd_weight_f32(const float *x, const float *grad_y, float *grad_w, long long rows, int cout,
                                   epn_stream_t stream);
 
+/* Attention pooling over the anchors in the 3DMatch head: replaces `attn = F.softmax(attn, dim=3)` and
+ * `x_out = (x.feats * attn).sum(-1, keepdim=True)` of InvOutBlockMVD.forward (SPConvNets/utils/base_so3conv.py:603-606)
+ * and their autograd backward, on channels-last rows [row = (b, p)][a][c] (na <= 64):
+ *   fwd: attn[row][a][c] = softmax over a of logits[row][a][c];  pooled[row][c] = sum_a feats[row][a][c] * attn[row][a][c]
+ *   bwd: g = grad_pooled * feats (+ grad_attn);  grad_logits = attn * (g - sum_a attn g);  grad_feats = grad_pooled * attn
+ *        grad_pooled or grad_attn_cl may be NULL (not both: EPN_ENULL), grad_feats_cl may be NULL (not wanted). */
+int epn_anchor_softmax_pool_fwd_f32(const float *feats_cl, const float *logits_cl, float *attn_cl, float *pooled,
+                                    long long rows, int na, int c, epn_stream_t stream);
+int epn_anchor_softmax_pool_bwd_f32(const float *feats_cl, const float *attn_cl, const float *grad_pooled,
+                                    const float *grad_attn_cl, float *grad_feats_cl, float *grad_logits_cl,
+                                    long long rows, int na, int c, epn_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif
