@@ -32,12 +32,17 @@ if ROOT not in sys.path:
 # /opt/skills/guides/MI355X_MICROARCH.md: "Peak FP32 (matrix)", "Peak BF16/FP16 MFMA" (dense), HBM3E peak
 PEAK_TFLOPS = {"f32": 157.3, "bf16": 2500.0}
 HBM_PEAK_GBS = 8000.0
+# Prediction only (configs.cls_dp_rank.predicted_eff_8gpu): bus bandwidth of a 31 MB ring all-reduce over 8 GPUs.  xGMI gives
+# 7 links x ~153 GB/s per GPU; RCCL's measured bus bandwidth at tens of MB is well below the link sum -- 100 GB/s is a
+# deliberately low figure, stated in the line as an assumption.
+XGMI_ALLREDUCE_BUSBW_GBS = 100.0
+XGMI_ALLREDUCE_LATENCY_MS = 0.05
 
 def _latest_profile(suffix):
     """profiles/r0N_<suffix> of the latest round that committed one (tools/collect_round.sh)."""
     import glob
-    found = sorted(glob.glob(os.path.join(ROOT, "profiles", "r0?_" + suffix)))
-    return found[-1] if found else os.path.join(ROOT, "profiles", "r04_" + suffix)
+    found = sorted(glob.glob(os.path.join(ROOT, "profiles", "r[0-9][0-9]_" + suffix)))
+    return found[-1] if found else os.path.join(ROOT, "profiles", "r05_" + suffix)
 
 
 PMC_FILE = _latest_profile("pmc_per_kernel.json")                        # tools/collect_profiles.sh + pmc_summary.py
@@ -58,6 +63,36 @@ def recorded_traffic(kernel_family, pmc_file=PMC_FILE):
             tot += e["hbm_bytes_per_launch"] * e["launches"]
             n += e["launches"]
     return round(tot / n) if n else None
+
+
+def recorded_step_traffic(pmc_file):
+    """HBM GB per step of a profiled workload: sum over every kernel of the committed PMC pass of bytes/launch x launches,
+    divided by the number of steps the profiled process ran (`_meta.step_equivalents`, written by tools/pmc_summary.py from
+    the bench line's own count of compute() calls; the round-4 files carry no _meta: 10)."""
+    try:
+        pmc = json.load(open(pmc_file))
+    except (OSError, TypeError):
+        return None
+    steps = (pmc.get("_meta") or {}).get("step_equivalents", 10)
+    tot = sum(e["hbm_bytes_per_launch"] * e["launches"] for k, e in pmc.items()
+              if k != "_meta" and isinstance(e, dict) and "hbm_bytes_per_launch" in e)
+    return round(tot / steps / 1e9, 1) if tot else None
+
+
+def algorithmic_work(layers, batch, points, esz, na=60, backward=True):
+    """SURVEY 8(d)'s algorithmic work of one step of a schedule: (flops, minimal HBM bytes).  Flops per layer:
+    schedule.hot_path_flops (weight generation + grouping + inter GEMM + intra GEMM); minimal bytes per separable block =
+    B A (Cin P1 + 3 Cout P2) sizeof (read the input, write/read the inter output, write the intra output).  fwd+bwd = 3 x
+    forward (dW + dX per contraction), as the survey prices it -- config 2 at B=32: 4.18 TF / 6.4 GB forward."""
+    from epn_pointcloud_amd import schedule as S
+    fl = sum(sum(d.values()) for d in S.hot_path_flops(layers, batch, points, na))
+    by, p1 = 0.0, points
+    for l in layers:
+        p2 = -(-p1 // l.stride)
+        by += batch * na * (l.cin * p1 + 3 * l.cout * p2) * esz
+        p1 = p2
+    m = 3.0 if backward else 1.0
+    return fl * m, by * m
 
 
 def norm_kernel_name(name):
@@ -92,9 +127,9 @@ def parse():
                     help="skip the second measurement with the exact-f32 MFMA GEMMs (fp32, single rank, split form only)")
     ap.add_argument("--cpu-clouds", type=int, default=4, help="sample size of the CPU baseline (SURVEY 8d: B=4 chunks)")
     ap.add_argument("--cpu-samples", type=int, default=2, help="timed fwd+bwd passes of the CPU baseline (median reported)")
-    ap.add_argument("--cpu-threads", type=int, default=16,
-                    help="torch CPU threads of the baseline (the GPU box's cgroup grants 16 CPUs; measured fastest of "
-                         "{16,48,256} on the 2x EPYC 9575F host: the materialising reference algorithm slows down with more)")
+    ap.add_argument("--cpu-threads", type=int, default=0,
+                    help="torch CPU threads of the baseline; 0 (default) = sweep {16, 64, all CPUs this process may run on} "
+                         "on a one-cloud forward pass and time the sample on the fastest")
     ap.add_argument("--forward-only", action="store_true")
     ap.add_argument("--no-graph", action="store_true", help="eager launches instead of replaying a captured HIP graph")
     ap.add_argument("--backbone-only", action="store_true", help="without the output head")
@@ -102,20 +137,38 @@ def parse():
     ap.add_argument("--no-extra-configs", action="store_true",
                     help="skip the other single-GPU configs (cls forward only, reg bf16, inv bf16) that the default run "
                          "embeds under \"configs\"")
+    ap.add_argument("--dp-path", action="store_true",
+                    help="run the program ONE RANK of a multi-GPU job runs, on a single GPU: gradients gathered into the flat "
+                         "GradBuckets buffer, the all-reduce issued on a 1-rank RCCL communicator after every replay, inside the "
+                         "timed region (what --gpus N adds to a rank's step, minus the wire time)")
+    ap.add_argument("--dp-collect", default="pack", choices=["pack", "accumulate"],
+                    help="how gradients reach the flat buffer (dp.GradBuckets): one multi-tensor copy at the end of backward "
+                         "(default) or autograd accumulating into views of it (round 4's form: one add per parameter + a fill)")
     ap.add_argument("--policy", default="", help="A/B switch of the tuning tools: epn_set_kernel_policy value (e.g. 0x401), see "
                                                  "include/epn_so3conv.h; default = the library's own choices")
     return ap.parse_args()
 
 
-def cpu_baseline(layers, product_sd, n_points, n_clouds, threads=16, head=True, samples=2):
+def usable_cpus():
+    """CPUs this process may run on (affinity mask / cgroup), not the host's count."""
+    try:
+        return len(os.sched_getaffinity(0))
+    except (AttributeError, OSError):
+        return os.cpu_count() or 1
+
+
+def cpu_baseline(layers, product_sd, n_points, n_clouds, threads=0, head=True, samples=2):
     """The oracle's materialising restatement of the same network (kind "port"), on the host cores: one warm-up
     forward of a single cloud, then `samples` timed forward + backward passes of `n_clouds` clouds (the median is
-    reported); the forward share is reported separately (north_star states its >= 10x target on the forward pass)."""
+    reported); the forward share is reported separately (north_star states its >= 10x target on the forward pass).
+    threads=0: BASELINE.md asks for "all physical cores" -- the thread count is swept over {16, 64, every CPU the process
+    may use} with a one-cloud forward pass and the sample is timed on the fastest (`cores`); the sweep is in `sweep`."""
     from epn_pointcloud_amd import schedule as S
     from epn_pointcloud_amd.vgtk.so3conv import functional as L
     from epn_pointcloud_amd.vgtk import functional as fr
     from oracle import backbone_ref
-    cores = max(1, min(threads, os.cpu_count() or 1))
+    avail = usable_cpus()
+    cores = max(1, min(threads or 16, os.cpu_count() or 1))
     torch.set_num_threads(cores)
     tables = (torch.from_numpy(L.get_anchors(60)), torch.from_numpy(fr.kernel_points_raw(24)),
               torch.from_numpy(L.get_intra_idx()).long())
@@ -127,6 +180,17 @@ def cpu_baseline(layers, product_sd, n_points, n_clouds, threads=16, head=True, 
     labels = torch.arange(n_clouds) % 40
     with torch.no_grad():                                   # warm-up: thread pool, allocator, C index library
         ref(pts[:1])
+    sweep = {}
+    if not threads:
+        for t in sorted({min(16, avail), min(64, avail), avail}):
+            torch.set_num_threads(t)
+            with torch.no_grad():
+                ref(pts[:1])                                # the pool of this size
+                t0 = time.perf_counter()
+                ref(pts[:1])
+                sweep[t] = round(time.perf_counter() - t0, 2)
+        cores = min(sweep, key=sweep.get)
+        torch.set_num_threads(cores)
     runs = []
     for _ in range(max(1, samples)):
         ref.zero_grad(set_to_none=True)
@@ -145,9 +209,9 @@ def cpu_baseline(layers, product_sd, n_points, n_clouds, threads=16, head=True, 
     tot, fwd = runs[(len(runs) - 1) // 2]                   # median (lower one of an even count)
     return {"value": round(n_clouds / tot, 4), "unit": "point-clouds/s", "cores": cores, "kind": "port",
             "samples": len(runs), "forward_only_value": round(n_clouds / fwd, 4),
-            "sample": f"{n_clouds} clouds N={n_points} A=60, fwd+bwd x{len(runs)} (median {tot:.1f} s, fwd {fwd:.1f} s), "
-                      f"oracle/backbone_ref.py on {torch.get_num_threads()} torch threads of {os.cpu_count()} host CPUs",
-            "all_samples_s": [round(r[0], 2) for r in runs]}
+            "sample": f"{n_clouds} clouds fwd+bwd x{len(runs)}, median {tot:.1f} s (fwd {fwd:.1f}); oracle/backbone_ref.py; "
+                      f"threads = best of sweep_s; {avail}/{os.cpu_count()} host CPUs usable",
+            "sweep": {"one_cloud_forward_s_by_threads": sweep}, "all_samples_s": [round(r[0], 2) for r in runs]}
 
 
 def index_kernel_line(pts, layers, dev, reps=20):
@@ -411,9 +475,15 @@ def measure(cfg, rank, local_rank, world, dev, first=True):
     # all-reduce runs on slices of it -- issued from backward hooks (eager) or right after the replayed graph
     # (world > 1 only: a single rank lets autograd hand its gradient tensors to p.grad directly -- no per-parameter
     # accumulate kernel, no zero fill)
-    buckets = None if cfg.forward_only or world == 1 else dp.GradBuckets(dp.stage_buckets(model), world, hooks=False)
+    # --dp-path: the same on a world of one (forced collectives on a single-rank communicator): the rank program measured
+    dp_path = bool(getattr(cfg, "dp_path", False)) and not cfg.forward_only
+    collect = getattr(cfg, "dp_collect", "pack")
+    buckets = (dp.GradBuckets(dp.stage_buckets(model), world, hooks=False, collect=collect, force_collectives=dp_path)
+               if not cfg.forward_only and (world > 1 or dp_path) else None)
+    calls = [0]
 
     def compute():                      # the hot path: forward (+ loss + backward)
+        calls[0] += 1
         if cfg.forward_only:
             with torch.no_grad():
                 return loss_of(model(pts))
@@ -424,12 +494,15 @@ def measure(cfg, rank, local_rank, world, dev, first=True):
                 p.grad = None
         loss = loss_of(model(pts))
         loss.backward()
+        if buckets is not None:
+            buckets.pack()              # (pack form) the step's gradients -> the flat buffer, one multi-tensor copy
         return loss
 
     def finish():
         if not cfg.forward_only:
             if buckets is not None:
-                buckets.finish()
+                # a replayed graph has no hook points: nothing to overlap with, ONE all-reduce of the whole buffer
+                buckets.finish(one_collective=graph is not None)
             opt.step()
 
     def eager_step():
@@ -467,11 +540,11 @@ def measure(cfg, rank, local_rank, world, dev, first=True):
             if rank == 0:
                 print(f"[bench] HIP graph capture unavailable ({type(e).__name__}: {e}); eager launches", file=sys.stderr)
 
-    if first:
-        dp.init_from_env()                       # RCCL communicator (world > 1), after the capture
+    if first or dp_path:
+        dp.init_from_env(force=dp_path)          # RCCL communicator (world > 1 or --dp-path), after the capture
     dp.broadcast_parameters(model)
-    if graph is None and buckets is not None and world > 1:      # eager: per-stage all-reduce from backward hooks
-        buckets = dp.GradBuckets(dp.stage_buckets(model), world, hooks=True)
+    if graph is None and buckets is not None:    # eager: per-stage all-reduce from backward hooks
+        buckets = dp.GradBuckets(dp.stage_buckets(model), world, hooks=True, force_collectives=dp_path)
 
     def step():
         if graph is None:
@@ -529,20 +602,38 @@ def measure(cfg, rank, local_rank, world, dev, first=True):
         "vs_baseline": None, "dtype": dtype_name, "data": "synthetic",
         "config": {"workload": WORKLOADS[cfg.model] + (HEADS[cfg.model] if head else ", backbone only)")
                                + f", B={batch}/GPU N={points} K={nn_desc} A=60 "
-                               + (("fp32 (contractions: lossless 3xbf16 split on bf16 MFMA, fp32 accumulate)"
+                               + (("fp32 (contractions: lossless 3xbf16 split, fp32 accumulate)"
                                    if split_gemm else "fp32") if dtype_name == "f32" else "bf16 features / fp32 accumulate")
                                + f", {'fwd' if cfg.forward_only else 'fwd+bwd+Adam'}",
-                   "global_batch": batch * world, "points": points, "anchors": 60, "launch": launch,
+                   "global_batch": batch * world, "launch": launch,
                    "hbm_peak_gb": round(torch.cuda.max_memory_allocated(dev) / 2 ** 30, 1),
                    "fp32_gemm": ("split" if split_gemm else "native") if dtype_name == "f32" else None,
-                   "inter_mode": os.environ.get("EPN_INTER_MODE", "auto"),
                    "parallelism": f"dp{world}"},
     }
+    if os.environ.get("EPN_INTER_MODE", "auto") != "auto":
+        out["config"]["inter_mode"] = os.environ["EPN_INTER_MODE"]
+    if dp_path:
+        out["config"]["dp_path"] = f"{collect}+1 all-reduce" if graph is not None else "hooks"
     if rank == 0:
         # PMC passes exist for the cls fp32 step (B=32) and the rotation network's bf16 step (B=64): their kernels' traffic
         profiled = (not cfg.forward_only) and ((cfg.model, batch, dtype_name) in (("cls", 32, "f32"), ("reg", 64, "bf16")))
-        out["roofline"], detail = roofline_of(records, prof_steps, dtype_name,
-                                              PMC_FILES.get(f"{cfg.model}_{dtype_name}") if profiled else None, graph is not None)
+        pmc_file = PMC_FILES.get(f"{cfg.model}_{dtype_name}") if profiled else None
+        out["roofline"], detail = roofline_of(records, prof_steps, dtype_name, pmc_file, graph is not None)
+        if head:
+            # what the STEP achieves (SURVEY 8d's algorithmic work of the config / the measured step time) beside the
+            # dominant kernel's figure; HBM GB per step from the committed PMC pass of the same workload
+            fl, by = algorithmic_work(layers, batch, points, 4 if dtype_name == "f32" else 2, backward=not cfg.forward_only)
+            tf = fl / (dt / cfg.steps) / 1e12
+            st = {"algorithmic_tflops": round(tf, 1), "frac_fp32_matrix": round(tf / PEAK_TFLOPS["f32"], 3),
+                  ("frac_bf16_pipe_x6" if split_gemm else "frac_bf16_pipe"):
+                      round(tf * (6 if split_gemm else 1) / PEAK_TFLOPS["bf16"], 3),
+                  "algorithmic_gb": round(by / 1e9, 1)}
+            gb = recorded_step_traffic(pmc_file) if pmc_file else None
+            if gb:
+                st["hbm_gb"], st["hbm_over_algorithmic"] = gb, round(gb * 1e9 / by, 1)
+            out["roofline"]["step"] = st
+        detail["compute_calls"] = calls[0]
+        print(f"[bench] compute_calls {calls[0]}", file=sys.stderr)
     else:
         detail = None
     handles = dict(detail=detail, model=model, layers=layers, flat_pts=flat_pts, compute=compute, finish=finish, opt=opt, graph=graph,
@@ -555,15 +646,26 @@ LINE_LIMIT = 3000            # bytes: the driver keeps ~9 KB of stdout; round 3'
 
 
 def compact_config(o):
-    """An embedded config of the one-line report: the numbers and the priced dominant kernel only."""
+    """An embedded config of the one-line report: the numbers, the priced dominant kernel and the step-level figures only
+    (the workload text of each is in the detail file and in DESIGN.md 5; the key names the BASELINE config)."""
     if "error" in o:
         return {"error": o["error"][:120]}
     r = o.get("roofline", {})
-    c = {"value": o["value"], "ms_per_step": o["ms_per_step"], "steps": o["steps"], "dtype": o["dtype"],
-         "workload": re.sub(r" \([^)]*\)", "", o["config"]["workload"]), "bound": r.get("bound"), "frac": r.get("frac"), "kernel": r.get("kernel")}
+    c = {"value": o["value"], "ms_per_step": o["ms_per_step"], "steps": o["steps"]}
+    if "overhead_ms" in o:          # the rank program: the headline's kernels, what matters is its difference to the headline
+        c.update({k: o[k] for k in ("overhead_ms", "vs_headline", "collect", "predicted_eff_8gpu", "assumes") if k in o})
+        return c
+    c.update(bound=r.get("bound"), frac=r.get("frac"), kernel=r.get("kernel"))
+    if r.get("traffic"):
+        c["traffic"] = r["traffic"]
     for k in ("dominant_memory_bound_kernel", "dominant_mfma_kernel"):
         if k in r:
-            c["other_roof"] = {"bound": "hbm" if "memory" in k else "mfma", "kernel": r[k]["kernel"], "frac": r[k]["frac"]}
+            c["other_roof"] = {"kernel": r[k]["kernel"], "frac": r[k]["frac"]}        # (the roof `bound` does not name)
+    if "step" in r:
+        st = r["step"]
+        c["step"] = {"tflops": st["algorithmic_tflops"]}
+        if st.get("hbm_gb"):
+            c["step"].update(hbm_gb=st["hbm_gb"], hbm_x=st["hbm_over_algorithmic"])
     if "vs_cpu_forward" in o:
         c["vs_cpu_forward"] = o["vs_cpu_forward"]
     return c
@@ -580,13 +682,15 @@ def compact_line(out):
     if "cpu_baseline" in out:
         line["cpu_baseline"] = {k: out["cpu_baseline"][k] for k in
                                 ("value", "unit", "cores", "kind", "samples", "forward_only_value", "sample")}
+        sw = out["cpu_baseline"].get("sweep", {}).get("one_cloud_forward_s_by_threads")
+        if sw:
+            line["cpu_baseline"]["sweep_s"] = sw
     if "native_fp32_mfma" in out:
         n = out["native_fp32_mfma"]
         line["native_fp32_mfma"] = ({"value": n["value"], "ms_per_step": n["ms_per_step"]} if "value" in n
                                     else {"error": n["error"][:120]})
     if "index_kernels" in out:
-        line["index_kernels"] = {k: {"us_per_launch": v["us_per_launch"], "GB/s": v["GB/s"]}
-                                 for k, v in out["index_kernels"].items()}
+        line["index_kernels"] = {k + "_us": v["us_per_launch"] for k, v in out["index_kernels"].items()}
     if "configs" in out:
         line["configs"] = {k: compact_config(v) for k, v in out["configs"].items()}
     line["detail"] = os.path.relpath(DETAIL_FILE, ROOT) if DETAIL_FILE.startswith(ROOT) else DETAIL_FILE
@@ -602,15 +706,27 @@ def fit_line(line):
 
     def drop_workloads(l):
         for c in l.get("configs", {}).values():
-            c.pop("workload", None)
-    trims = [lambda l: l.pop("index_kernels", None), drop_other_roofs, drop_workloads,
-             lambda l: l["roofline"].pop("dominant_memory_bound_kernel", None) or l["roofline"].pop("dominant_mfma_kernel", None),
+            c.pop("traffic", None)
+    def drop_roofs_of_line(l):
+        r = l.get("roofline", {})
+        r.pop("dominant_memory_bound_kernel", None)
+        r.pop("dominant_mfma_kernel", None)
+
+    def drop_config_steps(l):
+        for c in l.get("configs", {}).values():
+            c.pop("step", None)
+            c.pop("assumes", None)
+    trims = [drop_workloads, drop_other_roofs, lambda l: l.pop("index_kernels", None),
+             lambda l: l.get("cpu_baseline", {}).pop("sweep_s", None), drop_config_steps, drop_roofs_of_line,
              lambda l: l.pop("configs", None), lambda l: l.pop("native_fp32_mfma", None)]
     text = json.dumps(line)
     for t in trims:
         if len(text) < LINE_LIMIT:
             break
-        t(line)
+        try:                                     # a line is ALWAYS emitted: a failing trim is skipped, not fatal
+            t(line)
+        except Exception:
+            pass
         text = json.dumps(line)
     return text
 
@@ -711,6 +827,32 @@ def main():
                 extras[name] = {k: o[k] for k in ("metric", "value", "unit", "ms_per_step", "steps", "dtype", "config", "roofline")}
             except Exception as e:                          # a report, never a requirement
                 extras[name] = {"error": f"{type(e).__name__}: {e}"}
+        if not args.dp_path:
+            # The program ONE RANK of `--gpus N` runs (BASELINE configs[4]), measured on the single GPU a bench box has: flat
+            # gradient buffer + all-reduce on a 1-rank RCCL communicator inside the timed region.  LAST of the embedded
+            # configs: the communicator's watchdog thread must not exist while another workload captures its graph.
+            gc.collect()
+            torch.cuda.empty_cache()
+            c = copy.copy(args)
+            c.dp_path, c.warmup = True, min(args.warmup, 2)
+            try:
+                o, h = measure(c, rank, local_rank, world, dev, first=False)
+                grad_mb = sum(p.numel() for p in h["model"].parameters() if p.requires_grad) * 4 / 1e6
+                detail["configs"]["cls_dp_rank"] = h["detail"]
+                h.clear()
+                e = {k: o[k] for k in ("metric", "value", "unit", "ms_per_step", "steps", "dtype", "config", "roofline")}
+                wire_ms = grad_mb * 1e6 * 2 * 7 / 8 / (XGMI_ALLREDUCE_BUSBW_GBS * 1e9) * 1e3 + XGMI_ALLREDUCE_LATENCY_MS
+                e.update(overhead_ms=round(o["ms_per_step"] - out["ms_per_step"], 3),
+                         vs_headline=round(o["value"] / out["value"], 4), collect=o["config"].get("dp_path"),
+                         predicted_eff_8gpu=round(out["ms_per_step"] / (o["ms_per_step"] + wire_ms), 4),
+                         assumes=f"t1/(t_rank+wire); wire {wire_ms:.2f} ms = {grad_mb:.1f} MB ring all-reduce, 8 GPUs, "
+                                 f"{XGMI_ALLREDUCE_BUSBW_GBS:.0f} GB/s busbw + {XGMI_ALLREDUCE_LATENCY_MS} ms (ASSUMED, unmeasured), "
+                                 f"no overlap")
+                extras["cls_dp_rank"] = e
+            except Exception as e:                          # a report, never a requirement
+                extras["cls_dp_rank"] = {"error": f"{type(e).__name__}: {e}"}
+            if torch.distributed.is_initialized():
+                torch.distributed.destroy_process_group()
         out["configs"] = extras
     if rank == 0:
         if cpu is not None:
@@ -720,7 +862,7 @@ def main():
                 out["configs"]["cls_fwd"]["vs_cpu_forward"] = round(
                     out["configs"]["cls_fwd"]["value"] / out["cpu_baseline"]["forward_only_value"], 1)
         emit(out, detail)
-    if world > 1:
+    if torch.distributed.is_initialized():
         torch.distributed.destroy_process_group()
 
 

@@ -91,7 +91,8 @@ def init_from_env(backend=None, force=False):
             # EPN_DP_BACKEND=gloo: rehearsal of the multi-rank path on a box with fewer GPUs than ranks (see local_device)
             backend = os.environ.get("EPN_DP_BACKEND") or ("nccl" if torch.cuda.is_available() else "gloo")
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        os.environ.setdefault("MASTER_PORT", "29500")
+        # (a forced single-rank group rendezvouses with itself: any free port; real launchers always set one)
+        os.environ.setdefault("MASTER_PORT", str(free_port()) if world == 1 else "29500")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")   # dmabuf IPC only on this driver (RCCL needs it)
         kwargs = {}
         if backend == "nccl":
@@ -128,30 +129,43 @@ class GradBuckets:
       over xGMI against a >100 ms step.
     xGMI is point-to-point (7 links x ~153 GB/s per GPU): few large buckets, not NCCL-style 25 MB chunks."""
 
-    def __init__(self, buckets, world, hooks=True):
+    def __init__(self, buckets, world, hooks=True, collect="accumulate", force_collectives=False):
+        """collect="accumulate": `p.grad` are views of the flat buffer for the whole step, autograd's AccumulateGrad nodes
+        add into them (one small kernel per parameter + the zero fill of zero()).  collect="pack": autograd keeps handing
+        fresh gradient tensors to `p.grad` (the single-rank program, no accumulate kernels) and pack() gathers them into
+        the flat buffer with ONE multi-tensor copy (torch._foreach_copy_) at the end of backward -- graph-capturable; the
+        form bench.py's replayed step uses.  force_collectives=True issues the all-reduces on a world of one as well (the
+        rank program measured on the single GPU a bench box has)."""
+        assert collect in ("accumulate", "pack")
         self.world = world
+        self.collect = collect
+        self.force = bool(force_collectives)
         self.buckets = [[p for p in b if p.requires_grad] for b in buckets]
         self.buckets = [b for b in self.buckets if b]
         params = [p for b in self.buckets for p in b]
         if not params:
             raise ValueError("no trainable parameters")
         dev, total = params[0].device, sum(p.numel() for p in params)
+        self.params = params
         self.flat = torch.zeros(total, dtype=torch.float32, device=dev)
-        self.spans, off = [], 0
+        self.spans, self.views, off = [], [], 0
         for b in self.buckets:
             start = off
             for p in b:
-                p.grad = self.flat[off:off + p.numel()].view_as(p)
+                self.views.append(self.flat[off:off + p.numel()].view_as(p))
+                if collect == "accumulate":
+                    p.grad = self.views[-1]
                 off += p.numel()
             self.spans.append((start, off))
         self._pending = [len(b) for b in self.buckets]
         self._works = []
         self._handles = []
-        if hooks and world > 1:
+        hooks = hooks and collect == "accumulate" and (world > 1 or self.force)
+        if hooks:
             for bi, b in enumerate(self.buckets):
                 for p in b:
                     self._handles.append(p.register_post_accumulate_grad_hook(self._make_hook(bi)))
-        self.hooks = hooks and world > 1
+        self.hooks = hooks
 
     def _make_hook(self, bi):
         def hook(_p):
@@ -173,17 +187,52 @@ class GradBuckets:
         self._works.append(dist.all_reduce(self.flat[a:b], op=dist.ReduceOp.SUM, async_op=True))
 
     def zero(self):
-        self.flat.zero_()
+        """Start of a step.  accumulate: zero the flat buffer (autograd adds into its views); pack: drop the gradient
+        tensors so that autograd hands over fresh ones (no fill, no accumulate kernels)."""
+        if self.collect == "pack":
+            for p in self.params:
+                p.grad = None
+        else:
+            self.flat.zero_()
         self._pending = [len(b) for b in self.buckets]
 
-    def finish(self):
-        """Complete this step's all-reduces (issuing them first when no hooks ran) and average.  Returns the number of
-        collectives of the step."""
-        if self.world <= 1:
+    def pack(self):
+        """collect="pack", end of backward: the step's gradient tensors -> the flat buffer in one multi-tensor copy, and
+        `p.grad` := the views (what the all-reduce averages and the optimizer reads).  A parameter that received no
+        gradient this step contributes zeros.  No-op in the accumulate form."""
+        if self.collect != "pack":
+            return
+        dst, src = [], []
+        for p, v in zip(self.params, self.views):
+            g = p.grad
+            if g is None:
+                v.zero_()
+            elif g.data_ptr() != v.data_ptr():
+                dst.append(v)
+                src.append(g if g.dtype == v.dtype else g.to(v.dtype))
+            p.grad = v
+        if dst:
+            torch._foreach_copy_(dst, src)
+
+    def _span_all(self):
+        return [(self.spans[0][0], self.spans[-1][1])]
+
+    def finish(self, one_collective=False):
+        """Complete this step's all-reduces (issuing them first when no hooks ran) and average.  one_collective=True (no
+        hooks: nothing to overlap with) sends the whole flat buffer as ONE all-reduce -- xGMI is point-to-point, a ring
+        step costs its latency per collective.  Returns the number of collectives of the step."""
+        if self.world <= 1 and not self.force:
             return 0
         if not self.hooks:
-            for bi in range(len(self.buckets)):
-                self._issue(bi)
+            if one_collective:
+                saved, self.spans = self.spans, self._span_all()
+                try:
+                    self._issue(0)
+                finally:
+                    self.spans = saved
+            else:
+                for bi in range(len(self.buckets)):
+                    self._issue(bi)
         else:
             for bi, n in enumerate(self._pending):      # a bucket whose parameters got no gradient this step
                 if n > 0:
@@ -192,7 +241,8 @@ class GradBuckets:
         for w in self._works:
             w.wait()
         self._works = []
-        self.flat.div_(self.world)
+        if self.world > 1 or self.force:
+            self.flat.div_(self.world)
         self._pending = [len(b) for b in self.buckets]
         return n
 

@@ -46,9 +46,9 @@ def full_output():
     r32, d32 = bench.roofline_of(canned_records("f32"), 1, "f32", None, True)
     r16, d16 = bench.roofline_of(canned_records("bf16"), 1, "bf16", None, True)
     wl = ("ModelNet40 cls (cls_so3net_pn: 7 separable SO3 blocks + ClsOutBlockPointnet), B=32/GPU N=1024 K=32/16 A=60 fp32 "
-          "(contractions: lossless 3xbf16 split on bf16 MFMA, fp32 accumulate), fwd+bwd+Adam")
-    cfg = {"workload": wl, "global_batch": 32, "points": 1024, "anchors": 60, "launch": "hipgraph", "hbm_peak_gb": 35.2,
-           "fp32_gemm": "split", "inter_mode": "auto", "parallelism": "dp1"}
+          "(contractions: lossless 3xbf16 split, fp32 accumulate), fwd+bwd+Adam")
+    cfg = {"workload": wl, "global_batch": 32, "launch": "hipgraph", "hbm_peak_gb": 35.2,
+           "fp32_gemm": "split", "parallelism": "dp1"}
     base = {"metric": "point-clouds/sec fwd+bwd, ModelNet40 N=1024 A=60", "value": 396.923, "unit": "point-clouds/s",
             "n_gpus": 1, "steps": 20, "warmup": 5, "ms_per_step": 80.621, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f32", "data": "synthetic", "config": cfg, "roofline": r32}
@@ -57,12 +57,23 @@ def full_output():
     out["index_kernels"] = {"fps": {"n": 1024, "m": 512, "us_per_launch": 269.8, "us_per_cloud": 8.43, "GB/s": 1.7, "bound": "l"},
                             "ball_query": {"queries": 512, "support": 1024, "K": 32, "us_per_launch": 16.3, "us_per_cloud": 0.51,
                                            "GB/s": 164.4}}
-    out["configs"] = {n: dict(base, dtype="bf16", roofline=r16, vs_cpu_forward=1819.3)
+    step = {"algorithmic_tflops": 163.1, "frac_fp32_matrix": 1.037, "frac_bf16_pipe_x6": 0.391, "algorithmic_gb": 19.3,
+            "hbm_gb": 250.3, "hbm_over_algorithmic": 13.0}
+    out["roofline"] = dict(r32, step=step)
+    other = {"dominant_mfma_kernel": {"kernel": "gemm_tn_f32_kernel<2,2,1,1,32,true>", "achieved": 116.0, "unit": "TFLOP/s",
+                                      "frac": 0.0465, "traffic": None, "avg_launch_ms": 0.1}}
+    out["configs"] = {n: dict(base, dtype="bf16", roofline=dict(r16, traffic=1652000000, step=step, **other), vs_cpu_forward=1819.3)
                       for n in ("cls_fwd", "reg_bf16", "inv_bf16")}
+    out["configs"]["cls_fwd"]["roofline"] = dict(r16, step={"algorithmic_tflops": 157.0}, **other)     # forward: no PMC pass
+    out["configs"]["cls_dp_rank"] = dict(base, roofline=dict(r32, step=step), overhead_ms=0.412, vs_headline=0.9947,
+                                         collect="pack+1 all-reduce", predicted_eff_8gpu=0.9876,
+                                         assumes="t1/(t_rank+wire); wire 0.60 ms = 31.3 MB ring all-reduce, 8 GPUs, 100 GB/s busbw "
+                                                 "+ 0.05 ms (ASSUMED, unmeasured), no overlap")
     out["cpu_baseline"] = {"value": 0.3734, "unit": "point-clouds/s", "cores": 16, "kind": "port", "samples": 2,
                            "forward_only_value": 0.6078, "all_samples_s": [10.7, 10.9],
-                           "sample": "4 clouds N=1024 A=60, fwd+bwd x2 (median 10.7 s, fwd 6.6 s), oracle/backbone_ref.py on 16 "
-                                     "torch threads of 256 host CPUs"}
+                           "sweep": {"one_cloud_forward_s_by_threads": {"16": 1.52, "64": 2.31, "256": 7.9}},
+                           "sample": "4 clouds fwd+bwd x2, median 10.7 s (fwd 6.6); oracle/backbone_ref.py; threads = best of sweep_s; "
+                                     "256/256 host CPUs usable"}
     return out, {"headline": d32, "configs": {"reg_bf16": d16}}
 
 
@@ -76,10 +87,19 @@ def test_one_line_report_fits_the_driver_window():
         assert k in line, k
     assert set(line["roofline"]) <= {"bound", "kernel", "achieved", "peak", "unit", "frac", "algorithmic_fp32_tflops",
                                      "vs_fp32_mfma_peak", "traffic", "launches", "avg_launch_ms",
-                                     "algorithmic_bytes_per_launch", "dominant_memory_bound_kernel", "dominant_mfma_kernel"}
+                                     "algorithmic_bytes_per_launch", "dominant_memory_bound_kernel", "dominant_mfma_kernel",
+                                     "step"}
+    # what the STEP achieves is readable off the line (review item 5): TF/s, both fractions, GB per step and its ratio
+    assert set(line["roofline"]["step"]) >= {"algorithmic_tflops", "frac_fp32_matrix", "frac_bf16_pipe_x6", "hbm_gb",
+                                             "hbm_over_algorithmic"}
+    dpr = line["configs"]["cls_dp_rank"]
+    assert dpr["overhead_ms"] == 0.412 and dpr["predicted_eff_8gpu"] == 0.9876 and "ASSUMED" in dpr["assumes"]
+    assert line["configs"]["reg_bf16"]["traffic"] == 1652000000
     assert line["cpu_baseline"]["samples"] == 2 and "all_samples_s" not in line["cpu_baseline"]
+    assert all("other_roof" in c for n, c in line["configs"].items() if n != "cls_dp_rank")      # nothing had to be trimmed
     assert all(set(c) <= {"value", "ms_per_step", "steps", "dtype", "workload", "bound", "frac", "kernel", "other_roof",
-                          "vs_cpu_forward"} for c in line["configs"].values())
+                          "vs_cpu_forward", "traffic", "step", "overhead_ms", "vs_headline", "predicted_eff_8gpu", "assumes",
+                          "collect"} for c in line["configs"].values())
     assert "per_kernel" in detail["headline"] and len(detail["headline"]["per_kernel"]) >= 6
 
 

@@ -81,6 +81,50 @@ def test_launcher_gradbuckets_two_ranks(tmp_path):
             assert torch.allclose(g0, p.grad, atol=1e-6)
 
 
+def test_launcher_gradbuckets_pack_form_two_ranks(tmp_path):
+    """The form bench.py's replayed step uses (round 5): autograd hands fresh gradient tensors to p.grad (what a single rank
+    does), GradBuckets.pack() gathers them into the flat buffer with one multi-tensor copy, finish(one_collective=True)
+    averages the WHOLE buffer with one all-reduce; p.grad are views of the flat buffer afterwards (what Adam reads)."""
+    import sys as _sys
+    from epn_pointcloud_amd import dp
+    rc = dp.launch(2, [_sys.executable, os.path.join(ROOT, "tests", "dp_worker.py"), str(tmp_path), "pack"], timeout=600)
+    assert rc == 0
+    r0 = torch.load(tmp_path / "r0.pt")
+    r1 = torch.load(tmp_path / "r1.pt")
+    assert r0["collectives"] == 1 and r0["views"]
+    torch.manual_seed(0)
+    model = torch.nn.Sequential(torch.nn.Linear(6, 5), torch.nn.ReLU(), torch.nn.Linear(5, 3))
+    data = torch.arange(7 * 6, dtype=torch.float32).view(7, 6) / 10.0
+    for step in range(2):
+        model.zero_grad()
+        (model(data + step).square().sum() / 7.0).backward()
+        for g0, g1, p in zip(r0["grads"][step], r1["grads"][step], model.parameters()):
+            assert torch.equal(g0, g1)
+            assert torch.allclose(g0, p.grad, atol=1e-6)
+
+
+def test_gradbuckets_pack_single_process():
+    """pack(): parameters without a gradient contribute zeros, a second step does not accumulate onto the first, and a world
+    of one issues no collective unless forced (no process group exists here)."""
+    from epn_pointcloud_amd import dp
+    torch.manual_seed(1)
+    a, b, unused = torch.nn.Linear(4, 3), torch.nn.Linear(3, 2), torch.nn.Linear(2, 2)
+    gb = dp.GradBuckets([list(b.parameters()), list(a.parameters()) + list(unused.parameters())], 1, hooks=False, collect="pack")
+    x = torch.randn(5, 4)
+    for step in range(2):
+        gb.zero()
+        assert all(p.grad is None for p in a.parameters())
+        b(a(x + step)).sum().backward()
+        want = [p.grad.clone() for p in list(b.parameters()) + list(a.parameters())]
+        gb.pack()
+        assert gb.finish(one_collective=True) == 0
+        got = [p.grad for p in list(b.parameters()) + list(a.parameters())]
+        assert all(torch.equal(w, g) for w, g in zip(want, got))
+        assert all(p.grad.data_ptr() >= gb.flat.data_ptr() for p in gb.params)
+        assert all(float(p.grad.abs().sum()) == 0.0 for p in unused.parameters())
+    assert gb.flat.numel() == sum(p.numel() for p in gb.params)
+
+
 def test_shard_batch_covers_everything():
     from epn_pointcloud_amd import dp
     for gb in (1, 7, 32, 256):
