@@ -128,8 +128,8 @@ def parse():
     ap.add_argument("--cpu-clouds", type=int, default=4, help="sample size of the CPU baseline (SURVEY 8d: B=4 chunks)")
     ap.add_argument("--cpu-samples", type=int, default=2, help="timed fwd+bwd passes of the CPU baseline (median reported)")
     ap.add_argument("--cpu-threads", type=int, default=0,
-                    help="torch CPU threads of the baseline; 0 (default) = sweep {16, 64, all CPUs this process may run on} "
-                         "on a one-cloud forward pass and time the sample on the fastest")
+                    help="torch CPU threads of the baseline; 0 (default) = sweep {16, 64, physical cores} on a one-cloud "
+                         "forward pass and time the sample on the fastest")
     ap.add_argument("--forward-only", action="store_true")
     ap.add_argument("--no-graph", action="store_true", help="eager launches instead of replaying a captured HIP graph")
     ap.add_argument("--backbone-only", action="store_true", help="without the output head")
@@ -161,8 +161,10 @@ def cpu_baseline(layers, product_sd, n_points, n_clouds, threads=0, head=True, s
     """The oracle's materialising restatement of the same network (kind "port"), on the host cores: one warm-up
     forward of a single cloud, then `samples` timed forward + backward passes of `n_clouds` clouds (the median is
     reported); the forward share is reported separately (north_star states its >= 10x target on the forward pass).
-    threads=0: BASELINE.md asks for "all physical cores" -- the thread count is swept over {16, 64, every CPU the process
-    may use} with a one-cloud forward pass and the sample is timed on the fastest (`cores`); the sweep is in `sweep`."""
+    threads=0: BASELINE.md asks for "all physical cores" -- the thread count is swept over {16, 64, physical cores = half of
+    the host's logical CPUs} with a one-cloud forward pass and the sample is timed on the fastest (`cores`); the sweep is in
+    `sweep` (round 5, on the 2 x 64-core host of a GPU box: 16 threads 1.8 s, 64 threads 2.5 s, 256 threads 37 s -- the
+    materialising algorithm is bound by memory traffic and allocator contention, not by cores)."""
     from epn_pointcloud_amd import schedule as S
     from epn_pointcloud_amd.vgtk.so3conv import functional as L
     from epn_pointcloud_amd.vgtk import functional as fr
@@ -182,10 +184,10 @@ def cpu_baseline(layers, product_sd, n_points, n_clouds, threads=0, head=True, s
         ref(pts[:1])
     sweep = {}
     if not threads:
-        for t in sorted({min(16, avail), min(64, avail), avail}):
+        phys = max(1, min(avail, (os.cpu_count() or 2) // 2))      # SMT siblings are not "physical cores" 
+        for t in sorted({min(16, avail), min(64, avail), phys}):
             torch.set_num_threads(t)
             with torch.no_grad():
-                ref(pts[:1])                                # the pool of this size
                 t0 = time.perf_counter()
                 ref(pts[:1])
                 sweep[t] = round(time.perf_counter() - t0, 2)
@@ -740,7 +742,29 @@ def emit(out, detail):
     except OSError as e:
         print(f"[bench] cannot write {DETAIL_FILE}: {e}", file=sys.stderr)
     print("[bench] detail: " + json.dumps(full), file=sys.stderr, flush=True)
+    flush_native_stdout()
     print(fit_line(compact_line(out)), flush=True)
+
+
+def flush_native_stdout():
+    """Native libraries write to C stdio, which is block-buffered when stdout is a pipe or a file: RCCL's five-line version
+    banner (printed when a communicator is created) would otherwise be flushed at exit, AFTER the JSON line -- and the driver
+    parses the LAST stdout line.  Flush C stdio now, so that such output precedes the line."""
+    import ctypes
+    sys.stdout.flush()
+    try:
+        ctypes.CDLL(None).fflush(None)
+    except (OSError, AttributeError):
+        pass
+
+
+def stdout_to_stderr():
+    """After the JSON line: whatever native code still prints at teardown (communicator destruction) goes to stderr."""
+    flush_native_stdout()
+    try:
+        os.dup2(2, 1)
+    except OSError:
+        pass
 
 
 def main():
@@ -750,6 +774,8 @@ def main():
     if args.gpus > 1 and world == 1 and "EPN_DP_CHILD" not in os.environ:
         sys.exit(dp.launch(args.gpus, timeout=float(os.environ.get("EPN_DP_TIMEOUT", "1500"))))   # no launcher: start the ranks ourselves
     assert world == args.gpus, f"WORLD_SIZE={world} but --gpus {args.gpus}"
+    if rank != 0:
+        stdout_to_stderr()                              # under torchrun all ranks share stdout: only rank 0 owns it
     _lib.get_lib()                                      # fail loudly if the HIP library is missing
     assert torch.cuda.is_available(), "bench.py needs an MI355X"
     dev = dp.local_device(local_rank)
@@ -862,6 +888,7 @@ def main():
                 out["configs"]["cls_fwd"]["vs_cpu_forward"] = round(
                     out["configs"]["cls_fwd"]["value"] / out["cpu_baseline"]["forward_only_value"], 1)
         emit(out, detail)
+    stdout_to_stderr()                                  # every rank: nothing follows the JSON line on stdout
     if torch.distributed.is_initialized():
         torch.distributed.destroy_process_group()
 

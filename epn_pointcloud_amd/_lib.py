@@ -12,9 +12,11 @@ import torch
 _PKG = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("EPN_LIB", os.path.join(_PKG, "libepn_so3conv.so"))   # EPN_LIB: A/B builds (tools/)
 
+ABI_VERSION = 2          # EPN_ABI_VERSION of the include/epn_so3conv.h this binding was written against
+
 EXPORTS = [
-    "epn_version", "epn_strerror", "epn_set_kernel_policy",
-    "epn_ball_query_f32", "epn_fps_f32", "epn_gather_fwd_f32", "epn_gather_bwd_f32", "epn_initial_anchor_query_f32",
+    "epn_version", "epn_abi_version", "epn_strerror", "epn_set_kernel_policy",
+    "epn_ball_query_f32", "epn_fps_f32", "epn_fps_temp_f32", "epn_gather_fwd_f32", "epn_gather_bwd_f32", "epn_initial_anchor_query_f32",
     "epn_initial_anchor_query_f64", "epn_anchor_query_f64",
     "epn_inter_workspace_bytes", "epn_inter_is_fused", "epn_inter_so3conv_fwd_f32",
     "epn_inter_so3conv_bwd_data_f32", "epn_inter_so3conv_bwd_weight_f32", "epn_inter_weights_f32",
@@ -87,6 +89,13 @@ def get_lib():
             "`python -c 'import __graft_entry__ as g; g.build()'` (hipcc --offload-arch=gfx950). "
             "epn_pointcloud_amd has no CPU/eager fallback.")
     lib = ctypes.CDLL(LIB_PATH)
+    try:
+        got = int(lib.epn_abi_version())
+    except AttributeError:
+        got = None
+    if got != ABI_VERSION:
+        raise RuntimeError(f"{LIB_PATH} implements ABI revision {got}, this binding expects {ABI_VERSION} "
+                           "(include/epn_so3conv.h EPN_ABI_VERSION): rebuild the library -- signatures differ between revisions")
     lib.epn_version.restype = ctypes.c_char_p
     lib.epn_strerror.restype = ctypes.c_char_p
     lib.epn_last_kernel.restype = ctypes.c_char_p
@@ -101,6 +110,7 @@ def get_lib():
     lib.epn_gather_bwd_f32.argtypes = [_vp, _vp, _ci, _ci, _ci, _ci, _vp, _vp]
     lib.epn_ball_query_f64.argtypes = [_vp, _vp, _ci, _ci, _ci, ctypes.c_float, _ci, _vp, _vp]
     lib.epn_fps_f64.argtypes = [_vp, _ci, _ci, _ci, _vp, _vp, _vp]
+    lib.epn_fps_temp_f32.argtypes = lib.epn_fps_f64.argtypes
     lib.epn_gather_fwd_f64.argtypes = lib.epn_gather_fwd_f32.argtypes
     lib.epn_gather_bwd_f64.argtypes = lib.epn_gather_bwd_f32.argtypes
     dp = ctypes.POINTER(InterDesc)

@@ -88,7 +88,9 @@ static bool use_mfma(const epn_inter_desc *d) { return inter_uses_mfma(d) && !fo
 
 // 0.2: epn_gemm_nt_problem gained the trailing `col_stats` member (round 3) and epn_ball_query_f64 takes `float radius`
 // (round 4) -- callers compiled against the 0.1 header must be rebuilt; INTEGRATION.md "ABI revisions"
-extern "C" const char *epn_version(void) { return "epn_so3conv 0.2 (gfx950)"; }
+// 0.3 (round 5): epn_abi_version() added; new entry point epn_fps_temp_f32; nothing existing changed
+extern "C" const char *epn_version(void) { return "epn_so3conv 0.3 (gfx950)"; }
+extern "C" int epn_abi_version(void) { return EPN_ABI_VERSION; }
 
 extern "C" const char *epn_strerror(int code) {
     switch (code) {

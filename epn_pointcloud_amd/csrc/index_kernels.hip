@@ -279,31 +279,33 @@ __global__ __launch_bounds__(256) void gather_bwd_kernel(const T *__restrict__ g
     atomicAdd(grad_points + ((size_t)bi * c + ci) * n + a, grad_out[((size_t)bi * c + ci) * m + j]);
 }
 
-// fp64 FPS (furthest_point_sampling_cuda_kernel<scalar_t = double>, grouping_cuda_kernel.cu:351-466): not a hot path
-// (every shipped model samples fp32 coordinates), so this is the reference's own structure -- `block` virtual threads
-// scanning k = tid, tid + block, ..., a shared-memory tree with its __update tie rule (keep the first on ties) -- with
-// the running minima in global memory (temp) exactly like the reference.
-__global__ __launch_bounds__(1024) void fps_f64_kernel(const double *__restrict__ xyz, int n, int m, int block,
-                                                       double *__restrict__ temp, int32_t *__restrict__ idxs) {
-    __shared__ double dists[1024];
+// FPS with the running minima in global memory (furthest_point_sampling_cuda_kernel<scalar_t>, grouping_cuda_kernel.cu:351-466):
+// the reference's own structure -- `block` virtual threads scanning k = tid, tid + block, ... (no size limit: the strided
+// loop of :380-396), a shared-memory tree with its __update tie rule (keep the first on ties) -- with `temp` exactly like
+// the reference.  T = double: the fp64 dispatch (no shipped model samples fp64 coordinates); T = float: clouds beyond the
+// 32768 points the register-resident kernels above hold (epn_fps_temp_f32).  Neither is a hot path.
+template <typename T>
+__global__ __launch_bounds__(1024) void fps_temp_kernel(const T *__restrict__ xyz, int n, int m, int block,
+                                                        T *__restrict__ temp, int32_t *__restrict__ idxs) {
+    __shared__ T dists[1024];
     __shared__ int dists_i[1024];
     const int tid = threadIdx.x;
-    const double *d = xyz + (size_t)blockIdx.x * 3 * n;
-    double *tmp = temp + (size_t)blockIdx.x * n;
+    const T *d = xyz + (size_t)blockIdx.x * 3 * n;
+    T *tmp = temp + (size_t)blockIdx.x * n;
     int32_t *out = idxs + (size_t)blockIdx.x * m;
-    for (int k = tid; k < n; k += block) tmp[k] = 1e10;
+    for (int k = tid; k < n; k += block) tmp[k] = (T)1e10;
     if (tid == 0) out[0] = 0;
     __syncthreads();
     int old = 0;
     for (int j = 1; j < m; ++j) {
         int besti = 0;
-        double best = -1.0;
-        const double x1 = d[old], y1 = d[n + old], z1 = d[2 * n + old];
+        T best = (T)-1.0;
+        const T x1 = d[old], y1 = d[n + old], z1 = d[2 * n + old];
         for (int k = tid; k < n; k += block) {
-            const double x2 = d[k], y2 = d[n + k], z2 = d[2 * n + k];
-            if (sq3_t(x2, y2, z2) <= 1e-3) continue;
-            const double dd = sq3_t(x2 - x1, y2 - y1, z2 - z1);
-            const double d2 = dd < tmp[k] ? dd : tmp[k];
+            const T x2 = d[k], y2 = d[n + k], z2 = d[2 * n + k];
+            if ((double)sq3_t(x2, y2, z2) <= 1e-3) continue;       // `mag <= 1e-3`: a double literal (:385-387)
+            const T dd = sq3_t(x2 - x1, y2 - y1, z2 - z1);
+            const T d2 = dd < tmp[k] ? dd : tmp[k];
             tmp[k] = d2;
             besti = d2 > best ? k : besti;
             best = d2 > best ? d2 : best;
@@ -313,7 +315,7 @@ __global__ __launch_bounds__(1024) void fps_f64_kernel(const double *__restrict_
         __syncthreads();
         for (int off = block / 2; off >= 1; off >>= 1) {
             if (tid < off) {
-                const double v1 = dists[tid], v2 = dists[tid + off];
+                const T v1 = dists[tid], v2 = dists[tid + off];
                 const int i1 = dists_i[tid], i2 = dists_i[tid + off];
                 dists[tid] = v1 > v2 ? v1 : v2;
                 dists_i[tid] = v2 > v1 ? i2 : i1;
@@ -561,7 +563,17 @@ extern "C" int epn_fps_f64(const double *xyz, int b, int n, int m, double *temp,
     if (b == 0 || m == 0) return 0;
     if (!xyz || !temp || !idx) return EPN_ENULL;
     const int block = opt_n_threads(n);
-    EPN_LAUNCH(fps_f64_kernel, dim3(b), dim3(block), 0, epn_stream(stream), xyz, n, m, block, temp, idx);
+    EPN_LAUNCH(fps_temp_kernel<double>, dim3(b), dim3(block), 0, epn_stream(stream), xyz, n, m, block, temp, idx);
+    EPN_CHECK_LAUNCH();
+    return 0;
+}
+
+extern "C" int epn_fps_temp_f32(const float *xyz, int b, int n, int m, float *temp, int32_t *idx, epn_stream_t stream) {
+    if (b < 0 || n < 1 || m < 0) return EPN_EINVAL;
+    if (b == 0 || m == 0) return 0;
+    if (!xyz || !temp || !idx) return EPN_ENULL;
+    const int block = opt_n_threads(n);
+    EPN_LAUNCH(fps_temp_kernel<float>, dim3(b), dim3(block), 0, epn_stream(stream), xyz, n, m, block, temp, idx);
     EPN_CHECK_LAUNCH();
     return 0;
 }

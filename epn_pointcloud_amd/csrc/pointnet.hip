@@ -11,6 +11,11 @@
 namespace epn {
 namespace {
 
+// Sequential arg-max step in ascending point order with torch.max's semantics (the reference's `torch.max(dim=2)`,
+// so3conv/modules.py:230): the first maximum wins and NaN IS the maximum -- the first NaN sticks, so a diverged activation
+// shows up in the head's output instead of being silently dropped (advisor finding, round 4).
+__device__ __forceinline__ bool pn_takes(float v, float best) { return v > best || (v != v && best == best); }
+
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef int i32x4 __attribute__((ext_vector_type(4)));
 
@@ -103,7 +108,7 @@ __global__ __launch_bounds__(PN_T) void pointnet_fwd_kernel(PnArgs A) {
         }
 #pragma unroll
         for (int i = 0; i < PN_P; ++i)
-            if (p0 + i < A.p && acc[i] > best) { best = acc[i]; best_p = p0 + i; }   // first maximum wins
+            if (p0 + i < A.p && pn_takes(acc[i], best)) { best = acc[i]; best_p = p0 + i; }   // first maximum wins
     }
     if (o_ok) {
         const size_t at = ((size_t)bb * A.a + ai) * A.co + o;
@@ -215,7 +220,7 @@ __global__ __launch_bounds__(256) void pointnet_fwd_mfma_kernel(PnArgs A) {
 #pragma unroll
                 for (int nt = 0; nt < 2; ++nt) {
                     const float v = acc[mt][nt][r] + bias[nt] + w3[nt][0] * e0 + w3[nt][1] * e1 + w3[nt][2] * e2;
-                    if (p0 + pl < A.p && v > best[nt]) { best[nt] = v; bestp[nt] = p0 + pl; }   // ascending p: first max
+                    if (p0 + pl < A.p && pn_takes(v, best[nt])) { best[nt] = v; bestp[nt] = p0 + pl; }   // ascending p: first max
                 }
             }
     }
@@ -226,7 +231,10 @@ __global__ __launch_bounds__(256) void pointnet_fwd_mfma_kernel(PnArgs A) {
         for (int d = 16; d < 64; d <<= 1) {
             const float ov = __shfl_xor(best[nt], d, 64);
             const int op = __shfl_xor(bestp[nt], d, 64);
-            if (ov > best[nt] || (ov == best[nt] && op < bestp[nt])) { best[nt] = ov; bestp[nt] = op; }
+            const bool on = ov != ov, bn = best[nt] != best[nt];       // NaN is the maximum (torch.max), the first one wins
+            if ((on || bn) ? (on && (!bn || op < bestp[nt])) : (ov > best[nt] || (ov == best[nt] && op < bestp[nt]))) {
+                best[nt] = ov; bestp[nt] = op;
+            }
         }
         if (j == 0 && cok[nt]) {
             const size_t at = ((size_t)bb * A.a + ai) * A.co + co0 + 32 * wave + 16 * nt + x;
@@ -396,12 +404,12 @@ __global__ __launch_bounds__(256) void pointnet_max_kernel(PnMaxArgs A) {
 #pragma unroll
             for (int u = 0; u < 8; ++u) {
                 const float w = v[u] + bias + w3[0] * Es[i + u][0] + w3[1] * Es[i + u][1] + w3[2] * Es[i + u][2];
-                if (w > best) { best = w; bestp = p0 + i + u; }              // ascending p: first maximum wins
+                if (pn_takes(w, best)) { best = w; bestp = p0 + i + u; }     // ascending p: first maximum wins
             }
         }
         for (; i < np; ++i) {
             const float w = z[(size_t)(p0 + i) * zs] + bias + w3[0] * Es[i][0] + w3[1] * Es[i][1] + w3[2] * Es[i][2];
-            if (w > best) { best = w; bestp = p0 + i; }
+            if (pn_takes(w, best)) { best = w; bestp = p0 + i; }
         }
     }
     if (ok) {

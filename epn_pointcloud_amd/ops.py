@@ -254,14 +254,22 @@ class InterSO3ConvFn(torch.autograd.Function):
                                lambda: lib.epn_inter_so3conv_fwd_f32(ctypes.byref(d), _cl_ptr(f), _lib.dev_ptr(Wc, "W"),
                                                                      _cl_ptr(out), wsp, wsn, _lib.stream_of(f))),
                        "inter_so3conv_fwd")
-        ctx.save_for_backward(f, Wc)
-        ctx.geo, ctx.grouped = geo, grouped
+        # (the saved grouped values go through save_for_backward like any saved activation: saved-tensor hooks, version
+        # checks, release with the graph -- advisor finding, round 4)
+        if grouped is not None:
+            ctx.save_for_backward(f, Wc, grouped)
+        else:
+            ctx.save_for_backward(f, Wc)
+        ctx.geo, ctx.has_grouped = geo, grouped is not None
         return out
 
     @staticmethod
     def backward(ctx, grad_out):
         lib = _lib.get_lib()
-        f, Wc = ctx.saved_tensors
+        if ctx.has_grouped:
+            f, Wc, grouped = ctx.saved_tensors
+        else:
+            (f, Wc), grouped = ctx.saved_tensors, None
         geo = ctx.geo
         g = to_cl(grad_out, "grad_out")
         cout = Wc.shape[0]
@@ -276,7 +284,7 @@ class InterSO3ConvFn(torch.autograd.Function):
                                                                           _lib.dev_ptr(Wc, "W"), _cl_ptr(gf), wsp,
                                                                           wsn, _lib.stream_of(f))),
                        "inter_so3conv_bwd_data")
-        if ctx.needs_input_grad[1] and ctx.grouped is not None:
+        if ctx.needs_input_grad[1] and grouped is not None:
             gW = torch.empty_like(Wc)
             fl = 2.0 * d.b * d.p2 * d.na * cout * d.ks
             if os.environ.get("EPN_C1_DW", "gemm") == "gemm" and g.dtype == torch.float32:
@@ -284,10 +292,10 @@ class InterSO3ConvFn(torch.autograd.Function):
                 # library's TN kernels stream it at 3-4.5 TB/s, the dedicated kernel (one unpipelined stage per
                 # workgroup, 1536 atomics each) ran at 0.7 TB/s
                 _launch("inter_bwd_weight_c1", _inter_key(d), fl, f.device,
-                        lambda: gemm.gemm_tn(g.permute(0, 2, 3, 1).reshape(-1, cout), ctx.grouped, out=gW))
+                        lambda: gemm.gemm_tn(g.permute(0, 2, 3, 1).reshape(-1, cout), grouped, out=gW))
             else:
                 _lib.check(_launch("inter_bwd_weight_c1", _inter_key(d), fl, f.device,
-                                   lambda: lib.epn_inter_so3conv_bwd_weight_c1_f32(ctypes.byref(d), ctx.grouped.data_ptr(),
+                                   lambda: lib.epn_inter_so3conv_bwd_weight_c1_f32(ctypes.byref(d), grouped.data_ptr(),
                                                                                    _cl_ptr(g), _lib.dev_ptr(gW, "grad_W"),
                                                                                    _lib.stream_of(f))),
                            "inter_so3conv_bwd_weight_c1")
@@ -410,9 +418,26 @@ class InterSO3ConvSplitFn(torch.autograd.Function):
             return out, feats, part
         return out
 
+    # Tensor handles alive on a gradient that ONLY this backward can see: the engine's argument list + the Python wrapper.
+    # A consumer whose backward hands ONE tensor to two inputs (`shared + other`) leaves a third handle in the other input's
+    # buffer until that node has run -- writing in place would corrupt its gradient (advisor finding, round 4).
+    _SOLE_OWNER_HANDLES = 2
+
+    @staticmethod
+    def _sole_owner(t):
+        try:
+            return t._use_count() <= InterSO3ConvSplitFn._SOLE_OWNER_HANDLES
+        except AttributeError:                                  # a torch without the counter: never in place
+            return False
+
     @staticmethod
     def _may_write_into(ctx, grad_shared):
-        """May the scatter accumulate in place into the incoming gradient of the shared output?  (see forward)"""
+        """May the scatter accumulate in place into the incoming gradient of the shared output?  (see forward)  Only when
+        nobody else can observe that memory: the tensor (and, for the one accepted view, its base) has no other live handle,
+        no retained gradient and no hook."""
+        own = InterSO3ConvSplitFn._sole_owner
+        if not own(grad_shared):
+            return False
         base = grad_shared._base
         if base is not None:
             # a view: the base belongs to somebody else -- unless it is the fresh data gradient of the skip branch's 1x1
@@ -420,7 +445,7 @@ class InterSO3ConvSplitFn(torch.autograd.Function):
             # the whole buffer, seen by this Function alone (stride-1 blocks: three additions + three zero fills of a
             # [32, c, p, 60] tensor per classification step otherwise)
             if not (getattr(base, "_epn_private", False) and base.numel() == grad_shared.numel()
-                    and base.data_ptr() == grad_shared.data_ptr() and base.is_contiguous()):
+                    and base.data_ptr() == grad_shared.data_ptr() and base.is_contiguous() and own(base)):
                 return False
         ref = getattr(ctx, "shared_ref", None)
         shared = ref() if ref is not None else None

@@ -33,6 +33,12 @@ def furthest_point_sampling(source_xyz, m):
                                    _lib.dev_ptr(idx, "sampled_idx", torch.int32), _lib.stream_of(source_xyz)),
                    "furthest_point_sampling")
         return idx
+    if n > 32768:        # beyond the register-resident kernels: the reference's own structure, minima in `temp` (:167-168)
+        temp = torch.empty((b, n), dtype=torch.float32, device=source_xyz.device)
+        _lib.check(lib.epn_fps_temp_f32(p, b, n, int(m), _lib.dev_ptr(temp, "temp", dt),
+                                        _lib.dev_ptr(idx, "sampled_idx", torch.int32), _lib.stream_of(source_xyz)),
+                   "furthest_point_sampling")
+        return idx
     _lib.check(lib.epn_fps_f32(p, b, n, int(m), _lib.dev_ptr(idx, "sampled_idx", torch.int32),
                                _lib.stream_of(source_xyz)), "furthest_point_sampling")
     return idx

@@ -34,6 +34,13 @@ extern "C" {
 
 typedef void *epn_stream_t; /* hipStream_t; NULL = the null stream */
 
+/* Integer revision of this binary interface: bumped whenever an EXISTING signature or struct layout changes (new entry
+ * points alone do not bump it).  A host compares epn_abi_version() of the library it loaded with the EPN_ABI_VERSION of
+ * the header it was compiled against and refuses to run on a mismatch -- revision 2 changed `epn_ball_query_f64`'s radius
+ * from double to float and grew `struct epn_gemm_nt_problem`, which a caller built against revision 1 would not notice
+ * (INTEGRATION.md "ABI revisions").  epn_pointcloud_amd/_lib.py performs exactly this check at load time. */
+#define EPN_ABI_VERSION 2
+int epn_abi_version(void);
 const char *epn_version(void);
 const char *epn_strerror(int code);
 /* Diagnostic: the device kernel (exact template instance, "(anonymous namespace)::" removed, e.g.
@@ -60,8 +67,12 @@ int epn_ball_query_f32(const float *new_xyz, const float *xyz, int b, int n, int
 
 /* Replaces vgtk.cuda.grouping.furthest_point_sampling (grouping_cuda.cpp:160-174, kernel
  * grouping_cuda_kernel.cu:351-466).  xyz f32[b,3,n] -> idx i32[b,m].  The 1e10 `temp` buffer of
- * the reference lives in registers.  Requires 1 <= m, 1 <= n <= 32768. */
+ * the reference lives in registers.  Requires 1 <= m, 1 <= n <= 32768 (EPN_EINVAL beyond: use
+ * epn_fps_temp_f32, which keeps the running minima in a caller-provided `temp` f32[b,n] like the
+ * reference kernel -- its strided loop has no size limit, grouping_cuda_kernel.cu:380-396 -- and
+ * gives the same indices for every n). */
 int epn_fps_f32(const float *xyz, int b, int n, int m, int32_t *idx, epn_stream_t stream);
+int epn_fps_temp_f32(const float *xyz, int b, int n, int m, float *temp, int32_t *idx, epn_stream_t stream);
 
 /* Replace vgtk.cuda.gathering.gather_points_forward / _backward (gathering_cuda.cpp:29-60,
  * kernels gathering_cuda_kernel.cu:43-98).  points f32[b,c,n], idx i32[b,m] -> out f32[b,c,m];

@@ -612,6 +612,26 @@ def test_shared_input_gradient_is_folded_into_the_data_gradient(gpu, vgtk_alias,
         assert taken and taken[0][1] == (not taken[0][0]), taken
         monkeypatch.setattr(ops.InterSO3ConvSplitFn, "_may_write_into", orig)
 
+    # a consumer whose backward hands ONE gradient tensor to two inputs (`shared + other`; advisor finding, round 4): while the
+    # other input's node has not run, that tensor has a second owner -- the scatter must not accumulate into it.  `other` is
+    # created BEFORE the convolution, so its backward node runs AFTER the convolution's and would read the modified buffer.
+    if dt == "f32":
+        monkeypatch.setenv("EPN_SHARE_INPUT_GRAD", "1")
+        for through_view in (False, True):
+            f = feats.clone().requires_grad_(True)
+            other_leaf = torch.randn(b, cin, n, 60, device=gpu, requires_grad=True)
+            other = other_leaf * 1.0                             # older than the convolution's node
+            w = W.clone().requires_grad_(True)
+            out, h2, _part = ops.inter_so3conv(f * 1.0, w, geo, share_input=True)
+            if through_view:
+                mixed = (h2.permute(0, 2, 3, 1).reshape(-1, cin) + other.permute(0, 2, 3, 1).reshape(-1, cin)) * side_w.permute(0, 2, 3, 1).reshape(-1, cin)
+            else:
+                mixed = (h2 + other) * side_w
+            ((out ** 2).sum() + mixed.sum()).backward()
+            torch.cuda.synchronize()
+            assert torch.equal(other_leaf.grad, side_w), through_view          # untouched by the scatter
+            assert (f.grad - gf_ref).abs().max().item() <= tol * (gf_ref.abs().max().item() + 1e-12), through_view
+
     # a frozen input: no differentiable alias is handed out, W still gets its gradient, statistics still come back
     w = W.clone().requires_grad_(True)
     out, h2, part = ops.inter_so3conv(feats, w, geo, share_input=True)

@@ -38,6 +38,26 @@ def test_fps_vs_oracle_shapes(ext, b, n, m):
     assert torch.equal(got, index_ref.furthest_point_sampling(x, m))
 
 
+def test_fps_beyond_32768_points(ext):
+    """Float FPS has no size limit in the reference (strided loop, grouping_cuda_kernel.cu:380-396): clouds beyond what the
+    register-resident kernels hold go through epn_fps_temp_f32 (running minima in `temp`, the reference's own structure) --
+    bit-exact against the oracle at n = 40000, and the same indices as the register kernels where both apply."""
+    cuda_nn, _, dev = ext
+    from epn_pointcloud_amd import _lib
+    rng = np.random.default_rng(40000)
+    x = T(unit_ball_cloud(rng, 2, 40000))
+    got = cuda_nn.furthest_point_sampling(x.to(dev), 48).cpu()
+    assert got.dtype == torch.int32 and torch.equal(got, index_ref.furthest_point_sampling(x, 48))
+    lib = _lib.get_lib()
+    for n, m in ((1000, 300), (6, 4), (20000, 30)):
+        y = T(unit_ball_cloud(rng, 2, n)).to(dev)
+        temp = torch.empty(2, n, device=dev)
+        idx = torch.empty(2, m, dtype=torch.int32, device=dev)
+        _lib.check(lib.epn_fps_temp_f32(y.data_ptr(), 2, n, m, temp.data_ptr(), idx.data_ptr(), _lib.stream_of(y)), "fps_temp")
+        assert torch.equal(idx, cuda_nn.furthest_point_sampling(y, m)), n
+    assert lib.epn_fps_f32(x.to(dev).data_ptr(), 2, 40000, 4, got.to(dev).data_ptr(), None) != 0     # EPN_EINVAL, not garbage
+
+
 def test_fps_ties_and_degenerate(ext):
     cuda_nn, _, dev = ext
     rng = np.random.default_rng(1)

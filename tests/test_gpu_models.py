@@ -72,6 +72,30 @@ def test_pointnet_vs_oracle(gpu, monkeypatch, form, b, c, co, p, na):
         assert (u.cpu() - v).abs().max().item() < TOL * max(1.0, v.abs().max().item()), n
 
 
+@pytest.mark.parametrize("form", ["gemm", "fused"])
+def test_pointnet_max_propagates_nan(gpu, monkeypatch, form):
+    """The max over points is torch.max's (so3conv/modules.py:230): a NaN activation IS the maximum of its (cloud, anchor,
+    channel) column -- a diverged run must show in the head's output, not be filtered out (advisor finding, round 4) -- and the
+    other columns are unaffected."""
+    from epn_pointcloud_amd import ops
+    monkeypatch.setenv("EPN_POINTNET", form)
+    b, c, co, p, na = 2, 128, 128, 70, 60
+    rng = np.random.default_rng(3)
+    torch.manual_seed(3)
+    xyz = T(unit_ball_cloud(rng, b, p)).to(gpu)
+    f = torch.randn(b, c, p, na, device=gpu)
+    anchors = torch.linalg.qr(torch.randn(na, 3, 3))[0].contiguous().to(gpu)
+    w, bias = torch.randn(co, c + 3, 1, 1, device=gpu) / c ** 0.5, torch.randn(co, device=gpu)
+    clean = ops.pointnet_so3conv(f, xyz, anchors, w, bias)
+    f2 = f.clone()
+    f2[1, :, 37, 5] = float("nan")                    # every channel of one (cloud, point, anchor) row
+    y = ops.pointnet_so3conv(f2, xyz, anchors, w, bias)
+    assert torch.isnan(y[1, :, 5]).all()
+    mask = torch.ones_like(y, dtype=torch.bool)
+    mask[1, :, 5] = False
+    assert torch.equal(y[mask], clean[mask])
+
+
 def test_pointnet_bf16_features(gpu):
     """bf16 features go through the GEMM-composed form in bf16 (bf16 matrix pipe, fp32 accumulate, bf16 dZ / dF): against
     the fp32 oracle on the bf16-rounded inputs, within bf16 rounding of the operands; the arg-max may move between
