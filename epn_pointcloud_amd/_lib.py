@@ -302,6 +302,20 @@ class _LibProxy:
         return call
 
 
+class kernel_policy:
+    """`with _lib.kernel_policy(n):` -- epn_set_kernel_policy(n) for the block (1 = generic kernels, 2 = the first layer's VALU
+    kernel instead of its matrix-pipe form); cross-checks only."""
+
+    def __init__(self, policy):
+        self.policy = int(policy)
+
+    def __enter__(self):
+        check(get_lib().epn_set_kernel_policy(self.policy), "set_kernel_policy")
+
+    def __exit__(self, *exc):
+        check(get_lib().epn_set_kernel_policy(0), "set_kernel_policy")
+
+
 class generic_kernels:
     """`with _lib.generic_kernels():` -- run on the any-shape generic kernels (cross-check tests only)."""
 

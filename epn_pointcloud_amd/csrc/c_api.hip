@@ -10,10 +10,12 @@
 
 using namespace epn;
 
-static std::atomic<int> g_policy{0};   // the library's only process-wide state: 0 = best kernel, 1 = generic kernels
+static std::atomic<int> g_policy{0};   // the library's only process-wide state: 0 = best kernel, 1 = generic kernels,
+                                       // 2 = the first layer's VALU kernel instead of its matrix-pipe form (cross-check)
 static bool force_generic() { return g_policy.load(std::memory_order_relaxed) == 1; }
 
 namespace epn {
+bool first_layer_on_valu() { return g_policy.load(std::memory_order_relaxed) == 2; }
 #ifdef EPN_TUNING
 int kernel_policy() { return g_policy.load(std::memory_order_relaxed); }
 #else
@@ -65,9 +67,9 @@ extern "C" const char *epn_last_kernel(void) {
 
 extern "C" int epn_set_kernel_policy(int policy) {
 #ifdef EPN_TUNING   // tools/ builds (python -m epn_pointcloud_amd.build --tuning): 0x100 | cfg .. 0x400 | cfg = A/B switches
-    if (policy != 0 && policy != 1 && (policy & ~0xff) != 0x100 && (policy & ~0xff) != 0x200 && (policy & ~0xff) != 0x400 && (policy & ~0xff) != 0x800) return EPN_EINVAL;
+    if (policy != 0 && policy != 1 && policy != 2 && (policy & ~0xff) != 0x100 && (policy & ~0xff) != 0x200 && (policy & ~0xff) != 0x400 && (policy & ~0xff) != 0x800) return EPN_EINVAL;
 #else
-    if (policy != 0 && policy != 1) return EPN_EINVAL;
+    if (policy != 0 && policy != 1 && policy != 2) return EPN_EINVAL;
 #endif
     g_policy.store(policy, std::memory_order_relaxed);
     return 0;

@@ -27,6 +27,7 @@ static inline hipStream_t epn_stream(epn_stream_t s) { return (hipStream_t)s; }
 // call has launched nothing else.  Cost per launch: two thread-local stores.
 namespace epn {
 void note_kernel(const void *host_stub, bool aux);   // c_api.hip; thread-local, diagnostic only
+bool first_layer_on_valu();                           // c_api.hip: epn_set_kernel_policy(2)
 }  // namespace epn
 #define EPN_LAUNCH(kern, ...)                                                       \
     do {                                                                            \

@@ -471,8 +471,8 @@ bool inter_c1_bwd_weight_ok(const epn_inter_desc *d) {
 
 // matrix-pipe form: 24 kernel points, anchors in pairs, cout lanes per anchor, the B table + staging within the 160 KB of LDS
 static bool c1_mfma_ok(const epn_inter_desc *d) {
-    const char *e = getenv("EPN_C1_MFMA");       // "0": the VALU kernel for every input (A/B, tests)
-    return !(e && e[0] == '0') && d->ks == EPN_C1M_KS && d->na % 2 == 0 && d->na <= 128 && d->nn >= 1 && d->nn <= 128 &&
+    // (epn_set_kernel_policy(2): the VALU kernel for every input -- A/B and cross-check; the library reads no environment)
+    return !first_layer_on_valu() && d->ks == EPN_C1M_KS && d->na % 2 == 0 && d->na <= 128 && d->nn >= 1 && d->nn <= 128 &&
            (d->cout == 16 || d->cout == 32 || d->cout == 64);
 }
 

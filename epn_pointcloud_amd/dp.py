@@ -9,6 +9,7 @@ or index exchange.
                          bucket's all-reduce is issued from a backward hook as soon as its last gradient is
                          written, i.e. it overlaps with the rest of the backward pass
 """
+import contextlib
 import os
 import socket
 import subprocess
@@ -75,6 +76,27 @@ def launch(world, argv=None, env=None, timeout=None):
         time.sleep(0.05)
 
 
+@contextlib.contextmanager
+def _native_stdout_to_stderr(active=True):
+    """File descriptor 1 points at stderr inside the block (C stdio flushed on both edges): what native libraries print to
+    stdout while a communicator is created lands on stderr."""
+    if not active:
+        yield
+        return
+    import ctypes
+    libc = ctypes.CDLL(None)
+    sys.stdout.flush()
+    libc.fflush(None)
+    saved = os.dup(1)
+    os.dup2(2, 1)
+    try:
+        yield
+    finally:
+        libc.fflush(None)
+        os.dup2(saved, 1)
+        os.close(saved)
+
+
 def env_world():
     """(rank, local_rank, world) from the torchrun environment, without touching torch.distributed."""
     return (int(os.environ.get("RANK", "0")), int(os.environ.get("LOCAL_RANK", "0")),
@@ -98,7 +120,15 @@ def init_from_env(backend=None, force=False):
         if backend == "nccl":
             torch.cuda.set_device(local_rank)                       # one process per GPU, bound before RCCL init
             kwargs["device_id"] = torch.device("cuda", local_rank)
-        dist.init_process_group(backend=backend, rank=rank, world_size=world, **kwargs)
+        with _native_stdout_to_stderr(backend == "nccl"):
+            dist.init_process_group(backend=backend, rank=rank, world_size=world, **kwargs)
+            if backend == "nccl":
+                # create the communicator NOW (a first collective), while stdout is parked: RCCL prints a five-line version
+                # banner to C stdout when it does, and a program whose stdout is parsed (bench.py: one JSON line) must not
+                # carry it -- block-buffered C stdio would even emit it at exit, after everything else
+                t = torch.zeros(1, device=torch.device("cuda", local_rank))
+                dist.all_reduce(t)
+                torch.cuda.synchronize()
     return rank, local_rank, world
 
 

@@ -15,6 +15,8 @@ softmax, relu).
 import os
 
 import torch
+
+from ._ab import ab
 import torch.nn as nn
 import torch.nn.functional as F
 
@@ -123,7 +125,7 @@ class RelSO3OutBlockR(nn.Module):
         # bf16 feature networks: the 60 x 60 anchor-pair tensor ([b, 2c, a, a]: 115 200 rows x 512 channels, the largest
         # tensor of the head) and its 1x1 MLP follow the backbone's storage format -- bf16 values, fp32 accumulation in the
         # GEMMs, fp32 again from the two output convolutions on (softmax, rotation regressor); EPN_REG_MLP_BF16=0: all fp32
-        low = f1.dtype == torch.bfloat16 and f1.is_cuda and os.environ.get("EPN_REG_MLP_BF16", "1") == "1"
+        low = f1.dtype == torch.bfloat16 and f1.is_cuda and ab("EPN_REG_MLP_BF16") == "1"
         f1, f2 = self._pooling(x1, f1), self._pooling(x2, f2)
         nb, _, na = f1.shape
         if low:
@@ -173,7 +175,7 @@ class _SO3ConvModel(nn.Module):
         for stage in self.backbone:
             x = stage(x)
         if x.feats.dtype != torch.float32 and not (self.HEAD_TAKES_BF16 and x.feats.is_cuda
-                                                   and os.environ.get("EPN_HEAD_BF16", "1") == "1"):
+                                                   and ab("EPN_HEAD_BF16") == "1"):
             # bf16 feature path: the heads run in fp32 (their inputs are small)
             x = zptk.SphericalPointCloud(x.xyz, ops.cast_feats(x.feats, torch.float32), x.anchors)
         return x

@@ -10,6 +10,8 @@ import weakref
 
 import torch
 
+from ._ab import ab
+
 from . import _lib, gemm
 
 
@@ -239,16 +241,18 @@ class InterSO3ConvFn(torch.autograd.Function):
         out = empty_cl(d.b, cout, d.p2, d.na, f.device)
         ws, wsp, wsn = _workspace(lib, d, f.device)
         grouped = None
-        if cin == 1 and lib.epn_inter_c1_ok(ctypes.byref(d)) and os.environ.get("EPN_C1_SAVE", "1") == "1":
+        if cin == 1 and lib.epn_inter_c1_ok(ctypes.byref(d)) and ab("EPN_C1_SAVE") == "1":
             # first layer: keep the 24 grouped values per column for the weight gradient (96 B per column) instead of
             # regenerating the ks x nn weights there -- only when a weight gradient can be asked for
             if ctx.needs_input_grad[1]:
                 grouped = torch.empty((d.b * d.p2 * d.na, d.ks), dtype=torch.float32, device=f.device)
-            _lib.check(_launch("inter_fwd", _inter_key(d), _inter_flops(d), f.device,
-                               lambda: lib.epn_inter_so3conv_fwd_c1_f32(ctypes.byref(d), _cl_ptr(f), _lib.dev_ptr(Wc, "W"),
-                                                                        _cl_ptr(out), grouped.data_ptr() if grouped is not None
-                                                                        else None, wsp, wsn, _lib.stream_of(f))),
-                       "inter_so3conv_fwd_c1")
+            import contextlib
+            with (_lib.kernel_policy(2) if ab("EPN_C1_MFMA") == "0" else contextlib.nullcontext()):   # A/B: the VALU kernel
+                _lib.check(_launch("inter_fwd", _inter_key(d), _inter_flops(d), f.device,
+                                   lambda: lib.epn_inter_so3conv_fwd_c1_f32(ctypes.byref(d), _cl_ptr(f), _lib.dev_ptr(Wc, "W"),
+                                                                            _cl_ptr(out), grouped.data_ptr() if grouped is not None
+                                                                            else None, wsp, wsn, _lib.stream_of(f))),
+                           "inter_so3conv_fwd_c1")
         else:
             _lib.check(_launch("inter_fwd", _inter_key(d), _inter_flops(d), f.device,
                                lambda: lib.epn_inter_so3conv_fwd_f32(ctypes.byref(d), _cl_ptr(f), _lib.dev_ptr(Wc, "W"),
@@ -287,7 +291,7 @@ class InterSO3ConvFn(torch.autograd.Function):
         if ctx.needs_input_grad[1] and grouped is not None:
             gW = torch.empty_like(Wc)
             fl = 2.0 * d.b * d.p2 * d.na * cout * d.ks
-            if os.environ.get("EPN_C1_DW", "gemm") == "gemm" and g.dtype == torch.float32:
+            if ab("EPN_C1_DW") == "gemm" and g.dtype == torch.float32:
                 # dW[o][k] = sum_col dOut[col][o] G[col][k] is a tall-skinny weight-gradient GEMM (2e6 x 32 x 24): the
                 # library's TN kernels stream it at 3-4.5 TB/s, the dedicated kernel (one unpipelined stage per
                 # workgroup, 1536 atomics each) ran at 0.7 TB/s
@@ -1096,7 +1100,7 @@ def intra_so3conv_spectral(feats, W, intra_idx32, basis, pre_norm=None, pre_slop
     else:
         y = ToSpectralFn.apply(f, basis)
     # What^rho[(j, c), (i, o)] = sum_k W[o, c, k] rho(g_k)[i, j]: one small GEMM for all blocks, then a re-layout each
-    if W.dtype == torch.float32 and kn <= 16 and os.environ.get("EPN_SPECTRAL_WEIGHTS", "fused") == "fused":
+    if W.dtype == torch.float32 and kn <= 16 and ab("EPN_SPECTRAL_WEIGHTS") == "fused":
         nb_ = len(basis.dims)
         outs = SpectralWeightsFn.apply(W, basis, cin, cout, y.dtype == torch.bfloat16)   # one kernel per layout and dtype
         whats = outs[:nb_]
@@ -1344,7 +1348,7 @@ class NormToSpectralFn(torch.autograd.Function):
         xc, sums, g, bt = ctx.saved_tensors
         groups, rows, c, eps, slope, has_cb, (b, _, p, na) = ctx.cfg
         gf = empty_cl(b, c, p, na, gy.device, xc.dtype)
-        fused = (os.environ.get("EPN_NORM_BWD_EPILOGUE", "1") == "1" and ctx.needs_input_grad[0]
+        fused = (ab("EPN_NORM_BWD_EPILOGUE") == "1" and ctx.needs_input_grad[0]
                  and xc.numel() * xc.element_size() < 0x7fffff00 and b * p < (1 << 24))
         if fused:
             # the norm's backward reduction from the accumulators of the inverse basis change that produces its output gradient
@@ -1439,7 +1443,7 @@ def group_packed():
     """Grouped features of the split convolution in the packed column order (epn_inter_group_packed_*)?  EPN_GROUP_PACKED =
     1 | 0 (default 1).  The grouping kernel's stores become contiguous (8-20 % less kernel time per layer, measured on MI355X);
     the weights are permuted to match, so the product is the same up to fp32 summation order."""
-    return os.environ.get("EPN_GROUP_PACKED", "1") != "0"
+    return ab("EPN_GROUP_PACKED") != "0"
 
 
 def inter_mode():
@@ -1458,7 +1462,7 @@ def inter_so3conv(feats, W, geo, out_dtype=None, share_input=False):
     if share_input:
         mode = inter_mode()
         plain = (feats.shape[1] % 16 != 0 or isinstance(geo, DenseInterWeights) or not feats.is_cuda or mode not in ("auto", "split")
-                 or feats.dtype not in FEATURE_DTYPES or os.environ.get("EPN_SHARE_INPUT_GRAD", "1") != "1")
+                 or feats.dtype not in FEATURE_DTYPES or ab("EPN_SHARE_INPUT_GRAD") != "1")
         if not plain and feats.dtype == torch.float32:
             g_bytes = (geo.ball_idx.shape[0] * geo.ball_idx.shape[1] * geo.anchors.shape[0] * feats.shape[1] *
                        geo.kernels.shape[0] * 4)
@@ -1712,7 +1716,7 @@ def anchor_softmax_pool(feats, logits):
     """-> (attn [b,c,p,a], pooled [b,c,p,1]): the 3DMatch head's attention pooling over the anchors; CUDA fp32 tensors with at
     most 64 anchors run the fused kernels, anything else the reference's torch composition."""
     if (feats.is_cuda and feats.dtype == torch.float32 and logits.dtype == torch.float32 and feats.dim() == 4
-            and feats.shape == logits.shape and feats.shape[3] <= 64 and os.environ.get("EPN_ATTN_POOL", "1") == "1"):
+            and feats.shape == logits.shape and feats.shape[3] <= 64 and ab("EPN_ATTN_POOL") == "1"):
         return AnchorSoftmaxPoolFn.apply(feats, logits)
     attn = torch.nn.functional.softmax(logits, dim=3)
     return attn, (feats * attn).sum(-1, keepdim=True)
@@ -1887,7 +1891,7 @@ def pointnet_so3conv(feats, xyz, anchors, weight, bias):
     otherwise, and with EPN_POINTNET=fused, the fused fp32 kernels (bf16 features converted once).  EPN_POINTNET=gemm forces
     the composed form wherever the widths allow."""
     c, co = feats.shape[1], weight.shape[0]
-    form = os.environ.get("EPN_POINTNET", "auto")
+    form = ab("EPN_POINTNET")
     rows = feats.shape[0] * feats.shape[2] * feats.shape[3]
     if (feats.is_cuda and c % 16 == 0 and co % 8 == 0 and feats.dtype in FEATURE_DTYPES and form != "fused"
             and (form == "gemm" or rows >= 16384)):

@@ -12,6 +12,8 @@ import math
 from collections import namedtuple
 
 import torch
+
+from ._ab import ab
 import torch.nn as nn
 import torch.nn.functional as F
 
@@ -156,11 +158,11 @@ class FusedSeparableBlock(SeparableBlock):
             skip = x.feats
         # per-channel statistics of the two GEMM outputs that a norm follows (inter convolution, skip convolution) come from
         # the GEMMs' epilogues (block partials; EPN_EPILOGUE_STATS=0: separate passes over the tensors)
-        epi = os.environ.get("EPN_EPILOGUE_STATS", "1") == "1"
+        epi = ab("EPN_EPILOGUE_STATS") == "1"
         y_part = conv.__dict__.pop("_out_stats", None)
         y_part = y_part if epi else None
 
-        pair = os.environ.get("EPN_NORM_PAIR", "1") == "1"     # skip norm folded into the block's final pass
+        pair = ab("EPN_NORM_PAIR") == "1"     # skip norm folded into the block's final pass
 
         def skip_branch():
             sk = skip
@@ -180,7 +182,7 @@ class FusedSeparableBlock(SeparableBlock):
             side.wait_stream(main)
             with torch.cuda.stream(side):
                 s, s_part = skip_branch()
-        if os.environ.get("EPN_NORM_ON_LOAD", "1") == "1" and self.intra_conv.conv.takes_spectral_form(y.feats.is_cuda):
+        if ab("EPN_NORM_ON_LOAD") == "1" and self.intra_conv.conv.takes_spectral_form(y.feats.is_cuda):
             # norm + leaky_relu of the inter convolution applied as the intra convolution's basis change loads its
             # rows: the normalised tensor is never written
             iconv = self.intra_conv.conv

@@ -10,6 +10,12 @@ if ROOT not in sys.path:
 GOLDEN = os.path.join(ROOT, "tests", "golden")
 
 
+# the suite compares the two forms of settled kernel pairs (monkeypatch.setenv("EPN_SHARE_INPUT_GRAD", "0") ...): those A/B
+# switches are read only in A/B mode (epn_pointcloud_amd/_ab.py); subprocesses started by tests (bench.py) inherit it, which
+# changes nothing for them as long as no A/B variable is set
+os.environ.setdefault("EPN_AB", "1")
+
+
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
 

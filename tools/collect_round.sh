@@ -28,7 +28,7 @@ python tools/gemm_bench.py --dtype bf16 > $OUT/gemm_bench_bf16.txt 2>&1
 python tools/hbm_probe.py > $OUT/hbm_probe.txt 2>&1
 python tools/tn_probe.py --dtype bf16 2>&1 | grep -v amdgpu.ids > $OUT/tn_probe.txt; python tools/tn_probe.py --dtype f32 2>&1 | grep -v amdgpu.ids >> $OUT/tn_probe.txt
 (cd tools && python nt_shortk_probe.py 2>&1 | grep -v amdgpu.ids > $OUT/nt_shortk_probe.txt; python nt_shortk_probe.py --bf16 2>&1 | grep -v amdgpu.ids >> $OUT/nt_shortk_probe.txt)
-(cd tools && python c1_probe.py 2>&1 | grep -v "amdgpu.ids\|Warning\|run_backward" > $OUT/c1_probe.txt; EPN_C1_MFMA=0 python c1_probe.py 2>&1 | grep -v "amdgpu.ids\|Warning\|run_backward" >> $OUT/c1_probe.txt)
+(cd tools && python c1_probe.py 2>&1 | grep -v "amdgpu.ids\|Warning\|run_backward" > $OUT/c1_probe.txt; EPN_AB=1 EPN_C1_MFMA=0 python c1_probe.py 2>&1 | grep -v "amdgpu.ids\|Warning\|run_backward" >> $OUT/c1_probe.txt)
 EPN_BENCH_ARGS="--model reg --dtype bf16" bash tools/replay_profile.sh ${TAG}_replay_reg --model reg --dtype bf16 > $OUT/replay_reg.log 2>&1
 cp gpurun_out/${TAG}_replay_reg/per_replay.csv $OUT/per_replay_reg_bf16.csv; rm -rf gpurun_out/${TAG}_replay_reg
 rm -rf gpurun_out/${TAG}_reg gpurun_out/${TAG}_replay $OUT/pmc_*.log $OUT/stats.log

@@ -23,8 +23,9 @@ def main():
     dev = torch.device("cuda:0")
     lib = _lib.get_lib()
     vp, ll, ci = ctypes.c_void_p, ctypes.c_longlong, ctypes.c_int
-    lib.epn_lab_pp_split.argtypes = [vp, ll, ll, ci, vp, ci, ci, vp]
-    lib.epn_lab_gemm_nt_pp.argtypes = [vp, vp, vp, ll, ci, ci, ll, ci, ci, vp]
+    # (argtypes go on the CDLL's functions: the proxy hands out wrappers)
+    lib._cdll.epn_lab_pp_split.argtypes = [vp, ll, ll, ci, vp, ci, ci, vp]
+    lib._cdll.epn_lab_gemm_nt_pp.argtypes = [vp, vp, vp, ll, ci, ci, ll, ci, ci, vp]
     cfgs = [int(c) for c in (sys.argv[1].split(",") if len(sys.argv) > 1 else "0,1,2,3,4,5".split(","))]
     layouts = [int(c) for c in (sys.argv[2].split(",") if len(sys.argv) > 2 else "0,1".split(","))]
     torch.manual_seed(0)
