@@ -322,8 +322,22 @@ def aggregate(records, dtype_name):
     return agg
 
 
+def split_factor(k):
+    """Matrix instructions' worth of flops a kernel EXECUTES per algorithmic flop: 6 for the lossless three-piece bf16 form of
+    an fp32 contraction, 3 for the two-piece fp16 form, 1 otherwise -- from the template arguments the profiler prints
+    (gemm_nt_x3_kernel<WGM,WGN,TM,TN,NSTG[,NPL]>, gemm_tn_x3_kernel<..,BR[,NPL]>, gemm_tn_f32_kernel<..,BR,X3>)."""
+    m = re.search(r"gemm_(nt_x3|tn_x3|tn_f32)_kernel<([^>]*)>", k)
+    if m:
+        a = [v.strip() for v in m.group(2).split(",")]
+        last = a[5] if len(a) > 5 else ("3" if m.group(1) != "tn_f32" else "0")
+        return {"3": 6, "true": 6, "2": 3}.get(last, 1)
+    if "_x3_" in k or (k.startswith("epn::inter_fx") and "<float" in k):
+        return 6
+    return 1
+
+
 def is_split_kernel(k):
-    return "_x3_" in k or k.endswith("true>") or (k.startswith("epn::inter_fx") and "<float" in k)
+    return split_factor(k) > 1
 
 
 def price(k, d, dtype_name, traffic=None):
@@ -334,7 +348,7 @@ def price(k, d, dtype_name, traffic=None):
     # split form: every fp32 multiply-add is six bf16 MFMA multiply-adds (fp32 accumulate, csrc/gemm_x3.hip): the roof is
     # the bf16 matrix pipe and `achieved` the flops it EXECUTES; the fp32-equivalent rate is reported beside it
     peak = PEAK_TFLOPS["bf16"] if split else PEAK_TFLOPS[dtype_name]
-    exec_flops = d["flops"] * (6 if split else 1)
+    exec_flops = d["flops"] * split_factor(k)
     t_mfma, t_hbm = exec_flops / (peak * 1e12), d["bytes"] / (HBM_PEAK_GBS * 1e9)
     common = {"kernel": short_kernel(k), "traffic": traffic, "launches": d["launches"],
               "avg_launch_ms": round(d["ms"] / d["launches"], 4)}
@@ -438,7 +452,8 @@ def measure(cfg, rank, local_rank, world, dev, first=True):
     from epn_pointcloud_amd import dp, models as M, ops, schedule as S
     from epn_pointcloud_amd import gemm as _gemm
     dtype_name = cfg.dtype or ("f32" if cfg.model == "cls" else "bf16")
-    split_gemm = dtype_name == "f32" and _gemm.FP32_MODE == "split"
+    split_gemm = dtype_name == "f32" and _gemm.FP32_MODE != "native"
+    exec_x = {"split": 6, "f16x2": 3}.get(_gemm.FP32_MODE, 1) if dtype_name == "f32" else 1
     fdtype = torch.float32 if dtype_name == "f32" else torch.bfloat16
     batch = cfg.batch or (32 if cfg.model == "cls" else 64)
     points = cfg.points or (2048 if cfg.model == "inv" else 1024)   # 3DMatch patches (generate_eval.py:26,68)
@@ -604,12 +619,13 @@ def measure(cfg, rank, local_rank, world, dev, first=True):
         "vs_baseline": None, "dtype": dtype_name, "data": "synthetic",
         "config": {"workload": WORKLOADS[cfg.model] + (HEADS[cfg.model] if head else ", backbone only)")
                                + f", B={batch}/GPU N={points} K={nn_desc} A=60 "
-                               + (("fp32 (contractions: lossless 3xbf16 split, fp32 accumulate)"
-                                   if split_gemm else "fp32") if dtype_name == "f32" else "bf16 features / fp32 accumulate")
+                               + ({"split": "fp32 (contractions: lossless 3xbf16 split, fp32 accumulate)",
+                                   "f16x2": "fp32 (contractions: 2-piece fp16 split x 3 MFMA products, fp32 accumulate)"}
+                                  .get(_gemm.FP32_MODE, "fp32") if dtype_name == "f32" else "bf16 features / fp32 accumulate")
                                + f", {'fwd' if cfg.forward_only else 'fwd+bwd+Adam'}",
                    "global_batch": batch * world, "launch": launch,
                    "hbm_peak_gb": round(torch.cuda.max_memory_allocated(dev) / 2 ** 30, 1),
-                   "fp32_gemm": ("split" if split_gemm else "native") if dtype_name == "f32" else None,
+                   "fp32_gemm": _gemm.FP32_MODE if dtype_name == "f32" else None,
                    "parallelism": f"dp{world}"},
     }
     if os.environ.get("EPN_INTER_MODE", "auto") != "auto":
@@ -627,8 +643,8 @@ def measure(cfg, rank, local_rank, world, dev, first=True):
             fl, by = algorithmic_work(layers, batch, points, 4 if dtype_name == "f32" else 2, backward=not cfg.forward_only)
             tf = fl / (dt / cfg.steps) / 1e12
             st = {"algorithmic_tflops": round(tf, 1), "frac_fp32_matrix": round(tf / PEAK_TFLOPS["f32"], 3),
-                  ("frac_bf16_pipe_x6" if split_gemm else "frac_bf16_pipe"):
-                      round(tf * (6 if split_gemm else 1) / PEAK_TFLOPS["bf16"], 3),
+                  (f"frac_bf16_pipe_x{exec_x}" if exec_x > 1 else "frac_bf16_pipe"):
+                      round(tf * exec_x / PEAK_TFLOPS["bf16"], 3),
                   "algorithmic_gb": round(by / 1e9, 1)}
             gb = recorded_step_traffic(pmc_file) if pmc_file else None
             if gb:
@@ -691,6 +707,9 @@ def compact_line(out):
         n = out["native_fp32_mfma"]
         line["native_fp32_mfma"] = ({"value": n["value"], "ms_per_step": n["ms_per_step"]} if "value" in n
                                     else {"error": n["error"][:120]})
+    if out.get("fp32_modes"):
+        line["fp32_modes"] = {k: ({"value": v["value"], "ms_per_step": v["ms_per_step"]} if "value" in v else {"error": v["error"][:80]})
+                              for k, v in out["fp32_modes"].items()}
     if "index_kernels" in out:
         line["index_kernels"] = {k + "_us": v["us_per_launch"] for k, v in out["index_kernels"].items()}
     if "configs" in out:
@@ -720,7 +739,7 @@ def fit_line(line):
             c.pop("assumes", None)
     trims = [drop_workloads, drop_other_roofs, lambda l: l.pop("index_kernels", None),
              lambda l: l.get("cpu_baseline", {}).pop("sweep_s", None), drop_config_steps, drop_roofs_of_line,
-             lambda l: l.pop("configs", None), lambda l: l.pop("native_fp32_mfma", None)]
+             lambda l: l.pop("configs", None), lambda l: l.pop("native_fp32_mfma", None), lambda l: l.pop("fp32_modes", None)]
     text = json.dumps(line)
     for t in trims:
         if len(text) < LINE_LIMIT:
@@ -789,43 +808,50 @@ def main():
     if rank == 0:
         from epn_pointcloud_amd import gemm as _gemm
         if world == 1 and H["split_gemm"] and not args.no_native_line:
-            # the same step with the weight contractions / basis change on the fp32 matrix instruction
-            # (v_mfma_f32_32x32x2_f32, EPN_GEMM_FP32=native), measured right here: same box, same process, same inputs
+            # the same step with the weight contractions / basis change in the OTHER fp32 forms (gemm.FP32_MODES: the fp32
+            # matrix instruction v_mfma_f32_32x32x2_f32, the lossless three-piece bf16 form, the two-piece fp16 form), measured
+            # right here: same box, same process, same inputs
             compute, finish, graph = H["compute"], H["finish"], H["graph"]
-            try:
-                _gemm.set_fp32_mode("native")
-                compute()                                   # eager once (allocations), then its own graph
-                if not args.forward_only:
-                    H["opt"].step()
-                torch.cuda.synchronize()
-                g2 = None
-                if graph is not None:
-                    g2 = torch.cuda.CUDAGraph()
-                    with torch.cuda.graph(g2, capture_error_mode="thread_local"):
-                        compute()
+            mode0 = _gemm.FP32_MODE
+            out["fp32_modes"] = {}
+            for mode in [m for m in ("native", "split", "f16x2") if m != mode0]:
+                try:
+                    _gemm.set_fp32_mode(mode)
+                    compute()                                   # eager once (allocations), then its own graph
+                    if not args.forward_only:
+                        H["opt"].step()
+                    torch.cuda.synchronize()
+                    g2 = None
+                    if graph is not None:
+                        g2 = torch.cuda.CUDAGraph()
+                        with torch.cuda.graph(g2, capture_error_mode="thread_local"):
+                            compute()
 
-                def native_step():
-                    if g2 is None:
-                        compute()
-                    else:
-                        g2.replay()
-                    finish()
-                native_step()
-                torch.cuda.synchronize()
-                tn0 = time.perf_counter()
-                for _ in range(args.steps):
-                    native_step()
-                torch.cuda.synchronize()
-                dtn = time.perf_counter() - tn0
-                out["native_fp32_mfma"] = {"value": round(H["batch"] * args.steps / dtn, 3), "unit": "point-clouds/s",
-                                           "ms_per_step": round(dtn / args.steps * 1e3, 3), "steps": args.steps,
-                                           "note": "same step, fp32 contractions on v_mfma_f32_32x32x2_f32 instead of the "
-                                                   "lossless bf16 split (DESIGN.md 3.2b); value / this = speed-up of the split form"}
-                del g2
-            except Exception as e:                          # a report, never a requirement
-                out["native_fp32_mfma"] = {"error": f"{type(e).__name__}: {e}"}
-            finally:
-                _gemm.set_fp32_mode("split")
+                    def other_step():
+                        if g2 is None:
+                            compute()
+                        else:
+                            g2.replay()
+                        finish()
+                    other_step()
+                    torch.cuda.synchronize()
+                    tn0 = time.perf_counter()
+                    for _ in range(args.steps):
+                        other_step()
+                    torch.cuda.synchronize()
+                    dtn = time.perf_counter() - tn0
+                    rec = {"value": round(H["batch"] * args.steps / dtn, 3), "unit": "point-clouds/s",
+                           "ms_per_step": round(dtn / args.steps * 1e3, 3), "steps": args.steps}
+                    del g2
+                except Exception as e:                          # a report, never a requirement
+                    rec = {"error": f"{type(e).__name__}: {e}"}
+                finally:
+                    _gemm.set_fp32_mode(mode0)
+                if mode == "native":
+                    out["native_fp32_mfma"] = dict(rec, note="same step, fp32 contractions on v_mfma_f32_32x32x2_f32 (DESIGN.md "
+                                                             "3.2b); value / this = speed-up of the headline's form")
+                else:
+                    out["fp32_modes"][mode] = rec
         if world == 1:
             out["index_kernels"] = index_kernel_line(H["flat_pts"], H["layers"], dev)
         if world == 1 and not args.no_cpu_baseline and args.model == "cls" and not args.forward_only:

@@ -29,6 +29,7 @@ EXPORTS = [
     "epn_pointnet_so3conv_bwd_weight_f32",
     "epn_gemm_nt_f32", "epn_gemm_nt_bf16", "epn_gemm_nt_split_workspace_bytes", "epn_gemm_nt_split_f32", "epn_gemm_tn_workspace_bytes", "epn_gemm_tn_f32", "epn_gemm_tn_split_f32", "epn_gemm_tn_bf16",
     "epn_transpose_cast", "epn_cast", "epn_gemm_tn_grouped_workspace_bytes", "epn_gemm_tn_grouped",
+    "epn_absmax_f32", "epn_gemm_nt_f16x2_workspace_bytes", "epn_gemm_nt_f16x2_f32", "epn_gemm_tn_f16x2_f32", "epn_gemm_tn_grouped_f16x2",
     "epn_inter_group_bf16", "epn_inter_ungroup_bf16", "epn_intra_group_bf16", "epn_so3_basis_bf16",
     "epn_gather_rows", "epn_scatter_rows", "epn_conv1x1_c1_f32", "epn_conv1x1_c1_bwd_weight_f32",
     "epn_anchor_softmax_pool_fwd_f32", "epn_anchor_softmax_pool_bwd_f32",
@@ -211,6 +212,13 @@ def get_lib():
     lib.epn_gemm_tn_grouped_workspace_bytes.argtypes = [_ci, _ci, tp]
     lib.epn_gemm_tn_grouped_workspace_bytes.restype = _sz
     lib.epn_gemm_tn_grouped.argtypes = [_ci, _ci, tp, _vp, _sz, _vp]
+    pp = ctypes.POINTER(_vp)                 # const float *const * (arrays of device pointers, entries may be NULL)
+    lib.epn_absmax_f32.argtypes = [_vp, _ll, _ll, _ll, _vp, _vp]
+    lib.epn_gemm_nt_f16x2_workspace_bytes.argtypes = [_ci, gp]
+    lib.epn_gemm_nt_f16x2_workspace_bytes.restype = ctypes.c_size_t
+    lib.epn_gemm_nt_f16x2_f32.argtypes = [_ci, gp, pp, _vp, ctypes.c_size_t, _vp]
+    lib.epn_gemm_tn_f16x2_f32.argtypes = [_vp, _ll, _vp, _ll, _vp, _ll, _ll, _ci, _ci, _vp, _vp, _vp, _sz, _vp]
+    lib.epn_gemm_tn_grouped_f16x2.argtypes = [_ci, tp, pp, pp, _vp, _sz, _vp]
     lib.epn_gemm_tn_grouped.restype = _ci
     lib.epn_transpose_cast.argtypes = [_vp, _vp, _ci, _ci, _ci, _ci, _vp]
     lib.epn_cast.argtypes = [_vp, _vp, _sz, _ci, _ci, _vp]

@@ -16,6 +16,7 @@ struct GemmNtProb {        // C[M][N] = A[M][K] . Bt[N][K]^T
     unsigned ntile;        // its tiles; workgroups tile0 + ntile .. next tile0 are padding
     const void *Bp;        // split GEMM (gemm_x3.hip): the three bf16 planes [3][N][K] of Bt, filled by its launcher
     float *stats;          // optional: per-column (sum, sum of squares) of every 32-row block of C, [M/32][N][2] (M % 32 == 0)
+    const float *a_amax, *b_amax;   // two-piece fp16 form (gemm_x3.hip, NPL = 2): device scalars max|A|, max|Bt| -> power-of-two scales
 };
 struct GemmNtBatch {
     int nprob;
@@ -33,6 +34,7 @@ struct GemmTnArgs {        // C[N1][N2] = X[R][N1]^T . Y[R][N2]
     int tiles_n2, nsplit;
     unsigned block0;       // first workgroup of this problem inside a grouped launch
     const void *Xp;        // split form: the three bf16 planes [3][R/8][N1][8] of X (workspace), set by the plan
+    const float *x_amax, *y_amax;   // two-piece fp16 form: device scalars max|X|, max|Y|
 };
 struct GemmTnBatch {       // up to GEMM_MAX_PROB problems in ONE launch (the irreducible blocks of a spectral IntraSO3Conv)
     int nprob;
@@ -41,6 +43,46 @@ struct GemmTnBatch {       // up to GEMM_MAX_PROB problems in ONE launch (the ir
 };
 
 #ifdef __HIPCC__
+// ---- two-piece fp16 split ("f16x2", round 5): x 2^s = h + l with h = rne_f16(x 2^s), l = rne_f16(x 2^s - h) keeps 22-23
+// significant bits of every element within 2^-17 of the tensor's largest magnitude (absolute error <= max|x| 2^-39 below
+// that); a product is hh + hl + lh on v_mfma_f32_32x32x16_f16 -- THREE matrix instructions per 32 x 32 x 16 block where the
+// lossless bf16 form needs six.  The power-of-two scale 2^s puts max|x| into [2^14, 2^15) (fp16 overflows at 65504); it comes
+// from a device scalar holding max|x| (the producer's epilogue or epn_absmax_f32), so nothing is synchronised with the host.
+// Measured against fp64 (tools/pp2_probe.py, profiles/r05_f16x2_probe.txt): rms error 6.1e-7 at K = 3072 where the native fp32
+// MFMA kernel has 9.9e-7 and the lossless 3 x bf16 kernel 8.6e-7 -- the error of an fp32 GEMM is its accumulation, not its inputs.
+typedef _Float16 gemm_f16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 gemm_f16x2 __attribute__((ext_vector_type(2)));
+typedef float gemm_f32x2 __attribute__((ext_vector_type(2)));
+typedef float gemm_f32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned gemm_u32x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ float f2_scale_of(float amax) {          // power of two s with amax * s in [2^14, 2^15)
+    unsigned e = (__builtin_bit_cast(unsigned, amax) >> 23) & 255u;
+    e = e < 14u ? 14u : e;                                          // (zero / tiny tensors: the largest finite scale)
+    return __builtin_bit_cast(float, (268u - e) << 23);
+}
+__device__ __forceinline__ float f2_inverse(float pow2) {            // 1 / s for a power of two
+    return __builtin_bit_cast(float, (254u - (__builtin_bit_cast(unsigned, pow2) >> 23)) << 23);
+}
+__device__ __forceinline__ void f2_split_pair(float x0, float x1, float s, unsigned &h, unsigned &l) {
+    const gemm_f32x2 x = {x0 * s, x1 * s};
+    const gemm_f16x2 hp = __builtin_convertvector(x, gemm_f16x2);
+    const gemm_f32x2 hf = __builtin_convertvector(hp, gemm_f32x2);
+    const gemm_f32x2 r = {x[0] - hf[0], x[1] - hf[1]};
+    h = __builtin_bit_cast(unsigned, hp);
+    l = __builtin_bit_cast(unsigned, __builtin_convertvector(r, gemm_f16x2));
+}
+__device__ __forceinline__ void f2_split8(const float (&x)[8], float s, gemm_f16x8 &h, gemm_f16x8 &l) {
+    gemm_u32x4 H, L;
+#pragma unroll
+    for (int p = 0; p < 4; ++p) {
+        unsigned hp, lp;
+        f2_split_pair(x[2 * p], x[2 * p + 1], s, hp, lp);
+        H[p] = hp; L[p] = lp;
+    }
+    h = __builtin_bit_cast(gemm_f16x8, H);
+    l = __builtin_bit_cast(gemm_f16x8, L);
+}
+
 // Column statistics of an NT tile, taken from the accumulators in the epilogue (the per-channel sums a following
 // BatchNorm / InstanceNorm needs: SURVEY 8f.1 -- no separate pass over C).  acc[i][j]: 32 x 32 MFMA tile i (rows) x j
 // (columns) of the wave, D[row = (r&3) + 8 (r>>2) + 4 lj][col = li]; part[(row / 32)][n][2].  The sums are those of the
@@ -83,12 +125,15 @@ int launch_gemm_nt(GemmNtBatch &B, int dtype, int out_dtype, hipStream_t st);
 // not qualify (K % 32, alignment) or the workspace is missing
 bool gemm_nt_x3_ok(const GemmNtBatch &B);
 size_t gemm_nt_x3_workspace(const GemmNtBatch &B);
-int launch_gemm_nt_x3(GemmNtBatch &B, void *ws, size_t ws_bytes, hipStream_t st);
+int launch_gemm_nt_x3(GemmNtBatch &B, void *ws, size_t ws_bytes, hipStream_t st, int npl = 3);   // npl 2: two-piece fp16 form
+size_t gemm_nt_f2_workspace(const GemmNtBatch &B);
+// max |x| of a strided matrix into a device scalar (memset + one pass)
+int launch_absmax(const float *src, long long ld, long long rows, long long cols, float *out, hipStream_t st);
 int launch_gemm_tn(GemmTnArgs &G, int dtype, hipStream_t st);
 // grouped: plans tiles / splits for all problems (balanced K steps per workgroup), carves `ws` into the partial slabs
 int launch_gemm_tn_batch(GemmTnBatch &B, int dtype, void *ws, size_t ws_bytes, hipStream_t st);
 size_t gemm_tn_batch_workspace(GemmTnBatch &B, int dtype);
-void gemm_tn_tile(int dtype, int N1, int N2, int *bn1, int *bn2);   // dtype: 0 fp32, 1 bf16, 2 fp32 operands, split form
+void gemm_tn_tile(int dtype, int N1, int N2, int *bn1, int *bn2);   // dtype: 0 fp32, 1 bf16, 2 fp32 operands, split form (3 x bf16), 3 = two-piece fp16 form
 int gemm_tn_splits(int dtype, long long R, int N1, int N2);
 int launch_transpose_cast(const void *src, void *dst, int rows, int cols, int src_bf16, int dst_bf16, hipStream_t st);
 int launch_cast(const void *src, void *dst, size_t n, int src_bf16, int dst_bf16, hipStream_t st);

@@ -333,7 +333,7 @@ __device__ __forceinline__ unsigned tn_tile_of(unsigned lb, unsigned ntiles, uns
 #endif
 }
 
-template <int WGM, int WGN, int TM, int TN, int BR, bool X3 = false>
+template <int WGM, int WGN, int TM, int TN, int BR, int X3 = 0>     // X3: 0 = fp32 MFMA, 3 = three bf16 pieces, 2 = two fp16 pieces
 __global__ __launch_bounds__(64 * WGM * WGN) void gemm_tn_f32_kernel(GemmTnBatch B) {
     constexpr int NW = WGM * WGN;
     constexpr int BN1 = WGM * TM * 32, BN2 = WGN * TN * 32;
@@ -398,6 +398,8 @@ __global__ __launch_bounds__(64 * WGM * WGN) void gemm_tn_f32_kernel(GemmTnBatch
     const int li = lane & 31, lj = lane >> 5;
     const int xo = (wm * TM * 32 + TM * li) * 4;                 // byte offset inside a staged row
     const int yo = (BN1 + wn * TN * 32 + TN * li) * 4;
+    float x_scale = 1.0f, y_scale = 1.0f;                        // two-piece form: powers of two from the device maxima
+    if constexpr (X3 == 2) { x_scale = f2_scale_of(*G.x_amax); y_scale = f2_scale_of(*G.y_amax); }
 
     f32x16 acc[TM][TN];
 #pragma unroll
@@ -412,7 +414,7 @@ __global__ __launch_bounds__(64 * WGM * WGN) void gemm_tn_f32_kernel(GemmTnBatch
         __syncthreads();
         const char *base = smem + (kt & 1) * STAGE_B;
         const bool more = kt + 1 < nk;
-        if constexpr (X3) {
+        if constexpr (X3 != 0) {
             if (more) stage((kt + 1) & 1);
 #pragma unroll
             for (int s = 0; s < BR / 16; ++s) {     // 16 rows per fragment step: lane group lj holds rows 8 lj .. 8 lj + 7
@@ -439,6 +441,7 @@ __global__ __launch_bounds__(64 * WGM * WGN) void gemm_tn_f32_kernel(GemmTnBatch
                         yb[0][k] = *reinterpret_cast<const float *>(row + yo);
                     }
                 }
+                if constexpr (X3 == 3) {
                 bf16x8 ah[TM], am[TM], al[TM], bh[TN], bm[TN], bl[TN];
 #pragma unroll
                 for (int i = 0; i < TM; ++i) split3(xa[i], ah[i], am[i], al[i]);
@@ -454,6 +457,20 @@ __global__ __launch_bounds__(64 * WGM * WGN) void gemm_tn_f32_kernel(GemmTnBatch
                 EPN_X3_TERM(am, bh);
                 EPN_X3_TERM(ah, bh);
 #undef EPN_X3_TERM
+                } else {
+                gemm_f16x8 ah[TM], al[TM], bh[TN], bl[TN];
+#pragma unroll
+                for (int i = 0; i < TM; ++i) f2_split8(xa[i], x_scale, ah[i], al[i]);
+#pragma unroll
+                for (int j = 0; j < TN; ++j) f2_split8(yb[j], y_scale, bh[j], bl[j]);
+#define EPN_F2_TERM(PA, PB)                                                                                 \
+    _Pragma("unroll") for (int i = 0; i < TM; ++i) _Pragma("unroll") for (int j = 0; j < TN; ++j)         \
+        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(PA[i], PB[j], acc[i][j], 0, 0, 0)
+                EPN_F2_TERM(ah, bl);
+                EPN_F2_TERM(al, bh);
+                EPN_F2_TERM(ah, bh);
+#undef EPN_F2_TERM
+                }
             }
             continue;
         }
@@ -504,6 +521,15 @@ __global__ __launch_bounds__(64 * WGM * WGN) void gemm_tn_f32_kernel(GemmTnBatch
     }
 
     // ---- epilogue: MFMA row ri of tile tm = output row base1 + TM*ri + tm; column li of tile tn = base2 + TN*li + tn
+    if constexpr (X3 == 2) {
+        const float ux = f2_inverse(x_scale), uy = f2_inverse(y_scale);
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int j = 0; j < TN; ++j)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[i][j][r] = acc[i][j][r] * ux * uy;
+    }
     float *__restrict__ C = G.nsplit > 1 ? static_cast<float *>(G.part) + (size_t)split * G.N1 * G.N2
                                          : static_cast<float *>(G.C);
     const long long ldc = G.nsplit > 1 ? G.N2 : G.ldc;
@@ -561,12 +587,29 @@ __global__ void split_octets_kernel(const float *__restrict__ X, long long ldx, 
     planes[2 * n + i] = __builtin_bit_cast(u32x4, l);
 }
 
-template <int WGM, int WGN, int TM, int TN, int BR>
+// two-piece fp16 form: planes [2][R/8][N1][8], scaled by the power of two of max|X| (device scalar)
+__global__ void split_octets2_kernel(const float *__restrict__ X, long long ldx, long long R, int N1, u32x4 *__restrict__ planes,
+                                     const float *__restrict__ amax) {
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    const long long n = (R >> 3) * N1;
+    if (i >= n) return;
+    const long long o = i / N1;
+    const int c = (int)(i - o * N1);
+    float x[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) x[k] = X[(8 * o + k) * ldx + c];
+    gemm_f16x8 h, l;
+    f2_split8(x, f2_scale_of(*amax), h, l);
+    planes[i] = __builtin_bit_cast(u32x4, h);
+    planes[n + i] = __builtin_bit_cast(u32x4, l);
+}
+
+template <int WGM, int WGN, int TM, int TN, int BR, int NPL = 3>
 __global__ __launch_bounds__(64 * WGM * WGN) void gemm_tn_x3_kernel(GemmTnBatch B) {
     constexpr int NW = WGM * WGN;
     constexpr int BN1 = WGM * TM * 32, BN2 = WGN * TN * 32;
     constexpr int OCT = BR / 8;                     // row octets per stage
-    constexpr int XB = 3 * OCT * BN1 * 16;          // X planes of a stage: [plane][octet][n1] 16-byte chunks
+    constexpr int XB = NPL * OCT * BN1 * 16;        // X planes of a stage: [plane][octet][n1] 16-byte chunks
     constexpr int YB = BR * BN2 * 4;                // Y rows (fp32)
     constexpr int STAGE_B = XB + YB;
     constexpr int NIX = XB / 1024, NI = STAGE_B / 1024;
@@ -629,6 +672,8 @@ __global__ __launch_bounds__(64 * WGM * WGN) void gemm_tn_x3_kernel(GemmTnBatch 
     const int li = lane & 31, lj = lane >> 5;
     const int xo = (wm * TM * 32 + li) * 16;                      // chunk of MFMA tile 0 inside an [octet] row of a plane
     const int yo = XB + (wn * TN * 32 + TN * li) * 4;
+    float y_scale = 1.0f;
+    if constexpr (NPL == 2) y_scale = f2_scale_of(*G.y_amax);
 
     f32x16 acc[TM][TN];
 #pragma unroll
@@ -645,7 +690,6 @@ __global__ __launch_bounds__(64 * WGM * WGN) void gemm_tn_x3_kernel(GemmTnBatch 
         if (kt + 1 < nk) stage((kt + 1) & 1);
 #pragma unroll
         for (int s = 0; s < BR / 16; ++s) {         // 16 rows per fragment step: lane group lj holds octet 2 s + lj
-            bf16x8 ah[TM], am[TM], al[TM], bh[TN], bm[TN], bl[TN];
             float yb[TN][8];
 #pragma unroll
             for (int k = 0; k < 8; ++k) {
@@ -660,6 +704,8 @@ __global__ __launch_bounds__(64 * WGM * WGN) void gemm_tn_x3_kernel(GemmTnBatch 
                     yb[0][k] = *reinterpret_cast<const float *>(row + yo);
                 }
             }
+            if constexpr (NPL == 3) {
+            bf16x8 ah[TM], am[TM], al[TM], bh[TN], bm[TN], bl[TN];
 #pragma unroll
             for (int i = 0; i < TM; ++i) {
                 const char *xp = base + (2 * s + lj) * (BN1 * 16) + xo + i * 512;
@@ -679,9 +725,36 @@ __global__ __launch_bounds__(64 * WGM * WGN) void gemm_tn_x3_kernel(GemmTnBatch 
             EPN_X3_TERM(am, bh);
             EPN_X3_TERM(ah, bh);
 #undef EPN_X3_TERM
+            } else {
+            gemm_f16x8 ah[TM], al[TM], bh[TN], bl[TN];
+#pragma unroll
+            for (int i = 0; i < TM; ++i) {
+                const char *xp = base + (2 * s + lj) * (BN1 * 16) + xo + i * 512;
+                ah[i] = *reinterpret_cast<const gemm_f16x8 *>(xp);
+                al[i] = *reinterpret_cast<const gemm_f16x8 *>(xp + OCT * BN1 * 16);
+            }
+#pragma unroll
+            for (int j = 0; j < TN; ++j) f2_split8(yb[j], y_scale, bh[j], bl[j]);
+#define EPN_F2_TERM(PA, PB)                                                                                 \
+    _Pragma("unroll") for (int i = 0; i < TM; ++i) _Pragma("unroll") for (int j = 0; j < TN; ++j)         \
+        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(PA[i], PB[j], acc[i][j], 0, 0, 0)
+            EPN_F2_TERM(ah, bl);
+            EPN_F2_TERM(al, bh);
+            EPN_F2_TERM(ah, bh);
+#undef EPN_F2_TERM
+            }
         }
     }
 
+    if constexpr (NPL == 2) {
+        const float ux = f2_inverse(f2_scale_of(*G.x_amax)), uy = f2_inverse(y_scale);
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int j = 0; j < TN; ++j)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[i][j][r] = acc[i][j][r] * ux * uy;
+    }
     // ---- epilogue: MFMA row ri of tile i = output row base1 + 32 i + ri; column li of tile j = base2 + TN*li + j
     float *__restrict__ C = G.nsplit > 1 ? static_cast<float *>(G.part) + (size_t)split * G.N1 * G.N2
                                          : static_cast<float *>(G.C);
@@ -1311,7 +1384,8 @@ bool tn_fast_ok(const GemmTnArgs &G) {
 // Plan of a (grouped) TN launch: one block tile for all problems; splits so that every workgroup runs about the same
 // number of K steps and the launch has ~2048 workgroups (single problem) / ~1024 (group); partial slabs carved from `ws`.
 template <typename T>
-size_t tn_plan(GemmTnBatch &B, int *bn1_out, int *bn2_out, void *ws, bool x3 = false) {
+size_t tn_plan(GemmTnBatch &B, int *bn1_out, int *bn2_out, void *ws, int x3 = 0, size_t *amax_off = nullptr) {
+    // x3: 0 = operands as they are, 3 = fp32 operands in three bf16 pieces, 2 = in two fp16 pieces (same tiles and splits)
     const int bf = sizeof(T) == 2 ? 1 : (x3 ? 2 : 0);
     int max1 = 0, min2 = 1 << 30;
     for (int i = 0; i < B.nprob; ++i) {
@@ -1382,13 +1456,17 @@ size_t tn_plan(GemmTnBatch &B, int *bn1_out, int *bn2_out, void *ws, bool x3 = f
             GemmTnArgs &G = B.p[i];
             // (a null workspace = size query: a non-null marker keeps the two passes on the same path)
             G.Xp = ws ? static_cast<char *>(ws) + off : reinterpret_cast<const void *>(1);
-            off += ((size_t)6 * G.R * G.N1 + 255) & ~(size_t)255;
+            off += ((size_t)2 * x3 * G.R * G.N1 + 255) & ~(size_t)255;
         }
+    if (x3 == 2) {                              // two-piece form: [max|X_i|, max|Y_i|] per problem when the caller has none
+        if (amax_off) *amax_off = off;
+        off += 256;
+    }
     return off;
 }
 
 template <typename T>
-int launch_tn_typed(GemmTnBatch &B, void *ws, size_t ws_bytes, hipStream_t st, bool x3 = false) {
+int launch_tn_typed(GemmTnBatch &B, void *ws, size_t ws_bytes, hipStream_t st, int x3 = 0) {
     bool fast = true;
     for (int i = 0; i < B.nprob; ++i) {
         const GemmTnArgs &G = B.p[i];
@@ -1409,22 +1487,48 @@ int launch_tn_typed(GemmTnBatch &B, void *ws, size_t ws_bytes, hipStream_t st, b
         return 0;
     }
     int bn1, bn2;
-    const size_t need = tn_plan<T>(B, &bn1, &bn2, ws, x3);
+    size_t amax_off = 0;
+    const size_t need = tn_plan<T>(B, &bn1, &bn2, ws, x3, &amax_off);
     if (need > 0 && (!ws || ws_bytes < need)) return EPN_EWORKSPACE;
     const dim3 grid(B.nblocks);
     if constexpr (sizeof(T) == 4) {
+        if (x3 == 2) {                                  // maxima nobody supplied: one pass over the operand each
+            float *slots = reinterpret_cast<float *>(static_cast<char *>(ws) + amax_off);
+            for (int i = 0; i < B.nprob; ++i) {
+                GemmTnArgs &G = B.p[i];
+                if (!G.x_amax) {
+                    int rc = launch_absmax(static_cast<const float *>(G.X), G.ldx, G.R, G.N1, slots + 2 * i, st);
+                    if (rc) return rc;
+                    G.x_amax = slots + 2 * i;
+                }
+                if (!G.y_amax) {
+                    int rc = launch_absmax(static_cast<const float *>(G.Y), G.ldy, G.R, G.N2, slots + 2 * i + 1, st);
+                    if (rc) return rc;
+                    G.y_amax = slots + 2 * i + 1;
+                }
+            }
+        }
 #define EPN_TN(...)                                                                                                  \
     do {                                                                                                             \
-        if (x3) EPN_LAUNCH((gemm_tn_f32_kernel<__VA_ARGS__, true>), grid, dim3(64 * tn_waves(__VA_ARGS__)), 0, st, B);  \
-        else EPN_LAUNCH((gemm_tn_f32_kernel<__VA_ARGS__, false>), grid, dim3(64 * tn_waves(__VA_ARGS__)), 0, st, B);    \
+        if (x3 == 3) EPN_LAUNCH((gemm_tn_f32_kernel<__VA_ARGS__, 3>), grid, dim3(64 * tn_waves(__VA_ARGS__)), 0, st, B);  \
+        else if (x3 == 2) EPN_LAUNCH((gemm_tn_f32_kernel<__VA_ARGS__, 2>), grid, dim3(64 * tn_waves(__VA_ARGS__)), 0, st, B);  \
+        else EPN_LAUNCH((gemm_tn_f32_kernel<__VA_ARGS__, 0>), grid, dim3(64 * tn_waves(__VA_ARGS__)), 0, st, B);    \
     } while (0)
-#define EPN_TX(...) EPN_LAUNCH((gemm_tn_x3_kernel<__VA_ARGS__>), grid, dim3(64 * tn_waves(__VA_ARGS__)), 0, st, B)
+#define EPN_TX(...)                                                                                                  \
+    do {                                                                                                             \
+        if (x3 == 3) EPN_LAUNCH((gemm_tn_x3_kernel<__VA_ARGS__, 3>), grid, dim3(64 * tn_waves(__VA_ARGS__)), 0, st, B);   \
+        else EPN_LAUNCH((gemm_tn_x3_kernel<__VA_ARGS__, 2>), grid, dim3(64 * tn_waves(__VA_ARGS__)), 0, st, B);          \
+    } while (0)
         if (x3 && B.p[0].Xp) {
-            for (int i = 0; i < B.nprob; ++i) {         // X's bf16 planes (workspace, after the slabs)
+            for (int i = 0; i < B.nprob; ++i) {         // X's planes (workspace, after the slabs)
                 const GemmTnArgs &G = B.p[i];
                 const long long n = (G.R >> 3) * G.N1;
-                EPN_LAUNCH_AUX(split_octets_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st,
+                if (x3 == 3)
+                    EPN_LAUNCH_AUX(split_octets_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st,
                                    static_cast<const float *>(G.X), G.ldx, G.R, G.N1, static_cast<u32x4 *>(const_cast<void *>(G.Xp)));
+                else
+                    EPN_LAUNCH_AUX(split_octets2_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st,
+                                   static_cast<const float *>(G.X), G.ldx, G.R, G.N1, static_cast<u32x4 *>(const_cast<void *>(G.Xp)), G.x_amax);
                 EPN_CHECK_LAUNCH();
             }
             if (bn1 == 32) EPN_TX(1, 8, 1, 2, 32);           // (bn1, bn2) is one of tn_plan's x3_tile pairs
@@ -1576,7 +1680,8 @@ int launch_gemm_nt(GemmNtBatch &B, int dtype, int out_dtype, hipStream_t st) {
 
 int launch_gemm_tn_batch(GemmTnBatch &B, int dtype, void *ws, size_t ws_bytes, hipStream_t st) {
     if (B.nprob < 1 || B.nprob > GEMM_MAX_PROB) return EPN_EINVAL;
-    if (dtype == 2) return launch_tn_typed<float>(B, ws, ws_bytes, st, true);    // fp32 operands, split form
+    if (dtype == 2) return launch_tn_typed<float>(B, ws, ws_bytes, st, 3);    // fp32 operands, three bf16 pieces
+    if (dtype == 3) return launch_tn_typed<float>(B, ws, ws_bytes, st, 2);    // fp32 operands, two fp16 pieces
     return dtype == 0 ? launch_tn_typed<float>(B, ws, ws_bytes, st) : launch_tn_typed<__bf16>(B, ws, ws_bytes, st);
 }
 
@@ -1584,7 +1689,8 @@ size_t gemm_tn_batch_workspace(GemmTnBatch &B, int dtype) {
     int bn1, bn2;
     for (int i = 0; i < B.nprob; ++i)
         if (B.p[i].R < 32 || B.p[i].N1 < 1 || B.p[i].N2 < 1) return 0;
-    return dtype != 1 ? tn_plan<float>(B, &bn1, &bn2, nullptr, dtype == 2) : tn_plan<__bf16>(B, &bn1, &bn2, nullptr);
+    return dtype != 1 ? tn_plan<float>(B, &bn1, &bn2, nullptr, dtype == 2 ? 3 : (dtype == 3 ? 2 : 0))
+                      : tn_plan<__bf16>(B, &bn1, &bn2, nullptr);
 }
 
 int launch_gemm_tn(GemmTnArgs &G, int dtype, hipStream_t st) {
@@ -1653,7 +1759,7 @@ static int nt_entry(int nprob, const epn_gemm_nt_problem *probs, int dtype, int 
             const epn_gemm_nt_problem &q = probs[i0 + i];
             GemmNtProb &p = B.p[i];
             p.A = q.A; p.Bt = q.Bt; p.C = q.C; p.M = q.M; p.N = q.N; p.K = q.K; p.lda = q.lda; p.ldb = q.ldb; p.ldc = q.ldc;
-            p.tiles_n = 0; p.tile0 = 0; p.stats = q.col_stats;
+            p.tiles_n = 0; p.tile0 = 0; p.stats = q.col_stats; p.a_amax = p.b_amax = nullptr;
         }
         int rc = launch_gemm_nt(B, dtype, out_dtype, st);
         if (rc) return rc;
@@ -1670,16 +1776,17 @@ extern "C" int epn_gemm_nt_bf16(int nprob, const epn_gemm_nt_problem *probs, int
 
 extern "C" size_t epn_gemm_tn_workspace_bytes(int bf16, long long R, int N1, int N2) {
     if (R < 1 || N1 < 1 || N2 < 1) return 0;
-    const int s = gemm_tn_splits(bf16, R, N1, N2);
-    const size_t planes = bf16 == 2 && N2 >= 512 ? (((size_t)6 * R * N1 + 255) & ~(size_t)255) : 0;   // X's bf16 planes
-    return (s > 1 ? (((size_t)s * N1 * N2 * sizeof(float) + 255) & ~(size_t)255) : 0) + planes;
+    const int mode = bf16 == 3 ? 2 : bf16;            // 3 = two-piece fp16 form: the tiles and splits of the three-piece form
+    const int s = gemm_tn_splits(mode, R, N1, N2);
+    const size_t planes = mode == 2 && N2 >= 512 ? (((size_t)(bf16 == 3 ? 4 : 6) * R * N1 + 255) & ~(size_t)255) : 0;   // X's planes
+    return (s > 1 ? (((size_t)s * N1 * N2 * sizeof(float) + 255) & ~(size_t)255) : 0) + planes + (bf16 == 3 ? 256 : 0);
 }
 
 static int tn_entry(const void *X, long long ldx, const void *Y, long long ldy, float *C, long long ldc, long long R, int N1,
                     int N2, void *ws, size_t ws_bytes, int dtype, epn_stream_t stream) {
     GemmTnArgs G;
     G.X = X; G.Y = Y; G.C = C; G.part = ws; G.part_bytes = ws_bytes; G.R = R; G.N1 = N1; G.N2 = N2;
-    G.ldx = ldx; G.ldy = ldy; G.ldc = ldc; G.ntiles = 0; G.tiles_n2 = 0; G.nsplit = 1; G.block0 = 0; G.Xp = nullptr;
+    G.ldx = ldx; G.ldy = ldy; G.ldc = ldc; G.ntiles = 0; G.tiles_n2 = 0; G.nsplit = 1; G.block0 = 0; G.Xp = nullptr; G.x_amax = G.y_amax = nullptr;
     return launch_gemm_tn(G, dtype, epn_stream(stream));
 }
 extern "C" int epn_gemm_tn_f32(const float *X, long long ldx, const float *Y, long long ldy, float *C, long long ldc,
@@ -1694,6 +1801,15 @@ extern "C" int epn_gemm_tn_bf16(const void *X, long long ldx, const void *Y, lon
                                 long long R, int N1, int N2, void *workspace, size_t workspace_bytes, epn_stream_t stream) {
     return tn_entry(X, ldx, Y, ldy, C, ldc, R, N1, N2, workspace, workspace_bytes, 1, stream);
 }
+extern "C" int epn_gemm_tn_f16x2_f32(const float *X, long long ldx, const float *Y, long long ldy, float *C, long long ldc,
+                                     long long R, int N1, int N2, const float *x_amax, const float *y_amax, void *workspace,
+                                     size_t workspace_bytes, epn_stream_t stream) {
+    GemmTnArgs G;
+    G.X = X; G.Y = Y; G.C = C; G.part = workspace; G.part_bytes = workspace_bytes; G.R = R; G.N1 = N1; G.N2 = N2;
+    G.ldx = ldx; G.ldy = ldy; G.ldc = ldc; G.ntiles = 0; G.tiles_n2 = 0; G.nsplit = 1; G.block0 = 0; G.Xp = nullptr;
+    G.x_amax = x_amax; G.y_amax = y_amax;
+    return launch_gemm_tn(G, 3, epn_stream(stream));
+}
 
 static void tn_fill(GemmTnBatch &B, int nprob, const epn_gemm_tn_problem *probs) {
     B.nprob = nprob; B.nblocks = 0;
@@ -1701,7 +1817,7 @@ static void tn_fill(GemmTnBatch &B, int nprob, const epn_gemm_tn_problem *probs)
         GemmTnArgs &G = B.p[i];
         const epn_gemm_tn_problem &q = probs[i];
         G.X = q.X; G.Y = q.Y; G.C = q.C; G.part = nullptr; G.part_bytes = 0; G.R = q.R; G.N1 = q.N1; G.N2 = q.N2;
-        G.ldx = q.ldx; G.ldy = q.ldy; G.ldc = q.ldc; G.ntiles = 0; G.tiles_n2 = 0; G.nsplit = 1; G.block0 = 0; G.Xp = nullptr;
+        G.ldx = q.ldx; G.ldy = q.ldy; G.ldc = q.ldc; G.ntiles = 0; G.tiles_n2 = 0; G.nsplit = 1; G.block0 = 0; G.Xp = nullptr; G.x_amax = G.y_amax = nullptr;
     }
 }
 extern "C" size_t epn_gemm_tn_grouped_workspace_bytes(int bf16, int nprob, const epn_gemm_tn_problem *probs) {
@@ -1717,6 +1833,18 @@ extern "C" int epn_gemm_tn_grouped(int bf16, int nprob, const epn_gemm_tn_proble
     GemmTnBatch B;
     tn_fill(B, nprob, probs);
     return launch_gemm_tn_batch(B, bf16 == 2 ? 2 : (bf16 ? 1 : 0), workspace, workspace_bytes, epn_stream(stream));
+}
+extern "C" int epn_gemm_tn_grouped_f16x2(int nprob, const epn_gemm_tn_problem *probs, const float *const *x_amax,
+                                         const float *const *y_amax, void *workspace, size_t workspace_bytes, epn_stream_t stream) {
+    if (!probs) return EPN_ENULL;
+    if (nprob < 1 || nprob > GEMM_MAX_PROB) return EPN_EINVAL;
+    GemmTnBatch B;
+    tn_fill(B, nprob, probs);
+    for (int i = 0; i < nprob; ++i) {
+        B.p[i].x_amax = x_amax ? x_amax[i] : nullptr;
+        B.p[i].y_amax = y_amax ? y_amax[i] : nullptr;
+    }
+    return launch_gemm_tn_batch(B, 3, workspace, workspace_bytes, epn_stream(stream));
 }
 
 extern "C" int epn_transpose_cast(const void *src, void *dst, int rows, int cols, int src_bf16, int dst_bf16,

@@ -98,14 +98,94 @@ __global__ void split_planes_batch_kernel(SplitBatch S) {
     }
 }
 
-template <int WGM, int WGN, int TM, int TN, int NSTG>
+// two-piece fp16 form (gemm.h): the weights of every problem -> planes[2][N][K] (fp16), scaled by the power of two that
+// puts max|W| (device scalar) at 2^14
+struct Split2Batch {
+    const float *W[GEMM_MAX_PROB];
+    unsigned *planes[GEMM_MAX_PROB];
+    const float *amax[GEMM_MAX_PROB];
+    long long ldw[GEMM_MAX_PROB];
+    int N[GEMM_MAX_PROB], K[GEMM_MAX_PROB];
+};
+__global__ void split_planes2_batch_kernel(Split2Batch S) {
+    const int q = blockIdx.y;
+    const float *__restrict__ W = S.W[q];
+    unsigned *__restrict__ planes = S.planes[q];
+    const int N = S.N[q], k2 = S.K[q] >> 1;
+    const size_t plane = (size_t)N * k2;
+    const float sc = f2_scale_of(*S.amax[q]);
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < (long long)N * k2; i += (long long)gridDim.x * blockDim.x) {
+        const int n = (int)(i / k2), k = 2 * (int)(i % k2);
+        unsigned h, l;
+        f2_split_pair(W[n * S.ldw[q] + k], W[n * S.ldw[q] + k + 1], sc, h, l);
+        planes[i] = h;
+        planes[plane + i] = l;
+    }
+}
+
+// max |x| over a strided matrix -> *out (as the bit pattern of a non-negative float: unsigned order = float order).  Non-finite
+// values are left out of the maximum: a NaN / inf element then poisons only the rows it belongs to (x 2^s stays NaN / inf in
+// the split), as it would in an fp32 GEMM, instead of the scale of the whole tensor.  *out must be zero before the launch
+// (launch_absmax).  A streaming read: four independent 16-byte loads per thread and iteration.
+__device__ __forceinline__ unsigned absmax4(unsigned m, const u32x4 v) {
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const unsigned a = v[k] & 0x7fffffffu;
+        m = (a > m && a < 0x7f800000u) ? a : m;
+    }
+    return m;
+}
+__device__ __forceinline__ void absmax_finish(unsigned m, unsigned *out) {
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) {
+        const unsigned v = (unsigned)__shfl_xor((int)m, o, 64);
+        m = v > m ? v : m;
+    }
+    if ((threadIdx.x & 63) == 0 && m) atomicMax(out, m);
+}
+__global__ __launch_bounds__(256) void absmax_flat_kernel(const u32x4 *__restrict__ src, long long n4, unsigned *__restrict__ out) {
+    unsigned m = 0;
+    const long long stride = (long long)gridDim.x * 256;
+    long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+    for (; i + 3 * stride < n4; i += 4 * stride) {
+        const u32x4 v0 = __builtin_nontemporal_load(src + i), v1 = __builtin_nontemporal_load(src + i + stride);
+        const u32x4 v2 = __builtin_nontemporal_load(src + i + 2 * stride), v3 = __builtin_nontemporal_load(src + i + 3 * stride);
+        m = absmax4(absmax4(absmax4(absmax4(m, v0), v1), v2), v3);
+    }
+    for (; i < n4; i += stride) m = absmax4(m, src[i]);
+    absmax_finish(m, out);
+}
+__global__ __launch_bounds__(256) void absmax_kernel(const float *__restrict__ src, long long ld, long long rows, long long cols4,
+                                                     unsigned *__restrict__ out) {
+    unsigned m = 0;
+    const long long n = rows * cols4;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
+        const long long r = i / cols4, c = i - r * cols4;
+        m = absmax4(m, *reinterpret_cast<const u32x4 *>(src + r * ld + 4 * c));
+    }
+    absmax_finish(m, out);
+}
+__global__ void absmax_tail_kernel(const float *__restrict__ src, long long ld, long long rows, long long cols, long long c0,
+                                   unsigned *__restrict__ out) {       // columns c0 .. cols of every row (cols % 4 != 0, or unaligned)
+    const long long w = cols - c0, n = rows * w;
+    unsigned m = 0;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
+        const long long r = i / w, c = c0 + (i - r * w);
+        const unsigned a = __builtin_bit_cast(unsigned, src[r * ld + c]) & 0x7fffffffu;
+        m = (a > m && a < 0x7f800000u) ? a : m;
+    }
+    if (m) atomicMax(out, m);
+}
+
+template <int WGM, int WGN, int TM, int TN, int NSTG, int NPL = 3>
 __global__ __launch_bounds__(64 * WGM * WGN) void gemm_nt_x3_kernel(GemmNtBatch B) {
     constexpr int NW = WGM * WGN;
     constexpr int BM = WGM * TM * 32, BN = WGN * TN * 32;
     constexpr int A_BYTES = BM * 128;              // fp32 rows of the activation tile, 32 values per K step
     constexpr int P_BYTES = BN * 64;               // one bf16 plane of the weight tile
-    constexpr int STAGE = A_BYTES + 3 * P_BYTES;
-    constexpr int NGA = BM / 8, NGB = 3 * BN / 16;  // 1 KiB wave-level load instructions per stage (8 / 16 rows each)
+    constexpr int STAGE = A_BYTES + NPL * P_BYTES;  // NPL = 3: bf16 planes (lossless form); 2: fp16 planes (two-piece form)
+    constexpr int NGA = BM / 8, NGB = NPL * BN / 16;  // 1 KiB wave-level load instructions per stage (8 / 16 rows each)
+    constexpr int NTERM = NPL == 3 ? 6 : 3;         // matrix instructions per (A tile, B tile) and 16 contraction values
     constexpr int NG = NGA + NGB;
     constexpr int GPW = (NG + NW - 1) / NW;
     constexpr int INFLIGHT = NG % NW == 0 ? GPW : GPW - 1;   // loads of the youngest stage a wave may leave pending
@@ -164,12 +244,14 @@ __global__ __launch_bounds__(64 * WGM * WGN) void gemm_nt_x3_kernel(GemmNtBatch 
     // two-stage ring: the next stage's loads are spread over the twelve MFMA groups of the K step (a direct-to-LDS load
     // costs its wave ~100 cycles of issue; as one burst after the barrier both waves of a SIMD stall together)
     // (the 256 x 256 tile: +3 %; the smaller tiles measured 1-2 % slower spread than as a burst)
-    constexpr bool SPREAD = NSTG == 2 && GPW <= 12 && TM * TN >= 8;
+    constexpr bool SPREAD = NSTG == 2 && GPW <= 2 * NTERM && TM * TN >= 8;
     const int wpar = NW >= 8 ? __builtin_amdgcn_readfirstlane((wave >> 2) & 1) : 0;
 
     const int wm = wave / WGN, wn = wave % WGN;
     const int li = lane & 31, lj = lane >> 5;
     const int fswA = (li >> 1) & 7, fswB = (li >> 2) & 3;
+    float a_scale = 1.0f;                           // two-piece form: 2^s of the activations (device scalar max|A|)
+    if constexpr (NPL == 2) a_scale = f2_scale_of(*P.a_amax);
     int aoff[TM], boff[TN];
 #pragma unroll
     for (int i = 0; i < TM; ++i) aoff[i] = ((wm * TM + i) * 32 + li) * 128;
@@ -205,6 +287,21 @@ __global__ __launch_bounds__(64 * WGM * WGN) void gemm_nt_x3_kernel(GemmNtBatch 
         for (int s = 0; s < 2; ++s) {           // 16 contraction values per fragment step: lane group lj holds 8 of them
             const int sa0 = ((4 * s + 2 * lj) ^ fswA) * 16, sa1 = ((4 * s + 2 * lj + 1) ^ fswA) * 16;
             const int sb = ((2 * s + lj) ^ fswB) * 16;
+#define EPN_X3_LOAD(T_)                                                                                    \
+    if constexpr (SPREAD) {                                                                                 \
+        __builtin_amdgcn_sched_barrier(0);                                                                  \
+        if (more) {                                                                                         \
+            _Pragma("unroll") for (int i = 0; i < GPW; ++i) {                                               \
+                constexpr int LAST = 2 * NTERM - 1;                                                         \
+                const int g0 = (i * LAST) / (GPW > 1 ? GPW - 1 : 1);    /* slot of load i, 0 .. LAST */      \
+                const int g1 = g0 < LAST ? g0 + 1 : LAST;               /* partner wave: one slot later */   \
+                if ((g0 == NTERM * s + (T_) && wpar == 0) || (g1 == NTERM * s + (T_) && wpar != 0))         \
+                    stage_one((kt + 1) & 1, i);                                                             \
+            }                                                                                               \
+        }                                                                                                   \
+        __builtin_amdgcn_sched_barrier(0);                                                                  \
+    }
+            if constexpr (NPL == 3) {
             bf16x8 ah[TM], am[TM], al[TM], bh[TN], bm[TN], bl[TN];
 #pragma unroll
             for (int j = 0; j < TN; ++j) {
@@ -219,32 +316,50 @@ __global__ __launch_bounds__(64 * WGM * WGN) void gemm_nt_x3_kernel(GemmNtBatch 
 #define EPN_X3_TERM(PA, PB)                                                                                 \
     _Pragma("unroll") for (int i = 0; i < TM; ++i) _Pragma("unroll") for (int j = 0; j < TN; ++j)         \
         acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(PA[i], PB[j], acc[i][j], 0, 0, 0)
-#define EPN_X3_LOAD(T_)                                                                                    \
-    if constexpr (SPREAD) {                                                                                 \
-        __builtin_amdgcn_sched_barrier(0);                                                                  \
-        if (more) {                                                                                         \
-            _Pragma("unroll") for (int i = 0; i < GPW; ++i) {                                               \
-                const int g0 = (i * 11) / (GPW > 1 ? GPW - 1 : 1);      /* slot of load i, 0 .. 11 */        \
-                const int g1 = g0 < 11 ? g0 + 1 : 11;                   /* partner wave: one slot later */   \
-                if ((g0 == 6 * s + (T_) && wpar == 0) || (g1 == 6 * s + (T_) && wpar != 0))                 \
-                    stage_one((kt + 1) & 1, i);                                                             \
-            }                                                                                               \
-        }                                                                                                   \
-        __builtin_amdgcn_sched_barrier(0);                                                                  \
-    }
             EPN_X3_LOAD(0) EPN_X3_TERM(ah, bl);                // small terms first
             EPN_X3_LOAD(1) EPN_X3_TERM(al, bh);
             EPN_X3_LOAD(2) EPN_X3_TERM(am, bm);
             EPN_X3_LOAD(3) EPN_X3_TERM(ah, bm);
             EPN_X3_LOAD(4) EPN_X3_TERM(am, bh);
             EPN_X3_LOAD(5) EPN_X3_TERM(ah, bh);
-#undef EPN_X3_LOAD
 #undef EPN_X3_TERM
+            } else {
+            gemm_f16x8 ah[TM], al[TM], bh[TN], bl[TN];
+#pragma unroll
+            for (int j = 0; j < TN; ++j) {
+                bh[j] = *reinterpret_cast<const gemm_f16x8 *>(base + boff[j] + sb);
+                bl[j] = *reinterpret_cast<const gemm_f16x8 *>(base + boff[j] + P_BYTES + sb);
+            }
+#pragma unroll
+            for (int i = 0; i < TM; ++i) {
+                const f32x4 u = *reinterpret_cast<const f32x4 *>(base + aoff[i] + sa0);
+                const f32x4 v = *reinterpret_cast<const f32x4 *>(base + aoff[i] + sa1);
+                const float x[8] = {u[0], u[1], u[2], u[3], v[0], v[1], v[2], v[3]};
+                f2_split8(x, a_scale, ah[i], al[i]);
+            }
+#define EPN_F2_TERM(PA, PB)                                                                                 \
+    _Pragma("unroll") for (int i = 0; i < TM; ++i) _Pragma("unroll") for (int j = 0; j < TN; ++j)         \
+        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(PA[i], PB[j], acc[i][j], 0, 0, 0)
+            EPN_X3_LOAD(0) EPN_F2_TERM(ah, bl);                // small terms first
+            EPN_X3_LOAD(1) EPN_F2_TERM(al, bh);
+            EPN_X3_LOAD(2) EPN_F2_TERM(ah, bh);
+#undef EPN_F2_TERM
+            }
+#undef EPN_X3_LOAD
         }
     }
 
     // ---- epilogue: D[row = (r&3) + 8 (r>>2) + 4 lj][col = li]   (as gemm_nt_kernel)
     float *__restrict__ C = static_cast<float *>(P.C);
+    if constexpr (NPL == 2) {                       // undo the operand scales: two exact power-of-two multiplies
+        const float ua = f2_inverse(a_scale), ub = f2_inverse(f2_scale_of(*P.b_amax));
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int j = 0; j < TN; ++j)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[i][j][r] = acc[i][j][r] * ua * ub;
+    }
     if (P.stats) nt_col_stats<TM, TN, float>(acc, P.stats, P.M, P.N, m0 + wm * TM * 32, n0 + wn * TN * 32, li, lj);
     if (m0 + BM <= P.M && n0 + BN <= P.N && (long long)BM * P.ldc < (1LL << 30)) {
         float *__restrict__ cw = C + (size_t)(m0 + wm * TM * 32) * P.ldc + (n0 + wn * TN * 32);
@@ -279,7 +394,7 @@ __global__ __launch_bounds__(64 * WGM * WGN) void gemm_nt_x3_kernel(GemmNtBatch 
         }
 }
 
-template <int WGM, int WGN, int TM, int TN, int NSTG>
+template <int WGM, int WGN, int TM, int TN, int NSTG, int NPL = 3>
 int launch_x3_cfg(GemmNtBatch &B, hipStream_t st) {
     constexpr int BM = WGM * TM * 32, BN = WGN * TN * 32;
     for (int i = 1; i < B.nprob; ++i)           // longest contraction first (see launch_nt_cfg)
@@ -296,7 +411,7 @@ int launch_x3_cfg(GemmNtBatch &B, hipStream_t st) {
     }
     B.ntiles = total;
     if (total == 0) return 0;
-    EPN_LAUNCH((gemm_nt_x3_kernel<WGM, WGN, TM, TN, NSTG>), dim3(total), dim3(64 * WGM * WGN), 0, st, B);
+    EPN_LAUNCH((gemm_nt_x3_kernel<WGM, WGN, TM, TN, NSTG, NPL>), dim3(total), dim3(64 * WGM * WGN), 0, st, B);
     EPN_CHECK_LAUNCH();
     return 0;
 }
@@ -320,57 +435,129 @@ size_t gemm_nt_x3_workspace(const GemmNtBatch &B) {
     return n;
 }
 
-int launch_gemm_nt_x3(GemmNtBatch &B, void *ws, size_t ws_bytes, hipStream_t st) {
-    if (!gemm_nt_x3_ok(B) || !ws || ((uintptr_t)ws & 15) || ws_bytes < gemm_nt_x3_workspace(B))
+size_t gemm_nt_f2_workspace(const GemmNtBatch &B) {     // two-piece form: [a_amax, b_amax] per problem, then fp16 planes
+    size_t n = 256;
+    for (int i = 0; i < B.nprob; ++i) n += (((size_t)4 * B.p[i].N * B.p[i].K + 255) & ~(size_t)255);
+    return n;
+}
+
+int launch_absmax(const float *src, long long ld, long long rows, long long cols, float *out, hipStream_t st) {
+    if (!out) return EPN_ENULL;
+    EPN_HIP(hipMemsetAsync(out, 0, sizeof(float), st));
+    if (rows < 1 || cols < 1) return 0;
+    if (!src) return EPN_ENULL;
+    const bool vec = !((uintptr_t)src & 15) && ld % 4 == 0;
+    if (vec && (ld == cols || rows == 1) && (rows * cols) % 4 == 0) {       // contiguous: one flat stream
+        const long long n4 = rows * cols / 4;
+        const long long want = (n4 + 4 * 256 - 1) / (4 * 256);
+        const unsigned g = (unsigned)(want < 1 ? 1 : (want < 2048 ? want : 2048));
+        EPN_LAUNCH_AUX(absmax_flat_kernel, dim3(g), dim3(256), 0, st, reinterpret_cast<const u32x4 *>(src), n4,
+                       reinterpret_cast<unsigned *>(out));
+        EPN_CHECK_LAUNCH();
+        return 0;
+    }
+    const long long c4 = vec ? cols / 4 : 0;
+    if (c4 > 0) {
+        const long long n = rows * c4;
+        const unsigned g = (unsigned)((n + 255) / 256 < 4096 ? (n + 255) / 256 : 4096);
+        EPN_LAUNCH_AUX(absmax_kernel, dim3(g), dim3(256), 0, st, src, ld, rows, c4, reinterpret_cast<unsigned *>(out));
+        EPN_CHECK_LAUNCH();
+    }
+    if (4 * c4 < cols) {
+        const long long n = rows * (cols - 4 * c4);
+        const unsigned g = (unsigned)((n + 255) / 256 < 2048 ? (n + 255) / 256 : 2048);
+        EPN_LAUNCH_AUX(absmax_tail_kernel, dim3(g), dim3(256), 0, st, src, ld, rows, cols, 4 * c4, reinterpret_cast<unsigned *>(out));
+        EPN_CHECK_LAUNCH();
+    }
+    return 0;
+}
+
+template <int NPL>
+static int x3_dispatch(GemmNtBatch &B, int maxn, int minn, hipStream_t st) {
+    const int pol = kernel_policy();
+    if ((pol & ~0xff) == 0x100) {               // tuning override (tools/x3_probe.py)
+        switch (pol & 0xff) {
+            case 0x21: return launch_x3_cfg<4, 2, 2, 2, 2, NPL>(B, st);     // 256 x 128, 8 waves
+            case 0x22: return launch_x3_cfg<4, 2, 2, 4, 2, NPL>(B, st);     // 256 x 256, 8 waves (all of the LDS in the bf16 form)
+            case 0x23: return launch_x3_cfg<2, 2, 2, 2, 2, NPL>(B, st);     // 128 x 128, 4 waves
+            case 0x24: return launch_x3_cfg<2, 2, 2, 2, 3, NPL>(B, st);
+            case 0x25: return launch_x3_cfg<4, 1, 2, 2, 3, NPL>(B, st);     // 256 x 64, 4 waves
+            case 0x26: return launch_x3_cfg<4, 1, 2, 2, 2, NPL>(B, st);
+            case 0x27: return launch_x3_cfg<2, 2, 4, 2, 2, NPL>(B, st);     // 256 x 128, 4 waves (128 x 64 per wave)
+            case 0x28: return launch_x3_cfg<2, 4, 2, 2, 2, NPL>(B, st);     // 128 x 256, 8 waves
+            case 0x29: return launch_x3_cfg<2, 2, 2, 4, 2, NPL>(B, st);     // 128 x 256, 4 waves
+            case 0x2a: return launch_x3_cfg<8, 1, 2, 1, 2, NPL>(B, st);     // 512 x 32
+            case 0x2b: if constexpr (NPL == 2) return launch_x3_cfg<4, 2, 2, 2, 3, NPL>(B, st); else break;   // 256 x 128, three stages (144 KB)
+            default: break;
+        }
+    }
+    if (B.nprob > 1) {                          // grouped spectral blocks: ragged widths, narrow tiles (see launch_nt_typed)
+        if (maxn <= 320 && minn <= 64) return launch_x3_cfg<4, 1, 2, 2, 3, NPL>(B, st);
+        if (minn >= 256) return launch_x3_cfg<4, 2, 2, 4, 2, NPL>(B, st);   // c = 256 blocks: 0.76 -> 0.68 ms (A is re-read per tile column)
+        return launch_x3_cfg<2, 2, 2, 2, 2, NPL>(B, st);
+    }
+    if (maxn <= 32) return launch_x3_cfg<8, 1, 2, 1, 2, NPL>(B, st);
+    if (maxn <= 64) return launch_x3_cfg<4, 1, 2, 2, 3, NPL>(B, st);
+    if (maxn <= 128 || maxn % 256 > 128 || (maxn % 256 && maxn < 512)) return launch_x3_cfg<4, 2, 2, 2, 2, NPL>(B, st);
+    return launch_x3_cfg<4, 2, 2, 4, 2, NPL>(B, st);
+}
+
+// npl = 3: lossless three-piece bf16 form (planes of the weights in `ws`); npl = 2: two-piece fp16 form -- `ws` starts with
+// the amax slots ([2 i] = max|A_i| when the caller gave none in p.a_amax, [2 i + 1] = max|Bt_i|), then the fp16 planes
+int launch_gemm_nt_x3(GemmNtBatch &B, void *ws, size_t ws_bytes, hipStream_t st, int npl) {
+    const size_t need = npl == 2 ? gemm_nt_f2_workspace(B) : gemm_nt_x3_workspace(B);
+    if (!gemm_nt_x3_ok(B) || !ws || ((uintptr_t)ws & 15) || ws_bytes < need)
         return launch_gemm_nt(B, 0, 0, st);      // the planes are read with 16-byte direct-to-LDS loads
     char *w = static_cast<char *>(ws);
     int maxn = 0, minn = 1 << 30;
-    SplitBatch S;
     long long maxpairs = 0;
     for (int i = 0; i < B.nprob; ++i) {
-        GemmNtProb &p = B.p[i];
+        const GemmNtProb &p = B.p[i];
         const long long pairs = (long long)p.N * (p.K / 2);
-        S.W[i] = static_cast<const float *>(p.Bt); S.planes[i] = reinterpret_cast<unsigned *>(w); S.ldw[i] = p.ldb;
-        S.N[i] = p.N; S.K[i] = p.K;
         maxpairs = pairs > maxpairs ? pairs : maxpairs;
-        p.Bp = w;
-        w += planes_bytes(p);
         maxn = p.N > maxn ? p.N : maxn;
         minn = p.N < minn ? p.N : minn;
+    }
+    const unsigned gx = (unsigned)((maxpairs + 255) / 256 < 4096 ? (maxpairs + 255) / 256 : 4096);
+    if (npl == 2) {
+        float *slots = reinterpret_cast<float *>(w);
+        w += 256;
+        Split2Batch S;
+        for (int i = 0; i < B.nprob; ++i) {
+            GemmNtProb &p = B.p[i];
+            if (!p.a_amax) {                    // nobody knows max|A|: one pass over it (callers with a producer-side maximum skip this)
+                int rc = launch_absmax(static_cast<const float *>(p.A), p.lda, p.M, p.K, slots + 2 * i, st);
+                if (rc) return rc;
+                p.a_amax = slots + 2 * i;
+            }
+            int rc = launch_absmax(static_cast<const float *>(p.Bt), p.ldb, p.N, p.K, slots + 2 * i + 1, st);
+            if (rc) return rc;
+            p.b_amax = slots + 2 * i + 1;
+            S.W[i] = static_cast<const float *>(p.Bt); S.planes[i] = reinterpret_cast<unsigned *>(w); S.ldw[i] = p.ldb;
+            S.N[i] = p.N; S.K[i] = p.K; S.amax[i] = p.b_amax;
+            p.Bp = w;
+            w += ((size_t)4 * p.N * p.K + 255) & ~(size_t)255;
+        }
+        EPN_LAUNCH_AUX(split_planes2_batch_kernel, dim3(gx, B.nprob), dim3(256), 0, st, S);
+        EPN_CHECK_LAUNCH();
+        return x3_dispatch<2>(B, maxn, minn, st);
+    }
+    SplitBatch S;
+    for (int i = 0; i < B.nprob; ++i) {
+        GemmNtProb &p = B.p[i];
+        S.W[i] = static_cast<const float *>(p.Bt); S.planes[i] = reinterpret_cast<unsigned *>(w); S.ldw[i] = p.ldb;
+        S.N[i] = p.N; S.K[i] = p.K;
+        p.Bp = w;
+        w += planes_bytes(p);
     }
     if (B.nprob == 1) {
         EPN_LAUNCH_AUX(split_planes_kernel, dim3((unsigned)((maxpairs + 255) / 256)), dim3(256), 0, st, S.W[0], S.ldw[0], S.N[0],
                        S.K[0], S.planes[0]);
     } else {
-        const unsigned gx = (unsigned)((maxpairs + 255) / 256 < 4096 ? (maxpairs + 255) / 256 : 4096);
         EPN_LAUNCH_AUX(split_planes_batch_kernel, dim3(gx, B.nprob), dim3(256), 0, st, S);
     }
     EPN_CHECK_LAUNCH();
-    const int pol = kernel_policy();
-    if ((pol & ~0xff) == 0x100) {               // tuning override (tools/x3_probe.py)
-        switch (pol & 0xff) {
-            case 0x21: return launch_x3_cfg<4, 2, 2, 2, 2>(B, st);     // 256 x 128, 8 waves
-            case 0x22: return launch_x3_cfg<4, 2, 2, 4, 2>(B, st);     // 256 x 256, 8 waves (all of the LDS)
-            case 0x23: return launch_x3_cfg<2, 2, 2, 2, 2>(B, st);     // 128 x 128, 4 waves
-            case 0x24: return launch_x3_cfg<2, 2, 2, 2, 3>(B, st);
-            case 0x25: return launch_x3_cfg<4, 1, 2, 2, 3>(B, st);     // 256 x 64, 4 waves
-            case 0x26: return launch_x3_cfg<4, 1, 2, 2, 2>(B, st);
-            case 0x27: return launch_x3_cfg<2, 2, 4, 2, 2>(B, st);     // 256 x 128, 4 waves (128 x 64 per wave)
-            case 0x28: return launch_x3_cfg<2, 4, 2, 2, 2>(B, st);     // 128 x 256, 8 waves
-            case 0x29: return launch_x3_cfg<2, 2, 2, 4, 2>(B, st);     // 128 x 256, 4 waves
-            case 0x2a: return launch_x3_cfg<8, 1, 2, 1, 2>(B, st);     // 512 x 32
-            default: break;
-        }
-    }
-    if (B.nprob > 1) {                          // grouped spectral blocks: ragged widths, narrow tiles (see launch_nt_typed)
-        if (maxn <= 320 && minn <= 64) return launch_x3_cfg<4, 1, 2, 2, 3>(B, st);
-        if (minn >= 256) return launch_x3_cfg<4, 2, 2, 4, 2>(B, st);   // c = 256 blocks: 0.76 -> 0.68 ms (A is re-read per tile column)
-        return launch_x3_cfg<2, 2, 2, 2, 2>(B, st);
-    }
-    if (maxn <= 32) return launch_x3_cfg<8, 1, 2, 1, 2>(B, st);
-    if (maxn <= 64) return launch_x3_cfg<4, 1, 2, 2, 3>(B, st);
-    if (maxn <= 128 || maxn % 256 > 128 || (maxn % 256 && maxn < 512)) return launch_x3_cfg<4, 2, 2, 2, 2>(B, st);
-    return launch_x3_cfg<4, 2, 2, 4, 2>(B, st);
+    return x3_dispatch<3>(B, maxn, minn, st);
 }
 
 }  // namespace epn
@@ -399,11 +586,53 @@ extern "C" int epn_gemm_nt_split_f32(int nprob, const epn_gemm_nt_problem *probs
             GemmNtProb &p = B.p[i];
             p.A = q.A; p.Bt = q.Bt; p.C = q.C; p.M = q.M; p.N = q.N; p.K = q.K; p.lda = q.lda; p.ldb = q.ldb; p.ldc = q.ldc;
             p.tiles_n = 0; p.tile0 = 0; p.ntile = 0; p.Bp = nullptr; p.stats = q.col_stats;
+            p.a_amax = p.b_amax = nullptr;
         }
         const size_t need = gemm_nt_x3_workspace(B);
         int rc = launch_gemm_nt_x3(B, need <= left ? w : nullptr, need <= left ? need : 0, st);
         if (rc) return rc;
         if (need <= left) { w += need; left -= need; }
+    }
+    return 0;
+}
+
+extern "C" int epn_absmax_f32(const float *src, long long ld, long long rows, long long cols, float *out, epn_stream_t stream) {
+    if (rows < 0 || cols < 0 || (rows > 1 && ld < cols)) return EPN_EINVAL;
+    return launch_absmax(src, ld, rows, cols, out, epn_stream(stream));
+}
+
+extern "C" size_t epn_gemm_nt_f16x2_workspace_bytes(int nprob, const epn_gemm_nt_problem *probs) {
+    if (!probs || nprob < 1) return 0;
+    size_t n = 0;
+    for (int i0 = 0; i0 < nprob; i0 += GEMM_MAX_PROB) {
+        n += 256;
+        for (int i = i0; i < nprob && i < i0 + GEMM_MAX_PROB; ++i) n += (((size_t)4 * probs[i].N * probs[i].K + 255) & ~(size_t)255);
+    }
+    return n;
+}
+
+extern "C" int epn_gemm_nt_f16x2_f32(int nprob, const epn_gemm_nt_problem *probs, const float *const *a_amax, void *workspace,
+                                     size_t workspace_bytes, epn_stream_t stream) {
+    if (!probs) return EPN_ENULL;
+    if (nprob < 1) return EPN_EINVAL;
+    hipStream_t st = epn_stream(stream);
+    char *w = static_cast<char *>(workspace);
+    size_t left = workspace ? workspace_bytes : 0;
+    for (int i0 = 0; i0 < nprob; i0 += GEMM_MAX_PROB) {
+        GemmNtBatch B;
+        B.nprob = nprob - i0 < GEMM_MAX_PROB ? nprob - i0 : GEMM_MAX_PROB;
+        for (int i = 0; i < B.nprob; ++i) {
+            const epn_gemm_nt_problem &q = probs[i0 + i];
+            GemmNtProb &p = B.p[i];
+            p.A = q.A; p.Bt = q.Bt; p.C = q.C; p.M = q.M; p.N = q.N; p.K = q.K; p.lda = q.lda; p.ldb = q.ldb; p.ldc = q.ldc;
+            p.tiles_n = 0; p.tile0 = 0; p.ntile = 0; p.Bp = nullptr; p.stats = q.col_stats;
+            p.a_amax = a_amax ? a_amax[i0 + i] : nullptr; p.b_amax = nullptr;
+        }
+        const size_t need = gemm_nt_f2_workspace(B);
+        if (need > left) return EPN_EWORKSPACE;
+        int rc = launch_gemm_nt_x3(B, w, need, st, 2);
+        if (rc) return rc;
+        w += need; left -= need;
     }
     return 0;
 }

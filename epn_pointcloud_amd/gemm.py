@@ -13,16 +13,71 @@ import torch
 from . import _lib
 
 
-# fp32 contractions: "split" = on the bf16 matrix pipe with lossless three-way operand splitting (fp32 accuracy,
-# csrc/gemm_x3.hip), "native" = v_mfma_f32_32x32x2_f32
-FP32_MODE = os.environ.get("EPN_GEMM_FP32", "split")
+# fp32 contractions (fp32 operands, fp32 accumulation, fp32 result in every mode):
+#   "f16x2"  two fp16 pieces per operand, three v_mfma_f32_32x32x16_f16 per block (csrc/gemm.h): measured error vs fp64 at or
+#            below the fp32 matrix instruction's; needs max|operand| as a device scalar (`amax`, see absmax)
+#   "split"  three bf16 pieces, six v_mfma_f32_32x32x16_bf16 per block: no input bit is dropped (csrc/gemm_x3.hip)
+#   "native" v_mfma_f32_32x32x2_f32
+FP32_MODES = ("f16x2", "split", "native")
+FP32_MODE = os.environ.get("EPN_GEMM_FP32", "f16x2")
+if FP32_MODE not in FP32_MODES:
+    raise ValueError(f"EPN_GEMM_FP32 must be one of {FP32_MODES}")
 
 
 def set_fp32_mode(mode):
     global FP32_MODE
-    if mode not in ("split", "native"):
-        raise ValueError("fp32 GEMM mode is 'split' or 'native'")
+    if mode not in FP32_MODES:
+        raise ValueError(f"fp32 GEMM mode is one of {FP32_MODES}")
     FP32_MODE = mode
+
+
+def absmax(t):
+    """max |t| of a 2-D row-major (possibly row-strided) or contiguous fp32 tensor as a 1-element device tensor: the scale
+    source of the f16x2 GEMMs.  A producer that knows the maximum hands its own scalar to gemm_nt / gemm_tn instead."""
+    lib = _lib.get_lib()
+    if t.dtype != torch.float32 or not t.is_cuda:
+        raise TypeError("absmax: fp32 CUDA tensor expected")
+    out = torch.empty(1, dtype=torch.float32, device=t.device)
+    if t.dim() == 2 and t.stride(1) == 1:
+        rows, cols, ld = t.shape[0], t.shape[1], (t.stride(0) if t.shape[0] > 1 else t.shape[1])
+    else:
+        t = t.contiguous()
+        rows, cols, ld = 1, t.numel(), t.numel()
+    _lib.check(lib.epn_absmax_f32(t.data_ptr(), ld, rows, cols, out.data_ptr(), _lib.stream_of(t)), "absmax")
+    return out
+
+
+def f16x2_on(t):
+    """Do the fp32 contractions of this tensor run in the two-piece fp16 form (and so want max|operand| device scalars)?"""
+    return FP32_MODE == "f16x2" and t.dtype == torch.float32
+
+
+def absmax_cached(t):
+    """absmax(t), remembered ON the tensor object (and dropped when the tensor is written to): a tensor that is an operand of
+    several GEMMs -- an output gradient feeds the data-gradient and the weight-gradient contraction, a block input the
+    grouping and the skip convolution -- is scanned once."""
+    hit = getattr(t, "_epn_amax", None)
+    if hit is not None and hit[0] == t._version:
+        return hit[1]
+    a = absmax(t)
+    try:
+        t._epn_amax = (t._version, a)
+    except (AttributeError, RuntimeError):
+        pass
+    return a
+
+
+def _amax_array(amaxes):
+    """list of 1-element device tensors / None -> (ctypes array of pointers or None, keep-alive list)."""
+    if amaxes is None or all(a is None for a in amaxes):
+        return None, []
+    arr = (ctypes.c_void_p * len(amaxes))()
+    for i, a in enumerate(amaxes):
+        if a is not None:
+            if a.dtype != torch.float32 or a.numel() != 1 or not a.is_cuda:
+                raise ValueError("amax must be a 1-element fp32 CUDA tensor")
+            arr[i] = a.data_ptr()
+    return arr, [a for a in amaxes if a is not None]
 
 
 def _is_bf16(t):
@@ -53,8 +108,9 @@ def _problem(A, Bt, C):
     return p
 
 
-def gemm_nt_grouped(problems, out_dtype=None, col_stats=None):
+def gemm_nt_grouped(problems, out_dtype=None, col_stats=None, a_amax=None):
     """problems: list of (A [M,K], Bt [N,K], C [M,N] or None); one grouped launch per 6 problems.  Returns the C list.
+    a_amax: optional list (one per problem) of 1-element device tensors holding max|A| (f16x2 mode; None = computed here).
     All operands share one dtype (fp32 or bf16); C is that dtype unless out_dtype says float32.  col_stats: optional list
     (one entry per problem) of fp32 [M/32, N, 2] tensors the kernels fill with per-column (sum, sum of squares) of every
     32-row block of C from their accumulators (None entries: off)."""
@@ -88,6 +144,11 @@ def gemm_nt_grouped(problems, out_dtype=None, col_stats=None):
     if bf:
         out_f32 = 1 if outs[0].dtype == torch.float32 else 0
         _lib.check(lib.epn_gemm_nt_bf16(len(problems), arr, out_f32, st), "gemm_nt_bf16")
+    elif FP32_MODE == "f16x2":
+        nbytes = int(lib.epn_gemm_nt_f16x2_workspace_bytes(len(problems), arr))
+        ws = torch.empty(max(nbytes, 256), dtype=torch.uint8, device=outs[0].device)
+        parr, keep2 = _amax_array(a_amax)
+        _lib.check(lib.epn_gemm_nt_f16x2_f32(len(problems), arr, parr, ws.data_ptr(), ws.numel(), st), "gemm_nt_f16x2_f32")
     elif FP32_MODE == "split":
         nbytes = int(lib.epn_gemm_nt_split_workspace_bytes(len(problems), arr))
         ws = torch.empty(max(nbytes, 256), dtype=torch.uint8, device=outs[0].device)
@@ -97,18 +158,19 @@ def gemm_nt_grouped(problems, out_dtype=None, col_stats=None):
     return outs
 
 
-def gemm_nt(A, Bt, out=None, out_dtype=None, col_stats=False):
+def gemm_nt(A, Bt, out=None, out_dtype=None, col_stats=False, a_amax=None):
     """col_stats=True: returns (C, partials [M/32, N, 2] or None when M % 32 != 0) -- the per-channel statistics of C
-    from the kernel's epilogue (ops.sums_from_partials finishes them)."""
+    from the kernel's epilogue (ops.sums_from_partials finishes them).  a_amax: device scalar max|A| (f16x2 mode)."""
+    am = None if a_amax is None else [a_amax]
     if not col_stats:
-        return gemm_nt_grouped([(A, Bt, out)], out_dtype)[0]
+        return gemm_nt_grouped([(A, Bt, out)], out_dtype, a_amax=am)[0]
     M, N = A.shape[0], Bt.shape[0]
     part = torch.empty((M // 32, N, 2), dtype=torch.float32, device=A.device) if M % 32 == 0 and M > 0 else None
-    return gemm_nt_grouped([(A, Bt, out)], out_dtype, [part])[0], part
+    return gemm_nt_grouped([(A, Bt, out)], out_dtype, [part], a_amax=am)[0], part
 
 
-def gemm_tn(X, Y, out=None):
-    """X [R,N1], Y [R,N2] (same dtype) -> X^T Y fp32 [N1,N2]."""
+def gemm_tn(X, Y, out=None, x_amax=None, y_amax=None):
+    """X [R,N1], Y [R,N2] (same dtype) -> X^T Y fp32 [N1,N2].  x_amax / y_amax: device scalars max|X|, max|Y| (f16x2 mode)."""
     lib = _lib.get_lib()
     X, Y = _rowmajor(X, "X"), _rowmajor(Y, "Y")
     if X.shape[0] != Y.shape[0]:
@@ -122,20 +184,28 @@ def gemm_tn(X, Y, out=None):
     elif out.dtype != torch.float32 or out.stride(1) != 1 or tuple(out.shape) != (N1, N2):
         raise ValueError("gemm_tn: output must be row-major fp32 [N1,N2]")
     split = not bf and FP32_MODE == "split"
-    nbytes = int(lib.epn_gemm_tn_workspace_bytes(2 if split else bf, R, N1, N2))
+    f2 = not bf and FP32_MODE == "f16x2"
+    nbytes = int(lib.epn_gemm_tn_workspace_bytes(3 if f2 else (2 if split else bf), R, N1, N2))
     ws = torch.empty(max(nbytes, 16), dtype=torch.uint8, device=X.device)
     fn = lib.epn_gemm_tn_bf16 if bf else (lib.epn_gemm_tn_split_f32 if split else lib.epn_gemm_tn_f32)
     ldx = X.stride(0) if R > 1 else N1
     ldy = Y.stride(0) if R > 1 else N2
     ldc = out.stride(0) if N1 > 1 else N2
+    if f2:
+        _lib.check(lib.epn_gemm_tn_f16x2_f32(X.data_ptr(), ldx, Y.data_ptr(), ldy, out.data_ptr(), ldc, R, N1, N2,
+                                             None if x_amax is None else x_amax.data_ptr(),
+                                             None if y_amax is None else y_amax.data_ptr(), ws.data_ptr(), ws.numel(),
+                                             _lib.stream_of(X)), "gemm_tn_f16x2")
+        return out
     _lib.check(fn(X.data_ptr(), ldx, Y.data_ptr(), ldy, out.data_ptr(), ldc, R, N1, N2, ws.data_ptr(), ws.numel(),
                   _lib.stream_of(X)), "gemm_tn")
     return out
 
 
-def gemm_tn_grouped(problems, outs_into=None):
+def gemm_tn_grouped(problems, outs_into=None, x_amax=None, y_amax=None):
     """problems: list of (X [R,N1], Y [R,N2]) of one dtype -> list of fp32 X^T Y, ONE launch (+ one reduction launch).
-    outs_into: optional list of row-major fp32 [N1,N2] tensors to write the results into (e.g. slices of one buffer)."""
+    outs_into: optional list of row-major fp32 [N1,N2] tensors to write the results into (e.g. slices of one buffer).
+    x_amax / y_amax: optional lists of device scalars (f16x2 mode)."""
     lib = _lib.get_lib()
     arr = (_lib.GemmTnProblem * len(problems))()
     outs, keep, bf = [], [], None
@@ -161,9 +231,15 @@ def gemm_tn_grouped(problems, outs_into=None):
         p.ldc = C.shape[1]
         outs.append(C)
         keep += [X, Y]
-    mode = 2 if (not bf and FP32_MODE == "split") else bf
+    mode = bf if bf else {"split": 2, "f16x2": 3}.get(FP32_MODE, 0)
     nbytes = int(lib.epn_gemm_tn_grouped_workspace_bytes(mode, len(problems), arr))
     ws = torch.empty(max(nbytes, 16), dtype=torch.uint8, device=outs[0].device)
+    if mode == 3:
+        xa, k1 = _amax_array(x_amax)
+        ya, k2 = _amax_array(y_amax)
+        _lib.check(lib.epn_gemm_tn_grouped_f16x2(len(problems), arr, xa, ya, ws.data_ptr(), ws.numel(), _lib.stream_of(outs[0])),
+                   "gemm_tn_grouped_f16x2")
+        return outs
     _lib.check(lib.epn_gemm_tn_grouped(mode, len(problems), arr, ws.data_ptr(), ws.numel(), _lib.stream_of(outs[0])),
                "gemm_tn_grouped")
     return outs
@@ -201,11 +277,13 @@ class MatmulNT(torch.autograd.Function):
         Wc = W if W.dtype == A.dtype else cast(W, A.dtype)
         ctx.save_for_backward(A, W)
         M, K, N = A.shape[0], A.shape[1], W.shape[0]
+        a_amax = absmax_cached(A) if f16x2_on(A) else None        # (shared with the weight gradient, where A is the Y operand)
+        ctx.a_amax = a_amax
         if not col_stats:
-            return ops._launch("conv1x1_gemm", ("nt", M, N, K), 2.0 * M * N * K, A.device, lambda: gemm_nt(A, Wc))
+            return ops._launch("conv1x1_gemm", ("nt", M, N, K), 2.0 * M * N * K, A.device, lambda: gemm_nt(A, Wc, a_amax=a_amax))
         # (C, partial column statistics of C from the kernel's epilogue; an empty tensor when M % 32 != 0)
         C, part = ops._launch("conv1x1_gemm", ("nt", M, N, K), 2.0 * M * N * K, A.device,
-                              lambda: gemm_nt(A, Wc, col_stats=True))
+                              lambda: gemm_nt(A, Wc, col_stats=True, a_amax=a_amax))
         part = part if part is not None else torch.empty(0, dtype=torch.float32, device=A.device)
         ctx.mark_non_differentiable(part)
         return C, part
@@ -219,14 +297,16 @@ class MatmulNT(torch.autograd.Function):
         from . import ops
         dA = dW = None
         M, K, N = A.shape[0], A.shape[1], W.shape[0]
+        dc_amax = absmax(dC) if f16x2_on(dC) else None
         if ctx.needs_input_grad[0]:
             Wt = transpose_cast(W, A.dtype)
-            dA = ops._launch("conv1x1_gemm", ("nt", M, K, N), 2.0 * M * N * K, A.device, lambda: gemm_nt(dC, Wt))
+            dA = ops._launch("conv1x1_gemm", ("nt", M, K, N), 2.0 * M * N * K, A.device, lambda: gemm_nt(dC, Wt, a_amax=dc_amax))
             # a fresh buffer that is the gradient of exactly one tensor (A): a consumer that receives a re-layout VIEW of it
             # through autograd's view nodes may accumulate into it (ops.InterSO3ConvSplitFn._may_write_into)
             dA._epn_private = True
         if ctx.needs_input_grad[1]:
-            dW = ops._launch("conv1x1_gemm_dw", ("tn", M, N, K), 2.0 * M * N * K, A.device, lambda: gemm_tn(dC, A))
+            dW = ops._launch("conv1x1_gemm_dw", ("tn", M, N, K), 2.0 * M * N * K, A.device,
+                             lambda: gemm_tn(dC, A, x_amax=dc_amax, y_amax=ctx.a_amax))
         return dA, dW, None
 
 

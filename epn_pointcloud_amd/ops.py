@@ -109,7 +109,7 @@ def empty_cl(b, c, p, a, device, dtype=torch.float32):
 def _entry(lib, base, dtype):
     """C entry point of `base` for a feature dtype: epn_<base>_f32 | epn_<base>_bf16; the fp32 change of basis has a
     split form (bf16 matrix pipe, fp32 accuracy) that follows the GEMMs' switch (gemm.FP32_MODE)."""
-    if dtype != torch.bfloat16 and base in ("so3_basis", "so3_basis_norm", "so3_basis_stats", "so3_basis_dstats") and gemm.FP32_MODE == "split":
+    if dtype != torch.bfloat16 and base in ("so3_basis", "so3_basis_norm", "so3_basis_stats", "so3_basis_dstats") and gemm.FP32_MODE != "native":
         return getattr(lib, f"epn_{base}_split_f32")
     return getattr(lib, f"epn_{base}_{'bf16' if dtype == torch.bfloat16 else 'f32'}")
 
@@ -405,12 +405,19 @@ class InterSO3ConvSplitFn(torch.autograd.Function):
                                                                   _lib.stream_of(f)), "inter_pack_weights")
         else:
             Wd = gemm.cast(Wc, f.dtype)                              # fp32 master weights; bf16 copy per call
+        # two-piece fp16 contractions want max|G| as a device scalar.  Reading the 3-6 GB of G back for it would cost what the
+        # form saves; |G[col][c, k]| = |sum_n w[k][n] F[idx[n], a, c]| <= K max|F| (0 <= w <= 1) is a bound from a pass over the
+        # 24 x smaller feature tensor -- an over-estimated maximum only narrows the window of full relative precision from
+        # 2^17 to 2^17 / K below the true maximum (tests/test_gpu_bf16.py::test_f16x2_gemm_has_fp32_accuracy pins 64 x)
+        g_amax = gemm.absmax_cached(f) * float(d.nn) if gemm.f16x2_on(G) else None
         if share_input:        # a block asks: its norm follows -- per-channel statistics from the GEMM's epilogue
             out2d, part = _launch("inter_gemm", _inter_key(d), 2.0 * cols * cout * ck, f.device,
-                                  lambda: gemm.gemm_nt(G, Wd, col_stats=True))
+                                  lambda: gemm.gemm_nt(G, Wd, col_stats=True, a_amax=g_amax))
             part = part if part is not None else torch.empty(0, dtype=torch.float32, device=f.device)
         else:
-            out2d = _launch("inter_gemm", _inter_key(d), 2.0 * cols * cout * ck, f.device, lambda: gemm.gemm_nt(G, Wd))
+            out2d = _launch("inter_gemm", _inter_key(d), 2.0 * cols * cout * ck, f.device,
+                            lambda: gemm.gemm_nt(G, Wd, a_amax=g_amax))
+        ctx.g_amax = g_amax
         ctx.save_for_backward(G, Wc)
         ctx.geo, ctx.cin, ctx.packed = geo, cin, packed
         out = out2d.view(d.b, d.p2, d.na, cout).permute(0, 3, 1, 2)
@@ -474,8 +481,12 @@ class InterSO3ConvSplitFn(torch.autograd.Function):
         need_f, need_w = ctx.needs_input_grad[0], ctx.needs_input_grad[1]
         gemm_fl = 2.0 * cols * cout * ck
         gf = gW = None
+        # two-piece fp16 contractions: max|dOut| once for both GEMMs it feeds (a pass over the narrow operand), max|G| as the
+        # forward pass bounded it
+        go_amax = gemm.absmax(g2d) if gemm.f16x2_on(G) else None
         if need_w:
-            gW = _launch("inter_gemm_dw", _inter_key(d), gemm_fl, G.device, lambda: gemm.gemm_tn(g2d, G))
+            gW = _launch("inter_gemm_dw", _inter_key(d), gemm_fl, G.device,
+                         lambda: gemm.gemm_tn(g2d, G, x_amax=go_amax, y_amax=ctx.g_amax))
             if ctx.packed:                                           # computed against packed G: columns back in c*ks + k order
                 gWp, gW = gW, torch.empty_like(gW)
                 _lib.check(lib.epn_inter_unpack_weight_grad_f32(gWp.data_ptr(), cout, cin, d.ks, gW.data_ptr(),
@@ -513,7 +524,7 @@ class InterSO3ConvSplitFn(torch.autograd.Function):
                            "inter_so3conv_bwd_data")
             else:
                 Wt = gemm.transpose_cast(Wc, G.dtype)                        # [ck, cout]: dG = dOut W as an NT GEMM
-                dG = _launch("inter_gemm_dg", _inter_key(d), gemm_fl, G.device, lambda: gemm.gemm_nt(g2d, Wt))
+                dG = _launch("inter_gemm_dg", _inter_key(d), gemm_fl, G.device, lambda: gemm.gemm_nt(g2d, Wt, a_amax=go_amax))
                 ws, wsp, wsn = _group_workspace(lib, d, G.device)
                 gflops = 9.0 * cols * d.ks * d.nn + 2.0 * cols * cin * d.ks * d.nn
                 if deterministic_bwd(G.dtype) and isinstance(geo, InterGeometry) and d.na >= 16:
@@ -565,8 +576,8 @@ def inter_onchip_ok(feats, W, geo):
     """Does the on-chip form (csrc/inter_fx.hip: grouping = A-tile producer of the weight contraction) take this layer?"""
     if isinstance(geo, DenseInterWeights) or not feats.is_cuda or feats.dtype not in FEATURE_DTYPES:
         return False
-    if feats.dtype == torch.float32 and gemm.FP32_MODE != "split":
-        return False                      # the on-chip fp32 form IS the split (3 x bf16) contraction
+    if feats.dtype == torch.float32 and gemm.FP32_MODE == "native":
+        return False                      # the on-chip fp32 form IS a split (3 x bf16) contraction: not under the exact-f32 switch
     d = geo.desc(feats.shape[1], W.shape[0])
     return bool(_lib.get_lib().epn_inter_onchip_ok(ctypes.byref(d), int(feats.dtype == torch.bfloat16)))
 
@@ -1040,7 +1051,11 @@ class _BlockGemmsFn(torch.autograd.Function):
             wt = whats_t[bi] if whats_t is not None and whats_t[bi].dtype == y.dtype else gemm.transpose_cast(wh, y.dtype)
             probs.append((A, wt, O))                                        # Bt = What^T [d*cout, d*cin]
             fl += 2.0 * pts * d * d * cin * d * cout
-        _launch("intra_gemm", ("spectral", pts, cin, cout), fl, y.device, lambda: gemm.gemm_nt_grouped(probs))
+        # two-piece fp16 contractions: ONE maximum for the whole spectral buffer (its five slices are the operands)
+        y_amax = gemm.absmax(y) if gemm.f16x2_on(y) else None
+        _launch("intra_gemm", ("spectral", pts, cin, cout), fl, y.device,
+                lambda: gemm.gemm_nt_grouped(probs, a_amax=None if y_amax is None else [y_amax] * len(probs)))
+        ctx.y_amax = y_amax
         ctx.save_for_backward(y, *whats)
         ctx.cfg = (basis, pts, cin, cout)
         ctx.ops_n = whats_n if whats_n is not None and whats_n[0].dtype == y.dtype else None
@@ -1051,6 +1066,7 @@ class _BlockGemmsFn(torch.autograd.Function):
         y, *whats = ctx.saved_tensors
         basis, pts, cin, cout = ctx.cfg
         gz = gz.contiguous()
+        gz_amax = gemm.absmax(gz) if gemm.f16x2_on(gz) else None
         gy = torch.empty_like(y) if ctx.needs_input_grad[0] else None
         gws, probs, tprobs, tidx, fl, flw = [None] * len(whats), [], [], [], 0.0, 0.0
         for bi, (d, base, wh) in enumerate(zip(basis.dims, basis.bases, whats)):
@@ -1072,11 +1088,14 @@ class _BlockGemmsFn(torch.autograd.Function):
             into = [gw_flat[basis.bases[bi] * cc:(basis.bases[bi] + basis.dims[bi] ** 2) * cc].view(
                 basis.dims[bi] * cin, basis.dims[bi] * cout) for bi in tidx]
             outs = _launch("intra_gemm_dw", ("spectral_dw", pts, cin, cout), flw, y.device,
-                           lambda: gemm.gemm_tn_grouped(tprobs, into))
+                           lambda: gemm.gemm_tn_grouped(tprobs, into,
+                                                        x_amax=None if ctx.y_amax is None else [ctx.y_amax] * len(tprobs),
+                                                        y_amax=None if gz_amax is None else [gz_amax] * len(tprobs)))
             for bi, o in zip(tidx, outs):
                 gws[bi] = o
         if probs:
-            _launch("intra_gemm", ("spectral_dA", pts, cin, cout), fl, y.device, lambda: gemm.gemm_nt_grouped(probs))
+            _launch("intra_gemm", ("spectral_dA", pts, cin, cout), fl, y.device,
+                    lambda: gemm.gemm_nt_grouped(probs, a_amax=None if gz_amax is None else [gz_amax] * len(probs)))
         return (gy, None, None, None, None, None, *gws)
 
 

@@ -563,6 +563,27 @@ typedef struct epn_gemm_tn_problem {
 size_t epn_gemm_tn_grouped_workspace_bytes(int bf16, int nprob, const epn_gemm_tn_problem *probs);
 int epn_gemm_tn_grouped(int bf16, int nprob, const epn_gemm_tn_problem *probs, void *workspace, size_t workspace_bytes,
                         epn_stream_t stream);
+
+/* ---- fp32 contractions as THREE fp16 matrix products ("f16x2", round 5; csrc/gemm.h) -------------------------------------
+ * Same math as BasicSO3Conv.forward and its autograd transposes (vgtk/vgtk/so3conv/modules.py:48-55), fp32 operands, fp32
+ * accumulation, fp32 result.  Each operand is scaled by the power of two that puts its largest magnitude at 2^14 and split
+ * into two fp16 pieces x 2^s = h + l (22-23 significant bits for every element within 2^-17 of the tensor's maximum,
+ * absolute error <= max|x| 2^-39 below); a product is hh + hl + lh on v_mfma_f32_32x32x16_f16 -- half the matrix
+ * instructions of the lossless three-piece bf16 form (epn_gemm_*_split_f32), with a measured error against fp64 at or below
+ * that of the fp32 matrix instruction.  The scale comes from a DEVICE scalar holding max|x|: pass the
+ * pointer when a producer already knows it (epn_absmax_f32 computes one: memset + one pass), or NULL and the entry point
+ * makes that pass itself into its workspace.  Nothing is synchronised with the host; capturable into a HIP graph.
+ * `a_amax` / `x_amax` / `y_amax`: arrays of nprob device pointers (entries may be NULL), or NULL.
+ * Workspace: epn_gemm_nt_f16x2_workspace_bytes; epn_gemm_tn_workspace_bytes(3, ...) / epn_gemm_tn_grouped_workspace_bytes(3, ...). */
+int epn_absmax_f32(const float *src, long long ld, long long rows, long long cols, float *out, epn_stream_t stream);
+size_t epn_gemm_nt_f16x2_workspace_bytes(int nprob, const epn_gemm_nt_problem *probs);
+int epn_gemm_nt_f16x2_f32(int nprob, const epn_gemm_nt_problem *probs, const float *const *a_amax, void *workspace,
+                          size_t workspace_bytes, epn_stream_t stream);
+int epn_gemm_tn_f16x2_f32(const float *X, long long ldx, const float *Y, long long ldy, float *C, long long ldc, long long R,
+                          int N1, int N2, const float *x_amax, const float *y_amax, void *workspace, size_t workspace_bytes,
+                          epn_stream_t stream);
+int epn_gemm_tn_grouped_f16x2(int nprob, const epn_gemm_tn_problem *probs, const float *const *x_amax, const float *const *y_amax,
+                              void *workspace, size_t workspace_bytes, epn_stream_t stream);
 /* dst[cols][rows] = src[rows][cols]^T with an optional fp32 <-> bf16 conversion (weights: W^T for the data gradient,
  * bf16 copies of the fp32 master weights); epn_cast converts a flat array. */
 int epn_transpose_cast(const void *src, void *dst, int rows, int cols, int src_bf16, int dst_bf16, epn_stream_t stream);

@@ -40,9 +40,9 @@ def rel_l2(got, want):
 
 
 # ------------------------------------------------------------------------------------------------ GEMM kernels
-@pytest.fixture(params=["split", "native"])
+@pytest.fixture(params=["f16x2", "split", "native"])
 def fp32_mode(request):
-    """fp32 contractions: lossless 3 x bf16 split on the bf16 MFMAs (default) / v_mfma_f32_32x32x2_f32."""
+    """fp32 contractions: two fp16 pieces x three matrix products / lossless 3 x bf16 split / v_mfma_f32_32x32x2_f32."""
     from epn_pointcloud_amd import gemm
     old = gemm.FP32_MODE
     gemm.set_fp32_mode(request.param)
@@ -56,7 +56,7 @@ def fp32_mode(request):
                                    (1500, 200, 16)])
 def test_gemm_nt_vs_fp64(gpu, fp32_mode, dt, M, N, K):
     from epn_pointcloud_amd import gemm
-    if dt != torch.float32 and fp32_mode == "native":
+    if dt != torch.float32 and fp32_mode != "split":
         pytest.skip("mode only concerns fp32 operands")
     torch.manual_seed(M + N + K)
     A = torch.randn(M, K, device=gpu).to(dt)
@@ -77,7 +77,7 @@ def test_gemm_nt_epilogue_column_statistics(gpu, fp32_mode, dt, M, N, K):
     and epn_stats_finish's group sums (BatchNorm: 1 group, InstanceNorm: one per cloud; M = 98304: the two-level reduction
     of long partial lists)."""
     from epn_pointcloud_amd import gemm, ops
-    if dt != torch.float32 and fp32_mode == "native":
+    if dt != torch.float32 and fp32_mode != "split":
         pytest.skip("mode only concerns fp32 operands")
     torch.manual_seed(M + N + K)
     A = (torch.randn(M, K, device=gpu) + 0.3).to(dt)
@@ -110,7 +110,7 @@ def test_gemm_nt_epilogue_column_statistics(gpu, fp32_mode, dt, M, N, K):
                                       (61440, 256, 128)])
 def test_gemm_tn_vs_fp64(gpu, fp32_mode, dt, R_, N1, N2):
     from epn_pointcloud_amd import gemm
-    if dt != torch.float32 and fp32_mode == "native":
+    if dt != torch.float32 and fp32_mode != "split":
         pytest.skip("mode only concerns fp32 operands")
     torch.manual_seed(R_ + N1 + N2)
     X = torch.randn(R_, N1, device=gpu).to(dt)
@@ -142,7 +142,7 @@ def test_gemm_grouped_and_transpose(gpu, fp32_mode):
 def test_gemm_tn_grouped(gpu, fp32_mode, dt):
     """One launch for the five weight-gradient GEMMs of a spectral IntraSO3Conv layer (R = pts*d rows, d*c x d*c outputs)."""
     from epn_pointcloud_amd import gemm
-    if dt != torch.float32 and fp32_mode == "native":
+    if dt != torch.float32 and fp32_mode != "split":
         pytest.skip("mode only concerns fp32 operands")
     torch.manual_seed(8)
     for w1, w2 in ((64, 32), (256, 256), (512, 512)):   # (512, 512): every output >= 512 wide -- the split form pre-splits X
@@ -191,6 +191,68 @@ def test_split_gemm_has_fp32_accuracy(gpu, M, N, K):
         finally:
             gemm.set_fp32_mode(old)
         assert ((C.double() - ref).pow(2).mean().sqrt() / ref.pow(2).mean().sqrt()).item() < 1e-5
+
+
+@pytest.mark.parametrize("M,N,K", [(8192, 128, 1536), (4096, 256, 6144), (4096, 768, 256)])
+def test_f16x2_gemm_has_fp32_accuracy(gpu, M, N, K):
+    """The two-piece fp16 form (x 2^s = h + l, products hh + hl + lh, fp32 accumulate) against fp64, beside the fp32 matrix
+    instruction on the same operands.  What is asserted is what DESIGN.md 3.2c claims:
+      * rms error <= 1.1 x the native fp32 MFMA kernel's on N(0,1) operands, on non-negative (post-activation) operands and
+        on gradient-sized ones (x 1e-7: the power-of-two scale from max|x| keeps them out of fp16's subnormal range);
+      * every ROW keeps that accuracy as long as its magnitude is within ~2^-11 of the tensor's largest -- rows spanning four
+        decades: per-row-normalised error <= 1.5 x native;
+      * an over-estimated maximum (the K x max|F| bound the grouped features use: up to 64 x) costs nothing measurable;
+      * a row 1e-8 of the maximum is NOT kept to fp32 relative accuracy (absolute error <= max|x| 2^-39 instead): stated, and
+        pinned here so that the documentation cannot drift from the kernel."""
+    from epn_pointcloud_amd import gemm
+    torch.manual_seed(K)
+    B = torch.randn(N, K, device=gpu)
+    old = gemm.FP32_MODE
+
+    def errs(A, a_amax=None, per_row=False):
+        ref = A.double() @ B.double().t()
+        scale = ref.pow(2).mean(1, keepdim=True).sqrt() if per_row else ref.pow(2).mean().sqrt()
+        out = {}
+        try:
+            for mode in ("native", "f16x2"):
+                gemm.set_fp32_mode(mode)
+                C = gemm.gemm_nt(A, B, a_amax=a_amax if mode == "f16x2" else None)
+                out[mode] = ((C.double() - ref) / scale).pow(2).mean().sqrt().item()
+        finally:
+            gemm.set_fp32_mode(old)
+        return out
+
+    A = torch.randn(M, K, device=gpu)
+    for name, op in (("randn", A), ("post-activation", A.abs()), ("gradient-sized", A * 1e-7)):
+        e = errs(op)
+        assert e["f16x2"] <= 1.1 * e["native"], (name, e)
+    e = errs(A * (10.0 ** torch.linspace(-2, 2, M, device=gpu))[:, None], per_row=True)
+    assert e["f16x2"] <= 1.5 * e["native"], ("four decades", e)
+    e = errs(A, a_amax=gemm.absmax(A) * 64.0)
+    assert e["f16x2"] <= 1.1 * e["native"], ("64 x over-estimated maximum", e)
+    tiny = A.clone()
+    tiny[0] *= 1e-8
+    ref0 = tiny[:1].double() @ B.double().t()
+    try:
+        gemm.set_fp32_mode("f16x2")
+        C0 = gemm.gemm_nt(tiny, B)[:1]
+    finally:
+        gemm.set_fp32_mode(old)
+    rel0 = ((C0.double() - ref0).pow(2).mean().sqrt() / ref0.pow(2).mean().sqrt()).item()
+    assert 1e-6 < rel0 < 1e-2, rel0            # a row 1e-8 of the maximum: ~1e-4 relative, far below the tensor's scale in absolute terms
+    # weight-gradient forms: narrow output (both operands split in registers) and wide output (X pre-split into octet planes)
+    X = torch.randn(61440, 64, device=gpu)
+    for n2 in (128, 1536):
+        Y = torch.randn(61440, n2, device=gpu).abs()
+        ref = X.double().t() @ Y.double()
+        r = {}
+        try:
+            for mode in ("native", "f16x2"):
+                gemm.set_fp32_mode(mode)
+                r[mode] = ((gemm.gemm_tn(X, Y).double() - ref).pow(2).mean().sqrt() / ref.pow(2).mean().sqrt()).item()
+        finally:
+            gemm.set_fp32_mode(old)
+        assert r["f16x2"] <= 1.2 * r["native"] + 1e-7, (n2, r)
 
 
 def test_split_gemm_ragged_and_fallback(gpu):

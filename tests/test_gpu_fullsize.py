@@ -71,7 +71,7 @@ def test_inter_conv_full_size_slice_vs_oracle(gpu, vgtk_alias, pyramid, li):
     assert (dF[PICK].cpu() - odF).abs().max().item() < TOL
 
 
-@pytest.mark.parametrize("mode", ["split", "native"])
+@pytest.mark.parametrize("mode", ["f16x2", "split", "native"])
 @pytest.mark.parametrize("li", [1, 2, 3, 4, 5, 6])
 def test_weight_gradient_gemm_at_production_rows(gpu, pyramid, li, mode):
     """dW = dOut^T G of every cls layer at its production contraction length R = b*p2*na (983 040 ... 122 880 rows) on

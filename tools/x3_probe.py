@@ -18,21 +18,22 @@ def main():
     dev = torch.device("cuda:0")
     torch.manual_seed(0)
     shapes = [(983040, 64, 1536), (491520, 128, 1536), (245760, 256, 3072), (245760, 256, 6144), (245760, 6144, 256), (245760, 320, 320)]
-    cfgs = [int(c, 0) for c in (sys.argv[1].split(",") if len(sys.argv) > 1 else ["0", "0x1"])]
+    cfgs = [int(c, 0) for c in (sys.argv[1].split(",") if len(sys.argv) > 1 else ["0", "0x1", "0x2"])]
     for (M, N, K) in (shapes if "nt" in os.environ.get("X3_PROBE", "nt,tn") else []):
         A = torch.randn(M, K, device=dev) * torch.exp(torch.randn(M, 1, device=dev))
         B = torch.randn(N, K, device=dev)
         ref = A[:2048].double() @ B.double().t()
         C = torch.empty(M, N, device=dev)
         for cfg in cfgs:
-            gemm.set_fp32_mode("native" if cfg == 0 else "split")
-            _lib.check(_lib.get_lib().epn_set_kernel_policy(cfg if cfg > 1 else 0), "policy")
+            gemm.set_fp32_mode("native" if cfg == 0 else ("f16x2" if cfg == 2 or (cfg >> 12) == 2 else "split"))     # 0x2 / 0x21xx: two-piece fp16 form
+            _lib.check(_lib.get_lib().epn_set_kernel_policy((cfg & 0xfff) if cfg > 2 else 0), "policy")
             C.zero_()
-            gemm.gemm_nt(A, B, out=C)
+            am = gemm.absmax(A) if gemm.FP32_MODE == "f16x2" else None      # the producer supplies max|A| in deployment
+            gemm.gemm_nt(A, B, out=C, a_amax=am)
             err = ((C[:2048].double() - ref).abs().max() / ref.abs().max()).item()
             rms = ((C[:2048].double() - ref).pow(2).mean().sqrt() / ref.pow(2).mean().sqrt()).item()
             tail = (C[-2048:].double() - A[-2048:].double() @ B.double().t()).abs().max().item()
-            t = timeit(lambda: gemm.gemm_nt(A, B, out=C))
+            t = timeit(lambda: gemm.gemm_nt(A, B, out=C, a_amax=am))
             print(f"NT {M}x{N}x{K} cfg {cfg:#x}: {t:.3f} ms {2.0 * M * N * K / t / 1e9:.1f} TF  max {err:.2e} rms {rms:.2e} tail {tail:.1e}", flush=True)
         _lib.get_lib().epn_set_kernel_policy(0)
         del A, B, C, ref
@@ -40,13 +41,14 @@ def main():
         X = torch.randn(R, N1, device=dev) * torch.exp(torch.randn(1, N1, device=dev))
         Y = torch.randn(R, N2, device=dev)
         ref = X[:, :32].double().t() @ Y[:, :256].double()
-        for mode in ("native", "split"):
+        for mode in ("native", "split", "f16x2"):
             gemm.set_fp32_mode(mode)
-            C = gemm.gemm_tn(X, Y)
+            xa, ya = (gemm.absmax(X), gemm.absmax(Y)) if mode == "f16x2" else (None, None)
+            C = gemm.gemm_tn(X, Y, x_amax=xa, y_amax=ya)
             d = C[:32, :256].double() - ref
             err = (d.abs().max() / ref.abs().max()).item()
             rms = (d.pow(2).mean().sqrt() / ref.pow(2).mean().sqrt()).item()
-            t = timeit(lambda: gemm.gemm_tn(X, Y, out=C))
+            t = timeit(lambda: gemm.gemm_tn(X, Y, out=C, x_amax=xa, y_amax=ya))
             print(f"TN {R}x{N1}x{N2} {mode}: {t:.3f} ms {2.0 * R * N1 * N2 / t / 1e9:.1f} TF  max {err:.2e} rms {rms:.2e}", flush=True)
         del X, Y, C, ref
     _lib.get_lib().epn_set_kernel_policy(0)
