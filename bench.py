@@ -47,7 +47,8 @@ def _latest_profile(suffix):
 
 PMC_FILE = _latest_profile("pmc_per_kernel.json")                        # tools/collect_profiles.sh + pmc_summary.py
 PMC_FILES = {"cls_f32": PMC_FILE,                                        # which committed pass profiled which workload
-             "reg_bf16": _latest_profile("reg_bf16_pmc_per_kernel.json")}
+             "reg_bf16": _latest_profile("reg_bf16_pmc_per_kernel.json"),
+             "inv_bf16": _latest_profile("inv_bf16_pmc_per_kernel.json")}
 
 
 def recorded_traffic(kernel_family, pmc_file=PMC_FILE):
@@ -634,7 +635,8 @@ def measure(cfg, rank, local_rank, world, dev, first=True):
         out["config"]["dp_path"] = f"{collect}+1 all-reduce" if graph is not None else "hooks"
     if rank == 0:
         # PMC passes exist for the cls fp32 step (B=32) and the rotation network's bf16 step (B=64): their kernels' traffic
-        profiled = (not cfg.forward_only) and ((cfg.model, batch, dtype_name) in (("cls", 32, "f32"), ("reg", 64, "bf16")))
+        profiled = (not cfg.forward_only) and ((cfg.model, batch, dtype_name) in (("cls", 32, "f32"), ("reg", 64, "bf16"),
+                                                                                  ("inv", 64, "bf16")))
         pmc_file = PMC_FILES.get(f"{cfg.model}_{dtype_name}") if profiled else None
         out["roofline"], detail = roofline_of(records, prof_steps, dtype_name, pmc_file, graph is not None)
         if head:

@@ -29,6 +29,8 @@ EXPORTS = [
     "epn_pointnet_so3conv_bwd_weight_f32",
     "epn_gemm_nt_f32", "epn_gemm_nt_bf16", "epn_gemm_nt_split_workspace_bytes", "epn_gemm_nt_split_f32", "epn_gemm_tn_workspace_bytes", "epn_gemm_tn_f32", "epn_gemm_tn_split_f32", "epn_gemm_tn_bf16",
     "epn_transpose_cast", "epn_cast", "epn_gemm_tn_grouped_workspace_bytes", "epn_gemm_tn_grouped",
+    "epn_so3_basis_amax_split_f32", "epn_so3_basis_norm_amax_split_f32",
+    "epn_norm_act_pair_fwd_amax", "epn_norm_act_pair_bwd_apply_amax", "epn_norm_act_bwd_apply_amax_f32",
     "epn_absmax_f32", "epn_gemm_nt_f16x2_workspace_bytes", "epn_gemm_nt_f16x2_f32", "epn_gemm_tn_f16x2_f32", "epn_gemm_tn_grouped_f16x2",
     "epn_inter_group_bf16", "epn_inter_ungroup_bf16", "epn_intra_group_bf16", "epn_so3_basis_bf16",
     "epn_gather_rows", "epn_scatter_rows", "epn_conv1x1_c1_f32", "epn_conv1x1_c1_bwd_weight_f32",
@@ -179,6 +181,9 @@ def get_lib():
     lib.epn_so3_basis_norm_bf16.argtypes = lib.epn_so3_basis_norm_f32.argtypes
     lib.epn_so3_basis_norm_split_f32.argtypes = lib.epn_so3_basis_norm_f32.argtypes
     lib.epn_so3_basis_split_f32.argtypes = lib.epn_so3_basis_f32.argtypes
+    lib.epn_so3_basis_amax_split_f32.argtypes = [_vp, _vp, _vp, ctypes.c_longlong, _ci, _ci, _ci, _ci, _vp, _vp, _vp]
+    lib.epn_so3_basis_norm_amax_split_f32.argtypes = [_vp, _vp, _vp, ctypes.c_longlong, _ci, _ci, _ci, _vp, _vp, _ci,
+                                                      ctypes.c_longlong, _vp, _vp, _cf, _cf, _vp, _vp]
     lib.epn_inter_is_fused.argtypes = [dp]
     lib.epn_inter_is_fused.restype = _ci
     lib.epn_intra_is_fused.argtypes = [_ci, _ci, _ci, _ci]
@@ -233,6 +238,9 @@ def get_lib():
     lib.epn_norm_act_pair_bwd_reduce.argtypes = [_vp, _vp, _vp, _ci, _ll, _ci, sp, sp, _cf, _vp, _vp, _vp, _vp, _vp, _vp, _vp,
                                                  _sz, _ci, _vp]
     lib.epn_norm_act_pair_bwd_apply.argtypes = [_vp, _vp, _vp, _ci, _ll, _ci, sp, sp, _cf, _vp, _vp, _vp, _vp, _ci, _vp]
+    lib.epn_norm_act_pair_fwd_amax.argtypes = [_vp, _vp, _ci, _ll, _ci, sp, sp, _cf, _vp, _ci, _vp, _vp]
+    lib.epn_norm_act_pair_bwd_apply_amax.argtypes = [_vp, _vp, _vp, _ci, _ll, _ci, sp, sp, _cf, _vp, _vp, _vp, _vp, _ci, _vp, _vp]
+    lib.epn_norm_act_bwd_apply_amax_f32.argtypes = [_vp, _vp, _ci, _ll, _ci, _vp, _vp, _vp, _vp, _cf, _cf, _vp, _vp, _vp]
     for _n in ("epn_norm_act_pair_fwd", "epn_norm_act_pair_bwd_reduce", "epn_norm_act_pair_bwd_apply"):
         getattr(lib, _n).restype = _ci
     lib.epn_scatter_rows_add.restype = _ci

@@ -19,7 +19,27 @@ struct NormArgs {
     long long rows;
     int c, rows_per_block;
     float eps, slope, inv_rows;
+    unsigned *amax;       // optional (fp32): max |stored output| of the launch, atomicMax'ed as the bits of a non-negative float
 };
+
+// running max |v| of a lane as the bit pattern of a non-negative float (unsigned order = float order); non-finite values are
+// left out (gemm_x3.hip absmax4).  The producer-side maxima of the two-piece fp16 GEMMs' operands (gemm.h).
+__device__ __forceinline__ unsigned amax_acc4(unsigned m, const f32x4 v) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const unsigned a = __builtin_bit_cast(unsigned, v[i]) & 0x7fffffffu;
+        m = (a > m && a < 0x7f800000u) ? a : m;
+    }
+    return m;
+}
+__device__ __forceinline__ void amax_commit(unsigned m, unsigned *out) {      // one atomic per wave, only when it raises the value
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) {
+        const unsigned v = (unsigned)__shfl_xor((int)m, o, 64);
+        m = v > m ? v : m;
+    }
+    if ((threadIdx.x & 63) == 0 && m > __builtin_nontemporal_load(out)) atomicMax(out, m);
+}
 
 typedef __bf16 gbf16x4 __attribute__((ext_vector_type(4)));
 typedef float f32x2 __attribute__((ext_vector_type(2)));
@@ -289,6 +309,7 @@ __global__ __launch_bounds__(GT) void norm_act_bwd_apply_kernel(NormArgs A) {
     long long r1 = r0 + A.rows_per_block;
     r1 = r1 < A.rows ? r1 : A.rows;
     const size_t base = ((size_t)g * A.rows) * A.c + c4;
+    unsigned vmax = 0;
     for (long long r = r0 + rl; r < r1; r += rstep) {
         const size_t off = base + (size_t)r * A.c;
         const f32x4 v = ld4(static_cast<const T *>(A.x) + off);
@@ -302,7 +323,9 @@ __global__ __launch_bounds__(GT) void norm_act_bwd_apply_kernel(NormArgs A) {
             o[i] = rstd[i] * (dn - m1[i] - xh * m2[i]);
         }
         st4(static_cast<T *>(A.y) + off, o);
+        if constexpr (sizeof(T) == 4) vmax = amax_acc4(vmax, o);
     }
+    if constexpr (sizeof(T) == 4) { if (A.amax) amax_commit(vmax, A.amax); }
 }
 
 // ---- the tail of a separable block in ONE pass per direction:  y = leaky(norm_a(xa)) + leaky(norm_b(xb)),
@@ -325,6 +348,7 @@ struct NormArgs2 {
     long long rows;       // per cloud
     int c, rows_per_block;
     float slope;
+    unsigned *amax;       // optional (fp32): max |y| (fwd) / max |dx of side b| (bwd_apply): see NormArgs::amax
 };
 
 __device__ __forceinline__ void side_stats4(const NormSide &S, int c, int g, int c4, f32x4 &mean, f32x4 &rstd) {
@@ -351,6 +375,7 @@ __global__ __launch_bounds__(GT) void norm_act2_fwd_kernel(NormArgs2 A) {
     long long r1 = r0 + A.rows_per_block;
     r1 = r1 < A.rows ? r1 : A.rows;
     const size_t base = ((size_t)g * A.rows) * A.c + c4;
+    unsigned vmax = 0;
     for (long long r = r0 + rl; r < r1; r += rstep) {
         const size_t off = base + (size_t)r * A.c;
         const f32x4 va = ld4(static_cast<const T *>(A.a.x) + off);
@@ -363,7 +388,9 @@ __global__ __launch_bounds__(GT) void norm_act2_fwd_kernel(NormArgs2 A) {
             o[i] = (na > 0.0f ? na : na * A.slope) + (nb > 0.0f ? nb : nb * A.slope);
         }
         st4(static_cast<T *>(A.y) + off, o);
+        if constexpr (sizeof(T) == 4) vmax = amax_acc4(vmax, o);
     }
+    if constexpr (sizeof(T) == 4) { if (A.amax) amax_commit(vmax, A.amax); }
 }
 
 template <typename T>
@@ -438,6 +465,7 @@ __global__ __launch_bounds__(GT) void norm_act2_bwd_apply_kernel(NormArgs2 A) {
     long long r1 = r0 + A.rows_per_block;
     r1 = r1 < A.rows ? r1 : A.rows;
     const size_t base = ((size_t)g * A.rows) * A.c + c4;
+    unsigned vmax = 0;
     for (long long r = r0 + rl; r < r1; r += rstep) {
         const size_t off = base + (size_t)r * A.c;
         const f32x4 va = ld4(static_cast<const T *>(A.a.x) + off);
@@ -454,7 +482,9 @@ __global__ __launch_bounds__(GT) void norm_act2_bwd_apply_kernel(NormArgs2 A) {
         }
         if (A.a.dx) st4(static_cast<T *>(A.a.dx) + off, oa);
         if (A.b.dx) st4(static_cast<T *>(A.b.dx) + off, ob);
+        if constexpr (sizeof(T) == 4) vmax = amax_acc4(vmax, ob);
     }
+    if constexpr (sizeof(T) == 4) { if (A.amax && A.b.dx) amax_commit(vmax, A.amax); }
 }
 
 int check_norm(int groups, long long rows, int c) {
@@ -583,16 +613,26 @@ static int norm_act_bwd_reduce_any(const void *x_cl, const void *dy_cl, int grou
     return 0;
 }
 
+static int amax_prepare(float *amax, int bf16, hipStream_t st) {
+    if (!amax) return 0;
+    if (bf16) return EPN_EINVAL;             // the maximum is a by-product of the fp32 kernels only
+    EPN_HIP(hipMemsetAsync(amax, 0, sizeof(float), st));
+    return 0;
+}
+
 static int norm_act_bwd_apply_any(const void *x_cl, const void *dy_cl, int groups, long long rows, int c,
                                   const float *sums, const float *dsums, const float *gamma, const float *beta, float eps,
-                                  float slope, void *dx_cl, int bf16, epn_stream_t stream) {
+                                  float slope, void *dx_cl, int bf16, epn_stream_t stream, float *amax = nullptr) {
     int rc = check_norm(groups, rows, c);
+    if (rc) return rc;
+    rc = amax_prepare(amax, bf16, epn_stream(stream));
     if (rc) return rc;
     if (groups == 0 || rows == 0) return 0;
     if (!x_cl || !dy_cl || !sums || !dsums || !dx_cl) return EPN_ENULL;
     dim3 grid;
     NormArgs A = make_norm(rows, c, eps, slope, grid, groups);
     A.x = x_cl; A.dy = dy_cl; A.sums = sums; A.dsums = dsums; A.gamma = gamma; A.beta = beta; A.y = dx_cl;
+    A.amax = reinterpret_cast<unsigned *>(amax);
     if (bf16) EPN_LAUNCH(norm_act_bwd_apply_kernel<__bf16>, grid, dim3(GT), 0, epn_stream(stream), A);
     else EPN_LAUNCH(norm_act_bwd_apply_kernel<float>, grid, dim3(GT), 0, epn_stream(stream), A);
     EPN_CHECK_LAUNCH();
@@ -620,13 +660,16 @@ static int pair_setup(const epn_norm_pair_side *sa, const epn_norm_pair_side *sb
 }
 
 static int norm_act2_fwd_any(const void *xa, const void *xb, int b, long long rows, int c, const epn_norm_pair_side *sa,
-                             const epn_norm_pair_side *sb, float slope, void *y, int bf16, epn_stream_t stream) {
+                             const epn_norm_pair_side *sb, float slope, void *y, int bf16, epn_stream_t stream,
+                             float *amax = nullptr) {
     NormArgs2 A; dim3 grid;
     int rc = pair_setup(sa, sb, b, rows, c, slope, A, grid);
     if (rc) return rc;
+    rc = amax_prepare(amax, bf16, epn_stream(stream));
+    if (rc) return rc;
     if (b == 0 || rows == 0) return 0;
     if (!xa || !xb || !y || !sa->sums || !sb->sums) return EPN_ENULL;
-    A.a.x = xa; A.b.x = xb; A.y = y;
+    A.a.x = xa; A.b.x = xb; A.y = y; A.amax = reinterpret_cast<unsigned *>(amax);
     if (bf16) EPN_LAUNCH(norm_act2_fwd_kernel<__bf16>, grid, dim3(GT), 0, epn_stream(stream), A);
     else EPN_LAUNCH(norm_act2_fwd_kernel<float>, grid, dim3(GT), 0, epn_stream(stream), A);
     EPN_CHECK_LAUNCH();
@@ -676,13 +719,16 @@ static int norm_act2_bwd_reduce_any(const void *xa, const void *xb, const void *
 static int norm_act2_bwd_apply_any(const void *xa, const void *xb, const void *dy, int b, long long rows, int c,
                                    const epn_norm_pair_side *sa, const epn_norm_pair_side *sb, float slope,
                                    const float *dsums_a, const float *dsums_b, void *dxa, void *dxb, int bf16,
-                                   epn_stream_t stream) {
+                                   epn_stream_t stream, float *amax_b = nullptr) {
     NormArgs2 A; dim3 grid;
     int rc = pair_setup(sa, sb, b, rows, c, slope, A, grid);
+    if (rc) return rc;
+    rc = amax_prepare(amax_b, bf16, epn_stream(stream));
     if (rc) return rc;
     if (b == 0 || rows == 0) return 0;
     if (!xa || !xb || !dy || !sa->sums || !sb->sums || !dsums_a || !dsums_b) return EPN_ENULL;
     A.a.x = xa; A.b.x = xb; A.dy = dy; A.a.dsums = dsums_a; A.b.dsums = dsums_b; A.a.dx = dxa; A.b.dx = dxb;
+    A.amax = reinterpret_cast<unsigned *>(amax_b);
     if (bf16) EPN_LAUNCH(norm_act2_bwd_apply_kernel<__bf16>, grid, dim3(GT), 0, epn_stream(stream), A);
     else EPN_LAUNCH(norm_act2_bwd_apply_kernel<float>, grid, dim3(GT), 0, epn_stream(stream), A);
     EPN_CHECK_LAUNCH();
@@ -711,6 +757,30 @@ extern "C" int epn_norm_act_pair_bwd_apply(const void *xa_cl, const void *xb_cl,
                                            void *dxb_cl, int bf16, epn_stream_t stream) {
     return norm_act2_bwd_apply_any(xa_cl, xb_cl, dy_cl, b, rows, c, side_a, side_b, slope, dsums_a, dsums_b, dxa_cl, dxb_cl,
                                    bf16, stream);
+}
+
+// fp32 variants that also leave max |output| in a device scalar (zeroed by the call): the producer-side maxima of the
+// two-piece fp16 GEMMs' operands (gemm.h) -- the block output feeds the next block's grouping bound and skip convolution, the two
+// gradients are the narrow operands of the data- / weight-gradient GEMMs.  bf16 = 1: EPN_EINVAL.
+extern "C" int epn_norm_act_pair_fwd_amax(const void *xa_cl, const void *xb_cl, int b, long long rows, int c,
+                                          const epn_norm_pair_side *side_a, const epn_norm_pair_side *side_b, float slope,
+                                          void *y_cl, int bf16, float *y_amax, epn_stream_t stream) {
+    if (!y_amax) return EPN_ENULL;
+    return norm_act2_fwd_any(xa_cl, xb_cl, b, rows, c, side_a, side_b, slope, y_cl, bf16, stream, y_amax);
+}
+extern "C" int epn_norm_act_pair_bwd_apply_amax(const void *xa_cl, const void *xb_cl, const void *dy_cl, int b, long long rows,
+                                                int c, const epn_norm_pair_side *side_a, const epn_norm_pair_side *side_b,
+                                                float slope, const float *dsums_a, const float *dsums_b, void *dxa_cl,
+                                                void *dxb_cl, int bf16, float *dxb_amax, epn_stream_t stream) {
+    if (!dxb_amax) return EPN_ENULL;
+    return norm_act2_bwd_apply_any(xa_cl, xb_cl, dy_cl, b, rows, c, side_a, side_b, slope, dsums_a, dsums_b, dxa_cl, dxb_cl,
+                                   bf16, stream, dxb_amax);
+}
+extern "C" int epn_norm_act_bwd_apply_amax_f32(const float *x_cl, const float *dy_cl, int groups, long long rows, int c,
+                                               const float *sums, const float *dsums, const float *gamma, const float *beta,
+                                               float eps, float slope, float *dx_cl, float *dx_amax, epn_stream_t stream) {
+    if (!dx_amax) return EPN_ENULL;
+    return norm_act_bwd_apply_any(x_cl, dy_cl, groups, rows, c, sums, dsums, gamma, beta, eps, slope, dx_cl, 0, stream, dx_amax);
 }
 
 extern "C" int epn_bn_running_update_f32(const float *sums, double count, const float *conv_bias, float *running_mean,

@@ -38,6 +38,9 @@ struct SbArgs {
     // (glue.hip norm_act_bwd_reduce_kernel) taken from the accumulators that hold dy; nsums / ngamma / nbeta / neps /
     // nslope describe that norm and are NOT applied to the input rows in this mode
     const void *dstat_x;
+    // optional (fp32 split form): max |output| of the whole launch as the bit pattern of a non-negative float, atomicMax'ed
+    // into *amax (zeroed by the entry point) -- the scale source of the two-piece fp16 GEMMs that consume the output (gemm.h)
+    unsigned *amax;
 };
 
 // per-lane normalisation of its 4 channels: n = (v - mean) * rstd * gamma + beta, leaky (the formula of glue.hip's
@@ -495,13 +498,14 @@ __global__ __launch_bounds__(64 * SB_WAVES) __attribute__((amdgpu_waves_per_eu(2
     const int ncb = (A.c + 63) >> 6;      // c % 32 == 0: the last block of a 32 (mod 64) width is half empty (lanes x >= 8)
     const float *in = static_cast<const float *>(A.in);
     float *out = static_cast<float *>(A.out);
+    float vmax = 0.0f;                    // max |output| of this lane's tasks (A.amax)
     for (int it = 0; it < SB_TPW; ++it) {
         const long long task = ((long long)blockIdx.x * SB_WAVES + wave) * SB_TPW + it;
         // c == 32 (the first two blocks of the rotation / 3DMatch networks): a 64-channel block would leave lanes x >= 8 idle
         // (round 3: "half empty"); instead a task is TWO points, lanes x >= 8 carry the second one -- only the per-lane point
         // index of the loads, stores and statistics changes, M is the same for every column
         const bool pair = SMALL && A.pair;
-        if (task >= (pair ? (A.pts + 1) >> 1 : A.pts * ncb)) return;
+        if (task >= (pair ? (A.pts + 1) >> 1 : A.pts * ncb)) break;
         const long long pt = pair ? 2 * task + (x >> 3) : task / ncb;
         const int cb = pair ? 0 : (int)(task - pt * ncb);
         const int choff0 = pair ? 4 * (x & 7) : 64 * cb + 4 * x;
@@ -569,6 +573,14 @@ __global__ __launch_bounds__(64 * SB_WAVES) __attribute__((amdgpu_waves_per_eu(2
             if (A.dstat_x) sb_point_dstats<false>(acc, A, tab, rxs, upt, cho, pt, choff0, choff, cval, j);
             else if (A.pstats) sb_point_stats<false>(acc, A.pstats, pt, A.c, choff0, cval, j);
         } else if (A.pstats) sb_point_stats<false>(acc, A.pstats, pt, A.c, choff0, cval, j);
+        if (A.amax) {                     // rows >= na and lanes without channels hold zeros: no masking needed
+#pragma unroll
+            for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+                for (int nt = 0; nt < 4; ++nt)
+                    vmax = __builtin_fmaxf(__builtin_fmaxf(vmax, __builtin_fmaxf(__builtin_fabsf(acc[mt][nt][0]), __builtin_fabsf(acc[mt][nt][1]))),
+                                           __builtin_fmaxf(__builtin_fabsf(acc[mt][nt][2]), __builtin_fabsf(acc[mt][nt][3])));
+        }
         // acc[mt][nt][rr]: output row 16 mt + 4 j + rr, channel 4 x + nt
 #pragma unroll
         for (int mt = 0; mt < 4; ++mt)
@@ -580,6 +592,13 @@ __global__ __launch_bounds__(64 * SB_WAVES) __attribute__((amdgpu_waves_per_eu(2
                 else if (r < A.na && cval) sb_st(out + row_addr(A.out_spec, r), v);
             }
         if constexpr (SMALL) asm volatile("s_nop 4" ::: "memory");
+    }
+    if (A.amax) {                         // one atomic per wave, and only when it would raise the value seen
+#pragma unroll
+        for (int o = 32; o >= 1; o >>= 1) vmax = __builtin_fmaxf(vmax, __shfl_xor(vmax, o, 64));
+        vmax = __builtin_fminf(vmax, 3.4028235e38f);            // (an infinite output must not become the scale)
+        const unsigned m = __builtin_bit_cast(unsigned, vmax);
+        if (lane == 0 && m > __builtin_nontemporal_load(A.amax)) atomicMax(A.amax, m);
     }
 }
 
@@ -720,13 +739,19 @@ struct SbNormHost {
 
 static int so3_basis_any(const void *in, const float *M, const int32_t *blocks, long long pts, int na, int c,
                         int in_spectral, int out_spectral, void *out, int bf16, epn_stream_t stream,
-                        const SbNormHost *nh = nullptr, float *point_stats = nullptr, const void *dstat_x = nullptr) {
+                        const SbNormHost *nh = nullptr, float *point_stats = nullptr, const void *dstat_x = nullptr,
+                        float *amax_out = nullptr) {
     if (pts < 0 || na < 4 || na > 64 || (na & 3) || c < 32 || (c & 31)) return EPN_EINVAL;
     if (pts == 0) return 0;
     if (!in || !M || !blocks || !out) return EPN_ENULL;
     SbArgs A;
     A.in = in; A.M = M; A.blk = blocks; A.out = out; A.pts = pts; A.na = na; A.c = c; A.pstats = point_stats;
     A.in_spec = in_spectral; A.out_spec = out_spectral; A.dstat_x = dstat_x;
+    A.amax = reinterpret_cast<unsigned *>(amax_out);
+    if (amax_out) {
+        if (bf16 != 2) return EPN_EINVAL;       // the maximum is produced by the fp32 split-form kernel only
+        EPN_HIP(hipMemsetAsync(amax_out, 0, sizeof(float), epn_stream(stream)));
+    }
     A.nsums = nullptr; A.ngamma = A.nbeta = nullptr; A.neps = 0.f; A.nslope = 0.f; A.ninv_rows = 0.f; A.ngroups = 1;
     A.npts_per_group = pts;
     if (nh) {
@@ -767,6 +792,20 @@ extern "C" int epn_so3_basis_f32(const float *in, const float *M, const int32_t 
 extern "C" int epn_so3_basis_split_f32(const float *in, const float *M, const int32_t *blocks, long long pts, int na, int c,
                                        int in_spectral, int out_spectral, float *out, epn_stream_t stream) {
     return so3_basis_any(in, M, blocks, pts, na, c, in_spectral, out_spectral, out, 2, stream);
+}
+// ... + max |out| into the device scalar *amax_out (the scale source of the two-piece fp16 GEMMs that read `out`, gemm.h)
+extern "C" int epn_so3_basis_amax_split_f32(const float *in, const float *M, const int32_t *blocks, long long pts, int na, int c,
+                                            int in_spectral, int out_spectral, float *out, float *amax_out, epn_stream_t stream) {
+    if (!amax_out) return EPN_ENULL;
+    return so3_basis_any(in, M, blocks, pts, na, c, in_spectral, out_spectral, out, 2, stream, nullptr, nullptr, nullptr, amax_out);
+}
+extern "C" int epn_so3_basis_norm_amax_split_f32(const float *in, const float *M, const int32_t *blocks, long long pts, int na,
+                                                 int c, int out_spectral, float *out, const float *sums, int groups,
+                                                 long long pts_per_group, const float *gamma, const float *beta, float eps,
+                                                 float slope, float *amax_out, epn_stream_t stream) {
+    if (!amax_out) return EPN_ENULL;
+    const SbNormHost nh = {sums, gamma, beta, groups, pts_per_group, eps, slope};
+    return so3_basis_any(in, M, blocks, pts, na, c, 0, out_spectral, out, 2, stream, &nh, nullptr, nullptr, amax_out);
 }
 extern "C" int epn_so3_basis_bf16(const void *in, const float *M, const int32_t *blocks, long long pts, int na, int c,
                                   int in_spectral, int out_spectral, void *out, epn_stream_t stream) {

@@ -38,8 +38,11 @@ def absmax(t):
     if t.dtype != torch.float32 or not t.is_cuda:
         raise TypeError("absmax: fp32 CUDA tensor expected")
     out = torch.empty(1, dtype=torch.float32, device=t.device)
-    if t.dim() == 2 and t.stride(1) == 1:
-        rows, cols, ld = t.shape[0], t.shape[1], (t.stride(0) if t.shape[0] > 1 else t.shape[1])
+    dense = t.is_contiguous() or (t.dim() == 4 and t.is_contiguous(memory_format=torch.channels_last))
+    if dense:                              # any dense layout: the maximum does not care about the order
+        rows, cols, ld = 1, t.numel(), t.numel()
+    elif t.dim() == 2 and t.stride(1) == 1:
+        rows, cols, ld = t.shape[0], t.shape[1], t.stride(0)
     else:
         t = t.contiguous()
         rows, cols, ld = 1, t.numel(), t.numel()
@@ -55,16 +58,30 @@ def f16x2_on(t):
 def absmax_cached(t):
     """absmax(t), remembered ON the tensor object (and dropped when the tensor is written to): a tensor that is an operand of
     several GEMMs -- an output gradient feeds the data-gradient and the weight-gradient contraction, a block input the
-    grouping and the skip convolution -- is scanned once."""
-    hit = getattr(t, "_epn_amax", None)
-    if hit is not None and hit[0] == t._version:
-        return hit[1]
+    grouping and the skip convolution -- is scanned once, and a producer that knows the maximum tags its output the same way
+    (ops._tag_amax: basis change, block tail, norm backward).  A re-layout VIEW of a tagged tensor that covers all of it (what
+    autograd's view nodes hand to a 1x1 convolution's backward) has the same maximum."""
+    for cand in (t, t._base if t._base is not None and t._base.numel() == t.numel() else None):
+        hit = getattr(cand, "_epn_amax", None) if cand is not None else None
+        if hit is not None and hit[0] == cand._version:
+            return hit[1]
     a = absmax(t)
     try:
         t._epn_amax = (t._version, a)
     except (AttributeError, RuntimeError):
         pass
     return a
+
+
+def _use_amax(a):
+    """An amax scalar about to be read by a kernel on the current stream.  These 4-byte tensors are produced on one stream (a
+    block's main branch) and read on another (its skip branch, forward and backward): without record_stream the caching
+    allocator hands the block to the next 4-byte request the moment Python drops the tensor, and a later scalar overwrites it
+    under a GEMM that has not read its scale yet (found as non-finite losses at small batch sizes)."""
+    if a.dtype != torch.float32 or a.numel() != 1 or not a.is_cuda:
+        raise ValueError("amax must be a 1-element fp32 CUDA tensor")
+    a.record_stream(torch.cuda.current_stream(a.device))
+    return a.data_ptr()
 
 
 def _amax_array(amaxes):
@@ -74,9 +91,7 @@ def _amax_array(amaxes):
     arr = (ctypes.c_void_p * len(amaxes))()
     for i, a in enumerate(amaxes):
         if a is not None:
-            if a.dtype != torch.float32 or a.numel() != 1 or not a.is_cuda:
-                raise ValueError("amax must be a 1-element fp32 CUDA tensor")
-            arr[i] = a.data_ptr()
+            arr[i] = _use_amax(a)
     return arr, [a for a in amaxes if a is not None]
 
 
@@ -193,8 +208,8 @@ def gemm_tn(X, Y, out=None, x_amax=None, y_amax=None):
     ldc = out.stride(0) if N1 > 1 else N2
     if f2:
         _lib.check(lib.epn_gemm_tn_f16x2_f32(X.data_ptr(), ldx, Y.data_ptr(), ldy, out.data_ptr(), ldc, R, N1, N2,
-                                             None if x_amax is None else x_amax.data_ptr(),
-                                             None if y_amax is None else y_amax.data_ptr(), ws.data_ptr(), ws.numel(),
+                                             None if x_amax is None else _use_amax(x_amax),
+                                             None if y_amax is None else _use_amax(y_amax), ws.data_ptr(), ws.numel(),
                                              _lib.stream_of(X)), "gemm_tn_f16x2")
         return out
     _lib.check(fn(X.data_ptr(), ldx, Y.data_ptr(), ldy, out.data_ptr(), ldc, R, N1, N2, ws.data_ptr(), ws.numel(),
@@ -271,13 +286,16 @@ class MatmulNT(torch.autograd.Function):
     dA = dC @ W (NT against W^T), dW = dC^T @ A (TN, fp32)."""
 
     @staticmethod
-    def forward(ctx, A, W, col_stats=False):
+    def forward(ctx, A, W, col_stats=False, a_amax=None):
         from . import ops
         ctx.set_materialize_grads(False)   # (C, part): no zero-filled gradient for the statistics partials
         Wc = W if W.dtype == A.dtype else cast(W, A.dtype)
         ctx.save_for_backward(A, W)
         M, K, N = A.shape[0], A.shape[1], W.shape[0]
-        a_amax = absmax_cached(A) if f16x2_on(A) else None        # (shared with the weight gradient, where A is the Y operand)
+        if f16x2_on(A):                   # max|A| (or a bound the caller has): shared with the weight gradient, where A is the Y operand
+            a_amax = a_amax if a_amax is not None else absmax_cached(A)
+        else:
+            a_amax = None
         ctx.a_amax = a_amax
         if not col_stats:
             return ops._launch("conv1x1_gemm", ("nt", M, N, K), 2.0 * M * N * K, A.device, lambda: gemm_nt(A, Wc, a_amax=a_amax))
@@ -291,13 +309,13 @@ class MatmulNT(torch.autograd.Function):
     @staticmethod
     def backward(ctx, dC, _dpart=None):
         if dC is None:
-            return None, None, None
+            return None, None, None, None
         A, W = ctx.saved_tensors
         dC = dC if dC.dtype == A.dtype else dC.to(A.dtype)
         from . import ops
         dA = dW = None
         M, K, N = A.shape[0], A.shape[1], W.shape[0]
-        dc_amax = absmax(dC) if f16x2_on(dC) else None
+        dc_amax = absmax_cached(dC) if f16x2_on(dC) else None       # (tagged by the block tail's backward that produced it)
         if ctx.needs_input_grad[0]:
             Wt = transpose_cast(W, A.dtype)
             dA = ops._launch("conv1x1_gemm", ("nt", M, K, N), 2.0 * M * N * K, A.device, lambda: gemm_nt(dC, Wt, a_amax=dc_amax))
@@ -307,8 +325,8 @@ class MatmulNT(torch.autograd.Function):
         if ctx.needs_input_grad[1]:
             dW = ops._launch("conv1x1_gemm_dw", ("tn", M, N, K), 2.0 * M * N * K, A.device,
                              lambda: gemm_tn(dC, A, x_amax=dc_amax, y_amax=ctx.a_amax))
-        return dA, dW, None
+        return dA, dW, None, None
 
 
-def matmul_nt(A, W, col_stats=False):
-    return MatmulNT.apply(A, W, col_stats)
+def matmul_nt(A, W, col_stats=False, a_amax=None):
+    return MatmulNT.apply(A, W, col_stats, a_amax)

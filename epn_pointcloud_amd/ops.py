@@ -483,7 +483,7 @@ class InterSO3ConvSplitFn(torch.autograd.Function):
         gf = gW = None
         # two-piece fp16 contractions: max|dOut| once for both GEMMs it feeds (a pass over the narrow operand), max|G| as the
         # forward pass bounded it
-        go_amax = gemm.absmax(g2d) if gemm.f16x2_on(G) else None
+        go_amax = gemm.absmax_cached(g) if gemm.f16x2_on(G) else None      # (tagged by the norm backward that produced it)
         if need_w:
             gW = _launch("inter_gemm_dw", _inter_key(d), gemm_fl, G.device,
                          lambda: gemm.gemm_tn(g2d, G, x_amax=go_amax, y_amax=ctx.g_amax))
@@ -890,9 +890,29 @@ def spectral_basis(intra_idx32):
     return _BASIS_CACHE.get(intra_idx32, _make_basis)
 
 
+def _tag_amax(t, amax):
+    """Remember a producer-side max|t| on the tensor object (what gemm.absmax_cached looks for)."""
+    try:
+        t._epn_amax = (t._version, amax)
+    except (AttributeError, RuntimeError):
+        pass
+
+
 def _basis_call(lib, src, M, basis, pts, c, in_spec, out_spec, dst, kind):
     if src.dtype != dst.dtype or src.dtype not in FEATURE_DTYPES:
         raise TypeError(f"so3_basis: {src.dtype} -> {dst.dtype}")
+    if out_spec and gemm.f16x2_on(dst):
+        # a spectral buffer is the operand of two-piece fp16 GEMMs: its maximum from this kernel's accumulators, not from a
+        # pass over the 250 MB it writes
+        amax = torch.empty(1, dtype=torch.float32, device=dst.device)
+        _lib.check(_launch(kind, ("so3_basis", pts, c), 2.0 * pts * basis.na * basis.na * c, src.device,
+                           lambda: lib.epn_so3_basis_amax_split_f32(ctypes.c_void_p(src.data_ptr()), _lib.dev_ptr(M, "M"),
+                                                                    _lib.dev_ptr(basis.blocks, "blocks", torch.int32),
+                                                                    ctypes.c_longlong(pts), basis.na, c, in_spec, out_spec,
+                                                                    ctypes.c_void_p(dst.data_ptr()), amax.data_ptr(),
+                                                                    _lib.stream_of(src))), "so3_basis_amax")
+        _tag_amax(dst, amax)
+        return
     fn = _entry(lib, "so3_basis", src.dtype)
     _lib.check(_launch(kind, ("so3_basis", pts, c), 2.0 * pts * basis.na * basis.na * c, src.device,
                        lambda: fn(ctypes.c_void_p(src.data_ptr()), _lib.dev_ptr(M, "M"),
@@ -1052,7 +1072,7 @@ class _BlockGemmsFn(torch.autograd.Function):
             probs.append((A, wt, O))                                        # Bt = What^T [d*cout, d*cin]
             fl += 2.0 * pts * d * d * cin * d * cout
         # two-piece fp16 contractions: ONE maximum for the whole spectral buffer (its five slices are the operands)
-        y_amax = gemm.absmax(y) if gemm.f16x2_on(y) else None
+        y_amax = gemm.absmax_cached(y) if gemm.f16x2_on(y) else None      # (tagged by the basis change that wrote y)
         _launch("intra_gemm", ("spectral", pts, cin, cout), fl, y.device,
                 lambda: gemm.gemm_nt_grouped(probs, a_amax=None if y_amax is None else [y_amax] * len(probs)))
         ctx.y_amax = y_amax
@@ -1065,8 +1085,8 @@ class _BlockGemmsFn(torch.autograd.Function):
     def backward(ctx, gz):
         y, *whats = ctx.saved_tensors
         basis, pts, cin, cout = ctx.cfg
+        gz_amax = gemm.absmax_cached(gz) if gemm.f16x2_on(gz) else None  # (tagged by the basis change that wrote gz)
         gz = gz.contiguous()
-        gz_amax = gemm.absmax(gz) if gemm.f16x2_on(gz) else None
         gy = torch.empty_like(y) if ctx.needs_input_grad[0] else None
         gws, probs, tprobs, tidx, fl, flw = [None] * len(whats), [], [], [], 0.0, 0.0
         for bi, (d, base, wh) in enumerate(zip(basis.dims, basis.bases, whats)):
@@ -1212,9 +1232,16 @@ class NormActPairFn(torch.autograd.Function):
         gb, bb = (t.contiguous() if t is not None else None for t in (gamma_b, beta_b))
         y = empty_cl(b, c, p, a, xac.device, xac.dtype)
         sa, sb = _pair_side(sums_a, ga, ba, eps_a, inst_a), _pair_side(sums_b, gb, bb, eps_b, inst_b)
-        _lib.check(lib.epn_norm_act_pair_fwd(_cl_ptr(xac), _cl_ptr(xbc), b, rows, c, ctypes.byref(sa), ctypes.byref(sb),
-                                             float(slope), _cl_ptr(y), int(xac.dtype == torch.bfloat16),
-                                             _lib.stream_of(xac)), "norm_act_pair_fwd")
+        if gemm.f16x2_on(y):       # the block output is the next block's GEMM operand source: its maximum from this pass
+            amax = torch.empty(1, dtype=torch.float32, device=y.device)
+            _lib.check(lib.epn_norm_act_pair_fwd_amax(_cl_ptr(xac), _cl_ptr(xbc), b, rows, c, ctypes.byref(sa), ctypes.byref(sb),
+                                                      float(slope), _cl_ptr(y), 0, amax.data_ptr(), _lib.stream_of(xac)),
+                       "norm_act_pair_fwd_amax")
+            _tag_amax(y, amax)
+        else:
+            _lib.check(lib.epn_norm_act_pair_fwd(_cl_ptr(xac), _cl_ptr(xbc), b, rows, c, ctypes.byref(sa), ctypes.byref(sb),
+                                                 float(slope), _cl_ptr(y), int(xac.dtype == torch.bfloat16),
+                                                 _lib.stream_of(xac)), "norm_act_pair_fwd")
         ctx.save_for_backward(xac, xbc, sums_a, sums_b, ga, ba, gb, bb)
         ctx.cfg = (b, rows, c, bool(inst_a), bool(inst_b), float(eps_a), float(eps_b), float(slope), conv_bias_b is not None)
         ctx.mark_non_differentiable(sums_a, sums_b)
@@ -1248,12 +1275,20 @@ class NormActPairFn(torch.autograd.Function):
         dxa = torch.empty_like(xac) if ctx.needs_input_grad[0] else None
         dxb = torch.empty_like(xbc) if ctx.needs_input_grad[1] else None
         if dxa is not None or dxb is not None:
-            _lib.check(lib.epn_norm_act_pair_bwd_apply(_cl_ptr(xac), _cl_ptr(xbc), _cl_ptr(dy), b, rows, c, ctypes.byref(sa),
-                                                       ctypes.byref(sb), slope, _lib.dev_ptr(dsa, "dsums_a"),
-                                                       _lib.dev_ptr(dsb, "dsums_b"),
-                                                       _cl_ptr(dxa) if dxa is not None else ctypes.c_void_p(0),
-                                                       _cl_ptr(dxb) if dxb is not None else ctypes.c_void_p(0), bf,
-                                                       _lib.stream_of(xac)), "norm_act_pair_bwd_apply")
+            pa = _cl_ptr(dxa) if dxa is not None else ctypes.c_void_p(0)
+            pb = _cl_ptr(dxb) if dxb is not None else ctypes.c_void_p(0)
+            if dxb is not None and gemm.f16x2_on(dxb):      # side b's gradient feeds the skip convolution's backward GEMMs
+                amax = torch.empty(1, dtype=torch.float32, device=dxb.device)
+                _lib.check(lib.epn_norm_act_pair_bwd_apply_amax(_cl_ptr(xac), _cl_ptr(xbc), _cl_ptr(dy), b, rows, c, ctypes.byref(sa),
+                                                                ctypes.byref(sb), slope, _lib.dev_ptr(dsa, "dsums_a"),
+                                                                _lib.dev_ptr(dsb, "dsums_b"), pa, pb, bf, amax.data_ptr(),
+                                                                _lib.stream_of(xac)), "norm_act_pair_bwd_apply_amax")
+                _tag_amax(dxb, amax)
+            else:
+                _lib.check(lib.epn_norm_act_pair_bwd_apply(_cl_ptr(xac), _cl_ptr(xbc), _cl_ptr(dy), b, rows, c, ctypes.byref(sa),
+                                                           ctypes.byref(sb), slope, _lib.dev_ptr(dsa, "dsums_a"),
+                                                           _lib.dev_ptr(dsb, "dsums_b"), pa, pb, bf,
+                                                           _lib.stream_of(xac)), "norm_act_pair_bwd_apply")
         dcb = torch.zeros(c, **f32) if has_cb else None       # a bias the normalisation cancels: exact gradient 0
         return dxa, dxb, dga, dba, dgb, dbb, dcb, None, None, None, None, None, None, None
 
@@ -1346,13 +1381,23 @@ class NormToSpectralFn(torch.autograd.Function):
         g = gamma.contiguous() if gamma is not None else None
         bt = beta.contiguous() if beta is not None else None
         y = torch.empty(na * b * p * c, dtype=xc.dtype, device=xc.device)
-        fn = _entry(lib, "so3_basis_norm", xc.dtype)
-        _lib.check(_launch("so3_basis", ("so3_basis", b * p, c), 2.0 * b * p * na * na * c, xc.device,
-                           lambda: fn(_cl_ptr(xc), _lib.dev_ptr(basis.Ut, "M"), _lib.dev_ptr(basis.blocks, "blocks", torch.int32),
-                                      ctypes.c_longlong(b * p), na, c, 1, ctypes.c_void_p(y.data_ptr()),
-                                      _lib.dev_ptr(sums, "sums"), groups, ctypes.c_longlong(p),
-                                      _lib.dev_ptr(g, "gamma"), _lib.dev_ptr(bt, "beta"), float(eps), float(slope),
-                                      _lib.stream_of(xc))), "so3_basis_norm")
+        if gemm.f16x2_on(y):                                 # + max|y| for the two-piece GEMMs that read it (see _basis_call)
+            amax = torch.empty(1, dtype=torch.float32, device=y.device)
+            _lib.check(_launch("so3_basis", ("so3_basis", b * p, c), 2.0 * b * p * na * na * c, xc.device,
+                               lambda: lib.epn_so3_basis_norm_amax_split_f32(
+                                   _cl_ptr(xc), _lib.dev_ptr(basis.Ut, "M"), _lib.dev_ptr(basis.blocks, "blocks", torch.int32),
+                                   ctypes.c_longlong(b * p), na, c, 1, ctypes.c_void_p(y.data_ptr()), _lib.dev_ptr(sums, "sums"),
+                                   groups, ctypes.c_longlong(p), _lib.dev_ptr(g, "gamma"), _lib.dev_ptr(bt, "beta"), float(eps),
+                                   float(slope), amax.data_ptr(), _lib.stream_of(xc))), "so3_basis_norm_amax")
+            _tag_amax(y, amax)
+        else:
+            fn = _entry(lib, "so3_basis_norm", xc.dtype)
+            _lib.check(_launch("so3_basis", ("so3_basis", b * p, c), 2.0 * b * p * na * na * c, xc.device,
+                               lambda: fn(_cl_ptr(xc), _lib.dev_ptr(basis.Ut, "M"), _lib.dev_ptr(basis.blocks, "blocks", torch.int32),
+                                          ctypes.c_longlong(b * p), na, c, 1, ctypes.c_void_p(y.data_ptr()),
+                                          _lib.dev_ptr(sums, "sums"), groups, ctypes.c_longlong(p),
+                                          _lib.dev_ptr(g, "gamma"), _lib.dev_ptr(bt, "beta"), float(eps), float(slope),
+                                          _lib.stream_of(xc))), "so3_basis_norm")
         ctx.save_for_backward(xc, sums, g, bt)
         ctx.basis = basis
         ctx.cfg = (groups, rows, c, float(eps), float(slope), conv_bias is not None, (b, c, p, na))
@@ -1390,10 +1435,19 @@ class NormToSpectralFn(torch.autograd.Function):
                                                _lib.dev_ptr(dsums, "dsums"), _lib.dev_ptr(dg, "dgamma"), _lib.dev_ptr(db, "dbeta"),
                                                ws.data_ptr(), ws.numel(), _lib.stream_of(gf)), "norm_bwd_finish")
             dx = torch.empty_like(xc)
-            _lib.check(_entry(lib, "norm_act_bwd_apply", xc.dtype)(_cl_ptr(xc), _cl_ptr(gf), groups, rows, c,
-                                                                  _lib.dev_ptr(sums, "sums"), _lib.dev_ptr(dsums, "dsums"),
-                                                                  _lib.dev_ptr(g, "gamma"), _lib.dev_ptr(bt, "beta"), eps, slope,
-                                                                  _cl_ptr(dx), _lib.stream_of(gf)), "norm_act_bwd_apply")
+            if gemm.f16x2_on(dx):      # dx is the inter convolution's output gradient: the narrow operand of two backward GEMMs
+                amax = torch.empty(1, dtype=torch.float32, device=dx.device)
+                _lib.check(lib.epn_norm_act_bwd_apply_amax_f32(_cl_ptr(xc), _cl_ptr(gf), groups, rows, c,
+                                                               _lib.dev_ptr(sums, "sums"), _lib.dev_ptr(dsums, "dsums"),
+                                                               _lib.dev_ptr(g, "gamma"), _lib.dev_ptr(bt, "beta"), eps, slope,
+                                                               _cl_ptr(dx), amax.data_ptr(), _lib.stream_of(gf)),
+                           "norm_act_bwd_apply_amax")
+                _tag_amax(dx, amax)
+            else:
+                _lib.check(_entry(lib, "norm_act_bwd_apply", xc.dtype)(_cl_ptr(xc), _cl_ptr(gf), groups, rows, c,
+                                                                      _lib.dev_ptr(sums, "sums"), _lib.dev_ptr(dsums, "dsums"),
+                                                                      _lib.dev_ptr(g, "gamma"), _lib.dev_ptr(bt, "beta"), eps, slope,
+                                                                      _cl_ptr(dx), _lib.stream_of(gf)), "norm_act_bwd_apply")
             dcb = torch.zeros(c, dtype=torch.float32, device=xc.device) if has_cb else None
             return dx, dg, db, dcb, None, None, None, None, None
         _basis_call(lib, cast_feats(gy.contiguous(), xc.dtype), ctx.basis.U, ctx.basis, b * p, c, 1, 0, gf, "so3_basis")
@@ -1770,13 +1824,14 @@ class Conv1x1C1Fn(torch.autograd.Function):
         return gx, gw
 
 
-def conv1x1(x, weight, bias=None, col_stats=False):
+def conv1x1(x, weight, bias=None, col_stats=False, x_amax=None):
     """nn.Conv2d(cin, cout, 1) on a [b,c,p,a] tensor, channels-last in and out with no layout copy: one NT GEMM
     [cols, cin] x [cout, cin]^T on the zero-copy 2-D view (fp32 master weight, cast per call for bf16 features).
     bf16 widths that are only multiples of 16 run the fp32 intra GEMM kernel (single, identity anchor neighbour);
     cin = 1 (the occupancy feature of the first block) is an outer product; odd shapes go to torch.
     col_stats=True (bias must be None): returns (y, part) -- part = the block partials of y's per-channel statistics from the
-    GEMM's epilogue (sums_from_partials / norm_act_pair(part_b=...)), or None on the paths that do not produce them."""
+    GEMM's epilogue (sums_from_partials / norm_act_pair(part_b=...)), or None on the paths that do not produce them.
+    x_amax: device scalar >= max|x| when the caller has one (two-piece fp16 GEMMs, gemm.absmax)."""
     cout, cin = weight.shape[0], weight.shape[1]
     part = None
     if x.is_cuda and ((x.dtype == torch.bfloat16 and cin % 32 == 0) or (x.dtype == torch.float32 and cin % 16 == 0)):
@@ -1791,9 +1846,9 @@ def conv1x1(x, weight, bias=None, col_stats=False):
         if pad:
             w2 = torch.cat((w2, w2.new_zeros(pad, cin)), 0)
         if col_stats and not pad and bias is None:
-            y2d, part = gemm.matmul_nt(xc.permute(0, 2, 3, 1).reshape(-1, c), w2, True)
+            y2d, part = gemm.matmul_nt(xc.permute(0, 2, 3, 1).reshape(-1, c), w2, True, x_amax)
         else:
-            y2d = gemm.matmul_nt(xc.permute(0, 2, 3, 1).reshape(-1, c), w2)
+            y2d = gemm.matmul_nt(xc.permute(0, 2, 3, 1).reshape(-1, c), w2, False, x_amax)
         if pad:
             y2d = y2d[:, :cout]
         y = y2d.reshape(b, p, a, cout).permute(0, 3, 1, 2)

@@ -149,6 +149,11 @@ class FusedSeparableBlock(SeparableBlock):
         # x.feats feeds the inter convolution AND the skip branch: the convolution hands back the tensor for the second use
         # and folds that branch's gradient into its own data gradient (ops.InterSO3ConvSplitFn; EPN_SHARE_INPUT_GRAD=0: off)
         conv.share_input_grad = True
+        # two-piece fp16 GEMMs: max|x| once for both consumers of the block input (the grouped features' bound K max|x| and
+        # the skip convolution; a strided block's gathered rows are a subset: the same scalar bounds them)
+        x_amax = None
+        if x.feats.is_cuda and ops.gemm.f16x2_on(x.feats) and x.feats.shape[1] >= 16:
+            x_amax = ops.gemm.absmax_cached(ops.to_cl(x.feats))
         try:
             inter_idx, inter_w, sample_idx, y = conv(x, inter_idx, inter_w)
         finally:
@@ -169,8 +174,8 @@ class FusedSeparableBlock(SeparableBlock):
             if self.stride > 1:                                    # batched_index_select(skip, 2, sample_idx) on rows
                 sk = ops.gather_rows(sk, sample_idx)
             if pair and epi:
-                return ops.conv1x1(sk, self.skip_conv.weight, None, col_stats=True)     # (tensor, partial statistics)
-            sk = ops.conv1x1(sk, self.skip_conv.weight, None)       # the norm cancels the bias: see ops.norm_act
+                return ops.conv1x1(sk, self.skip_conv.weight, None, col_stats=True, x_amax=x_amax)   # (tensor, partial statistics)
+            sk = ops.conv1x1(sk, self.skip_conv.weight, None, x_amax=x_amax)    # the norm cancels the bias: see ops.norm_act
             return (sk, None) if pair else (ops.norm_act(sk, self.norm, conv_bias=self.skip_conv.bias), None)
 
         side = None

@@ -251,6 +251,20 @@ int epn_norm_act_pair_bwd_apply(const void *xa_cl, const void *xb_cl, const void
                                 const float *dsums_a, const float *dsums_b, void *dxa_cl, void *dxb_cl, int bf16,
                                 epn_stream_t stream);
 
+/* fp32 variants of three of the passes above that also write max |output| (of y / of dx / of side b's dx) into a device
+ * scalar, zeroed by the call: the producer-side maxima of the two-piece fp16 GEMMs that consume those tensors (see
+ * epn_gemm_nt_f16x2_f32).  bf16 = 1: EPN_EINVAL. */
+int epn_norm_act_pair_fwd_amax(const void *xa_cl, const void *xb_cl, int b, long long rows, int c,
+                               const epn_norm_pair_side *side_a, const epn_norm_pair_side *side_b, float slope, void *y_cl,
+                               int bf16, float *y_amax, epn_stream_t stream);
+int epn_norm_act_pair_bwd_apply_amax(const void *xa_cl, const void *xb_cl, const void *dy_cl, int b, long long rows, int c,
+                                     const epn_norm_pair_side *side_a, const epn_norm_pair_side *side_b, float slope,
+                                     const float *dsums_a, const float *dsums_b, void *dxa_cl, void *dxb_cl, int bf16,
+                                     float *dxb_amax, epn_stream_t stream);
+int epn_norm_act_bwd_apply_amax_f32(const float *x_cl, const float *dy_cl, int groups, long long rows, int c,
+                                    const float *sums, const float *dsums, const float *gamma, const float *beta, float eps,
+                                    float slope, float *dx_cl, float *dx_amax, epn_stream_t stream);
+
 /* replaces vgtk.cuda.grouping.initial_anchor_query (vgtk/vgtk/cuda/grouping_cuda.cpp:138-158, kernel
  * grouping_cuda_kernel.cu:116-167; only consumer: KernelPropagation, vgtk/vgtk/so3conv/modules.py:57-119).
  *   centers f32[b][3][nc]   xyz f32[m][3] (fragment points, shared by the batch)   kernel_points f32[ks][na][3]
@@ -575,6 +589,15 @@ int epn_gemm_tn_grouped(int bf16, int nprob, const epn_gemm_tn_problem *probs, v
  * makes that pass itself into its workspace.  Nothing is synchronised with the host; capturable into a HIP graph.
  * `a_amax` / `x_amax` / `y_amax`: arrays of nprob device pointers (entries may be NULL), or NULL.
  * Workspace: epn_gemm_nt_f16x2_workspace_bytes; epn_gemm_tn_workspace_bytes(3, ...) / epn_gemm_tn_grouped_workspace_bytes(3, ...). */
+/* The anchor basis change in the fp32 split form + max |out| into the device scalar *amax_out (zeroed by the call): the
+ * producer-side maximum of the spectral buffers, so that the two-piece GEMMs that read them need no pass of their own.
+ * Arguments as epn_so3_basis_split_f32 / epn_so3_basis_norm_split_f32. */
+int epn_so3_basis_amax_split_f32(const float *in, const float *M, const int32_t *blocks, long long pts, int na, int c,
+                                 int in_spectral, int out_spectral, float *out, float *amax_out, epn_stream_t stream);
+int epn_so3_basis_norm_amax_split_f32(const float *in, const float *M, const int32_t *blocks, long long pts, int na, int c,
+                                      int out_spectral, float *out, const float *sums, int groups, long long pts_per_group,
+                                      const float *gamma, const float *beta, float eps, float slope, float *amax_out,
+                                      epn_stream_t stream);
 int epn_absmax_f32(const float *src, long long ld, long long rows, long long cols, float *out, epn_stream_t stream);
 size_t epn_gemm_nt_f16x2_workspace_bytes(int nprob, const epn_gemm_nt_problem *probs);
 int epn_gemm_nt_f16x2_f32(int nprob, const epn_gemm_nt_problem *probs, const float *const *a_amax, void *workspace,

@@ -19,5 +19,5 @@ grep -v "^[WE]2026" $OUT/stats.log | tail -1 > $OUT/bench_under_rocprof.json
 # summarise on the box and drop the raw traces (gpurun copies back at most 64 MiB)
 python $R/tools/rocprof_summary.py $(find $OUT/stats -name "*.db" | head -1) $OUT/kernel_stats.csv
 python $R/tools/pmc_summary.py $OUT $OUT/pmc_per_kernel.json
-rm -rf $OUT/stats $OUT/pmc_*/
+rm -rf $OUT/stats $OUT/pmc_*/ $OUT/pmc_*.log
 ls $OUT

@@ -11,6 +11,8 @@ cd $R
 bash tools/collect_profiles.sh $TAG > $OUT/collect.log 2>&1
 EPN_BENCH_ARGS="--model reg --dtype bf16" bash tools/collect_profiles.sh ${TAG}_reg > $OUT/collect_reg.log 2>&1
 for f in kernel_stats.csv pmc_per_kernel.json bench_under_rocprof.json; do cp gpurun_out/${TAG}_reg/$f $OUT/reg_bf16_$f; done
+EPN_BENCH_ARGS="--model inv --dtype bf16" bash tools/collect_profiles.sh ${TAG}_inv > $OUT/collect_inv.log 2>&1
+for f in kernel_stats.csv pmc_per_kernel.json; do cp gpurun_out/${TAG}_inv/$f $OUT/inv_bf16_$f; done; rm -rf gpurun_out/${TAG}_inv
 bash tools/replay_profile.sh ${TAG}_replay > $OUT/replay.log 2>&1
 cp gpurun_out/${TAG}_replay/per_replay.csv $OUT/per_replay_cls.csv
 # the driver's own command form first: ONE stdout line (< 3 KB) + the complete record in the detail file

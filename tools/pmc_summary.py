@@ -24,6 +24,13 @@ def short(n):
 
 root, out = sys.argv[1], sys.argv[2]
 res = {}
+# how many steps the profiled process ran: bench.py prints "[bench] compute_calls N" (every eager / captured / profiled step)
+steps = None
+for log in sorted(glob.glob(os.path.join(root, "pmc_*.log"))) + sorted(glob.glob(os.path.join(root, "stats.log"))):
+    m = re.findall(r"\[bench\] compute_calls (\d+)", open(log, errors="replace").read())
+    if m:
+        steps = int(m[-1])
+        break
 for d in sorted(glob.glob(os.path.join(root, "pmc_*"))):
     f = os.path.join(d, "p_counter_collection.csv")
     if not os.path.exists(f):
@@ -48,5 +55,7 @@ for k, e in res.items():
         for c in ("SQ_WAIT_ANY", "SQ_WAIT_INST_ANY", "SQ_ACTIVE_INST_ANY"):
             if c in e:
                 e[c + "_frac"] = e[c] / e["SQ_WAVE_CYCLES"]
+if steps:
+    res["_meta"] = {"step_equivalents": steps, "note": "compute() calls of the profiled bench process (warm-up, capture, timed, profiled)"}
 json.dump(res, open(out, "w"), indent=1, sort_keys=True)
 print(f"{len(res)} kernels -> {out}")
