@@ -129,6 +129,7 @@ int launch_gemm_nt_x3(GemmNtBatch &B, void *ws, size_t ws_bytes, hipStream_t st,
 size_t gemm_nt_f2_workspace(const GemmNtBatch &B);
 // max |x| of a strided matrix into a device scalar (memset + one pass)
 int launch_absmax(const float *src, long long ld, long long rows, long long cols, float *out, hipStream_t st);
+int launch_scale_scalar(float *v, float factor, hipStream_t st);
 int launch_gemm_tn(GemmTnArgs &G, int dtype, hipStream_t st);
 // grouped: plans tiles / splits for all problems (balanced K steps per workgroup), carves `ws` into the partial slabs
 int launch_gemm_tn_batch(GemmTnBatch &B, int dtype, void *ws, size_t ws_bytes, hipStream_t st);

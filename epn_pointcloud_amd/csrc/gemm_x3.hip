@@ -441,6 +441,16 @@ size_t gemm_nt_f2_workspace(const GemmNtBatch &B) {     // two-piece form: [a_am
     return n;
 }
 
+namespace {
+__global__ void scale_scalar_kernel(float *v, float f) { *v *= f; }
+}  // namespace
+int launch_scale_scalar(float *v, float factor, hipStream_t st) {       // *v *= factor (a bound derived from a maximum)
+    if (!v) return EPN_ENULL;
+    EPN_LAUNCH_AUX(scale_scalar_kernel, dim3(1), dim3(1), 0, st, v, factor);
+    EPN_CHECK_LAUNCH();
+    return 0;
+}
+
 int launch_absmax(const float *src, long long ld, long long rows, long long cols, float *out, hipStream_t st) {
     if (!out) return EPN_ENULL;
     EPN_HIP(hipMemsetAsync(out, 0, sizeof(float), st));

@@ -2,8 +2,11 @@
 //
 // replaces  InterSO3Conv.forward (vgtk/vgtk/so3conv/modules.py:157-174: L.inter_so3conv_grouping + BasicSO3Conv matmul)
 //           and the autograd transposes torch derives from it -- the same boundary as epn_inter_so3conv_{fwd,bwd_*}_f32,
-//           but on the kernel chain the benchmark times: packed grouping -> split-form (3 x bf16) / bf16 GEMM ->
-//           (backward) weight-gradient GEMM, data-gradient GEMM, LDS-pre-reduced transpose of the grouping.
+//           but on the kernel chain the benchmark times: packed grouping -> two-piece fp16 (fp32 features) / bf16 GEMM ->
+//           (backward) weight-gradient GEMM, data-gradient GEMM, LDS-pre-reduced transpose of the grouping.  fp32: the
+//           GEMMs' scales come from device maxima exactly as ops.InterSO3ConvSplitFn supplies them -- K max|feats| bounds
+//           the grouped features (kept in the last 256 bytes of `saved` for the backward pass), max|grad_out| is scanned
+//           once for the two GEMMs it feeds.
 // Nothing new is computed here: every step is one of this library's public entry points, called in the order
 // ops.InterSO3ConvSplitFn calls them, on slices of the caller's two buffers (`saved`: the grouped features kept from forward
 // to backward; `workspace`: scratch of one call).  A host that binds the pybind-sized surface of the reference
@@ -12,6 +15,7 @@
 
 #include "../../include/epn_so3conv.h"
 #include "conv_internal.h"
+#include "gemm.h"
 
 namespace {
 
@@ -50,15 +54,21 @@ int make_plan(const epn_inter_desc *d, int bf16, SplitPlan &P) {
     epn_gemm_nt_problem fw = nt_problem(nullptr, nullptr, nullptr, (long long)P.cols, d->cout, (int)P.ck);
     epn_gemm_nt_problem dg = nt_problem(nullptr, nullptr, nullptr, (long long)P.cols, (int)P.ck, d->cout);
     P.f_wd = wbytes;
-    P.f_gemm = bf16 ? 0 : rnd256(epn_gemm_nt_split_workspace_bytes(1, &fw));
+    P.f_gemm = bf16 ? 0 : rnd256(epn_gemm_nt_f16x2_workspace_bytes(1, &fw));
     P.f_total = P.grp_ws + P.f_wd + P.f_gemm;
     P.b_wt = wbytes;
     P.b_dg = rnd256(P.cols * P.ck * P.esz);
     P.b_gw = rnd256((size_t)d->cout * P.ck * sizeof(float));
-    P.b_nt = bf16 ? 0 : rnd256(epn_gemm_nt_split_workspace_bytes(1, &dg));
-    P.b_tn = rnd256(epn_gemm_tn_workspace_bytes(bf16 ? 1 : 2, (long long)P.cols, d->cout, (int)P.ck));
+    P.b_nt = bf16 ? 0 : rnd256(epn_gemm_nt_f16x2_workspace_bytes(1, &dg)) + 256;      // + the max|grad_out| slot
+    P.b_tn = rnd256(epn_gemm_tn_workspace_bytes(bf16 ? 1 : 3, (long long)P.cols, d->cout, (int)P.ck));
     P.b_total = P.grp_ws + P.b_wt + P.b_dg + P.b_gw + P.b_nt + P.b_tn;
     return 0;
+}
+
+// fp32: the grouped features + a 256-byte tail holding their maximum's bound (device scalar) for the backward GEMM
+size_t saved_need(const SplitPlan &P, int bf16) { return rnd256(P.cols * P.ck * P.esz) + (bf16 ? 0 : 256); }
+float *saved_amax(const SplitPlan &P, const void *saved) {
+    return reinterpret_cast<float *>(static_cast<char *>(const_cast<void *>(saved)) + rnd256(P.cols * P.ck * P.esz));
 }
 
 int forward(const epn_inter_desc *d, const void *feats_cl, const float *W, void *out_cl, float *out_col_stats, void *saved,
@@ -68,7 +78,7 @@ int forward(const epn_inter_desc *d, const void *feats_cl, const float *W, void 
     if (rc) return rc;
     if (P.cols == 0) return 0;
     if (!feats_cl || !W || !out_cl || !saved) return EPN_ENULL;
-    if (saved_bytes < P.cols * P.ck * P.esz) return EPN_EWORKSPACE;
+    if (saved_bytes < saved_need(P, bf16)) return EPN_EWORKSPACE;
     if (!workspace || workspace_bytes < P.f_total) return EPN_EWORKSPACE;
     char *ws = static_cast<char *>(workspace);
     void *grp_ws = ws;
@@ -96,7 +106,15 @@ int forward(const epn_inter_desc *d, const void *feats_cl, const float *W, void 
     // 3. out = G W^T (a12: so3conv/modules.py:48-55)
     epn_gemm_nt_problem p = nt_problem(saved, Wop, out_cl, (long long)P.cols, d->cout, (int)P.ck);
     p.col_stats = (P.cols % 32 == 0) ? out_col_stats : nullptr;
-    return bf16 ? epn_gemm_nt_bf16(1, &p, 0, stream) : epn_gemm_nt_split_f32(1, &p, gemm_ws, P.f_gemm, stream);
+    if (bf16) return epn_gemm_nt_bf16(1, &p, 0, stream);
+    // two-piece fp16 form: |G| <= K max|feats| (0 <= w <= 1) -- a pass over the 24 x smaller feature tensor, not over G
+    float *g_amax = saved_amax(P, saved);
+    const long long nf = (long long)d->b * d->p1 * d->na * d->cin;
+    rc = epn::launch_absmax(static_cast<const float *>(feats_cl), nf, 1, nf, g_amax, (hipStream_t)stream);
+    if (!rc) rc = epn::launch_scale_scalar(g_amax, (float)d->nn, (hipStream_t)stream);
+    if (rc) return rc;
+    const float *am[1] = {g_amax};
+    return epn_gemm_nt_f16x2_f32(1, &p, am, gemm_ws, P.f_gemm, stream);
 }
 
 int backward(const epn_inter_desc *d, const void *grad_out_cl, const float *W, const void *saved, size_t saved_bytes,
@@ -112,7 +130,7 @@ int backward(const epn_inter_desc *d, const void *grad_out_cl, const float *W, c
             rc = (int)hipMemsetAsync(grad_feats_cl, 0, sizeof(float) * (size_t)d->b * d->p1 * d->na * d->cin, (hipStream_t)stream);
         return rc;
     }
-    if (saved_bytes < P.cols * P.ck * P.esz) return EPN_EWORKSPACE;
+    if (saved_bytes < saved_need(P, bf16)) return EPN_EWORKSPACE;
     if (!workspace || workspace_bytes < P.b_total) return EPN_EWORKSPACE;
     char *ws = static_cast<char *>(workspace);
     void *grp_ws = ws;
@@ -121,14 +139,21 @@ int backward(const epn_inter_desc *d, const void *grad_out_cl, const float *W, c
     float *gWp = reinterpret_cast<float *>(ws + P.grp_ws + P.b_wt + P.b_dg);
     void *nt_ws = ws + P.grp_ws + P.b_wt + P.b_dg + P.b_gw;
     void *tn_ws = ws + P.grp_ws + P.b_wt + P.b_dg + P.b_gw + P.b_nt;
+    float *go_amax = nullptr;                   // fp32: max|grad_out|, once for both GEMMs it feeds (last 256 bytes of the NT scratch)
+    if (!bf16) {
+        go_amax = reinterpret_cast<float *>(static_cast<char *>(nt_ws) + P.b_nt - 256);
+        const long long ng = (long long)P.cols * d->cout;
+        rc = epn::launch_absmax(static_cast<const float *>(grad_out_cl), ng, 1, ng, go_amax, (hipStream_t)stream);
+        if (rc) return rc;
+    }
     if (grad_W) {
         // dW = dOut^T G (contraction over the b p2 na columns, deterministic split); against packed G: columns un-permuted
         float *target = P.packed ? gWp : grad_W;
         rc = bf16 ? epn_gemm_tn_bf16(grad_out_cl, d->cout, saved, (long long)P.ck, target, (long long)P.ck, (long long)P.cols,
                                      d->cout, (int)P.ck, tn_ws, P.b_tn, stream)
-                  : epn_gemm_tn_split_f32(static_cast<const float *>(grad_out_cl), d->cout, static_cast<const float *>(saved),
-                                          (long long)P.ck, target, (long long)P.ck, (long long)P.cols, d->cout, (int)P.ck, tn_ws,
-                                          P.b_tn, stream);
+                  : epn_gemm_tn_f16x2_f32(static_cast<const float *>(grad_out_cl), d->cout, static_cast<const float *>(saved),
+                                          (long long)P.ck, target, (long long)P.ck, (long long)P.cols, d->cout, (int)P.ck,
+                                          go_amax, saved_amax(P, saved), tn_ws, P.b_tn, stream);
         if (rc) return rc;
         if (P.packed) rc = epn_inter_unpack_weight_grad_f32(gWp, d->cout, d->cin, d->ks, grad_W, stream);
         if (rc) return rc;
@@ -138,7 +163,8 @@ int backward(const epn_inter_desc *d, const void *grad_out_cl, const float *W, c
         rc = epn_transpose_cast(W, Wt, d->cout, (int)P.ck, 0, bf16, stream);
         if (rc) return rc;
         epn_gemm_nt_problem p = nt_problem(grad_out_cl, Wt, dG, (long long)P.cols, (int)P.ck, d->cout);
-        rc = bf16 ? epn_gemm_nt_bf16(1, &p, 0, stream) : epn_gemm_nt_split_f32(1, &p, nt_ws, P.b_nt, stream);
+        const float *am[1] = {go_amax};
+        rc = bf16 ? epn_gemm_nt_bf16(1, &p, 0, stream) : epn_gemm_nt_f16x2_f32(1, &p, am, nt_ws, P.b_nt - 256, stream);
         if (rc) return rc;
         // transpose of the grouping: scatter pre-reduced in LDS, one fp32 atomic per distinct destination (a17)
         if (bf16) rc = accumulate ? epn_inter_ungroup_acc_bf16(d, dG, grad_feats_cl, grp_ws, P.grp_ws, stream)
@@ -159,7 +185,7 @@ extern "C" int epn_inter_split_ok(const epn_inter_desc *d) {
 extern "C" size_t epn_inter_split_saved_bytes(const epn_inter_desc *d, int bf16) {
     SplitPlan P;
     if (make_plan(d, bf16, P)) return 0;
-    return P.cols * P.ck * P.esz;
+    return saved_need(P, bf16);
 }
 
 extern "C" size_t epn_inter_split_workspace_bytes(const epn_inter_desc *d, int bf16, int backward_pass) {
