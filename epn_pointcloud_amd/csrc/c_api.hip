@@ -125,8 +125,10 @@ extern "C" size_t epn_inter_workspace_bytes(const epn_inter_desc *d) {
     return w.total_floats * sizeof(float);
 }
 
+// need_rk: the [na][ks][3] rotated-kernel table of the generic / cin = 1 kernels; the MFMA kernels read the [na][32][4] table
+// only, which launch_inter_tables_mfma derives from the anchors itself (one table launch per call instead of two)
 static int prep(const epn_inter_desc *d, void *workspace, size_t bytes, bool need_big, InterWs &ws, float *&base,
-                hipStream_t st) {
+                hipStream_t st, bool need_rk = true) {
     int rc = check_desc(d);
     if (rc) return rc;
     ws = inter_ws(d);
@@ -134,7 +136,7 @@ static int prep(const epn_inter_desc *d, void *workspace, size_t bytes, bool nee
                                 : ws.total_floats - ws.big_off;
     if (!workspace || bytes < (ws.big_off + big) * sizeof(float)) return EPN_EWORKSPACE;
     base = static_cast<float *>(workspace);
-    if (!d->dense_w) {
+    if (!d->dense_w && need_rk) {
         rc = launch_rk_table(d, base + ws.rk_off, st);
         if (rc) return rc;
     }
@@ -156,7 +158,7 @@ extern "C" int epn_inter_so3conv_fwd_f32(const epn_inter_desc *d, const float *f
     InterWs ws;
     float *base = nullptr;
     const bool mf = d && use_mfma(d);
-    int rc = prep(d, workspace, workspace_bytes, !mf, ws, base, st);
+    int rc = prep(d, workspace, workspace_bytes, !mf, ws, base, st, !mf);
     if (rc) return rc;
     if (!feats_cl || !W || !out_cl) return EPN_ENULL;
     if (d->b == 0 || d->p2 == 0) return 0;
@@ -209,7 +211,7 @@ extern "C" int epn_inter_so3conv_bwd_data_f32(const epn_inter_desc *d, const flo
     InterWs ws;
     float *base = nullptr;
     const bool mf = d && use_mfma(d);
-    int rc = prep(d, workspace, workspace_bytes, !mf, ws, base, st);
+    int rc = prep(d, workspace, workspace_bytes, !mf, ws, base, st, !mf);
     if (rc) return rc;
     if (!grad_feats_cl) return EPN_ENULL;
     EPN_HIP(hipMemsetAsync(grad_feats_cl, 0, sizeof(float) * (size_t)d->b * d->p1 * d->na * d->cin, st));
@@ -233,7 +235,7 @@ extern "C" int epn_inter_so3conv_bwd_weight_f32(const epn_inter_desc *d, const f
     InterWs ws;
     float *base = nullptr;
     const bool mf = d && use_mfma(d);
-    int rc = prep(d, workspace, workspace_bytes, !mf, ws, base, st);
+    int rc = prep(d, workspace, workspace_bytes, !mf, ws, base, st, !mf);
     if (rc) return rc;
     if (!grad_W) return EPN_ENULL;
     EPN_HIP(hipMemsetAsync(grad_W, 0, sizeof(float) * (size_t)d->cout * d->cin * d->ks, st));
@@ -261,14 +263,14 @@ extern "C" size_t epn_inter_group_workspace_bytes(const epn_inter_desc *d) {
 }
 
 static int prep_tables(const epn_inter_desc *d, void *workspace, size_t bytes, InterWs &ws, float *&base,
-                       hipStream_t st) {
+                       hipStream_t st, bool need_rk = true) {
     int rc = check_desc(d);
     if (rc) return rc;
     if (d->dense_w) return EPN_EINVAL;
     ws = inter_ws(d);
     if (!workspace || bytes < ws.big_off * sizeof(float)) return EPN_EWORKSPACE;
     base = static_cast<float *>(workspace);
-    return launch_rk_table(d, base + ws.rk_off, st);
+    return need_rk ? launch_rk_table(d, base + ws.rk_off, st) : 0;
 }
 
 // ---- on-chip form: grouping fused into the weight contraction as its A-tile producer (inter_fx.hip)
@@ -291,7 +293,7 @@ static int inter_onchip_fwd(const epn_inter_desc *d, const void *feats_cl, const
     if (workspace_bytes < epn_inter_onchip_workspace_bytes(d, bf16)) return EPN_EWORKSPACE;
     InterWs ws;
     float *base = nullptr;
-    rc = prep_tables(d, workspace, workspace_bytes, ws, base, st);
+    rc = prep_tables(d, workspace, workspace_bytes, ws, base, st, false);
     if (rc) return rc;
     if (d->b == 0 || d->p2 == 0) return 0;
     if (!feats_cl || !W || !out_cl) return EPN_ENULL;
@@ -315,7 +317,7 @@ static int inter_group_any(const epn_inter_desc *d, const void *feats_cl, void *
     hipStream_t st = epn_stream(stream);
     InterWs ws;
     float *base = nullptr;
-    int rc = prep_tables(d, workspace, workspace_bytes, ws, base, st);
+    int rc = prep_tables(d, workspace, workspace_bytes, ws, base, st, !(d && inter_group_mfma_ok(d) && !force_generic()));
     if (rc) return rc;
     if (d->b == 0 || d->p2 == 0) return 0;
     if (!feats_cl || !grouped) return EPN_ENULL;
@@ -333,7 +335,7 @@ static int inter_ungroup_any(const epn_inter_desc *d, const void *grad_grouped, 
     hipStream_t st = epn_stream(stream);
     InterWs ws;
     float *base = nullptr;
-    int rc = prep_tables(d, workspace, workspace_bytes, ws, base, st);
+    int rc = prep_tables(d, workspace, workspace_bytes, ws, base, st, !(d && inter_group_mfma_ok(d) && !force_generic()));
     if (rc) return rc;
     if (!grad_feats_cl) return EPN_ENULL;
     if (!accumulate)
@@ -432,7 +434,7 @@ static int inter_ungroup_det_any(const epn_inter_desc *d, const void *grad_group
     hipStream_t st = epn_stream(stream);
     InterWs ws;
     float *base = nullptr;
-    int rc = prep_tables(d, workspace, workspace_bytes, ws, base, st);
+    int rc = prep_tables(d, workspace, workspace_bytes, ws, base, st, false);
     if (rc) return rc;
     if (!inter_group_mfma_ok(d) || d->na < 16 || (d->na * d->cin) % 4) return EPN_EINVAL;
     if (!grad_feats_cl) return EPN_ENULL;

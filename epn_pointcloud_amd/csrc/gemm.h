@@ -16,7 +16,7 @@ struct GemmNtProb {        // C[M][N] = A[M][K] . Bt[N][K]^T
     unsigned ntile;        // its tiles; workgroups tile0 + ntile .. next tile0 are padding
     const void *Bp;        // split GEMM (gemm_x3.hip): the three bf16 planes [3][N][K] of Bt, filled by its launcher
     float *stats;          // optional: per-column (sum, sum of squares) of every 32-row block of C, [M/32][N][2] (M % 32 == 0)
-    const float *a_amax, *b_amax;   // two-piece fp16 form (gemm_x3.hip, NPL = 2): device scalars max|A|, max|Bt| -> power-of-two scales
+    const float *a_amax, *b_amax;   // two-piece fp16 form (gemm_x3.hip, NPL = 2): device scalar max|A|; b_amax[n] = max|Bt[n][:]| per weight row (filled by the launcher) -> power-of-two scales
 };
 struct GemmNtBatch {
     int nprob;

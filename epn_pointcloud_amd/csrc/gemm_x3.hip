@@ -98,28 +98,50 @@ __global__ void split_planes_batch_kernel(SplitBatch S) {
     }
 }
 
-// two-piece fp16 form (gemm.h): the weights of every problem -> planes[2][N][K] (fp16), scaled by the power of two that
-// puts max|W| (device scalar) at 2^14
+// two-piece fp16 form (gemm.h): the weights of every problem -> planes[2][N][K] (fp16), every ROW n scaled by the power of two
+// that puts max|W[n][:]| at 2^14.  A weight row is one output column of the NT product, so its scale is undone per column in
+// the GEMM's epilogue (rowmax[n] is what the kernel reads); the row's maximum is taken by the wave that splits it -- one launch
+// per grouped GEMM where a tensor-wide scale needed a memset, a reduction pass and the split (three dependent launches of
+// 6-9 us each per weight, 94 weights per classification step), and a row of small weights keeps its full 22 bits.
+// Non-finite elements are left out of the maximum (they poison their own products only, as in an fp32 GEMM).
 struct Split2Batch {
     const float *W[GEMM_MAX_PROB];
     unsigned *planes[GEMM_MAX_PROB];
-    const float *amax[GEMM_MAX_PROB];
+    float *rowmax[GEMM_MAX_PROB];
     long long ldw[GEMM_MAX_PROB];
     int N[GEMM_MAX_PROB], K[GEMM_MAX_PROB];
 };
-__global__ void split_planes2_batch_kernel(Split2Batch S) {
+__global__ __launch_bounds__(256) void split_rows2_batch_kernel(Split2Batch S) {
     const int q = blockIdx.y;
     const float *__restrict__ W = S.W[q];
     unsigned *__restrict__ planes = S.planes[q];
     const int N = S.N[q], k2 = S.K[q] >> 1;
     const size_t plane = (size_t)N * k2;
-    const float sc = f2_scale_of(*S.amax[q]);
-    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < (long long)N * k2; i += (long long)gridDim.x * blockDim.x) {
-        const int n = (int)(i / k2), k = 2 * (int)(i % k2);
-        unsigned h, l;
-        f2_split_pair(W[n * S.ldw[q] + k], W[n * S.ldw[q] + k + 1], sc, h, l);
-        planes[i] = h;
-        planes[plane + i] = l;
+    const int lane = threadIdx.x & 63;
+    for (int n = blockIdx.x * 4 + (threadIdx.x >> 6); n < N; n += gridDim.x * 4) {      // wave-uniform
+        const float *__restrict__ row = W + (size_t)n * S.ldw[q];
+        unsigned m = 0;
+        for (int i = lane; i < k2; i += 64) {
+            const float2 v = make_float2(row[2 * i], row[2 * i + 1]);
+            const unsigned a = __builtin_bit_cast(unsigned, v.x) & 0x7fffffffu, b = __builtin_bit_cast(unsigned, v.y) & 0x7fffffffu;
+            m = (a > m && a < 0x7f800000u) ? a : m;
+            m = (b > m && b < 0x7f800000u) ? b : m;
+        }
+#pragma unroll
+        for (int o = 32; o >= 1; o >>= 1) {
+            const unsigned v = (unsigned)__shfl_xor((int)m, o, 64);
+            m = v > m ? v : m;
+        }
+        const float amax = __builtin_bit_cast(float, m);
+        const float sc = f2_scale_of(amax);
+        if (lane == 0) S.rowmax[q][n] = amax;
+        for (int i = lane; i < k2; i += 64) {
+            const float2 v = make_float2(row[2 * i], row[2 * i + 1]);
+            unsigned h, l;
+            f2_split_pair(v.x, v.y, sc, h, l);
+            planes[(size_t)n * k2 + i] = h;
+            planes[plane + (size_t)n * k2 + i] = l;
+        }
     }
 }
 
@@ -135,13 +157,23 @@ __device__ __forceinline__ unsigned absmax4(unsigned m, const u32x4 v) {
     }
     return m;
 }
-__device__ __forceinline__ void absmax_finish(unsigned m, unsigned *out) {
+// one atomic per WORKGROUP, and only when it would raise the value: 8192 waves hammering one address made the pass over a 126 MB
+// operand take 105 us (1.2 TB/s) -- the maximum is monotonic, so a stale read only costs an atomic that changes nothing
+__device__ __forceinline__ void absmax_finish(unsigned m, unsigned *out) {      // blockDim.x == 256
+    __shared__ unsigned red[4];
 #pragma unroll
     for (int o = 32; o >= 1; o >>= 1) {
         const unsigned v = (unsigned)__shfl_xor((int)m, o, 64);
         m = v > m ? v : m;
     }
-    if ((threadIdx.x & 63) == 0 && m) atomicMax(out, m);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = m;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        m = red[0];
+#pragma unroll
+        for (int w = 1; w < 4; ++w) m = red[w] > m ? red[w] : m;
+        if (m > __atomic_load_n(out, __ATOMIC_RELAXED)) atomicMax(out, m);
+    }
 }
 __global__ __launch_bounds__(256) void absmax_flat_kernel(const u32x4 *__restrict__ src, long long n4, unsigned *__restrict__ out) {
     unsigned m = 0;
@@ -351,14 +383,18 @@ __global__ __launch_bounds__(64 * WGM * WGN) void gemm_nt_x3_kernel(GemmNtBatch 
 
     // ---- epilogue: D[row = (r&3) + 8 (r>>2) + 4 lj][col = li]   (as gemm_nt_kernel)
     float *__restrict__ C = static_cast<float *>(P.C);
-    if constexpr (NPL == 2) {                       // undo the operand scales: two exact power-of-two multiplies
-        const float ua = f2_inverse(a_scale), ub = f2_inverse(f2_scale_of(*P.b_amax));
+    if constexpr (NPL == 2) {                       // undo the operand scales: one exact power-of-two multiply per value
+        const float ua = f2_inverse(a_scale);
 #pragma unroll
-        for (int i = 0; i < TM; ++i)
+        for (int j = 0; j < TN; ++j) {              // the weights are scaled per row = per output column (split_rows2_batch_kernel)
+            int n = n0 + (wn * TN + j) * 32 + li;
+            n = n < P.N ? n : P.N - 1;
+            const float u = ua * f2_inverse(f2_scale_of(P.b_amax[n]));     // 2^-a 2^-b: a, b in [-113, 14] -- exact down to 2^-126, flushed below (as the product would be)
 #pragma unroll
-            for (int j = 0; j < TN; ++j)
+            for (int i = 0; i < TM; ++i)
 #pragma unroll
-                for (int r = 0; r < 16; ++r) acc[i][j][r] = acc[i][j][r] * ua * ub;
+                for (int r = 0; r < 16; ++r) acc[i][j][r] *= u;
+        }
     }
     if (P.stats) nt_col_stats<TM, TN, float>(acc, P.stats, P.M, P.N, m0 + wm * TM * 32, n0 + wn * TN * 32, li, lj);
     if (m0 + BM <= P.M && n0 + BN <= P.N && (long long)BM * P.ldc < (1LL << 30)) {
@@ -435,9 +471,13 @@ size_t gemm_nt_x3_workspace(const GemmNtBatch &B) {
     return n;
 }
 
-size_t gemm_nt_f2_workspace(const GemmNtBatch &B) {     // two-piece form: [a_amax, b_amax] per problem, then fp16 planes
+// two-piece form: a_amax slot per problem (256 B), then per problem the fp16 planes [2][N][K] and the row maxima [N]
+static size_t f2_prob_bytes(long long N, long long K) {
+    return (((size_t)4 * N * K + 255) & ~(size_t)255) + (((size_t)4 * N + 255) & ~(size_t)255);
+}
+size_t gemm_nt_f2_workspace(const GemmNtBatch &B) {
     size_t n = 256;
-    for (int i = 0; i < B.nprob; ++i) n += (((size_t)4 * B.p[i].N * B.p[i].K + 255) & ~(size_t)255);
+    for (int i = 0; i < B.nprob; ++i) n += f2_prob_bytes(B.p[i].N, B.p[i].K);
     return n;
 }
 
@@ -533,22 +573,26 @@ int launch_gemm_nt_x3(GemmNtBatch &B, void *ws, size_t ws_bytes, hipStream_t st,
         float *slots = reinterpret_cast<float *>(w);
         w += 256;
         Split2Batch S;
+        int rows_max = 0;
         for (int i = 0; i < B.nprob; ++i) {
             GemmNtProb &p = B.p[i];
             if (!p.a_amax) {                    // nobody knows max|A|: one pass over it (callers with a producer-side maximum skip this)
-                int rc = launch_absmax(static_cast<const float *>(p.A), p.lda, p.M, p.K, slots + 2 * i, st);
+                int rc = launch_absmax(static_cast<const float *>(p.A), p.lda, p.M, p.K, slots + i, st);
                 if (rc) return rc;
-                p.a_amax = slots + 2 * i;
+                p.a_amax = slots + i;
             }
-            int rc = launch_absmax(static_cast<const float *>(p.Bt), p.ldb, p.N, p.K, slots + 2 * i + 1, st);
-            if (rc) return rc;
-            p.b_amax = slots + 2 * i + 1;
             S.W[i] = static_cast<const float *>(p.Bt); S.planes[i] = reinterpret_cast<unsigned *>(w); S.ldw[i] = p.ldb;
-            S.N[i] = p.N; S.K[i] = p.K; S.amax[i] = p.b_amax;
+            S.N[i] = p.N; S.K[i] = p.K;
             p.Bp = w;
             w += ((size_t)4 * p.N * p.K + 255) & ~(size_t)255;
+            S.rowmax[i] = reinterpret_cast<float *>(w);
+            p.b_amax = S.rowmax[i];
+            w += ((size_t)4 * p.N + 255) & ~(size_t)255;
+            rows_max = p.N > rows_max ? p.N : rows_max;
         }
-        EPN_LAUNCH_AUX(split_planes2_batch_kernel, dim3(gx, B.nprob), dim3(256), 0, st, S);
+        // a wave per weight row
+        const unsigned gr = (unsigned)((rows_max + 3) / 4 < 2048 ? (rows_max + 3) / 4 : 2048);
+        EPN_LAUNCH_AUX(split_rows2_batch_kernel, dim3(gr, B.nprob), dim3(256), 0, st, S);
         EPN_CHECK_LAUNCH();
         return x3_dispatch<2>(B, maxn, minn, st);
     }
@@ -616,7 +660,7 @@ extern "C" size_t epn_gemm_nt_f16x2_workspace_bytes(int nprob, const epn_gemm_nt
     size_t n = 0;
     for (int i0 = 0; i0 < nprob; i0 += GEMM_MAX_PROB) {
         n += 256;
-        for (int i = i0; i < nprob && i < i0 + GEMM_MAX_PROB; ++i) n += (((size_t)4 * probs[i].N * probs[i].K + 255) & ~(size_t)255);
+        for (int i = i0; i < nprob && i < i0 + GEMM_MAX_PROB; ++i) n += f2_prob_bytes(probs[i].N, probs[i].K);
     }
     return n;
 }

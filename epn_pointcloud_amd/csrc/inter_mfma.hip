@@ -1629,14 +1629,22 @@ __global__ __launch_bounds__(256) void inter_reduce_slots_kernel(const TG *__res
     st4f(dF + (size_t)bq * rowlen + 4 * c4, acc);
 }
 
-__global__ void rk4_table_kernel(const float *__restrict__ rk, int na, int ks, float sigma_inv,
-                                 float *__restrict__ rk4) {
+// rk4[a][k] = ((2/sigma) R_a kappa_k, beta_k = -|R_a kappa_k|^2 / sigma), zero / -1e30 padded to EPN_KS_MAX kernel points --
+// straight from the anchors (the rotation is rk_table_kernel's expression, functional.py:190): one table launch per call
+__global__ void rk4_table_kernel(const float *__restrict__ anchors, const float *__restrict__ kernels, int na, int ks,
+                                 float sigma_inv, float *__restrict__ rk4) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= na * EPN_KS_MAX) return;
     const int k = i % EPN_KS_MAX, a = i / EPN_KS_MAX;
     f32x4 v = {0.f, 0.f, 0.f, -1e30f};
     if (k < ks) {
-        const float *r = rk + ((size_t)a * ks + k) * 3;
+        const float *kp = kernels + k * 3;
+        float r[3];
+#pragma unroll
+        for (int d = 0; d < 3; ++d) {
+            const float *R = anchors + a * 9 + d * 3;
+            r[d] = R[0] * kp[0] + R[1] * kp[1] + R[2] * kp[2];
+        }
         v[0] = 2.0f * sigma_inv * r[0];
         v[1] = 2.0f * sigma_inv * r[1];
         v[2] = 2.0f * sigma_inv * r[2];
@@ -1693,10 +1701,10 @@ int set_lds(K kern, size_t bytes) {
 }  // namespace
 
 int launch_inter_tables_mfma(const epn_inter_desc *d, const float *rk, float *rk4, float *beta, hipStream_t st) {
-    (void)beta;
+    (void)beta; (void)rk;
     const int n = d->na * EPN_KS_MAX;
-    EPN_LAUNCH_AUX(rk4_table_kernel, dim3(epn_cdiv(n, 256)), dim3(256), 0, st, rk, d->na, d->ks, 1.0f / d->sigma,
-                       rk4);
+    EPN_LAUNCH_AUX(rk4_table_kernel, dim3(epn_cdiv(n, 256)), dim3(256), 0, st, d->anchors, d->kernels, d->na, d->ks,
+                   1.0f / d->sigma, rk4);
     EPN_CHECK_LAUNCH();
     return 0;
 }
