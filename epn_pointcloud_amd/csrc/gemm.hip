@@ -1370,9 +1370,13 @@ constexpr int tn_waves(int wgm, int wgn, int, int, int) { return wgm * wgn; }
 // (N2 = the narrowest output; groups of c = 128 blocks measured slower with the extra pass over X: 1.43 vs 1.34 ms,
 // c = 256 ones too once timed cold -- X is as large as Y in a spectral block, so the pre-split is a full extra pass)
 #ifndef EPN_TN_GROUP_PLANES     // narrowest output from which a GROUP takes the pre-split planes kernel (256 x 256 tiles)
-#define EPN_TN_GROUP_PLANES 512  // cold, tools/tn_probe.py: c = 256 groups 1.05 ms in-kernel split vs 1.14 planes; c = 512: 2.40 vs 1.48
+#define EPN_TN_GROUP_PLANES 512  // (three-piece form; the two-piece form: 256, see below) cold, tools/tn_probe.py, three-piece bf16 form: c = 256 groups 1.05 ms in-kernel split vs 1.14 planes; c = 512: 2.40 vs 1.48.
+                                 // Two-piece fp16 form (round 5: the planes are 4 bytes per value, the MFMA half is twice as fast, so the in-kernel split of BOTH
+                                 // operands weighs more; tools/spectral_dw_probe.py, maxima supplied): c = 256, 4096 points 0.751 -> 0.632 ms, 2048 points 0.368 -> 0.361;
+                                 // c = 128 0.420 -> 0.441, c = 64 0.296 -> 0.346 (stay on the in-kernel split)
 #endif
-inline bool tn_planes_form(int nprob, int N2) { return N2 >= (nprob == 1 ? 512 : EPN_TN_GROUP_PLANES); }
+inline int tn_group_planes(int x3) { return x3 == 2 ? EPN_TN_GROUP_PLANES / 2 : EPN_TN_GROUP_PLANES; }
+inline bool tn_planes_form(int nprob, int N2, int x3) { return N2 >= (nprob == 1 ? 512 : tn_group_planes(x3)); }
 
 template <typename T>
 bool tn_fast_ok(const GemmTnArgs &G) {
@@ -1394,7 +1398,7 @@ size_t tn_plan(GemmTnBatch &B, int *bn1_out, int *bn2_out, void *ws, int x3 = 0,
     }
     int bn1, bn2;
     gemm_tn_tile(B.nprob > 1 && bf == 2 ? 0 : bf, max1, B.nprob > 1 && min2 < 256 ? 256 : min2, &bn1, &bn2);   // groups: the wide tiles
-    if (B.nprob > 1 && bf == 2 && min2 >= EPN_TN_GROUP_PLANES) {       // wide spectral groups (c >= 512), split form: 256 x 256 tiles
+    if (B.nprob > 1 && bf == 2 && min2 >= tn_group_planes(x3)) {       // wide spectral groups (c >= 512), split form: 256 x 256 tiles
         int min1 = 1 << 30;                             // halve the re-reads of X and Y (every tile row / column streams
         for (int i = 0; i < B.nprob; ++i) min1 = B.p[i].N1 < min1 ? B.p[i].N1 : min1;   // the other operand again)
         if (min1 >= 256) { bn1 = 256; bn2 = 256; }
@@ -1451,7 +1455,7 @@ size_t tn_plan(GemmTnBatch &B, int *bn1_out, int *bn2_out, void *ws, int x3 = 0,
     for (int i = 0; i < B.nprob; ++i) B.p[i].Xp = nullptr;
     const bool x3_tile = (bn1 == 32 && bn2 == 512) || (bn1 == 64 && bn2 == 512) || (bn1 == 256 && bn2 == 256) ||
                          (bn1 == 128 && (bn2 == 256 || bn2 == 512));      // instances of gemm_tn_x3_kernel
-    if (x3 && x3_tile && tn_planes_form(B.nprob, min2))  // bf16 planes of X: 6 bytes per value
+    if (x3 && x3_tile && tn_planes_form(B.nprob, min2, x3))  // bf16 planes of X: 6 bytes per value
         for (int i = 0; i < B.nprob; ++i) {
             GemmTnArgs &G = B.p[i];
             // (a null workspace = size query: a non-null marker keeps the two passes on the same path)

@@ -397,6 +397,10 @@ __global__ __launch_bounds__(64 * WGM * WGN) void gemm_nt_x3_kernel(GemmNtBatch 
         }
     }
     if (P.stats) nt_col_stats<TM, TN, float>(acc, P.stats, P.M, P.N, m0 + wm * TM * 32, n0 + wn * TN * 32, li, lj);
+    // (round 5, measured and dropped: whole tiles leaving through LDS -- a wave's 32 x 32 TN accumulator block transposed in the
+    // idle stage buffers and stored as 16-byte pieces of whole rows, 8x fewer store instructions: 2-7 % SLOWER on every
+    // output-heavy shape (245760 x 6144 x 256: 2.88 -> 2.94 ms, 983040 x 1536 x 64: 1.25 -> 1.35).  The store tail of these tiles
+    // is not bound by store issue; the direct form's 128-byte row segments are already whole cache lines.)
     if (m0 + BM <= P.M && n0 + BN <= P.N && (long long)BM * P.ldc < (1LL << 30)) {
         float *__restrict__ cw = C + (size_t)(m0 + wm * TM * 32) * P.ldc + (n0 + wn * TN * 32);
         const unsigned ldc = (unsigned)P.ldc;
