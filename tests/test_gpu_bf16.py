@@ -240,6 +240,23 @@ def test_f16x2_gemm_has_fp32_accuracy(gpu, M, N, K):
         gemm.set_fp32_mode(old)
     rel0 = ((C0.double() - ref0).pow(2).mean().sqrt() / ref0.pow(2).mean().sqrt()).item()
     assert 1e-6 < rel0 < 1e-2, rel0            # a row 1e-8 of the maximum: ~1e-4 relative, far below the tensor's scale in absolute terms
+    # the WEIGHT operand is scaled per row (round 5: the wave that splits a weight row takes its maximum): output columns whose
+    # weight rows span sixteen decades -- down to 1e-8 of the largest, what a tensor-wide scale loses (above) -- keep the native
+    # kernel's per-column relative accuracy, and an all-zero weight row gives exact zeros
+    Bw = B * (10.0 ** torch.linspace(-8, 8, N, device=gpu))[:, None]
+    Bw[N // 2] = 0.0
+    refw = A.double() @ Bw.double().t()
+    colscale = refw.pow(2).mean(0, keepdim=True).sqrt().clamp_min(1e-300)
+    rw = {}
+    try:
+        for mode in ("native", "f16x2"):
+            gemm.set_fp32_mode(mode)
+            Cw = gemm.gemm_nt(A, Bw)
+            assert torch.all(Cw[:, N // 2] == 0), mode
+            rw[mode] = ((Cw.double() - refw) / colscale).pow(2).mean().sqrt().item()
+    finally:
+        gemm.set_fp32_mode(old)
+    assert rw["f16x2"] <= 1.1 * rw["native"], ("weight rows over sixteen decades", rw)
     # weight-gradient forms: narrow output (both operands split in registers) and wide output (X pre-split into octet planes)
     X = torch.randn(61440, 64, device=gpu)
     for n2 in (128, 1536):
