@@ -545,13 +545,21 @@ static int x3_dispatch(GemmNtBatch &B, int maxn, int minn, hipStream_t st) {
             default: break;
         }
     }
+    // 256 x 64 tiles: three stages (120-132 KB: one workgroup per CU) in the three-piece form; the two-piece form's stage is
+    // 40 KB, and TWO stages leave room for two workgroups per CU -- what the short contractions of these narrow problems want
+    // (c = 64 spectral groups 0.214 -> 0.171 ms, 983040 x 64 x 64 0.120 -> 0.105, 491520 x 64 x 128 0.099 -> 0.089; the long
+    // K = 1536 forward GEMM of the cout = 64 layer is unchanged at 1.12 ms: tools/spectral_nt_probe.py)
+    constexpr int NSTG64 = NPL == 2 ? 2 : 3;
     if (B.nprob > 1) {                          // grouped spectral blocks: ragged widths, narrow tiles (see launch_nt_typed)
-        if (maxn <= 320 && minn <= 64) return launch_x3_cfg<4, 1, 2, 2, 3, NPL>(B, st);
+        if (maxn <= 320 && minn <= 64) return launch_x3_cfg<4, 1, 2, 2, NSTG64, NPL>(B, st);
         if (minn >= 256) return launch_x3_cfg<4, 2, 2, 4, 2, NPL>(B, st);   // c = 256 blocks: 0.76 -> 0.68 ms (A is re-read per tile column)
         return launch_x3_cfg<2, 2, 2, 2, 2, NPL>(B, st);
     }
     if (maxn <= 32) return launch_x3_cfg<8, 1, 2, 1, 2, NPL>(B, st);
-    if (maxn <= 64) return launch_x3_cfg<4, 1, 2, 2, 3, NPL>(B, st);
+    if (maxn <= 64) return launch_x3_cfg<4, 1, 2, 2, NSTG64, NPL>(B, st);
+    // cout <= 128 in the two-piece form: 128 x 128 tiles of four waves (64 KB of stages: two workgroups per CU) edge out the
+    // 256 x 128 tile (491520 x 128 x 1536: 0.857 -> 0.819 ms cold, x 3072: 1.617 -> 1.573, x 128: 0.125 -> 0.116; tools/nt_tile_probe.py)
+    if (NPL == 2 && maxn <= 128) return launch_x3_cfg<2, 2, 2, 2, 2, NPL>(B, st);
     if (maxn <= 128 || maxn % 256 > 128 || (maxn % 256 && maxn < 512)) return launch_x3_cfg<4, 2, 2, 2, 2, NPL>(B, st);
     return launch_x3_cfg<4, 2, 2, 4, 2, NPL>(B, st);
 }
