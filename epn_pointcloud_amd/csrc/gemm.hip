@@ -1403,6 +1403,9 @@ size_t tn_plan(GemmTnBatch &B, int *bn1_out, int *bn2_out, void *ws, int x3 = 0,
         for (int i = 0; i < B.nprob; ++i) min1 = B.p[i].N1 < min1 ? B.p[i].N1 : min1;   // the other operand again)
         if (min1 >= 256) { bn1 = 256; bn2 = 256; }
     }
+    // narrow spectral groups (c < 256) in the two-piece form: 128 x 128 tiles -- 64 KB of stages, two workgroups per CU, and the
+    // ragged widths (c, 3c, 3c, 4c, 5c) pad less: c = 64 0.302 -> 0.279 ms, c = 128 0.422 -> 0.348 (tools/spectral_dw_probe.py)
+    if (B.nprob > 1 && x3 == 2 && min2 < 256) { bn1 = 128; bn2 = 128; }
     *bn1_out = bn1; *bn2_out = bn2;
     long long tiles[GEMM_MAX_PROB], chunks[GEMM_MAX_PROB];
     for (int i = 0; i < B.nprob; ++i) {
