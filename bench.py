@@ -568,6 +568,7 @@ def measure(cfg, rank, local_rank, world, dev, first=True):
         if graph is None:
             return eager_step()
         graph.replay()
+        calls[0] += 1                            # a replay runs a step's kernels without calling compute()
         finish()
         return static_loss
 
