@@ -552,6 +552,7 @@ def measure(cfg, rank, local_rank, world, dev, first=True):
             with torch.cuda.graph(graph, capture_error_mode="thread_local"):
                 static_loss = compute()
             launch = "hipgraph"
+            calls[0] -= 1                        # captured, not executed: not a step's worth of kernels
         except Exception as e:                   # capture is an optimisation, never a requirement
             graph = None
             torch.cuda.synchronize()

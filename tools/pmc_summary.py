@@ -56,6 +56,6 @@ for k, e in res.items():
             if c in e:
                 e[c + "_frac"] = e[c] / e["SQ_WAVE_CYCLES"]
 if steps:
-    res["_meta"] = {"step_equivalents": steps, "note": "steps the profiled bench process ran: compute() calls (warm-up, capture, profiled eager steps) + graph replays"}
+    res["_meta"] = {"step_equivalents": steps, "note": "steps the profiled bench process ran: executed compute() calls (warm-up, eager steps) + graph replays; the capture runs no kernel"}
 json.dump(res, open(out, "w"), indent=1, sort_keys=True)
 print(f"{len(res)} kernels -> {out}")
