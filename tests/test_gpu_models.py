@@ -206,23 +206,39 @@ def test_inv_model_vs_reference_golden(gpu, fused):
     assert all(torch.isfinite(p.grad).all() for p in m.parameters() if p.grad is not None)
 
 
-def test_full_width_cls_step_matches_oracle_loss(gpu):
-    """Full-width classification network on 2 clouds: loss and a head / backbone gradient against the CPU oracle."""
+_ORACLE_STEP = {}
+
+
+@pytest.mark.parametrize("inter_mode", ["auto", "onchip"])
+def test_full_width_cls_step_matches_oracle_loss(gpu, monkeypatch, inter_mode):
+    """Full-width classification network on 2 clouds: loss and a head / backbone gradient against the CPU oracle -- in the
+    default split form and with EPN_INTER_MODE=onchip, the COMPLETE path of north_star's fused form: every InterSO3Conv of the
+    step keeps its grouped features on chip in both directions (forward csrc/inter_fx.hip, data and weight gradients the fused
+    transposes of csrc/inter_mfma.hip; no [cols, cin*ks] tensor is ever allocated -- ops.InterSO3ConvOnChipFn)."""
     from epn_pointcloud_amd import models as M, schedule as S
     from oracle import backbone_ref as B
     from test_models_cpu import tables
+    monkeypatch.setenv("EPN_INTER_MODE", inter_mode)
     layers = S.cls_so3net_schedule(1024)
     torch.manual_seed(5)
     m = M.ClsSO3ConvModel(layers, out_mlps=(256,), pooling="attention").train()
-    ref = B.RefClsModel(layers, tables(), out_mlps=(256,), pooling="attention").train()
-    ref.load_from_product(m.state_dict())
     pts = S.synthetic_clouds(2, 1024, "cpu", seed=11)
     labels = torch.tensor([7, 31])
-    lr, _ = ref(pts)
-    loss_r = torch.nn.functional.cross_entropy(lr, labels)
     names = ["outblock.fc2.weight", "backbone.3.blocks.0.inter_conv.conv.basic_conv.W"]
-    gr = torch.autograd.grad(loss_r, [dict(ref.named_parameters())[n] for n in names])
+    if "r" not in _ORACLE_STEP:                 # same seed, same weights for both forms: the oracle runs once
+        ref = B.RefClsModel(layers, tables(), out_mlps=(256,), pooling="attention").train()
+        ref.load_from_product(m.state_dict())
+        lr, _ = ref(pts)
+        loss_r = torch.nn.functional.cross_entropy(lr, labels)
+        gr = torch.autograd.grad(loss_r, [dict(ref.named_parameters())[n] for n in names])
+        _ORACLE_STEP["r"] = (lr.detach(), loss_r.detach(), [g.detach() for g in gr])
+    lr, loss_r, gr = _ORACLE_STEP["r"]
     m = m.to(gpu)
+    if inter_mode == "onchip":                  # the form really is taken by the layers it serves (cin >= 16)
+        from epn_pointcloud_amd import ops
+        taken = []
+        real = ops.InterSO3ConvOnChipFn.forward
+        monkeypatch.setattr(ops.InterSO3ConvOnChipFn, "forward", staticmethod(lambda ctx, *a: (taken.append(1), real(ctx, *a))[1]))
     lg, _ = m(pts.to(gpu))
     loss_g = torch.nn.functional.cross_entropy(lg, labels.to(gpu))
     gg = torch.autograd.grad(loss_g, [dict(m.named_parameters())[n] for n in names])
@@ -230,6 +246,8 @@ def test_full_width_cls_step_matches_oracle_loss(gpu):
     assert abs(loss_g.item() - loss_r.item()) < TOL
     for n, u, v in zip(names, gg, gr):
         assert grad_close(u, v), n
+    if inter_mode == "onchip":
+        assert len(taken) >= 6, taken
 
 
 @pytest.mark.parametrize("dt", ["f32", "bf16"])
