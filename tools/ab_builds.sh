@@ -1,5 +1,5 @@
 #!/bin/bash
-# A/B of two library builds inside one box: tools/r5_ab.sh <tagged lib suffix> [bench args]
+# A/B of two library builds inside one box: tools/ab_builds.sh <tagged lib suffix> [bench args]
 R=$(cd "$(dirname "$0")/.." && pwd); cd $R
 T=$1; shift
 B="python bench.py --steps 20 --warmup 5 --no-extra-configs --no-cpu-baseline --no-native-line $@"
