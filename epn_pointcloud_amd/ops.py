@@ -295,8 +295,15 @@ class InterSO3ConvFn(torch.autograd.Function):
                 # dW[o][k] = sum_col dOut[col][o] G[col][k] is a tall-skinny weight-gradient GEMM (2e6 x 32 x 24): the
                 # library's TN kernels stream it at 3-4.5 TB/s, the dedicated kernel (one unpipelined stage per
                 # workgroup, 1536 atomics each) ran at 0.7 TB/s
+                # two-piece fp16 mode: the maxima without passes over the operands -- max|dOut| from its producer's tag (the
+                # norm backward), |grouped| <= K max|feats| (0 <= w <= 1; the features are 32 x 1024 x 60 values): the two
+                # passes cost 0.22 ms beside a 0.07 ms GEMM
+                xa = ya = None
+                if gemm.f16x2_on(g):
+                    xa = gemm.absmax_cached(g)
+                    ya = gemm.absmax_cached(f) * float(d.nn)
                 _launch("inter_bwd_weight_c1", _inter_key(d), fl, f.device,
-                        lambda: gemm.gemm_tn(g.permute(0, 2, 3, 1).reshape(-1, cout), grouped, out=gW))
+                        lambda: gemm.gemm_tn(g.permute(0, 2, 3, 1).reshape(-1, cout), grouped, out=gW, x_amax=xa, y_amax=ya))
             else:
                 _lib.check(_launch("inter_bwd_weight_c1", _inter_key(d), fl, f.device,
                                    lambda: lib.epn_inter_so3conv_bwd_weight_c1_f32(ctypes.byref(d), grouped.data_ptr(),
