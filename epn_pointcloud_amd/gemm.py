@@ -55,6 +55,15 @@ def f16x2_on(t):
     return FP32_MODE == "f16x2" and t.dtype == torch.float32
 
 
+def amax_tag(t):
+    """The producer-side (or earlier computed) max|t| of a tensor, or None -- never a pass over t."""
+    for cand in (t, t._base if t._base is not None and t._base.numel() == t.numel() else None):
+        hit = getattr(cand, "_epn_amax", None) if cand is not None else None
+        if hit is not None and hit[0] == cand._version:
+            return hit[1]
+    return None
+
+
 def absmax_cached(t):
     """absmax(t), remembered ON the tensor object (and dropped when the tensor is written to): a tensor that is an operand of
     several GEMMs -- an output gradient feeds the data-gradient and the weight-gradient contraction, a block input the
@@ -184,8 +193,10 @@ def gemm_nt(A, Bt, out=None, out_dtype=None, col_stats=False, a_amax=None):
     return gemm_nt_grouped([(A, Bt, out)], out_dtype, [part], a_amax=am)[0], part
 
 
-def gemm_tn(X, Y, out=None, x_amax=None, y_amax=None):
-    """X [R,N1], Y [R,N2] (same dtype) -> X^T Y fp32 [N1,N2].  x_amax / y_amax: device scalars max|X|, max|Y| (f16x2 mode)."""
+def gemm_tn(X, Y, out=None, x_amax=None, y_amax=None, fp32_mode=None):
+    """X [R,N1], Y [R,N2] (same dtype) -> X^T Y fp32 [N1,N2].  x_amax / y_amax: device scalars max|X|, max|Y| (f16x2 mode).
+    fp32_mode: the form of THIS call for fp32 operands (default: the process-wide FP32_MODE) -- a bandwidth-bound contraction
+    whose operands carry no maximum runs as fast in the lossless form, without the two passes."""
     lib = _lib.get_lib()
     X, Y = _rowmajor(X, "X"), _rowmajor(Y, "Y")
     if X.shape[0] != Y.shape[0]:
@@ -198,8 +209,9 @@ def gemm_tn(X, Y, out=None, x_amax=None, y_amax=None):
         out = torch.empty((N1, N2), dtype=torch.float32, device=X.device)
     elif out.dtype != torch.float32 or out.stride(1) != 1 or tuple(out.shape) != (N1, N2):
         raise ValueError("gemm_tn: output must be row-major fp32 [N1,N2]")
-    split = not bf and FP32_MODE == "split"
-    f2 = not bf and FP32_MODE == "f16x2"
+    mode = fp32_mode or FP32_MODE
+    split = not bf and mode == "split"
+    f2 = not bf and mode == "f16x2"
     nbytes = int(lib.epn_gemm_tn_workspace_bytes(3 if f2 else (2 if split else bf), R, N1, N2))
     ws = torch.empty(max(nbytes, 16), dtype=torch.uint8, device=X.device)
     fn = lib.epn_gemm_tn_bf16 if bf else (lib.epn_gemm_tn_split_f32 if split else lib.epn_gemm_tn_f32)

@@ -298,12 +298,16 @@ class InterSO3ConvFn(torch.autograd.Function):
                 # two-piece fp16 mode: the maxima without passes over the operands -- max|dOut| from its producer's tag (the
                 # norm backward), |grouped| <= K max|feats| (0 <= w <= 1; the features are 32 x 1024 x 60 values): the two
                 # passes cost 0.22 ms beside a 0.07 ms GEMM
-                xa = ya = None
+                xa = ya = form = None
                 if gemm.f16x2_on(g):
-                    xa = gemm.absmax_cached(g)
-                    ya = gemm.absmax_cached(f) * float(d.nn)
+                    xa = gemm.amax_tag(g)
+                    if xa is None:          # bf16 networks hand in an fp32 COPY of the gradient: no tag -- the lossless form
+                        form = "split"      # needs no maximum and this contraction is bound by its operand stream anyway
+                    else:
+                        ya = gemm.absmax_cached(f) * float(d.nn)
                 _launch("inter_bwd_weight_c1", _inter_key(d), fl, f.device,
-                        lambda: gemm.gemm_tn(g.permute(0, 2, 3, 1).reshape(-1, cout), grouped, out=gW, x_amax=xa, y_amax=ya))
+                        lambda: gemm.gemm_tn(g.permute(0, 2, 3, 1).reshape(-1, cout), grouped, out=gW, x_amax=xa, y_amax=ya,
+                                             fp32_mode=form))
             else:
                 _lib.check(_launch("inter_bwd_weight_c1", _inter_key(d), fl, f.device,
                                    lambda: lib.epn_inter_so3conv_bwd_weight_c1_f32(ctypes.byref(d), grouped.data_ptr(),
