@@ -27,7 +27,12 @@ struct NormArgs {
 __device__ __forceinline__ unsigned amax_acc4(unsigned m, const f32x4 v) {
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
-        const unsigned a = __builtin_bit_cast(unsigned, v[i]) & 0x7fffffffu;
+        // (the element goes through a scalar first: __builtin_bit_cast applied to the vector subscript v[i] itself compiled to
+        // element 0 for every i with this toolchain -- the maxima were those of every fourth value, up to 1.7x low on
+        // gradients, and an operand more than 2x above its reported maximum overflows fp16 in the two-piece GEMMs: the rare
+        // non-finite step tests/test_gpu_bf16.py::test_producer_side_maxima_are_the_maxima now guards against)
+        const float f = v[i];
+        const unsigned a = __float_as_uint(f) & 0x7fffffffu;
         m = (a > m && a < 0x7f800000u) ? a : m;
     }
     return m;

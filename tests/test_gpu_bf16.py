@@ -193,6 +193,33 @@ def test_split_gemm_has_fp32_accuracy(gpu, M, N, K):
         assert ((C.double() - ref).pow(2).mean().sqrt() / ref.pow(2).mean().sqrt()).item() < 1e-5
 
 
+def test_producer_side_maxima_are_the_maxima(gpu, monkeypatch):
+    """Every max|x| a producing kernel leaves behind for the two-piece fp16 GEMMs (ops._tag_amax: basis change, block tail,
+    norm backward) IS the maximum of the tensor it tags -- over a whole classification step (forward + backward, 4 clouds).
+    An under-reported maximum is silent until an operand exceeds twice it and overflows fp16: round 5 shipped one for a day
+    (a vector-subscript bit cast that compiled to element 0: every fourth value only; up to 1.7x low on gradients, one
+    non-finite training step in ten)."""
+    from epn_pointcloud_amd import models as M, ops, schedule as S
+    seen = []
+    real = ops._tag_amax
+
+    def recording(t, amax):
+        seen.append((t, amax))
+        real(t, amax)
+
+    monkeypatch.setattr(ops, "_tag_amax", recording)
+    torch.manual_seed(3)
+    layers = S.cls_so3net_schedule(1024)
+    m = S.set_feature_dtype(M.ClsSO3ConvModel(layers, out_mlps=(256,), pooling="attention").to(gpu).train(), torch.float32)
+    pts = S.synthetic_clouds(4, 1024, gpu, seed=5)
+    loss = torch.nn.functional.cross_entropy(m(pts)[0], torch.tensor([1, 2, 3, 4], device=gpu))
+    loss.backward()
+    assert len(seen) >= 30, len(seen)
+    for t, amax in seen:
+        true = t.float().abs().max().item()
+        assert abs(amax.item() - true) <= 1e-6 * max(true, 1e-30), (tuple(t.shape), amax.item(), true)
+
+
 @pytest.mark.parametrize("M,N,K", [(8192, 128, 1536), (4096, 256, 6144), (4096, 768, 256)])
 def test_f16x2_gemm_has_fp32_accuracy(gpu, M, N, K):
     """The two-piece fp16 form (x 2^s = h + l, products hh + hl + lh, fp32 accumulate) against fp64, beside the fp32 matrix
