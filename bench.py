@@ -45,6 +45,7 @@ def _latest_profile(suffix):
     return found[-1] if found else os.path.join(ROOT, "profiles", "r05_" + suffix)
 
 
+TRACE = os.environ.get("EPN_BENCH_TRACE_LOSS") == "1"      # diagnostics: print the loss of every warm-up / timed step (synchronises)
 PMC_FILE = _latest_profile("pmc_per_kernel.json")                        # tools/collect_profiles.sh + pmc_summary.py
 PMC_FILES = {"cls_f32": PMC_FILE,                                        # which committed pass profiled which workload
              "reg_bf16": _latest_profile("reg_bf16_pmc_per_kernel.json"),
@@ -446,9 +447,6 @@ def hold_gpu(ms, dev):
     torch.cuda._sleep(int(ms * _SLEEP_CYCLES_PER_MS))
 
 
-_FLAGS = []
-
-
 def measure(cfg, rank, local_rank, world, dev, first=True):
     """One workload (cfg: model, dtype, forward_only, steps, warmup, batch, points, no_graph, backbone_only): builds the
     network, warms up, captures the step into a HIP graph, times exactly cfg.steps steps between barrier + synchronize
@@ -543,21 +541,8 @@ def measure(cfg, rank, local_rank, world, dev, first=True):
             wl = compute()
             if not cfg.forward_only:
                 opt.step()
-            if os.environ.get("EPN_DEBUG_FLAGS") == "1" and rank == 0:
-                _FLAGS.append(("opsdbg", list(ops.DEBUG_FLAGS)))
-                del ops.DEBUG_FLAGS[:]
-            if os.environ.get("EPN_BENCH_TRACE_LOSS") == "3" and rank == 0:      # device-side flags, no host synchronisation
-                _FLAGS.append(("warm-up params finite", torch.stack([torch.isfinite(p).all() for p in params]).all()))
-                _FLAGS.append(("warm-up grads finite", torch.stack([torch.isfinite(p.grad).all() for p in params if p.grad is not None]).all()))
-                _FLAGS.append(("warm-up loss", wl.detach().clone()))
-                gl = [(n, q) for n, q in model.named_parameters() if q.grad is not None]
-                _FLAGS.append(("names", [n for n, _ in gl], torch.stack([torch.isfinite(q.grad).all() for _, q in gl]),
-                               torch.stack([q.grad.abs().max() for _, q in gl])))
-            if os.environ.get("EPN_BENCH_TRACE_LOSS") == "2" and rank == 0:
-                torch.cuda.synchronize()
-                badp = [n for n, p in model.named_parameters() if not torch.isfinite(p).all()]
-                badg = [n for n, p in model.named_parameters() if p.grad is not None and not torch.isfinite(p.grad).all()]
-                print(f"[bench] warm-up loss {float(wl):.6g} bad params {badp[:3]} bad grads {badg[:3]}", file=sys.stderr, flush=True)
+            if TRACE and rank == 0:                  # diagnostics (EPN_BENCH_TRACE_LOSS=1): synchronises every step
+                print(f"[bench] warm-up loss {float(wl):.6g}", file=sys.stderr, flush=True)
     torch.cuda.current_stream(dev).wait_stream(side)
     torch.cuda.synchronize(dev)
 
@@ -577,14 +562,6 @@ def measure(cfg, rank, local_rank, world, dev, first=True):
             if rank == 0:
                 print(f"[bench] HIP graph capture unavailable ({type(e).__name__}: {e}); eager launches", file=sys.stderr)
 
-    if os.environ.get("EPN_TMP_SYNC_AFTER_CAPTURE") == "1":
-        torch.cuda.synchronize()
-    if os.environ.get("EPN_TMP_POISON"):       # diagnostics: fill every free small block of the eager pool with NaN after the capture
-        torch.cuda.synchronize()
-        nbytes = int(os.environ["EPN_TMP_POISON"])
-        junk = [torch.full((max(nbytes // 4, 1),), float("nan"), device=dev) for _ in range(8192)]
-        torch.cuda.synchronize()
-        del junk
     if first or dp_path:
         dp.init_from_env(force=dp_path)          # RCCL communicator (world > 1 or --dp-path), after the capture
     dp.broadcast_parameters(model)
@@ -594,18 +571,9 @@ def measure(cfg, rank, local_rank, world, dev, first=True):
     def step():
         if graph is None:
             return eager_step()
-        trace3 = os.environ.get("EPN_BENCH_TRACE_LOSS") == "3" and rank == 0
-        if trace3:
-            _FLAGS.append(("params finite before replay", torch.stack([torch.isfinite(p).all() for p in params]).all()))
-            _FLAGS.append(("buffers finite before replay", torch.stack([torch.isfinite(b).all() for b in model.buffers() if b.is_floating_point()]).all()))
         graph.replay()
         calls[0] += 1                            # a replay runs a step's kernels without calling compute()
-        if trace3:
-            _FLAGS.append(("replay loss", static_loss.detach().clone()))
-            _FLAGS.append(("grads finite after replay", torch.stack([torch.isfinite(p.grad).all() for p in params if p.grad is not None]).all()))
         finish()
-        if trace3:
-            _FLAGS.append(("params finite after finish", torch.stack([torch.isfinite(p).all() for p in params]).all()))
         return static_loss
 
     def fence():
@@ -613,45 +581,16 @@ def measure(cfg, rank, local_rank, world, dev, first=True):
             torch.distributed.barrier()
         torch.cuda.synchronize()
 
-    if os.environ.get("EPN_BENCH_TRACE_LOSS") == "2" and rank == 0:
-        torch.cuda.synchronize()
-        badp = [n for n, p in model.named_parameters() if not torch.isfinite(p).all()]
-        print(f"[bench] before the first replay: bad params {badp[:3]}", file=sys.stderr, flush=True)
-        if graph is not None:
-            graph.replay()
-            torch.cuda.synchronize()
-            badg = [n for n, p in model.named_parameters() if p.grad is not None and not torch.isfinite(p.grad).all()]
-            print(f"[bench] probe replay: loss {float(static_loss):.6g} bad grads {badg[:4]} of {len(badg)}", file=sys.stderr, flush=True)
     ul = step()                                  # one untimed step on the final path (RCCL lazy init included)
     fence()
-    if os.environ.get("EPN_BENCH_TRACE_LOSS") in ("1", "2") and rank == 0:
+    if TRACE and rank == 0:
         print(f"[bench] untimed-step loss {float(ul):.6g}", file=sys.stderr, flush=True)
     if graph is None:
         ops.profile_begin()                      # eager: HIP events around every call of the timed region itself
     t0 = time.perf_counter()
-    if os.environ.get("EPN_BENCH_TRACE_LOSS") == "3" and rank == 0:
-        for fl in _FLAGS:
-            if fl[0] == "opsdbg":
-                for nm, t in fl[1]:
-                    v = t.tolist()
-                    bad = (v[0] != 1.0) or not (v[2] <= v[1] * 1.0001) or not (v[3] <= v[4] * 1.0001)
-                    if bad:
-                        print(f"[bench] flag OPS {nm}: g finite {v[0]} tag {v[1]:.6g} true max|g| {v[2]:.6g} max|G| {v[3]:.6g} G bound {v[4]:.6g}", file=sys.stderr, flush=True)
-                continue
-            if fl[0] == "names":
-                bad = [(n, float(m)) for n, ok, m in zip(fl[1], fl[2].tolist(), fl[3].tolist()) if not ok]
-                if bad:
-                    allv = list(zip(fl[1], fl[2].tolist(), fl[3].tolist()))
-                    last = max(i for i, v in enumerate(allv) if not v[1])
-                    print(f"[bench] flag non-finite grads ({len(bad)} of {len(fl[1])}): around the last bad one: "
-                          f"{[(n.replace('backbone.', 'b').replace('blocks.', ''), ok, float('%.3g' % m)) for n, ok, m in allv[max(0, last - 3):last + 8]]}",
-                          file=sys.stderr, flush=True)
-                continue
-            print(f"[bench] flag {fl[0]}: {fl[1].item()}", file=sys.stderr, flush=True)
-        del _FLAGS[:]
     for _ in range(cfg.steps):
         last = step()
-        if os.environ.get("EPN_BENCH_TRACE_LOSS") in ("1", "2") and rank == 0:      # diagnostics: synchronises every step
+        if TRACE and rank == 0:
             print(f"[bench] loss {float(last):.6g}", file=sys.stderr, flush=True)
     fence()
     dt = time.perf_counter() - t0

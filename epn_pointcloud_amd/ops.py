@@ -299,7 +299,7 @@ class InterSO3ConvFn(torch.autograd.Function):
                 # norm backward), |grouped| <= K max|feats| (0 <= w <= 1; the features are 32 x 1024 x 60 values): the two
                 # passes cost 0.22 ms beside a 0.07 ms GEMM
                 xa = ya = form = None
-                if gemm.f16x2_on(g) and os.environ.get("EPN_TMP_C1AMAX", "1") == "1":
+                if gemm.f16x2_on(g):
                     xa = gemm.amax_tag(g)
                     if xa is None:          # bf16 networks hand in an fp32 COPY of the gradient: no tag -- the lossless form
                         form = "split"      # needs no maximum and this contraction is bound by its operand stream anyway
@@ -495,10 +495,6 @@ class InterSO3ConvSplitFn(torch.autograd.Function):
         # two-piece fp16 contractions: max|dOut| once for both GEMMs it feeds (a pass over the narrow operand), max|G| as the
         # forward pass bounded it
         go_amax = gemm.absmax_cached(g) if gemm.f16x2_on(G) else None      # (tagged by the norm backward that produced it)
-        if os.environ.get("EPN_DEBUG_FLAGS") == "1" and go_amax is not None:
-            DEBUG_FLAGS.append((f"inter bwd {cin}->{cout} p2={d.p2}", torch.stack([
-                torch.isfinite(g).all().float(), go_amax.reshape(()).clone(), g.abs().max(), G.abs().max(),
-                ctx.g_amax.reshape(()).clone() if ctx.g_amax is not None else g.new_zeros(())])))
         if need_w:
             gW = _launch("inter_gemm_dw", _inter_key(d), gemm_fl, G.device,
                          lambda: gemm.gemm_tn(g2d, G, x_amax=go_amax, y_amax=ctx.g_amax))
@@ -668,7 +664,6 @@ class InterSO3ConvOnChipFn(torch.autograd.Function):
         return gf, gW, None
 
 
-DEBUG_FLAGS = []
 _SIDE = {}
 
 

@@ -1,12 +1,9 @@
 #!/bin/bash
-# repeated default bench lines under a toggle: which embedded config fails?  usage: tools/nan_hunt.sh VAR "v1 v2 ..." [reps]
+# Repeated bench.py runs with the loss trace (EPN_BENCH_TRACE_LOSS=1): one line of losses per run; how round 5 found the
+# under-reported producer-side maxima (one non-finite data-parallel step in ten).  usage: tools/nan_hunt.sh reps bench-args...
 R=$(cd "$(dirname "$0")/.." && pwd); cd $R
-VAR=$1; VALS=$2; REPS=${3:-3}
+REPS=$1; shift
 for r in $(seq $REPS); do
-  for v in $VALS; do
-    env $VAR=$v python bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-native-line 2>/dev/null | python -c "
-import sys,json
-d=json.loads(sys.stdin.read().strip().splitlines()[-1])
-print('$VAR=$v', d['value'], {k:c.get('value',c.get('error')) for k,c in d['configs'].items()})"
-  done
+  EPN_BENCH_TRACE_LOSS=1 python bench.py "$@" --no-cpu-baseline --no-native-line --no-extra-configs 2>&1 >/dev/null | grep "bench\] \(warm-up\|untimed-step\)\? \?loss" | awk '{print $NF}' | tr "\n" " "
+  echo
 done
