@@ -45,7 +45,6 @@ def _latest_profile(suffix):
     return found[-1] if found else os.path.join(ROOT, "profiles", "r05_" + suffix)
 
 
-TRACE = os.environ.get("EPN_BENCH_TRACE_LOSS") == "1"      # diagnostics: print the loss of every warm-up / timed step (synchronises)
 PMC_FILE = _latest_profile("pmc_per_kernel.json")                        # tools/collect_profiles.sh + pmc_summary.py
 PMC_FILES = {"cls_f32": PMC_FILE,                                        # which committed pass profiled which workload
              "reg_bf16": _latest_profile("reg_bf16_pmc_per_kernel.json"),
@@ -146,6 +145,9 @@ def parse():
     ap.add_argument("--dp-collect", default="pack", choices=["pack", "accumulate"],
                     help="how gradients reach the flat buffer (dp.GradBuckets): one multi-tensor copy at the end of backward "
                          "(default) or autograd accumulating into views of it (round 4's form: one add per parameter + a fill)")
+    ap.add_argument("--trace-loss", action="store_true",
+                    help="diagnostics: print the loss of every warm-up / untimed / timed step to stderr (synchronises every step; "
+                         "tools/nan_hunt.sh)")
     ap.add_argument("--policy", default="", help="A/B switch of the tuning tools: epn_set_kernel_policy value (e.g. 0x401), see "
                                                  "include/epn_so3conv.h; default = the library's own choices")
     return ap.parse_args()
@@ -453,6 +455,7 @@ def measure(cfg, rank, local_rank, world, dev, first=True):
     fences (max over ranks), then profiles a few eager steps call by call.  Returns (json_dict, handles) on every rank."""
     from epn_pointcloud_amd import dp, models as M, ops, schedule as S
     from epn_pointcloud_amd import gemm as _gemm
+    TRACE = bool(getattr(cfg, "trace_loss", False))
     dtype_name = cfg.dtype or ("f32" if cfg.model == "cls" else "bf16")
     split_gemm = dtype_name == "f32" and _gemm.FP32_MODE != "native"
     exec_x = {"split": 6, "f16x2": 3}.get(_gemm.FP32_MODE, 1) if dtype_name == "f32" else 1
@@ -541,7 +544,7 @@ def measure(cfg, rank, local_rank, world, dev, first=True):
             wl = compute()
             if not cfg.forward_only:
                 opt.step()
-            if TRACE and rank == 0:                  # diagnostics (EPN_BENCH_TRACE_LOSS=1): synchronises every step
+            if TRACE and rank == 0:                  # diagnostics (--trace-loss): synchronises every step
                 print(f"[bench] warm-up loss {float(wl):.6g}", file=sys.stderr, flush=True)
     torch.cuda.current_stream(dev).wait_stream(side)
     torch.cuda.synchronize(dev)
