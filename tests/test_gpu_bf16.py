@@ -220,6 +220,23 @@ def test_producer_side_maxima_are_the_maxima(gpu, monkeypatch):
         assert abs(amax.item() - true) <= 1e-6 * max(true, 1e-30), (tuple(t.shape), amax.item(), true)
 
 
+def test_absmax_pass_is_exact(gpu):
+    """epn_absmax_f32 (the pass an entry point makes when nobody supplies a maximum): contiguous, strided rows, a tail that is
+    not a multiple of four, non-finite elements left out, an all-zero tensor."""
+    from epn_pointcloud_amd import gemm
+    torch.manual_seed(9)
+    for shape, sl in (((245760, 256), None), ((4099, 67), None), ((8192, 160), slice(0, 128)), ((3, 5), None)):
+        t = torch.randn(*shape, device=gpu) * 3.0
+        t[torch.randint(0, shape[0], (1,)), torch.randint(0, shape[1] if sl is None else 128, (1,))] = -77.5
+        v = t if sl is None else t[:, sl]
+        assert gemm.absmax(v).item() == v.abs().max().item(), shape
+    t = torch.randn(1024, 64, device=gpu)
+    t[5, 7], t[9, 1] = float("inf"), float("nan")
+    fin = torch.where(torch.isfinite(t), t, torch.zeros_like(t))
+    assert gemm.absmax(t).item() == fin.abs().max().item()
+    assert gemm.absmax(torch.zeros(256, 32, device=gpu)).item() == 0.0
+
+
 @pytest.mark.parametrize("M,N,K", [(8192, 128, 1536), (4096, 256, 6144), (4096, 768, 256)])
 def test_f16x2_gemm_has_fp32_accuracy(gpu, M, N, K):
     """The two-piece fp16 form (x 2^s = h + l, products hh + hl + lh, fp32 accumulate) against fp64, beside the fp32 matrix
