@@ -193,7 +193,8 @@ def test_split_gemm_has_fp32_accuracy(gpu, M, N, K):
         assert ((C.double() - ref).pow(2).mean().sqrt() / ref.pow(2).mean().sqrt()).item() < 1e-5
 
 
-def test_producer_side_maxima_are_the_maxima(gpu, monkeypatch):
+@pytest.mark.parametrize("net", ["cls", "reg"])
+def test_producer_side_maxima_are_the_maxima(gpu, monkeypatch, net):
     """Every max|x| a producing kernel leaves behind for the two-piece fp16 GEMMs (ops._tag_amax: basis change, block tail,
     norm backward) IS the maximum of the tensor it tags -- over a whole classification step (forward + backward, 4 clouds).
     An under-reported maximum is silent until an operand exceeds twice it and overflows fp16: round 5 shipped one for a day
@@ -209,10 +210,15 @@ def test_producer_side_maxima_are_the_maxima(gpu, monkeypatch):
 
     monkeypatch.setattr(ops, "_tag_amax", recording)
     torch.manual_seed(3)
-    layers = S.cls_so3net_schedule(1024)
-    m = S.set_feature_dtype(M.ClsSO3ConvModel(layers, out_mlps=(256,), pooling="attention").to(gpu).train(), torch.float32)
     pts = S.synthetic_clouds(4, 1024, gpu, seed=5)
-    loss = torch.nn.functional.cross_entropy(m(pts)[0], torch.tensor([1, 2, 3, 4], device=gpu))
+    if net == "cls":
+        layers = S.cls_so3net_schedule(1024)
+        m = S.set_feature_dtype(M.ClsSO3ConvModel(layers, out_mlps=(256,), pooling="attention").to(gpu).train(), torch.float32)
+        loss = torch.nn.functional.cross_entropy(m(pts)[0], torch.tensor([1, 2, 3, 4], device=gpu))
+    else:                                   # the rotation network in fp32: 32-channel layers (two points per basis-change task), K = 64
+        m = S.set_feature_dtype(M.RegSO3ConvModel(S.reg_so3net_schedule(1024)).to(gpu).train(), torch.float32)
+        out = m(pts.view(2, 2, 1024, 3))
+        loss = out[0].square().mean() + out[1].square().mean()
     loss.backward()
     assert len(seen) >= 30, len(seen)
     for t, amax in seen:
