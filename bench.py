@@ -588,6 +588,11 @@ def measure(cfg, rank, local_rank, world, dev, first=True):
     fence()
     if TRACE and rank == 0:
         print(f"[bench] untimed-step loss {float(ul):.6g}", file=sys.stderr, flush=True)
+    f2_mode = dtype_name == "f32" and _gemm.FP32_MODE == "f16x2"
+    if f2_mode:
+        _gemm.f16x2_overflow_count(reset=True)   # the timed region must leave the overflow sentinel at zero (checked below)
+    if buckets is not None:
+        buckets.record_timing, buckets.timings = True, []
     if graph is None:
         ops.profile_begin()                      # eager: HIP events around every call of the timed region itself
     t0 = time.perf_counter()
@@ -595,8 +600,46 @@ def measure(cfg, rank, local_rank, world, dev, first=True):
         last = step()
         if TRACE and rank == 0:
             print(f"[bench] loss {float(last):.6g}", file=sys.stderr, flush=True)
+    torch.cuda.synchronize()
+    dt_local = time.perf_counter() - t0          # this rank's own time, before it waits for the others
     fence()
     dt = time.perf_counter() - t0
+    # ---- what a multi-rank line needs to explain itself (world > 1, or the rank program on one GPU): per-rank step time,
+    # the collective phase as the compute stream sees it, its bus bandwidth, and the same step WITHOUT the collective timed
+    # right here on every rank at once (so the comparison shares this run's clocks, power state and neighbours)
+    dp_info = None
+    if buckets is not None:
+        ar_ms = buckets.collective_ms()
+        buckets.record_timing = False
+        nbytes = buckets.flat.numel() * 4
+        ar = sum(ar_ms) / max(len(ar_ms), 1)
+        dp_info = {"ms_per_step_local": round(dt_local / cfg.steps * 1e3, 3),
+                   "allreduce_ms": round(ar, 3), "allreduce_mb": round(nbytes / 2 ** 20, 1),
+                   "allreduce_per_step": len(ar_ms) // max(cfg.steps, 1),
+                   # ring convention (rccl-tests' busbw): 2 (N - 1) / N of the buffer crosses every link
+                   "bus_gbps": round(2.0 * (world - 1) / max(world, 1) * nbytes / max(ar, 1e-6) / 1e6, 1) if world > 1 else None}
+
+        dp_info["no_comm_ms_per_step_local"] = None
+        if graph is not None:                    # (eager mode issues its collectives from backward hooks: no comm-free form)
+            fence()
+            t1 = time.perf_counter()
+            for _ in range(cfg.steps):           # the rank program minus its collective (replicas drift: timing only)
+                graph.replay()
+                opt.step()
+            torch.cuda.synchronize()
+            dp_info["no_comm_ms_per_step_local"] = round((time.perf_counter() - t1) / cfg.steps * 1e3, 3)
+            fence()
+        if world > 1:                            # every rank's two figures on rank 0
+            mine = torch.tensor([dp_info["ms_per_step_local"], dp_info["no_comm_ms_per_step_local"] or 0.0, dp_info["allreduce_ms"]],
+                                dtype=torch.float64, device=dev)
+            allr = [torch.zeros_like(mine) for _ in range(world)]
+            torch.distributed.all_gather(allr, mine)
+            rows = torch.stack(allr).cpu()
+            dp_info["per_rank_ms_per_step"] = [round(float(rows[:, 0].min()), 3), round(float(rows[:, 0].max()), 3)]
+            if graph is not None:
+                dp_info["per_rank_no_comm_ms"] = [round(float(rows[:, 1].min()), 3), round(float(rows[:, 1].max()), 3)]
+            dp_info["per_rank_allreduce_ms"] = [round(float(rows[:, 2].min()), 3), round(float(rows[:, 2].max()), 3)]
+            dp.broadcast_parameters(model)       # re-synchronise the replicas the comm-free steps let drift
     if graph is None:
         records, prof_steps = ops.profile_end(), cfg.steps
     else:
@@ -621,6 +664,10 @@ def measure(cfg, rank, local_rank, world, dev, first=True):
         torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
         dt = float(t.item())
     assert torch.isfinite(last.float()).all(), "non-finite output in the timed region"
+    f2_overflow = _gemm.f16x2_overflow_count(reset=True) if f2_mode else None
+    if f2_overflow:
+        raise RuntimeError(f"{f2_overflow} wave(s) of two-piece fp16 GEMMs ended with a non-finite accumulator during the timed "
+                           "region: a reported max|operand| was too small (epn_f16x2_overflow_count) -- the measurement is void")
 
     nn_desc = "/".join(str(k) for k in sorted({l.nn for l in layers}, reverse=True))
     out = {
@@ -645,6 +692,13 @@ def measure(cfg, rank, local_rank, world, dev, first=True):
         out["config"]["inter_mode"] = os.environ["EPN_INTER_MODE"]
     if dp_path:
         out["config"]["dp_path"] = f"{collect}+1 all-reduce" if graph is not None else "hooks"
+    if f2_overflow is not None:
+        out["f16x2_overflow"] = f2_overflow      # the sentinel of the two-piece kernels over the timed region (0, or the run raised)
+    if dp_info is not None:
+        # efficiency against the rank program measured in THIS run: value / (N x the comm-free rate of the slowest rank)
+        slow = dp_info.get("per_rank_no_comm_ms", [None, dp_info["no_comm_ms_per_step_local"]])[1]
+        dp_info["eff_vs_rank_program"] = round(slow / (dt / cfg.steps * 1e3), 4) if slow else None
+        out["dp"] = dp_info
     if rank == 0:
         # PMC passes exist for the cls fp32 step (B=32) and the rotation network's bf16 step (B=64): their kernels' traffic
         profiled = (not cfg.forward_only) and ((cfg.model, batch, dtype_name) in (("cls", 32, "f32"), ("reg", 64, "bf16"),
@@ -685,7 +739,8 @@ def compact_config(o):
     r = o.get("roofline", {})
     c = {"value": o["value"], "ms_per_step": o["ms_per_step"], "steps": o["steps"]}
     if "overhead_ms" in o:          # the rank program: the headline's kernels, what matters is its difference to the headline
-        c.update({k: o[k] for k in ("overhead_ms", "vs_headline", "collect", "predicted_eff_8gpu", "assumes") if k in o})
+        c.update({k: o[k] for k in ("overhead_ms", "vs_headline", "collect", "allreduce_ms", "no_comm_ms", "predicted_eff_8gpu",
+                                    "wire") if k in o})     # (`assumes`, the long form of `wire`, is in the detail file)
         return c
     c.update(bound=r.get("bound"), frac=r.get("frac"), kernel=r.get("kernel"))
     if r.get("traffic"):
@@ -711,6 +766,9 @@ def compact_line(out):
                                 "scaling", "vs_baseline", "dtype", "data", "config") if k in out}
     if "roofline" in out:
         line["roofline"] = out["roofline"]
+    for k in ("f16x2_overflow", "dp"):          # the overflow sentinel over the timed region; the multi-rank self-explanation
+        if k in out:
+            line[k] = out[k]
     if "cpu_baseline" in out:
         line["cpu_baseline"] = {k: out["cpu_baseline"][k] for k in
                                 ("value", "unit", "cores", "kind", "samples", "forward_only_value", "sample")}
@@ -906,11 +964,15 @@ def main():
                 grad_mb = sum(p.numel() for p in h["model"].parameters() if p.requires_grad) * 4 / 1e6
                 detail["configs"]["cls_dp_rank"] = h["detail"]
                 h.clear()
-                e = {k: o[k] for k in ("metric", "value", "unit", "ms_per_step", "steps", "dtype", "config", "roofline")}
+                e = {k: o[k] for k in ("metric", "value", "unit", "ms_per_step", "steps", "dtype", "config", "roofline", "dp") if k in o}
                 wire_ms = grad_mb * 1e6 * 2 * 7 / 8 / (XGMI_ALLREDUCE_BUSBW_GBS * 1e9) * 1e3 + XGMI_ALLREDUCE_LATENCY_MS
                 e.update(overhead_ms=round(o["ms_per_step"] - out["ms_per_step"], 3),
                          vs_headline=round(o["value"] / out["value"], 4), collect=o["config"].get("dp_path"),
                          predicted_eff_8gpu=round(out["ms_per_step"] / (o["ms_per_step"] + wire_ms), 4),
+                         # measured in that run: the 1-rank all-reduce + average as the compute stream sees it, and the same
+                         # step without them (what `dp` reports per rank when world > 1)
+                         allreduce_ms=o.get("dp", {}).get("allreduce_ms"), no_comm_ms=o.get("dp", {}).get("no_comm_ms_per_step_local"),
+                         wire=f"ASSUMED {XGMI_ALLREDUCE_BUSBW_GBS:.0f} GB/s busbw",
                          assumes=f"t1/(t_rank+wire); wire {wire_ms:.2f} ms = {grad_mb:.1f} MB ring all-reduce, 8 GPUs, "
                                  f"{XGMI_ALLREDUCE_BUSBW_GBS:.0f} GB/s busbw + {XGMI_ALLREDUCE_LATENCY_MS} ms (ASSUMED, unmeasured), "
                                  f"no overlap")

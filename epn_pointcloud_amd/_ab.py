@@ -25,12 +25,37 @@ AB_DEFAULTS = {
     "EPN_POINTNET": "auto",          # PointnetSO3Conv: GEMM-composed from 16 k rows | "gemm" | "fused"
     "EPN_HEAD_BF16": "1",            # bf16 networks: rotation head reads bf16 features itself
     "EPN_REG_MLP_BF16": "1",         # ... and its anchor-pair MLP keeps bf16 values
+    "EPN_CHECK_AMAX": "0",           # debug: re-derive every maximum a two-piece fp16 GEMM consumes and assert (synchronises; eager only)
 }
 
 
+_RESOLVED = {}        # name -> value, resolved once per process (the switches are read on hot forward paths)
+_WARNED = False
+
+
+def _warn_ignored():
+    """One warning per process when A/B variables are set but EPN_AB=1 is not: earlier rounds honoured them unconditionally, and a
+    tool or a debugging workaround that still sets one would otherwise silently measure the default form (advisor, round 5)."""
+    global _WARNED
+    if _WARNED:
+        return
+    _WARNED = True
+    stray = sorted(k for k in AB_DEFAULTS if k in os.environ and os.environ[k] != AB_DEFAULTS[k])
+    if stray:
+        import warnings
+        warnings.warn("epn_pointcloud_amd: " + ", ".join(f"{k}={os.environ[k]}" for k in stray) + " ignored -- A/B switches are "
+                      "read only when EPN_AB=1 is set (INTEGRATION.md 'Run-time switches'); the settled defaults are in effect",
+                      RuntimeWarning, stacklevel=3)
+
+
 def ab(name):
-    """Value of an A/B switch: the settled default unless the process opted into A/B mode with EPN_AB=1."""
-    default = AB_DEFAULTS[name]
-    if os.environ.get("EPN_AB", "0") != "1":
-        return default
-    return os.environ.get(name, default)
+    """Value of an A/B switch: the settled default unless the process opted into A/B mode with EPN_AB=1.  In A/B mode the
+    environment is looked at on every call (tests flip switches with monkeypatch between calls); outside it the answer is the
+    cached default."""
+    if os.environ.get("EPN_AB", "0") == "1":
+        return os.environ.get(name, AB_DEFAULTS[name])
+    v = _RESOLVED.get(name)
+    if v is None:
+        _warn_ignored()
+        v = _RESOLVED[name] = AB_DEFAULTS[name]
+    return v

@@ -91,7 +91,11 @@ static bool use_mfma(const epn_inter_desc *d) { return inter_uses_mfma(d) && !fo
 // 0.2: epn_gemm_nt_problem gained the trailing `col_stats` member (round 3) and epn_ball_query_f64 takes `float radius`
 // (round 4) -- callers compiled against the 0.1 header must be rebuilt; INTEGRATION.md "ABI revisions"
 // 0.3 (round 5): epn_abi_version() added; new entry point epn_fps_temp_f32; nothing existing changed
-extern "C" const char *epn_version(void) { return "epn_so3conv 0.3 (gfx950)"; }
+// 0.4 (round 6): epn_f16x2_overflow_count (the two-piece kernels' overflow sentinel); the tail of the composed split form's
+// `saved` buffer carries a tag word and an untagged tail is re-derived, not trusted; no signature changed.  (0.3 DID change
+// behaviour without changing a signature -- fp32 `saved` grew by 256 bytes and the composed entries moved to the two-piece
+// GEMMs: INTEGRATION.md "ABI revisions" says so; the note above was too short.)
+extern "C" const char *epn_version(void) { return "epn_so3conv 0.4 (gfx950)"; }
 extern "C" int epn_abi_version(void) { return EPN_ABI_VERSION; }
 
 extern "C" const char *epn_strerror(int code) {

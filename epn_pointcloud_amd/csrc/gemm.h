@@ -83,6 +83,21 @@ __device__ __forceinline__ void f2_split8(const float (&x)[8], float s, gemm_f16
     l = __builtin_bit_cast(gemm_f16x8, L);
 }
 
+// ---- the scale contract made loud (round 6).  The scale leaves a factor 2-4 below fp16's 65504: an operand element above
+// 2-4 x the REPORTED maximum becomes inf in the split, the products inf / NaN, and the result is silently non-finite.  Every
+// two-piece kernel therefore folds its accumulators into one value per lane in the epilogue (`chk = fma(acc, 0, chk)`: NaN iff
+// an accumulator was inf or NaN -- one VALU instruction per accumulator and TILE, nothing per K step) and a wave with a
+// non-finite accumulator bumps a sticky device counter (one atomic per wave, only then).  With finite operands a non-zero
+// count can only be a violated scale contract; epn_f16x2_overflow_count() reads (and optionally clears) the sum over the
+// library's two GEMM translation units.  Each TU owns its counter (no relocatable device code in this build).
+#define EPN_F2_SENTINEL_DECL __device__ unsigned g_f2_nonfinite = 0u;
+#define EPN_F2_CHECK(chk_)                                                                       \
+    do {                                                                                         \
+        const float c__ = (chk_);                                                                \
+        if (__builtin_amdgcn_ballot_w64(c__ != c__) != 0ull && (threadIdx.x & 63) == 0)          \
+            atomicAdd(&g_f2_nonfinite, 1u);                                                      \
+    } while (0)
+
 // Column statistics of an NT tile, taken from the accumulators in the epilogue (the per-channel sums a following
 // BatchNorm / InstanceNorm needs: SURVEY 8f.1 -- no separate pass over C).  acc[i][j]: 32 x 32 MFMA tile i (rows) x j
 // (columns) of the wave, D[row = (r&3) + 8 (r>>2) + 4 lj][col = li]; part[(row / 32)][n][2].  The sums are those of the
@@ -117,6 +132,11 @@ __device__ __forceinline__ void nt_col_stats(const gemm_f32x16 (&acc)[TM][TN], f
 }
 #endif
 
+// f16x2 sentinel: sticky per-device count of waves that ended a two-piece GEMM tile with a non-finite accumulator, per TU
+// (gemm.hip, gemm_x3.hip); take = read (synchronously, on the current device) and optionally clear.  < 0: a hipError_t, negated
+long long f2_nonfinite_take_gemm(bool reset);
+long long f2_nonfinite_take_x3(bool reset);
+
 int kernel_policy();   // c_api.hip: epn_set_kernel_policy (0x100 | cfg = NT tile override of the tuning tool)
 
 // dtype / out_dtype: 0 = fp32, 1 = bf16
@@ -129,7 +149,10 @@ int launch_gemm_nt_x3(GemmNtBatch &B, void *ws, size_t ws_bytes, hipStream_t st,
 size_t gemm_nt_f2_workspace(const GemmNtBatch &B);
 // max |x| of a strided matrix into a device scalar (memset + one pass)
 int launch_absmax(const float *src, long long ld, long long rows, long long cols, float *out, hipStream_t st);
-int launch_scale_scalar(float *v, float factor, hipStream_t st);
+int launch_scale_scalar(float *v, float factor, hipStream_t st, unsigned tag = 0);   // tag != 0: also v[1] = tag (bit pattern)
+// slot[0] = max|src[0..n)| UNLESS slot[1] already holds `tag` (then slot[0] is trusted as it is): two launches, the scan
+// returns at once for a tagged slot.  n % 4 == 0, src 16-byte aligned.
+int launch_absmax_unless_tagged(const float *src, long long n, float *slot, unsigned tag, hipStream_t st);
 int launch_gemm_tn(GemmTnArgs &G, int dtype, hipStream_t st);
 // grouped: plans tiles / splits for all problems (balanced K steps per workgroup), carves `ws` into the partial slabs
 int launch_gemm_tn_batch(GemmTnBatch &B, int dtype, void *ws, size_t ws_bytes, hipStream_t st);

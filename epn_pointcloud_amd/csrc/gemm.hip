@@ -17,6 +17,7 @@
 
 namespace epn {
 namespace {
+EPN_F2_SENTINEL_DECL
 
 typedef __attribute__((address_space(3))) void lds_void;
 typedef __attribute__((address_space(1))) const void glb_void;
@@ -523,12 +524,17 @@ __global__ __launch_bounds__(64 * WGM * WGN) void gemm_tn_f32_kernel(GemmTnBatch
     // ---- epilogue: MFMA row ri of tile tm = output row base1 + TM*ri + tm; column li of tile tn = base2 + TN*li + tn
     if constexpr (X3 == 2) {
         const float ux = f2_inverse(x_scale), uy = f2_inverse(y_scale);
+        float chk = 0.0f;                           // NaN iff an accumulator of this lane is inf / NaN (gemm.h: EPN_F2_CHECK)
 #pragma unroll
         for (int i = 0; i < TM; ++i)
 #pragma unroll
             for (int j = 0; j < TN; ++j)
 #pragma unroll
-                for (int r = 0; r < 16; ++r) acc[i][j][r] = acc[i][j][r] * ux * uy;
+                for (int r = 0; r < 16; ++r) {
+                    chk = fmaf(acc[i][j][r], 0.0f, chk);
+                    acc[i][j][r] = acc[i][j][r] * ux * uy;
+                }
+        EPN_F2_CHECK(chk);
     }
     float *__restrict__ C = G.nsplit > 1 ? static_cast<float *>(G.part) + (size_t)split * G.N1 * G.N2
                                          : static_cast<float *>(G.C);
@@ -748,12 +754,17 @@ __global__ __launch_bounds__(64 * WGM * WGN) void gemm_tn_x3_kernel(GemmTnBatch 
 
     if constexpr (NPL == 2) {
         const float ux = f2_inverse(f2_scale_of(*G.x_amax)), uy = f2_inverse(y_scale);
+        float chk = 0.0f;                           // NaN iff an accumulator of this lane is inf / NaN (gemm.h: EPN_F2_CHECK)
 #pragma unroll
         for (int i = 0; i < TM; ++i)
 #pragma unroll
             for (int j = 0; j < TN; ++j)
 #pragma unroll
-                for (int r = 0; r < 16; ++r) acc[i][j][r] = acc[i][j][r] * ux * uy;
+                for (int r = 0; r < 16; ++r) {
+                    chk = fmaf(acc[i][j][r], 0.0f, chk);
+                    acc[i][j][r] = acc[i][j][r] * ux * uy;
+                }
+        EPN_F2_CHECK(chk);
     }
     // ---- epilogue: MFMA row ri of tile i = output row base1 + 32 i + ri; column li of tile j = base2 + TN*li + j
     float *__restrict__ C = G.nsplit > 1 ? static_cast<float *>(G.part) + (size_t)split * G.N1 * G.N2
@@ -1619,6 +1630,18 @@ int launch_tn_typed(GemmTnBatch &B, void *ws, size_t ws_bytes, hipStream_t st, i
 }
 
 }  // namespace
+
+long long f2_nonfinite_take_gemm(bool reset) {
+    unsigned v = 0;
+    hipError_t e = hipMemcpyFromSymbol(&v, HIP_SYMBOL(g_f2_nonfinite), sizeof(v), 0, hipMemcpyDeviceToHost);
+    if (e != hipSuccess) return -(long long)e;
+    if (reset && v) {
+        const unsigned zero = 0;
+        e = hipMemcpyToSymbol(HIP_SYMBOL(g_f2_nonfinite), &zero, sizeof(zero), 0, hipMemcpyHostToDevice);
+        if (e != hipSuccess) return -(long long)e;
+    }
+    return (long long)v;
+}
 
 // block tile of the TN kernels for an output of N1 x N2 (shared with the workspace query)
 void gemm_tn_tile(int dtype, int N1, int N2, int *bn1, int *bn2) {   // dtype: 0 fp32, 1 bf16, 2 fp32 split form

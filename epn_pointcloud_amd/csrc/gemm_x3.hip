@@ -21,6 +21,7 @@
 
 namespace epn {
 namespace {
+EPN_F2_SENTINEL_DECL
 
 typedef __attribute__((address_space(3))) void lds_void;
 typedef __attribute__((address_space(1))) const void glb_void;
@@ -385,6 +386,7 @@ __global__ __launch_bounds__(64 * WGM * WGN) void gemm_nt_x3_kernel(GemmNtBatch 
     float *__restrict__ C = static_cast<float *>(P.C);
     if constexpr (NPL == 2) {                       // undo the operand scales: one exact power-of-two multiply per value
         const float ua = f2_inverse(a_scale);
+        float chk = 0.0f;                           // NaN iff an accumulator of this lane is inf / NaN (gemm.h: EPN_F2_CHECK)
 #pragma unroll
         for (int j = 0; j < TN; ++j) {              // the weights are scaled per row = per output column (split_rows2_batch_kernel)
             int n = n0 + (wn * TN + j) * 32 + li;
@@ -393,8 +395,12 @@ __global__ __launch_bounds__(64 * WGM * WGN) void gemm_nt_x3_kernel(GemmNtBatch 
 #pragma unroll
             for (int i = 0; i < TM; ++i)
 #pragma unroll
-                for (int r = 0; r < 16; ++r) acc[i][j][r] *= u;
+                for (int r = 0; r < 16; ++r) {
+                    chk = fmaf(acc[i][j][r], 0.0f, chk);
+                    acc[i][j][r] *= u;
+                }
         }
+        EPN_F2_CHECK(chk);
     }
     if (P.stats) nt_col_stats<TM, TN, float>(acc, P.stats, P.M, P.N, m0 + wm * TM * 32, n0 + wn * TN * 32, li, lj);
     // (round 5, measured and dropped: whole tiles leaving through LDS -- a wave's 32 x 32 TN accumulator block transposed in the
@@ -460,6 +466,18 @@ inline size_t planes_bytes(const GemmNtProb &p) { return ((size_t)6 * p.N * p.K 
 
 }  // namespace
 
+long long f2_nonfinite_take_x3(bool reset) {
+    unsigned v = 0;
+    hipError_t e = hipMemcpyFromSymbol(&v, HIP_SYMBOL(g_f2_nonfinite), sizeof(v), 0, hipMemcpyDeviceToHost);
+    if (e != hipSuccess) return -(long long)e;
+    if (reset && v) {
+        const unsigned zero = 0;
+        e = hipMemcpyToSymbol(HIP_SYMBOL(g_f2_nonfinite), &zero, sizeof(zero), 0, hipMemcpyHostToDevice);
+        if (e != hipSuccess) return -(long long)e;
+    }
+    return (long long)v;
+}
+
 bool gemm_nt_x3_ok(const GemmNtBatch &B) {
     for (int i = 0; i < B.nprob; ++i) {
         const GemmNtProb &p = B.p[i];
@@ -486,11 +504,39 @@ size_t gemm_nt_f2_workspace(const GemmNtBatch &B) {
 }
 
 namespace {
-__global__ void scale_scalar_kernel(float *v, float f) { *v *= f; }
+__global__ void scale_scalar_kernel(float *v, float f, unsigned tag) {
+    *v *= f;
+    if (tag) reinterpret_cast<unsigned *>(v)[1] = tag;
+}
+// A maximum that travels between two calls in a caller-owned buffer (the tail of `saved`, inter_split.hip) carries a tag word
+// behind it.  A buffer without the tag -- written by a 0.2 forward pass, or never written -- must not be trusted as a scale:
+// the guard zeroes the slot, and the scan below (which a tagged buffer skips in its first instruction) takes the maximum.
+__global__ void amax_guard_kernel(unsigned *slot, unsigned tag) {
+    if (slot[1] != tag) slot[0] = 0u;
+}
+__global__ __launch_bounds__(256) void absmax_untagged_kernel(const u32x4 *__restrict__ src, long long n4, unsigned *__restrict__ slot,
+                                                              unsigned tag) {
+    if (__atomic_load_n(slot + 1, __ATOMIC_RELAXED) == tag) return;
+    unsigned m = 0;
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n4; i += (long long)gridDim.x * 256) m = absmax4(m, src[i]);
+    absmax_finish(m, slot);
+}
 }  // namespace
-int launch_scale_scalar(float *v, float factor, hipStream_t st) {       // *v *= factor (a bound derived from a maximum)
+int launch_scale_scalar(float *v, float factor, hipStream_t st, unsigned tag) {   // *v *= factor (a bound derived from a maximum); tag != 0: v[1] = tag
     if (!v) return EPN_ENULL;
-    EPN_LAUNCH_AUX(scale_scalar_kernel, dim3(1), dim3(1), 0, st, v, factor);
+    EPN_LAUNCH_AUX(scale_scalar_kernel, dim3(1), dim3(1), 0, st, v, factor, tag);
+    EPN_CHECK_LAUNCH();
+    return 0;
+}
+int launch_absmax_unless_tagged(const float *src, long long n, float *slot, unsigned tag, hipStream_t st) {
+    if (!slot || !src) return EPN_ENULL;
+    if (n % 4 || ((uintptr_t)src & 15)) return EPN_EINVAL;
+    EPN_LAUNCH_AUX(amax_guard_kernel, dim3(1), dim3(1), 0, st, reinterpret_cast<unsigned *>(slot), tag);
+    EPN_CHECK_LAUNCH();
+    const long long n4 = n / 4, want = (n4 + 4 * 256 - 1) / (4 * 256);
+    const unsigned g = (unsigned)(want < 1 ? 1 : (want < 2048 ? want : 2048));
+    EPN_LAUNCH_AUX(absmax_untagged_kernel, dim3(g), dim3(256), 0, st, reinterpret_cast<const u32x4 *>(src), n4,
+                   reinterpret_cast<unsigned *>(slot), tag);
     EPN_CHECK_LAUNCH();
     return 0;
 }
@@ -665,6 +711,13 @@ extern "C" int epn_gemm_nt_split_f32(int nprob, const epn_gemm_nt_problem *probs
 extern "C" int epn_absmax_f32(const float *src, long long ld, long long rows, long long cols, float *out, epn_stream_t stream) {
     if (rows < 0 || cols < 0 || (rows > 1 && ld < cols)) return EPN_EINVAL;
     return launch_absmax(src, ld, rows, cols, out, epn_stream(stream));
+}
+
+extern "C" long long epn_f16x2_overflow_count(int reset) {
+    const long long a = f2_nonfinite_take_gemm(reset != 0);
+    if (a < 0) return a;
+    const long long b = f2_nonfinite_take_x3(reset != 0);
+    return b < 0 ? b : a + b;
 }
 
 extern "C" size_t epn_gemm_nt_f16x2_workspace_bytes(int nprob, const epn_gemm_nt_problem *probs) {

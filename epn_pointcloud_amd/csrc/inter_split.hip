@@ -65,7 +65,11 @@ int make_plan(const epn_inter_desc *d, int bf16, SplitPlan &P) {
     return 0;
 }
 
-// fp32: the grouped features + a 256-byte tail holding their maximum's bound (device scalar) for the backward GEMM
+// fp32: the grouped features + a 256-byte tail holding their maximum's bound (device scalar) for the backward GEMM, and
+// behind it a tag word.  The backward pass trusts the bound only when the tag is there: a `saved` buffer that a 0.2 forward
+// pass wrote (no tail) and that passes the size check through over-allocation has its maximum taken by a pass over the grouped
+// features instead of being read as garbage (advisor finding, round 5).
+constexpr unsigned SAVED_TAG = 0x324e5045u;   // "EPN2"
 size_t saved_need(const SplitPlan &P, int bf16) { return rnd256(P.cols * P.ck * P.esz) + (bf16 ? 0 : 256); }
 float *saved_amax(const SplitPlan &P, const void *saved) {
     return reinterpret_cast<float *>(static_cast<char *>(const_cast<void *>(saved)) + rnd256(P.cols * P.ck * P.esz));
@@ -111,7 +115,7 @@ int forward(const epn_inter_desc *d, const void *feats_cl, const float *W, void 
     float *g_amax = saved_amax(P, saved);
     const long long nf = (long long)d->b * d->p1 * d->na * d->cin;
     rc = epn::launch_absmax(static_cast<const float *>(feats_cl), nf, 1, nf, g_amax, (hipStream_t)stream);
-    if (!rc) rc = epn::launch_scale_scalar(g_amax, (float)d->nn, (hipStream_t)stream);
+    if (!rc) rc = epn::launch_scale_scalar(g_amax, (float)d->nn, (hipStream_t)stream, SAVED_TAG);
     if (rc) return rc;
     const float *am[1] = {g_amax};
     return epn_gemm_nt_f16x2_f32(1, &p, am, gemm_ws, P.f_gemm, stream);
@@ -145,6 +149,11 @@ int backward(const epn_inter_desc *d, const void *grad_out_cl, const float *W, c
         const long long ng = (long long)P.cols * d->cout;
         rc = epn::launch_absmax(static_cast<const float *>(grad_out_cl), ng, 1, ng, go_amax, (hipStream_t)stream);
         if (rc) return rc;
+        if ((P.cols * P.ck) % 4 == 0) {         // (always: ks % 4 == 0) an untagged tail is replaced by a pass over `saved`
+            rc = epn::launch_absmax_unless_tagged(static_cast<const float *>(saved), (long long)(P.cols * P.ck), saved_amax(P, saved),
+                                                  SAVED_TAG, (hipStream_t)stream);
+            if (rc) return rc;
+        }
     }
     if (grad_W) {
         // dW = dOut^T G (contraction over the b p2 na columns, deterministic split); against packed G: columns un-permuted

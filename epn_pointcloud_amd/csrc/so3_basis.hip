@@ -574,12 +574,30 @@ __global__ __launch_bounds__(64 * SB_WAVES) __attribute__((amdgpu_waves_per_eu(2
             else if (A.pstats) sb_point_stats<false>(acc, A.pstats, pt, A.c, choff0, cval, j);
         } else if (A.pstats) sb_point_stats<false>(acc, A.pstats, pt, A.c, choff0, cval, j);
         if (A.amax) {                     // rows >= na and lanes without channels hold zeros: no masking needed
+            float tmax = 0.0f;            // (fmaxf drops NaNs by itself)
 #pragma unroll
             for (int mt = 0; mt < 4; ++mt)
 #pragma unroll
                 for (int nt = 0; nt < 4; ++nt)
-                    vmax = __builtin_fmaxf(__builtin_fmaxf(vmax, __builtin_fmaxf(__builtin_fabsf(acc[mt][nt][0]), __builtin_fabsf(acc[mt][nt][1]))),
+                    tmax = __builtin_fmaxf(__builtin_fmaxf(tmax, __builtin_fmaxf(__builtin_fabsf(acc[mt][nt][0]), __builtin_fabsf(acc[mt][nt][1]))),
                                            __builtin_fmaxf(__builtin_fabsf(acc[mt][nt][2]), __builtin_fabsf(acc[mt][nt][3])));
+            // An infinite output is left OUT of the maximum, as absmax4 / split_rows2 leave non-finite elements out (advisor
+            // finding, round 5: clamped to FLT_MAX it became the scale, 2^-113, and every finite element of the buffer
+            // underflowed to zero in the consuming GEMMs; an fp32 GEMM poisons only the rows the element belongs to).  The
+            // masked rescan runs only in a wave that saw one.
+            if (__builtin_amdgcn_ballot_w64(tmax > 3.4028235e38f) != 0ull) {
+                tmax = 0.0f;
+#pragma unroll
+                for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+                    for (int nt = 0; nt < 4; ++nt)
+#pragma unroll
+                        for (int rr = 0; rr < 4; ++rr) {
+                            const float v = __builtin_fabsf(acc[mt][nt][rr]);
+                            tmax = __builtin_fmaxf(tmax, v <= 3.4028235e38f ? v : 0.0f);
+                        }
+            }
+            vmax = __builtin_fmaxf(vmax, tmax);
         }
         // acc[mt][nt][rr]: output row 16 mt + 4 j + rr, channel 4 x + nt
 #pragma unroll
@@ -596,7 +614,6 @@ __global__ __launch_bounds__(64 * SB_WAVES) __attribute__((amdgpu_waves_per_eu(2
     if (A.amax) {                         // one atomic per wave, and only when it would raise the value seen
 #pragma unroll
         for (int o = 32; o >= 1; o >>= 1) vmax = __builtin_fmaxf(vmax, __shfl_xor(vmax, o, 64));
-        vmax = __builtin_fminf(vmax, 3.4028235e38f);            // (an infinite output must not become the scale)
         const unsigned m = __builtin_bit_cast(unsigned, vmax);
         if (lane == 0 && m > __builtin_nontemporal_load(A.amax)) atomicMax(A.amax, m);
     }

@@ -190,6 +190,8 @@ class GradBuckets:
         self._pending = [len(b) for b in self.buckets]
         self._works = []
         self._handles = []
+        self.record_timing = False      # finish(): keep (start, end) of every step's collective phase in self.timings
+        self.timings = []
         hooks = hooks and collect == "accumulate" and (world > 1 or self.force)
         if hooks:
             for bi, b in enumerate(self.buckets):
@@ -253,6 +255,17 @@ class GradBuckets:
         step costs its latency per collective.  Returns the number of collectives of the step."""
         if self.world <= 1 and not self.force:
             return 0
+        rec = None
+        if self.record_timing:
+            # what the step pays for its collectives as the COMPUTE stream sees it: from the moment they are issued (after the
+            # side stream's gradients have landed) to the moment the stream may go on -- device time on CUDA tensors (events
+            # on the current stream), host time otherwise.  bench.py turns it into ms and bus bandwidth per step.
+            if self.flat.is_cuda:
+                rec = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
+                rec[0].record(torch.cuda.current_stream(self.flat.device))
+            else:
+                import time
+                rec = time.perf_counter()
         if not self.hooks:
             if one_collective:
                 saved, self.spans = self.spans, self._span_all()
@@ -271,10 +284,30 @@ class GradBuckets:
         for w in self._works:
             w.wait()
         self._works = []
+        if rec is not None:
+            if self.flat.is_cuda:
+                rec[1].record(torch.cuda.current_stream(self.flat.device))
+                self.timings.append(rec)
+            else:
+                import time
+                self.timings.append((time.perf_counter() - rec) * 1e3)
         if self.world > 1 or self.force:
             self.flat.div_(self.world)
         self._pending = [len(b) for b in self.buckets]
         return n
+
+    def collective_ms(self):
+        """Milliseconds each recorded finish() spent between issuing its collectives and being allowed to continue (needs the
+        device to be idle: synchronises); clears the record."""
+        out = []
+        for t in self.timings:
+            if isinstance(t, tuple):
+                t[1].synchronize()
+                out.append(t[0].elapsed_time(t[1]))
+            else:
+                out.append(t)
+        self.timings = []
+        return out
 
     def remove_hooks(self):
         for h in self._handles:
@@ -300,39 +333,6 @@ def stage_buckets(model):
             take(stage)
     take(model)                                   # whatever is left
     return buckets
-
-
-def allreduce_gradients(params, world, bucket_bytes=64 << 20):
-    """Stand-alone form (no GradBuckets): average the existing p.grad tensors across ranks with a few flat
-    all-reduces.  Kept for callers that own their gradient tensors; bench.py uses GradBuckets."""
-    if world <= 1:
-        return 0
-    grads = [p.grad for p in params if p.grad is not None]
-    if not grads:
-        return 0
-    buckets, cur, cur_bytes = [], [], 0
-    for g in grads:
-        nb = g.numel() * g.element_size()
-        if cur and cur_bytes + nb > bucket_bytes:
-            buckets.append(cur)
-            cur, cur_bytes = [], 0
-        cur.append(g)
-        cur_bytes += nb
-    if cur:
-        buckets.append(cur)
-    works = []
-    for bucket in buckets:
-        flat = torch.cat([g.reshape(-1) for g in bucket])
-        works.append((dist.all_reduce(flat, op=dist.ReduceOp.SUM, async_op=True), flat, bucket))
-    for work, flat, bucket in works:
-        work.wait()
-        flat.div_(world)
-        off = 0
-        for g in bucket:
-            n = g.numel()
-            g.copy_(flat[off:off + n].view_as(g))
-            off += n
-    return len(buckets)
 
 
 def broadcast_parameters(module, src=0):

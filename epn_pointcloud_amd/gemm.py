@@ -11,6 +11,7 @@ import os
 import torch
 
 from . import _lib
+from ._ab import ab
 
 
 # fp32 contractions (fp32 operands, fp32 accumulation, fp32 result in every mode):
@@ -80,6 +81,54 @@ def absmax_cached(t):
     except (AttributeError, RuntimeError):
         pass
     return a
+
+
+def mark_written(t):
+    """A tensor that already existed is about to be (or was just) written through its raw pointer by a library kernel -- an
+    accumulating scatter onto an incoming gradient, a GEMM into a caller's `out`.  Raw-pointer writes do not touch torch's
+    version counter, and the maxima remembered on tensors (`_epn_amax`) are keyed on it: a tagged tensor written this way would
+    keep a stale maximum, and the two-piece scale leaves only a factor 2-4 of headroom (advisor finding, round 5).  Bumping the
+    counter -- which the tensor shares with every view and detach() alias -- drops every such tag at once, and it is what an
+    in-place torch op on the same memory would have done.  Returns t."""
+    if t is not None:
+        torch._C._increment_version(t)
+        for cand in (t, t._base):
+            if cand is not None and getattr(cand, "_epn_amax", None) is not None:
+                try:
+                    del cand._epn_amax
+                except AttributeError:
+                    pass
+    return t
+
+
+def f16x2_overflow_count(reset=False, device=None):
+    """epn_f16x2_overflow_count of `device` (default: the current one): waves of two-piece fp16 GEMMs that ended a tile with a
+    non-finite accumulator since the counter was last cleared.  With finite operands any non-zero value means a reported
+    maximum was too small (include/epn_so3conv.h).  Synchronises; not inside a stream capture."""
+    lib = _lib.get_lib()
+    with torch.cuda.device(device if device is not None else torch.cuda.current_device()):
+        torch.cuda.synchronize()
+        n = int(lib.epn_f16x2_overflow_count(1 if reset else 0))
+    if n < 0:
+        raise RuntimeError(f"epn_f16x2_overflow_count failed: hipError {-n}")
+    return n
+
+
+# Debug mode of the scale contract (EPN_AB=1 EPN_CHECK_AMAX=1, or gemm.CHECK_AMAX = True): every maximum a two-piece GEMM is
+# about to consume is re-derived by a pass over its operand and compared on the host -- a synchronising, eager-only check that
+# turns a stale / under-reported tag into an exception naming the call (tests/test_gpu_bf16.py runs a training step under it).
+CHECK_AMAX = ab("EPN_CHECK_AMAX") == "1"
+
+
+def _check_amax(t, a, what):
+    if not CHECK_AMAX or a is None or t is None or t.dtype != torch.float32:
+        return
+    if torch.cuda.is_current_stream_capturing():
+        raise RuntimeError("EPN_CHECK_AMAX synchronises with the host: run eagerly (bench.py --no-graph)")
+    true, given = float(absmax(t).item()), float(a.item())
+    if not true <= given * (1.0 + 1e-6):
+        raise AssertionError(f"{what}: reported max|x| = {given:.9g} but the operand holds {true:.9g} "
+                             f"(stale or under-reported maximum: the two-piece scale would overflow at {4 * given:.3g})")
 
 
 def _use_amax(a):
@@ -155,6 +204,10 @@ def gemm_nt_grouped(problems, out_dtype=None, col_stats=None, a_amax=None):
             C = torch.empty((A.shape[0], Bt.shape[0]), dtype=odt, device=A.device)
         elif C.dtype != odt or C.stride(1) != 1 or tuple(C.shape) != (A.shape[0], Bt.shape[0]):
             raise ValueError("gemm_nt: output must be row-major [M,N] of the output dtype")
+        else:
+            mark_written(C)
+        if a_amax is not None and not b and FP32_MODE == "f16x2":
+            _check_amax(A, a_amax[i], f"gemm_nt problem {i} {tuple(A.shape)} x {tuple(Bt.shape)}^T, operand A")
         arr[i] = _problem(A, Bt, C)
         if col_stats is not None and col_stats[i] is not None:
             part = col_stats[i]
@@ -209,9 +262,14 @@ def gemm_tn(X, Y, out=None, x_amax=None, y_amax=None, fp32_mode=None):
         out = torch.empty((N1, N2), dtype=torch.float32, device=X.device)
     elif out.dtype != torch.float32 or out.stride(1) != 1 or tuple(out.shape) != (N1, N2):
         raise ValueError("gemm_tn: output must be row-major fp32 [N1,N2]")
+    else:
+        mark_written(out)
     mode = fp32_mode or FP32_MODE
     split = not bf and mode == "split"
     f2 = not bf and mode == "f16x2"
+    if f2:
+        _check_amax(X, x_amax, f"gemm_tn {tuple(X.shape)}^T x {tuple(Y.shape)}, operand X")
+        _check_amax(Y, y_amax, f"gemm_tn {tuple(X.shape)}^T x {tuple(Y.shape)}, operand Y")
     nbytes = int(lib.epn_gemm_tn_workspace_bytes(3 if f2 else (2 if split else bf), R, N1, N2))
     ws = torch.empty(max(nbytes, 16), dtype=torch.uint8, device=X.device)
     fn = lib.epn_gemm_tn_bf16 if bf else (lib.epn_gemm_tn_split_f32 if split else lib.epn_gemm_tn_f32)
@@ -248,6 +306,7 @@ def gemm_tn_grouped(problems, outs_into=None, x_amax=None, y_amax=None):
             C = outs_into[i]
             if C.dtype != torch.float32 or tuple(C.shape) != (X.shape[1], Y.shape[1]) or not C.is_contiguous():
                 raise ValueError("gemm_tn_grouped: outputs must be contiguous fp32 [N1,N2]")
+            mark_written(C)
         else:
             C = torch.empty((X.shape[1], Y.shape[1]), dtype=torch.float32, device=X.device)
         p = arr[i]
@@ -262,6 +321,11 @@ def gemm_tn_grouped(problems, outs_into=None, x_amax=None, y_amax=None):
     nbytes = int(lib.epn_gemm_tn_grouped_workspace_bytes(mode, len(problems), arr))
     ws = torch.empty(max(nbytes, 16), dtype=torch.uint8, device=outs[0].device)
     if mode == 3:
+        for i, (X, Y) in enumerate(problems):
+            if x_amax is not None:
+                _check_amax(_rowmajor(X, "X"), x_amax[i], f"gemm_tn_grouped problem {i}, operand X {tuple(X.shape)}")
+            if y_amax is not None:
+                _check_amax(_rowmajor(Y, "Y"), y_amax[i], f"gemm_tn_grouped problem {i}, operand Y {tuple(Y.shape)}")
         xa, k1 = _amax_array(x_amax)
         ya, k2 = _amax_array(y_amax)
         _lib.check(lib.epn_gemm_tn_grouped_f16x2(len(problems), arr, xa, ya, ws.data_ptr(), ws.numel(), _lib.stream_of(outs[0])),

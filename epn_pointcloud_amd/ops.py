@@ -443,12 +443,47 @@ class InterSO3ConvSplitFn(torch.autograd.Function):
     # Tensor handles alive on a gradient that ONLY this backward can see: the engine's argument list + the Python wrapper.
     # A consumer whose backward hands ONE tensor to two inputs (`shared + other`) leaves a third handle in the other input's
     # buffer until that node has run -- writing in place would corrupt its gradient (advisor finding, round 4).
-    _SOLE_OWNER_HANDLES = 2
+    # That baseline is a detail of the autograd engine of the torch that is running (2 in torch 2.10), so it is MEASURED once
+    # per process instead of assumed (advisor finding, round 5: one handle fewer in another version would accept a tensor with
+    # a real second owner): a probe Function receives a gradient nobody else holds and records its handle count; a second
+    # probe receives one that IS shared with another node's input buffer and must see more.  No usable measurement (no
+    # counter, or the two probes do not separate) -> never in place.
+    _SOLE_OWNER_HANDLES = None
+
+    @staticmethod
+    def _calibrate_sole_owner():
+        seen = {}
+
+        class _Probe(torch.autograd.Function):
+            @staticmethod
+            def forward(ctx, x, key):
+                ctx.key = key
+                return x.view_as(x)
+
+            @staticmethod
+            def backward(ctx, g):
+                seen[ctx.key] = g._use_count()
+                return g, None
+        try:
+            with torch.enable_grad():
+                a = torch.zeros(4, requires_grad=True)
+                (_Probe.apply(a, "sole") * 2.0).sum().backward()               # mul's backward hands over a fresh tensor
+                b = torch.zeros(4, requires_grad=True)
+                # add's backward hands ONE tensor to both inputs: the probe's gradient has a second owner (c's buffer) while it runs
+                c = torch.zeros(4, requires_grad=True)
+                (_Probe.apply(b, "shared") + c).backward(torch.ones(4))
+            sole, shared = seen.get("sole"), seen.get("shared")
+            return sole if sole is not None and shared is not None and shared > sole else 0
+        except Exception:                                         # no _use_count, or an engine that works differently
+            return 0
 
     @staticmethod
     def _sole_owner(t):
+        cls = InterSO3ConvSplitFn
+        if cls._SOLE_OWNER_HANDLES is None:
+            cls._SOLE_OWNER_HANDLES = cls._calibrate_sole_owner()
         try:
-            return t._use_count() <= InterSO3ConvSplitFn._SOLE_OWNER_HANDLES
+            return cls._SOLE_OWNER_HANDLES > 0 and t._use_count() <= cls._SOLE_OWNER_HANDLES
         except AttributeError:                                  # a torch without the counter: never in place
             return False
 
@@ -511,7 +546,9 @@ class InterSO3ConvSplitFn(torch.autograd.Function):
                     and mode != "fused" and not deterministic_bwd(G.dtype)
                     and InterSO3ConvSplitFn._may_write_into(ctx, grad_shared))
             if onto:
-                gf, grad_shared = to_cl(grad_shared, "grad_shared").detach(), None
+                # the scatter writes this tensor through its raw pointer: bump its version so that no maximum remembered on
+                # it (or on a view / alias of it) survives the write (gemm.mark_written)
+                gf, grad_shared = gemm.mark_written(to_cl(grad_shared, "grad_shared").detach()), None
             else:
                 gf = empty_cl(d.b, cin, d.p1, d.na, G.device)       # fp32: the scatter target of either dtype
             if G.dtype != torch.float32 or deterministic_bwd(G.dtype):

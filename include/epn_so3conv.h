@@ -607,6 +607,17 @@ int epn_gemm_tn_f16x2_f32(const float *X, long long ldx, const float *Y, long lo
                           epn_stream_t stream);
 int epn_gemm_tn_grouped_f16x2(int nprob, const epn_gemm_tn_problem *probs, const float *const *x_amax, const float *const *y_amax,
                               void *workspace, size_t workspace_bytes, epn_stream_t stream);
+/* The scale contract of the two-piece form made loud (round 6).  The power-of-two scale leaves a factor 2-4 below fp16's
+ * 65504, so an operand element above 2-4 x the maximum the caller REPORTED becomes inf in the split and the product silently
+ * non-finite -- where the fp32 matmul these entry points replace (torch.matmul in vgtk/vgtk/so3conv/modules.py:48-55) would
+ * have returned a finite number.  Every two-piece kernel checks its accumulators once per tile in the epilogue; a wave that
+ * ends with a non-finite accumulator bumps a sticky per-device counter.  epn_f16x2_overflow_count returns that count for the
+ * CURRENT device (reset != 0 also clears it); with finite operands any non-zero value is a violated maximum (a stale or
+ * under-reported `*_amax`).  Non-finite operands raise it too (their rows are legitimately non-finite) -- clear the counter
+ * after feeding such inputs on purpose.  Synchronous (a 4-byte device read): call it outside timed regions and never during
+ * stream capture.  A negative return is a negated hipError_t.  bench.py reports it in its line; tests/conftest.py fails any
+ * GPU test that leaves it non-zero. */
+long long epn_f16x2_overflow_count(int reset);
 /* dst[cols][rows] = src[rows][cols]^T with an optional fp32 <-> bf16 conversion (weights: W^T for the data gradient,
  * bf16 copies of the fp32 master weights); epn_cast converts a flat array. */
 int epn_transpose_cast(const void *src, void *dst, int rows, int cols, int src_bf16, int dst_bf16, epn_stream_t stream);

@@ -18,6 +18,30 @@ os.environ.setdefault("EPN_AB", "1")
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+    config.addinivalue_line("markers", "nonfinite_inputs: the test feeds inf / NaN into two-piece fp16 GEMMs on purpose "
+                                       "(the overflow sentinel is cleared, not asserted, after it)")
+
+
+@pytest.fixture(autouse=True)
+def f16x2_scale_contract(request):
+    """Finaliser of every GPU test: no two-piece fp16 GEMM of the test may have ended a tile with a non-finite accumulator
+    (epn_f16x2_overflow_count, include/epn_so3conv.h).  With finite inputs that can only be a maximum that was reported too small
+    -- the failure round 5 shipped for a day while 559 parity tests stayed green (an under-reported maximum is silent until an
+    operand exceeds 2-4 x it).  Tests that feed non-finite values on purpose carry @pytest.mark.nonfinite_inputs."""
+    if request.node.get_closest_marker("gpu") is None:
+        yield
+        return
+    import torch
+    if not torch.cuda.is_available():
+        yield
+        return
+    from epn_pointcloud_amd import gemm
+    gemm.f16x2_overflow_count(reset=True)
+    yield
+    n = gemm.f16x2_overflow_count(reset=True)
+    if request.node.get_closest_marker("nonfinite_inputs") is None:
+        assert n == 0, (f"{n} wave(s) of two-piece fp16 GEMMs ended with a non-finite accumulator during this test: a reported "
+                        "max|operand| was too small (or the test feeds non-finite inputs and lacks @pytest.mark.nonfinite_inputs)")
 
 
 def golden(name):

@@ -52,7 +52,7 @@ def full_output():
     base = {"metric": "point-clouds/sec fwd+bwd, ModelNet40 N=1024 A=60", "value": 396.923, "unit": "point-clouds/s",
             "n_gpus": 1, "steps": 20, "warmup": 5, "ms_per_step": 80.621, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f32", "data": "synthetic", "config": cfg, "roofline": r32}
-    out = dict(base)
+    out = dict(base, f16x2_overflow=0)
     out["native_fp32_mfma"] = {"value": 314.439, "unit": "point-clouds/s", "ms_per_step": 101.769, "steps": 20, "note": "x" * 200}
     out["index_kernels"] = {"fps": {"n": 1024, "m": 512, "us_per_launch": 269.8, "us_per_cloud": 8.43, "GB/s": 1.7, "bound": "l"},
                             "ball_query": {"queries": 512, "support": 1024, "K": 32, "us_per_launch": 16.3, "us_per_cloud": 0.51,
@@ -66,7 +66,11 @@ def full_output():
                       for n in ("cls_fwd", "reg_bf16", "inv_bf16")}
     out["configs"]["cls_fwd"]["roofline"] = dict(r16, step={"algorithmic_tflops": 157.0}, **other)     # forward: no PMC pass
     out["configs"]["cls_dp_rank"] = dict(base, roofline=dict(r32, step=step), overhead_ms=0.412, vs_headline=0.9947,
-                                         collect="pack+1 all-reduce", predicted_eff_8gpu=0.9876,
+                                         collect="pack+1 all-reduce", predicted_eff_8gpu=0.9876, allreduce_ms=0.061,
+                                         no_comm_ms=80.2, wire="ASSUMED 100 GB/s busbw",
+                                         dp={"ms_per_step_local": 80.6, "allreduce_ms": 0.061, "allreduce_mb": 29.9,
+                                             "allreduce_per_step": 1, "bus_gbps": None, "no_comm_ms_per_step_local": 80.2,
+                                             "eff_vs_rank_program": 0.995},
                                          assumes="t1/(t_rank+wire); wire 0.60 ms = 31.3 MB ring all-reduce, 8 GPUs, 100 GB/s busbw "
                                                  "+ 0.05 ms (ASSUMED, unmeasured), no overlap")
     out["cpu_baseline"] = {"value": 0.3734, "unit": "point-clouds/s", "cores": 16, "kind": "port", "samples": 2,
@@ -93,14 +97,31 @@ def test_one_line_report_fits_the_driver_window():
     assert set(line["roofline"]["step"]) >= {"algorithmic_tflops", "frac_fp32_matrix", "frac_bf16_pipe_x6", "hbm_gb",
                                              "hbm_over_algorithmic"}
     dpr = line["configs"]["cls_dp_rank"]
-    assert dpr["overhead_ms"] == 0.412 and dpr["predicted_eff_8gpu"] == 0.9876 and "ASSUMED" in dpr["assumes"]
+    assert dpr["overhead_ms"] == 0.412 and dpr["predicted_eff_8gpu"] == 0.9876 and "ASSUMED" in dpr["wire"]
+    assert dpr["allreduce_ms"] == 0.061 and dpr["no_comm_ms"] == 80.2 and "assumes" not in dpr     # (long form: detail file)
+    assert line["f16x2_overflow"] == 0
     assert line["configs"]["reg_bf16"]["traffic"] == 1652000000
     assert line["cpu_baseline"]["samples"] == 2 and "all_samples_s" not in line["cpu_baseline"]
     assert all("other_roof" in c for n, c in line["configs"].items() if n != "cls_dp_rank")      # nothing had to be trimmed
     assert all(set(c) <= {"value", "ms_per_step", "steps", "dtype", "workload", "bound", "frac", "kernel", "other_roof",
-                          "vs_cpu_forward", "traffic", "step", "overhead_ms", "vs_headline", "predicted_eff_8gpu", "assumes",
-                          "collect"} for c in line["configs"].values())
+                          "vs_cpu_forward", "traffic", "step", "overhead_ms", "vs_headline", "predicted_eff_8gpu", "wire",
+                          "collect", "allreduce_ms", "no_comm_ms"} for c in line["configs"].values())
     assert "per_kernel" in detail["headline"] and len(detail["headline"]["per_kernel"]) >= 6
+
+
+def test_a_multi_rank_line_explains_itself():
+    """world > 1: the line carries per-rank step times, the collective phase and its bus bandwidth, and the efficiency against
+    the comm-free rank program timed in the same run (review item 7) -- and still fits the window."""
+    out, _ = full_output()
+    for k in ("configs", "cpu_baseline", "native_fp32_mfma", "index_kernels"):
+        out.pop(k, None)                                   # single-rank extras
+    out.update(n_gpus=8, value=3100.5)
+    out["dp"] = {"ms_per_step_local": 81.9, "allreduce_ms": 0.71, "allreduce_mb": 29.9, "allreduce_per_step": 1, "bus_gbps": 77.2,
+                 "no_comm_ms_per_step_local": 80.9, "per_rank_ms_per_step": [81.7, 82.5], "per_rank_no_comm_ms": [80.4, 81.3],
+                 "per_rank_allreduce_ms": [0.55, 1.4], "eff_vs_rank_program": 0.9855}
+    line = json.loads(bench.fit_line(bench.compact_line(out)))
+    assert line["dp"]["per_rank_ms_per_step"] == [81.7, 82.5] and line["dp"]["bus_gbps"] == 77.2
+    assert line["dp"]["eff_vs_rank_program"] == 0.9855 and line["n_gpus"] == 8
 
 
 def test_emit_writes_the_detail_file_and_one_stdout_line(tmp_path, capsys, monkeypatch):

@@ -33,11 +33,17 @@ def _worker(rank, world, port, out):
     dp.broadcast_parameters(model)
     data = torch.arange(7 * 6, dtype=torch.float32).view(7, 6) / 10.0
     lo, hi = dp.shard_batch(7, rank, world)
-    loss = model(data[lo:hi]).square().sum() / 7.0          # global-mean loss, shard-local sum
+    # gradients as views of one flat buffer, no hooks, one all-reduce per bucket issued by finish() (the accumulate form
+    # without overlap), with the collective phase timed the way bench.py reports it for world > 1
+    layers = [m for m in model if isinstance(m, torch.nn.Linear)]
+    gb = dp.GradBuckets([list(layers[1].parameters()), list(layers[0].parameters())], world, hooks=False, collect="accumulate")
+    gb.record_timing = True
+    gb.zero()
+    loss = model(data[lo:hi]).square().sum() / 7.0 * world  # global-mean loss, shard-local sum; finish() averages over ranks
     loss.backward()
-    for p in model.parameters():                             # allreduce_gradients averages -> pre-scale by world
-        p.grad.mul_(world)
-    nb = dp.allreduce_gradients(list(model.parameters()), world, bucket_bytes=64)
+    nb = gb.finish()
+    ms = gb.collective_ms()
+    assert len(ms) == 1 and ms[0] >= 0.0 and gb.timings == []
     torch.save({"grads": [p.grad.clone() for p in model.parameters()], "buckets": nb, "shard": (lo, hi)},
                os.path.join(out, f"r{rank}.pt"))
     dist.destroy_process_group()
@@ -49,7 +55,7 @@ def test_two_rank_gradient_allreduce_matches_single_process(tmp_path):
     r0 = torch.load(tmp_path / "r0.pt")
     r1 = torch.load(tmp_path / "r1.pt")
     assert r0["shard"] == (0, 4) and r1["shard"] == (4, 7)
-    assert r0["buckets"] > 1                                  # small bucket size forces several all-reduces
+    assert r0["buckets"] == 2                                 # one all-reduce per bucket
     torch.manual_seed(0)
     model = torch.nn.Sequential(torch.nn.Linear(6, 5), torch.nn.ReLU(), torch.nn.Linear(5, 3))
     data = torch.arange(7 * 6, dtype=torch.float32).view(7, 6) / 10.0

@@ -497,9 +497,29 @@ def test_config_full_size_bf16(gpu, model, points, batch):
         g = torch.cat([p.grad.flatten().float().cpu() for p in net.parameters() if p.grad is not None])
         return loss.item(), feats, g
 
+    def run_backbone():
+        """The backbone's gradients probed BEFORE the head (review item 5, round 5): a fixed random linear functional of the
+        feature tensor the head would receive -- the 3DMatch head (softmax over raw attention logits -> max over 64 points -> L2
+        normalisation) amplifies a 0.4 % input difference into 13-27 % of gradient, which forced a 40 % bound on the
+        through-the-head comparison below; in front of it the backward kernels of all eight blocks are seen at their own
+        accuracy."""
+        for p in net.parameters():
+            p.grad = None
+        x = net.features(inp if model != "reg" else torch.cat((inp[:, 0], inp[:, 1]), dim=0))
+        gen = torch.Generator(device="cpu").manual_seed(9)
+        probe = torch.randn(x.feats.shape, generator=gen).to(x.feats.device)
+        (x.feats.float() * probe).sum().backward()
+        return torch.cat([p.grad.flatten().float().cpu() for p in net.backbone.parameters() if p.grad is not None])
+
     l32, f32, g32 = run()
+    gb32 = run_backbone()
     S.set_feature_dtype(net, torch.bfloat16)
     l16, f16, g16 = run()
+    gb16 = run_backbone()
+    dgb = rel_l2(gb16, gb32)
+    print(f"{model}: bf16 vs fp32 backbone gradient (probe in front of the head) rel-L2 {dgb:.4f}")
+    assert torch.isfinite(gb16).all() and gb32.abs().max() > 0
+    assert dgb < 0.05, dgb
     assert np.isfinite(l16) and torch.isfinite(f16).all() and torch.isfinite(g16).all()
     dl, df, dg = abs(l16 - l32) / abs(l32), rel_l2(f16, f32), rel_l2(g16, g32)
     print(f"{model}: bf16 vs fp32 network: loss {dl:.4f}, output rel-L2 {df:.4f}, gradient rel-L2 {dg:.4f}")

@@ -61,6 +61,19 @@ def test_bench_two_ranks_rehearsal_on_one_gpu(gpu, extra, launch):
     out = json.loads(line)
     assert out["n_gpus"] == 2 and out["config"]["global_batch"] == 8 and out["config"]["parallelism"] == "dp2"
     assert out["value"] > 0 and out["config"]["launch"] == launch     # eager: per-stage all-reduce from backward hooks
+    # a multi-rank line explains itself (review item 7): every rank's own step time, the collective phase as the compute stream
+    # sees it with its bus bandwidth, and -- graph mode -- the same step without the collective, timed in the same run on
+    # every rank at once: value / (N x that) is the efficiency against the rank program
+    d = out["dp"]
+    lo, hi = d["per_rank_ms_per_step"]
+    assert 0 < lo <= hi <= 1.05 * out["ms_per_step"] + 1.0
+    assert d["allreduce_ms"] > 0 and d["bus_gbps"] > 0 and d["allreduce_mb"] > 20 and d["allreduce_per_step"] >= 1
+    assert len(d["per_rank_allreduce_ms"]) == 2
+    if launch == "hipgraph":
+        assert d["allreduce_per_step"] == 1 and 0 < d["per_rank_no_comm_ms"][0] <= d["per_rank_no_comm_ms"][1]
+        assert 0.2 < d["eff_vs_rank_program"] < 1.5, d            # (two ranks time-slicing one GPU over gloo: not a measurement)
+    else:
+        assert d["eff_vs_rank_program"] is None
 
 
 def test_two_rank_gradients_equal_single_process_on_the_real_network(gpu, tmp_path):

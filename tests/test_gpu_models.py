@@ -211,10 +211,14 @@ _ORACLE_STEP = {}
 
 @pytest.mark.parametrize("inter_mode", ["auto", "onchip"])
 def test_full_width_cls_step_matches_oracle_loss(gpu, monkeypatch, inter_mode):
-    """Full-width classification network on 2 clouds: loss and a head / backbone gradient against the CPU oracle -- in the
-    default split form and with EPN_INTER_MODE=onchip, the COMPLETE path of north_star's fused form: every InterSO3Conv of the
-    step keeps its grouped features on chip in both directions (forward csrc/inter_fx.hip, data and weight gradients the fused
-    transposes of csrc/inter_mfma.hip; no [cols, cin*ks] tensor is ever allocated -- ops.InterSO3ConvOnChipFn)."""
+    """Full-width classification network on 2 clouds: logits, loss and EVERY parameter gradient against the CPU oracle
+    (SPConvNets/models/cls_so3net_pn.py:15-40 restated by oracle/backbone_ref.py) -- in the default split form and with
+    EPN_INTER_MODE=onchip, the COMPLETE path of north_star's fused form: every InterSO3Conv of the step keeps its grouped
+    features on chip in both directions (forward csrc/inter_fx.hip, data and weight gradients the fused transposes of
+    csrc/inter_mfma.hip; no [cols, cin*ks] tensor is ever allocated -- ops.InterSO3ConvOnChipFn).
+    Round 5 compared two of the ~100 gradient tensors the oracle computes (review); now all of them, except those whose exact
+    gradient is ZERO (biases a normalisation cancels, the first block's skip convolution over a constant occupancy feature:
+    what the oracle holds there is its own rounding noise, < 1e-3 of the largest gradient of the network)."""
     from epn_pointcloud_amd import models as M, schedule as S
     from oracle import backbone_ref as B
     from test_models_cpu import tables
@@ -224,14 +228,14 @@ def test_full_width_cls_step_matches_oracle_loss(gpu, monkeypatch, inter_mode):
     m = M.ClsSO3ConvModel(layers, out_mlps=(256,), pooling="attention").train()
     pts = S.synthetic_clouds(2, 1024, "cpu", seed=11)
     labels = torch.tensor([7, 31])
-    names = ["outblock.fc2.weight", "backbone.3.blocks.0.inter_conv.conv.basic_conv.W"]
     if "r" not in _ORACLE_STEP:                 # same seed, same weights for both forms: the oracle runs once
         ref = B.RefClsModel(layers, tables(), out_mlps=(256,), pooling="attention").train()
         ref.load_from_product(m.state_dict())
         lr, _ = ref(pts)
         loss_r = torch.nn.functional.cross_entropy(lr, labels)
-        gr = torch.autograd.grad(loss_r, [dict(ref.named_parameters())[n] for n in names])
-        _ORACLE_STEP["r"] = (lr.detach(), loss_r.detach(), [g.detach() for g in gr])
+        rp = {n: p for n, p in ref.named_parameters() if p.requires_grad}
+        gr = torch.autograd.grad(loss_r, list(rp.values()), allow_unused=True)
+        _ORACLE_STEP["r"] = (lr.detach(), loss_r.detach(), {n: g.detach() for n, g in zip(rp, gr) if g is not None})
     lr, loss_r, gr = _ORACLE_STEP["r"]
     m = m.to(gpu)
     if inter_mode == "onchip":                  # the form really is taken by the layers it serves (cin >= 16)
@@ -241,11 +245,26 @@ def test_full_width_cls_step_matches_oracle_loss(gpu, monkeypatch, inter_mode):
         monkeypatch.setattr(ops.InterSO3ConvOnChipFn, "forward", staticmethod(lambda ctx, *a: (taken.append(1), real(ctx, *a))[1]))
     lg, _ = m(pts.to(gpu))
     loss_g = torch.nn.functional.cross_entropy(lg, labels.to(gpu))
-    gg = torch.autograd.grad(loss_g, [dict(m.named_parameters())[n] for n in names])
+    pd = {n: p for n, p in m.named_parameters() if p.requires_grad}
+    assert set(gr) <= set(pd), sorted(set(gr) - set(pd))          # the oracle's module tree is the product's, key for key
+    names = sorted(gr)
+    gg = dict(zip(names, torch.autograd.grad(loss_g, [pd[n] for n in names], allow_unused=True)))
     assert (lg.detach().cpu() - lr.detach()).abs().max().item() < TOL * max(1.0, lr.abs().max().item())
     assert abs(loss_g.item() - loss_r.item()) < TOL
-    for n, u, v in zip(names, gg, gr):
-        assert grad_close(u, v), n
+    gmax = max(g.abs().max().item() for g in gr.values())
+    bad, checked = [], 0
+    for n in names:
+        v = gr[n]
+        if v.abs().max().item() < 1e-3 * gmax:                     # exact gradient zero: nothing but rounding on either side
+            assert gg[n] is None or gg[n].abs().max().item() < 2e-3 * gmax, n
+            continue
+        checked += 1
+        if gg[n] is None or not grad_close(gg[n], v):
+            bad.append((n, None if gg[n] is None else ((gg[n].detach().cpu().reshape(v.shape) - v).norm() / v.norm()).item()))
+    assert not bad, bad
+    assert checked >= 40, checked                                  # 7 blocks x (2 conv W + skip W + 2 norm affine pairs) + head
+    for n in ("outblock.fc2.weight", "backbone.3.blocks.0.inter_conv.conv.basic_conv.W", "backbone.0.blocks.1.intra_conv.conv.basic_conv.W"):
+        assert n in gr and gr[n].abs().max().item() >= 1e-3 * gmax, n   # (the named ones of round 5 are among the checked)
     if inter_mode == "onchip":
         assert len(taken) >= 6, taken
 
@@ -411,7 +430,10 @@ def test_default_bench_run_prints_one_small_parsable_line(gpu, tmp_path):
     # timed region) costs at most 3 % of the single-GPU step (review item 1; measured 0.x ms)
     dpr = line["configs"]["cls_dp_rank"]
     assert dpr["vs_headline"] >= 0.97 and dpr["overhead_ms"] < 0.03 * line["ms_per_step"], dpr
-    assert 0.9 < dpr["predicted_eff_8gpu"] <= 1.02 and "ASSUMED" in dpr["assumes"]
+    assert 0.9 < dpr["predicted_eff_8gpu"] <= 1.02 and "ASSUMED" in dpr["wire"]
+    # measured in the rank program's own run: the 1-rank all-reduce + average of the 31 MB buffer, and the step without it
+    assert 0 < dpr["allreduce_ms"] < 2.0 and 0.9 * dpr["ms_per_step"] < dpr["no_comm_ms"] <= 1.02 * dpr["ms_per_step"], dpr
+    assert line["f16x2_overflow"] == 0                        # the overflow sentinel of the two-piece GEMMs over the timed region
     st = line["roofline"]["step"]
     assert 100 < st["algorithmic_tflops"] < 400 and st["hbm_gb"] > st["algorithmic_gb"]
     assert 0 < st.get("frac_bf16_pipe_x3", st.get("frac_bf16_pipe_x6", 0)) < 1

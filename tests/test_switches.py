@@ -24,6 +24,23 @@ def test_ab_switches_are_inert_outside_ab_mode(monkeypatch):
     assert _ab.ab("EPN_SHARE_INPUT_GRAD") == "1"
 
 
+def test_a_stray_ab_variable_is_reported_once(monkeypatch):
+    """Outside A/B mode an A/B variable changes nothing -- and says so, once per process (advisor finding, round 5)."""
+    import warnings
+    from epn_pointcloud_amd import _ab
+    monkeypatch.setenv("EPN_AB", "0")
+    monkeypatch.setenv("EPN_NORM_PAIR", "0")
+    monkeypatch.setattr(_ab, "_WARNED", False)
+    monkeypatch.setattr(_ab, "_RESOLVED", {})
+    with warnings.catch_warnings(record=True) as w:
+        warnings.simplefilter("always")
+        assert _ab.ab("EPN_NORM_PAIR") == "1"
+        assert _ab.ab("EPN_GROUP_PACKED") == "1"
+        assert _ab.ab("EPN_NORM_PAIR") == "1"
+    msgs = [str(x.message) for x in w if "EPN_NORM_PAIR=0 ignored" in str(x.message)]
+    assert len(msgs) == 1, [str(x.message) for x in w]
+
+
 def test_every_variable_the_package_reads_is_listed():
     from epn_pointcloud_amd import _ab
     seen = set()
