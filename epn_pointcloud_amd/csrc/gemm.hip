@@ -300,6 +300,26 @@ __device__ __forceinline__ void split3(const float (&x)[8], bf16x8 &h, bf16x8 &m
 #ifndef EPN_TN_SINGLE_TARGET_BF16
 #define EPN_TN_SINGLE_TARGET_BF16 512
 #endif
+// Image of the staged rows of the bf16 weight-gradient kernels (round 6).  A 16-lane group of `ds_read_b64_tr_b16` reads four
+// consecutive rows of a 16-column tile (32 bytes each); the instruction is serviced in two 32-lane groups, i.e. eight rows
+// ({r .. r+3} of two lane groups 8 rows apart) at once, and the bank of a byte is (a / 4) mod 64.  In the linear image of
+// the 128 x 256 tile a row is 768 bytes = 3 x 256: all eight rows start on bank 0 and the 64 chunks of a wave queue on 8
+// banks -- SQ_LDS_BANK_CONFLICT / SQ_LDS_IDX_ACTIVE 0.75-0.88 in rounds 3-5's PMC files (review, round 5).  1: the 16-byte
+// slots of row r are XOR-ed with 2 rho(r), rho = (r & 3) | ((r >> 3) & 1) << 2 -- applied to the SOURCE address of the
+// direct-to-LDS loads (their LDS side is lane-linear), so the eight rows of a group land on eight different 32-byte windows
+// of the 256-byte bank row.  Needs operand regions that are multiples of 16 slots (128 columns): the 128 x 256 tiles;
+// narrower tiles keep the linear image (tools/lds_tr_probe.hip measures the candidates).
+#ifndef EPN_TN_SWZ
+#define EPN_TN_SWZ 1
+#endif
+__device__ __forceinline__ int tn_row_swz(int r) { return 2 * ((r & 3) | (((r >> 3) & 1) << 2)); }
+// column (bf16 index inside the staged row) where the swizzled image keeps logical column `col` of row r; rows r and r + 4
+// share the mask (bit 2 of r is not used), so the second read of a fragment keeps its fixed row offset
+template <bool SWZ>
+__device__ __forceinline__ int tn_swz_col(int col, int r) {
+    if constexpr (!SWZ) return col;
+    return (((col >> 3) ^ tn_row_swz(r)) << 3) | (col & 7);
+}
 #ifndef EPN_TN_WIDE_NSTG
 #define EPN_TN_WIDE_NSTG 3
 #endif
@@ -831,13 +851,16 @@ __global__ __launch_bounds__(64 * WGM * WGN) void gemm_tn_bf16_kernel(GemmTnBatc
     const __bf16 *__restrict__ X = static_cast<const __bf16 *>(G.X);
     const __bf16 *__restrict__ Y = static_cast<const __bf16 *>(G.Y);
 
+    constexpr bool SWZ = EPN_TN_SWZ && BN1 % 128 == 0 && BN2 % 128 == 0;   // (see EPN_TN_SWZ)
     const __bf16 *src[IPW];
     long long sstep[IPW];
 #pragma unroll
     for (int i = 0; i < IPW; ++i) {
         const int q = wave + i * NW;
         const int eo = 512 * q + 8 * lane;            // bf16 offset inside the [BR][ROWE] image
-        const int r = eo / ROWE, c = eo % ROWE;
+        const int r = eo / ROWE;
+        int c = eo % ROWE;
+        if constexpr (SWZ) c = 8 * ((c >> 3) ^ tn_row_swz(r));      // this LDS slot holds the row's slot (s ^ swz): an involution
         if (c < BN1) {
             int n = n1_0 + c;
             n = n < G.N1 - 8 ? n : G.N1 - 8;
@@ -880,7 +903,7 @@ __global__ __launch_bounds__(64 * WGM * WGN) void gemm_tn_bf16_kernel(GemmTnBatc
         bf16x8 a[TM], b[TN];
 #pragma unroll
         for (int i = 0; i < TM; ++i) {
-            const int col = (wm * TM + i) * 16 + tr_col;
+            const int col = tn_swz_col<SWZ>((wm * TM + i) * 16 + tr_col, tr_row);
             const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
                 (__attribute__((address_space(3))) s16x4 *)(base + ((tr_row)*ROWE + col) * 2));
             const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
@@ -891,7 +914,7 @@ __global__ __launch_bounds__(64 * WGM * WGN) void gemm_tn_bf16_kernel(GemmTnBatc
         }
 #pragma unroll
         for (int j = 0; j < TN; ++j) {
-            const int col = BN1 + (wn * TN + j) * 16 + tr_col;
+            const int col = tn_swz_col<SWZ>(BN1 + (wn * TN + j) * 16 + tr_col, tr_row);
             const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
                 (__attribute__((address_space(3))) s16x4 *)(base + ((tr_row)*ROWE + col) * 2));
             const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
@@ -987,13 +1010,16 @@ __global__ __launch_bounds__(64 * WGM * WGN) void gemm_tn_bf16_ring_kernel(GemmT
     // every wave issues IPW loads per stage so that one vmcnt value holds for all (a wave past the last piece requests
     // piece q - NI again: same bytes to the same place); rows past the end of the operands (last stage of the last
     // split) are clamped to the last row -- loaded, never multiplied
+    constexpr bool SWZ = EPN_TN_SWZ && BN1 % 128 == 0 && BN2 % 128 == 0;   // (see EPN_TN_SWZ)
     const __bf16 *src[IPW], *lim[IPW];
     long long sstep[IPW];
 #pragma unroll
     for (int i = 0; i < IPW; ++i) {
         const int q = (wave + i * NW) % NI;
         const int eo = 512 * q + 8 * lane;            // bf16 offset inside the [BR][ROWE] image
-        const int r = eo / ROWE, c = eo % ROWE;
+        const int r = eo / ROWE;
+        int c = eo % ROWE;
+        if constexpr (SWZ) c = 8 * ((c >> 3) ^ tn_row_swz(r));
         if (c < BN1) {
             int n = n1_0 + c;
             n = n < G.N1 - 8 ? n : G.N1 - 8;
@@ -1048,7 +1074,7 @@ __global__ __launch_bounds__(64 * WGM * WGN) void gemm_tn_bf16_ring_kernel(GemmT
             s16x4 lo[TM + TN], hi[TM + TN];
 #pragma unroll
             for (int f = 0; f < TM + TN; ++f) {
-                const int col = f < TN ? BN1 + (wn * TN + f) * 16 + tr_col : (wm * TM + (f - TN)) * 16 + tr_col;
+                const int col = tn_swz_col<SWZ>(f < TN ? BN1 + (wn * TN + f) * 16 + tr_col : (wm * TM + (f - TN)) * 16 + tr_col, tr_row);
                 const unsigned ad =
                     (unsigned)(uintptr_t)(__attribute__((address_space(3))) char *)(base + (tr_row * ROWE + col) * 2);
                 asm volatile("ds_read_b64_tr_b16 %0, %1" : "=v"(lo[f]) : "v"(ad));

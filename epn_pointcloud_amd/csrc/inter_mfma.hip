@@ -1170,6 +1170,18 @@ __global__ __launch_bounds__(64 * GP) void inter_ungroup_shared_kernel(InterArgs
     // spreads the four lane groups over the banks just as evenly, and with 16-bit index arrays the tile is 78 KB -- TWO
     // workgroups per CU (at 86 KB, one: 1.68-1.78 -> 1.76-1.89 ms per layer)
     constexpr int SS = 16 * CW + (CW == 2 ? 2 : 4);
+    // CW = 2 (row pitch 34 floats): a `ds_write_b32` of the per-slot stores is serviced in two 32-lane groups, lane groups
+    // j = 0, 1 (rows 4 apart: 4 x 34 = 136 = 8 mod 32 banks) overlapped on 8 of their 16 banks -- a 2-way conflict on every
+    // store, SQ_LDS_BANK_CONFLICT / SQ_LDS_IDX_ACTIVE 0.30-0.34 since round 3's "padding of 2 floats" (review, round 5; the
+    // 16-point instances with pitch 20 / 68 sit at 0.002).  The tile ROW of slot n = 16 t + 4 j + r is free as long as writers
+    // and readers agree: with bits 2 and 3 of the row swapped the two lane groups of a store are 8 rows = 272 = 16 banks apart
+    // (disjoint), at the same 78 KB.  The readers' slot words (pk[], and list[] for destinations with more than three slots)
+    // carry the permuted row.
+#ifndef EPN_UNG_ROWPERM
+#define EPN_UNG_ROWPERM 1
+#endif
+    constexpr bool RP = EPN_UNG_ROWPERM && CW == 2 && !DET;
+    auto rowp = [](unsigned e) -> unsigned { return RP ? ((e & ~12u) | ((e & 4u) << 1) | ((e & 8u) >> 1)) : e; };
     typedef typename std::conditional<CW == 2, short, int>::type ix_t;   // destinations < 32768 (p1 <= USH_TAB), slots < 1024
     static_assert((CW == 1 && CS == 1) || !DET, "the deterministic form handles one chunk per step");
     constexpr int NTH = 64 * GP;
@@ -1315,7 +1327,7 @@ __global__ __launch_bounds__(64 * GP) void inter_ungroup_shared_kernel(InterArgs
     int *pk = slot_of;                          // (its readers finished before the barrier above)
     for (int u = tid; u < U; u += NTH) {
         const int k0 = off[u], len = off[u + 1] - k0;
-        const unsigned s0 = list[k0], s1 = len > 1 ? list[k0 + 1] : E, s2 = len > 2 ? list[k0 + 2] : E;
+        const unsigned s0 = rowp(list[k0]), s1 = len > 1 ? rowp(list[k0 + 1]) : E, s2 = len > 2 ? rowp(list[k0 + 2]) : E;
         pk[u] = (int)(s0 | (s1 << 10) | (s2 << 20) | (len > 3 ? 1u << 30 : 0u));
         // element offset of the destination's gradient row inside the cloud (cnt[] is dead by now unless DET keeps its slab
         // rows there): the atomic's address becomes a wave-uniform 64-bit base + this 32-bit offset -- round 3 rebuilt it per
@@ -1428,7 +1440,7 @@ __global__ __launch_bounds__(64 * GP) void inter_ungroup_shared_kernel(InterArgs
 #ifdef EPN_TUNING
                         if (!(A.wk & 4) || tt[r] == 12345.678f)
 #endif
-                        buf[(16 * t + 4 * j + r) * SS + 16 * cw] = tt[r] * h.mul[t][r];
+                        buf[(16 * t + (RP ? 8 * (j & 1) + 4 * (j >> 1) : 4 * j) + r) * SS + 16 * cw] = tt[r] * h.mul[t][r];
                 }
             __syncthreads();
             const float *rb = Tb + (ph & (NB - 1)) * BS;
@@ -1444,7 +1456,7 @@ __global__ __launch_bounds__(64 * GP) void inter_ungroup_shared_kernel(InterArgs
                 sum += rb[((e >> 20) & 1023u) * SS + c];
                 if (e >> 30) {
                     const int k1 = off[u + 1];
-                    for (int k = off[u] + 3; k < k1; ++k) sum += rb[list[k] * SS + c];
+                    for (int k = off[u] + 3; k < k1; ++k) sum += rb[rowp((unsigned)list[k]) * SS + c];
                 }
                 if constexpr (DET) {
                     TG *srow = reinterpret_cast<TG *>(A.out) + ((size_t)cnt[u] * A.na + a) * A.cin + 16 * ct + c;

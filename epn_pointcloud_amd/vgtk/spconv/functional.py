@@ -1,8 +1,6 @@
 """Grouping helpers shared by the SO(3) path (vgtk/vgtk/spconv/functional.py).  The fused modules in
 vgtk.so3conv never materialise what these return; they exist so code written against the reference's
 functional API keeps working, and they too run on the HIP library (no CPU path)."""
-import math
-
 import torch
 
 from .. import pc as pctk
@@ -35,14 +33,16 @@ def ball_query(query_points, support_points, radius, n_sample, support_feats=Non
 
 
 def batched_index_select(input, dim, index):
-    """spconv/functional.py:361-369 (used by SPConvNets for the strided skip connection)."""
-    for ii in range(1, len(input.shape)):
-        if ii != dim:
-            index = index.unsqueeze(ii)
-    expanse = list(input.shape)
-    expanse[0] = -1
-    expanse[dim] = -1
-    return torch.gather(input, dim, index.expand(expanse))
+    """spconv/functional.py:361-369: out[b, ..., j, ...] = input[b, ..., index[b, j], ...] along `dim` (used by SPConvNets for
+    the strided skip connection).  The [b, c, p, a] feature case is whole (anchor, channel) rows moving: the library's row
+    gather (ops.gather_rows: epn_gather_rows forward, the accumulating epn_scatter_rows_add backward); any other rank, axis
+    or dtype is torch.gather with the index laid along `dim` and broadcast over the remaining axes."""
+    if dim == 2 and input.dim() == 4 and index.dim() == 2 and input.is_cuda and input.dtype in ops.FEATURE_DTYPES:
+        return ops.gather_rows(input, index)
+    lead = [1] * input.dim()
+    lead[0], lead[dim] = index.shape[0], index.shape[1]
+    full = [-1 if ax in (0, dim) else n for ax, n in enumerate(input.shape)]
+    return torch.gather(input, dim, index.reshape(lead).expand(full))
 
 
 def inter_zpconv_grouping_naive(inter_idx, inter_w, feats):
@@ -59,28 +59,33 @@ def inter_zpconv_grouping_naive(inter_idx, inter_w, feats):
     return out.view(b, c, ks, p, a).contiguous()
 
 
+def _neighbour_mean(inter_idx, feats):
+    """Mean of every output point's neighbour rows, [b, c, p, a]: the shadow row (index n_points, zeros) stands in for the
+    slots the ball query left empty, exactly as the reference's gather-then-mean does -- so the divisor is the slot count."""
+    b, p, slots = inter_idx.shape
+    padded = add_shadow_feature(feats)
+    rows = batched_index_select(padded, 2, inter_idx.reshape(b, p * slots).long())      # [b, c, p * slots, a]
+    return rows.reshape(b, feats.shape[1], p, slots, feats.shape[3]).mean(dim=3)
+
+
 def inter_pooling_naive(inter_idx, sample_idx, feats, alpha=0.5):
-    """spconv/functional.py:393-399 (pooling='stride'; unused by the shipped models)."""
-    b, p, pnn = inter_idx.shape
-    a = feats.shape[3]
-    new_feats = batched_index_select(feats, 2, sample_idx.long())
-    grouped = batched_index_select(add_shadow_feature(feats), 2, inter_idx.long().view(b, -1)).view(b, -1, p, pnn, a)
-    return alpha * new_feats + (1 - alpha) * grouped.mean(3)
+    """spconv/functional.py:393-399 (pooling='stride'; unused by the shipped models): the sampled point's own features blended
+    with the mean over its ball."""
+    own = batched_index_select(feats, 2, sample_idx.long())
+    return torch.lerp(_neighbour_mean(inter_idx, feats), own, alpha)
 
 
 def inter_blurring_naive(inter_idx, feats, alpha=0.5):
-    """spconv/functional.py:402-407 (pooling='no-stride'; unused by the shipped models)."""
-    b, p, pnn = inter_idx.shape
-    _, c, q, a = feats.shape
-    assert p == q
-    grouped = batched_index_select(add_shadow_feature(feats), 2, inter_idx.long().view(b, -1)).view(b, -1, p, pnn, a)
-    return alpha * feats + (1 - alpha) * grouped.mean(3)
+    """spconv/functional.py:402-407 (pooling='no-stride'; unused by the shipped models): as above with every point its own
+    sample, so the ball query must have been made for all of them."""
+    if inter_idx.shape[1] != feats.shape[2]:
+        raise AssertionError(f"inter_blurring_naive: {inter_idx.shape[1]} neighbourhoods for {feats.shape[2]} points")
+    return torch.lerp(_neighbour_mean(inter_idx, feats), feats, alpha)
 
 
 def inter_zpconv_grouping_ball(xyz, stride, radius, n_neighbor, lazy_sample=True):
-    """spconv/functional.py:412-421 -> (grouped_xyz [b,3,p2,nn], ball_idx, sample_idx, sample_xyz)."""
-    n_sample = math.ceil(xyz.shape[2] / stride)
-    idx, sample_xyz = pctk.furthest_sample(xyz, n_sample, lazy_sample)
-    ball_idx, grouped_xyz = ball_query(sample_xyz, xyz, radius, n_neighbor)
-    grouped_xyz = grouped_xyz - sample_xyz.unsqueeze(3)
-    return grouped_xyz, ball_idx, idx, sample_xyz
+    """spconv/functional.py:412-421 -> (grouped_xyz [b,3,p2,nn] relative to the ball centres, ball_idx, sample_idx, sample_xyz):
+    FPS picks ceil(n / stride) centres, the ball query groups the cloud around them."""
+    centres_idx, centres = pctk.furthest_sample(xyz, int(-(-xyz.shape[2] // stride)), lazy_sample)
+    ball_idx, neighbours = ball_query(centres, xyz, radius, n_neighbor)
+    return neighbours - centres[..., None], ball_idx, centres_idx, centres

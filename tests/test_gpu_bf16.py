@@ -502,24 +502,40 @@ def test_config_full_size_bf16(gpu, model, points, batch):
         feature tensor the head would receive -- the 3DMatch head (softmax over raw attention logits -> max over 64 points -> L2
         normalisation) amplifies a 0.4 % input difference into 13-27 % of gradient, which forced a 40 % bound on the
         through-the-head comparison below; in front of it the backward kernels of all eight blocks are seen at their own
-        accuracy."""
+        accuracy.  Returns {parameter name: gradient}."""
         for p in net.parameters():
             p.grad = None
         x = net.features(inp if model != "reg" else torch.cat((inp[:, 0], inp[:, 1]), dim=0))
         gen = torch.Generator(device="cpu").manual_seed(9)
         probe = torch.randn(x.feats.shape, generator=gen).to(x.feats.device)
         (x.feats.float() * probe).sum().backward()
-        return torch.cat([p.grad.flatten().float().cpu() for p in net.backbone.parameters() if p.grad is not None])
+        return {n: p.grad.detach().float().cpu() for n, p in net.backbone.named_parameters() if p.grad is not None}
 
     l32, f32, g32 = run()
     gb32 = run_backbone()
     S.set_feature_dtype(net, torch.bfloat16)
     l16, f16, g16 = run()
     gb16 = run_backbone()
-    dgb = rel_l2(gb16, gb32)
-    print(f"{model}: bf16 vs fp32 backbone gradient (probe in front of the head) rel-L2 {dgb:.4f}")
-    assert torch.isfinite(gb16).all() and gb32.abs().max() > 0
+    # The first block's skip convolution sees the constant occupancy feature: its output is constant per channel, the
+    # InstanceNorm behind it subtracts that constant and divides the ROUNDING NOISE that is left by sqrt(eps) -- the weight's
+    # exact gradient is zero and what either network holds there is O(1) noise (same exclusion as
+    # test_captured_step_reproduces_the_eager_gradients).  Everything else is compared, parameter by parameter.
+    noise = {"0.blocks.0.skip_conv.weight", "0.blocks.0.skip_conv.bias"}
+    gmax = max(v.abs().max().item() for n, v in gb32.items() if n not in noise)
+    rows = []
+    for n, v in gb32.items():
+        if n in noise or v.abs().max().item() < 1e-3 * gmax:
+            continue
+        rows.append((rel_l2(gb16[n], v), n, v.abs().max().item()))
+    rows.sort(reverse=True)
+    for r in rows[:6]:
+        print(f"{model}: backbone gradient bf16 vs fp32 (probe in front of the head) {r[1]}: rel-L2 {r[0]:.4f}, scale {r[2]:.3g}")
+    keep = [n for _, n, _ in rows]
+    dgb = rel_l2(torch.cat([gb16[n].flatten() for n in keep]), torch.cat([gb32[n].flatten() for n in keep]))
+    print(f"{model}: backbone gradient bf16 vs fp32, {len(keep)} parameters together: rel-L2 {dgb:.4f}")
+    assert all(torch.isfinite(v).all() for v in gb16.values()) and len(keep) >= 20
     assert dgb < 0.05, dgb
+    assert rows[0][0] < 0.15, rows[0]
     assert np.isfinite(l16) and torch.isfinite(f16).all() and torch.isfinite(g16).all()
     dl, df, dg = abs(l16 - l32) / abs(l32), rel_l2(f16, f32), rel_l2(g16, g32)
     print(f"{model}: bf16 vs fp32 network: loss {dl:.4f}, output rel-L2 {df:.4f}, gradient rel-L2 {dg:.4f}")
