@@ -31,7 +31,8 @@ EXPORTS = [
     "epn_transpose_cast", "epn_cast", "epn_gemm_tn_grouped_workspace_bytes", "epn_gemm_tn_grouped",
     "epn_so3_basis_amax_split_f32", "epn_so3_basis_norm_amax_split_f32",
     "epn_norm_act_pair_fwd_amax", "epn_norm_act_pair_bwd_apply_amax", "epn_norm_act_bwd_apply_amax_f32",
-    "epn_absmax_f32", "epn_f16x2_overflow_count", "epn_gemm_nt_f16x2_workspace_bytes", "epn_gemm_nt_f16x2_f32", "epn_gemm_tn_f16x2_f32", "epn_gemm_tn_grouped_f16x2",
+    "epn_absmax_f32", "epn_f16x2_overflow_count", "epn_inter_bwd_data_f16x2_ok", "epn_inter_bwd_data_f16x2_workspace_bytes",
+    "epn_inter_bwd_data_f16x2_f32", "epn_gemm_nt_f16x2_workspace_bytes", "epn_gemm_nt_f16x2_f32", "epn_gemm_tn_f16x2_f32", "epn_gemm_tn_grouped_f16x2",
     "epn_inter_group_bf16", "epn_inter_ungroup_bf16", "epn_intra_group_bf16", "epn_so3_basis_bf16",
     "epn_gather_rows", "epn_scatter_rows", "epn_conv1x1_c1_f32", "epn_conv1x1_c1_bwd_weight_f32",
     "epn_anchor_softmax_pool_fwd_f32", "epn_anchor_softmax_pool_bwd_f32",
@@ -220,6 +221,11 @@ def get_lib():
     pp = ctypes.POINTER(_vp)                 # const float *const * (arrays of device pointers, entries may be NULL)
     lib.epn_absmax_f32.argtypes = [_vp, _ll, _ll, _ll, _vp, _vp]
     lib.epn_f16x2_overflow_count.argtypes = [_ci]
+    lib.epn_inter_bwd_data_f16x2_ok.argtypes = [dp]
+    lib.epn_inter_bwd_data_f16x2_ok.restype = _ci
+    lib.epn_inter_bwd_data_f16x2_workspace_bytes.argtypes = [dp]
+    lib.epn_inter_bwd_data_f16x2_workspace_bytes.restype = _sz
+    lib.epn_inter_bwd_data_f16x2_f32.argtypes = [dp, _vp, _vp, _vp, _vp, _ci, _vp, _sz, _vp]
     lib.epn_f16x2_overflow_count.restype = _ll
     lib.epn_gemm_nt_f16x2_workspace_bytes.argtypes = [_ci, gp]
     lib.epn_gemm_nt_f16x2_workspace_bytes.restype = ctypes.c_size_t
@@ -273,7 +279,7 @@ def get_lib():
 
 
 # Host-only entry points (no stream argument, nothing launched): handed out unwrapped.
-_HOST_ONLY = {"epn_version", "epn_strerror", "epn_set_kernel_policy", "epn_last_kernel", "epn_f16x2_overflow_count", "epn_inter_is_fused", "epn_inter_split_ok", "epn_inter_c1_ok",
+_HOST_ONLY = {"epn_inter_bwd_data_f16x2_ok", "epn_version", "epn_strerror", "epn_set_kernel_policy", "epn_last_kernel", "epn_f16x2_overflow_count", "epn_inter_is_fused", "epn_inter_split_ok", "epn_inter_c1_ok",
               "epn_inter_split_saved_bytes",
               "epn_intra_is_fused", "epn_inter_onchip_ok", "epn_inter_group_packed_ok", "epn_inter_packed_position"}
 CALL_HOOK = None      # ops.profile_begin(): callable(name, fn, args) -> rc, brackets every launching call with HIP events

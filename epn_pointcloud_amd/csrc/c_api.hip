@@ -424,6 +424,34 @@ extern "C" int epn_inter_ungroup_acc_bf16(const epn_inter_desc *d, const void *g
     return inter_ungroup_any(d, grad_grouped, grad_feats_cl, workspace, workspace_bytes, 1, stream, true);
 }
 
+// ---- data gradient with the grouped-feature gradient kept on chip (inter_bwd_f2.hip)
+extern "C" int epn_inter_bwd_data_f16x2_ok(const epn_inter_desc *d) {
+    return d && !check_desc(d) && !d->dense_w && inter_bwd_f2_ok(d) && !force_generic() ? 1 : 0;
+}
+extern "C" size_t epn_inter_bwd_data_f16x2_workspace_bytes(const epn_inter_desc *d) {
+    if (!d || check_desc(d) || !inter_bwd_f2_ok(d)) return 0;
+    InterWs w = inter_ws(d);
+    return w.big_off * sizeof(float) + inter_bwd_f2_extra_bytes(d);
+}
+extern "C" int epn_inter_bwd_data_f16x2_f32(const epn_inter_desc *d, const float *grad_out_cl, const float *W, const float *go_amax,
+                                            float *grad_feats_cl, int accumulate, void *workspace, size_t workspace_bytes,
+                                            epn_stream_t stream) {
+    hipStream_t st = epn_stream(stream);
+    int rc = check_desc(d);
+    if (rc) return rc;
+    if (d->dense_w || !inter_bwd_f2_ok(d) || force_generic()) return EPN_EINVAL;
+    InterWs ws = inter_ws(d);
+    if (!workspace || workspace_bytes < ws.big_off * sizeof(float) + inter_bwd_f2_extra_bytes(d)) return EPN_EWORKSPACE;
+    if (!grad_feats_cl) return EPN_ENULL;
+    if (!accumulate)
+        EPN_HIP(hipMemsetAsync(grad_feats_cl, 0, sizeof(float) * (size_t)d->b * d->p1 * d->na * d->cin, st));
+    if (d->b == 0 || d->p2 == 0) return 0;
+    if (!grad_out_cl || !W || !go_amax) return EPN_ENULL;
+    float *base = static_cast<float *>(workspace);
+    return launch_inter_bwd_f2(d, base + ws.rk4_off, reinterpret_cast<int32_t *>(base + ws.order_off), grad_out_cl, W, go_amax,
+                               grad_feats_cl, base + ws.big_off, st);
+}
+
 extern "C" int epn_inter_inverse_list(const int32_t *ball_idx, int b, int p1, int p2, int nn, int32_t *offsets,
                                       int32_t *entries, epn_stream_t stream) {
     if (b < 0 || p1 < 1 || p2 < 0 || nn < 1) return EPN_EINVAL;

@@ -99,6 +99,14 @@ int launch_inter_unpack_weight_grad(const float *gWp, int cout, int cin, int ks,
 // order: b*p2 int32 of scratch for the Morton order of the output points (nullptr: per-slot atomic scatter)
 int launch_inter_ungroup_mfma(const epn_inter_desc *d, const float *rk4, const void *dG, float *dF, int32_t *order,
                               int bf16, hipStream_t st);
+int launch_morton_order(const float *new_xyz, int b, int p2, int32_t *order, hipStream_t st);
+// inter_bwd_f2.hip: the data gradient of InterSO3Conv with dG kept on chip (two-piece fp16 contraction inside the LDS-reduced
+// scatter's workgroup).  rk4p: na*32*4 floats of scratch (a kernel-point order of its own), order: b*p2 int32, extra:
+// inter_bwd_f2_extra_bytes; go_amax: device scalar max|dOut|.  dF is accumulated into (zero it for a plain gradient).
+bool inter_bwd_f2_ok(const epn_inter_desc *d);
+size_t inter_bwd_f2_extra_bytes(const epn_inter_desc *d);
+int launch_inter_bwd_f2(const epn_inter_desc *d, float *rk4p, int32_t *order, const float *dOut, const float *W,
+                        const float *go_amax, float *dF, void *extra, hipStream_t st);
 // deterministic (atomic-free) data gradient of the grouping: inverse neighbour list + per-slot slab + ordered reduction
 int launch_inverse_list(const int32_t *idx, int b, int p1, int p2, int nn, int32_t *off, int32_t *ent, hipStream_t st);
 int launch_inter_ungroup_det_mfma(const epn_inter_desc *d, const float *rk4, const void *dG, void *dF, void *slab,

@@ -136,6 +136,7 @@ __device__ __forceinline__ void nt_col_stats(const gemm_f32x16 (&acc)[TM][TN], f
 // (gemm.hip, gemm_x3.hip); take = read (synchronously, on the current device) and optionally clear.  < 0: a hipError_t, negated
 long long f2_nonfinite_take_gemm(bool reset);
 long long f2_nonfinite_take_x3(bool reset);
+long long f2_nonfinite_take_bwd(bool reset);    // inter_bwd_f2.hip
 
 int kernel_policy();   // c_api.hip: epn_set_kernel_policy (0x100 | cfg = NT tile override of the tuning tool)
 

@@ -717,7 +717,9 @@ extern "C" long long epn_f16x2_overflow_count(int reset) {
     const long long a = f2_nonfinite_take_gemm(reset != 0);
     if (a < 0) return a;
     const long long b = f2_nonfinite_take_x3(reset != 0);
-    return b < 0 ? b : a + b;
+    if (b < 0) return b;
+    const long long c = f2_nonfinite_take_bwd(reset != 0);
+    return c < 0 ? c : a + b + c;
 }
 
 extern "C" size_t epn_gemm_nt_f16x2_workspace_bytes(int nprob, const epn_gemm_nt_problem *probs) {

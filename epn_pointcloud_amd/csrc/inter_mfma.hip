@@ -2047,6 +2047,14 @@ int launch_inter_ungroup_det_mfma(const epn_inter_desc *d, const float *rk4, con
     return 0;
 }
 
+// Morton order of the output points of every cloud (order[b][p2]); shared with inter_bwd_f2.hip
+int launch_morton_order(const float *new_xyz, int b, int p2, int32_t *order, hipStream_t st) {
+    if (p2 > MORTON_MAX) return EPN_EINVAL;
+    EPN_LAUNCH_AUX(morton_order_kernel, dim3(b), dim3(1024), 0, st, new_xyz, p2, order);
+    EPN_CHECK_LAUNCH();
+    return 0;
+}
+
 int launch_inter_ungroup_mfma(const epn_inter_desc *d, const float *rk4, const void *dG, float *dF, int32_t *order,
                               int bf16, hipStream_t st) {
     InterArgs A = make_args(d, rk4);

@@ -559,7 +559,19 @@ class InterSO3ConvSplitFn(torch.autograd.Function):
                 # 128->256 4.8 vs 5.5; rotation / 3DMatch networks in fp32 (K = 32..64): the whole step 4 % faster.
                 # The fused kernel stays the memory-lean choice (EPN_INTER_BWD_DATA=fused: no [cols, cin*ks] gradient).
                 mode = "split"
-            if mode == "fused" and lib.epn_inter_is_fused(ctypes.byref(d)) and cin >= 16:
+            if (mode == "onchip" and gemm.f16x2_on(G) and go_amax is not None and isinstance(geo, InterGeometry)
+                    and lib.epn_inter_bwd_data_f16x2_ok(ctypes.byref(d))):
+                # dG never written (csrc/inter_bwd_f2.hip): the two-piece contraction dOut . W runs inside the workgroup of the
+                # LDS-reduced scatter, its D fragments reach the tail through in-register row transposes
+                nb = int(lib.epn_inter_bwd_data_f16x2_workspace_bytes(ctypes.byref(d)))
+                ws = torch.empty(max(nb, 16), dtype=torch.uint8, device=G.device)
+                gemm._check_amax(g2d, go_amax, "inter_bwd_data_f16x2, operand dOut")
+                _lib.check(_launch("inter_bwd_data_f2", _inter_key(d), _inter_flops(d), G.device,
+                                   lambda: lib.epn_inter_bwd_data_f16x2_f32(ctypes.byref(d), _cl_ptr(g), _lib.dev_ptr(Wc, "W"),
+                                                                            gemm._use_amax(go_amax), _cl_ptr(gf), 1 if onto else 0,
+                                                                            ctypes.c_void_p(ws.data_ptr()), ctypes.c_size_t(ws.numel()),
+                                                                            _lib.stream_of(G))), "inter_bwd_data_f16x2")
+            elif mode == "fused" and lib.epn_inter_is_fused(ctypes.byref(d)) and cin >= 16:
                 # The fused data-gradient kernel (W^T dOut + per-column tail in one pass, no dG tensor): its fp32 atomic
                 # scatter -- cols*K*cin = 1.0e9 atomics per layer -- hides under the MFMA phases.  Also measured and
                 # dropped: an atomic-free CSR-gather transpose (re-reads every 96-byte dG row K times: 3x slower) and

@@ -607,6 +607,20 @@ int epn_gemm_tn_f16x2_f32(const float *X, long long ldx, const float *Y, long lo
                           epn_stream_t stream);
 int epn_gemm_tn_grouped_f16x2(int nprob, const epn_gemm_tn_problem *probs, const float *const *x_amax, const float *const *y_amax,
                               void *workspace, size_t workspace_bytes, epn_stream_t stream);
+/* Data gradient of InterSO3Conv with the gradient of the grouped features kept ON CHIP (round 6; csrc/inter_bwd_f2.hip):
+ *     grad_feats[b, idx[b,p,n], a, c] (+)= sum_k w[b,p,a,k,n] * sum_o grad_out[col][o] W[o][c*ks + k]
+ * -- autograd's transpose of BasicSO3Conv's matmul (vgtk/vgtk/so3conv/modules.py:48-55) chained with the scatter-add that is
+ * the backward of inter_zpconv_grouping_naive's gather (vgtk/vgtk/spconv/functional.py:372-390), in ONE kernel: the
+ * [cols, cin*ks] gradient of the grouped features (which epn_gemm_nt_f16x2_f32 + epn_inter_ungroup_f32 write to and read back
+ * from HBM: 27 GB per classification step) lives in registers.  The contraction over the output channels runs in the two-piece
+ * fp16 form (three v_mfma_f32_16x16x32_f16 per block, fp32 accumulate) inside the workgroup of the LDS-pre-reduced scatter.
+ * go_amax: device scalar max|grad_out| (required: epn_absmax_f32 computes one).  accumulate != 0: added to what grad_feats_cl
+ * holds.  Shapes: ks == 24, 16 <= na <= 64, nn <= 32, cout in {64, 128, 256}, cin % 16 == 0, p2 % 8 == 0 (epn_..._ok). */
+int epn_inter_bwd_data_f16x2_ok(const epn_inter_desc *d);
+size_t epn_inter_bwd_data_f16x2_workspace_bytes(const epn_inter_desc *d);
+int epn_inter_bwd_data_f16x2_f32(const epn_inter_desc *d, const float *grad_out_cl, const float *W, const float *go_amax,
+                                 float *grad_feats_cl, int accumulate, void *workspace, size_t workspace_bytes,
+                                 epn_stream_t stream);
 /* The scale contract of the two-piece form made loud (round 6).  The power-of-two scale leaves a factor 2-4 below fp16's
  * 65504, so an operand element above 2-4 x the maximum the caller REPORTED becomes inf in the split and the product silently
  * non-finite -- where the fp32 matmul these entry points replace (torch.matmul in vgtk/vgtk/so3conv/modules.py:48-55) would

@@ -534,8 +534,62 @@ def test_config_full_size_bf16(gpu, model, points, batch):
     dgb = rel_l2(torch.cat([gb16[n].flatten() for n in keep]), torch.cat([gb32[n].flatten() for n in keep]))
     print(f"{model}: backbone gradient bf16 vs fp32, {len(keep)} parameters together: rel-L2 {dgb:.4f}")
     assert all(torch.isfinite(v).all() for v in gb16.values()) and len(keep) >= 20
-    assert dgb < 0.05, dgb
-    assert rows[0][0] < 0.15, rows[0]
+    # What this measured on its first run (round 6): 0.23 (rotation) / 0.26 (3DMatch) together, 0.26-0.33 for EVERY parameter of
+    # the first blocks -- so the 40 % of the through-the-head comparison is not the head's doing.  It is leaky_relu: a
+    # pre-activation within one bf16 rounding of zero (a fraction ~ 2^-9 x pdf(0) ~ 1.5e-3 of the elements per layer) takes the
+    # other slope in the other network and changes that element's gradient by 99 %; in relative L2 that is sqrt(fraction) ~ 4 % per
+    # nonlinearity, ~ 15-30 % after the 14-16 of a backbone.  A network-level bf16-vs-fp32 gradient can therefore only catch a
+    # BROKEN layer (100 % and more); the backward kernels themselves are pinned per layer against the oracle on identical
+    # inputs (test_gpu_fullsize.py: 8e-3 asserted, 3-4e-3 measured).
+    assert dgb < 0.45, dgb
+    assert rows[0][0] < 0.6, rows[0]
+
+
+@pytest.mark.parametrize("model,points,batch", [("reg", 1024, 16), ("inv", 2048, 16)])
+def test_bf16_network_gradient_without_the_sign_flips(gpu, monkeypatch, model, points, batch):
+    """The well-conditioned network-level check of the bf16 backward path (review item 5, round 5): the same networks with
+    leaky_relu's negative slope set to 1 (every activation the identity, so no element can take 'the other slope'): convolutions,
+    norms, skip branches, basis changes and their transposes remain, and the bf16 network's backbone gradients must then agree
+    with the fp32 network's to a few bf16 roundings -- parameter by parameter."""
+    from epn_pointcloud_amd import models as M, ops, schedule as S
+    # the slope is a default argument of the three glue entry points the blocks call
+    monkeypatch.setattr(ops.norm_act, "__defaults__", (None, 1.0, None))
+    d = list(ops.norm_act_pair.__defaults__)
+    d[1] = 1.0
+    monkeypatch.setattr(ops.norm_act_pair, "__defaults__", tuple(d))
+    d = list(ops.intra_so3conv_spectral.__defaults__)
+    d[1] = 1.0
+    monkeypatch.setattr(ops.intra_so3conv_spectral, "__defaults__", tuple(d))
+    import inspect
+    assert inspect.signature(ops.norm_act).parameters["slope"].default == 1.0
+    assert inspect.signature(ops.norm_act_pair).parameters["slope"].default == 1.0
+    assert inspect.signature(ops.intra_so3conv_spectral).parameters["pre_slope"].default == 1.0
+    torch.manual_seed(11)
+    net = (M.build_reg if model == "reg" else M.build_inv)(points).to(gpu).train()
+    pts = S.synthetic_clouds(batch, points, gpu, seed=77, scale=0.4 if model == "inv" else 1.0)
+
+    def run_backbone():
+        for p in net.parameters():
+            p.grad = None
+        x = net.features(pts)
+        gen = torch.Generator(device="cpu").manual_seed(9)
+        probe = torch.randn(x.feats.shape, generator=gen).to(x.feats.device)
+        (x.feats.float() * probe).sum().backward()
+        return x.feats.detach().float().cpu(), {n: p.grad.detach().float().cpu() for n, p in net.backbone.named_parameters()
+                                                  if p.grad is not None}
+
+    f32, g32 = run_backbone()
+    S.set_feature_dtype(net, torch.bfloat16)
+    f16, g16 = run_backbone()
+    noise = {"0.blocks.0.skip_conv.weight", "0.blocks.0.skip_conv.bias"}     # constant input: exact zero gradient (see above)
+    gmax = max(v.abs().max().item() for n, v in g32.items() if n not in noise)
+    rows = sorted(((rel_l2(g16[n], v), n) for n, v in g32.items() if n not in noise and v.abs().max().item() >= 1e-3 * gmax),
+                  reverse=True)
+    for r in rows[:4]:
+        print(f"{model} (slope 1): backbone gradient bf16 vs fp32 {r[1]}: rel-L2 {r[0]:.4f}")
+    print(f"{model} (slope 1): output rel-L2 {rel_l2(f16, f32):.4f}")
+    assert len(rows) >= 20 and rel_l2(f16, f32) < 0.02
+    assert rows[0][0] < 0.08, rows[:3]
     assert np.isfinite(l16) and torch.isfinite(f16).all() and torch.isfinite(g16).all()
     dl, df, dg = abs(l16 - l32) / abs(l32), rel_l2(f16, f32), rel_l2(g16, g32)
     print(f"{model}: bf16 vs fp32 network: loss {dl:.4f}, output rel-L2 {df:.4f}, gradient rel-L2 {dg:.4f}")
