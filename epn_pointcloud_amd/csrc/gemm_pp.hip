@@ -1,7 +1,7 @@
 // Split-form NT GEMM whose BOTH operands arrive as three bf16 planes ("pre-split"): no fp32 -> 3 x bf16 arithmetic in the
 // main loop at all (gemm_nt_x3_kernel splits its A fragments in registers: 36 VALU instructions per fragment, 1.5 per MFMA
 // on the 64 x 128 wave tile).  Round 5, review item 3: the producer of A (the grouping kernel / the basis change) would
-// emit the planes; this file is the consumer, measured stand-alone first (tools/pp_probe.py) against gemm_nt_x3_kernel.
+// emit the planes; this file is the consumer, measured stand-alone first (tools/pp2_probe.py) against gemm_nt_x3_kernel.
 //
 //   C[M][N] = sum over the six kept piece products of (Ah + Am + Al)[M][K] . (Bh + Bm + Bl)[N][K]^T      (gemm_x3.hip)
 //
@@ -370,7 +370,7 @@ int launch_pp(const PPArgs &P, hipStream_t st) {
 
 using namespace epn;
 
-// tuning library only (tools/pp_probe.py)
+// tuning library only (tools/pp2_probe.py)
 extern "C" int epn_lab_pp_split(const float *src, long long ld, long long rows, int K, void *planes, int layout, int KS,
                                 epn_stream_t stream) {
     hipStream_t st = epn_stream(stream);

@@ -772,7 +772,7 @@ __global__ __launch_bounds__(64 * NW8) void inter_bwd_data8_kernel(InterArgs A) 
 // ------------------------------------------------------------------------------------ grouping only
 // "Split" path: the grouped features G[col][c*ks + k] go to HBM once (kept for the backward pass) and the weight
 // contraction is a plain [cols x cin*ks] x [cin*ks x cout] GEMM for the BLAS library (measured 110-150 TFLOP/s fp32 on
-// these shapes, tools/gemm_probe.py, against 67-84 for the fused kernels above).  A wave owns one 16-column tile; no
+// these shapes in round 1 -- CHANGELOG 3.2 -- against 67-84 for the fused kernels above).  A wave owns one 16-column tile; no
 // LDS, no barriers: weight generation + neighbour contraction exactly as in the fused kernels, the D fragment of
 // the contraction (4 consecutive kernel points of one channel) is one 16-byte global store.
 template <int NT, int KT, typename TF>
