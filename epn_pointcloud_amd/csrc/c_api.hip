@@ -67,7 +67,7 @@ extern "C" const char *epn_last_kernel(void) {
 
 extern "C" int epn_set_kernel_policy(int policy) {
 #ifdef EPN_TUNING   // tools/ builds (python -m epn_pointcloud_amd.build --tuning): 0x100 | cfg .. 0x400 | cfg = A/B switches
-    if (policy != 0 && policy != 1 && policy != 2 && (policy & ~0xff) != 0x100 && (policy & ~0xff) != 0x200 && (policy & ~0xff) != 0x400 && (policy & ~0xff) != 0x800) return EPN_EINVAL;
+    if (policy != 0 && policy != 1 && policy != 2 && (policy & ~0xff) != 0x100 && (policy & ~0xff) != 0x200 && (policy & ~0xff) != 0x400 && (policy & ~0xff) != 0x800 && (policy & ~0xff) != 0x900) return EPN_EINVAL;
 #else
     if (policy != 0 && policy != 1 && policy != 2) return EPN_EINVAL;
 #endif

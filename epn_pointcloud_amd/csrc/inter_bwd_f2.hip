@@ -319,13 +319,22 @@ __global__ __launch_bounds__(64 * GP) void inter_bwd_data_f2_kernel(BwdF2Args P)
                     const float xx[8] = {au[0], au[1], au[2], au[3], av[0], av[1], av[2], av[3]};
                     f2_split8(xx, a_scale, ah, al);
                 }
+#ifdef EPN_TUNING
+                if (!(A.wk & 4))
+#endif
                 if (stepi + 1 < nsteps) {
                     stage(stepi + 1);
                     load_a(stepi + 1, au, av);
                 }
                 const char *slab = smem + (stepi & 1) * BF_SLAB + roff;
+#ifdef EPN_TUNING
+                const bool skip_mfma = A.wk & 2;
+#else
+                constexpr bool skip_mfma = false;
+#endif
 #pragma unroll
                 for (int k = 0; k < BF_KS; ++k) {
+                    if (skip_mfma) break;
                     // (fragment reads are kept within four kernel points of their MFMAs: hoisted freely, the 48 reads of a step
                     // hold 192 registers and the kernel spills)
                     if (k % 4 == 0) __builtin_amdgcn_sched_barrier(0);
@@ -362,6 +371,15 @@ __global__ __launch_bounds__(64 * GP) void inter_bwd_data_f2_kernel(BwdF2Args P)
                 for (int ja = 0; ja < 4; ++ja) {
                     const int a = 16 * at + 4 * ja + ra;
                     if (a >= A.na) continue;                               // wave-uniform (and workgroup-uniform)
+#ifdef EPN_TUNING
+                    if (A.wk & 1) {                                        // ablation: no tail (the values are still consumed)
+                        float q = 0.f;
+                        for (int r = 0; r < 4; ++r) q += dg[bf_kidx(ja, r)][ra];
+                        for (int r = 0; r < 2; ++r) q += dg[bf_kidx(ja, 4 + r)][ra];
+                        if (q == 12345.678f) atomicAdd(dcloud, q);
+                        continue;
+                    }
+#endif
                     // (the table offset is made opaque: left to itself hipcc hoists the 32 row addresses of a tile's anchors out of
                     // the chunk loop as 64-bit values and spills them)
                     unsigned rko = (unsigned)a * (EPN_KS_MAX * 4) + rklane;
@@ -397,6 +415,9 @@ __global__ __launch_bounds__(64 * GP) void inter_bwd_data_f2_kernel(BwdF2Args P)
                             const int k1 = off[u + 1];
                             for (int k = off[u] + 3; k < k1; ++k) sum += rb[list[k] * SS + c];
                         }
+#ifdef EPN_TUNING
+                        if (!(A.wk & 8) || sum == 12345.678f)
+#endif
                         atomicAdd(dstep + ((unsigned)cnt[u] + (unsigned)c), sum);
                     }
                     if constexpr (NB == 1) __syncthreads();
@@ -455,6 +476,9 @@ int launch_inter_bwd_f2(const epn_inter_desc *d, float *rk4p, int32_t *order, co
     A.sigma_inv = 1.0f / d->sigma;
     A.b = d->b; A.p1 = d->p1; A.p2 = d->p2; A.nn = d->nn; A.na = d->na; A.ks = d->ks; A.cin = d->cin; A.cout = d->cout;
     A.wk = 0; A.packed = 0; A.ncol = (long long)d->b * d->p2 * d->na; A.col_tiles_per_wg = 1;
+#ifdef EPN_TUNING
+    if ((kernel_policy() & 0xf00) == 0x900) A.wk = kernel_policy() & 0xff;   // ablation bits (tools/bwd_onchip_probe.py)
+#endif
     P.planes = planes; P.go_amax = go_amax; P.w_amax = wmax; P.order = order;
     constexpr int GP = 8;
     const int nchunk = d->cin >> 4;

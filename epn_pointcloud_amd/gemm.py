@@ -91,7 +91,7 @@ def mark_written(t):
     counter -- which the tensor shares with every view and detach() alias -- drops every such tag at once, and it is what an
     in-place torch op on the same memory would have done.  Returns t."""
     if t is not None:
-        torch._C._increment_version(t)
+        torch._C._increment_version((t,))       # (takes an ITERABLE of tensors: a bare tensor is walked row by row)
         for cand in (t, t._base):
             if cand is not None and getattr(cand, "_epn_amax", None) is not None:
                 try:

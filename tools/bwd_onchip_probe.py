@@ -8,6 +8,11 @@ import os
 import sys
 
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
+ABL = [int(v, 0) for v in sys.argv[2:]]          # ablation bits of the on-chip kernel (tuning library): 1 no tail, 2 no MFMAs /
+if ABL:                                          # fragment reads, 4 no staging, 8 no atomics -- times only, results are wrong
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    from _tuning import use_tuning_lib
+    use_tuning_lib()
 import torch
 
 import epn_pointcloud_amd
@@ -79,6 +84,11 @@ def main():
                                "bwd_data_f16x2")
                 t_o = timeit(onchip)
                 kern = lib.epn_last_kernel().decode().split("::")[-1]
+                for e in ABL:
+                    assert lib.epn_set_kernel_policy(0x900 | e) == 0
+                    kern += f"  [{e}] {timeit(onchip):.3f}"
+                    lib.epn_set_kernel_policy(0)
+                    onchip()
                 diff = ((gf_o - gf_s).abs().max() / gf_s.abs().max()).item()
                 tot[2] += t_o
             tot[0] += t_g; tot[1] += t_u
