@@ -131,8 +131,12 @@ __global__ __launch_bounds__(64 * GP) void inter_bwd_data_f2_kernel(BwdF2Args P)
     // pipeline): [ring of two W stages | tile buffers | index arrays]
     constexpr int OFF_T = 2 * BF_SLAB;
     constexpr int OFF_I = OFF_T + NB * BS * 4;
-    constexpr int NINT = 6 * E + 1 + CH + 3;
-    constexpr int TOTAL = OFF_I + NINT * 4;
+    constexpr int NINT = ((6 * E + 1 + CH + 3) + 3) & ~3;
+    // the rotated-kernel table of the launch (na <= 64 anchors x 32 rows x 4 floats): every anchor step of every chunk reads two
+    // of its rows -- from global memory (v1) that was a ~1 us dependent load in front of each of the 60 x chunks steps of a
+    // workgroup, the largest single item of the tail (profiles/r06_bwd_onchip_ablation_v1.txt)
+    constexpr int OFF_R = OFF_I + NINT * 4;
+    constexpr int TOTAL = OFF_R + 64 * EPN_KS_MAX * 4 * 4;
     static_assert(TOTAL <= 160 * 1024, "LDS");
     static_assert(2 * BF_SLAB >= BF_TAB * 4, "direct-address table aliases the W ring");
     __shared__ __attribute__((aligned(1024))) char smem[TOTAL];
@@ -140,6 +144,7 @@ __global__ __launch_bounds__(64 * GP) void inter_bwd_data_f2_kernel(BwdF2Args P)
     int *qlist = reinterpret_cast<int *>(smem + OFF_I);
     int *slot_of = qlist + E, *uq = slot_of + E, *cnt = uq + E, *off = cnt + E, *list = off + E + 1, *chunk_cnt = list + E;
     int *tab = reinterpret_cast<int *>(smem);   // set-up only
+    float *rkl = reinterpret_cast<float *>(smem + OFF_R);
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -169,6 +174,8 @@ __global__ __launch_bounds__(64 * GP) void inter_bwd_data_f2_kernel(BwdF2Args P)
             }
     }
     for (int e = tid; e < E; e += NTH) cnt[e] = 0;
+    for (int i = tid; i < A.na * EPN_KS_MAX; i += NTH)
+        reinterpret_cast<f32x4 *>(rkl)[i] = reinterpret_cast<const f32x4 *>(A.rk4)[i];
     __syncthreads();
     int myq[EPT], myr[EPT];
 #pragma unroll
@@ -278,7 +285,7 @@ __global__ __launch_bounds__(64 * GP) void inter_bwd_data_f2_kernel(BwdF2Args P)
             }
         }
     };
-    const unsigned rklane = (unsigned)(x * 4 + j);
+    const int rklane = x * 4 + j;
     const int rslot = ((x >> 2) ^ ((-j) & 3)) * 16;           // byte offset of this lane's slot inside a 64-byte row
     const int roff = x * 64 + rslot;
 
@@ -298,6 +305,17 @@ __global__ __launch_bounds__(64 * GP) void inter_bwd_data_f2_kernel(BwdF2Args P)
         v = *reinterpret_cast<const f32x4 *>(src + 4);
     };
     __syncthreads();                            // set-up reads of tab are over: the ring may be written
+    constexpr int NC = NT == 1 ? 2 : 1;         // cached gather-sum items per thread (512 threads x 16 channels: 32 destinations each)
+    unsigned cpk[NC], coff[NC];
+#pragma unroll
+    for (int q = 0; q < NC; ++q) {
+        const int i = tid + q * NTH;
+        const bool ok = i < U * 16;
+        cpk[q] = ok ? (unsigned)pk[i >> 4] : 0u;
+        coff[q] = ok ? (unsigned)cnt[i >> 4] + (unsigned)(i & 15) : 0u;
+    }
+    float rkn[2] = {0.f, 0.f};
+    int rkn_a = -1;                             // anchor whose table rows rkn holds
     stage(0);
     f32x4 au, av;
     load_a(0, au, av);
@@ -332,17 +350,41 @@ __global__ __launch_bounds__(64 * GP) void inter_bwd_data_f2_kernel(BwdF2Args P)
 #else
                 constexpr bool skip_mfma = false;
 #endif
+                // Fragment reads one pair of kernel points ahead of their MFMAs, as inline assembly with hand-counted waits: left to
+                // hipcc each ds_read_b128 sits directly in front of its three DEPENDENT MFMAs (read latency + three accumulate
+                // latencies per kernel point, v1: 2400 cycles per step for 1152 cycles of matrix work).  Two kernel points form a
+                // group: term by term across the pair, so that no MFMA waits for its predecessor's result.
+                if (!skip_mfma) {
+                    const unsigned sl = (unsigned)(uintptr_t)(__attribute__((address_space(3))) const char *)slab;
+                    gemm_f16x8 fh[3][2], fl[3][2];          // [buffer][kernel point of the pair]: two pairs in flight ahead
+#define BF_RD(buf_, q_, k_)                                                                                                    \
+    asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(fh[buf_][q_]) : "v"(sl), "n"((k_) * 1024));                            \
+    asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(fl[buf_][q_]) : "v"(sl), "n"((BF_KS + (k_)) * 1024))
+#define BF_RD2(buf_, g_) do { BF_RD(buf_, 0, 2 * (g_)); BF_RD(buf_, 1, 2 * (g_) + 1); } while (0)
+                    BF_RD2(0, 0); BF_RD2(1, 1);
 #pragma unroll
-                for (int k = 0; k < BF_KS; ++k) {
-                    if (skip_mfma) break;
-                    // (fragment reads are kept within four kernel points of their MFMAs: hoisted freely, the 48 reads of a step
-                    // hold 192 registers and the kernel spills)
-                    if (k % 4 == 0) __builtin_amdgcn_sched_barrier(0);
-                    const gemm_f16x8 bh = *reinterpret_cast<const gemm_f16x8 *>(slab + k * 1024);
-                    const gemm_f16x8 bl = *reinterpret_cast<const gemm_f16x8 *>(slab + (BF_KS + k) * 1024);
-                    acc[k] = mfma_f16_k32(ah, bl, acc[k]);
-                    acc[k] = mfma_f16_k32(al, bh, acc[k]);
-                    acc[k] = mfma_f16_k32(ah, bh, acc[k]);
+                    for (int g = 0; g < BF_KS / 2; ++g) {
+                        const int cb = g % 3, nb = (g + 2) % 3;
+                        if (g + 2 < BF_KS / 2) {
+                            if (nb == 0) BF_RD2(0, g + 2); else if (nb == 1) BF_RD2(1, g + 2); else BF_RD2(2, g + 2);
+                            asm volatile("s_waitcnt lgkmcnt(8)" ::: "memory");      // two younger pairs may be outstanding
+                        } else if (g + 1 < BF_KS / 2) {
+                            asm volatile("s_waitcnt lgkmcnt(4)" ::: "memory");
+                        } else {
+                            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                        }
+                        if (cb == 0) { asm volatile("" : "+v"(fh[0][0]), "+v"(fl[0][0]), "+v"(fh[0][1]), "+v"(fl[0][1])); }
+                        else if (cb == 1) { asm volatile("" : "+v"(fh[1][0]), "+v"(fl[1][0]), "+v"(fh[1][1]), "+v"(fl[1][1])); }
+                        else { asm volatile("" : "+v"(fh[2][0]), "+v"(fl[2][0]), "+v"(fh[2][1]), "+v"(fl[2][1])); }
+                        acc[2 * g] = mfma_f16_k32(ah, fl[cb][0], acc[2 * g]);
+                        acc[2 * g + 1] = mfma_f16_k32(ah, fl[cb][1], acc[2 * g + 1]);
+                        acc[2 * g] = mfma_f16_k32(al, fh[cb][0], acc[2 * g]);
+                        acc[2 * g + 1] = mfma_f16_k32(al, fh[cb][1], acc[2 * g + 1]);
+                        acc[2 * g] = mfma_f16_k32(ah, fh[cb][0], acc[2 * g]);
+                        acc[2 * g + 1] = mfma_f16_k32(ah, fh[cb][1], acc[2 * g + 1]);
+                    }
+#undef BF_RD2
+#undef BF_RD
                 }
                 __builtin_amdgcn_sched_barrier(0);
                 ++stepi;
@@ -380,32 +422,62 @@ __global__ __launch_bounds__(64 * GP) void inter_bwd_data_f2_kernel(BwdF2Args P)
                         continue;
                     }
 #endif
-                    // (the table offset is made opaque: left to itself hipcc hoists the 32 row addresses of a tile's anchors out of
-                    // the chunk loop as 64-bit values and spills them)
-                    unsigned rko = (unsigned)a * (EPN_KS_MAX * 4) + rklane;
-                    asm volatile("" : "+v"(rko));
+                    // rows of the rotated-kernel table: requested one anchor step ahead (an LDS round trip in front of the first
+                    // MFMA of every step otherwise)
                     float rk[2];
-                    rk[0] = A.rk4[rko];
-                    rk[1] = A.rk4[rko + 64];
+                    if (rkn_a != a) {            // (first step of a tile, or the step before was past the last anchor)
+                        rk[0] = rkl[a * (EPN_KS_MAX * 4) + rklane];
+                        rk[1] = rkl[a * (EPN_KS_MAX * 4) + 64 + rklane];
+                    } else {
+                        rk[0] = rkn[0]; rk[1] = rkn[1];
+                    }
                     float *buf = Tb + (phase & (NB - 1)) * BS + wave * EW * SS + x;
 #pragma unroll
                     for (int t = 0; t < NT; ++t) {
                         f32x4 w0 = {alphaN[t], alphaN[t], alphaN[t], alphaN[t]}, w1 = w0;
                         w0 = mfma4(rk[0], gB[t], w0);
                         w1 = mfma4(rk[1], gB[t], w1);
-                        f32x4 tt = {0.f, 0.f, 0.f, 0.f};
+                        // two accumulation chains of three (a single chain of six waits for each predecessor's result)
+                        f32x4 ta = {0.f, 0.f, 0.f, 0.f}, tb = ta;
+                        ta = mfma4(relu_f(w0[0]), dg[bf_kidx(ja, 0)][ra], ta);
+                        tb = mfma4(relu_f(w0[1]), dg[bf_kidx(ja, 1)][ra], tb);
+                        ta = mfma4(relu_f(w0[2]), dg[bf_kidx(ja, 2)][ra], ta);
+                        tb = mfma4(relu_f(w0[3]), dg[bf_kidx(ja, 3)][ra], tb);
+                        ta = mfma4(relu_f(w1[0]), dg[bf_kidx(ja, 4)][ra], ta);
+                        tb = mfma4(relu_f(w1[1]), dg[bf_kidx(ja, 5)][ra], tb);
+                        // lane (x = c, j), register r -> slot n = 16 t + 4 j + r
 #pragma unroll
-                        for (int r = 0; r < 4; ++r) tt = mfma4(relu_f(w0[r]), dg[bf_kidx(ja, r)][ra], tt);
-#pragma unroll
-                        for (int r = 0; r < 2; ++r) tt = mfma4(relu_f(w1[r]), dg[bf_kidx(ja, 4 + r)][ra], tt);
-                        // tt: lane (x = c, j), register r -> slot n = 16 t + 4 j + r
-#pragma unroll
-                        for (int r = 0; r < 4; ++r) buf[(16 * t + 4 * j + r) * SS] = tt[r] * hmul[t][r];
+                        for (int r = 0; r < 4; ++r) buf[(16 * t + 4 * j + r) * SS] = (ta[r] + tb[r]) * hmul[t][r];
                     }
-                    __syncthreads();
+                    lds_barrier();               // (not __syncthreads: that would wait for the previous step's atomics)
+                    if (!(ra == 3 && ja == 3)) {
+                        const int an = 16 * at + (ja == 3 ? ra + 1 : 4 * (ja + 1) + ra);       // next anchor of the tile
+                        rkn[0] = rkl[an * (EPN_KS_MAX * 4) + rklane];
+                        rkn[1] = rkl[an * (EPN_KS_MAX * 4) + 64 + rklane];
+                        rkn_a = an;
+                    }
                     const float *rb = Tb + (phase & (NB - 1)) * BS;
                     float *dstep = dcloud + (size_t)a * A.cin + 16 * ct;   // wave-uniform
-                    for (int i = tid; i < U * 16; i += NTH) {
+                    // a thread's first NC (destination, channel) items are the same in every step: their slot words and row
+                    // offsets live in registers (two dependent LDS round trips less per item and step)
+#pragma unroll
+                    for (int q = 0; q < NC; ++q) {
+                        if (tid + q * NTH < U * 16) {
+                            const unsigned e = cpk[q];
+                            float sum = rb[(e & 1023u) * SS + (tid & 15)];
+                            sum += rb[((e >> 10) & 1023u) * SS + (tid & 15)];
+                            sum += rb[((e >> 20) & 1023u) * SS + (tid & 15)];
+                            if (e >> 30) {
+                                const int u = (tid + q * NTH) >> 4, k1 = off[u + 1];
+                                for (int k = off[u] + 3; k < k1; ++k) sum += rb[list[k] * SS + (tid & 15)];
+                            }
+#ifdef EPN_TUNING
+                            if (!(A.wk & 8) || sum == 12345.678f)
+#endif
+                            atomicAdd(dstep + coff[q], sum);
+                        }
+                    }
+                    for (int i = tid + NC * NTH; i < U * 16; i += NTH) {
                         const int u = i >> 4, c = i & 15;
                         const unsigned e = (unsigned)pk[u];
                         float sum = rb[(e & 1023u) * SS + c];
@@ -420,7 +492,7 @@ __global__ __launch_bounds__(64 * GP) void inter_bwd_data_f2_kernel(BwdF2Args P)
 #endif
                         atomicAdd(dstep + ((unsigned)cnt[u] + (unsigned)c), sum);
                     }
-                    if constexpr (NB == 1) __syncthreads();
+                    if constexpr (NB == 1) lds_barrier();
                     ++phase;
                 }
         }

@@ -40,6 +40,16 @@ __device__ __forceinline__ f32x4 mfma4(float a, float b, f32x4 c) {
     return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0);
 }
 
+// Workgroup barrier for data exchanged through LDS ONLY.  __syncthreads() is `s_waitcnt vmcnt(0) lgkmcnt(0); s_barrier`: it also
+// waits for every outstanding global access of the wave -- in the LDS-reduced scatters that is the acknowledgement of the fp32
+// atomics of the previous anchor step (1-3 us each step, found in the ISA of inter_bwd_f2.hip, round 6) and the prefetched dG
+// fragments of the next one.  Here only the LDS queue is drained; global loads are waited for where their values are used.
+__device__ __forceinline__ void lds_barrier() {
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+}
+
 // Feature / grouped-feature storage type of the grouping kernels: float, or __bf16 for the bf16 feature path (weights
 // w and the neighbour contraction stay fp32: "bf16 features, fp32 accumulate").
 typedef __bf16 bf16x4_t __attribute__((ext_vector_type(4)));

@@ -1442,7 +1442,11 @@ __global__ __launch_bounds__(64 * GP) void inter_ungroup_shared_kernel(InterArgs
 #endif
                         buf[(16 * t + (RP ? 8 * (j & 1) + 4 * (j >> 1) : 4 * j) + r) * SS + 16 * cw] = tt[r] * h.mul[t][r];
                 }
-            __syncthreads();
+#ifndef EPN_UNG_RAWBAR
+#define EPN_UNG_RAWBAR 1
+#endif
+            if constexpr (EPN_UNG_RAWBAR) lds_barrier();     // (inter_device.h: no wait for the atomics / the prefetched dG)
+            else __syncthreads();
             const float *rb = Tb + (ph & (NB - 1)) * BS;
             float *dstep = dcloud + (size_t)a * A.cin + 16 * cs * CW;      // wave-uniform
 #ifdef EPN_TUNING
@@ -1468,7 +1472,10 @@ __global__ __launch_bounds__(64 * GP) void inter_ungroup_shared_kernel(InterArgs
                     atomicAdd(dstep + ((unsigned)cnt[u] + (unsigned)c), sum);
                 }
             }
-            if constexpr (NB == 1) __syncthreads();
+            if constexpr (NB == 1) {
+                if constexpr (EPN_UNG_RAWBAR) lds_barrier();
+                else __syncthreads();
+            }
         }
     }
     }

@@ -554,11 +554,14 @@ class InterSO3ConvSplitFn(torch.autograd.Function):
             if G.dtype != torch.float32 or deterministic_bwd(G.dtype):
                 mode = "split"          # bf16 features / deterministic mode: dG GEMM + (atomic-free) transpose of the grouping
             elif mode == "auto":
-                # dG GEMM + LDS-pre-reduced scatter (epn_inter_ungroup) against the fused kernel, measured per layer of
-                # the ModelNet schedule at B=32: 64->64 3.65 vs 4.05 ms, 64->128 3.4 vs 3.6, 128->128 5.6 vs 5.7,
-                # 128->256 4.8 vs 5.5; rotation / 3DMatch networks in fp32 (K = 32..64): the whole step 4 % faster.
-                # The fused kernel stays the memory-lean choice (EPN_INTER_BWD_DATA=fused: no [cols, cin*ks] gradient).
-                mode = "split"
+                # Three forms, measured per layer of the ModelNet schedule at B = 32 (tools/bwd_onchip_probe.py,
+                # profiles/r06_bwd_onchip_probe.txt; ms, pair = dG GEMM + LDS-pre-reduced transpose | on-chip):
+                #   K = 16:  64->64 3.09 | 2.50   128->128 3.40 | 2.94   256->256 4.56 | 4.26     -> on-chip (dG never written)
+                #   K = 32:  64->128 2.17 | 2.80  128->256 2.52 | 3.24   256->256 2.58 | 3.16     -> pair
+                # (at K = 32 the on-chip kernel's workgroup holds 8 points x 32 slots: two weight tiles per anchor step, one tile
+                # buffer, and the pair's transpose runs 16 points per workgroup).  Round 1's fused exact-f32 kernel stays the
+                # memory-lean choice for everything (EPN_INTER_BWD_DATA=fused).
+                mode = "onchip" if d.nn <= 16 else "split"
             if (mode == "onchip" and gemm.f16x2_on(G) and go_amax is not None and isinstance(geo, InterGeometry)
                     and lib.epn_inter_bwd_data_f16x2_ok(ctypes.byref(d))):
                 # dG never written (csrc/inter_bwd_f2.hip): the two-piece contraction dOut . W runs inside the workgroup of the
