@@ -290,6 +290,9 @@ def algo_bytes(kind, key, esz):
         b_, p1, p2, nn_, na, ks, cin, _ = key
         feats, grouped = b_ * p1 * na * cin, b_ * p2 * na * cin * ks
         return feats * (esz if kind == "inter_group" else 4) + grouped * esz
+    if kind == "inter_bwd_data_f2":            # on-chip data gradient: dOut [cols, cout] read, dF [b p1 na, cin] accumulated into
+        b_, p1, p2, nn_, na, ks, cin, cout = key
+        return (b_ * p2 * na * cout + b_ * p1 * na * cin) * 4
     if kind in ("inter_gemm", "inter_gemm_dw", "inter_gemm_dg"):       # G [cols, cin ks] and out / dOut [cols, cout]
         b_, p1, p2, nn_, na, ks, cin, cout = key
         return b_ * p2 * na * (cin * ks + cout) * esz

@@ -1442,8 +1442,11 @@ __global__ __launch_bounds__(64 * GP) void inter_ungroup_shared_kernel(InterArgs
 #endif
                         buf[(16 * t + (RP ? 8 * (j & 1) + 4 * (j >> 1) : 4 * j) + r) * SS + 16 * cw] = tt[r] * h.mul[t][r];
                 }
+// (round 6, measured: an LDS-only barrier here -- no wait for the previous step's atomics or the prefetched dG fragments --
+// changes nothing on the bf16 networks and costs the classification step 1.2 %: 530.6 / 529.0 against 536.6 / 536.5
+// point-clouds/s, A/B of two builds on one box, profiles/r06_ab_rawbar_onchip.txt.  The wait is not what the waves wait for.)
 #ifndef EPN_UNG_RAWBAR
-#define EPN_UNG_RAWBAR 1
+#define EPN_UNG_RAWBAR 0
 #endif
             if constexpr (EPN_UNG_RAWBAR) lds_barrier();     // (inter_device.h: no wait for the atomics / the prefetched dG)
             else __syncthreads();

@@ -554,14 +554,17 @@ class InterSO3ConvSplitFn(torch.autograd.Function):
             if G.dtype != torch.float32 or deterministic_bwd(G.dtype):
                 mode = "split"          # bf16 features / deterministic mode: dG GEMM + (atomic-free) transpose of the grouping
             elif mode == "auto":
-                # Three forms, measured per layer of the ModelNet schedule at B = 32 (tools/bwd_onchip_probe.py,
-                # profiles/r06_bwd_onchip_probe.txt; ms, pair = dG GEMM + LDS-pre-reduced transpose | on-chip):
-                #   K = 16:  64->64 3.09 | 2.50   128->128 3.40 | 2.94   256->256 4.56 | 4.26     -> on-chip (dG never written)
-                #   K = 32:  64->128 2.17 | 2.80  128->256 2.52 | 3.24   256->256 2.58 | 3.16     -> pair
-                # (at K = 32 the on-chip kernel's workgroup holds 8 points x 32 slots: two weight tiles per anchor step, one tile
-                # buffer, and the pair's transpose runs 16 points per workgroup).  Round 1's fused exact-f32 kernel stays the
-                # memory-lean choice for everything (EPN_INTER_BWD_DATA=fused).
-                mode = "onchip" if d.nn <= 16 else "split"
+                # Three forms.  Measured per layer of the ModelNet schedule at B = 32 (ms; pair = dG GEMM + LDS-pre-reduced
+                # transpose | on-chip kernel, csrc/inter_bwd_f2.hip: dG never written):
+                #   stand-alone (tools/bwd_onchip_probe.py, profiles/r06_bwd_onchip_probe.txt)
+                #     K = 16:  64->64 3.09 | 2.50   128->128 3.40 | 2.94   256->256 4.56 | 4.26
+                #     K = 32:  64->128 2.17 | 2.80  128->256 2.52 | 3.24   256->256 2.58 | 3.16
+                #   inside the training step (bench per_call, one box): K = 16: 2.75 | 2.72, 3.38 | 3.33, 4.39 | 4.81 -- the pair is
+                #   HBM-bound and keeps its speed on a chip at its power limit, the on-chip kernel is latency-bound and does not;
+                #   the step: 536-537 point-clouds/s (pair everywhere) vs 530-532 (on-chip at K = 16) vs 505-510 (on-chip everywhere).
+                # So the pair stays the default; EPN_INTER_BWD_DATA=onchip is the form that moves 36-54 GB less per step and
+                # allocates no [cols, cin*ks] gradient; round 1's fused exact-f32 kernel (=fused) writes no such tensor either.
+                mode = "split"
             if (mode == "onchip" and gemm.f16x2_on(G) and go_amax is not None and isinstance(geo, InterGeometry)
                     and lib.epn_inter_bwd_data_f16x2_ok(ctypes.byref(d))):
                 # dG never written (csrc/inter_bwd_f2.hip): the two-piece contraction dOut . W runs inside the workgroup of the

@@ -210,7 +210,7 @@ def test_inv_model_vs_reference_golden(gpu, fused):
 _ORACLE_STEP = {}
 
 
-@pytest.mark.parametrize("inter_mode", ["auto", "onchip"])
+@pytest.mark.parametrize("inter_mode", ["auto", "onchip", "auto+bwd_data_onchip"])
 def test_full_width_cls_step_matches_oracle_loss(gpu, monkeypatch, inter_mode):
     """Full-width classification network on 2 clouds: logits, loss and EVERY parameter gradient against the CPU oracle
     (SPConvNets/models/cls_so3net_pn.py:15-40 restated by oracle/backbone_ref.py) -- in the default split form and with
@@ -223,6 +223,10 @@ def test_full_width_cls_step_matches_oracle_loss(gpu, monkeypatch, inter_mode):
     from epn_pointcloud_amd import models as M, schedule as S
     from oracle import backbone_ref as B
     from test_models_cpu import tables
+    bwd_onchip = inter_mode == "auto+bwd_data_onchip"       # the split form with dG kept on chip (csrc/inter_bwd_f2.hip, round 6)
+    if bwd_onchip:
+        inter_mode = "auto"
+        monkeypatch.setenv("EPN_INTER_BWD_DATA", "onchip")
     monkeypatch.setenv("EPN_INTER_MODE", inter_mode)
     layers = S.cls_so3net_schedule(1024)
     torch.manual_seed(5)
@@ -244,6 +248,11 @@ def test_full_width_cls_step_matches_oracle_loss(gpu, monkeypatch, inter_mode):
         taken = []
         real = ops.InterSO3ConvOnChipFn.forward
         monkeypatch.setattr(ops.InterSO3ConvOnChipFn, "forward", staticmethod(lambda ctx, *a: (taken.append(1), real(ctx, *a))[1]))
+    if bwd_onchip:
+        from epn_pointcloud_amd import ops
+        kinds = []
+        real_launch = ops._launch
+        monkeypatch.setattr(ops, "_launch", lambda kind, *a: (kinds.append(kind), real_launch(kind, *a))[1])
     lg, _ = m(pts.to(gpu))
     loss_g = torch.nn.functional.cross_entropy(lg, labels.to(gpu))
     pd = {n: p for n, p in m.named_parameters() if p.requires_grad}
@@ -277,6 +286,8 @@ def test_full_width_cls_step_matches_oracle_loss(gpu, monkeypatch, inter_mode):
         assert n in gr and gr[n].abs().max().item() >= 1e-3 * gmax, n   # (the named ones of round 5 are among the checked)
     if inter_mode == "onchip":
         assert len(taken) >= 6, taken
+    if bwd_onchip:                              # every InterSO3Conv with cin >= 16 took it; no dG GEMM, no separate transpose
+        assert kinds.count("inter_bwd_data_f2") >= 6 and "inter_gemm_dg" not in kinds and "inter_ungroup" not in kinds, kinds
 
 
 @pytest.mark.parametrize("dt", ["f32", "bf16"])
