@@ -411,8 +411,11 @@ def roofline_of(records, prof_steps, dtype_name, with_traffic, graph_mode):
                 for (kind, key, kname), (ms, n, fl, by) in sorted(calls.items(), key=lambda kv: -kv[1][0])]
     detail = {
         "per_call": per_call,
-        "per_kernel": {k: dict(all_priced.get(k, {}), kernel_exact=k, ms_per_step=round(v["ms"] / prof_steps, 3),
-                               launches_per_step=round(v["launches"] / prof_steps, 1))
+        # keyed by the READABLE instance name (short_kernel: also decodes the names the C++ demangler leaves mangled -- every
+        # bf16 instance, whose template arguments contain 'DF16b'); `kernel_exact` keeps the library's / rocprofv3's string
+        "per_kernel": {(short_kernel(k) if not k.startswith("(host)") else k):
+                       dict(all_priced.get(k, {}), kernel_exact=k, ms_per_step=round(v["ms"] / prof_steps, 3),
+                            launches_per_step=round(v["launches"] / prof_steps, 1))
                        for k, v in sorted(agg.items())},
         "per_kernel_ms_sum": round(sum(v["ms"] for v in agg.values()) / prof_steps, 3),
         "dominant_kernel_exact": dom,

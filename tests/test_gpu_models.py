@@ -413,7 +413,8 @@ def test_bench_line_kernel_names_are_profiler_names(gpu, tmp_path):
     assert line["detail"] == detail_file and line["value"] > 0 and line["roofline"]["frac"] > 0
     assert len(json.dumps(line["roofline"])) < 900
     detail = json.load(open(detail_file))["detail"]["headline"]
-    names = set(detail["per_kernel"])
+    assert not any(k.startswith("_Z") for k in detail["per_kernel"]), "per_kernel keys are readable instance names"
+    names = {v["kernel_exact"] for v in detail["per_kernel"].values()}
     assert detail["dominant_kernel_exact"] in known
     assert bench.short_kernel(detail["dominant_kernel_exact"]) == line["roofline"]["kernel"]
     missing = sorted(n for n in names if n not in known and not n.startswith("(host)"))
