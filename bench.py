@@ -597,6 +597,7 @@ def measure(cfg, rank, local_rank, world, dev, first=True):
     f2_mode = dtype_name == "f32" and _gemm.FP32_MODE == "f16x2"
     if f2_mode:
         _gemm.f16x2_overflow_count(reset=True)   # the timed region must leave the overflow sentinel at zero (checked below)
+    _gemm.fixed_point_range_count(reset=True)    # ... and the range sentinel of the fixed-point transpose of the grouping
     if buckets is not None:
         buckets.record_timing, buckets.timings = True, []
     if graph is None:
@@ -675,6 +676,11 @@ def measure(cfg, rank, local_rank, world, dev, first=True):
         raise RuntimeError(f"{f2_overflow} wave(s) of two-piece fp16 GEMMs ended with a non-finite accumulator during the timed "
                            "region: a reported max|operand| was too small (epn_f16x2_overflow_count) -- the measurement is void")
 
+    fx_range = _gemm.fixed_point_range_count(reset=True)
+    if fx_range:
+        raise RuntimeError(f"{fx_range} workgroup(s) of the fixed-point transpose of the grouping saw a contribution beyond the range "
+                           "its reported max|dG| allows (epn_inter_ungroup_cloud_range_count) -- the measurement is void")
+
     nn_desc = "/".join(str(k) for k in sorted({l.nn for l in layers}, reverse=True))
     out = {
         "metric": (f"point-clouds/sec {'fwd' if cfg.forward_only else 'fwd+bwd'}, "
@@ -700,6 +706,7 @@ def measure(cfg, rank, local_rank, world, dev, first=True):
         out["config"]["dp_path"] = f"{collect}+1 all-reduce" if graph is not None else "hooks"
     if f2_overflow is not None:
         out["f16x2_overflow"] = f2_overflow      # the sentinel of the two-piece kernels over the timed region (0, or the run raised)
+    out["fixed_point_range"] = fx_range          # ... of the fixed-point transpose of the grouping (0, or the run raised)
     if dp_info is not None:
         # efficiency against the rank program measured in THIS run: value / (N x the comm-free rate of the slowest rank)
         slow = dp_info.get("per_rank_no_comm_ms", [None, dp_info["no_comm_ms_per_step_local"]])[1]
@@ -772,7 +779,7 @@ def compact_line(out):
                                 "scaling", "vs_baseline", "dtype", "data", "config") if k in out}
     if "roofline" in out:
         line["roofline"] = out["roofline"]
-    for k in ("f16x2_overflow", "dp"):          # the overflow sentinel over the timed region; the multi-rank self-explanation
+    for k in ("f16x2_overflow", "fixed_point_range", "dp"):          # the overflow sentinel over the timed region; the multi-rank self-explanation
         if k in out:
             line[k] = out[k]
     if "cpu_baseline" in out:

@@ -32,7 +32,8 @@ EXPORTS = [
     "epn_so3_basis_amax_split_f32", "epn_so3_basis_norm_amax_split_f32",
     "epn_norm_act_pair_fwd_amax", "epn_norm_act_pair_bwd_apply_amax", "epn_norm_act_bwd_apply_amax_f32",
     "epn_absmax_f32", "epn_f16x2_overflow_count", "epn_inter_bwd_data_f16x2_ok", "epn_inter_bwd_data_f16x2_workspace_bytes",
-    "epn_inter_bwd_data_f16x2_f32", "epn_gemm_nt_f16x2_workspace_bytes", "epn_gemm_nt_f16x2_f32", "epn_gemm_tn_f16x2_f32", "epn_gemm_tn_grouped_f16x2",
+    "epn_inter_bwd_data_f16x2_f32", "epn_inter_ungroup_cloud_ok", "epn_inter_ungroup_cloud_workspace_bytes", "epn_inter_ungroup_cloud_f32",
+    "epn_inter_ungroup_cloud_bf16", "epn_inter_ungroup_cloud_range_count", "epn_gemm_nt_f16x2_workspace_bytes", "epn_gemm_nt_f16x2_f32", "epn_gemm_tn_f16x2_f32", "epn_gemm_tn_grouped_f16x2",
     "epn_inter_group_bf16", "epn_inter_ungroup_bf16", "epn_intra_group_bf16", "epn_so3_basis_bf16",
     "epn_gather_rows", "epn_scatter_rows", "epn_conv1x1_c1_f32", "epn_conv1x1_c1_bwd_weight_f32",
     "epn_anchor_softmax_pool_fwd_f32", "epn_anchor_softmax_pool_bwd_f32",
@@ -70,7 +71,7 @@ class NormPairSide(ctypes.Structure):
 class GemmNtProblem(ctypes.Structure):
     """struct epn_gemm_nt_problem (include/epn_so3conv.h)."""
     _fields_ = [("A", _vp), ("Bt", _vp), ("C", _vp), ("M", ctypes.c_longlong), ("lda", ctypes.c_longlong),
-                ("ldb", ctypes.c_longlong), ("ldc", ctypes.c_longlong), ("N", _ci), ("K", _ci), ("col_stats", _vp)]
+                ("ldb", ctypes.c_longlong), ("ldc", ctypes.c_longlong), ("N", _ci), ("K", _ci), ("col_stats", _vp), ("c_amax", _vp)]
 
 
 class GemmTnProblem(ctypes.Structure):
@@ -227,6 +228,14 @@ def get_lib():
     lib.epn_inter_bwd_data_f16x2_workspace_bytes.restype = _sz
     lib.epn_inter_bwd_data_f16x2_f32.argtypes = [dp, _vp, _vp, _vp, _vp, _ci, _vp, _sz, _vp]
     lib.epn_f16x2_overflow_count.restype = _ll
+    lib.epn_inter_ungroup_cloud_ok.argtypes = [dp]
+    lib.epn_inter_ungroup_cloud_ok.restype = _ci
+    lib.epn_inter_ungroup_cloud_workspace_bytes.argtypes = [dp]
+    lib.epn_inter_ungroup_cloud_workspace_bytes.restype = _sz
+    lib.epn_inter_ungroup_cloud_f32.argtypes = [dp, _vp, _vp, _vp, _vp, _vp, _sz, _vp]
+    lib.epn_inter_ungroup_cloud_bf16.argtypes = [dp, _vp, _vp, _vp, _vp, _vp, _sz, _vp]
+    lib.epn_inter_ungroup_cloud_range_count.argtypes = [_ci]
+    lib.epn_inter_ungroup_cloud_range_count.restype = _ll
     lib.epn_gemm_nt_f16x2_workspace_bytes.argtypes = [_ci, gp]
     lib.epn_gemm_nt_f16x2_workspace_bytes.restype = ctypes.c_size_t
     lib.epn_gemm_nt_f16x2_f32.argtypes = [_ci, gp, pp, _vp, ctypes.c_size_t, _vp]
@@ -279,7 +288,7 @@ def get_lib():
 
 
 # Host-only entry points (no stream argument, nothing launched): handed out unwrapped.
-_HOST_ONLY = {"epn_inter_bwd_data_f16x2_ok", "epn_version", "epn_strerror", "epn_set_kernel_policy", "epn_last_kernel", "epn_f16x2_overflow_count", "epn_inter_is_fused", "epn_inter_split_ok", "epn_inter_c1_ok",
+_HOST_ONLY = {"epn_inter_bwd_data_f16x2_ok", "epn_inter_ungroup_cloud_ok", "epn_inter_ungroup_cloud_range_count", "epn_version", "epn_strerror", "epn_set_kernel_policy", "epn_last_kernel", "epn_f16x2_overflow_count", "epn_inter_is_fused", "epn_inter_split_ok", "epn_inter_c1_ok",
               "epn_inter_split_saved_bytes",
               "epn_intra_is_fused", "epn_inter_onchip_ok", "epn_inter_group_packed_ok", "epn_inter_packed_position"}
 CALL_HOOK = None      # ops.profile_begin(): callable(name, fn, args) -> rc, brackets every launching call with HIP events

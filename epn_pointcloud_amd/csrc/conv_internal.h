@@ -100,6 +100,15 @@ int launch_inter_unpack_weight_grad(const float *gWp, int cout, int cin, int ks,
 int launch_inter_ungroup_mfma(const epn_inter_desc *d, const float *rk4, const void *dG, float *dF, int32_t *order,
                               int bf16, hipStream_t st);
 int launch_morton_order(const float *new_xyz, int b, int p2, int32_t *order, hipStream_t st);
+// inter_ungroup_cloud.hip: the transpose of the grouping with a cloud's gradient rows resident in LDS (64-bit fixed-point
+// accumulators, no global atomics).  extra = workspace behind the rotated-kernel table, inter_ungroup_cloud_extra_bytes; dg_amax:
+// device scalar max|dG|; add: optional tensor of dF's shape and type added to the result (may be dF itself); bf16: dG is bf16;
+// out_bf16: dF (and add) are bf16
+bool inter_ungroup_cloud_ok(const epn_inter_desc *d);
+size_t inter_ungroup_cloud_extra_bytes(const epn_inter_desc *d);
+int launch_inter_ungroup_cloud(const epn_inter_desc *d, const float *rk4, const void *dG, const float *dg_amax, void *dF,
+                               const void *add, int bf16, int out_bf16, void *extra, hipStream_t st);
+long long ungroup_cloud_range_take(bool reset);
 // inter_bwd_f2.hip: the data gradient of InterSO3Conv with dG kept on chip (two-piece fp16 contraction inside the LDS-reduced
 // scatter's workgroup).  rk4p: na*32*4 floats of scratch (a kernel-point order of its own), order: b*p2 int32, extra:
 // inter_bwd_f2_extra_bytes; go_amax: device scalar max|dOut|.  dF is accumulated into (zero it for a plain gradient).

@@ -17,6 +17,7 @@ struct GemmNtProb {        // C[M][N] = A[M][K] . Bt[N][K]^T
     const void *Bp;        // split GEMM (gemm_x3.hip): the three bf16 planes [3][N][K] of Bt, filled by its launcher
     float *stats;          // optional: per-column (sum, sum of squares) of every 32-row block of C, [M/32][N][2] (M % 32 == 0)
     const float *a_amax, *b_amax;   // two-piece fp16 form (gemm_x3.hip, NPL = 2): device scalar max|A|; b_amax[n] = max|Bt[n][:]| per weight row (filled by the launcher) -> power-of-two scales
+    unsigned *c_amax;      // optional: device scalar the kernel raises to max|C| (as stored; bit pattern of a non-negative float, atomicMax); the caller zeroes it
 };
 struct GemmNtBatch {
     int nprob;
@@ -129,6 +130,34 @@ __device__ __forceinline__ void nt_col_stats(const gemm_f32x16 (&acc)[TM][TN], f
             }
         }
     }
+}
+#endif
+
+// max |C| of an NT tile from its accumulators into the device scalar *out (epilogue by-product for a consumer that needs the
+// range of C -- the cloud-resident transpose of the grouping, inter_ungroup_cloud.hip -- without a pass over C).  Values as
+// stored (rounded to bf16 first when C is bf16); non-finite ones are left out, as in launch_absmax.  Rows / columns beyond M / N
+// hold copies of the last valid ones (the loaders clamp), so no masking is needed.
+#ifdef __HIPCC__
+template <int TM, int TN, typename TO>
+__device__ __forceinline__ void nt_c_amax(const gemm_f32x16 (&acc)[TM][TN], unsigned *__restrict__ out) {
+    // one v_max3_f32 per two accumulators (|x| is an operand modifier; maxNum drops NaN): the first version -- integer compares
+    // with the non-finite test per element, four instructions per accumulator -- cost the short-K data-gradient GEMMs 6-18 %
+    float mf = 0.0f;
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; r += 2) mf = fmaxf(fmaxf(mf, fabsf(acc[i][j][r])), fabsf(acc[i][j][r + 1]));
+    if constexpr (sizeof(TO) == 2) mf = (float)(__bf16)mf;      // rounding is monotonic: max of the rounded values = the rounded max
+    unsigned m = __builtin_bit_cast(unsigned, mf);
+    m = m < 0x7f800000u ? m : 0u;                               // (an infinite element: left out, as launch_absmax does; its consumer's own check reports it)
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) {
+        const unsigned v = (unsigned)__shfl_xor((int)m, o, 64);
+        m = v > m ? v : m;
+    }
+    if ((threadIdx.x & 63) == 0 && m > __atomic_load_n(out, __ATOMIC_RELAXED)) atomicMax(out, m);
 }
 #endif
 

@@ -219,6 +219,7 @@ __global__ __launch_bounds__(64 * WGM * WGN) void gemm_nt_kernel(GemmNtBatch B) 
     // ---- epilogue: D[row = (r&3) + 8 (r>>2) + 4 lj][col = li]
     TO *__restrict__ C = static_cast<TO *>(P.C);
     if (P.stats) nt_col_stats<TM, TN, TO>(acc, P.stats, P.M, P.N, m0 + wm * TM * 32, n0 + wn * TN * 32, li, lj);
+    if (P.c_amax) nt_c_amax<TM, TN, TO>(acc, P.c_amax);
     if (m0 + BM <= P.M && n0 + BN <= P.N && (long long)BM * P.ldc < (1LL << 30)) {
         // interior tile: wave-uniform base + 32-bit lane offset; one scalar multiply and one vector add per output row.
         // (The checked form below costs ~15 VALU instructions per element -- 128 elements per lane: measured as a fixed
@@ -1295,6 +1296,21 @@ __global__ void gemm_nt_generic_kernel(const T *__restrict__ A, const T *__restr
     for (int k = 0; k < K; ++k) s = fmaf((float)A[m * lda + k], (float)Bt[(long long)n * ldb + k], s);
     store_out(C + m * ldc + n, s);
 }
+// generic path: max|C| by a pass over C (the MFMA kernels take it from their accumulators, gemm.h nt_c_amax)
+template <typename TO>
+__global__ __launch_bounds__(256) void nt_amax_from_c_kernel(const TO *__restrict__ C, long long M, int N, long long ldc, unsigned *__restrict__ out) {
+    unsigned m = 0;
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < M * N; i += (long long)gridDim.x * 256) {
+        const unsigned a = __builtin_bit_cast(unsigned, (float)C[(i / N) * ldc + i % N]) & 0x7fffffffu;
+        m = (a > m && a < 0x7f800000u) ? a : m;
+    }
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) {
+        const unsigned v = (unsigned)__shfl_xor((int)m, o, 64);
+        m = v > m ? v : m;
+    }
+    if ((threadIdx.x & 63) == 0 && m > __atomic_load_n(out, __ATOMIC_RELAXED)) atomicMax(out, m);
+}
 template <typename T>
 __global__ void gemm_tn_generic_kernel(const T *__restrict__ X, const T *__restrict__ Y, float *__restrict__ C,
                                        long long R, int N1, int N2, long long ldx, long long ldy, long long ldc) {
@@ -1353,6 +1369,11 @@ int launch_nt_typed(GemmNtBatch &B, hipStream_t st) {
                                static_cast<const T *>(p.A), static_cast<const T *>(p.Bt), static_cast<TO *>(p.C), p.M,
                                p.N, p.K, p.lda, p.ldb, p.ldc);
             EPN_CHECK_LAUNCH();
+            if (p.c_amax) {
+                EPN_LAUNCH_AUX((nt_amax_from_c_kernel<TO>), dim3((unsigned)((n + 255) / 256 < 4096 ? (n + 255) / 256 : 4096)), dim3(256), 0, st,
+                               static_cast<const TO *>(p.C), p.M, p.N, p.ldc, p.c_amax);
+                EPN_CHECK_LAUNCH();
+            }
             if (p.stats) {
                 const long long ns = (p.M >> 5) * p.N;
                 EPN_LAUNCH_AUX((nt_stats_from_c_kernel<TO>), dim3((unsigned)((ns + 255) / 256)), dim3(256), 0, st,
@@ -1815,7 +1836,7 @@ static int nt_entry(int nprob, const epn_gemm_nt_problem *probs, int dtype, int 
             const epn_gemm_nt_problem &q = probs[i0 + i];
             GemmNtProb &p = B.p[i];
             p.A = q.A; p.Bt = q.Bt; p.C = q.C; p.M = q.M; p.N = q.N; p.K = q.K; p.lda = q.lda; p.ldb = q.ldb; p.ldc = q.ldc;
-            p.tiles_n = 0; p.tile0 = 0; p.stats = q.col_stats; p.a_amax = p.b_amax = nullptr;
+            p.tiles_n = 0; p.tile0 = 0; p.stats = q.col_stats; p.c_amax = reinterpret_cast<unsigned *>(q.c_amax); p.a_amax = p.b_amax = nullptr;
         }
         int rc = launch_gemm_nt(B, dtype, out_dtype, st);
         if (rc) return rc;

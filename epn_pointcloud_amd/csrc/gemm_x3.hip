@@ -403,6 +403,7 @@ __global__ __launch_bounds__(64 * WGM * WGN) void gemm_nt_x3_kernel(GemmNtBatch 
         EPN_F2_CHECK(chk);
     }
     if (P.stats) nt_col_stats<TM, TN, float>(acc, P.stats, P.M, P.N, m0 + wm * TM * 32, n0 + wn * TN * 32, li, lj);
+    if (P.c_amax) nt_c_amax<TM, TN, float>(acc, P.c_amax);
     // (round 5, measured and dropped: whole tiles leaving through LDS -- a wave's 32 x 32 TN accumulator block transposed in the
     // idle stage buffers and stored as 16-byte pieces of whole rows, 8x fewer store instructions: 2-7 % SLOWER on every
     // output-heavy shape (245760 x 6144 x 256: 2.88 -> 2.94 ms, 983040 x 1536 x 64: 1.25 -> 1.35).  The store tail of these tiles
@@ -697,7 +698,7 @@ extern "C" int epn_gemm_nt_split_f32(int nprob, const epn_gemm_nt_problem *probs
             const epn_gemm_nt_problem &q = probs[i0 + i];
             GemmNtProb &p = B.p[i];
             p.A = q.A; p.Bt = q.Bt; p.C = q.C; p.M = q.M; p.N = q.N; p.K = q.K; p.lda = q.lda; p.ldb = q.ldb; p.ldc = q.ldc;
-            p.tiles_n = 0; p.tile0 = 0; p.ntile = 0; p.Bp = nullptr; p.stats = q.col_stats;
+            p.tiles_n = 0; p.tile0 = 0; p.ntile = 0; p.Bp = nullptr; p.stats = q.col_stats; p.c_amax = reinterpret_cast<unsigned *>(q.c_amax);
             p.a_amax = p.b_amax = nullptr;
         }
         const size_t need = gemm_nt_x3_workspace(B);
@@ -746,7 +747,7 @@ extern "C" int epn_gemm_nt_f16x2_f32(int nprob, const epn_gemm_nt_problem *probs
             const epn_gemm_nt_problem &q = probs[i0 + i];
             GemmNtProb &p = B.p[i];
             p.A = q.A; p.Bt = q.Bt; p.C = q.C; p.M = q.M; p.N = q.N; p.K = q.K; p.lda = q.lda; p.ldb = q.ldb; p.ldc = q.ldc;
-            p.tiles_n = 0; p.tile0 = 0; p.ntile = 0; p.Bp = nullptr; p.stats = q.col_stats;
+            p.tiles_n = 0; p.tile0 = 0; p.ntile = 0; p.Bp = nullptr; p.stats = q.col_stats; p.c_amax = reinterpret_cast<unsigned *>(q.c_amax);
             p.a_amax = a_amax ? a_amax[i0 + i] : nullptr; p.b_amax = nullptr;
         }
         const size_t need = gemm_nt_f2_workspace(B);

@@ -36,7 +36,7 @@ epn_gemm_nt_problem nt_problem(const void *A, const void *Bt, void *C, long long
     p.A = A; p.Bt = Bt; p.C = C;
     p.M = M; p.lda = K; p.ldb = K; p.ldc = N;
     p.N = N; p.K = K;
-    p.col_stats = nullptr;
+    p.col_stats = nullptr; p.c_amax = nullptr;
     return p;
 }
 

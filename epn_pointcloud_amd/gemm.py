@@ -114,6 +114,19 @@ def f16x2_overflow_count(reset=False, device=None):
     return n
 
 
+def fixed_point_range_count(reset=False, device=None):
+    """epn_inter_ungroup_cloud_range_count of `device`: workgroups of the cloud-resident transpose of the grouping that saw a
+    contribution beyond the range its reported max|dG| allows (or a non-finite dG) since the counter was last cleared; their
+    rows were written as NaN.  Synchronises; not inside a stream capture."""
+    lib = _lib.get_lib()
+    with torch.cuda.device(device if device is not None else torch.cuda.current_device()):
+        torch.cuda.synchronize()
+        n = int(lib.epn_inter_ungroup_cloud_range_count(1 if reset else 0))
+    if n < 0:
+        raise RuntimeError(f"epn_inter_ungroup_cloud_range_count failed: hipError {-n}")
+    return n
+
+
 # Debug mode of the scale contract (EPN_AB=1 EPN_CHECK_AMAX=1, or gemm.CHECK_AMAX = True): every maximum a two-piece GEMM is
 # about to consume is re-derived by a pass over its operand and compared on the host -- a synchronising, eager-only check that
 # turns a stale / under-reported tag into an exception naming the call (tests/test_gpu_bf16.py runs a training step under it).
@@ -181,8 +194,10 @@ def _problem(A, Bt, C):
     return p
 
 
-def gemm_nt_grouped(problems, out_dtype=None, col_stats=None, a_amax=None):
+def gemm_nt_grouped(problems, out_dtype=None, col_stats=None, a_amax=None, c_amax=None):
     """problems: list of (A [M,K], Bt [N,K], C [M,N] or None); one grouped launch per 6 problems.  Returns the C list.
+    c_amax: optional list (one per problem) of ZEROED 1-element fp32 device tensors the kernels raise to max|C| from their
+    accumulators (None entries: off).
     a_amax: optional list (one per problem) of 1-element device tensors holding max|A| (f16x2 mode; None = computed here).
     All operands share one dtype (fp32 or bf16); C is that dtype unless out_dtype says float32.  col_stats: optional list
     (one entry per problem) of fp32 [M/32, N, 2] tensors the kernels fill with per-column (sum, sum of squares) of every
@@ -215,6 +230,8 @@ def gemm_nt_grouped(problems, out_dtype=None, col_stats=None, a_amax=None):
                     or part.numel() != A.shape[0] // 32 * Bt.shape[0] * 2):
                 raise ValueError("gemm_nt: col_stats must be a contiguous fp32 [M/32, N, 2] tensor, M % 32 == 0")
             arr[i].col_stats = part.data_ptr()
+        if c_amax is not None and c_amax[i] is not None:
+            arr[i].c_amax = _use_amax(c_amax[i])
         outs.append(C)
         keep += [A, Bt]
     st = _lib.stream_of(outs[0])
@@ -235,10 +252,19 @@ def gemm_nt_grouped(problems, out_dtype=None, col_stats=None, a_amax=None):
     return outs
 
 
-def gemm_nt(A, Bt, out=None, out_dtype=None, col_stats=False, a_amax=None):
+def gemm_nt(A, Bt, out=None, out_dtype=None, col_stats=False, a_amax=None, c_amax=False):
     """col_stats=True: returns (C, partials [M/32, N, 2] or None when M % 32 != 0) -- the per-channel statistics of C
-    from the kernel's epilogue (ops.sums_from_partials finishes them).  a_amax: device scalar max|A| (f16x2 mode)."""
+    from the kernel's epilogue (ops.sums_from_partials finishes them).  a_amax: device scalar max|A| (f16x2 mode).
+    c_amax=True: returns (C, max|C| as a 1-element device tensor, from the kernel's epilogue; C is tagged with it)."""
     am = None if a_amax is None else [a_amax]
+    if c_amax:
+        cm = torch.zeros(1, dtype=torch.float32, device=A.device)
+        C = gemm_nt_grouped([(A, Bt, out)], out_dtype, a_amax=am, c_amax=[cm])[0]
+        try:
+            C._epn_amax = (C._version, cm)
+        except (AttributeError, RuntimeError):
+            pass
+        return C, cm
     if not col_stats:
         return gemm_nt_grouped([(A, Bt, out)], out_dtype, a_amax=am)[0]
     M, N = A.shape[0], Bt.shape[0]

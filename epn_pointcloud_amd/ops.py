@@ -539,6 +539,29 @@ class InterSO3ConvSplitFn(torch.autograd.Function):
                                                                 _lib.stream_of(G)), "inter_unpack_weight_grad")
         if need_f:
             mode = os.environ.get("EPN_INTER_BWD_DATA", "auto")
+            if mode in ("auto", "cloud") and _ungroup_cloud_takes(lib, d, geo, G.dtype, mode):
+                # dG GEMM (its epilogue leaves max|dG|) + the transpose of the grouping with the cloud's gradient rows resident
+                # in LDS (csrc/inter_ungroup_cloud.hip: 64-bit fixed-point accumulators, no global atomics): no zero fill of a
+                # scatter target, the gradient is written in its own dtype, the other branch's gradient of a shared input is
+                # folded into the write-out, and the result is bitwise repeatable (so this is also the deterministic form)
+                Wt = gemm.transpose_cast(Wc, G.dtype)
+                dG, dg_amax = _launch("inter_gemm_dg", _inter_key(d), gemm_fl, G.device,
+                                      lambda: gemm.gemm_nt(g2d, Wt, a_amax=go_amax, c_amax=True))
+                add = None
+                if grad_shared is not None:
+                    add = cast_feats(to_cl(grad_shared, "grad_shared"), G.dtype)
+                gf = empty_cl(d.b, cin, d.p1, d.na, G.device, G.dtype)
+                nb = int(lib.epn_inter_ungroup_cloud_workspace_bytes(ctypes.byref(d)))
+                ws = torch.empty(max(nb, 16), dtype=torch.uint8, device=G.device)
+                gflops = 9.0 * cols * d.ks * d.nn + 2.0 * cols * cin * d.ks * d.nn
+                fn = _entry(lib, "inter_ungroup_cloud", G.dtype)
+                _lib.check(_launch("inter_ungroup", _inter_key(d), gflops, G.device,
+                                   lambda: fn(ctypes.byref(d), ctypes.c_void_p(dG.data_ptr()), gemm._use_amax(dg_amax), _cl_ptr(gf),
+                                              None if add is None else _cl_ptr(add), ctypes.c_void_p(ws.data_ptr()),
+                                              ctypes.c_size_t(ws.numel()), _lib.stream_of(G))), "inter_ungroup_cloud")
+                return gf, gW, None, None
+            if mode == "cloud":
+                mode = "split"
             # the other branch's gradient of the shared input: fp32 -> the scatter accumulates onto it; otherwise added below
             # (bf16 features: starting the fp32 scatter target from the converted gradient instead of zeros measured no gain --
             # 1444 vs 1455 point-clouds/s on the rotation network -- so that path keeps the plain addition)
@@ -626,6 +649,20 @@ class InterSO3ConvSplitFn(torch.autograd.Function):
             if grad_shared is not None:
                 gf = gf + grad_shared.to(gf.dtype)
         return gf, gW, None, None
+
+
+def _ungroup_cloud_takes(lib, d, geo, dtype, mode):
+    """Does the cloud-resident transpose of the grouping (epn_inter_ungroup_cloud_*) take this layer?  mode "cloud": whenever
+    the kernel can; "auto": where it is measured faster INSIDE the training step than the LDS-pre-reduced atomic scatter --
+    bf16 features: rotation network 1950 -> 2022-2043 point-clouds/s, 3DMatch 1874-1882 -> 1950-1962 (no fp32 scatter target,
+    zero fill or conversion pass either); fp32 features: the kernel itself is 5-15 % faster per call at K <= 32, but the step is
+    not (cls 530-532 -> 524-528, rotation fp32 1033 -> 1013: profiles/r06_ab_ungroup_cloud.txt) -- and always in
+    deterministic mode, which it satisfies by construction (the slab-based kernels cost 3.6-8 % of a step)."""
+    if not isinstance(geo, InterGeometry) or not lib.epn_inter_ungroup_cloud_ok(ctypes.byref(d)):
+        return False
+    if mode == "cloud" or deterministic_bwd(dtype):
+        return True
+    return dtype == torch.bfloat16
 
 
 def _lib_generic():

@@ -537,6 +537,10 @@ typedef struct epn_gemm_nt_problem {
      * take: the per-channel statistics pass of a following BatchNorm / InstanceNorm (base_so3conv.py:196-204) without
      * reading C again. */
     float *col_stats;
+    /* Optional (NULL: off; library 0.4): device scalar the kernel RAISES to max|C| (values as stored; non-finite ones left
+     * out) from its accumulators -- zero it before the call.  What epn_inter_ungroup_cloud_* takes as dg_amax when C is the
+     * gradient of the grouped features. */
+    float *c_amax;
 } epn_gemm_nt_problem;
 int epn_gemm_nt_f32(int nprob, const epn_gemm_nt_problem *probs, epn_stream_t stream);
 /* sums[g][c][2] = sum over the blocks_per_group consecutive 32-row blocks of group g of partials[block][c][2] (fixed
@@ -621,6 +625,29 @@ size_t epn_inter_bwd_data_f16x2_workspace_bytes(const epn_inter_desc *d);
 int epn_inter_bwd_data_f16x2_f32(const epn_inter_desc *d, const float *grad_out_cl, const float *W, const float *go_amax,
                                  float *grad_feats_cl, int accumulate, void *workspace, size_t workspace_bytes,
                                  epn_stream_t stream);
+/* Transpose of the grouping with a whole cloud's gradient rows resident in LDS (round 6; csrc/inter_ungroup_cloud.hip):
+ *     grad_feats[b, idx[b,p,n], a, c] = (add[...] +) sum over (p, n) of sum_k w[b,p,a,k,n] * grad_grouped[(b,p,a)][c*ks + k]
+ * -- the backward of inter_zpconv_grouping_naive's gather (vgtk/vgtk/spconv/functional.py:372-390), as epn_inter_ungroup_*, with
+ * NO global atomics: a workgroup owns every output point of one (cloud, anchor) and with them the destination rows outright,
+ * accumulates them in LDS as 64-bit fixed-point integers (integer LDS atomics run at the LDS store rate on gfx950, the
+ * floating-point ones 31 x slower) and writes them once.  Consequences: no zero fill of the target, the result is written in the
+ * gradient's own type (bf16 entry: bf16 in, bf16 out -- no fp32 scatter target + conversion pass), `add` (same shape and type as
+ * grad_feats_cl; may BE grad_feats_cl; or NULL) is folded into the write-out, and the sum does not depend on the order in which
+ * waves arrive: bitwise repeatable.
+ * Fixed point: unit = max|grad_grouped| * 2^-(43 .. 50) (from the device scalar *dg_amax and the largest multiplicity of the
+ * index table; every contribution is rounded ONCE to the unit, the sum is exact, one rounding to the output type).  dg_amax
+ * NULL: the entry takes the maximum itself (one more pass over grad_grouped).  An UNDERSTATED maximum makes contributions leave
+ * the representable range: such a workgroup writes NaN to its rows and bumps a sticky device counter
+ * (epn_inter_ungroup_cloud_range_count; reset != 0 clears it), as does a non-finite grad_grouped.
+ * Shapes (epn_..._ok): the MFMA grouping's (cin % 16 == 0, ks % 4 == 0, ks <= 32, nn <= 64), p2 <= 4096, and p1 small enough
+ * for (p1 + 4) * 16 * 8 bytes of accumulators (p1 <= 1148). */
+int epn_inter_ungroup_cloud_ok(const epn_inter_desc *d);
+size_t epn_inter_ungroup_cloud_workspace_bytes(const epn_inter_desc *d);
+int epn_inter_ungroup_cloud_f32(const epn_inter_desc *d, const float *grad_grouped, const float *dg_amax, float *grad_feats_cl,
+                                const float *add, void *workspace, size_t workspace_bytes, epn_stream_t stream);
+int epn_inter_ungroup_cloud_bf16(const epn_inter_desc *d, const void *grad_grouped, const float *dg_amax, void *grad_feats_cl,
+                                 const void *add, void *workspace, size_t workspace_bytes, epn_stream_t stream);
+long long epn_inter_ungroup_cloud_range_count(int reset);
 /* The scale contract of the two-piece form made loud (round 6).  The power-of-two scale leaves a factor 2-4 below fp16's
  * 65504, so an operand element above 2-4 x the maximum the caller REPORTED becomes inf in the split and the product silently
  * non-finite -- where the fp32 matmul these entry points replace (torch.matmul in vgtk/vgtk/so3conv/modules.py:48-55) would

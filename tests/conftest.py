@@ -37,8 +37,14 @@ def f16x2_scale_contract(request):
         return
     from epn_pointcloud_amd import gemm
     gemm.f16x2_overflow_count(reset=True)
+    gemm.fixed_point_range_count(reset=True)
     yield
     n = gemm.f16x2_overflow_count(reset=True)
+    m = gemm.fixed_point_range_count(reset=True)
+    if request.node.get_closest_marker("nonfinite_inputs") is None:
+        assert m == 0, (f"{m} workgroup(s) of the fixed-point transpose of the grouping saw a contribution beyond the range the reported "
+                        "max|dG| allows (epn_inter_ungroup_cloud_range_count): an under-reported maximum, or non-finite inputs "
+                        "without @pytest.mark.nonfinite_inputs")
     if request.node.get_closest_marker("nonfinite_inputs") is None:
         assert n == 0, (f"{n} wave(s) of two-piece fp16 GEMMs ended with a non-finite accumulator during this test: a reported "
                         "max|operand| was too small (or the test feeds non-finite inputs and lacks @pytest.mark.nonfinite_inputs)")
