@@ -45,15 +45,25 @@ __device__ unsigned g_uc_range = 0u;       // waves that saw a contribution beyo
 constexpr int UC_DUMMY = 4;                // accumulator rows behind the cloud's p1 rows: slots that name no input point, one per lane group
 constexpr int UC_LDS_MAX = 160 * 1024;     // LDS of one workgroup: the whole CU
 
-// slot table: tab[(b * p2 + p) * EW + n] = byte offset of the accumulator row (row * rowb < 2^24) | multiplicity << 24.  Row = the input
-// point, or p1 + (n / 4) % 4 for a slot that names none (beyond nn, shadow / negative index).  Multiplicity as load_hood (inter_device.h): the ball query pads a
-// row that found cnt < nn neighbours by repeating them cyclically (vgtk/vgtk/cuda/grouping_cuda_kernel.cu:100-104); the first
-// occurrence carries the number of slots holding that point, the repeats 0.  mulmax: largest multiplicity of the call.
-__global__ __launch_bounds__(256) void uc_slots_kernel(const int32_t *__restrict__ idx, long long npts, int p1, int nn, int ew,
-                                                       unsigned rowb, uint32_t *__restrict__ tab, unsigned *__restrict__ mulmax) {
+// Per-call tables of the neighbourhoods, one wave per output point (everything about a point that does not depend on the
+// anchor -- the main kernel visits every point once per ANCHOR, so it only loads):
+//   off[(b * p2 + p) * EW + n]      byte offset of slot n's accumulator row (row * rowb): the input point, or p1 + (n / 4) % 4 for a
+//                                   slot that names none (beyond nn, shadow / negative index)
+//   hood[((b * p2 + p) * NT + t) * 80 + c * 16 + x]   for neighbour n = 16 t + x, times its multiplicity m:
+//                                   c = 0..2: (xyz[idx[n]] - centre) m;  c = 3: m;  c = 4: alpha m  (alpha = 1 - |g|^2 / sigma)
+//                                   -- the S-MFMA operand of lane (x, j) is entry c = j, its accumulator start entry c = 4
+// Multiplicity as load_hood (inter_device.h): the ball query pads a row that found cnt < nn neighbours by repeating them
+// cyclically (vgtk/vgtk/cuda/grouping_cuda_kernel.cu:100-104); the first occurrence carries the number of slots holding that
+// point, the repeats (and slots without a point) 0 -- their weights come out as relu(0) = 0.  mulmax: largest multiplicity.
+__global__ __launch_bounds__(256) void uc_slots_kernel(const int32_t *__restrict__ idx, const float *__restrict__ xyz,
+                                                       const float *__restrict__ new_xyz, long long npts, int p1, int p2, int nn, int ew,
+                                                       float sigma_inv, unsigned rowb, uint32_t *__restrict__ off,
+                                                       float *__restrict__ hood, unsigned *__restrict__ mulmax) {
     const int lane = threadIdx.x & 63;
     const long long pt = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
     if (pt >= npts) return;                                   // wave-uniform
+    const long long bb = pt / p2;
+    const int pp = (int)(pt - bb * p2);
     const int32_t *row = idx + pt * nn;
     const int first = row[0];
     const bool in = lane < nn;
@@ -65,7 +75,16 @@ __global__ __launch_bounds__(256) void uc_slots_kernel(const int32_t *__restrict
     if (__ballot(bad) != 0ull) cnt = nn;
     const bool valid = q >= 0 && q < p1;
     const unsigned mul = (valid && lane < cnt) ? (unsigned)((nn - 1 - lane) / cnt + 1) : 0u;
-    if (lane < ew) tab[pt * ew + lane] = (valid ? (unsigned)q : (unsigned)(p1 + ((lane >> 2) & 3))) * rowb | (mul << 24);
+    if (lane < ew) {
+        off[pt * ew + lane] = (valid ? (unsigned)q : (unsigned)(p1 + ((lane >> 2) & 3))) * rowb;
+        const float *s = xyz + bb * 3 * p1, *c = new_xyz + bb * 3 * p2;
+        const int qq = valid ? q : 0;
+        const float gx = s[qq] - c[pp], gy = s[p1 + qq] - c[p2 + pp], gz = s[2 * p1 + qq] - c[2 * p2 + pp];
+        const float alpha = 1.0f - (gx * gx + gy * gy + gz * gz) * sigma_inv;
+        const float m = (float)mul;
+        float *h = hood + (pt * (ew >> 4) + (lane >> 4)) * 80 + (lane & 15);
+        h[0] = gx * m; h[16] = gy * m; h[32] = gz * m; h[48] = m; h[64] = alpha * m;
+    }
     unsigned m = mul;
 #pragma unroll
     for (int o = 32; o >= 1; o >>= 1) {
@@ -96,7 +115,8 @@ __global__ __launch_bounds__(256) void uc_absmax_kernel(const TG *__restrict__ s
 
 struct UcArgs {
     InterArgs A;               // gout = dG [ncol][cin*ks] (TG), out = dF (fp32 or bf16), rk4 = the rotated-kernel table
-    const uint32_t *tab;       // slot table [b][p2][16 NT]
+    const uint32_t *tab;       // accumulator-row offsets [b][p2][16 NT]
+    const float *hood;         // neighbourhood table [b][p2][NT][5][16]
     const unsigned *mulmax;
     const float *dg_amax;      // device scalar max|dG|
     const void *add;           // optional tensor of dF's shape and type added to the result (NULL: none)
@@ -120,7 +140,7 @@ __device__ __forceinline__ float uc_scale(float amax, unsigned mulmax, int ks) {
 
 template <int NT, int KT, typename TG, int NWV, int NL>
 __global__ __launch_bounds__(64 * NWV) void inter_ungroup_cloud_kernel(UcArgs P) {
-    // LDS: [accumulators (p1 + UC_DUMMY) rows x CR x 8 bytes | 16 bytes: poison flag | the cloud's input coordinates 3 x p1 floats]
+    // LDS: [accumulators (p1 + UC_DUMMY) rows x CR x 8 bytes | 16 bytes: poison flag]
     extern __shared__ __attribute__((aligned(16))) char uc_smem[];
     const InterArgs &A = P.A;
     constexpr int EW = 16 * NT;
@@ -138,15 +158,12 @@ __global__ __launch_bounds__(64 * NWV) void inter_ungroup_cloud_kernel(UcArgs P)
     const int c0 = blockIdx.y * CR;
     const int rows = A.p1 + UC_DUMMY;
     int *poison = reinterpret_cast<int *>(uc_smem + (size_t)rows * ROWB);
-    float *lx = reinterpret_cast<float *>(uc_smem + (size_t)rows * ROWB + 16);
 
-    {   // zero the accumulators, stage the coordinates of the cloud's input points
+    {   // zero the accumulators
         const u32x4_t z = {0u, 0u, 0u, 0u};
         u32x4_t *acc4 = reinterpret_cast<u32x4_t *>(uc_smem);
         for (int i = tid; i < rows * (CR / 2); i += NTH) acc4[i] = z;
         if (tid == 0) *poison = 0;
-        const float *sx = A.xyz + (size_t)bb * 3 * A.p1;
-        for (int i = tid; i < 3 * A.p1; i += NTH) lx[i] = sx[i];
     }
     const float S = uc_scale(*P.dg_amax, *P.mulmax, A.ks);
     const float invS = __builtin_bit_cast(float, (254u - (__builtin_bit_cast(unsigned, S) >> 23)) << 23);
@@ -154,8 +171,8 @@ __global__ __launch_bounds__(64 * NWV) void inter_ungroup_cloud_kernel(UcArgs P)
 #pragma unroll
     for (int kt = 0; kt < KT; ++kt) rk[kt] = A.rk4[((size_t)a * EPN_KS_MAX + 16 * kt + x) * 4 + j];
     const int gss = A.cin * A.ks;
-    const float *cx = A.new_xyz + (size_t)bb * 3 * A.p2;
-    const uint32_t *tabc = P.tab + (size_t)bb * A.p2 * EW;
+    const uint32_t *tabc = P.tab + (size_t)bb * A.p2 * EW + 4 * j;
+    const float *hoodc = P.hood + (size_t)bb * A.p2 * NT * 80 + lane;         // lane (x, j) -> entry c = j of neighbour x
     // dG fragment of (point p, chunk cw): lane (x = channel, j) <- dG[(b, p, a)][(c0 + 16 cw + x) * ks + 16 kt + 4 j .. + 3]
     const TG *dGc = reinterpret_cast<const TG *>(A.gout) + ((size_t)bb * A.p2 * A.na + a) * gss + (size_t)(c0 + x) * A.ks;
     int koff[KT];
@@ -169,74 +186,57 @@ __global__ __launch_bounds__(64 * NWV) void inter_ungroup_cloud_kernel(UcArgs P)
             else d[kt] = ld4f(src + koff[kt]);
         }
     };
-    auto load_tab = [&](int p, unsigned (&e1)[NT], u32x4_t (&e4)[NT]) {
+    auto load_tab = [&](int p, float (&hb)[NT], float (&ha)[NT], u32x4_t (&e4)[NT]) {
         const uint32_t *t0 = tabc + (size_t)p * EW;
+        const float *h0 = hoodc + (size_t)p * NT * 80;
 #pragma unroll
         for (int t = 0; t < NT; ++t) {
-            e1[t] = t0[16 * t + x];
-            e4[t] = *reinterpret_cast<const u32x4_t *>(t0 + 16 * t + 4 * j);
+            hb[t] = h0[80 * t];                           // S-MFMA operand: (g_x, g_y, g_z, 1)[j] m of neighbour 16 t + x
+            ha[t] = h0[80 * t + 64 - 16 * j];             // its accumulator start: alpha m of neighbour x
+            e4[t] = *reinterpret_cast<const u32x4_t *>(t0 + 16 * t);
         }
     };
-    __syncthreads();                                            // accumulators are zero, coordinates staged
+    __syncthreads();                                            // accumulators are zero
 
+    typedef __attribute__((address_space(3))) char lds_char;
+    typedef __attribute__((address_space(3))) unsigned long long lds_u64;
+    const unsigned x8b = (unsigned)(uintptr_t)(lds_char *)uc_smem + 8u * (unsigned)x;
     int chkp = 0;                 // range check, as bit patterns: largest positive contribution of the lane (signed order; NaN / inf on top) ...
     unsigned chkn = 0u;           // ... and the most negative one (unsigned order puts the sign bit on top)
     if (wave < A.p2) {
-        unsigned e1n[NT];
+        float hbn[NT], han[NT];
         u32x4_t e4n[NT];
         // dG fragments are requested D chunks ahead of their use (a ring over the flattened (point, chunk) sequence): with four
         // waves per SIMD -- all a 1024-thread workgroup can have -- a fragment requested one chunk (~500 cycles) ahead arrived
         // an HBM round trip too late, and every wave waited it out once per chunk (v4: 0.90 ms on the 32-channel K = 64 layer)
         constexpr int D = sizeof(TG) == 2 ? NL : (NL < 4 ? NL : 4);
         frag_t ring[D][KT];
-        float pcn[3] = {cx[wave], cx[A.p2 + wave], cx[2 * A.p2 + wave]};     // centre of the next point (scalar loads, one point ahead)
-        load_tab(wave, e1n, e4n);
+        load_tab(wave, hbn, han, e4n);
 #pragma unroll
         for (int i = 0; i < D; ++i) load_dg(wave, i, ring[i]);
         for (int p = wave; p < A.p2; p += NWV) {
-            // ---- neighbourhood fragments of the point.  All twelve coordinate reads first, pinned as values: left alone, hipcc
-            // sinks each read into the lane-group branch that uses it and waits for them one at a time (v2: 2-3 LDS round
-            // trips per 16 neighbours in front of everything else a point does)
-            const float pcx = pcn[0], pcy = pcn[1], pcz = pcn[2];
-            float gA[NT];           // S-MFMA operand, already times multiplicity x scale of its neighbour (>= 0: relu commutes with it)
-            float gB[NT];
+            // ---- neighbourhood fragments of the point: loads only (uc_slots_kernel), times the scale of the accumulators (both
+            // operands of the S-MFMA scale with it: relu commutes with a non-negative factor)
+            float gB[NT], alphaN[NT];
             unsigned rowoff[NT][4];
-            float g3[NT][3];
-            bool valid[NT];
 #pragma unroll
             for (int t = 0; t < NT; ++t) {
-                const unsigned o1 = e1n[t] & 0xffffffu;
-                valid[t] = o1 < (unsigned)A.p1 * ROWB;
-                const unsigned qq4 = valid[t] ? o1 / (ROWB / 4u) : 0u;              // byte offset of the point's x coordinate
-                const float *lq = reinterpret_cast<const float *>(reinterpret_cast<const char *>(lx) + qq4);
-                g3[t][0] = lq[0]; g3[t][1] = lq[A.p1]; g3[t][2] = lq[2 * A.p1];
-            }
+                gB[t] = hbn[t] * S;
+                alphaN[t] = han[t] * S;
 #pragma unroll
-            for (int t = 0; t < NT; ++t) asm volatile("" : "+v"(g3[t][0]), "+v"(g3[t][1]), "+v"(g3[t][2]));
-#pragma unroll
-            for (int t = 0; t < NT; ++t) {
-                const float gx = g3[t][0] - pcx, gy = g3[t][1] - pcy, gz = g3[t][2] - pcz;
-                const float alpha = valid[t] ? 1.0f - (gx * gx + gy * gy + gz * gz) * A.sigma_inv : -1e30f;
-                const float mS = (float)(e1n[t] >> 24) * S;                          // multiplicity of neighbour 16 t + x, in accumulator units
-                const float gxy = j & 1 ? gy : gx, gza = j & 1 ? alpha : gz;
-                gA[t] = (j & 2 ? gza : gxy) * mS;
-                gB[t] = j == 3 ? mS : gA[t];
-#pragma unroll
-                for (int r = 0; r < 4; ++r) rowoff[t][r] = (e4n[t][r] & 0xffffffu) | (8u * (unsigned)x);
+                for (int r = 0; r < 4; ++r) rowoff[t][r] = e4n[t][r] + x8b;       // LDS address of (row, this lane's column)
             }
             const int pn = p + NWV < A.p2 ? p + NWV : p;       // (the last point re-reads its own entries: cache hits, unused)
-            load_tab(pn, e1n, e4n);
-            pcn[0] = cx[pn]; pcn[1] = cx[A.p2 + pn]; pcn[2] = cx[2 * A.p2 + pn];
+            load_tab(pn, hbn, han, e4n);
             // ---- kernel-influence weights of (point, anchor), times multiplicity and scale of their neighbour (folded into the
-            // S-MFMA's operands above): lane (x, j), register r -> w[k = 16 kt + 4 j + r][n = 16 t + x] -- the A operand of the
+            // S-MFMA's operands): lane (x, j), register r -> w[k = 16 kt + 4 j + r][n = 16 t + x] -- the A operand of the
             // contraction (row = neighbour x)
             frag_t wgt[NT][KT];
 #pragma unroll
             for (int t = 0; t < NT; ++t) {
-                const float alphaN = __shfl(gA[t], 48 + x, 64);
 #pragma unroll
                 for (int kt = 0; kt < KT; ++kt) {
-                    f32x4 sk = {alphaN, alphaN, alphaN, alphaN};
+                    f32x4 sk = {alphaN[t], alphaN[t], alphaN[t], alphaN[t]};
                     sk = mfma4(rk[kt], gB[t], sk);
                     if constexpr (sizeof(TG) == 2) {
                         wgt[t][kt] = relu_pack4(sk);
@@ -280,8 +280,11 @@ __global__ __launch_bounds__(64 * NWV) void inter_ungroup_cloud_kernel(UcArgs P)
                         const double dv = (double)v + 6755399441055744.0;                    // 1.5 * 2^52
                         u32x2_t w = __builtin_bit_cast(u32x2_t, dv);
                         w[1] -= 0x43380000u;                                                // bits(1.5 * 2^52): low word zero
-                        unsigned long long *dst = reinterpret_cast<unsigned long long *>(uc_smem + rowoff[t][r] + cw * 128);
-                        __hip_atomic_fetch_add(dst, __builtin_bit_cast(unsigned long long, w), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                        // (the address as an integer: through a pointer into uc_smem hipcc re-adds the array's -- link-time -- base to
+                        // every one of them, two instructions per value and chunk)
+                        lds_u64 *dst = (lds_u64 *)(uintptr_t)(rowoff[t][r] + (unsigned)cw * 128u);
+                        __hip_atomic_fetch_add((unsigned long long *)dst, __builtin_bit_cast(unsigned long long, w), __ATOMIC_RELAXED,
+                                               __HIP_MEMORY_SCOPE_WORKGROUP);
                     }
             }
         }
@@ -322,8 +325,8 @@ __global__ __launch_bounds__(64 * NWV) void inter_ungroup_cloud_kernel(UcArgs P)
     }
 }
 
-// LDS of one workgroup at cr channels: accumulators + flag + coordinates
-size_t uc_lds_bytes(const epn_inter_desc *d, int cr) { return (size_t)(d->p1 + UC_DUMMY) * cr * 8 + 16 + (size_t)d->p1 * 12; }
+// LDS of one workgroup at cr channels: accumulators + flag
+size_t uc_lds_bytes(const epn_inter_desc *d, int cr) { return (size_t)(d->p1 + UC_DUMMY) * cr * 8 + 16; }
 
 int uc_channels_per_wg(const epn_inter_desc *d, int bf16) {     // 16, 32, 64 or 128: the largest that divides cin and fits
     int best = 0;
@@ -358,10 +361,14 @@ bool inter_ungroup_cloud_ok(const epn_inter_desc *d) {
            uc_channels_per_wg(d, 0) > 0 && (long long)d->b * d->p2 * d->na * d->cin * d->ks < (1LL << 40);
 }
 
-// workspace behind the rotated-kernel table: slot table [b][p2][16 nt] + 256 bytes (largest multiplicity)
+// workspace behind the rotated-kernel table: offsets [b][p2][16 nt] + neighbourhood table [b][p2][nt][80] + 256 bytes (scalars)
+static size_t uc_off_bytes(const epn_inter_desc *d) {
+    const int nt = d->nn <= 16 ? 1 : (d->nn <= 32 ? 2 : 4);
+    return ((size_t)d->b * d->p2 * 16 * nt * 4 + 255) & ~(size_t)255;
+}
 size_t inter_ungroup_cloud_extra_bytes(const epn_inter_desc *d) {
     const int nt = d->nn <= 16 ? 1 : (d->nn <= 32 ? 2 : 4);
-    return (((size_t)d->b * d->p2 * 16 * nt * 4 + 255) & ~(size_t)255) + 256;
+    return uc_off_bytes(d) + (((size_t)d->b * d->p2 * nt * 80 * 4 + 255) & ~(size_t)255) + 256;
 }
 
 int launch_inter_ungroup_cloud(const epn_inter_desc *d, const float *rk4, const void *dG, const float *dg_amax, void *dF,
@@ -380,7 +387,9 @@ int launch_inter_ungroup_cloud(const epn_inter_desc *d, const float *rk4, const 
         dg_amax = reinterpret_cast<const float *>(slot);
     }
     const long long npts = (long long)d->b * d->p2;
-    EPN_LAUNCH_AUX(uc_slots_kernel, dim3((unsigned)((npts + 3) / 4)), dim3(256), 0, st, d->ball_idx, npts, d->p1, d->nn, ew, (unsigned)uc_channels_per_wg(d, bf16) * 8u, tab, mulmax);
+    float *hood = reinterpret_cast<float *>(static_cast<char *>(extra) + uc_off_bytes(d));
+    EPN_LAUNCH_AUX(uc_slots_kernel, dim3((unsigned)((npts + 3) / 4)), dim3(256), 0, st, d->ball_idx, d->xyz, d->new_xyz, npts, d->p1, d->p2,
+                   d->nn, ew, 1.0f / d->sigma, (unsigned)uc_channels_per_wg(d, bf16) * 8u, tab, hood, mulmax);
     EPN_CHECK_LAUNCH();
     UcArgs P;
     InterArgs &A = P.A;
@@ -389,7 +398,7 @@ int launch_inter_ungroup_cloud(const epn_inter_desc *d, const float *rk4, const 
     A.sigma_inv = 1.0f / d->sigma;
     A.b = d->b; A.p1 = d->p1; A.p2 = d->p2; A.nn = d->nn; A.na = d->na; A.ks = d->ks; A.cin = d->cin; A.cout = d->cout;
     A.wk = 0; A.packed = 0; A.ncol = (long long)d->b * d->p2 * d->na; A.col_tiles_per_wg = 1;
-    P.tab = tab; P.mulmax = mulmax; P.dg_amax = dg_amax; P.add = add; P.out_bf16 = out_bf16;
+    P.tab = tab; P.hood = hood; P.mulmax = mulmax; P.dg_amax = dg_amax; P.add = add; P.out_bf16 = out_bf16;
     P.cr = uc_channels_per_wg(d, bf16);
     const size_t lds = uc_lds_bytes(d, P.cr);
     const dim3 grid((unsigned)(d->b * d->na), (unsigned)(d->cin / P.cr));
