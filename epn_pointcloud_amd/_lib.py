@@ -233,7 +233,7 @@ def get_lib():
     lib.epn_inter_ungroup_cloud_workspace_bytes.argtypes = [dp]
     lib.epn_inter_ungroup_cloud_workspace_bytes.restype = _sz
     lib.epn_inter_ungroup_cloud_f32.argtypes = [dp, _vp, _vp, _vp, _vp, _vp, _sz, _vp]
-    lib.epn_inter_ungroup_cloud_bf16.argtypes = [dp, _vp, _vp, _vp, _vp, _vp, _sz, _vp]
+    lib.epn_inter_ungroup_cloud_bf16.argtypes = [dp, _vp, _vp, _vp, _vp, _ci, _vp, _sz, _vp]
     lib.epn_inter_ungroup_cloud_range_count.argtypes = [_ci]
     lib.epn_inter_ungroup_cloud_range_count.restype = _ll
     lib.epn_gemm_nt_f16x2_workspace_bytes.argtypes = [_ci, gp]

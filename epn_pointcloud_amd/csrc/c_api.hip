@@ -434,7 +434,7 @@ extern "C" size_t epn_inter_ungroup_cloud_workspace_bytes(const epn_inter_desc *
     return w.big_off * sizeof(float) + inter_ungroup_cloud_extra_bytes(d);
 }
 static int inter_ungroup_cloud_any(const epn_inter_desc *d, const void *grad_grouped, const float *dg_amax, void *grad_feats_cl,
-                                   const void *add, void *workspace, size_t workspace_bytes, int bf16, epn_stream_t stream) {
+                                   const void *add, void *workspace, size_t workspace_bytes, int bf16, int out_bf16, epn_stream_t stream) {
     hipStream_t st = epn_stream(stream);
     int rc = check_desc(d);
     if (rc) return rc;
@@ -444,7 +444,7 @@ static int inter_ungroup_cloud_any(const epn_inter_desc *d, const void *grad_gro
     if (!grad_feats_cl) return EPN_ENULL;
     if (d->b == 0) return 0;
     if (d->p2 == 0) {                      // no output points: the gradient is what `add` holds, or zero
-        const size_t bytes = (size_t)d->b * d->p1 * d->na * d->cin * (bf16 ? 2 : 4);
+        const size_t bytes = (size_t)d->b * d->p1 * d->na * d->cin * (out_bf16 ? 2 : 4);
         if (add && add != grad_feats_cl) EPN_HIP(hipMemcpyAsync(grad_feats_cl, add, bytes, hipMemcpyDeviceToDevice, st));
         else if (!add) EPN_HIP(hipMemsetAsync(grad_feats_cl, 0, bytes, st));
         return 0;
@@ -453,17 +453,17 @@ static int inter_ungroup_cloud_any(const epn_inter_desc *d, const void *grad_gro
     float *base = static_cast<float *>(workspace);
     rc = launch_inter_tables_mfma(d, base + ws.rk_off, base + ws.rk4_off, base + ws.beta_off, st);
     if (rc) return rc;
-    return launch_inter_ungroup_cloud(d, base + ws.rk4_off, grad_grouped, dg_amax, grad_feats_cl, add, bf16, bf16, base + ws.big_off, st);
+    return launch_inter_ungroup_cloud(d, base + ws.rk4_off, grad_grouped, dg_amax, grad_feats_cl, add, bf16, out_bf16, base + ws.big_off, st);
 }
 extern "C" int epn_inter_ungroup_cloud_f32(const epn_inter_desc *d, const float *grad_grouped, const float *dg_amax,
                                            float *grad_feats_cl, const float *add, void *workspace, size_t workspace_bytes,
                                            epn_stream_t stream) {
-    return inter_ungroup_cloud_any(d, grad_grouped, dg_amax, grad_feats_cl, add, workspace, workspace_bytes, 0, stream);
+    return inter_ungroup_cloud_any(d, grad_grouped, dg_amax, grad_feats_cl, add, workspace, workspace_bytes, 0, 0, stream);
 }
 extern "C" int epn_inter_ungroup_cloud_bf16(const epn_inter_desc *d, const void *grad_grouped, const float *dg_amax,
-                                            void *grad_feats_cl, const void *add, void *workspace, size_t workspace_bytes,
-                                            epn_stream_t stream) {
-    return inter_ungroup_cloud_any(d, grad_grouped, dg_amax, grad_feats_cl, add, workspace, workspace_bytes, 1, stream);
+                                            void *grad_feats_cl, const void *add, int out_f32, void *workspace,
+                                            size_t workspace_bytes, epn_stream_t stream) {
+    return inter_ungroup_cloud_any(d, grad_grouped, dg_amax, grad_feats_cl, add, workspace, workspace_bytes, 1, out_f32 ? 0 : 1, stream);
 }
 extern "C" long long epn_inter_ungroup_cloud_range_count(int reset) { return ungroup_cloud_range_take(reset != 0); }
 

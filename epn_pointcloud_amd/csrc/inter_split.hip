@@ -28,7 +28,7 @@ struct SplitPlan {
     // forward scratch
     size_t f_wd, f_gemm, f_total;
     // backward scratch
-    size_t b_wt, b_dg, b_gw, b_nt, b_tn, b_total;
+    size_t b_wt, b_dg, b_gw, b_nt, b_tn, b_uc, b_total;
 };
 
 epn_gemm_nt_problem nt_problem(const void *A, const void *Bt, void *C, long long M, int N, int K) {
@@ -61,7 +61,10 @@ int make_plan(const epn_inter_desc *d, int bf16, SplitPlan &P) {
     P.b_gw = rnd256((size_t)d->cout * P.ck * sizeof(float));
     P.b_nt = bf16 ? 0 : rnd256(epn_gemm_nt_f16x2_workspace_bytes(1, &dg)) + 256;      // + the max|grad_out| slot
     P.b_tn = rnd256(epn_gemm_tn_workspace_bytes(bf16 ? 1 : 3, (long long)P.cols, d->cout, (int)P.ck));
-    P.b_total = P.grp_ws + P.b_wt + P.b_dg + P.b_gw + P.b_nt + P.b_tn;
+    // bf16: the transpose of the grouping runs in its cloud-resident form where that takes the layer (what ops.InterSO3ConvSplitFn
+    // does): its workspace (tables) + 256 bytes for max|dG| from the data-gradient GEMM's epilogue
+    P.b_uc = (bf16 && epn_inter_ungroup_cloud_ok(d)) ? rnd256(epn_inter_ungroup_cloud_workspace_bytes(d)) + 256 : 0;
+    P.b_total = P.grp_ws + P.b_wt + P.b_dg + P.b_gw + P.b_nt + P.b_tn + P.b_uc;
     return 0;
 }
 
@@ -173,8 +176,18 @@ int backward(const epn_inter_desc *d, const void *grad_out_cl, const float *W, c
         if (rc) return rc;
         epn_gemm_nt_problem p = nt_problem(grad_out_cl, Wt, dG, (long long)P.cols, (int)P.ck, d->cout);
         const float *am[1] = {go_amax};
+        char *uc_ws = static_cast<char *>(tn_ws) + P.b_tn;
+        float *dg_amax = P.b_uc ? reinterpret_cast<float *>(uc_ws + P.b_uc - 256) : nullptr;
+        if (dg_amax) {                               // the GEMM's epilogue raises it to max|dG|
+            rc = (int)hipMemsetAsync(dg_amax, 0, sizeof(float), (hipStream_t)stream);
+            if (rc) return rc;
+            p.c_amax = dg_amax;
+        }
         rc = bf16 ? epn_gemm_nt_bf16(1, &p, 0, stream) : epn_gemm_nt_f16x2_f32(1, &p, am, nt_ws, P.b_nt - 256, stream);
         if (rc) return rc;
+        if (dg_amax)          // bf16: cloud-resident transpose (no atomics, no zero fill; fp32 out as this entry's contract says)
+            return epn_inter_ungroup_cloud_bf16(d, dG, dg_amax, grad_feats_cl, accumulate ? grad_feats_cl : nullptr, 1, uc_ws,
+                                                P.b_uc - 256, stream);
         // transpose of the grouping: scatter pre-reduced in LDS, one fp32 atomic per distinct destination (a17)
         if (bf16) rc = accumulate ? epn_inter_ungroup_acc_bf16(d, dG, grad_feats_cl, grp_ws, P.grp_ws, stream)
                                   : epn_inter_ungroup_bf16(d, dG, grad_feats_cl, grp_ws, P.grp_ws, stream);

@@ -554,11 +554,14 @@ class InterSO3ConvSplitFn(torch.autograd.Function):
                 nb = int(lib.epn_inter_ungroup_cloud_workspace_bytes(ctypes.byref(d)))
                 ws = torch.empty(max(nb, 16), dtype=torch.uint8, device=G.device)
                 gflops = 9.0 * cols * d.ks * d.nn + 2.0 * cols * cin * d.ks * d.nn
+                args = [ctypes.byref(d), ctypes.c_void_p(dG.data_ptr()), gemm._use_amax(dg_amax), _cl_ptr(gf),
+                        None if add is None else _cl_ptr(add)]
+                if G.dtype == torch.bfloat16:
+                    args.append(0)                       # out_f32 = 0: the gradient leaves in bf16
                 fn = _entry(lib, "inter_ungroup_cloud", G.dtype)
                 _lib.check(_launch("inter_ungroup", _inter_key(d), gflops, G.device,
-                                   lambda: fn(ctypes.byref(d), ctypes.c_void_p(dG.data_ptr()), gemm._use_amax(dg_amax), _cl_ptr(gf),
-                                              None if add is None else _cl_ptr(add), ctypes.c_void_p(ws.data_ptr()),
-                                              ctypes.c_size_t(ws.numel()), _lib.stream_of(G))), "inter_ungroup_cloud")
+                                   lambda: fn(*args, ctypes.c_void_p(ws.data_ptr()), ctypes.c_size_t(ws.numel()),
+                                              _lib.stream_of(G))), "inter_ungroup_cloud")
                 return gf, gW, None, None
             if mode == "cloud":
                 mode = "split"

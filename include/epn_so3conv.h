@@ -631,7 +631,8 @@ int epn_inter_bwd_data_f16x2_f32(const epn_inter_desc *d, const float *grad_out_
  * NO global atomics: a workgroup owns every output point of one (cloud, anchor) and with them the destination rows outright,
  * accumulates them in LDS as 64-bit fixed-point integers (integer LDS atomics run at the LDS store rate on gfx950, the
  * floating-point ones 31 x slower) and writes them once.  Consequences: no zero fill of the target, the result is written in the
- * gradient's own type (bf16 entry: bf16 in, bf16 out -- no fp32 scatter target + conversion pass), `add` (same shape and type as
+ * gradient's own type (bf16 entry: bf16 in, bf16 out -- no fp32 scatter target + conversion pass; out_f32 != 0: fp32 out and
+ * add, the contract of epn_inter_ungroup_bf16), `add` (same shape and type as
  * grad_feats_cl; may BE grad_feats_cl; or NULL) is folded into the write-out, and the sum does not depend on the order in which
  * waves arrive: bitwise repeatable.
  * Fixed point: unit = max|grad_grouped| * 2^-(43 .. 50) (from the device scalar *dg_amax and the largest multiplicity of the
@@ -646,7 +647,7 @@ size_t epn_inter_ungroup_cloud_workspace_bytes(const epn_inter_desc *d);
 int epn_inter_ungroup_cloud_f32(const epn_inter_desc *d, const float *grad_grouped, const float *dg_amax, float *grad_feats_cl,
                                 const float *add, void *workspace, size_t workspace_bytes, epn_stream_t stream);
 int epn_inter_ungroup_cloud_bf16(const epn_inter_desc *d, const void *grad_grouped, const float *dg_amax, void *grad_feats_cl,
-                                 const void *add, void *workspace, size_t workspace_bytes, epn_stream_t stream);
+                                 const void *add, int out_f32, void *workspace, size_t workspace_bytes, epn_stream_t stream);
 long long epn_inter_ungroup_cloud_range_count(int reset);
 /* The scale contract of the two-piece form made loud (round 6).  The power-of-two scale leaves a factor 2-4 below fp16's
  * 65504, so an operand element above 2-4 x the maximum the caller REPORTED becomes inf in the split and the product silently

@@ -137,9 +137,12 @@ def test_auto_takes_the_cloud_form_where_it_is_faster(gpu, monkeypatch):
 
 def _call(lib, d, dG, amax, out, add, ws):
     from epn_pointcloud_amd import _lib, ops
-    fn = lib.epn_inter_ungroup_cloud_bf16 if dG.dtype == torch.bfloat16 else lib.epn_inter_ungroup_cloud_f32
-    return fn(ctypes.byref(d), ctypes.c_void_p(dG.data_ptr()), None if amax is None else ctypes.c_void_p(amax.data_ptr()),
-              ops._cl_ptr(out), None if add is None else ops._cl_ptr(add), ctypes.c_void_p(ws.data_ptr()), ws.numel(), _lib.stream_of(dG))
+    args = [ctypes.byref(d), ctypes.c_void_p(dG.data_ptr()), None if amax is None else ctypes.c_void_p(amax.data_ptr()),
+            ops._cl_ptr(out), None if add is None else ops._cl_ptr(add)]
+    if dG.dtype == torch.bfloat16:
+        args.append(1 if out.dtype == torch.float32 else 0)
+        return lib.epn_inter_ungroup_cloud_bf16(*args, ctypes.c_void_p(ws.data_ptr()), ws.numel(), _lib.stream_of(dG))
+    return lib.epn_inter_ungroup_cloud_f32(*args, ctypes.c_void_p(ws.data_ptr()), ws.numel(), _lib.stream_of(dG))
 
 
 def test_cloud_entry_arguments_range_contract_and_edge_cases(gpu):
@@ -172,6 +175,12 @@ def test_cloud_entry_arguments_range_contract_and_edge_cases(gpu):
     assert _call(lib, d, z, z.abs().max().reshape(1), out, None, ws) == 0
     assert out.abs().max().item() == 0.0
     assert gemm.fixed_point_range_count(reset=True) == 0
+    # bf16 gradient in, fp32 out (the contract of epn_inter_ungroup_bf16: what the composed split backward uses)
+    dGb = dG.to(torch.bfloat16)
+    outb = ops.empty_cl(b, cin, n, 60, gpu, torch.bfloat16)
+    assert _call(lib, d, dGb, amax, outb, None, ws) == 0 and _call(lib, d, dGb, amax, out, None, ws) == 0
+    assert (out.to(torch.bfloat16).float() - outb.float()).abs().max().item() <= 2 ** -7 * ref.abs().max().item()
+    assert (out - ref).abs().max().item() <= 2 ** -6 * ref.abs().max().item()
     # argument checks
     assert _call(lib, d, dG, amax, out, None, ws[:64]) == -2                 # EPN_EWORKSPACE
     d2 = geo.desc(40, cout)                                                  # cin % 16 != 0: not this kernel's

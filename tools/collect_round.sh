@@ -13,6 +13,9 @@ EPN_BENCH_ARGS="--model reg --dtype bf16" bash tools/collect_profiles.sh ${TAG}_
 for f in kernel_stats.csv pmc_per_kernel.json bench_under_rocprof.json; do cp gpurun_out/${TAG}_reg/$f $OUT/reg_bf16_$f; done
 EPN_BENCH_ARGS="--model inv --dtype bf16" bash tools/collect_profiles.sh ${TAG}_inv > $OUT/collect_inv.log 2>&1
 for f in kernel_stats.csv pmc_per_kernel.json; do cp gpurun_out/${TAG}_inv/$f $OUT/inv_bf16_$f; done; rm -rf gpurun_out/${TAG}_inv
+# the bf16 networks with the atomic scatter everywhere (EPN_INTER_BWD_DATA=split: the round-5 path), for the before / after of the LDS and L2-atomic counters
+EPN_INTER_BWD_DATA=split EPN_BENCH_ARGS="--model reg --dtype bf16" bash tools/collect_profiles.sh ${TAG}_regsplit > $OUT/collect_regsplit.log 2>&1
+for f in kernel_stats.csv pmc_per_kernel.json; do cp gpurun_out/${TAG}_regsplit/$f $OUT/reg_bf16_atomic_scatter_$f; done; rm -rf gpurun_out/${TAG}_regsplit
 # the same step with the data gradient of every InterSO3Conv on chip (EPN_INTER_BWD_DATA=onchip: dG never written): kernel stats + PMC
 EPN_INTER_BWD_DATA=onchip bash tools/collect_profiles.sh ${TAG}_onchip > $OUT/collect_onchip.log 2>&1
 for f in kernel_stats.csv pmc_per_kernel.json bench_under_rocprof.json; do cp gpurun_out/${TAG}_onchip/$f $OUT/cls_bwd_onchip_$f; done; rm -rf gpurun_out/${TAG}_onchip
@@ -38,7 +41,12 @@ python tools/tn_probe.py --dtype bf16 2>&1 | grep -v amdgpu.ids > $OUT/tn_probe.
 # round 6: hardware probes + per-layer A/B of the on-chip data gradient + the transposes priced against the L2 atomic roof
 hipcc --offload-arch=gfx950 -O3 tools/lds_tr_probe.hip -o $OUT/lds_tr_probe 2>/dev/null && $OUT/lds_tr_probe > $OUT/lds_tr_probe.txt 2>&1
 hipcc --offload-arch=gfx950 -O3 tools/atomic_rate_probe.hip -o $OUT/atomic_rate_probe 2>/dev/null && $OUT/atomic_rate_probe > $OUT/atomic_rate_probe.txt 2>&1
-rm -f $OUT/lds_tr_probe $OUT/atomic_rate_probe
+hipcc --offload-arch=gfx950 -O3 -w tools/lds_atomic_probe.hip -o $OUT/lds_atomic_probe 2>/dev/null && $OUT/lds_atomic_probe > $OUT/lds_atomic_probe.txt 2>&1
+hipcc --offload-arch=gfx950 -O3 -w tools/valu_rate_probe.hip -o $OUT/valu_rate_probe 2>/dev/null && $OUT/valu_rate_probe > $OUT/valu_rate_probe.txt 2>&1
+rm -f $OUT/lds_tr_probe $OUT/atomic_rate_probe $OUT/lds_atomic_probe $OUT/valu_rate_probe
+# the two transposes of the grouping per layer (atomic scatter | cloud-resident fixed point), and inside the step
+for m in "reg bf16" "inv bf16" "cls f32" "reg f32"; do python tools/ungroup_cloud_probe.py $m 2>&1 | grep -v amdgpu.ids >> $OUT/ungroup_cloud_probe.txt; done
+rm -f gpurun_out/r06_ab_ungroup_cloud.txt; bash tools/r06_ab4.sh > /dev/null 2>&1; cp gpurun_out/r06_ab_ungroup_cloud.txt $OUT/ab_ungroup_cloud.txt
 python tools/bwd_onchip_probe.py cls 2>&1 | grep -v amdgpu.ids > $OUT/bwd_onchip_probe.txt
 for m in "reg bf16" "inv bf16" "cls f32"; do python tools/ungroup_atomic_pricing.py $m 2>&1 | grep -v amdgpu.ids >> $OUT/ungroup_atomic_pricing.txt; done
 EPN_BENCH_ARGS="--model reg --dtype bf16" bash tools/replay_profile.sh ${TAG}_replay_reg --model reg --dtype bf16 > $OUT/replay_reg.log 2>&1

@@ -73,7 +73,8 @@ def main():
             fc = lib.epn_inter_ungroup_cloud_bf16 if bf else lib.epn_inter_ungroup_cloud_f32
 
             def cloud(o=out):
-                _lib.check(fc(ctypes.byref(d), G.data_ptr(), amax.data_ptr(), ops._cl_ptr(o), None, ws2.data_ptr(), ws2.numel(),
+                extra = (0,) if bf else ()
+                _lib.check(fc(ctypes.byref(d), G.data_ptr(), amax.data_ptr(), ops._cl_ptr(o), None, *extra, ws2.data_ptr(), ws2.numel(),
                               _lib.stream_of(G)), "ungroup_cloud")
             t_cloud = timed(cloud)
             cloud(out2)
