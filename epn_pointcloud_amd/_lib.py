@@ -12,7 +12,7 @@ import torch
 _PKG = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("EPN_LIB", os.path.join(_PKG, "libepn_so3conv.so"))   # EPN_LIB: A/B builds (tools/)
 
-ABI_VERSION = 2          # EPN_ABI_VERSION of the include/epn_so3conv.h this binding was written against
+ABI_VERSION = 3          # EPN_ABI_VERSION of the include/epn_so3conv.h this binding was written against
 
 EXPORTS = [
     "epn_version", "epn_abi_version", "epn_strerror", "epn_set_kernel_policy",

@@ -95,7 +95,10 @@ static bool use_mfma(const epn_inter_desc *d) { return inter_uses_mfma(d) && !fo
 // `saved` buffer carries a tag word and an untagged tail is re-derived, not trusted; no signature changed.  (0.3 DID change
 // behaviour without changing a signature -- fp32 `saved` grew by 256 bytes and the composed entries moved to the two-piece
 // GEMMs: INTEGRATION.md "ABI revisions" says so; the note above was too short.)
-extern "C" const char *epn_version(void) { return "epn_so3conv 0.4 (gfx950)"; }
+// 0.5 (round 6, second half; EPN_ABI_VERSION 3): epn_gemm_nt_problem gained the trailing `c_amax` member (max|C| from the
+// kernels' epilogue) -- callers that build the struct must be recompiled; new entry points epn_inter_ungroup_cloud_* (the transpose
+// of the grouping with a cloud's gradient rows resident in LDS); the composed bf16 split backward runs on it
+extern "C" const char *epn_version(void) { return "epn_so3conv 0.5 (gfx950)"; }
 extern "C" int epn_abi_version(void) { return EPN_ABI_VERSION; }
 
 extern "C" const char *epn_strerror(int code) {

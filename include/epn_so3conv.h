@@ -37,9 +37,10 @@ typedef void *epn_stream_t; /* hipStream_t; NULL = the null stream */
 /* Integer revision of this binary interface: bumped whenever an EXISTING signature or struct layout changes (new entry
  * points alone do not bump it).  A host compares epn_abi_version() of the library it loaded with the EPN_ABI_VERSION of
  * the header it was compiled against and refuses to run on a mismatch -- revision 2 changed `epn_ball_query_f64`'s radius
- * from double to float and grew `struct epn_gemm_nt_problem`, which a caller built against revision 1 would not notice
+ * from double to float and grew `struct epn_gemm_nt_problem`, which a caller built against revision 1 would not notice;
+ * revision 3 (round 6) grew that struct again (`c_amax`)
  * (INTEGRATION.md "ABI revisions").  epn_pointcloud_amd/_lib.py performs exactly this check at load time. */
-#define EPN_ABI_VERSION 2
+#define EPN_ABI_VERSION 3
 int epn_abi_version(void);
 const char *epn_version(void);
 const char *epn_strerror(int code);
