@@ -1397,6 +1397,15 @@ int launch_nt_typed(GemmNtBatch &B, hipStream_t st) {
             case 4: return launch_nt_cfg<T, TO, 2, 4, 2, 2>(B, st);      // 128 x 256, 8 waves
             case 5: return launch_nt_cfg<T, TO, 4, 1, 2, 2>(B, st);      // 256 x 64, 4 waves
             case 6: return launch_nt_cfg<T, TO, 2, 2, 4, 2>(B, st);      // 256 x 128, 4 waves, 128 x 64 per wave
+#ifdef EPN_TUNING
+            // short-K (data-gradient) shapes: four-wave workgroups with 128 accumulators per wave and a half-width K step, so that TWO
+            // fit a CU and one's store epilogue overlaps the other's loads (round 6 sweep, tools/r06_dg_sweep.sh ->
+            // profiles/r06_bf16_dg_tile_sweep.txt).  MEASURED 25-30 % SLOWER than the 256 x 256 tile on every bf16 data-gradient
+            // shape (245760 x 3072 x 256: 0.76-0.79 vs 0.60 ms; hipBLASLt through torch.mm: 0.60-0.62): kept for the record only
+            case 7: return launch_nt_cfg<T, TO, 2, 2, 2, 4, 4, 2>(B, st);   // 128 x 256, 4 waves, K step 32 (bf16) / 16 (fp32), 48 KB
+            case 8: return launch_nt_cfg<T, TO, 2, 2, 4, 2, 4, 2>(B, st);   // 256 x 128, 4 waves, same
+            case 10: return launch_nt_cfg<T, TO, 2, 2, 2, 4, 8, 2>(B, st);  // 128 x 256, 4 waves, full K step (96 KB: one workgroup per CU)
+#endif
             default: break;
         }
     }
