@@ -49,49 +49,72 @@ constexpr int UC_LDS_MAX = 160 * 1024;     // LDS of one workgroup: the whole CU
 // anchor -- the main kernel visits every point once per ANCHOR, so it only loads):
 //   off[(b * p2 + p) * EW + n]      byte offset of slot n's accumulator row (row * rowb): the input point, or p1 + (n / 4) % 4 for a
 //                                   slot that names none (beyond nn, shadow / negative index)
-//   hood[((b * p2 + p) * NT + t) * 80 + c * 16 + x]   for neighbour n = 16 t + x, times its multiplicity m:
+//   hood[((b * p2 + p) * 5 + c) * EW + n]             for neighbour n (= 16 t + x), times its multiplicity m:
 //                                   c = 0..2: (xyz[idx[n]] - centre) m;  c = 3: m;  c = 4: alpha m  (alpha = 1 - |g|^2 / sigma)
 //                                   -- the S-MFMA operand of lane (x, j) is entry c = j, its accumulator start entry c = 4
 // Multiplicity as load_hood (inter_device.h): the ball query pads a row that found cnt < nn neighbours by repeating them
 // cyclically (vgtk/vgtk/cuda/grouping_cuda_kernel.cu:100-104); the first occurrence carries the number of slots holding that
 // point, the repeats (and slots without a point) 0 -- their weights come out as relu(0) = 0.  mulmax: largest multiplicity.
+constexpr int UC_PTS = 8;                  // output points per wave of the table kernel
 __global__ __launch_bounds__(256) void uc_slots_kernel(const int32_t *__restrict__ idx, const float *__restrict__ xyz,
                                                        const float *__restrict__ new_xyz, long long npts, int p1, int p2, int nn, int ew,
                                                        float sigma_inv, unsigned rowb, uint32_t *__restrict__ off,
                                                        float *__restrict__ hood, unsigned *__restrict__ mulmax) {
+    // UC_PTS points per wave, their loads issued together: one point per wave was a chain of three dependent global round trips
+    // (index row, the row again at lane - cnt, coordinates) per 1.5 KB of table -- 85-91 us per call, 0.5 ms per rotation step
     const int lane = threadIdx.x & 63;
-    const long long pt = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (pt >= npts) return;                                   // wave-uniform
-    const long long bb = pt / p2;
-    const int pp = (int)(pt - bb * p2);
-    const int32_t *row = idx + pt * nn;
-    const int first = row[0];
+    const long long pt0 = ((long long)blockIdx.x * 4 + (threadIdx.x >> 6)) * UC_PTS;
+    if (pt0 >= npts) return;                                  // wave-uniform
     const bool in = lane < nn;
-    const int q = in ? row[lane] : -1;
-    const unsigned long long rep = __ballot(in && lane > 0 && q == first);
-    int cnt = rep ? (int)__builtin_ctzll(rep) : nn;
-    // only a genuinely cyclic row is de-duplicated (index tensors handed in by the caller may be arbitrary)
-    const bool bad = in && lane >= cnt && q != row[lane - cnt];
-    if (__ballot(bad) != 0ull) cnt = nn;
-    const bool valid = q >= 0 && q < p1;
-    const unsigned mul = (valid && lane < cnt) ? (unsigned)((nn - 1 - lane) / cnt + 1) : 0u;
-    if (lane < ew) {
-        off[pt * ew + lane] = (valid ? (unsigned)q : (unsigned)(p1 + ((lane >> 2) & 3))) * rowb;
-        const float *s = xyz + bb * 3 * p1, *c = new_xyz + bb * 3 * p2;
-        const int qq = valid ? q : 0;
-        const float gx = s[qq] - c[pp], gy = s[p1 + qq] - c[p2 + pp], gz = s[2 * p1 + qq] - c[2 * p2 + pp];
-        const float alpha = 1.0f - (gx * gx + gy * gy + gz * gz) * sigma_inv;
-        const float m = (float)mul;
-        float *h = hood + (pt * (ew >> 4) + (lane >> 4)) * 80 + (lane & 15);
-        h[0] = gx * m; h[16] = gy * m; h[32] = gz * m; h[48] = m; h[64] = alpha * m;
+    int q[UC_PTS];
+#pragma unroll
+    for (int i = 0; i < UC_PTS; ++i) {
+        const long long pt = pt0 + i < npts ? pt0 + i : npts - 1;      // (a ragged tail repeats the last point: same values, same addresses)
+        q[i] = in ? idx[pt * nn + lane] : -1;
     }
-    unsigned m = mul;
+    bool valid[UC_PTS];
+    unsigned mul[UC_PTS];
+    float g[UC_PTS][3], cc[UC_PTS][3];
+#pragma unroll
+    for (int i = 0; i < UC_PTS; ++i) {
+        const long long pt = pt0 + i < npts ? pt0 + i : npts - 1;
+        const long long bb = pt / p2;
+        const int pp = (int)(pt - bb * p2);
+        const int first = __shfl(q[i], 0, 64);
+        const unsigned long long rep = __ballot(in && lane > 0 && q[i] == first);
+        int cnt = rep ? (int)__builtin_ctzll(rep) : nn;
+        // only a genuinely cyclic row is de-duplicated (index tensors handed in by the caller may be arbitrary)
+        const int qprev = __shfl(q[i], lane >= cnt ? lane - cnt : lane, 64);
+        const bool bad = in && lane >= cnt && q[i] != qprev;
+        if (__ballot(bad) != 0ull) cnt = nn;
+        valid[i] = q[i] >= 0 && q[i] < p1;
+        mul[i] = (valid[i] && lane < cnt) ? (unsigned)((nn - 1 - lane) / cnt + 1) : 0u;
+        const float *s = xyz + bb * 3 * p1, *c = new_xyz + bb * 3 * p2;
+        const int qq = valid[i] ? q[i] : 0;
+        g[i][0] = s[qq]; g[i][1] = s[p1 + qq]; g[i][2] = s[2 * p1 + qq];
+        cc[i][0] = c[pp]; cc[i][1] = c[p2 + pp]; cc[i][2] = c[2 * p2 + pp];
+    }
+    unsigned m = 0;
+#pragma unroll
+    for (int i = 0; i < UC_PTS; ++i) {
+        const long long pt = pt0 + i < npts ? pt0 + i : npts - 1;
+        if (lane < ew) {
+            off[pt * ew + lane] = (valid[i] ? (unsigned)q[i] : (unsigned)(p1 + ((lane >> 2) & 3))) * rowb;
+            const float gx = g[i][0] - cc[i][0], gy = g[i][1] - cc[i][1], gz = g[i][2] - cc[i][2];
+            const float alpha = 1.0f - (gx * gx + gy * gy + gz * gz) * sigma_inv;
+            const float mf = (float)mul[i];
+            float *h = hood + pt * 5 * ew + lane;                  // [point][entry c][slot]: every store instruction one contiguous run
+            h[0] = gx * mf; h[ew] = gy * mf; h[2 * ew] = gz * mf; h[3 * ew] = mf; h[4 * ew] = alpha * mf;
+        }
+        m = mul[i] > m ? mul[i] : m;
+    }
 #pragma unroll
     for (int o = 32; o >= 1; o >>= 1) {
         const unsigned v = (unsigned)__shfl_xor((int)m, o, 64);
         m = v > m ? v : m;
     }
-    if (lane == 0 && m > __atomic_load_n(mulmax, __ATOMIC_RELAXED)) atomicMax(mulmax, m);
+    // (multiplicity 1 is what uc_scale assumes for a zero slot: recording it made every wave of the launch queue up on one address)
+    if (lane == 0 && m > 1u && m > __atomic_load_n(mulmax, __ATOMIC_RELAXED)) atomicMax(mulmax, m);
 }
 
 // max|dG| for callers that do not have it (a pass over dG: the GEMM that writes dG can supply it for free, gemm.h c_amax).
@@ -116,7 +139,7 @@ __global__ __launch_bounds__(256) void uc_absmax_kernel(const TG *__restrict__ s
 struct UcArgs {
     InterArgs A;               // gout = dG [ncol][cin*ks] (TG), out = dF (fp32 or bf16), rk4 = the rotated-kernel table
     const uint32_t *tab;       // accumulator-row offsets [b][p2][16 NT]
-    const float *hood;         // neighbourhood table [b][p2][NT][5][16]
+    const float *hood;         // neighbourhood table [b][p2][5][16 NT]
     const unsigned *mulmax;
     const float *dg_amax;      // device scalar max|dG|
     const void *add;           // optional tensor of dF's shape and type added to the result (NULL: none)
@@ -172,7 +195,7 @@ __global__ __launch_bounds__(64 * NWV) void inter_ungroup_cloud_kernel(UcArgs P)
     for (int kt = 0; kt < KT; ++kt) rk[kt] = A.rk4[((size_t)a * EPN_KS_MAX + 16 * kt + x) * 4 + j];
     const int gss = A.cin * A.ks;
     const uint32_t *tabc = P.tab + (size_t)bb * A.p2 * EW + 4 * j;
-    const float *hoodc = P.hood + (size_t)bb * A.p2 * NT * 80 + lane;         // lane (x, j) -> entry c = j of neighbour x
+    const float *hoodc = P.hood + (size_t)bb * A.p2 * 5 * EW + j * EW + x;    // lane (x, j) -> entry c = j of neighbour 16 t + x
     // dG fragment of (point p, chunk cw): lane (x = channel, j) <- dG[(b, p, a)][(c0 + 16 cw + x) * ks + 16 kt + 4 j .. + 3]
     const TG *dGc = reinterpret_cast<const TG *>(A.gout) + ((size_t)bb * A.p2 * A.na + a) * gss + (size_t)(c0 + x) * A.ks;
     int koff[KT];
@@ -188,11 +211,11 @@ __global__ __launch_bounds__(64 * NWV) void inter_ungroup_cloud_kernel(UcArgs P)
     };
     auto load_tab = [&](int p, float (&hb)[NT], float (&ha)[NT], u32x4_t (&e4)[NT]) {
         const uint32_t *t0 = tabc + (size_t)p * EW;
-        const float *h0 = hoodc + (size_t)p * NT * 80;
+        const float *h0 = hoodc + (size_t)p * 5 * EW;
 #pragma unroll
         for (int t = 0; t < NT; ++t) {
-            hb[t] = h0[80 * t];                           // S-MFMA operand: (g_x, g_y, g_z, 1)[j] m of neighbour 16 t + x
-            ha[t] = h0[80 * t + 64 - 16 * j];             // its accumulator start: alpha m of neighbour x
+            hb[t] = h0[16 * t];                           // S-MFMA operand: (g_x, g_y, g_z, 1)[j] m of neighbour 16 t + x
+            ha[t] = h0[16 * t + (4 - j) * EW];            // its accumulator start: alpha m of neighbour x
             e4[t] = *reinterpret_cast<const u32x4_t *>(t0 + 16 * t);
         }
     };
@@ -388,7 +411,7 @@ int launch_inter_ungroup_cloud(const epn_inter_desc *d, const float *rk4, const 
     }
     const long long npts = (long long)d->b * d->p2;
     float *hood = reinterpret_cast<float *>(static_cast<char *>(extra) + uc_off_bytes(d));
-    EPN_LAUNCH_AUX(uc_slots_kernel, dim3((unsigned)((npts + 3) / 4)), dim3(256), 0, st, d->ball_idx, d->xyz, d->new_xyz, npts, d->p1, d->p2,
+    EPN_LAUNCH_AUX(uc_slots_kernel, dim3((unsigned)((npts + 4 * UC_PTS - 1) / (4 * UC_PTS))), dim3(256), 0, st, d->ball_idx, d->xyz, d->new_xyz, npts, d->p1, d->p2,
                    d->nn, ew, 1.0f / d->sigma, (unsigned)uc_channels_per_wg(d, bf16) * 8u, tab, hood, mulmax);
     EPN_CHECK_LAUNCH();
     UcArgs P;
