@@ -61,9 +61,9 @@ int make_plan(const epn_inter_desc *d, int bf16, SplitPlan &P) {
     P.b_gw = rnd256((size_t)d->cout * P.ck * sizeof(float));
     P.b_nt = bf16 ? 0 : rnd256(epn_gemm_nt_f16x2_workspace_bytes(1, &dg)) + 256;      // + the max|grad_out| slot
     P.b_tn = rnd256(epn_gemm_tn_workspace_bytes(bf16 ? 1 : 3, (long long)P.cols, d->cout, (int)P.ck));
-    // bf16: the transpose of the grouping runs in its cloud-resident form where that takes the layer (what ops.InterSO3ConvSplitFn
-    // does): its workspace (tables) + 256 bytes for max|dG| from the data-gradient GEMM's epilogue
-    P.b_uc = (bf16 && epn_inter_ungroup_cloud_ok(d)) ? rnd256(epn_inter_ungroup_cloud_workspace_bytes(d)) + 256 : 0;
+    // the transpose of the grouping runs in its cloud-resident form where ops.InterSO3ConvSplitFn takes it (bf16 features; fp32 up
+    // to K = 32): its workspace (tables) + 256 bytes for max|dG| from the data-gradient GEMM's epilogue
+    P.b_uc = ((bf16 || d->nn <= 32) && epn_inter_ungroup_cloud_ok(d)) ? rnd256(epn_inter_ungroup_cloud_workspace_bytes(d)) + 256 : 0;
     P.b_total = P.grp_ws + P.b_wt + P.b_dg + P.b_gw + P.b_nt + P.b_tn + P.b_uc;
     return 0;
 }
@@ -185,9 +185,11 @@ int backward(const epn_inter_desc *d, const void *grad_out_cl, const float *W, c
         }
         rc = bf16 ? epn_gemm_nt_bf16(1, &p, 0, stream) : epn_gemm_nt_f16x2_f32(1, &p, am, nt_ws, P.b_nt - 256, stream);
         if (rc) return rc;
-        if (dg_amax)          // bf16: cloud-resident transpose (no atomics, no zero fill; fp32 out as this entry's contract says)
-            return epn_inter_ungroup_cloud_bf16(d, dG, dg_amax, grad_feats_cl, accumulate ? grad_feats_cl : nullptr, 1, uc_ws,
-                                                P.b_uc - 256, stream);
+        if (dg_amax)          // cloud-resident transpose (no atomics, no zero fill; fp32 out as this entry's contract says)
+            return bf16 ? epn_inter_ungroup_cloud_bf16(d, dG, dg_amax, grad_feats_cl, accumulate ? grad_feats_cl : nullptr, 1, uc_ws,
+                                                       P.b_uc - 256, stream)
+                        : epn_inter_ungroup_cloud_f32(d, static_cast<const float *>(dG), dg_amax, grad_feats_cl,
+                                                      accumulate ? grad_feats_cl : nullptr, uc_ws, P.b_uc - 256, stream);
         // transpose of the grouping: scatter pre-reduced in LDS, one fp32 atomic per distinct destination (a17)
         if (bf16) rc = accumulate ? epn_inter_ungroup_acc_bf16(d, dG, grad_feats_cl, grp_ws, P.grp_ws, stream)
                                   : epn_inter_ungroup_bf16(d, dG, grad_feats_cl, grp_ws, P.grp_ws, stream);

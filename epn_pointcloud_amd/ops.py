@@ -656,16 +656,18 @@ class InterSO3ConvSplitFn(torch.autograd.Function):
 
 def _ungroup_cloud_takes(lib, d, geo, dtype, mode):
     """Does the cloud-resident transpose of the grouping (epn_inter_ungroup_cloud_*) take this layer?  mode "cloud": whenever
-    the kernel can; "auto": where it is measured faster INSIDE the training step than the LDS-pre-reduced atomic scatter --
-    bf16 features: rotation network 1950 -> 2022-2043 point-clouds/s, 3DMatch 1874-1882 -> 1950-1962 (no fp32 scatter target,
-    zero fill or conversion pass either); fp32 features: the kernel itself is 5-15 % faster per call at K <= 32, but the step is
-    not (cls 530-532 -> 524-528, rotation fp32 1033 -> 1013: profiles/r06_ab_ungroup_cloud.txt) -- and always in
-    deterministic mode, which it satisfies by construction (the slab-based kernels cost 3.6-8 % of a step)."""
+    the kernel can; "auto": where it is measured faster INSIDE the training step than the LDS-pre-reduced atomic scatter
+    (profiles/r06_ab_ungroup_cloud.txt, A/B on one box) -- bf16 features: rotation network 1957-1966 -> 2095-2115
+    point-clouds/s, 3DMatch 1890-1919 -> 2033-2066 (no fp32 scatter target, zero fill or conversion pass either); fp32
+    features up to K = 32: cls 530-532 -> 537-538 (until its table kernel was fixed -- 91 -> 20 us per call -- this was a tie);
+    fp32 at K = 64 regenerates its weights per 16 channels under the register cap and loses (rotation network in fp32 with the
+    form everywhere: 1033 -> 1004) -- and always in deterministic mode, which it satisfies by construction (the slab-based
+    kernels cost 3.6-8 % of a step)."""
     if not isinstance(geo, InterGeometry) or not lib.epn_inter_ungroup_cloud_ok(ctypes.byref(d)):
         return False
     if mode == "cloud" or deterministic_bwd(dtype):
         return True
-    return dtype == torch.bfloat16
+    return dtype == torch.bfloat16 or d.nn <= 32
 
 
 def _lib_generic():

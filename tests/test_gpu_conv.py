@@ -597,6 +597,9 @@ def test_shared_input_gradient_is_folded_into_the_data_gradient(gpu, vgtk_alias,
     # fresh [rows, c] output -- accepted as scatter target (marked private by gemm.MatmulNT.backward), same gradients as the
     # out-of-place form; a view of anything else is not accepted
     if dt == "f32":
+        # (the in-place accumulation belongs to the atomic scatter, EPN_INTER_BWD_DATA=split: the cloud-resident transpose that
+        # "auto" takes up to K = 32 reads the other branch's gradient and writes a fresh tensor -- nothing to guard)
+        monkeypatch.setenv("EPN_INTER_BWD_DATA", "split")
         wskip = torch.randn(cout, cin, 1, 1, device=gpu) / cin ** 0.5
         taken = []
         orig = ops.InterSO3ConvSplitFn._may_write_into

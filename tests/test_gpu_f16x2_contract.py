@@ -130,6 +130,7 @@ def test_the_accumulating_scatter_marks_its_target(gpu, vgtk_alias, f16x2, monke
     from epn_pointcloud_amd.vgtk.so3conv import functional as L
     from epn_pointcloud_amd.vgtk import functional as fr
     monkeypatch.setenv("EPN_SHARE_INPUT_GRAD", "1")
+    monkeypatch.setenv("EPN_INTER_BWD_DATA", "split")       # the atomic scatter: the cloud-resident transpose of "auto" writes a fresh tensor
     rng = np.random.default_rng(5)
     torch.manual_seed(5)
     b, n, cin, cout, K, radius, sigma = 2, 96, 32, 48, 16, 0.45, 0.09

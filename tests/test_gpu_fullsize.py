@@ -44,10 +44,10 @@ def pyramid(gpu, vgtk_alias):
     return layers, levels
 
 
-@pytest.mark.parametrize("bwd_data", ["auto", "cloud"])   # cloud: the fixed-point transpose of the grouping (csrc/inter_ungroup_cloud.hip) at fp32 production geometry
+@pytest.mark.parametrize("bwd_data", ["auto", "split"])   # auto: the fixed-point transpose of the grouping (csrc/inter_ungroup_cloud.hip); split: the atomic scatter
 @pytest.mark.parametrize("li", [0, 1, 2, 3, 4, 5, 6])     # li = 0: the cin = 1 kernels (inter_c1_*) at B=32, N=1024, K=32
 def test_inter_conv_full_size_slice_vs_oracle(gpu, vgtk_alias, pyramid, li, bwd_data, monkeypatch):
-    if bwd_data == "cloud" and li == 0:
+    if bwd_data == "split" and li == 0:
         pytest.skip("the cin = 1 layer has no grouped-feature gradient")
     monkeypatch.setenv("EPN_INTER_BWD_DATA", bwd_data)
     sptk, zptk = _mods(vgtk_alias)

@@ -210,7 +210,7 @@ def test_inv_model_vs_reference_golden(gpu, fused):
 _ORACLE_STEP = {}
 
 
-@pytest.mark.parametrize("inter_mode", ["auto", "onchip", "auto+bwd_data_onchip", "auto+bwd_data_cloud"])
+@pytest.mark.parametrize("inter_mode", ["auto", "onchip", "auto+bwd_data_onchip", "auto+bwd_data_split"])
 def test_full_width_cls_step_matches_oracle_loss(gpu, monkeypatch, inter_mode):
     """Full-width classification network on 2 clouds: logits, loss and EVERY parameter gradient against the CPU oracle
     (SPConvNets/models/cls_so3net_pn.py:15-40 restated by oracle/backbone_ref.py) -- in the default split form and with
@@ -227,9 +227,9 @@ def test_full_width_cls_step_matches_oracle_loss(gpu, monkeypatch, inter_mode):
     if bwd_onchip:
         inter_mode = "auto"
         monkeypatch.setenv("EPN_INTER_BWD_DATA", "onchip")
-    if inter_mode == "auto+bwd_data_cloud":                 # ... with the cloud-resident fixed-point transpose of the grouping in every layer
+    if inter_mode == "auto+bwd_data_split":                 # ... with the LDS-pre-reduced atomic scatter in every layer (auto: the cloud-resident fixed-point transpose)
         inter_mode = "auto"
-        monkeypatch.setenv("EPN_INTER_BWD_DATA", "cloud")
+        monkeypatch.setenv("EPN_INTER_BWD_DATA", "split")
     monkeypatch.setenv("EPN_INTER_MODE", inter_mode)
     layers = S.cls_so3net_schedule(1024)
     torch.manual_seed(5)

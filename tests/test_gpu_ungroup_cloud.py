@@ -119,7 +119,7 @@ def test_auto_takes_the_cloud_form_where_it_is_faster(gpu, monkeypatch):
     took = []
     real = ops._ungroup_cloud_takes
     monkeypatch.setattr(ops, "_ungroup_cloud_takes", lambda *a: (took.append(real(*a)), took[-1])[1])
-    for (cin, cout, K, dtype, want) in [(64, 64, 16, torch.float32, False), (64, 64, 32, torch.bfloat16, True),
+    for (cin, cout, K, dtype, want) in [(64, 64, 16, torch.float32, True), (64, 64, 32, torch.bfloat16, True),
                                          (32, 64, 64, torch.bfloat16, True), (32, 64, 64, torch.float32, False)]:
         geo, feats, W, gy, _ = _layer(gpu, 2, 128, cin, cout, K, 1, dtype=dtype)
         del took[:]
